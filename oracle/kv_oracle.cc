@@ -1,0 +1,642 @@
+// kv_oracle.cc — CPU restatement of the tfplus KvVariable hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under tfplus_amd/ (the product) may link,
+// import or call this file.  Allowed users: tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg, and there only as the checker / timed baseline.
+//
+// What it restates (all citations relative to /root/reference/):
+//   * table data structure: 1031 segments of std::unordered_map keyed with
+//     MurmurHash64A, segment = MurmurHash64B % 1031, reader/writer spin lock per
+//     segment                       tfplus/kv_variable/kernels/hashmap.h:50-78,335-543
+//   * per-key meta {in_black, under_threshold, uint32 freq(lo16)|day(hi16), row*}
+//                                   tfplus/kv_variable/kernels/embedding_value.h:185-235
+//   * FindOrInsert / FindOrZeros / FindOrInsertUnsafe / blacklist handling
+//                                   tfplus/kv_variable/kernels/kv_variable.h:239-421,837-912
+//                                   tfplus/kv_variable/kernels/hybrid_embedding/table_manager.h:91-237,335-372
+//   * optimizer row math: GroupAdam V4 / V3, Adagrad, SparseGroupFtrl(V2)
+//                                   tfplus/kv_variable/kernels/training_ops.cc:6980-7213,5709-5965,1372-1498,532-778
+//   * readback (ExportValues first_n=2), size, sum_freq
+//                                   tfplus/kv_variable/kernels/dynamic_save.hpp:47-195
+//                                   tfplus/kv_variable/kernels/kv_variable.h:139-175
+//   * TF-core grad de-dup (tf.unique + unsorted_segment_sum, tensorflow-cpu 2.13.0,
+//     NOT under /root/reference): first-occurrence unique, sequential fp32 sum in
+//     occurrence order.  Call site: tfplus/kv_variable/python/ops/variable_scope.py:1096-1106.
+//
+// Pinning status: the reference cannot be compiled or imported in the build
+// container (every file on the path includes tensorflow/core/... and tbb; no TF
+// wheel, no headers), so this restatement is pinned against the known-answer
+// content of the reference's own tests (tests/test_oracle_golden.py lists each one
+// with its file:line) and NOT against a run of the reference binary.
+// Third-party arithmetic that is parity-UNPINNED and only matched to 1e-6 rel:
+//   - Eigen's vectorised reduction order for the l1_linear norm
+//     (training_ops.cc:7180) — this file sums sequentially in fp32;
+//   - Eigen's packet rsqrt in Adagrad (training_ops.cc:1479) — this file uses 1/sqrtf;
+//   - smhasher MurmurHash64A/B (WORKSPACE:49-56): restated from the published
+//     public-domain algorithm; affects only export iteration order.
+//   - std::rand() row picks (kv_variable.h:889-898): not reproducible in the
+//     reference itself (shared libc state, multi-threaded); picker mode 1 below is
+//     the counter-hash pick the GPU path uses, so random-init rows can be compared.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, no fast-math).
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <functional>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---- smhasher MurmurHash64A / 64B (Austin Appleby, public domain) -------------
+// reference call sites: hashmap.h:59 (A: bucket hash), hashmap.h:76 (B: segment id)
+inline uint64_t MurmurHash64A(const void* key, int len, uint64_t seed) {
+  const uint64_t m = 0xc6a4a7935bd1e995ULL;
+  const int r = 47;
+  uint64_t h = seed ^ (static_cast<uint64_t>(len) * m);
+  const unsigned char* p = static_cast<const unsigned char*>(key);
+  const unsigned char* end = p + (len / 8) * 8;
+  while (p != end) {
+    uint64_t k;
+    std::memcpy(&k, p, 8);
+    p += 8;
+    k *= m; k ^= k >> r; k *= m;
+    h ^= k; h *= m;
+  }
+  switch (len & 7) {
+    case 7: h ^= uint64_t(p[6]) << 48;  // fallthrough
+    case 6: h ^= uint64_t(p[5]) << 40;  // fallthrough
+    case 5: h ^= uint64_t(p[4]) << 32;  // fallthrough
+    case 4: h ^= uint64_t(p[3]) << 24;  // fallthrough
+    case 3: h ^= uint64_t(p[2]) << 16;  // fallthrough
+    case 2: h ^= uint64_t(p[1]) << 8;   // fallthrough
+    case 1: h ^= uint64_t(p[0]); h *= m;
+  }
+  h ^= h >> r; h *= m; h ^= h >> r;
+  return h;
+}
+
+inline uint64_t MurmurHash64B(const void* key, int len, uint64_t seed) {
+  const uint32_t m = 0x5bd1e995;
+  const int r = 24;
+  uint32_t h1 = uint32_t(seed) ^ uint32_t(len);
+  uint32_t h2 = uint32_t(seed >> 32);
+  const unsigned char* p = static_cast<const unsigned char*>(key);
+  while (len >= 8) {
+    uint32_t k1; std::memcpy(&k1, p, 4); p += 4;
+    k1 *= m; k1 ^= k1 >> r; k1 *= m; h1 *= m; h1 ^= k1; len -= 4;
+    uint32_t k2; std::memcpy(&k2, p, 4); p += 4;
+    k2 *= m; k2 ^= k2 >> r; k2 *= m; h2 *= m; h2 ^= k2; len -= 4;
+  }
+  if (len >= 4) {
+    uint32_t k1; std::memcpy(&k1, p, 4); p += 4;
+    k1 *= m; k1 ^= k1 >> r; k1 *= m; h1 *= m; h1 ^= k1; len -= 4;
+  }
+  switch (len) {
+    case 3: h2 ^= uint32_t(p[2]) << 16;  // fallthrough
+    case 2: h2 ^= uint32_t(p[1]) << 8;   // fallthrough
+    case 1: h2 ^= uint32_t(p[0]); h2 *= m;
+  }
+  h1 ^= h2 >> 18; h1 *= m;
+  h2 ^= h1 >> 22; h2 *= m;
+  h1 ^= h2 >> 17; h1 *= m;
+  h2 ^= h1 >> 19; h2 *= m;
+  return (uint64_t(h1) << 32) | h2;
+}
+
+constexpr uint64_t kMagicSeed = 0x5446534d;  // hashmap.h:51
+constexpr int kSegments = 1031;              // hashmap.h:50
+constexpr float kCutoff = 1.0e-20f;          // kv_variable_interface.h:54-55 (enable_cutoff = true)
+
+struct HashA {
+  size_t operator()(const int64_t& k) const { return MurmurHash64A(&k, 8, kMagicSeed); }
+};
+
+// ---- utility.h:57-71 ----------------------------------------------------------
+inline uint16_t SaturateMaxFrequency(int32_t f) {
+  return static_cast<uint16_t>(std::min<int32_t>(f, 65535));
+}
+inline uint16_t SaturateAddFrequency(uint16_t val, uint16_t delta) {
+  uint16_t nv = static_cast<uint16_t>(val + delta);
+  if (nv < val) nv = 0xFFFF;
+  return nv;
+}
+
+// ---- embedding_value.h:225-235 ------------------------------------------------
+struct Meta {
+  bool in_black = false;
+  bool under_threshold = false;
+  uint32_t freq = 1;       // EmbeddingValue(..., freq_val = 1, ...) table_manager.h:94
+  float* row = nullptr;    // nullptr while blacklisted (storage_table.h:102-108 Evict)
+  void AddFrequency(uint16_t f, uint16_t day) {  // embedding_value.h:189-193
+    uint16_t lo = SaturateAddFrequency(uint16_t(freq & 0xFFFF), f);
+    freq = (uint32_t(day) << 16) | lo;
+  }
+};
+
+// minimal reader/writer spin lock standing in for tbb::spin_rw_mutex (mutex.h:22-199)
+struct RwSpin {
+  std::atomic<int> s{0};  // -1 writer, >0 readers
+  void lock_read() {
+    for (;;) {
+      int v = s.load(std::memory_order_relaxed);
+      if (v >= 0 && s.compare_exchange_weak(v, v + 1, std::memory_order_acquire)) return;
+    }
+  }
+  void unlock_read() { s.fetch_sub(1, std::memory_order_release); }
+  void lock() {
+    for (;;) {
+      int v = 0;
+      if (s.compare_exchange_weak(v, -1, std::memory_order_acquire)) return;
+    }
+  }
+  void unlock() { s.store(0, std::memory_order_release); }
+  // upgrade; returns true when no other thread got in between (table_manager.h:177)
+  bool upgrade() {
+    int one = 1;
+    if (s.compare_exchange_strong(one, -1, std::memory_order_acquire)) return true;
+    unlock_read();
+    lock();
+    return false;
+  }
+};
+
+struct Segment {
+  std::unordered_map<int64_t, Meta, HashA> map;
+  RwSpin mu;
+};
+
+inline uint64_t mix64(uint64_t x) {  // splitmix64 finaliser; picker mode 1 only
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+struct Table {
+  int dim;
+  uint16_t enter_threshold;
+  std::vector<float> init_table;
+  int64_t init_rows = 0;
+  bool initialized = false;
+  int picker = 0;  // 0 = std::rand() (reference), 1 = counter hash (GPU-compatible)
+  uint64_t seed = 0;
+  int32_t fixed_day = -1;  // <0: wall clock (utility.cc:38-40)
+  std::vector<float> zero_row;
+  Segment* seg;
+
+  Table(int d, int thr) : dim(d), enter_threshold(SaturateMaxFrequency(thr)), zero_row(d, 0.f) {
+    seg = new Segment[kSegments];
+  }
+  ~Table() {
+    for (int s = 0; s < kSegments; ++s)
+      for (auto& kv : seg[s].map) std::free(kv.second.row);
+    delete[] seg;
+  }
+  int SegId(int64_t k) const { return int(MurmurHash64B(&k, 8, kMagicSeed) % kSegments); }
+  uint16_t Today() const {
+    if (fixed_day >= 0) return uint16_t(fixed_day);
+    return uint16_t(std::time(nullptr) / (3600 * 24));
+  }
+  bool LowFreq(uint32_t f) const { return uint16_t(f & 0xFFFF) < enter_threshold; }  // kv_variable.h:910-912
+
+  // kv_variable.h:889-898
+  void GenerateRandomInitialValue(int64_t key, float* out) const {
+    int64_t r1, r2;
+    if (picker == 0) {
+      r1 = std::rand() % init_rows;
+      r2 = std::rand() % init_rows;
+    } else {
+      uint64_t h = mix64(uint64_t(key) ^ (seed * 0x9E3779B97F4A7C15ULL));
+      r1 = int64_t(uint32_t(h) % uint64_t(init_rows));
+      r2 = int64_t(uint32_t(h >> 32) % uint64_t(init_rows));
+    }
+    const float* a = &init_table[size_t(r1) * dim];
+    const float* b = &init_table[size_t(r2) * dim];
+    for (int e = 0; e < dim; ++e) out[e] = (a[e] + b[e]) * 0.5f;
+  }
+  // kv_variable.h:837-861 (enable_cutoff defaults true, 1e-20)
+  void UpdateUnderThreshold(Meta* m) const {
+    if (m->in_black || m->row == nullptr) { m->under_threshold = true; return; }
+    for (int e = 0; e < dim; ++e)
+      if (std::fabs(m->row[e]) >= kCutoff) { m->under_threshold = false; return; }
+    m->under_threshold = true;
+  }
+  float* NewRow() const { return static_cast<float*>(std::malloc(sizeof(float) * size_t(dim))); }
+
+  // table_manager.h:335-357 (context != nullptr branch)
+  void MarkBlacklist(Meta* m) const {
+    if (!m->in_black) {
+      m->in_black = true;
+      m->under_threshold = true;
+      std::free(m->row);
+      m->row = nullptr;
+    }
+  }
+  // table_manager.h:359-372
+  void RemoveBlacklist(Meta* m) const {
+    m->row = NewRow();
+    std::memset(m->row, 0, sizeof(float) * size_t(dim));
+    m->in_black = false;
+    m->under_threshold = true;
+  }
+
+  // kv_variable.h:382-416.  Caller holds the VAR table's segment write lock.
+  // filter_out != nullptr: forward variable; nullptr: optimizer slot table.
+  // Returns the row to operate on (zero_row scratch never escapes: a blacklisted
+  // row that is not filtered is un-blacklisted to a fresh zero row first).
+  Meta* FindOrInsertUnsafe(int64_t key, bool* filter_out) {
+    Segment& sg = seg[SegId(key)];
+    auto it = sg.map.find(key);
+    if (it == sg.map.end()) {
+      Meta m;  // freq_val = 1, not blacklisted
+      m.row = NewRow();
+      GenerateRandomInitialValue(key, m.row);
+      UpdateUnderThreshold(&m);
+      it = sg.map.insert_or_assign(key, m).first;
+      return &it->second;  // succ == false: neither filter nor frequency touched
+    }
+    Meta* m = &it->second;
+    if (filter_out != nullptr) {
+      bool should_filter = LowFreq(m->freq);
+      *filter_out = should_filter;
+      if (m->in_black && !should_filter) RemoveBlacklist(m);
+    } else {
+      m->AddFrequency(1, Today());
+    }
+    return m;
+  }
+};
+
+// tensorflow::Shard stand-in: contiguous blocks over nthreads (work_sharder.h in
+// tensorflow-cpu 2.13; cost_per_unit = 5000 at every call site on this path).
+void Shard(int nthreads, int64_t total, const std::function<void(int64_t, int64_t)>& fn) {
+  if (nthreads <= 1 || total < 2) { fn(0, total); return; }
+  int64_t nblk = std::min<int64_t>(nthreads, total);
+  int64_t per = (total + nblk - 1) / nblk;
+  std::vector<std::thread> th;
+  for (int64_t b = 0; b < nblk; ++b) {
+    int64_t s = b * per, e = std::min(total, s + per);
+    if (s >= e) break;
+    th.emplace_back([=, &fn] { fn(s, e); });
+  }
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+void* kvo_create(int dim, int enter_threshold) { return new Table(dim, enter_threshold); }
+void kvo_destroy(void* h) { delete static_cast<Table*>(h); }
+
+// kv_variable.h:184-206 — first call wins
+void kvo_init_table(void* h, const float* T, int64_t R) {
+  Table* t = static_cast<Table*>(h);
+  if (t->initialized && !t->init_table.empty()) return;
+  t->init_table.assign(T, T + R * t->dim);
+  t->init_rows = R;
+  t->initialized = true;
+}
+int kvo_is_initialized(void* h) { return static_cast<Table*>(h)->initialized ? 1 : 0; }
+void kvo_set_picker(void* h, int mode, uint64_t seed) {
+  Table* t = static_cast<Table*>(h); t->picker = mode; t->seed = seed;
+}
+void kvo_set_day(void* h, int day) { static_cast<Table*>(h)->fixed_day = day; }
+void kvo_srand(unsigned s) { std::srand(s); }
+
+// kv_variable.h:263-380 (counts may be null)
+void kvo_gather_or_insert(void* h, const int64_t* ids, const int32_t* counts, int64_t n,
+                          float* out, int nthreads) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  const uint16_t day = t->Today();
+  Shard(nthreads, n, [&](int64_t s, int64_t e) {
+    for (int64_t i = s; i < e; ++i) {
+      const int64_t key = ids[i];
+      Segment& sg = t->seg[t->SegId(key)];
+      sg.mu.lock_read();
+      bool writer = false;
+      auto it = sg.map.find(key);
+      if (it == sg.map.end()) {
+        if (!sg.mu.upgrade()) it = sg.map.find(key);  // re-probe (table_manager.h:181-186)
+        writer = true;
+      }
+      if (it != sg.map.end()) {
+        Meta* m = &it->second;  // find_func kv_variable.h:320-332
+        uint16_t f = counts ? SaturateMaxFrequency(counts[i]) : uint16_t(1);
+        m->AddFrequency(f, day);
+        t->UpdateUnderThreshold(m);
+        const float* src = m->in_black ? t->zero_row.data() : m->row;  // table_manager.h:224-226
+        std::memcpy(out + i * D, src, sizeof(float) * size_t(D));
+      } else {
+        Meta m;  // insert_func kv_variable.h:339-363
+        uint16_t lo = counts ? SaturateMaxFrequency(counts[i]) : uint16_t(1);
+        m.freq = (uint32_t(day) << 16) | lo;
+        m.row = t->NewRow();
+        t->GenerateRandomInitialValue(key, m.row);
+        t->UpdateUnderThreshold(&m);
+        std::memcpy(out + i * D, m.row, sizeof(float) * size_t(D));
+        sg.map.insert_or_assign(key, m);
+      }
+      if (writer) sg.mu.unlock(); else sg.mu.unlock_read();
+    }
+  });
+}
+
+// kv_variable.h:239-254, table_manager.h:112-154
+void kvo_gather_or_zeros(void* h, const int64_t* ids, int64_t n, float* out, int nthreads) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  Shard(nthreads, n, [&](int64_t s, int64_t e) {
+    for (int64_t i = s; i < e; ++i) {
+      Segment& sg = t->seg[t->SegId(ids[i])];
+      sg.mu.lock_read();
+      auto it = sg.map.find(ids[i]);
+      const float* src = t->zero_row.data();
+      if (it != sg.map.end() && !it->second.in_black) src = it->second.row;
+      std::memcpy(out + i * D, src, sizeof(float) * size_t(D));
+      sg.mu.unlock_read();
+    }
+  });
+}
+
+// training_ops.cc:6980-7213 (version 4) and :5709-5965 (version 3).
+// Returns 0, or a negative code mirroring the OP_REQUIRES failures.
+int kvo_apply_group_adam(void* hv, void* hs, const float* grad, const int64_t* ids, int64_t n,
+                         float lr, float b1p, float b2p, float b1, float b2, float eps,
+                         float l1, float l2, float l21, int version, int nthreads) {
+  Table* tv = static_cast<Table*>(hv);
+  Table* ts = static_cast<Table*>(hs);
+  if (!tv->initialized || !ts->initialized) return -2;          // FailedPrecondition :7001-7008
+  if (!(lr > 0.f) || l1 < 0.f || l2 < 0.f || l21 < 0.f) return -1;  // InvalidArgument :7024-7061
+  const int D = tv->dim;
+  if (ts->dim != D && ts->dim != 3 * D) return -1;              // :7072-7088
+  float l1s, l2s, l21s, alpha;
+  if (version == 4) {  // :7111-7119
+    l1s = l1 * lr; l2s = l2 * lr; l21s = l21 * lr;
+    alpha = lr * std::sqrt(1.f - b2p) / (1.f - b1p);
+  } else {             // :5840-5848
+    l1s = l1; l2s = l2; l21s = l21;
+    alpha = std::sqrt(1.f - b2p) / (1.f - b1p);
+  }
+  const float l21_norm = l21s * std::sqrt(float(D));
+  const float omb1 = 1.f - b1, omb2 = 1.f - b2, two_l2 = 2.f * l2s;
+  Shard(nthreads, n, [&](int64_t s, int64_t e) {
+    std::vector<float> u(D);
+    for (int64_t i = s; i < e; ++i) {
+      const int64_t key = ids[i];
+      Segment& sg = tv->seg[tv->SegId(key)];
+      sg.mu.lock();                                             // :7145-7147
+      bool should_filter = false;
+      Meta* mv = tv->FindOrInsertUnsafe(key, &should_filter);   // :7148
+      if (should_filter) { sg.mu.unlock(); continue; }          // :7150-7152
+      Meta* ms = ts->FindOrInsertUnsafe(key, nullptr);          // :7155 (slot map not locked)
+      float* x = mv->row;
+      float* m = ms->row;
+      float* v = ms->row + D;
+      float* z = ms->row + 2 * D;
+      const float* g = grad + i * D;
+      for (int k = 0; k < D; ++k) m[k] = b1 * m[k] + omb1 * g[k];
+      float sumsq = 0.f;
+      for (int k = 0; k < D; ++k) {
+        float nv = b2 * v[k] + omb2 * (g[k] * g[k]);
+        float sq = std::sqrt(nv);
+        float d;
+        if (version == 4) {
+          d = (b1 > b1p) ? (sq - std::sqrt(v[k])) * x[k] : (sq + eps) * x[k];
+        } else {
+          d = (b1 > b1p) ? (sq - std::sqrt(v[k])) / lr * x[k]
+                         : (sq - std::sqrt(v[k]) + eps) / lr * x[k];
+        }
+        z[k] = z[k] + (alpha * m[k] - d);
+        float adj = std::max(std::min(z[k], l1s), -l1s);
+        u[k] = adj - z[k];
+        sumsq += u[k] * u[k];
+      }
+      float norm = std::sqrt(sumsq);
+      if (norm > l21_norm) {
+        float scale = 1.f - l21_norm / norm;
+        for (int k = 0; k < D; ++k) {
+          float nv = b2 * v[k] + omb2 * (g[k] * g[k]);
+          float sq = std::sqrt(nv);
+          float y = (version == 4) ? (sq + eps) + two_l2 : (sq + eps) / lr + two_l2;
+          x[k] = u[k] * scale / y;
+        }
+        tv->UpdateUnderThreshold(mv);                           // CoverUpdateUnsafe :7187
+      } else {
+        tv->MarkBlacklist(mv);                                  // :7190
+      }
+      for (int k = 0; k < D; ++k) v[k] = b2 * v[k] + omb2 * (g[k] * g[k]);
+      ts->UpdateUnderThreshold(ms);                             // :7194
+      sg.mu.unlock();
+    }
+  });
+  return 0;
+}
+
+// training_ops.cc:1372-1498
+int kvo_apply_adagrad(void* hv, void* ha, float lr, const float* grad, const int64_t* ids,
+                      int64_t n, int update_slots, int nthreads) {
+  Table* tv = static_cast<Table*>(hv);
+  Table* ta = static_cast<Table*>(ha);
+  if (!tv->initialized || !ta->initialized) return -2;
+  const int D = tv->dim;
+  if (ta->dim != D) return -1;
+  Shard(nthreads, n, [&](int64_t s, int64_t e) {
+    for (int64_t i = s; i < e; ++i) {
+      const int64_t key = ids[i];
+      Segment& sg = tv->seg[tv->SegId(key)];
+      sg.mu.lock();
+      bool should_filter = false;
+      Meta* mv = tv->FindOrInsertUnsafe(key, &should_filter);
+      if (should_filter) { sg.mu.unlock(); continue; }
+      Meta* ma = ta->FindOrInsertUnsafe(key, nullptr);
+      float* x = mv->row;
+      float* a = ma->row;
+      const float* g = grad + i * D;
+      if (update_slots)
+        for (int k = 0; k < D; ++k) a[k] = a[k] + g[k] * g[k];
+      if (D > 1) {
+        for (int k = 0; k < D; ++k) x[k] = x[k] - (lr * g[k]) * (1.f / std::sqrt(a[k]));
+      } else {
+        x[0] = x[0] - (lr * g[0]) / std::sqrt(a[0]);
+      }
+      sg.mu.unlock();  // no CoverUpdate: under_threshold flags stay as they were
+    }
+  });
+  return 0;
+}
+
+// training_ops.cc:532-778, has_l2_shrinkage = true (KvVariableSparseGroupSparseApplyFtrlV2)
+int kvo_apply_sparse_group_ftrl(void* hv, void* ha, void* hl, const float* grad,
+                                const int64_t* ids, int64_t n, float lr, float l1, float l2,
+                                float l21, float l2s, float lr_power, int nthreads) {
+  Table* tv = static_cast<Table*>(hv);
+  Table* ta = static_cast<Table*>(ha);
+  Table* tl = static_cast<Table*>(hl);
+  if (!tv->initialized || !ta->initialized || !tl->initialized) return -2;
+  if (!(lr > 0.f) || l1 < 0.f || l2 < 0.f || l21 < 0.f || l2s < 0.f || lr_power > 0.f) return -1;
+  const int D = tv->dim;
+  if (ta->dim != D || tl->dim != D) return -1;
+  const float l21_norm = l21 * std::sqrt(float(D));
+  const float two_l2 = 2.f * l2, two_l2s = 2.f * l2s;
+  const bool half = (lr_power == -0.5f);
+  auto powa = [&](float a) { return half ? std::sqrt(a) : std::pow(a, -lr_power); };
+  Shard(nthreads, n, [&](int64_t s, int64_t e) {
+    std::vector<float> u(D), xo(D);
+    for (int64_t i = s; i < e; ++i) {
+      const int64_t key = ids[i];
+      Segment& sg = tv->seg[tv->SegId(key)];
+      sg.mu.lock();
+      bool should_filter = false;
+      Meta* mv = tv->FindOrInsertUnsafe(key, &should_filter);
+      if (should_filter) { sg.mu.unlock(); continue; }
+      Meta* ml = tl->FindOrInsertUnsafe(key, nullptr);          // :701-702
+      Meta* ma = ta->FindOrInsertUnsafe(key, nullptr);          // :703-704
+      float* x = mv->row;
+      float* z = ml->row;
+      float* a = ma->row;
+      const float* g = grad + i * D;
+      float sumsq = 0.f;
+      for (int k = 0; k < D; ++k) {
+        xo[k] = x[k];
+        float gs = g[k] + two_l2s * x[k];                       // lazy grad_with_shrinkage :754-755
+        float na = a[k] + gs * gs;
+        z[k] = z[k] + (gs - (powa(na) - powa(a[k])) / lr * x[k]);  // :716-721
+        float adj = std::max(std::min(z[k], l1), -l1);
+        u[k] = adj - z[k];
+        sumsq += u[k] * u[k];
+      }
+      float norm = std::sqrt(sumsq);
+      bool updated = norm > l21_norm;
+      if (updated) {
+        float scale = 1.f - (l21_norm / norm);
+        for (int k = 0; k < D; ++k) {
+          float gs = g[k] + two_l2s * x[k];                     // old x: element-wise evaluation
+          float na = a[k] + gs * gs;
+          float y = powa(na) / lr + two_l2;                     // :732-738
+          x[k] = u[k] * scale / y;
+        }
+        tv->UpdateUnderThreshold(mv);
+      } else {
+        tv->MarkBlacklist(mv);
+      }
+      // :747 `accum += grad_to_use.square()` re-evaluates the lazy expression with the
+      // UPDATED var.  On the blacklist branch the reference reads the just-freed row
+      // (use-after-free, value unspecified); this restatement uses the pre-blacklist row.
+      for (int k = 0; k < D; ++k) {
+        float xv = updated ? x[k] : xo[k];
+        float gs = g[k] + two_l2s * xv;
+        a[k] = a[k] + gs * gs;
+      }
+      tl->UpdateUnderThreshold(ml);
+      ta->UpdateUnderThreshold(ma);
+      sg.mu.unlock();
+    }
+  });
+  return 0;
+}
+
+// TF-core a9: tf.unique (first-occurrence order) + unsorted_segment_sum (fp32, occurrence
+// order).  uniq_ids/summed/pos sized for n.  Returns U.
+int64_t kvo_dedup_segment_sum(const int64_t* ids, const float* grads, int64_t n, int D,
+                              int64_t* uniq_ids, float* summed, int32_t* pos) {
+  std::unordered_map<int64_t, int32_t> idx;
+  idx.reserve(size_t(n));
+  int64_t U = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = idx.find(ids[i]);
+    int32_t p;
+    if (it == idx.end()) {
+      p = int32_t(U);
+      idx.emplace(ids[i], p);
+      uniq_ids[U] = ids[i];
+      std::memset(summed + U * D, 0, sizeof(float) * size_t(D));
+      ++U;
+    } else {
+      p = it->second;
+    }
+    if (pos) pos[i] = p;
+    float* dst = summed + int64_t(p) * D;
+    const float* src = grads + i * D;
+    for (int k = 0; k < D; ++k) dst[k] += src[k];
+  }
+  return U;
+}
+
+// kv_variable.h:139-175
+int64_t kvo_size(void* h) {
+  Table* t = static_cast<Table*>(h);
+  int64_t c = 0;
+  for (int s = 0; s < kSegments; ++s)
+    for (auto& kv : t->seg[s].map)
+      if (!kv.second.in_black && !t->LowFreq(kv.second.freq)) ++c;
+  return c;
+}
+int64_t kvo_sum_freq(void* h) {
+  Table* t = static_cast<Table*>(h);
+  int64_t c = 0;
+  for (int s = 0; s < kSegments; ++s)
+    for (auto& kv : t->seg[s].map)
+      if (!kv.second.in_black && !t->LowFreq(kv.second.freq)) c += kv.second.freq & 0xFFFF;
+  return c;
+}
+int64_t kvo_map_size(void* h) {  // GetShape()[0] kv_variable.h:177-182
+  Table* t = static_cast<Table*>(h);
+  int64_t c = 0;
+  for (int s = 0; s < kSegments; ++s) c += int64_t(t->seg[s].map.size());
+  return c;
+}
+
+// ExportValues, dynamic_save.hpp:47-195.  Pass keys == nullptr to count.
+// first_n: 2 keys+values; >=3 also blacklist; >4 also freq (uint32 words).
+// counts[3] = {num_rows, blacklist_nums, freq_nums}
+void kvo_export(void* h, int first_n, int64_t* counts, int64_t* keys, float* values,
+                int64_t* blacklist, int64_t* freq_keys, uint32_t* freq_values) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  int64_t nr = 0, nb = 0, nf = 0;
+  for (int s = 0; s < kSegments; ++s) {
+    for (auto& kv : t->seg[s].map) {
+      const Meta& m = kv.second;
+      if (m.in_black) {
+        // blacklisted keys are listed only for first_n > 3 (dynamic_save.hpp:113-115);
+        // they carry under_threshold = true, so they never reach keys/values either
+        if (first_n > 3) { if (blacklist) blacklist[nb] = kv.first; ++nb; }
+      } else if ((first_n <= 3 || !t->LowFreq(m.freq)) && !m.under_threshold) {
+        if (keys) {
+          keys[nr] = kv.first;
+          std::memcpy(values + nr * D, m.row, sizeof(float) * size_t(D));
+        }
+        ++nr;
+      }
+      if (first_n > 4) {
+        if (freq_keys) { freq_keys[nf] = kv.first; freq_values[nf] = m.freq; }
+        ++nf;
+      }
+    }
+  }
+  counts[0] = nr; counts[1] = nb; counts[2] = nf;
+}
+
+// test helper: meta of one key. returns 0 if absent.
+int kvo_get_meta(void* h, int64_t key, uint32_t* freq, int* in_black, int* under_threshold) {
+  Table* t = static_cast<Table*>(h);
+  Segment& sg = t->seg[t->SegId(key)];
+  auto it = sg.map.find(key);
+  if (it == sg.map.end()) return 0;
+  *freq = it->second.freq;
+  *in_black = it->second.in_black;
+  *under_threshold = it->second.under_threshold;
+  return 1;
+}
+
+uint64_t kvo_murmur64a(int64_t key) { return MurmurHash64A(&key, 8, kMagicSeed); }
+uint64_t kvo_murmur64b(int64_t key) { return MurmurHash64B(&key, 8, kMagicSeed); }
+
+}  // extern "C"
