@@ -1,0 +1,176 @@
+/* kvhip.h — C ABI of the MI355X-native KvVariable hot path (libkvhip.so).
+ *
+ * This is the drop-in boundary: every entry point below is what a TensorFlow custom-op
+ * shim (or any FFI: ctypes, cgo, JNI) binds in place of one reference OpKernel.  Plain
+ * pointers and sizes only — no TF, torch or C++ types.  All `ids`, `counts`, `grad`,
+ * `out`, `keys`, `values` … buffers are DEVICE pointers on the table's GPU (HBM
+ * resident); scalars are passed by value.  Every call enqueues its kernels on `stream`
+ * (a hipStream_t, NULL = the default stream) and returns without synchronising unless
+ * its comment says "synchronous".
+ *
+ * Return value: 0 (KV_OK) or a tensorflow::error::Code-compatible integer, the same
+ * category the reference's OP_REQUIRES would have set; kv_last_error() gives the text
+ * for the calling thread.  Citations are relative to the reference tree
+ * (intelligent-machine-learning/tfplus).
+ */
+#ifndef KVHIP_H_
+#define KVHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kv_table* kv_handle_t; /* opaque; one KvVariable<K, float> resource */
+typedef void* kv_stream_t;            /* hipStream_t */
+
+/* status codes (tensorflow/core/protobuf/error_codes.proto numbering) */
+#define KV_OK 0
+#define KV_INVALID_ARGUMENT 3    /* errors::InvalidArgument */
+#define KV_RESOURCE_EXHAUSTED 8  /* HBM allocation failed */
+#define KV_FAILED_PRECONDITION 9 /* "Failed to use uninitialized variables" */
+#define KV_UNIMPLEMENTED 12
+#define KV_INTERNAL 13 /* HIP runtime error */
+
+/* key_dtype / value_dtype (tensorflow DataType numbering, kernels/kv_variable_ops.cc:149-156) */
+#define KV_DT_FLOAT 1
+#define KV_DT_INT32 3
+#define KV_DT_INT64 9
+#define KV_DT_UINT64 23
+
+/* kv_scatter_update ops (kernels/kv_variable_interface.h:44-52) */
+#define KV_SCATTER_ASSIGN 0
+#define KV_SCATTER_ADD 1
+#define KV_SCATTER_SUB 2
+#define KV_SCATTER_MUL 3
+#define KV_SCATTER_DIV 4
+#define KV_SCATTER_MIN 5
+#define KV_SCATTER_MAX 6
+
+const char* kv_last_error(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+
+/* Replaces CreateKvVariableOp::Compute (kernels/kv_variable_ops.cc:58-116) + KvVariable ctor
+ * (kernels/kv_variable.h:92-114).  `dim` = value_shape.num_elements(); `enter_threshold` is
+ * clamped to uint16 like SaturateMaxFrequency.  `capacity_hint` pre-sizes the HBM hash index
+ * and row slab for that many keys (0 = small default; both grow on demand).  Keys of every
+ * supported key_dtype are handled as their 64-bit two's-complement pattern; `ids` buffers are
+ * int64 (KV_DT_INT64 / KV_DT_UINT64) or int32 (KV_DT_INT32). */
+int kv_create(int key_dtype, int value_dtype, int dim, int enter_threshold, int64_t capacity_hint,
+              int device, kv_handle_t* out);
+/* Replaces DestroyKvVariableOp (kernels/kv_variable_ops.cc:295-323). Synchronous. */
+int kv_destroy(kv_handle_t h);
+/* Grows index + slab so that `capacity` keys fit without a rehash. Synchronous. */
+int kv_reserve(kv_handle_t h, int64_t capacity);
+
+/* Replaces InitKvVariableOp (kernels/kv_variable_ops.cc:188-200) -> InitRandomValues
+ * (kernels/kv_variable.h:184-206): stores the [rows, dim] fp32 init table; first call wins. */
+int kv_init_table(kv_handle_t h, const float* table, int64_t rows, kv_stream_t stream);
+/* KvVariableIsInitializedV2 (kernels/kv_variable_ops.cc:202-220) */
+int kv_is_initialized(kv_handle_t h, int* out);
+
+/* Test / reproducibility hooks (no reference counterpart): the reference stamps rows with
+ * time(NULL)/86400 (kernels/utility.cc:38-40) and picks init rows with std::rand()
+ * (kernels/kv_variable.h:889-898).  day < 0 restores the wall clock. */
+int kv_set_clock_days(kv_handle_t h, int day);
+int kv_set_seed(kv_handle_t h, uint64_t seed);
+
+/* ---- readback / statistics (synchronous: they return host scalars) ---------------------- */
+
+/* KvVariableSizeV2 -> size() (kernels/kv_variable.h:139-156): rows that are not blacklisted
+ * and whose frequency >= enter_threshold. */
+int kv_size(kv_handle_t h, int64_t* out, kv_stream_t stream);
+/* KvVariableShapeV2 dim 0 (kernels/kv_variable.h:177-182): every key in the map. */
+int kv_map_size(kv_handle_t h, int64_t* out, kv_stream_t stream);
+/* KvVariableFrequency -> sum_freq() (kernels/kv_variable.h:158-175) */
+int kv_sum_freq(kv_handle_t h, int64_t* out, kv_stream_t stream);
+/* Per-key meta for tests: freq_words[i] = (day << 16) | frequency, flags[i] bit0 = blacklist,
+ * bit1 = under_threshold, bit7 = key present (EmbeddingValue, kernels/embedding_value.h:225-235). */
+int kv_get_meta(kv_handle_t h, const int64_t* ids, int64_t n, uint32_t* freq_words, uint8_t* flags,
+                kv_stream_t stream);
+
+/* ---- lookup (HOT LOOP 1) ------------------------------------------------------------------ */
+
+/* Replaces KvVariableGatherOrInsertOp / ...WithCountsOp::Compute
+ * (kernels/kv_variable_ops.cc:498-538, 564-606) -> KvVariable::FindOrInsert
+ * (kernels/kv_variable.h:263-380).  out[i, :] = row(ids[i]); missing keys are inserted with
+ * 0.5*(T[r1]+T[r2]); every occurrence bumps the saturating uint16 frequency by 1 or by
+ * min(counts[i], 65535) and stamps the day; blacklisted keys read as zeros.  `counts` may be NULL.
+ * n == 0 is a no-op.  Fails with KV_FAILED_PRECONDITION if the init table is not set and a key
+ * would have to be inserted (the reference dereferences an empty tensor there). */
+int kv_gather_or_insert(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n,
+                        float* out, kv_stream_t stream);
+/* Replaces KvVariableGatherOrZerosOp::Compute (kernels/kv_variable_ops.cc:348-405) -> FindOrZeros
+ * (kernels/kv_variable.h:239-254): no insert, no frequency change, misses read as zeros. */
+int kv_gather_or_zeros(kv_handle_t h, const void* ids, int64_t n, float* out, kv_stream_t stream);
+
+/* ---- sparse optimizer apply (HOT LOOP 2) ---------------------------------------------------
+ * Common contract: `ids` [n] and `grad` [n, dim] as the op receives them.  Repeated ids are
+ * first combined the TF-core way (tf.unique + tf.unsorted_segment_sum, what
+ * optimizer._resource_apply_sparse_duplicate_indices does in front of the reference op,
+ * python/ops/variable_scope.py:1096-1106) inside the same call — the "segment-reduced
+ * scatter-add fused with the row update".  Rows whose var frequency < enter_threshold are
+ * skipped; new keys are inserted with the init rule; slot tables count one hit per apply. */
+
+/* Replaces KvVariableGroupSparseApplyAdamV4Op::Compute (kernels/training_ops.cc:6988-7213,
+ * version = 4) and ...V3Op (:5709-5965, version = 3).  `m_v_linear` has dim 3*dim ([m|v|z]).
+ * Scalars in the op's input order (ops/training_ops.cc:1266-1285): lr, beta1_power,
+ * beta2_power, beta1 ("beat1"), beta2, epsilon, l1, l2, l21. */
+int kv_apply_group_adam(kv_handle_t var, kv_handle_t m_v_linear, const float* grad, const void* ids,
+                        int64_t n, float lr, float beta1_power, float beta2_power, float beta1,
+                        float beta2, float epsilon, float l1, float l2, float l21, int version,
+                        kv_stream_t stream);
+/* Replaces KvVariableSparseApplyAdagradOp::Compute (kernels/training_ops.cc:1372-1498);
+ * argument order of ops/training_ops.cc:214-226. */
+int kv_apply_adagrad(kv_handle_t var, kv_handle_t accum, float lr, const float* grad,
+                     const void* ids, int64_t n, int update_slots, kv_stream_t stream);
+/* Replaces KvVariableSparseGroupSparseApplyFtrlOp<..., has_l2_shrinkage = true>::Compute
+ * (kernels/training_ops.cc:532-778); argument order of ops/training_ops.cc:135-150. */
+int kv_apply_sparse_group_ftrl(kv_handle_t var, kv_handle_t accum, kv_handle_t linear,
+                               const float* grad, const void* ids, int64_t n, float lr, float l1,
+                               float l2, float l21, float l2_shrinkage, float lr_power,
+                               kv_stream_t stream);
+
+/* The TF-core step on its own (for callers that want the [U, dim] IndexedSlices):
+ * uniq_ids [n], summed [n, dim] are filled for the first *num_unique entries; inverse [n]
+ * (may be NULL) maps each input position to its unique row.  Unique order is unspecified
+ * (TF-core gives first-occurrence order; consumers here are order-independent).  `h` only
+ * supplies the device, stream workspace and dim.  Synchronous (returns the host count). */
+int kv_dedup_segment_sum(kv_handle_t h, const void* ids, const float* grad, int64_t n,
+                         int64_t* uniq_ids, float* summed, int32_t* inverse, int64_t* num_unique,
+                         kv_stream_t stream);
+
+/* ---- export / import ("next" rows) -------------------------------------------
+ * Replaces ReadKvVariableOp / KvVariableExport (kernels/kv_variable_ops.cc:325-346, 779-860) ->
+ * ExportValues (kernels/dynamic_save.hpp:47-195).  Two-phase: kv_export_count fills
+ * counts[3] = {num_rows, blacklist_nums, freq_nums} on the host (synchronous), then the caller
+ * allocates and kv_export_fill writes keys [num_rows], values [num_rows, dim],
+ * blacklist [blacklist_nums], freq_keys / freq_values [freq_nums] (any of the last three may be
+ * NULL when its count is 0).  first_n: 2 = keys+values; >3 adds blacklist; >4 adds the uint32
+ * frequency words.  Row order is unspecified (the reference's is hash-map iteration order). */
+int kv_export_count(kv_handle_t h, int first_n, int64_t* counts, kv_stream_t stream);
+int kv_export_fill(kv_handle_t h, int first_n, int64_t* keys, float* values, int64_t* blacklist,
+                   int64_t* freq_keys, uint32_t* freq_values, kv_stream_t stream);
+/* Replaces KvVariableImport (kernels/kv_variable_ops.cc:862-940) -> ImportValues
+ * (kernels/dynamic_restore.hpp:29-195): clears the table, then loads keys/values, the
+ * blacklist and the frequency words (NULL / 0 to skip). */
+int kv_import(kv_handle_t h, const int64_t* keys, const float* values, int64_t n,
+              const int64_t* blacklist, int64_t n_blacklist, const int64_t* freq_keys,
+              const uint32_t* freq_values, int64_t n_freq, kv_stream_t stream);
+
+/* Replaces KvVariableInsertV2 (kernels/kv_variable_ops.cc:703-747) -> InsertOrUpdate
+ * (kernels/kv_variable.h:423-485): row(ids[i]) = values[i, :] (insert or overwrite). */
+int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv_stream_t stream);
+/* Replaces KvVariableScatter{Update,Add,Sub,Mul,Div,Min,Max}V2 (kernels/kv_variable_ops.cc:
+ * 1097-1161) -> ScatterUpdate (kernels/kv_variable.h:616-734): row = row <op> updates[i]; missing
+ * keys are inserted with the init rule first; blacklisted rows are left untouched. ids must
+ * be unique within one call (the reference races on duplicates). */
+int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
+                      kv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVHIP_H_ */

@@ -1,0 +1,355 @@
+"""Op-level host interface: one function per reference custom op, same names, argument
+order and error behaviour as the wrappers `tf.load_op_library("_kv_variable_ops.so")`
+generates in the reference (tfplus/kv_variable/python/ops/kv_variable_ops.py:74,
+REGISTER_OPs in tfplus/kv_variable/ops/{kv_variable_ops,training_ops}.cc).
+
+Tensors are torch tensors living in the GPU's HBM (host arrays are copied over); the
+`table_handle` is a KvHandle around the opaque C pointer.  Every op runs on torch's current
+HIP stream for the table's device, so it orders with surrounding torch work.  All compute
+goes through libkvhip.so (include/kvhip.h); there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from tfplus_amd import _lib
+
+_TORCH_KEY = {torch.int64: _lib.KV_DT_INT64, torch.int32: _lib.KV_DT_INT32}
+
+
+class KvHandle(object):
+  """The DT_RESOURCE scalar of the reference (`table_handle`)."""
+
+  def __init__(self, ptr, dim, key_dtype, value_dtype, device, enter_threshold, name):
+    self.ptr = ptr
+    self.dim = dim
+    self.key_dtype = key_dtype
+    self.value_dtype = value_dtype
+    self.device = device
+    self.enter_threshold = enter_threshold
+    self.name = name
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        _lib.lib().kv_destroy(self.ptr)
+        self.ptr = None
+    except Exception:  # interpreter shutdown
+      pass
+
+
+def _dev(handle):
+  return torch.device("cuda", handle.device)
+
+
+def _stream(handle):
+  return ctypes.c_void_p(torch.cuda.current_stream(_dev(handle)).cuda_stream)
+
+
+def _ids(handle, indices):
+  t = torch.as_tensor(indices)
+  if t.dtype != handle.key_dtype:
+    t = t.to(handle.key_dtype)
+  return t.to(_dev(handle)).contiguous()
+
+
+def _f32(handle, x):
+  return torch.as_tensor(x, dtype=torch.float32).to(_dev(handle)).contiguous()
+
+
+def _p(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def _scalar(x):
+  if isinstance(x, torch.Tensor):
+    return float(x.detach().to(torch.float32).item())
+  return float(np.float32(x))
+
+
+# ---- lifecycle --------------------------------------------------------------------------------
+def kv_variable(value_shape, key_dtype=torch.int64, value_dtype=torch.float32, container="",
+                shared_name="", use_node_name_sharing=False, key_shape=(), enter_threshold=0,
+                capacity_hint=0, device=None, name=None):
+  """REGISTER_OP("KvVariable") ops/kv_variable_ops.cc:37-74 (and V2–V4 :78-201)."""
+  if value_dtype != torch.float32:
+    raise _lib.UnimplementedError("value_dtype %s: only float32 rows are supported" % value_dtype)
+  if key_dtype not in _TORCH_KEY:
+    raise _lib.InvalidArgumentError("key_dtype %s: int32 / int64 only" % key_dtype)
+  dim = int(np.prod(list(value_shape))) if len(tuple(value_shape)) else 1
+  if device is None:
+    device = torch.cuda.current_device()
+  device = torch.device(device).index if not isinstance(device, int) else device
+  out = ctypes.c_void_p()
+  _lib.check(_lib.lib().kv_create(_TORCH_KEY[key_dtype], _lib.KV_DT_FLOAT, dim, int(enter_threshold),
+                                  int(capacity_hint), int(device), ctypes.byref(out)))
+  return KvHandle(out.value, dim, key_dtype, value_dtype, int(device),
+                  min(int(enter_threshold), 65535), shared_name or name or "kv_variable")
+
+
+kv_variable_v2 = kv_variable
+kv_variable_v3 = kv_variable
+kv_variable_v4 = kv_variable
+
+
+def init_kv_variable_v2(table_handle, random_initializer, name=None):
+  """REGISTER_OP("InitKvVariableV2") ops/kv_variable_ops.cc:212-222."""
+  t = _f32(table_handle, random_initializer)
+  if t.dim() != 2 or t.shape[1] != table_handle.dim:
+    raise _lib.InvalidArgumentError("random_initializer must be [rows, %d], got %s" %
+                                    (table_handle.dim, tuple(t.shape)))
+  _lib.check(_lib.lib().kv_init_table(table_handle.ptr, _p(t), t.shape[0], _stream(table_handle)))
+
+
+def kv_variable_is_initialized_v2(table_handle, name=None):
+  out = ctypes.c_int()
+  _lib.check(_lib.lib().kv_is_initialized(table_handle.ptr, ctypes.byref(out)))
+  return bool(out.value)
+
+
+def destroy_kv_variable_op_v2(table_handle, ignore_lookup_error=True, name=None):
+  if table_handle.ptr:
+    _lib.check(_lib.lib().kv_destroy(table_handle.ptr))
+    table_handle.ptr = None
+
+
+def _i64_out(fn, handle):
+  out = ctypes.c_int64()
+  _lib.check(fn(handle.ptr, ctypes.byref(out), _stream(handle)))
+  return out.value
+
+
+def kv_variable_shape_v2(table_handle, out_type=torch.int64, name=None):
+  """[number of keys in the map, dim] (kernels/kv_variable_ops.cc:159-177)."""
+  return [_i64_out(_lib.lib().kv_map_size, table_handle), table_handle.dim]
+
+
+kv_variable_shape = kv_variable_shape_v2
+
+
+def kv_variable_size_v2(table_handle, T=torch.int64, name=None):
+  return _i64_out(_lib.lib().kv_size, table_handle)
+
+
+def kv_variable_frequency(table_handle, name=None):
+  return _i64_out(_lib.lib().kv_sum_freq, table_handle)
+
+
+# ---- lookup -------------------------------------------------------------------------------------
+def _gather_out(table_handle, ids):
+  return torch.empty(tuple(ids.shape) + (table_handle.dim,), dtype=torch.float32,
+                     device=_dev(table_handle))
+
+
+def kv_variable_gather_or_insert_v2(table_handle, indices, dtype=torch.float32, name=None):
+  """REGISTER_OP("KvVariableGatherOrInsertV2") ops/kv_variable_ops.cc:310-320."""
+  ids = _ids(table_handle, indices)
+  out = _gather_out(table_handle, ids)
+  _lib.check(_lib.lib().kv_gather_or_insert(table_handle.ptr, _p(ids), None, ids.numel(), _p(out),
+                                            _stream(table_handle)))
+  return out
+
+
+def kv_variable_gather_or_insert_with_counts(table_handle, indices, counts, dtype=torch.float32,
+                                             name=None):
+  """REGISTER_OP("KvVariableGatherOrInsertWithCounts") ops/kv_variable_ops.cc:322-332."""
+  ids = _ids(table_handle, indices)
+  cnt = torch.as_tensor(counts)
+  if cnt.dtype != torch.int32:
+    # kv_variable.h:276-280
+    raise _lib.InvalidArgumentError("KvVariable %s: increment count, counts dtype must be int32" %
+                                    table_handle.name)
+  if tuple(cnt.shape) != tuple(ids.shape):
+    # kv_variable.h:268-274
+    raise _lib.InvalidArgumentError(
+        "KvVariable %s: increment count, indices shape %s does not match with counts shape %s" %
+        (table_handle.name, tuple(ids.shape), tuple(cnt.shape)))
+  cnt = cnt.to(_dev(table_handle)).contiguous()
+  out = _gather_out(table_handle, ids)
+  _lib.check(_lib.lib().kv_gather_or_insert(table_handle.ptr, _p(ids), _p(cnt), ids.numel(), _p(out),
+                                            _stream(table_handle)))
+  return out
+
+
+def kv_variable_gather_or_zeros_v2(table_handle, indices, dtype=torch.float32, name=None):
+  """REGISTER_OP("KvVariableGatherOrZerosV2") ops/kv_variable_ops.cc:285-295."""
+  ids = _ids(table_handle, indices)
+  out = _gather_out(table_handle, ids)
+  _lib.check(_lib.lib().kv_gather_or_zeros(table_handle.ptr, _p(ids), ids.numel(), _p(out),
+                                           _stream(table_handle)))
+  return out
+
+
+kv_variable_gather_v2 = kv_variable_gather_or_zeros_v2
+
+
+# ---- optimizers ---------------------------------------------------------------------------------
+def _grad_ids(var, grad, indices):
+  ids = _ids(var, indices)
+  if ids.dim() != 1:
+    raise _lib.InvalidArgumentError("indices must be one-dimensional")
+  g = _f32(var, grad)
+  if g.dim() < 1 or g.shape[0] != ids.shape[0]:
+    raise _lib.InvalidArgumentError("grad must be the same size as indices in the first dimension.")
+  if g.numel() != ids.shape[0] * var.dim:
+    raise _lib.InvalidArgumentError("var and grad must match in dimension 1")
+  return g, ids
+
+
+def _group_adam(version, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2,
+                epsilon, l1, l2, l21, use_locking):
+  g, ids = _grad_ids(var, grad, indices)
+  _lib.check(_lib.lib().kv_apply_group_adam(
+      var.ptr, m_v_linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(beta1_power),
+      _scalar(beta2_power), _scalar(beat1), _scalar(beta2), _scalar(epsilon), _scalar(l1), _scalar(l2),
+      _scalar(l21), version, _stream(var)))
+
+
+def kv_variable_group_sparse_apply_adam_v4(var, m_v_linear, grad, indices, lr, beta1_power,
+                                           beta2_power, beat1, beta2, epsilon, l1, l2, l21,
+                                           use_locking=False, name=None):
+  """REGISTER_OP("KvVariableGroupSparseApplyAdamV4") ops/training_ops.cc:1266-1285."""
+  _group_adam(4, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2, epsilon,
+              l1, l2, l21, use_locking)
+
+
+def kv_variable_group_sparse_apply_adam_v3(var, m_v_linear, grad, indices, lr, beta1_power,
+                                           beta2_power, beat1, beta2, epsilon, l1, l2, l21,
+                                           use_locking=False, name=None):
+  """REGISTER_OP("KvVariableGroupSparseApplyAdamV3") ops/training_ops.cc:1086-1105."""
+  _group_adam(3, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2, epsilon,
+              l1, l2, l21, use_locking)
+
+
+def kv_variable_sparse_apply_adagrad(var, accum, lr, grad, indices, use_locking=False,
+                                     update_slots=True, name=None):
+  """REGISTER_OP("KvVariableSparseApplyAdagrad") ops/training_ops.cc:214-226."""
+  g, ids = _grad_ids(var, grad, indices)
+  _lib.check(_lib.lib().kv_apply_adagrad(var.ptr, accum.ptr, _scalar(lr), _p(g), _p(ids), ids.numel(),
+                                         int(bool(update_slots)), _stream(var)))
+
+
+def kv_variable_sparse_group_sparse_apply_ftrl_v2(var, accum, linear, grad, indices, lr, l1, l2, l21,
+                                                  l2_shrinkage, lr_power, use_locking=False,
+                                                  name=None):
+  """REGISTER_OP("KvVariableSparseGroupSparseApplyFtrlV2") ops/training_ops.cc:135-150."""
+  g, ids = _grad_ids(var, grad, indices)
+  _lib.check(_lib.lib().kv_apply_sparse_group_ftrl(
+      var.ptr, accum.ptr, linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(l1),
+      _scalar(l2), _scalar(l21), _scalar(l2_shrinkage), _scalar(lr_power), _stream(var)))
+
+
+def kv_dedup_segment_sum(table_handle, indices, grad):
+  """tf.unique + tf.unsorted_segment_sum (TF-core _deduplicate_indexed_slices) on the GPU.
+  Returns (unique_ids [U], summed [U, dim], inverse [n])."""
+  g, ids = _grad_ids(table_handle, grad, indices)
+  n = ids.numel()
+  dev = _dev(table_handle)
+  uniq = torch.empty(n, dtype=torch.int64, device=dev)
+  summed = torch.empty((n, table_handle.dim), dtype=torch.float32, device=dev)
+  inv = torch.empty(n, dtype=torch.int32, device=dev)
+  nu = ctypes.c_int64()
+  _lib.check(_lib.lib().kv_dedup_segment_sum(table_handle.ptr, _p(ids), _p(g), n, _p(uniq), _p(summed),
+                                             _p(inv), ctypes.byref(nu), _stream(table_handle)))
+  return uniq[:nu.value], summed[:nu.value], inv
+
+
+# ---- readback / export / import ---------------------------------------------------------------------
+def kv_variable_export(table_handle, first_n=6, enable_cutoff=True, cutoff_value=1e-20, name=None):
+  """REGISTER_OP("KvVariableExport") ops/kv_variable_ops.cc:360-390 -> ExportValues.
+  Returns (keys, values, blacklist, freq_keys, freq_values); init_table is the caller's."""
+  cnt = (ctypes.c_int64 * 3)()
+  _lib.check(_lib.lib().kv_export_count(table_handle.ptr, int(first_n), cnt, _stream(table_handle)))
+  dev = _dev(table_handle)
+  keys = torch.empty(cnt[0], dtype=torch.int64, device=dev)
+  vals = torch.empty((cnt[0], table_handle.dim), dtype=torch.float32, device=dev)
+  bl = torch.empty(cnt[1], dtype=torch.int64, device=dev)
+  fk = torch.empty(cnt[2], dtype=torch.int64, device=dev)
+  fv = torch.empty(cnt[2], dtype=torch.int32, device=dev)
+  _lib.check(_lib.lib().kv_export_fill(table_handle.ptr, int(first_n), _p(keys), _p(vals), _p(bl),
+                                       _p(fk), _p(fv), _stream(table_handle)))
+  return keys, vals, bl, fk, fv
+
+
+def read_kv_variable_op_v2(table_handle, Tkeys=torch.int64, Tvalues=torch.float32, name=None):
+  """REGISTER_OP("ReadKvVariableOpV2") -> ExportValues(first_n = 2): (keys, values)."""
+  k, v, _, _, _ = kv_variable_export(table_handle, first_n=2)
+  return k, v
+
+
+def kv_variable_import(table_handle, keys, values, blacklist=None, freq_keys=None, freq_values=None,
+                       first_n=6, name=None):
+  """REGISTER_OP("KvVariableImport") ops/kv_variable_ops.cc:392-420 -> ImportValues."""
+  dev = _dev(table_handle)
+  k = torch.as_tensor(keys, dtype=torch.int64).to(dev).contiguous()
+  v = _f32(table_handle, values)
+  if v.numel() != k.numel() * table_handle.dim:
+    raise _lib.InvalidArgumentError("values must be [len(keys), %d]" % table_handle.dim)
+  bl = None if blacklist is None else torch.as_tensor(blacklist, dtype=torch.int64).to(dev).contiguous()
+  fk = None if freq_keys is None else torch.as_tensor(freq_keys, dtype=torch.int64).to(dev).contiguous()
+  fv = None
+  if freq_values is not None:
+    fv = torch.as_tensor(np.asarray(freq_values).astype(np.uint32).view(np.int32)
+                         if not isinstance(freq_values, torch.Tensor) else freq_values).to(dev).contiguous()
+  _lib.check(_lib.lib().kv_import(table_handle.ptr, _p(k), _p(v), k.numel(), _p(bl),
+                                  0 if bl is None else bl.numel(), _p(fk), _p(fv),
+                                  0 if fk is None else fk.numel(), _stream(table_handle)))
+
+
+def kv_variable_insert_v2(table_handle, indices, values, name=None):
+  """REGISTER_OP("KvVariableInsertV2") ops/kv_variable_ops.cc:334-347."""
+  ids = _ids(table_handle, indices)
+  v = _f32(table_handle, values)
+  if v.numel() != ids.numel() * table_handle.dim:
+    raise _lib.InvalidArgumentError("values must be indices.shape + [%d]" % table_handle.dim)
+  _lib.check(_lib.lib().kv_insert(table_handle.ptr, _p(ids), _p(v), ids.numel(), _stream(table_handle)))
+
+
+def _scatter(op):
+
+  def fn(table_handle, indices, updates, name=None):
+    ids = _ids(table_handle, indices)
+    u = _f32(table_handle, updates)
+    if u.numel() != ids.numel() * table_handle.dim:
+      raise _lib.InvalidArgumentError("updates must be indices.shape + [%d]" % table_handle.dim)
+    _lib.check(_lib.lib().kv_scatter_update(table_handle.ptr, _p(ids), _p(u), ids.numel(), op,
+                                            _stream(table_handle)))
+
+  return fn
+
+
+# REGISTER_OP("KvVariableScatter*V2") ops/kv_variable_ops.cc:422-560
+kv_variable_scatter_update_v2 = _scatter(0)
+kv_variable_scatter_add_v2 = _scatter(1)
+kv_variable_scatter_sub_v2 = _scatter(2)
+kv_variable_scatter_mul_v2 = _scatter(3)
+kv_variable_scatter_div_v2 = _scatter(4)
+kv_variable_scatter_min_v2 = _scatter(5)
+kv_variable_scatter_max_v2 = _scatter(6)
+
+
+# ---- test hooks (no reference counterpart) ---------------------------------------------------------
+def kv_set_clock_days(table_handle, day):
+  _lib.check(_lib.lib().kv_set_clock_days(table_handle.ptr, int(day)))
+
+
+def kv_set_seed(table_handle, seed):
+  _lib.check(_lib.lib().kv_set_seed(table_handle.ptr, int(seed)))
+
+
+def kv_get_meta(table_handle, indices):
+  ids = torch.as_tensor(indices, dtype=torch.int64).to(_dev(table_handle)).contiguous().view(-1)
+  fw = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)
+  fl = torch.empty(ids.numel(), dtype=torch.uint8, device=ids.device)
+  _lib.check(_lib.lib().kv_get_meta(table_handle.ptr, _p(ids), ids.numel(), _p(fw), _p(fl),
+                                    _stream(table_handle)))
+  fw = fw.cpu().numpy().view(np.uint32)
+  fl = fl.cpu().numpy()
+  return [None if not (b & 0x80) else {"freq": int(w & 0xFFFF), "day": int(w >> 16),
+                                       "blacklist": bool(b & 1), "under_threshold": bool(b & 2)}
+          for w, b in zip(fw, fl)]
+
+
+def kv_reserve(table_handle, capacity):
+  _lib.check(_lib.lib().kv_reserve(table_handle.ptr, int(capacity)))
