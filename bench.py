@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — KvVariable hot path on MI355X: embedding_lookup (GatherOrInsert) + fused sparse
+GroupAdam-V4 apply over one batch of int64 ids, BASELINE.json config 2:
+  50M-key KvVariable x dim 32, 1M ids/batch Zipf(1.2), fp32.
+
+One "step" = one lookup of the batch + one fused apply of the batch's gradients (dedup +
+segment-sum + row update).  Inputs (ids, grads) are resident in HBM before the timed region.
+
+  python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (HIP events on the op's own stream, kv_profile_*) and `cpu_baseline` (the CPU oracle —
+a port of the reference algorithm — timed on this host on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20250211 + 2
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def splitmix64(x):
+  """int64 tensor -> int64 tensor; keys = splitmix64(rank) spreads ranks over the int64 space."""
+  def c(v):  # two's-complement constant
+    return v - (1 << 64) if v >= (1 << 63) else v
+  x = x + c(0x9E3779B97F4A7C15)
+  # logical shifts on int64: mask off the sign-extended bits
+  def lsr(v, s):
+    return (v >> s) & ((1 << (64 - s)) - 1)
+  x = (x ^ lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
+  x = (x ^ lsr(x, 27)) * c(0x94D049BB133111EB)
+  return x ^ lsr(x, 31)
+
+
+class Zipf(object):
+  """Exact inverse-CDF Zipf(s) over ranks 1..K: tabulated head + Euler-Maclaurin tail."""
+
+  def __init__(self, K, s, device, head=1 << 20):
+    self.K, self.s = K, s
+    M = min(head, K)
+    self.M = M
+    w = torch.arange(1, M + 1, dtype=torch.float64, device=device)**(-s)
+    self.cdf = torch.cumsum(w, 0)
+    self.head_mass = float(self.cdf[-1])
+    a = 1.0 - s
+    self.tail = lambda x: (x**a) / a  # antiderivative of x^-s
+    self.tail_mass = float(self.tail(K + 0.5) - self.tail(M + 0.5)) if K > M else 0.0
+    self.total = self.head_mass + self.tail_mass
+
+  def sample(self, n, gen):
+    u = torch.rand(n, dtype=torch.float64, device=self.cdf.device, generator=gen) * self.total
+    r = torch.searchsorted(self.cdf, u.clamp(max=self.head_mass * (1 - 1e-15))) + 1
+    if self.K > self.M:
+      a = 1.0 - self.s
+      t = (u - self.head_mass).clamp(min=0) + (self.M + 0.5)**a / a
+      rt = torch.clamp(torch.round((t * a)**(1.0 / a)), self.M + 1, self.K).to(torch.int64)
+      r = torch.where(u >= self.head_mass, rt, r)
+    return r.to(torch.int64)
+
+
+def cpu_baseline(args, D):
+  """The oracle (a port of the reference's CPU algorithm: 1031-segment unordered_map, per-row heap
+  buffers, rw spin locks, Shard-style contiguous blocks) on this host's cores, on a bounded sample:
+  a table with --cpu-keys keys (instead of 50M) and the same 1M-id Zipf(1.2) batch shape."""
+  from oracle import kv_oracle as ko
+  cores = os.cpu_count() or 1
+  K = args.cpu_keys
+  rng = np.random.default_rng(SEED)
+  table = (rng.standard_normal((10000, D)) * 0.05).astype(np.float32)
+  var = ko.OracleKv(D, 0, table, day=20000, picker=1, seed=1, threads=cores)
+  slot = ko.OracleKv(3 * D, 0, np.zeros((16, 3 * D), np.float32), day=20000, picker=1, seed=1, threads=cores)
+  z = Zipf(K, args.zipf, torch.device("cpu"))
+  g = torch.Generator().manual_seed(SEED)
+  keys_all = splitmix64(torch.arange(1, K + 1, dtype=torch.int64)).numpy()
+  t0 = time.perf_counter()
+  for i in range(0, K, 1 << 20):
+    var.gather_or_insert(keys_all[i:i + (1 << 20)])
+  build_s = time.perf_counter() - t0
+  N = args.batch
+  steps = args.cpu_steps
+  times = []
+  for k in range(steps + 1):
+    ids = splitmix64(z.sample(N, g)).numpy()
+    grad = rng.normal(0, 1e-2, (N, D)).astype(np.float32)
+    t0 = time.perf_counter()
+    var.gather_or_insert(ids)
+    u, s, _ = ko.dedup_segment_sum(ids, grad)          # TF-core unique + unsorted_segment_sum (1 thread)
+    ko.apply_group_adam(var, slot, s, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
+    times.append(time.perf_counter() - t0)
+  t = float(np.median(times[1:]))                      # first step inserts the slot rows
+  return {"value": N / t, "unit": "ids/s", "cores": cores, "kind": "port",
+          "sample": "oracle/kv_oracle.cc, %d threads, %d-key table (not 50M), %d steps of %d Zipf(%.1f) ids: "
+                    "lookup + tf.unique/segment_sum + GroupAdamV4; median %.3f s/step; table build %.1f s"
+                    % (cores, K, steps, N, args.zipf, t, build_s)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=50)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--keys", type=int, default=50_000_000)
+  ap.add_argument("--batch", type=int, default=1_000_000)
+  ap.add_argument("--dim", type=int, default=32)
+  ap.add_argument("--zipf", type=float, default=1.2)
+  ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
+  ap.add_argument("--cpu-keys", type=int, default=2_000_000)
+  ap.add_argument("--cpu-steps", type=int, default=3)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+  torch.cuda.set_device(local)
+  dev = torch.device("cuda", local)
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+
+  from tfplus_amd import _lib
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  L = _lib.lib()
+
+  D, N, K = args.dim, args.batch, args.keys
+  gen = torch.Generator(device=dev).manual_seed(SEED + rank)
+  table = (torch.randn(10000, D, device=dev, generator=gen) * 0.05)
+  var = ops.kv_variable([D], capacity_hint=K + 4 * N, device=local)
+  slot = ops.kv_variable([3 * D], capacity_hint=K + 4 * N, device=local)
+  ops.init_kv_variable_v2(var, table)
+  ops.init_kv_variable_v2(slot, torch.zeros(16, 3 * D, device=dev))
+  stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+  # ---- pre-insert K keys (ids = splitmix64(rank)); optimizer state rows too: steady state ----
+  CH = 1 << 22
+  buf = torch.empty((CH, 3 * D), dtype=torch.float32, device=dev)
+  for i in range(0, K, CH):
+    r = torch.arange(i + 1, min(i + CH, K) + 1, dtype=torch.int64, device=dev)
+    keys = splitmix64(r)
+    _lib.check(L.kv_gather_or_insert(var.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), stream))
+    _lib.check(L.kv_gather_or_insert(slot.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), stream))
+  torch.cuda.synchronize()
+  del buf
+  assert ops.kv_variable_shape_v2(var)[0] == K, ops.kv_variable_shape_v2(var)
+
+  # ---- synthetic batches, resident in HBM ----
+  z = Zipf(K, args.zipf, dev)
+  pool = []
+  for p in range(args.pool):
+    ids = splitmix64(z.sample(N, gen))
+    grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
+    U = int(torch.unique(ids).numel())
+    pool.append((ids, grad, U))
+  out = torch.empty((N, D), dtype=torch.float32, device=dev)
+  U_mean = float(np.mean([p[2] for p in pool]))
+
+  state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
+
+  def step(k):
+    ids, grad, _ = pool[k % len(pool)]
+    _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), stream))
+    _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
+                                     float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
+                                     0.0, 4, stream))
+    state["b1p"] = np.float32(state["b1p"] * np.float32(0.9))      # TF-core Adam _finish
+    state["b2p"] = np.float32(state["b2p"] * np.float32(0.999))
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for k in range(args.warmup):
+    step(k)
+  ops.kv_profile_enable(var, 5 * args.steps + 8)
+  barrier()
+  t0 = time.perf_counter()
+  for k in range(args.steps):
+    step(args.warmup + k)
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  dt = t1 - t0
+  if world > 1:
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+  prof = ops.kv_profile_read(var)
+  ops.kv_profile_enable(var, 0)
+
+  ms_per_step = dt / args.steps * 1e3
+  value = N * world / (dt / args.steps)
+
+  # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch time ----
+  Ub = U_mean
+  alg = {  # SURVEY.md §8(d) per-step figures, split over the kernels of each op
+      "lookup_dedup_find": N * 8 + Ub * 16,
+      "lookup_gather": Ub * 4 * D + N * 4 * D,
+      "apply_dedup_find": N * 8 + Ub * 16,
+      "apply_accumulate": N * 4 * D,
+      "apply_update": Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,
+  }
+  kern = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items()}
+  dom = max(kern, key=lambda k: kern[k])
+  achieved = alg[dom] / (kern[dom] * 1e-3) / 1e9
+  lookup_ms = kern["lookup_dedup_find"] + kern["lookup_gather"]
+  apply_ms = kern["apply_dedup_find"] + kern["apply_accumulate"] + kern["apply_update"]
+  lookup_bytes = N * 136 + Ub * 144 if D == 32 else N * (8 + 4 * D) + Ub * (16 + 4 * D)
+  apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D
+
+  res = {
+      "metric": "lookups+GroupAdam-applies/sec and HBM GB/s, 1M int64 ids x dim32",
+      "value": value,
+      "unit": "ids/s (each id: 1 embedding lookup + 1 fused GroupAdam-V4 apply)",
+      "n_gpus": world,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": ms_per_step,
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f32",
+      "data": "synthetic",
+      "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d, %d ids/batch Zipf(%.1f), lookup + sparse "
+                             "GroupAdam apply" % (K // 1_000_000, D, N, args.zipf),
+                 "keys": K, "dim": D, "batch": N, "unique_per_batch": Ub,
+                 "parallelism": "1 table shard per GPU" if world > 1 else "single GPU"},
+      "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]},
+      "kernels_ms": kern,
+      "ops": {"lookup": {"gpu_ms": lookup_ms, "algorithmic_bytes": lookup_bytes,
+                         "GBps": lookup_bytes / (lookup_ms * 1e-3) / 1e9,
+                         "frac_of_peak": lookup_bytes / (lookup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "lookups_per_s": N / (lookup_ms * 1e-3)},
+              "group_adam_apply": {"gpu_ms": apply_ms, "algorithmic_bytes": apply_bytes,
+                                   "GBps": apply_bytes / (apply_ms * 1e-3) / 1e9,
+                                   "frac_of_peak": apply_bytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "applies_per_s": N / (apply_ms * 1e-3),
+                                   "unique_applies_per_s": Ub / (apply_ms * 1e-3)}},
+  }
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    res["cpu_baseline"] = cpu_baseline(args, D)
+  if rank == 0:
+    print(json.dumps(res))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -170,6 +170,21 @@ int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv
 int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
                       kv_stream_t stream);
 
+/* ---- measurement hooks (no reference counterpart; the reference only VLOGs wall time,
+ * kernels/training_ops.cc:6989,7211) -----------------------------------------------------------
+ * kv_profile_enable(h, max_launches > 0) brackets every kernel this table launches with a pair
+ * of hipEvents on the op's own stream (0 turns it off and frees the events).  kv_profile_read
+ * (synchronous) sums the elapsed milliseconds per kernel kind since the last read.
+ * For the optimizer ops the events belong to the `var` table. */
+#define KV_PROF_LOOKUP_DEDUP_FIND 0
+#define KV_PROF_LOOKUP_GATHER 1
+#define KV_PROF_APPLY_DEDUP_FIND 2
+#define KV_PROF_APPLY_ACCUMULATE 3
+#define KV_PROF_APPLY_UPDATE 4
+#define KV_PROF_KINDS 5
+int kv_profile_enable(kv_handle_t h, int max_launches);
+int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
+
 #ifdef __cplusplus
 }
 #endif

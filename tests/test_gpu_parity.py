@@ -289,11 +289,28 @@ def test_group_adam_parity_with_regularizers_and_blacklist(ops):
                 l21=2e-2)
     nb = sum(1 for k in ids if ov.meta(int(k))["blacklist"])
     assert 0 < nb < ids.size, nb                      # the case really exercises both branches
-    # rows within 1e-9 of the threshold may legitimately flip with the reduction order: none here
-    _assert_same_table(ops, hv, ov, ids, rtol=RTOL, atol=1e-9)
+    # x = u * (1 - l21n/||u||) / y: the norm's fp32 reduction order (Eigen packets in the
+    # reference, sequential in the oracle, an 8-lane shuffle tree on the GPU) moves ||u|| by an
+    # ulp, which the subtraction amplifies by 1/scale.  Tolerance per row = 1e-6 / scale;
+    # rows closer than 1e-4 relative to the threshold may legitimately flip and are skipped.
+    lr, l1s, l21n = np.float32(0.05), np.float32(1e-3 * 0.05), np.float32(2e-2 * 0.05) * np.sqrt(np.float32(D))
+    z = os_.gather_or_zeros(ids)[:, 2 * D:]
+    nrm = np.sqrt(((np.clip(z, -l1s, l1s) - z).astype(np.float64)**2).sum(1))
+    scale = 1.0 - l21n / np.maximum(nrm, 1e-30)
+    clear = np.abs(scale) > 1e-4
+    assert clear.sum() > ids.size * 0.99
+    got, exp = _np(ops.kv_variable_gather_or_zeros_v2(hv, ids)), ov.gather_or_zeros(ids)
+    tol = RTOL / np.maximum(scale, 1e-4)[:, None] * np.abs(exp) + 1e-9
+    assert np.all((np.abs(got - exp) <= tol)[clear])
+    gm, om = ops.kv_get_meta(hv, ids), [ov.meta(int(k)) for k in ids]
+    assert all(a == b for a, b, c in zip(gm, om, clear) if c)
     _assert_same_table(ops, hs, os_, ids, rtol=RTOL, atol=1e-12)
     # blacklisted keys read as zeros through both lookups, and still count frequency
-    np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_insert_v2(hv, ids)), ov.gather_or_insert(ids))
+    gi, oi = _np(ops.kv_variable_gather_or_insert_v2(hv, ids)), ov.gather_or_insert(ids)
+    np.testing.assert_array_equal(gi, got)             # training lookup == inference lookup
+    black = np.array([m["blacklist"] for m in om])
+    assert np.all(gi[black & clear] == 0) and np.all(oi[black] == 0)
+    assert [m["freq"] for m in ops.kv_get_meta(hv, ids)] == [ov.meta(int(k))["freq"] for k in ids]
   ek, ev, ebl, efk, efv = ops.kv_variable_export(hv, first_n=6)
   ok, ovv, obl, ofk, ofv = ov.export(first_n=6)
   assert sorted(_np(ebl)) == sorted(obl) and sorted(_np(ek)) == sorted(ok)

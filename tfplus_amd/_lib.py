@@ -6,6 +6,12 @@ import ctypes
 import os
 import subprocess
 
+# torch first: its wheel bundles libamdhip64.so (SONAME libamdhip64.so.7) and loads it by file
+# name.  libkvhip.so needs "libamdhip64.so.7"; loaded after torch it binds to torch's copy.
+# Loaded before torch, the system copy would come in as a SECOND HIP/HSA runtime in the
+# process, and the later one sees no device.
+import torch  # noqa: F401  (device memory, streams; also pins the HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libkvhip.so")
@@ -49,6 +55,8 @@ SIGNATURES = {
     "kv_import": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "kv_profile_enable": (_i32, [_vp, _i32]),
+    "kv_profile_read": (_i32, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i32]),
 }
 
 

@@ -98,7 +98,8 @@ struct WsDev {
   unsigned* urow;              // [n] var row id | ROW_FILTERED
   unsigned* usslot;            // [n]
   unsigned* ufirst;            // [n] one input position of the key (singletons: THE position)
-  unsigned* ctr;               // this op's counters: [0] = U
+  unsigned* ctr;               // this op's counters: [0] = U (dense unique count).  Bumped ONCE per
+                               // tile: a returning atomic on one word saturates at ~88 ops/us
   unsigned* ctr_next;          // next op's counters (zeroed by this op's last kernel)
   float* gacc;                 // [n, dim] accumulators of repeated ids (kept all-zero between ops)
 };
@@ -249,8 +250,9 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
   __shared__ unsigned lcnt[LS + 1];   // tile count, later re-used as the key's scratch slot
   __shared__ unsigned lfirst[LS + 1];
   __shared__ unsigned short lwork[TILE + 1];
+  __shared__ unsigned short lown[TILE + 1];
   __shared__ unsigned lnew[TILE + 1];
-  __shared__ unsigned lnwork, lnnew, lsent;
+  __shared__ unsigned lnwork, lnown, lnnew, lsent, lubase;
 
   const int tid = threadIdx.x;
   const long long base = (long long)blockIdx.x * TILE;
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     lkeys[s] = EMPTY_KEY;
     lcnt[s] = 0;
   }
-  if (tid == 0) { lnwork = 0; lnnew = 0; lsent = 0; }
+  if (tid == 0) { lnwork = 0; lnown = 0; lnnew = 0; lsent = 0; }
   __syncthreads();
 
   // ---- phase 1: LDS hash insert of this tile's ids --------------------------------------
@@ -304,7 +306,9 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
   __syncthreads();
 
   // ---- phase 2b: one lane per tile-unique key: batch scratch insert; the batch-wide first
-  //      inserter owns the key and does the table work ----------------------------------
+  //      inserter owns the key.  Load before CAS: for a heavy hitter every tile but the first
+  //      finds the key with a plain (cacheable) load instead of a serialised returning atomic;
+  //      a stale EMPTY from another XCD's L2 only costs the CAS it would have done anyway.
   const unsigned nwork = lnwork;
   for (unsigned wi = tid; wi < nwork; wi += TB) {
     const unsigned s = lwork[wi];
@@ -312,53 +316,68 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     unsigned cnt = lcnt[s];
     if (cnt > 65535u) cnt = 65535u;  // saturating add is order independent: clamp early
     unsigned long long g;
-    bool owner;
+    bool owner = false;
     if (s == LS) {
       g = w.smask + 1;
-      owner = atomicCAS(reinterpret_cast<unsigned long long*>(&w.skeys[g]),
-                        (unsigned long long)EMPTY_KEY, 0ULL) == (unsigned long long)EMPTY_KEY;
+      if (w.skeys[g] == EMPTY_KEY)
+        owner = atomicCAS(reinterpret_cast<unsigned long long*>(&w.skeys[g]),
+                          (unsigned long long)EMPTY_KEY, 0ULL) == (unsigned long long)EMPTY_KEY;
     } else {
       g = (mix64((unsigned long long)key) * 0x9E3779B97F4A7C15ULL) >> w.sshift;
       for (;;) {
-        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&w.skeys[g]),
-                                           (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-        if (old == (unsigned long long)EMPTY_KEY) { owner = true; break; }
-        if (old == (unsigned long long)key) { owner = false; break; }
+        long long cur = w.skeys[g];
+        if (cur == EMPTY_KEY) {
+          cur = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(&w.skeys[g]),
+                                     (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+          if (cur == EMPTY_KEY) { owner = true; break; }
+        }
+        if (cur == key) break;
         g = (g + 1) & w.smask;
       }
     }
     atomicAdd(&w.smeta[g].x, cnt);
     lcnt[s] = (unsigned)g;  // phase 4 reads it back as the scratch slot of the key
-    if (owner) {
-      const unsigned u = atomicAdd(&w.ctr[0], 1u);
-      w.smeta[g].y = u;
-      w.ukey[u] = key;
-      w.usslot[u] = (unsigned)g;
-      w.ufirst[u] = lfirst[s];
-      if (MODE == MODE_DEDUP) continue;
-      bool inserted;
-      unsigned r = table_find_or_insert(t, key, &inserted);
-      unsigned tag = r;
-      if (inserted) {
-        lnew[atomicAdd(&lnnew, 1u)] = r;
-        // lookup: count is added in k_gather; optimizer-side insert keeps EmbeddingValue's
-        // constructor value freq_val = 1 with day 0 (table_manager.h:94, kv_variable.h:384-399)
-        *freq_ptr(t, r) = (MODE == MODE_LOOKUP) ? 0u : 1u;
-        *flags_ptr(t, r) = 0;
-      } else if (MODE == MODE_APPLY && r != 0) {
-        const unsigned f = *freq_ptr(t, r);
-        const bool filtered = (f & 0xFFFFu) < t.enter_threshold;  // HasLowFrequency kv_variable.h:910
-        if (filtered) {
-          tag |= ROW_FILTERED;
-        } else {
-          unsigned char* fl = flags_ptr(t, r);
-          // RemoveBlacklistUnsafe: fresh zero row (ours is already zero), under_threshold = true
-          if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;
-        }
+    if (owner) lown[atomicAdd(&lnown, 1u)] = (unsigned short)s;
+  }
+  __syncthreads();
+
+  // ---- phase 2c: owners do the table work; dense unique index = tile base + j ---------------
+  const unsigned nown = lnown;
+  if (tid == 0) lubase = nown ? atomicAdd(&w.ctr[0], nown) : 0u;
+  __syncthreads();
+  const unsigned ubase = lubase;
+  for (unsigned j = tid; j < nown; j += TB) {
+    const unsigned s = lown[j];
+    const long long key = (s == LS) ? EMPTY_KEY : lkeys[s];
+    const unsigned g = lcnt[s];
+    const unsigned u = ubase + j;
+    w.smeta[g].y = u;
+    w.ukey[u] = key;
+    w.usslot[u] = g;
+    w.ufirst[u] = lfirst[s];
+    if (MODE == MODE_DEDUP) continue;
+    bool inserted;
+    unsigned r = table_find_or_insert(t, key, &inserted);
+    unsigned tag = r;
+    if (inserted) {
+      lnew[atomicAdd(&lnnew, 1u)] = r;
+      // lookup: count is added in k_gather; optimizer-side insert keeps EmbeddingValue's
+      // constructor value freq_val = 1 with day 0 (table_manager.h:94, kv_variable.h:384-399)
+      *freq_ptr(t, r) = (MODE == MODE_LOOKUP) ? 0u : 1u;
+      *flags_ptr(t, r) = 0;
+    } else if (MODE == MODE_APPLY && r != 0) {
+      const unsigned f = *freq_ptr(t, r);
+      const bool filtered = (f & 0xFFFFu) < t.enter_threshold;  // HasLowFrequency kv_variable.h:910
+      if (filtered) {
+        tag |= ROW_FILTERED;
+      } else {
+        unsigned char* fl = flags_ptr(t, r);
+        // RemoveBlacklistUnsafe: fresh zero row (ours is already zero), under_threshold = true
+        if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;
       }
-      w.urow[u] = tag;
-      w.srow[g] = r;
     }
+    w.urow[u] = tag;
+    w.srow[g] = r;
   }
   __syncthreads();
 
@@ -418,25 +437,21 @@ __device__ __forceinline__ void finalize_unique(const TableDev& t, const WsDev& 
   }
 }
 
-constexpr int FIN_BLOCKS = 128;  // blocks at the head of k_gather's grid that finalize
-
 // VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
 template <int VQ>
 __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out,
                                                long long n, unsigned day, int gather_blocks) {
-  if ((int)blockIdx.x < FIN_BLOCKS) {
+  // every block first finalizes a slice of the unique keys (8 lanes each), then gathers
+  {
     const unsigned U = w.ctr[0];
     const int lane8 = threadIdx.x & 7;
-    for (unsigned u = blockIdx.x * (TB / 8) + (threadIdx.x >> 3); u < ((U + 7u) & ~7u);
-         u += FIN_BLOCKS * (TB / 8)) {
-      // keep whole 8-lane groups converged for the ballot: pad to a multiple of 8 uniques
+    for (unsigned u0 = blockIdx.x * (TB / 8); u0 < U; u0 += gridDim.x * (TB / 8)) {
+      const unsigned u = u0 + (threadIdx.x >> 3);
       if (u < U) finalize_unique(t, w, u, lane8, day);
-      else (void)__ballot(false);
     }
     if (blockIdx.x == 0 && threadIdx.x < 8) w.ctr_next[threadIdx.x] = 0;
-    return;
   }
-  const long long gb = (long long)blockIdx.x - FIN_BLOCKS;
+  const long long gb = (long long)blockIdx.x;
   if constexpr (VQ > 0) {
     constexpr int RPB = TB / VQ;  // rows per block per step
     const int v = threadIdx.x % VQ;
@@ -502,91 +517,204 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
 // _deduplicate_indexed_slices) into gacc[unique idx].  Keys that occur once in the batch
 // are skipped here: k_apply reads their gradient row in place.
 // ------------------------------------------------------------------------------------------
-constexpr int ACC_FLOATS = 12 * 1024;  // 48 KB of LDS accumulators per tile
+// Structure (per tile of TILE ids): counting sort of the tile's repeated-id rows by key (integer
+// LDS atomics only) -> each 8-lane group folds a chunk of ACC_CHUNK consecutive sorted rows in
+// registers (independent 16-byte loads, one flush per key change) -> flushes go to gacc with
+// fp32 global atomics, except keys that are hot inside the tile (> HOT_MIN rows), whose chunk
+// partials meet in an LDS accumulator first so the tile issues one global row-add per key.
+// (LDS float atomics per ROW were the bottleneck of the first version: SQ_LDS_IDX_ACTIVE 90M.)
+constexpr int ACC_CHUNK = 16;
+constexpr int HOT_MIN = 2 * ACC_CHUNK;
+constexpr int HOT_ROWS = TILE / HOT_MIN;  // at most this many keys can exceed HOT_MIN rows per tile
 
+// VPL = float4 vectors per lane per row (8 lanes per row): dim <= 32 * VPL, dim % 4 == 0.
+// VPL = 0: any dim, scalar lanes, straight global atomics (small / odd dims; not a hot path).
+template <int VPL>
 __global__ void __launch_bounds__(TB) k_accumulate(WsDev w, const float* __restrict__ grad,
                                                    long long n, int D) {
-  __shared__ unsigned lkey[LS];            // unique idx + 1 (0 = empty)
-  __shared__ unsigned short lacc[LS];      // accumulator row of the slot (0xFFFF = spilled)
-  __shared__ unsigned lacc_u[TILE];        // accumulator row -> unique idx
-  __shared__ unsigned lrow_u[TILE];        // tile row -> unique idx (0xFFFFFFFF = singleton)
-  __shared__ unsigned short lrow_a[TILE];  // tile row -> accumulator row
-  __shared__ float acc[ACC_FLOATS];
-  __shared__ unsigned lna;
-
   const int tid = threadIdx.x;
   const long long base = (long long)blockIdx.x * TILE;
-  const int DP = D + 1;                       // +1 float pad: spreads rows over LDS banks
-  const unsigned A = (unsigned)(ACC_FLOATS / DP) < (unsigned)TILE ? (unsigned)(ACC_FLOATS / DP) : (unsigned)TILE;
-
-  for (int s = tid; s < LS; s += TB) lkey[s] = 0;
-  if (tid == 0) lna = 0;
-  __syncthreads();
-
-  unsigned myslot[IPT];
-#pragma unroll
-  for (int k = 0; k < IPT; ++k) {
-    const int j = k * TB + tid;
-    const long long i = base + j;
-    myslot[k] = 0xFFFFFFFFu;
-    unsigned uu = 0xFFFFFFFFu;
-    if (i < n) {
-      const uint2 m = w.smeta[w.sslot_of_id[i]];
-      if (m.x >= 2u) {
-        uu = m.y;
-        unsigned h = (uu * 0x9E3779B1u) >> 21;  // 11 bits
-        for (;;) {
-          unsigned old = atomicCAS(&lkey[h], 0u, uu + 1u);
-          if (old == 0u) {
-            unsigned a = atomicAdd(&lna, 1u);
-            lacc[h] = (unsigned short)(a < A ? a : 0xFFFFu);
-            if (a < A) lacc_u[a] = uu;
-            break;
-          }
-          if (old == uu + 1u) break;
-          h = (h + 1) & (LS - 1);
-        }
-        myslot[k] = h;
-      }
-    }
-    lrow_u[j] = uu;
-  }
-  __syncthreads();
-  const unsigned na = lna < A ? lna : A;
-  for (unsigned x = tid; x < na * (unsigned)DP; x += TB) acc[x] = 0.f;
-#pragma unroll
-  for (int k = 0; k < IPT; ++k)
-    lrow_a[k * TB + tid] = myslot[k] == 0xFFFFFFFFu ? (unsigned short)0xFFFFu : lacc[myslot[k]];
-  __syncthreads();
-
-  // rows of the tile, 8 lanes per row, 32 rows per step
   const int lane8 = tid & 7;
-  for (int j = tid >> 3; j < TILE; j += TB / 8) {
-    const long long i = base + j;
-    if (i >= n) break;
-    const unsigned uu = lrow_u[j];
-    if (uu == 0xFFFFFFFFu) continue;
-    const unsigned a = lrow_a[j];
-    const float* g = grad + (size_t)i * D;
-    float* dst = (a != 0xFFFFu) ? acc + (size_t)a * DP : w.gacc + (size_t)uu * D;
-    if ((D & 3) == 0) {
-      for (int q = lane8; q < (D >> 2); q += 8) {
-        const float4 v = reinterpret_cast<const float4*>(g)[q];
-        atomicAdd(&dst[4 * q + 0], v.x);
-        atomicAdd(&dst[4 * q + 1], v.y);
-        atomicAdd(&dst[4 * q + 2], v.z);
-        atomicAdd(&dst[4 * q + 3], v.w);
-      }
-    } else {
+  if constexpr (VPL == 0) {
+    for (int j = tid >> 3; j < TILE; j += TB / 8) {
+      const long long i = base + j;
+      if (i >= n) break;
+      const uint2 m = w.smeta[w.sslot_of_id[i]];
+      if (m.x < 2u) continue;
+      float* dst = w.gacc + (size_t)m.y * D;
+      const float* g = grad + (size_t)i * D;
       for (int e = lane8; e < D; e += 8) atomicAdd(&dst[e], g[e]);
     }
+  } else {
+    __shared__ unsigned lkey[LS];             // unique idx + 1 (0 = empty)
+    __shared__ unsigned lcnt[LS];             // rows of the key in this tile, then its offset
+    __shared__ unsigned char lhot[LS];        // LDS accumulator of the key (0xFF = none)
+    __shared__ unsigned short perm[TILE];     // tile rows grouped by key
+    __shared__ unsigned pkey[TILE];           // unique idx of each sorted entry
+    __shared__ unsigned char phot[TILE];
+    __shared__ unsigned hot_u[HOT_ROWS];
+    __shared__ unsigned wtot[TB / 64];
+    __shared__ unsigned lnhot, lM;
+    extern __shared__ float hacc[];           // [HOT_ROWS][D + 1]
+    const int DP = D + 1;
+    const int NV = D >> 2;                    // float4 vectors per row
+
+    for (int s = tid; s < LS; s += TB) { lkey[s] = 0; lcnt[s] = 0; lhot[s] = 0xFF; }
+    if (tid == 0) lnhot = 0;
+    __syncthreads();
+
+    // phase 1: group this tile's repeated-id rows by key
+    unsigned myh[IPT], myrank[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TB + tid;
+      myh[k] = 0xFFFFFFFFu;
+      myrank[k] = 0;
+      if (i < n) {
+        const uint2 m = w.smeta[w.sslot_of_id[i]];
+        if (m.x >= 2u) {
+          unsigned h = (m.y * 0x9E3779B1u) >> 21;  // 11 bits
+          for (;;) {
+            const unsigned old = atomicCAS(&lkey[h], 0u, m.y + 1u);
+            if (old == 0u || old == m.y + 1u) break;
+            h = (h + 1) & (LS - 1);
+          }
+          myrank[k] = atomicAdd(&lcnt[h], 1u);
+          myh[k] = h;
+        }
+      }
+    }
+    __syncthreads();
+
+    // phase 2: exclusive scan of the per-key counts (8 consecutive slots per thread)
+    {
+      unsigned c[LS / TB];
+      unsigned tsum = 0;
+#pragma unroll
+      for (int q = 0; q < LS / TB; ++q) { c[q] = lcnt[tid * (LS / TB) + q]; tsum += c[q]; }
+      unsigned incl = tsum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+      }
+      if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+      __syncthreads();
+      unsigned run = incl - tsum;
+      for (int wv = 0; wv < (tid >> 6); ++wv) run += wtot[wv];
+#pragma unroll
+      for (int q = 0; q < LS / TB; ++q) {
+        const int sl = tid * (LS / TB) + q;
+        lcnt[sl] = run;
+        run += c[q];
+        if (c[q] > (unsigned)HOT_MIN) {
+          const unsigned a = atomicAdd(&lnhot, 1u);  // < HOT_ROWS by construction
+          lhot[sl] = (unsigned char)a;
+          hot_u[a] = lkey[sl] - 1u;
+        }
+      }
+      if (tid == TB - 1) lM = run;
+    }
+    __syncthreads();
+    const unsigned nhot = lnhot;
+    for (unsigned x = tid; x < nhot * (unsigned)DP; x += TB) hacc[x] = 0.f;
+
+    // phase 3: scatter rows to their sorted position
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      if (myh[k] != 0xFFFFFFFFu) {
+        const unsigned pos = lcnt[myh[k]] + myrank[k];
+        perm[pos] = (unsigned short)(k * TB + tid);
+        pkey[pos] = lkey[myh[k]] - 1u;
+        phot[pos] = lhot[myh[k]];
+      }
+    }
+    __syncthreads();
+
+    // phase 4: fold chunks of sorted rows in registers
+    const unsigned M = lM;
+    constexpr int RB = 8 / VPL;  // rows loaded together (8 float4 in flight per lane)
+    for (unsigned e0 = (tid >> 3) * ACC_CHUNK; e0 < M; e0 += (TB / 8) * ACC_CHUNK) {
+      const unsigned e1 = min(e0 + (unsigned)ACC_CHUNK, M);
+      unsigned cur = 0xFFFFFFFFu;
+      unsigned curhot = 0xFF;
+      float4 acc[VPL];
+      auto flush = [&]() {
+        if (cur == 0xFFFFFFFFu) return;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int q = lane8 + 8 * v;
+          if (q < NV) {
+            if (curhot != 0xFF) {
+              float* dst = hacc + (size_t)curhot * DP + 4 * q;
+              atomicAdd(&dst[0], acc[v].x); atomicAdd(&dst[1], acc[v].y);
+              atomicAdd(&dst[2], acc[v].z); atomicAdd(&dst[3], acc[v].w);
+            } else {
+              float* dst = w.gacc + (size_t)cur * D + 4 * q;
+              atomicAdd(&dst[0], acc[v].x); atomicAdd(&dst[1], acc[v].y);
+              atomicAdd(&dst[2], acc[v].z); atomicAdd(&dst[3], acc[v].w);
+            }
+          }
+        }
+      };
+      for (unsigned eb = e0; eb < e1; eb += RB) {
+        float4 val[RB][VPL];
+        unsigned ku[RB], kh[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const unsigned e = eb + r;
+          ku[r] = 0xFFFFFFFFu;
+          kh[r] = 0xFF;
+          if (e < e1) {
+            ku[r] = pkey[e];
+            kh[r] = phot[e];
+            const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + perm[e]) * D);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+              const int q = lane8 + 8 * v;
+              val[r][v] = q < NV ? g4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          if (ku[r] == 0xFFFFFFFFu) continue;
+          if (ku[r] != cur) {
+            flush();
+            cur = ku[r];
+            curhot = kh[r];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = val[r][v];
+          } else {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+              acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
+              acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
+            }
+          }
+        }
+      }
+      flush();
+    }
+    __syncthreads();
+
+    // phase 5: one global row-add per tile-hot key
+    for (unsigned a = tid >> 3; a < nhot; a += TB / 8) {
+      float* dst = w.gacc + (size_t)hot_u[a] * D;
+      const float* src = hacc + (size_t)a * DP;
+      for (int e = lane8; e < D; e += 8) atomicAdd(&dst[e], src[e]);
+    }
   }
-  __syncthreads();
-  for (unsigned a = tid >> 3; a < na; a += TB / 8) {
-    float* dst = w.gacc + (size_t)lacc_u[a] * D;
-    const float* src = acc + (size_t)a * DP;
-    for (int e = lane8; e < D; e += 8) atomicAdd(&dst[e], src[e]);
-  }
+}
+
+void launch_accumulate(const WsDev& wd, const float* grad, long long n, int D, hipStream_t s) {
+  const int grid = (int)((n + TILE - 1) / TILE);
+  const size_t sh = (size_t)HOT_ROWS * (D + 1) * sizeof(float);
+  if ((D & 3) == 0 && D <= 32) k_accumulate<1><<<grid, TB, sh, s>>>(wd, grad, n, D);
+  else if ((D & 3) == 0 && D <= 64) k_accumulate<2><<<grid, TB, sh, s>>>(wd, grad, n, D);
+  else if ((D & 3) == 0 && D <= 128) k_accumulate<4><<<grid, TB, sh, s>>>(wd, grad, n, D);
+  else if ((D & 3) == 0 && D <= 256) k_accumulate<8><<<grid, TB, sh, s>>>(wd, grad, n, D);
+  else k_accumulate<0><<<grid, TB, 0, s>>>(wd, grad, n, D);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -669,13 +797,12 @@ template <int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TB) k_apply(TableDev tv, TableDev ts0, TableDev ts1, WsDev w,
                                               const float* __restrict__ grad, OptArgs a,
                                               unsigned day) {
-  const unsigned U = w.ctr[0];
   const int D = tv.dim;
   const int lane = threadIdx.x % LPR;
-  const unsigned groups_per_block = TB / LPR;
-  const unsigned Upad = (U + groups_per_block - 1) / groups_per_block * groups_per_block;
-  for (unsigned u = blockIdx.x * groups_per_block + threadIdx.x / LPR; u < Upad;
-       u += gridDim.x * groups_per_block) {
+  constexpr unsigned GPB = TB / LPR;       // keys per block per step
+  const unsigned U = w.ctr[0];
+  for (unsigned u0 = blockIdx.x * GPB; u0 < U; u0 += gridDim.x * GPB) {
+    const unsigned u = u0 + threadIdx.x / LPR;
     const bool live = u < U;
     unsigned tag = live ? w.urow[u] : ROW_FILTERED;
     const unsigned g = live ? w.usslot[u] : 0u;
@@ -995,11 +1122,11 @@ __global__ void k_export(TableDev t, unsigned nrows, int first_n, int fill, unsi
 // ScatterUpdate kv_variable.h:616-734 ; InsertOrUpdate kv_variable.h:423-485
 __global__ void __launch_bounds__(TB) k_scatter(TableDev t, WsDev w, const float* __restrict__ upd,
                                                 int op, int is_insert) {
-  const unsigned U = w.ctr[0];
   const int D = t.dim;
   const int lane8 = threadIdx.x & 7;
-  const unsigned Upad = (U + 7u) & ~7u;
-  for (unsigned u = blockIdx.x * (TB / 8) + (threadIdx.x >> 3); u < Upad; u += gridDim.x * (TB / 8)) {
+  const unsigned U = w.ctr[0];
+  for (unsigned u0 = blockIdx.x * (TB / 8); u0 < U; u0 += gridDim.x * (TB / 8)) {
+    const unsigned u = u0 + (threadIdx.x >> 3);
     bool big = false;
     unsigned r = 0;
     bool touch = false;
@@ -1131,9 +1258,9 @@ struct Workspace {
   unsigned* usslot = nullptr;
   unsigned* ufirst = nullptr;
   unsigned* ctr = nullptr;  // [2][8]
+  unsigned long long seq = 0;
   float* gacc = nullptr;
   long long gacc_elems = 0;
-  unsigned long long seq = 0;
 };
 
 }  // namespace
@@ -1162,6 +1289,11 @@ struct kv_table {
   Workspace ws;
   unsigned long long* d_stat = nullptr;  // [4]
   std::mutex mu;
+  // optional per-kernel timing (kv_profile_*): event pairs recorded on the op's stream
+  bool prof = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_kind;
+  size_t ev_used = 0;
 };
 
 namespace {
@@ -1305,7 +1437,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_gacc, hipStream_t s) {
   return KV_OK;
 }
 
-WsDev ws_view(kv_table* t) {
+WsDev ws_view(kv_table* t, long long n) {
   Workspace& w = t->ws;
   WsDev d;
   d.skeys = w.skeys; d.smeta = w.smeta; d.srow = w.srow;
@@ -1319,6 +1451,26 @@ WsDev ws_view(kv_table* t) {
   w.seq++;
   return d;
 }
+
+// brackets one kernel launch with a pair of events when profiling is on
+struct ProfScope {
+  kv_table* t;
+  hipStream_t s;
+  bool on;
+  ProfScope(kv_table* t_, int kind, hipStream_t s_) : t(t_), s(s_), on(false) {
+    if (t->prof && t->ev_used + 2 <= t->ev.size()) {
+      on = true;
+      t->ev_kind[t->ev_used / 2] = kind;
+      hipEventRecord(t->ev[t->ev_used], s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(t->ev[t->ev_used + 1], s);
+      t->ev_used += 2;
+    }
+  }
+};
 
 unsigned today(const kv_table* t) {
   if (t->fixed_day >= 0) return (unsigned)t->fixed_day & 0xFFFFu;
@@ -1400,10 +1552,16 @@ int apply_prologue(kv_table* v, std::initializer_list<kv_table*> slots, const fl
     if ((rc = ensure_capacity(sl, n, s))) return rc;
   if ((rc = ensure_workspace(v, n, true, s))) return rc;
   *tv = dev_view(v);
-  *wd = ws_view(v);
+  *wd = ws_view(v, n);
   *day = today(v);
-  launch_dedup<MODE_APPLY>(v, *tv, *wd, ids, nullptr, n, *day, s);
-  k_accumulate<<<(int)((n + TILE - 1) / TILE), TB, 0, s>>>(*wd, grad, n, v->dim);
+  {
+    ProfScope ps(v, KV_PROF_APPLY_DEDUP_FIND, s);
+    launch_dedup<MODE_APPLY>(v, *tv, *wd, ids, nullptr, n, *day, s);
+  }
+  {
+    ProfScope ps(v, KV_PROF_APPLY_ACCUMULATE, s);
+    launch_accumulate(*wd, grad, n, v->dim, s);
+  }
   return KV_OK;
 }
 
@@ -1464,6 +1622,7 @@ int kv_destroy(kv_handle_t t) {
   for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.freq); hipFree(c.flags); hipFree(c.keys); }
   hipFree(t->entries); hipFree(t->d_chunks); hipFree(t->d_counters); hipFree(t->d_stat);
   hipFree(t->init_table);
+  for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
   hipFree(w.skeys); hipFree(w.smeta); hipFree(w.srow); hipFree(w.sslot_of_id); hipFree(w.ukey);
   hipFree(w.urow); hipFree(w.usslot); hipFree(w.ufirst); hipFree(w.ctr); hipFree(w.gacc);
@@ -1592,15 +1751,19 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
   if ((rc = ensure_capacity(t, n, s))) return rc;
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
   const TableDev td = dev_view(t);
-  const WsDev wd = ws_view(t);
+  const WsDev wd = ws_view(t, n);
   const unsigned day = today(t);
-  launch_dedup<MODE_LOOKUP>(t, td, wd, ids, counts, n, day, s);
+  {
+    ProfScope ps(t, KV_PROF_LOOKUP_DEDUP_FIND, s);
+    launch_dedup<MODE_LOOKUP>(t, td, wd, ids, counts, n, day, s);
+  }
+  ProfScope ps_gather(t, KV_PROF_LOOKUP_GATHER, s);
   const int D = t->dim;
   const int q = (D % 4 == 0) ? D / 4 : 0;
   const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= TB;
   const long long rows_per_block = vec ? TB / q : 1;
   int gb = vec ? nblocks((n + 3) / 4, (int)rows_per_block, 4096) : nblocks(n * D, TB, 4096);
-  const int grid = FIN_BLOCKS + gb;
+  const int grid = gb;
   switch (vec ? q : 0) {
     case 1: k_gather<1><<<grid, TB, 0, s>>>(td, wd, out, n, day, gb); break;
     case 2: k_gather<2><<<grid, TB, 0, s>>>(td, wd, out, n, day, gb); break;
@@ -1668,8 +1831,11 @@ int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const
   }
   a.l21_norm = a.l21 * std::sqrt((float)v->dim);
   const TableDev ts = dev_view(mvl);
-  rc = version == 4 ? launch_apply<OPT_ADAM_V4>(tv, ts, ts, wd, grad, a, day, n, s)
-                    : launch_apply<OPT_ADAM_V3>(tv, ts, ts, wd, grad, a, day, n, s);
+  {
+    ProfScope ps(v, KV_PROF_APPLY_UPDATE, s);
+    rc = version == 4 ? launch_apply<OPT_ADAM_V4>(tv, ts, ts, wd, grad, a, day, n, s)
+                      : launch_apply<OPT_ADAM_V3>(tv, ts, ts, wd, grad, a, day, n, s);
+  }
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -1692,7 +1858,11 @@ int kv_apply_adagrad(kv_handle_t v, kv_handle_t acc, float lr, const float* grad
   OptArgs a{};
   a.lr = lr; a.update_slots = update_slots;
   const TableDev ts = dev_view(acc);
-  if ((rc = launch_apply<OPT_ADAGRAD>(tv, ts, ts, wd, grad, a, day, n, s))) return rc;
+  {
+    ProfScope ps(v, KV_PROF_APPLY_UPDATE, s);
+    rc = launch_apply<OPT_ADAGRAD>(tv, ts, ts, wd, grad, a, day, n, s);
+  }
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1723,7 +1893,11 @@ int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, 
   OptArgs a{};
   a.lr = lr; a.l1 = l1; a.l2 = l2; a.l21 = l21; a.l2s = l2s; a.lr_power = lr_power;
   a.l21_norm = l21 * std::sqrt((float)v->dim);  // :728
-  if ((rc = launch_apply<OPT_FTRL>(tv, dev_view(acc), dev_view(lin), wd, grad, a, day, n, s))) return rc;
+  {
+    ProfScope ps(v, KV_PROF_APPLY_UPDATE, s);
+    rc = launch_apply<OPT_FTRL>(tv, dev_view(acc), dev_view(lin), wd, grad, a, day, n, s);
+  }
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1741,16 +1915,52 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   hipStream_t s = (hipStream_t)stream;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
   const TableDev td = dev_view(t);
-  const WsDev wd = ws_view(t);
+  const WsDev wd = ws_view(t, n);
   launch_dedup<MODE_DEDUP>(t, td, wd, ids, nullptr, n, 0, s);
-  k_accumulate<<<(int)((n + TILE - 1) / TILE), TB, 0, s>>>(wd, grad, n, t->dim);
+  launch_accumulate(wd, grad, n, t->dim, s);
   k_dedup_emit<<<nblocks(n, TB / 8, 2048), TB, 0, s>>>(wd, grad, t->dim, (long long*)uniq, summed);
   if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
   unsigned U = 0;
   HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
   k_dedup_clean<<<nblocks(n, TB, 1024), TB, 0, s>>>(wd);
   HIP_TRY(hipStreamSynchronize(s));
-  *num_unique = U;
+  *num_unique = (int64_t)U;
+  return KV_OK;
+}
+
+int kv_profile_enable(kv_handle_t t, int max_launches) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  for (auto e : t->ev) hipEventDestroy(e);
+  t->ev.clear();
+  t->ev_kind.clear();
+  t->ev_used = 0;
+  t->prof = max_launches > 0;
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    t->ev.push_back(e);
+  }
+  t->ev_kind.assign((size_t)std::max(max_launches, 0), 0);
+  return KV_OK;
+}
+
+int kv_profile_read(kv_handle_t t, double* ms_sum, int64_t* launches, int n_kinds) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  for (int k = 0; k < n_kinds; ++k) { ms_sum[k] = 0; launches[k] = 0; }
+  for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(t->ev[i + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
+    const int k = t->ev_kind[i / 2];
+    if (k < n_kinds) { ms_sum[k] += ms; launches[k] += 1; }
+  }
+  t->ev_used = 0;
   return KV_OK;
 }
 
@@ -1800,7 +2010,7 @@ static int scatter_like(kv_handle_t t, const void* ids, const float* vals, int64
   if ((rc = ensure_capacity(t, n, s))) return rc;
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
   const TableDev td = dev_view(t);
-  const WsDev wd = ws_view(t);
+  const WsDev wd = ws_view(t, n);
   if (is_insert && !t->initialized) {
     // InsertOrUpdate never consults the init table; give new rows a defined value source
     TableDev td2 = td;
@@ -1854,7 +2064,7 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
     if ((rc = ensure_workspace(t, n_black, false, s))) return rc;
     TableDev td = dev_view(t);
     if (!t->initialized) { td.init_table = t->chunks[0].rows; td.init_rows = 1; }
-    const WsDev wd = ws_view(t);
+    const WsDev wd = ws_view(t, n_black);
     launch_dedup<MODE_SCATTER>(t, td, wd, blacklist, nullptr, n_black, 0, s);
     k_import_mark<<<nblocks(n_black, TB, 1024), TB, 0, s>>>(td, wd, 0, nullptr);
   }
@@ -1863,7 +2073,7 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
     if ((rc = ensure_workspace(t, n_freq, false, s))) return rc;
     TableDev td = dev_view(t);
     if (!t->initialized) { td.init_table = t->chunks[0].rows; td.init_rows = 1; }
-    const WsDev wd = ws_view(t);
+    const WsDev wd = ws_view(t, n_freq);
     launch_dedup<MODE_SCATTER>(t, td, wd, fkeys, nullptr, n_freq, 0, s);
     k_import_mark<<<nblocks(n_freq, TB, 1024), TB, 0, s>>>(td, wd, 1, fvals);
   }

@@ -353,3 +353,20 @@ def kv_get_meta(table_handle, indices):
 
 def kv_reserve(table_handle, capacity):
   _lib.check(_lib.lib().kv_reserve(table_handle.ptr, int(capacity)))
+
+
+PROF_KINDS = ("lookup_dedup_find", "lookup_gather", "apply_dedup_find", "apply_accumulate",
+              "apply_update")
+
+
+def kv_profile_enable(table_handle, max_launches):
+  _lib.check(_lib.lib().kv_profile_enable(table_handle.ptr, int(max_launches)))
+
+
+def kv_profile_read(table_handle):
+  """{kernel kind: (total ms, launches)} from the HIP events recorded since the last read."""
+  n = len(PROF_KINDS)
+  ms = (ctypes.c_double * n)()
+  cnt = (ctypes.c_int64 * n)()
+  _lib.check(_lib.lib().kv_profile_read(table_handle.ptr, ms, cnt, n))
+  return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
