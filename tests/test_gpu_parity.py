@@ -304,7 +304,7 @@ def test_group_adam_parity_with_regularizers_and_blacklist(ops):
     assert np.all((np.abs(got - exp) <= tol)[clear])
     gm, om = ops.kv_get_meta(hv, ids), [ov.meta(int(k)) for k in ids]
     assert all(a == b for a, b, c in zip(gm, om, clear) if c)
-    _assert_same_table(ops, hs, os_, ids, rtol=RTOL, atol=1e-12)
+    _assert_same_table(ops, hs, os_, ids, rtol=RTOL, atol=1e-10)   # z cancels towards 0
     # blacklisted keys read as zeros through both lookups, and still count frequency
     gi, oi = _np(ops.kv_variable_gather_or_insert_v2(hv, ids)), ov.gather_or_insert(ids)
     np.testing.assert_array_equal(gi, got)             # training lookup == inference lookup

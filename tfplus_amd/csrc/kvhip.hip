@@ -102,7 +102,16 @@ struct WsDev {
                                // tile: a returning atomic on one word saturates at ~88 ops/us
   unsigned* ctr_next;          // next op's counters (zeroed by this op's last kernel)
   float* gacc;                 // [n, dim] accumulators of repeated ids (kept all-zero between ops)
+  unsigned long long* dbg;     // diagnostic build only (-DKV_STAMPS): per-block phase stamps
 };
+
+// In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
+// block stores s_memtime at phase boundaries into a buffer nothing else reads.
+#ifdef KV_STAMPS
+#define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); } while (0)
+#else
+#define KV_STAMP(slot) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -256,6 +265,7 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
 
   const int tid = threadIdx.x;
   const long long base = (long long)blockIdx.x * TILE;
+  KV_STAMP(0);
 
   for (int s = tid; s <= LS; s += TB) {
     lkeys[s] = EMPTY_KEY;
@@ -297,6 +307,7 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     }
   }
   __syncthreads();
+  KV_STAMP(1);
 
   // ---- phase 2a: compact the occupied LDS slots into a work list -------------------------
   for (int s = tid; s < LS; s += TB) {
@@ -304,6 +315,7 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
   }
   if (tid == 0 && lsent) lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)LS;
   __syncthreads();
+  KV_STAMP(2);
 
   // ---- phase 2b: one lane per tile-unique key: batch scratch insert; the batch-wide first
   //      inserter owns the key.  Load before CAS: for a heavy hitter every tile but the first
@@ -340,11 +352,13 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     if (owner) lown[atomicAdd(&lnown, 1u)] = (unsigned short)s;
   }
   __syncthreads();
+  KV_STAMP(3);
 
   // ---- phase 2c: owners do the table work; dense unique index = tile base + j ---------------
   const unsigned nown = lnown;
   if (tid == 0) lubase = nown ? atomicAdd(&w.ctr[0], nown) : 0u;
   __syncthreads();
+  KV_STAMP(4);
   const unsigned ubase = lubase;
   for (unsigned j = tid; j < nown; j += TB) {
     const unsigned s = lown[j];
@@ -380,6 +394,7 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     w.srow[g] = r;
   }
   __syncthreads();
+  KV_STAMP(5);
 
   // ---- phase 3: cooperative init of the rows this tile inserted ---------------------------
   if (MODE != MODE_DEDUP) {
@@ -404,6 +419,11 @@ __global__ void __launch_bounds__(TB) k_dedup_find(TableDev t, WsDev w, const Id
     const long long i = base + (long long)k * TB + tid;
     if (i < n) w.sslot_of_id[i] = lcnt[tslot[k]];
   }
+  KV_STAMP(6);
+  if (threadIdx.x == 0) { KV_STAMP(7); }
+#ifdef KV_STAMPS
+  if (threadIdx.x == 0) { w.dbg[(size_t)blockIdx.x * 16 + 8] = lnwork; w.dbg[(size_t)blockIdx.x * 16 + 9] = lnown; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1258,6 +1278,7 @@ struct Workspace {
   unsigned* usslot = nullptr;
   unsigned* ufirst = nullptr;
   unsigned* ctr = nullptr;  // [2][8]
+  unsigned long long* dbg = nullptr;
   unsigned long long seq = 0;
   float* gacc = nullptr;
   long long gacc_elems = 0;
@@ -1425,6 +1446,10 @@ int ensure_workspace(kv_table* t, long long n, bool need_gacc, hipStream_t s) {
       HIP_TRY(hipMalloc(&w.ctr, 16 * sizeof(unsigned)));
       HIP_TRY(hipMemsetAsync(w.ctr, 0, 16 * sizeof(unsigned), s));
     }
+#ifdef KV_STAMPS
+    hipFree(w.dbg);
+    HIP_TRY(hipMalloc(&w.dbg, (size_t)(cap / TILE + 1) * 16 * sizeof(unsigned long long)));
+#endif
     w.cap_n = cap;
   }
   if (need_gacc && w.gacc_elems < w.cap_n * t->dim) {
@@ -1448,6 +1473,7 @@ WsDev ws_view(kv_table* t, long long n) {
   d.ctr = w.ctr + 8 * (w.seq & 1);
   d.ctr_next = w.ctr + 8 * ((w.seq + 1) & 1);
   d.gacc = w.gacc;
+  d.dbg = w.dbg;
   w.seq++;
   return d;
 }
@@ -1963,6 +1989,15 @@ int kv_profile_read(kv_handle_t t, double* ms_sum, int64_t* launches, int n_kind
   t->ev_used = 0;
   return KV_OK;
 }
+
+#ifdef KV_STAMPS
+int kv_debug_read_stamps(kv_handle_t t, unsigned long long* out, int64_t nblocks_) {
+  DeviceGuard dg(t->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, t->ws.dbg, (size_t)nblocks_ * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return KV_OK;
+}
+#endif
 
 int kv_export_count(kv_handle_t t, int first_n, int64_t* counts, kv_stream_t stream) {
   int rc;
