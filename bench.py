@@ -165,14 +165,24 @@ def main():
     ids = splitmix64(z.sample(N, gen))
     grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
     U = int(torch.unique(ids).numel())
-    pool.append((ids, grad, U))
+    # rows whose key occurs once inside its 1024-id tile (read by the partition pass, not the tile pass)
+    pad = (-N) % 1024
+    tiles = torch.cat([ids, torch.full((pad,), ids.min().item() - 1, device=dev, dtype=ids.dtype)]).view(-1, 1024)
+    srt = torch.sort(tiles, dim=1).values
+    eq_prev = torch.zeros_like(srt, dtype=torch.bool)
+    eq_prev[:, 1:] = srt[:, 1:] == srt[:, :-1]
+    eq_next = torch.zeros_like(srt, dtype=torch.bool)
+    eq_next[:, :-1] = eq_prev[:, 1:]
+    S = int((~(eq_prev | eq_next)).sum().item()) - (1 if pad == 1 else 0)
+    pool.append((ids, grad, U, S))
   out = torch.empty((N, D), dtype=torch.float32, device=dev)
   U_mean = float(np.mean([p[2] for p in pool]))
+  S_mean = float(np.mean([p[3] for p in pool]))
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
   def step(k):
-    ids, grad, _ = pool[k % len(pool)]
+    ids, grad = pool[k % len(pool)][:2]
     _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), stream))
     _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
                                      float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
@@ -207,20 +217,24 @@ def main():
   value = N * world / (dt / args.steps)
 
   # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch time ----
-  Ub = U_mean
-  alg = {  # SURVEY.md §8(d) per-step figures, split over the kernels of each op
-      "lookup_dedup_find": N * 8 + Ub * 16,
+  # SURVEY.md §8(d) per-step figures, split over the kernels of each op by which kernel moves the
+  # bytes: ids are read by the tile pass; a gradient row is read once, by the
+  # tile pass if its key repeats inside the 1024-id tile (in-tile fold) and by the partition pass
+  # otherwise; probes and optimizer state belong to the partition pass; rows to the gather.
+  Ub, Sb = U_mean, S_mean
+  alg = {
+      "lookup_tile": N * 8,
+      "lookup_part": Ub * 16,
       "lookup_gather": Ub * 4 * D + N * 4 * D,
-      "apply_dedup_find": N * 8 + Ub * 16,
-      "apply_accumulate": N * 4 * D,
-      "apply_update": Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,
+      "apply_tile": N * 8 + (N - Sb) * 4 * D,
+      "apply_part": Sb * 4 * D + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,
   }
   kern = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items()}
   dom = max(kern, key=lambda k: kern[k])
   achieved = alg[dom] / (kern[dom] * 1e-3) / 1e9
-  lookup_ms = kern["lookup_dedup_find"] + kern["lookup_gather"]
-  apply_ms = kern["apply_dedup_find"] + kern["apply_accumulate"] + kern["apply_update"]
-  lookup_bytes = N * 136 + Ub * 144 if D == 32 else N * (8 + 4 * D) + Ub * (16 + 4 * D)
+  lookup_ms = kern["lookup_tile"] + kern["lookup_part"] + kern["lookup_gather"]
+  apply_ms = kern["apply_tile"] + kern["apply_part"]
+  lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)
   apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D
 
   res = {
@@ -238,7 +252,7 @@ def main():
       "data": "synthetic",
       "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d, %d ids/batch Zipf(%.1f), lookup + sparse "
                              "GroupAdam apply" % (K // 1_000_000, D, N, args.zipf),
-                 "keys": K, "dim": D, "batch": N, "unique_per_batch": Ub,
+                 "keys": K, "dim": D, "batch": N, "unique_per_batch": Ub, "tile_single_rows_per_batch": Sb,
                  "parallelism": "1 table shard per GPU" if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,

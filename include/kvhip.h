@@ -176,11 +176,11 @@ int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int6
  * of hipEvents on the op's own stream (0 turns it off and frees the events).  kv_profile_read
  * (synchronous) sums the elapsed milliseconds per kernel kind since the last read.
  * For the optimizer ops the events belong to the `var` table. */
-#define KV_PROF_LOOKUP_DEDUP_FIND 0
-#define KV_PROF_LOOKUP_GATHER 1
-#define KV_PROF_APPLY_DEDUP_FIND 2
-#define KV_PROF_APPLY_ACCUMULATE 3
-#define KV_PROF_APPLY_UPDATE 4
+#define KV_PROF_LOOKUP_TILE 0   /* k_tile<LOOKUP>: tile dedup + partition sort */
+#define KV_PROF_LOOKUP_PART 1   /* k_part<LOOKUP>: find / insert / frequency */
+#define KV_PROF_LOOKUP_GATHER 2 /* k_gather */
+#define KV_PROF_APPLY_TILE 3    /* k_tile<APPLY>: dedup + in-tile gradient fold */
+#define KV_PROF_APPLY_PART 4    /* k_part<APPLY>: contribution sum + fused row update */
 #define KV_PROF_KINDS 5
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);

@@ -1,0 +1,528 @@
+// kv_device.h — device-side types and helpers of libkvhip (included by kvhip.hip only).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// constants
+// ------------------------------------------------------------------------------------------
+constexpr long long EMPTY_KEY = (long long)0x8000000000000000ULL;
+constexpr unsigned FLAG_BLACK = 1u;   // EmbeddingValue::in_black_   (embedding_value.h:225)
+constexpr unsigned FLAG_UNDER = 2u;   // EmbeddingValue::under_threshold_
+constexpr float CUTOFF = 1.0e-20f;    // DEFAULT_CUTOFF_VALUE (kv_variable_interface.h:55)
+constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < enter_threshold
+constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
+constexpr unsigned PART_BIT = 0x80000000u;      // gradient locator: partial-sum row, not an input row
+
+constexpr int TB = 256;          // threads per block of the tile / gather kernels
+constexpr int IPT = 4;           // ids per thread in the tile kernel
+constexpr int TILE = TB * IPT;   // ids per tile (1024)
+constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
+constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
+constexpr int HOT_MIN = 32;      // rows of one key in one tile above which the whole block folds it
+constexpr int MAX_P = 1024;      // partitions (power of two)
+constexpr int TBP = 512;         // threads per block of the partition kernel
+constexpr int CAPB = 1536;       // entries a partition block holds in LDS per round
+constexpr int HS = 4096;         // its LDS hash slots
+constexpr int HEAVY = 32;        // entries of one key in one partition above which the block folds it
+constexpr int MAX_CHUNKS = 1024;
+
+enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4 };
+enum Opt { OPT_ADAM_V4 = 0, OPT_ADAM_V3 = 1, OPT_ADAGRAD = 2, OPT_FTRL = 3 };
+
+struct __attribute__((aligned(16))) Entry {
+  long long key;
+  unsigned row;
+  unsigned pad;
+};
+
+struct Chunk {
+  float* rows;
+  unsigned* freq;
+  unsigned char* flags;
+  long long* keys;
+};
+
+// device view of one table; passed to kernels by value
+struct TableDev {
+  Entry* entries;
+  unsigned long long mask;  // cap - 1; entries[cap] = sentinel-key home
+  Chunk* chunks;
+  int chunk_bits;
+  unsigned* counters;  // [0] next_row  [1] error flag (row overflow)
+  unsigned max_rows;
+  const float* init_table;
+  unsigned init_rows;
+  int dim;
+  unsigned enter_threshold;
+  unsigned long long seed;
+};
+
+// device view of the per-batch workspace (kv_kernels.h explains the pipeline)
+struct WsDev {
+  long long* ent_key;      // [ntiles * TILE] tile t's deduplicated entries, sorted by partition
+  unsigned* ent_a;         // lookup: saturating count of the key in the tile; else: one input
+                           // position of the key in the tile
+  unsigned* ent_b;         // apply / dedup: gradient locator of the tile's contribution (an input
+                           // position, or PART_BIT | partial-sum row).  OUT of the partition pass:
+                           // lookup -> var row id of the key; dedup -> dense unique index
+  unsigned short* toff;    // [ntiles][P + 1] partition boundaries inside each tile's entry list
+  unsigned* slot_of_id;    // [n] entry index of every input position
+  float* part;             // [ntiles * PARTCAP][dim] per-tile partial gradient sums
+  unsigned* ctr;           // [8] op counters ([0]: kv_dedup_segment_sum's unique count); host-zeroed
+  unsigned ntiles, P;
+  int pshift;              // 64 - log2(P)
+  unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
+};
+
+// In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
+// block stores s_memtime at phase boundaries into a buffer nothing else reads.
+#ifdef KV_STAMPS
+#define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); } while (0)
+#else
+#define KV_STAMP(slot) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+// same picker as oracle/kv_oracle.cc (splitmix64 finaliser) — see kv_set_seed
+__device__ __forceinline__ unsigned long long pick64(unsigned long long x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+__device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
+  const Chunk& c = t.chunks[r >> t.chunk_bits];
+  return c.rows + (size_t)(r & ((1u << t.chunk_bits) - 1)) * t.dim;
+}
+__device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) {
+  return t.chunks[r >> t.chunk_bits].freq + (r & ((1u << t.chunk_bits) - 1));
+}
+__device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) {
+  return t.chunks[r >> t.chunk_bits].flags + (r & ((1u << t.chunk_bits) - 1));
+}
+__device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) {
+  return t.chunks[r >> t.chunk_bits].keys + (r & ((1u << t.chunk_bits) - 1));
+}
+
+__device__ __forceinline__ Entry load_entry(const Entry* e) {
+  const uint4 v = *reinterpret_cast<const uint4*>(e);
+  Entry r;
+  r.key = (long long)(((unsigned long long)v.y << 32) | v.x);
+  r.row = v.z;
+  r.pad = v.w;
+  return r;
+}
+
+// read-only probe; 0 = absent (row 0 is the zero row)
+__device__ __forceinline__ unsigned table_find(const TableDev& t, long long key) {
+  if (key == EMPTY_KEY) {
+    Entry e = load_entry(&t.entries[t.mask + 1]);
+    return e.key == 0 ? e.row : 0u;
+  }
+  unsigned long long p = mix64((unsigned long long)key) & t.mask;
+  for (;;) {
+    Entry e = load_entry(&t.entries[p]);
+    if (e.key == key) return e.row;
+    if (e.key == EMPTY_KEY) return 0u;
+    p = (p + 1) & t.mask;
+  }
+}
+
+// Find or insert.  The caller is the ONLY lane of the launch that handles `key` (batch
+// dedup guarantees it), so a freshly claimed entry is never read by anyone else before the
+// kernel ends; other keys racing for the same empty entry are settled by the 64-bit CAS.
+// Returns the row id; *inserted tells whether it was allocated now.  Returns 0 and raises
+// counters[1] when the slab is full (the host pre-sizes, so this is a bug trap).
+__device__ __forceinline__ unsigned table_find_or_insert(const TableDev& t, long long key,
+                                                        bool* inserted) {
+  *inserted = false;
+  Entry* slot;
+  long long stored;
+  if (key == EMPTY_KEY) {
+    slot = &t.entries[t.mask + 1];
+    stored = 0;  // the sentinel's home holds 0 when occupied
+    Entry e = load_entry(slot);
+    if (e.key == stored) return e.row;
+  } else {
+    stored = key;
+    unsigned long long p = mix64((unsigned long long)key) & t.mask;
+    for (;;) {
+      slot = &t.entries[p];
+      Entry e = load_entry(slot);
+      if (e.key == key) return e.row;
+      if (e.key == EMPTY_KEY) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slot->key),
+                                           (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (old == (unsigned long long)EMPTY_KEY) goto claimed;
+        // another key took it between our load and the CAS: keep probing
+      }
+      p = (p + 1) & t.mask;
+    }
+  }
+  {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slot->key),
+                                       (unsigned long long)EMPTY_KEY, (unsigned long long)stored);
+    if (old != (unsigned long long)EMPTY_KEY) return load_entry(slot).row;  // cannot happen (single owner)
+  }
+claimed:
+  unsigned r = atomicAdd(&t.counters[0], 1u);
+  if (r >= t.max_rows) {
+    atomicExch(&t.counters[1], 1u);
+    slot->row = 0;
+    return 0u;
+  }
+  slot->row = r;
+  *key_ptr(t, r) = key;
+  *inserted = true;
+  return r;
+}
+
+// kv_variable.h:889-898 GenerateRandomInitialValue: row = 0.5 * (T[r1] + T[r2]).  The
+// reference draws r1, r2 from std::rand(); here they are a hash of (key, seed) so a run is
+// reproducible.  Executed by `lanes` cooperating lanes (lane = 0..lanes-1).  Returns
+// whether this lane saw any |x| >= CUTOFF.
+__device__ __forceinline__ bool init_row_coop(const TableDev& t, long long key, float* dst,
+                                              int lane, int lanes) {
+  unsigned long long h = pick64((unsigned long long)key ^ (t.seed * 0x9E3779B97F4A7C15ULL));
+  const float* a = t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim;
+  const float* b = t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim;
+  bool big = false;
+  for (int e = lane; e < t.dim; e += lanes) {
+    float v = (a[e] + b[e]) * 0.5f;
+    dst[e] = v;
+    big |= fabsf(v) >= CUTOFF;
+  }
+  return big;
+}
+
+// partition that owns a key (top bits of the hash; table probes use the low bits)
+__device__ __forceinline__ unsigned part_of(long long key, int pshift) {
+  return pshift >= 64 ? 0u : (unsigned)(mix64((unsigned long long)key) >> pshift);
+}
+
+// exclusive scan of one value per thread across the block (NW = waves per block);
+// wtot: LDS scratch [NW + 1]; returns the exclusive prefix, *total = block sum.
+template <int NW>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* wtot, unsigned* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  __syncthreads();  // wtot may still be read from a previous scan
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const unsigned x = wtot[i];
+    if (i < wv) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+template <typename IdT>
+__device__ __forceinline__ long long load_id(const IdT* ids, size_t i) {
+  return (long long)ids[i];
+}
+
+
+struct OptArgs {
+  float lr, b1p, b2p, b1, b2, eps, l1, l2, l21, l2s, lr_power;
+  float alpha, l21_norm;  // host-precomputed in fp32 exactly as the reference does
+  int update_slots;
+};
+
+// optimizer-side slot-table access: FindOrInsertUnsafe(filter_out == nullptr), kv_variable.h:382-416.
+// Called by the group leader only.  New rows get freq word 1 (day 0); hits AddFrequency(1, today).
+__device__ __forceinline__ unsigned slot_find_or_insert(const TableDev& t, long long key,
+                                                       unsigned day, bool* inserted) {
+  unsigned r = table_find_or_insert(t, key, inserted);
+  if (r == 0) return 0;
+  unsigned* fp = freq_ptr(t, r);
+  if (*inserted) {
+    *fp = 1u;
+  } else {
+    unsigned lo = (*fp & 0xFFFFu) + 1u;
+    if (lo > 65535u) lo = 65535u;
+    *fp = (day << 16) | lo;
+  }
+  return r;
+}
+
+// V-wide row access (V = 4: one 16-byte access per lane; V = 1: scalar)
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
+  if (V == 4) {
+    const float4 t4 = *reinterpret_cast<const float4*>(p);
+    o[0] = t4.x; o[1 % V] = t4.y; o[2 % V] = t4.z; o[3 % V] = t4.w;
+  } else {
+    o[0] = p[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
+  if (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1 % V], o[2 % V], o[3 % V]);
+  } else {
+    p[0] = o[0];
+  }
+}
+// slot row element block: existing row, or the init rule 0.5 * (T[r1] + T[r2]) for a new key
+template <int V>
+__device__ __forceinline__ void ldslot(const float* row, const float* ia, const float* ib, bool isnew,
+                                       int e, float (&o)[V]) {
+  if (isnew) {
+    float a[V], b[V];
+    ldv<V>(ia + e, a);
+    ldv<V>(ib + e, b);
+#pragma unroll
+    for (int c = 0; c < V; ++c) o[c] = (a[c] + b[c]) * 0.5f;
+  } else {
+    ldv<V>(row + e, o);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ bool group_any(bool p) {
+  const unsigned long long m = __ballot(p);
+  if (W >= 64) return m != 0;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long gm = (W >= 64) ? ~0ull : ((1ull << W) - 1ull);
+  return ((m >> (lane & ~(W - 1))) & gm) != 0;
+}
+
+
+// One unique key's fused optimizer update, executed by LPR cooperating lanes (lane = 0..LPR-1).
+// `tag` = var row id | ROW_FILTERED; gv = the key's summed gradient, element e at lane
+// (e / V) % LPR, step (e / V) / LPR.  All LPR lanes of every group in the wave must call it
+// (shuffles inside); `live` masks groups without a key.
+// Restates the per-id body of KvVariableGroupSparseApplyAdamV4Op / V3Op / SparseApplyAdagradOp /
+// SparseGroupSparseApplyFtrlOp (training_ops.cc:7142-7197, 5871-5927, 1455-1486, 684-763).
+template <int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDev& ts0,
+                                               const TableDev& ts1, long long key, unsigned tag,
+                                               bool live, const float (&gv)[K][V], const OptArgs& a,
+                                               unsigned day, int lane) {
+  const int D = tv.dim;
+  const bool skip = !live || (tag & ROW_FILTERED) || (tag & ROW_MASK) == 0u;  // training_ops.cc:7150-7152
+  const unsigned rv = tag & ROW_MASK;
+
+  // slot tables (leader probes, group shares the row id)
+  unsigned r0 = 0, r1 = 0;
+  bool new0 = false, new1 = false;
+  if (!skip && lane == 0) {
+    // FTRL probes linear (ts1) before accum (ts0): training_ops.cc:701-704
+    if (OPT == OPT_FTRL) r1 = slot_find_or_insert(ts1, key, day, &new1);
+    r0 = slot_find_or_insert(ts0, key, day, &new0);
+  }
+  r0 = __shfl(r0, 0, LPR);
+  new0 = __shfl((int)new0, 0, LPR) != 0;
+  if (OPT == OPT_FTRL) {
+    r1 = __shfl(r1, 0, LPR);
+    new1 = __shfl((int)new1, 0, LPR) != 0;
+  }
+  const bool act = !skip && r0 != 0 && (OPT != OPT_FTRL || r1 != 0);
+
+  float* xrow = row_ptr(tv, act ? rv : 0u);
+  float* s0row = row_ptr(ts0, act ? r0 : 0u);
+  float* s1row = (OPT == OPT_FTRL) ? row_ptr(ts1, act ? r1 : 0u) : nullptr;
+
+  // new slot rows are initialised in registers with the slot table's init rule
+  const float *ia0 = nullptr, *ib0 = nullptr, *ia1 = nullptr, *ib1 = nullptr;
+  if (act && new0) {
+    unsigned long long h = pick64((unsigned long long)key ^ (ts0.seed * 0x9E3779B97F4A7C15ULL));
+    ia0 = ts0.init_table + (size_t)((unsigned)h % ts0.init_rows) * ts0.dim;
+    ib0 = ts0.init_table + (size_t)((unsigned)(h >> 32) % ts0.init_rows) * ts0.dim;
+  }
+  if (OPT == OPT_FTRL && act && new1) {
+    unsigned long long h = pick64((unsigned long long)key ^ (ts1.seed * 0x9E3779B97F4A7C15ULL));
+    ia1 = ts1.init_table + (size_t)((unsigned)h % ts1.init_rows) * ts1.dim;
+    ib1 = ts1.init_table + (size_t)((unsigned)(h >> 32) % ts1.init_rows) * ts1.dim;
+  }
+  if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) {
+    // training_ops.cc:7166-7195 (V4) / :5895-5925 (V3); slot row = [m | v | z]
+    float m[K][V], nv[K][V], sq[K][V], z[K][V], uu[K][V];
+    float part = 0.f;
+    const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      float xo[V], mo[V], vo[V], zo[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) xo[c] = mo[c] = vo[c] = zo[c] = 0.f;
+      const bool valid = act && e0 < D;
+      if (valid) {
+        ldv<V>(xrow + e0, xo);
+        ldslot<V>(s0row, ia0, ib0, new0, e0, mo);
+        ldslot<V>(s0row, ia0, ib0, new0, e0 + D, vo);
+        ldslot<V>(s0row, ia0, ib0, new0, e0 + 2 * D, zo);
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const float gg = gv[k][c];
+        const float mn = a.b1 * mo[c] + omb1 * gg;
+        const float vn = a.b2 * vo[c] + omb2 * (gg * gg);
+        const float s = sqrtf(vn);
+        float d;
+        if (OPT == OPT_ADAM_V4) {
+          d = (a.b1 > a.b1p) ? (s - sqrtf(vo[c])) * xo[c] : (s + a.eps) * xo[c];
+        } else {
+          d = (a.b1 > a.b1p) ? (s - sqrtf(vo[c])) / a.lr * xo[c]
+                             : (s - sqrtf(vo[c]) + a.eps) / a.lr * xo[c];
+        }
+        const float zn = zo[c] + (a.alpha * mn - d);
+        const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
+        const float uv = adj - zn;
+        m[k][c] = mn; nv[k][c] = vn; sq[k][c] = s; z[k][c] = zn; uu[k][c] = uv;
+        if (valid) part += uv * uv;
+      }
+    }
+    const float norm = sqrtf(group_sum<LPR>(part));
+    const bool upd = norm > a.l21_norm;
+    const float scale = 1.f - a.l21_norm / norm;
+    const float two_l2 = 2.f * a.l2;
+    bool big = false, sbig = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (act && e0 < D) {
+        float xn[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          xn[c] = 0.f;  // blacklist: the row reads as zeros (table_manager.h:335-357)
+          if (upd) {
+            const float y = (OPT == OPT_ADAM_V4) ? (sq[k][c] + a.eps) + two_l2
+                                                 : (sq[k][c] + a.eps) / a.lr + two_l2;
+            xn[c] = uu[k][c] * scale / y;
+          }
+          big |= fabsf(xn[c]) >= CUTOFF;
+          sbig |= fabsf(m[k][c]) >= CUTOFF || fabsf(nv[k][c]) >= CUTOFF || fabsf(z[k][c]) >= CUTOFF;
+        }
+        stv<V>(xrow + e0, xn);
+        stv<V>(s0row + e0, m[k]);
+        stv<V>(s0row + e0 + D, nv[k]);
+        stv<V>(s0row + e0 + 2 * D, z[k]);
+      }
+    }
+    const bool anyx = group_any<LPR>(big), anys = group_any<LPR>(sbig);
+    if (act && lane == 0) {
+      // CoverUpdateUnsafe -> UpdateUnderThreshold, or MarkBlacklistUnsafe (:7187-7195)
+      *flags_ptr(tv, rv) = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
+      *flags_ptr(ts0, r0) = (unsigned char)(anys ? 0u : FLAG_UNDER);
+    }
+  } else if (OPT == OPT_ADAGRAD) {
+    // training_ops.cc:1470-1482.  No CoverUpdate: flags of existing rows are left alone.
+    bool sbig = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (act && e0 < D) {
+        float xo[V], acc[V];
+        ldv<V>(xrow + e0, xo);
+        ldslot<V>(s0row, ia0, ib0, new0, e0, acc);
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          const float gg = gv[k][c];
+          sbig |= fabsf(acc[c]) >= CUTOFF;
+          if (a.update_slots) acc[c] = acc[c] + gg * gg;
+          xo[c] = (D > 1) ? xo[c] - (a.lr * gg) * (1.f / sqrtf(acc[c]))
+                          : xo[c] - (a.lr * gg) / sqrtf(acc[c]);
+        }
+        stv<V>(xrow + e0, xo);
+        stv<V>(s0row + e0, acc);
+      }
+    }
+    const bool anys = group_any<LPR>(sbig);
+    if (act && new0 && lane == 0) *flags_ptr(ts0, r0) = (unsigned char)(anys ? 0u : FLAG_UNDER);
+  } else {
+    // OPT_FTRL: training_ops.cc:713-751 with has_l2_shrinkage; ts0 = accum, ts1 = linear
+    float x[K][V], ac[K][V], z[K][V], uu[K][V];
+    float part = 0.f;
+    const bool half = a.lr_power == -0.5f;
+    const float two_l2s = 2.f * a.l2s;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      float zo[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) x[k][c] = ac[k][c] = zo[c] = 0.f;
+      const bool valid = act && e0 < D;
+      if (valid) {
+        ldv<V>(xrow + e0, x[k]);
+        ldslot<V>(s0row, ia0, ib0, new0, e0, ac[k]);
+        ldslot<V>(s1row, ia1, ib1, new1, e0, zo);
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const float xo = x[k][c], ao = ac[k][c];
+        const float gs = gv[k][c] + two_l2s * xo;
+        const float na = ao + gs * gs;
+        const float pn = half ? sqrtf(na) : powf(na, -a.lr_power);
+        const float po = half ? sqrtf(ao) : powf(ao, -a.lr_power);
+        const float zn = zo[c] + (gs - (pn - po) / a.lr * xo);
+        const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
+        const float uv = adj - zn;
+        z[k][c] = zn; uu[k][c] = uv;
+        if (valid) part += uv * uv;
+      }
+    }
+    const float norm = sqrtf(group_sum<LPR>(part));
+    const bool upd = norm > a.l21_norm;
+    const float scale = 1.f - (a.l21_norm / norm);
+    const float two_l2 = 2.f * a.l2;
+    bool big = false, abig = false, zbig = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (act && e0 < D) {
+        float xn[V], an[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          const float xo = x[k][c];
+          const float gs = gv[k][c] + two_l2s * xo;
+          const float na = ac[k][c] + gs * gs;
+          const float pn = half ? sqrtf(na) : powf(na, -a.lr_power);
+          xn[c] = 0.f;
+          if (upd) xn[c] = uu[k][c] * scale / (pn / a.lr + two_l2);
+          // accum += grad_to_use.square() re-evaluates the lazy expression with the updated
+          // var (:747); on the blacklist branch the reference reads a freed row — we keep
+          // the pre-blacklist value like oracle/kv_oracle.cc
+          const float xa = upd ? xn[c] : xo;
+          const float gs2 = gv[k][c] + two_l2s * xa;
+          an[c] = ac[k][c] + gs2 * gs2;
+          big |= fabsf(xn[c]) >= CUTOFF;
+          abig |= fabsf(an[c]) >= CUTOFF;
+          zbig |= fabsf(z[k][c]) >= CUTOFF;
+        }
+        stv<V>(xrow + e0, xn);
+        stv<V>(s0row + e0, an);
+        stv<V>(s1row + e0, z[k]);
+      }
+    }
+    const bool anyx = group_any<LPR>(big), anya = group_any<LPR>(abig), anyz = group_any<LPR>(zbig);
+    if (act && lane == 0) {
+      *flags_ptr(tv, rv) = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
+      *flags_ptr(ts0, r0) = (unsigned char)(anya ? 0u : FLAG_UNDER);
+      *flags_ptr(ts1, r1) = (unsigned char)(anyz ? 0u : FLAG_UNDER);
+    }
+  }
+}

@@ -1,0 +1,877 @@
+// kv_kernels.h — the batch pipeline (included by kvhip.hip only).
+//
+// Why this shape.  The first version de-duplicated a batch through a global scratch hash with
+// atomics.  On MI355X a returning or non-returning device-scope atomic on ONE address costs
+// ~40 ns and same-address atomics serialise; a Zipf(1.2) batch of 1M ids has ~100 keys that
+// occur in (nearly) every 1024-id tile, so each of those addresses took ~1000 serial atomics
+// (in-kernel stamps: 73 % of the dedup kernel).  fp32 atomic accumulation of gradient rows hit
+// the same wall.  This pipeline has NO global atomics on the data path:
+//
+//   k_tile  one block per 1024 input positions: LDS hash dedup of the tile; the tile's unique
+//           keys ("entries") are counting-sorted by the key's hash partition and written with
+//           plain coalesced stores (ent_*), with the partition boundaries in toff[tile][0..P].
+//           Optimizer ops also fold the gradient rows of keys that repeat inside the tile into
+//           one partial-sum row (registers; whole block for tile-hot keys).
+//   k_part  one block per partition p: gathers partition p's entries from EVERY tile, so it sees
+//           all occurrences of its keys: exact counts, exclusive ownership of the table rows
+//           (find / insert / frequency / flags), and for optimizer ops the sum of the per-tile
+//           contributions in registers followed by the fused row update.  Results that input
+//           positions need (row ids) are written back per entry.
+//   k_gather  out[i] = rows[ent_b[slot_of_id[i]]], 16 bytes per lane.
+//
+// Summation order of repeated ids is deterministic (tile order inside a partition, sorted-run
+// order inside a tile up to the LDS-atomic rank; no float atomics in global memory).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// k_tile
+// ------------------------------------------------------------------------------------------
+// MODE_LOOKUP : ent_a = min(sum of per-occurrence counts, 65535)     (kv_variable.h:320-350)
+// others      : ent_a = one input position of the key in the tile;
+//   MODE_APPLY / MODE_DEDUP additionally ent_b = gradient locator, VPL = float4 per lane per row
+//   (8 lanes per row; VPL = 0 -> scalar lanes for dims that are not multiples of 4)
+struct TileSmem {
+  long long* lkeys;        // [LS + 1]   (slot LS: the key that equals EMPTY_KEY)
+  unsigned* lcnt;          // [LS + 1]
+  unsigned* lfirst;        // [LS + 1]   (not MODE_LOOKUP) later: sorted-row offset of the key
+  unsigned short* lpos;    // [LS + 1]   entry position of the slot's key
+  unsigned short* lwork;   // [TILE + 1] occupied slots
+  unsigned* hist;          // [MAX_P + 1]
+  unsigned* wtot;          // [8]
+  unsigned short* lpart;   // [LS + 1]   partial row of the slot's key (apply / dedup)
+  // aliases of lkeys, valid after the entries are written:
+  unsigned short* perm;    // [TILE]     tile rows grouped by key
+  unsigned short* mlist;   // [PARTCAP]  partial row -> slot
+  float* red;              // [TB / 8][dim] block fold scratch
+};
+
+__host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
+  size_t b = (size_t)(LS + 1) * 8 + 16;        // lkeys
+  b += (size_t)(LS + 1) * 4 + 16;              // lcnt
+  b += (size_t)(LS + 1) * 2 + 16;              // lpos
+  b += (size_t)(TILE + 1) * 2 + 16;            // lwork
+  b += (size_t)(MAX_P + 1) * 4 + 16;           // hist
+  b += 64;                                     // wtot
+  if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 4 + 16;  // lfirst
+  if (mode == MODE_APPLY || mode == MODE_DEDUP) {
+    b += (size_t)(LS + 1) * 2 + 16;            // lpart
+    const size_t alias = (size_t)TILE * 2 + (size_t)PARTCAP * 2 + (size_t)(TB / 8) * D * 4 + 64;
+    const size_t lk = (size_t)(LS + 1) * 8 + 16;
+    if (alias > lk) b += alias - lk;           // big dims: the fold scratch outgrows lkeys
+  }
+  return b;
+}
+
+template <int MODE>
+__device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
+  TileSmem s;
+  auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
+  char* lk = take((size_t)(LS + 1) * 8);
+  s.lkeys = reinterpret_cast<long long*>(lk);
+  if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
+    const size_t alias = (size_t)TILE * 2 + (size_t)PARTCAP * 2 + (size_t)(TB / 8) * D * 4 + 64;
+    const size_t lkb = ((size_t)(LS + 1) * 8 + 15) & ~(size_t)15;
+    if (alias > lkb) take(alias - lkb);
+    s.perm = reinterpret_cast<unsigned short*>(lk);
+    s.mlist = reinterpret_cast<unsigned short*>(lk + (size_t)TILE * 2);
+    s.red = reinterpret_cast<float*>(lk + (size_t)TILE * 2 + (size_t)PARTCAP * 2 + 32);
+  } else {
+    s.perm = nullptr; s.mlist = nullptr; s.red = nullptr;
+  }
+  s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
+  s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
+  s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
+  s.wtot = reinterpret_cast<unsigned*>(take(64));
+  s.lfirst = (MODE != MODE_LOOKUP) ? reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4)) : nullptr;
+  s.lpart = (MODE == MODE_APPLY || MODE == MODE_DEDUP)
+                ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
+  return s;
+}
+
+// fold rows [e0, e1) of the tile's sorted row list into acc (8 lanes per row, lane8 = 0..7)
+template <int VPL>
+__device__ __forceinline__ void fold_rows(const float* __restrict__ grad, long long base, int D,
+                                          const unsigned short* perm, unsigned e0, unsigned e1,
+                                          int lane8, float4 (&acc)[VPL > 0 ? VPL : 1]) {
+  constexpr int RB = VPL > 0 ? (8 / VPL > 0 ? 8 / VPL : 1) : 1;  // rows loaded together
+  const int NV = D >> 2;
+  for (unsigned eb = e0; eb < e1; eb += RB) {
+    float4 val[RB][VPL > 0 ? VPL : 1];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const unsigned e = eb + r;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < e1) {
+        const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + perm[e]) * D);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int q = lane8 + 8 * v;
+          if (q < NV) val[r][v] = g4[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
+        acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
+      }
+    }
+  }
+}
+
+template <int MODE, typename IdT, int VPL>
+__global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ ids,
+                                             const int* __restrict__ counts,
+                                             const float* __restrict__ grad, long long n, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  TileSmem sm = carve_tile<MODE>(smem_raw, D);
+  __shared__ unsigned lnwork, lsent, lnpart;
+
+  const int tid = threadIdx.x;
+  const unsigned tile = blockIdx.x;
+  const long long base = (long long)tile * TILE;
+  const unsigned P = w.P;
+  KV_STAMP(0);
+
+  for (int s = tid; s <= LS; s += TB) {
+    sm.lkeys[s] = EMPTY_KEY;
+    sm.lcnt[s] = 0;
+  }
+  for (unsigned p = tid; p <= P; p += TB) sm.hist[p] = 0;
+  if (tid == 0) { lnwork = 0; lsent = 0; lnpart = 0; }
+  __syncthreads();
+
+  // ---- phase 1: LDS hash insert of this tile's ids --------------------------------------
+  unsigned tslot[IPT], myrank[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const long long i = base + (long long)k * TB + tid;
+    tslot[k] = 0xFFFFFFFFu;
+    myrank[k] = 0;
+    if (i < n) {
+      const long long key = load_id(ids, (size_t)i);
+      unsigned c = 1;
+      if (MODE == MODE_LOOKUP && counts != nullptr) {
+        // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
+        const int ci = counts[i];
+        c = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      }
+      unsigned h;
+      if (key == EMPTY_KEY) {
+        h = LS;
+        if (atomicCAS(&lsent, 0u, 1u) == 0u && MODE != MODE_LOOKUP) sm.lfirst[LS] = (unsigned)i;
+      } else {
+        h = (unsigned)(mix64((unsigned long long)key) >> 40) & (LS - 1);
+        for (;;) {
+          const unsigned long long old =
+              atomicCAS(reinterpret_cast<unsigned long long*>(&sm.lkeys[h]),
+                        (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+          if (old == (unsigned long long)EMPTY_KEY) {
+            if (MODE != MODE_LOOKUP) sm.lfirst[h] = (unsigned)i;
+            break;
+          }
+          if (old == (unsigned long long)key) break;
+          h = (h + 1) & (LS - 1);
+        }
+      }
+      myrank[k] = atomicAdd(&sm.lcnt[h], c);
+      tslot[k] = h;
+    }
+  }
+  __syncthreads();
+  KV_STAMP(1);
+
+  // ---- phase 2: compact the occupied slots into a work list ------------------------------
+  for (int s = tid; s < LS; s += TB)
+    if (sm.lkeys[s] != EMPTY_KEY) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)s;
+  if (tid == 0 && lsent) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)LS;
+  __syncthreads();
+  const unsigned nwork = lnwork;
+
+  // ---- phase 3: counting sort of the tile's unique keys by owning partition ---------------
+  constexpr int WPT = (TILE + 1 + TB - 1) / TB;  // work items per thread (5)
+  unsigned wp[WPT], wr[WPT];
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    const unsigned wi = tid + q * TB;
+    wp[q] = 0; wr[q] = 0;
+    if (wi < nwork) {
+      const unsigned s = sm.lwork[wi];
+      const long long key = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
+      wp[q] = part_of(key, w.pshift);
+      wr[q] = atomicAdd(&sm.hist[wp[q]], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned per = (P + TB - 1) / TB;
+    const unsigned p0 = tid * per, p1 = min(p0 + per, P);
+    unsigned sum = 0;
+    for (unsigned p = p0; p < p1; ++p) sum += sm.hist[p];
+    unsigned tot;
+    unsigned run = block_excl_scan<TB / 64>(sum, sm.wtot, &tot);
+    for (unsigned p = p0; p < p1; ++p) { const unsigned c = sm.hist[p]; sm.hist[p] = run; run += c; }
+    if (tid == 0) sm.hist[P] = nwork;
+  }
+  __syncthreads();
+  unsigned short* toff = w.toff + (size_t)tile * (P + 1);
+  for (unsigned p = tid; p <= P; p += TB) toff[p] = (unsigned short)sm.hist[p];
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    const unsigned wi = tid + q * TB;
+    if (wi < nwork) {
+      const unsigned s = sm.lwork[wi];
+      const long long key = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
+      const unsigned pos = sm.hist[wp[q]] + wr[q];
+      const size_t e = (size_t)tile * TILE + pos;
+      sm.lpos[s] = (unsigned short)pos;
+      w.ent_key[e] = key;
+      if (MODE == MODE_LOOKUP) {
+        const unsigned c = sm.lcnt[s];
+        w.ent_a[e] = c > 65535u ? 65535u : c;  // saturating add is order independent: clamp early
+      } else {
+        w.ent_a[e] = sm.lfirst[s];
+        if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
+          if (sm.lcnt[s] >= 2u) {
+            const unsigned k = atomicAdd(&lnpart, 1u);
+            sm.lpart[s] = (unsigned short)k;
+            w.ent_b[e] = PART_BIT | (tile * PARTCAP + k);
+          } else {
+            sm.lpart[s] = 0xFFFFu;
+            w.ent_b[e] = sm.lfirst[s];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  KV_STAMP(2);
+
+  // ---- phase 4: every input position learns its key's entry -------------------------------
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const long long i = base + (long long)k * TB + tid;
+    if (i < n) w.slot_of_id[i] = tile * TILE + sm.lpos[tslot[k]];
+  }
+  KV_STAMP(3);
+
+  // ---- phase 5 (optimizer ops): fold the rows of keys that repeat inside the tile ---------
+  if constexpr (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
+    // offsets of the multi-row keys in the sorted row list (lfirst is free now)
+    {
+      constexpr int PER = (LS + 1 + TB - 1) / TB;  // 9
+      unsigned c[PER];
+      unsigned sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int s = tid * PER + q;
+        c[q] = (s <= LS && sm.lcnt[s] >= 2u) ? sm.lcnt[s] : 0u;
+        sum += c[q];
+      }
+      unsigned tot;
+      unsigned run = block_excl_scan<TB / 64>(sum, sm.wtot, &tot);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int s = tid * PER + q;
+        if (s <= LS) { sm.lfirst[s] = run; run += c[q]; }
+      }
+      (void)tot;
+    }
+    __syncthreads();  // lkeys is dead from here on: perm / mlist / red alias it
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      if (tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] >= 2u)
+        sm.perm[sm.lfirst[tslot[k]] + myrank[k]] = (unsigned short)(k * TB + tid);
+    }
+    for (int s = tid; s <= LS; s += TB)
+      if (sm.lcnt[s] >= 2u) sm.mlist[sm.lpart[s]] = (unsigned short)s;
+    __syncthreads();
+    const unsigned npart = lnpart;
+    const int lane8 = tid & 7;
+    const int grp = tid >> 3;
+    float* prow0 = w.part + (size_t)tile * PARTCAP * D;
+    if constexpr (VPL > 0) {
+      const int NV = D >> 2;
+      // keys with few rows: one 8-lane group folds all of them, one plain store
+      for (unsigned k = grp; k < npart; k += TB / 8) {
+        const unsigned s = sm.mlist[k];
+        const unsigned cnt = sm.lcnt[s];
+        if (cnt > (unsigned)HOT_MIN) continue;
+        float4 acc[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        fold_rows<VPL>(grad, base, D, sm.perm, sm.lfirst[s], sm.lfirst[s] + cnt, lane8, acc);
+        float4* dst = reinterpret_cast<float4*>(prow0 + (size_t)k * D);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int q = lane8 + 8 * v;
+          if (q < NV) dst[q] = acc[v];
+        }
+      }
+      // tile-hot keys: every group folds a slice, the slices meet in LDS (no atomics)
+      for (unsigned k = 0; k < npart; ++k) {
+        const unsigned s = sm.mlist[k];
+        const unsigned cnt = sm.lcnt[s];
+        if (cnt <= (unsigned)HOT_MIN) continue;  // block-uniform
+        const unsigned per = (cnt + TB / 8 - 1) / (TB / 8);
+        const unsigned e0 = sm.lfirst[s] + min(cnt, grp * per), e1 = sm.lfirst[s] + min(cnt, (grp + 1) * per);
+        float4 acc[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        fold_rows<VPL>(grad, base, D, sm.perm, e0, e1, lane8, acc);
+        float4* rd = reinterpret_cast<float4*>(sm.red + (size_t)grp * D);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int q = lane8 + 8 * v;
+          if (q < NV) rd[q] = acc[v];
+        }
+        __syncthreads();
+        for (int e = tid; e < D; e += TB) {
+          float sum = 0.f;
+          for (int g2 = 0; g2 < TB / 8; ++g2) sum += sm.red[(size_t)g2 * D + e];
+          prow0[(size_t)k * D + e] = sum;
+        }
+        __syncthreads();
+      }
+    } else {
+      // any dim: one thread per element, rows in sorted order
+      for (unsigned k = 0; k < npart; ++k) {
+        const unsigned s = sm.mlist[k];
+        const unsigned cnt = sm.lcnt[s], o = sm.lfirst[s];
+        for (int e = tid; e < D; e += TB) {
+          float sum = 0.f;
+          for (unsigned r = 0; r < cnt; ++r) sum += grad[(size_t)(base + sm.perm[o + r]) * D + e];
+          prow0[(size_t)k * D + e] = sum;
+        }
+      }
+    }
+  }
+  KV_STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_part
+// ------------------------------------------------------------------------------------------
+struct PartSmem {
+  long long* bkey;       // [CAPB]
+  unsigned* ba;          // [CAPB] ent_a
+  unsigned* bb;          // [CAPB] ent_b (apply / dedup) or the global entry index (lookup / dedup out)
+  unsigned* bloc;        // [CAPB] global entry index (modes that write results back per entry)
+  unsigned* hslot;       // [HS]   entry index + 1 of the key's representative
+  unsigned short* erep;  // [CAPB] representative entry of each entry
+  unsigned* rcnt;        // [CAPB] (at rep) entries of the key
+  unsigned* rsum;        // [CAPB] (at rep) lookup: summed count; apply: offset into perm
+  unsigned* rrow;        // [CAPB] (at rep) result (row id / dense index)
+  unsigned short* ulist; // [CAPB] representatives, dense
+  unsigned short* perm;  // [CAPB] entries grouped by key
+  unsigned* wtot;        // [16]
+  float* red;            // [TBP / LPR][dim] block fold scratch (apply / dedup)
+};
+
+__host__ __device__ inline size_t part_smem_bytes(int mode, int D, int lpr) {
+  size_t b = (size_t)CAPB * 8 + (size_t)CAPB * 4 * 6 + (size_t)HS * 4 + (size_t)CAPB * 2 * 3 + 64 + 16 * 12;
+  if (mode == MODE_APPLY || mode == MODE_DEDUP) b += (size_t)(TBP / lpr) * D * 4 + 16;
+  return b;
+}
+
+__device__ __forceinline__ PartSmem carve_part(char* base, int mode, int D, int lpr) {
+  PartSmem s;
+  auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
+  s.bkey = reinterpret_cast<long long*>(take((size_t)CAPB * 8));
+  s.ba = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.bb = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.bloc = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.hslot = reinterpret_cast<unsigned*>(take((size_t)HS * 4));
+  s.rcnt = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.rsum = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.rrow = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
+  s.erep = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
+  s.ulist = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
+  s.perm = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
+  s.wtot = reinterpret_cast<unsigned*>(take(64));
+  s.red = (mode == MODE_APPLY || mode == MODE_DEDUP)
+              ? reinterpret_cast<float*>(take((size_t)(TBP / lpr) * D * 4)) : nullptr;
+  return s;
+}
+
+struct PartArgs {
+  TableDev tv, ts0, ts1;      // var table; optimizer slot tables (apply)
+  OptArgs opt;
+  const float* grad;          // apply / dedup: input gradient rows; scatter: update rows
+  unsigned day;
+  int scatter_op, is_insert;  // MODE_SCATTER
+  int mark_what;              // MODE_MARK: 0 = blacklist, 1 = frequency words (in fvals)
+  const unsigned* fvals;
+  long long* out_keys;        // MODE_DEDUP
+  float* out_sum;
+};
+
+// sum of one key's per-tile contributions: entries perm[o .. o + cnt) of the partition block,
+// element layout of opt_update_row (V, LPR, K).  slice = [j0, j1) within the key's entries.
+template <int V, int LPR, int K>
+__device__ __forceinline__ void sum_contribs(const PartSmem& sm, const WsDev& w, const float* grad,
+                                             int D, unsigned o, unsigned j0, unsigned j1, int lane,
+                                             float (&gv)[K][V]) {
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  for (unsigned jb = j0; jb < j1; jb += RB) {
+    float val[RB][K][V];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
+      if (jb + r < j1) {
+        const unsigned loc = sm.bb[sm.perm[o + jb + r]];
+        const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
+                                            : grad + (size_t)loc * D;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) ldv<V>(src + e0, val[r][k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
+  }
+}
+
+// var-table side of one unique key for the optimizer ops:
+// KvVariable::FindOrInsertUnsafe(filter_out != nullptr) kv_variable.h:382-408 (+ table_manager.h:359-372).
+// Leader lane only.  Returns row | ROW_FILTERED; *isnew when the row must be initialised.
+__device__ __forceinline__ unsigned var_find_or_insert_for_apply(const TableDev& t, long long key,
+                                                                 bool* isnew) {
+  unsigned r = table_find_or_insert(t, key, isnew);
+  if (r == 0) return 0;
+  if (*isnew) {
+    *freq_ptr(t, r) = 1u;  // EmbeddingValue ctor value, day 0 (table_manager.h:94)
+    *flags_ptr(t, r) = 0;
+    return r;
+  }
+  const unsigned f = *freq_ptr(t, r);
+  if ((f & 0xFFFFu) < t.enter_threshold) return r | ROW_FILTERED;  // HasLowFrequency kv_variable.h:910
+  unsigned char* fl = flags_ptr(t, r);
+  if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;  // RemoveBlacklistUnsafe: fresh zero row (ours already is)
+  return r;
+}
+
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBP) k_part(WsDev w, PartArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int D = a.tv.dim;
+  PartSmem sm = carve_part(smem_raw, MODE, D, LPR);
+  __shared__ unsigned lnu, lbase;
+
+  const int tid = threadIdx.x;
+  const unsigned p = blockIdx.x;
+  const unsigned P = w.P, NT = w.ntiles;
+  constexpr bool SUMS = (MODE == MODE_APPLY || MODE == MODE_DEDUP);
+  constexpr unsigned GPB = TBP / LPR;
+  const int lane = tid % LPR;
+  const unsigned grp = tid / LPR;
+  KV_STAMP(0);
+
+  // ---- how many entries does this partition hold?  more than CAPB -> rounds by sub-hash -----
+  unsigned mine = 0;
+  for (unsigned t = tid; t < NT; t += TBP) {
+    const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+    mine += (unsigned)to[1] - (unsigned)to[0];
+  }
+  unsigned E;
+  block_excl_scan<TBP / 64>(mine, sm.wtot, &E);
+  if (E == 0) return;
+  unsigned R = 1;
+  while ((E + R - 1) / R > (unsigned)(CAPB * 3 / 4) && R < 4096) R <<= 1;
+
+  for (unsigned round = 0; round < R; ++round) {
+    // ---- phase 1: copy this round's entries into LDS (deterministic order) -----------------
+    unsigned cnt = 0;
+    for (unsigned t = tid; t < NT; t += TBP) {
+      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+      const unsigned s0 = to[0], s1 = to[1];
+      if (R == 1) cnt += s1 - s0;
+      else
+        for (unsigned e = s0; e < s1; ++e)
+          cnt += (((mix64((unsigned long long)w.ent_key[(size_t)t * TILE + e]) >> 20) & (R - 1)) == round);
+    }
+    unsigned Er;
+    unsigned pos = block_excl_scan<TBP / 64>(cnt, sm.wtot, &Er);
+    if (Er > (unsigned)CAPB) {
+      // unlucky split: double the rounds and start over (block-uniform decision)
+      R <<= 1;
+      round = (unsigned)-1;
+      __syncthreads();
+      continue;
+    }
+    for (int s = tid; s < HS; s += TBP) sm.hslot[s] = 0;
+    for (unsigned t = tid; t < NT; t += TBP) {
+      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+      const unsigned s0 = to[0], s1 = to[1];
+      for (unsigned e = s0; e < s1; ++e) {
+        const size_t ge = (size_t)t * TILE + e;
+        const long long key = w.ent_key[ge];
+        if (R > 1 && ((mix64((unsigned long long)key) >> 20) & (R - 1)) != round) continue;
+        sm.bkey[pos] = key;
+        sm.ba[pos] = w.ent_a[ge];
+        if (SUMS) sm.bb[pos] = w.ent_b[ge];
+        sm.bloc[pos] = (unsigned)ge;
+        sm.rcnt[pos] = 0;
+        sm.rsum[pos] = 0;
+        ++pos;
+      }
+    }
+    if (tid == 0) lnu = 0;
+    __syncthreads();
+    KV_STAMP(1);
+
+    // ---- phase 2: group the entries by key (LDS hash of representatives) -------------------
+    unsigned myrank[(CAPB + TBP - 1) / TBP];
+#pragma unroll
+    for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
+      const unsigned e = tid + q * TBP;
+      myrank[q] = 0;
+      if (e < Er) {
+        const long long key = sm.bkey[e];
+        unsigned h = (unsigned)(mix64((unsigned long long)key) >> 8) & (HS - 1);
+        unsigned rep;
+        for (;;) {
+          const unsigned old = atomicCAS(&sm.hslot[h], 0u, e + 1u);
+          if (old == 0u) { rep = e; break; }
+          if (sm.bkey[old - 1u] == key) { rep = old - 1u; break; }
+          h = (h + 1) & (HS - 1);
+        }
+        sm.erep[e] = (unsigned short)rep;
+        myrank[q] = atomicAdd(&sm.rcnt[rep], 1u);
+        if (MODE == MODE_LOOKUP) atomicAdd(&sm.rsum[rep], sm.ba[e]);
+        if (rep == e) sm.ulist[atomicAdd(&lnu, 1u)] = (unsigned short)e;
+      }
+    }
+    __syncthreads();
+    const unsigned nu = lnu;
+    if constexpr (SUMS) {
+      // entries of each key contiguous in perm: offsets by a scan over the unique list
+      unsigned c[(CAPB + TBP - 1) / TBP];
+      unsigned sum = 0;
+#pragma unroll
+      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
+        const unsigned u = tid * ((CAPB + TBP - 1) / TBP) + q;
+        c[q] = u < nu ? sm.rcnt[sm.ulist[u]] : 0u;
+        sum += c[q];
+      }
+      unsigned tot;
+      unsigned run = block_excl_scan<TBP / 64>(sum, sm.wtot, &tot);
+#pragma unroll
+      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
+        const unsigned u = tid * ((CAPB + TBP - 1) / TBP) + q;
+        if (u < nu) { sm.rsum[sm.ulist[u]] = run; run += c[q]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
+        const unsigned e = tid + q * TBP;
+        if (e < Er) sm.perm[sm.rsum[sm.erep[e]] + myrank[q]] = (unsigned short)e;
+      }
+      __syncthreads();
+    }
+    KV_STAMP(2);
+
+    // ---- phase 3: owner work, one group of lanes per unique key ---------------------------
+    if constexpr (MODE == MODE_LOOKUP) {
+      // FindOrInsertLocally kv_variable.h:287-380 per unique key; 8 lanes per key
+      const int lane8 = tid & 7;
+      const unsigned upad = (nu + 7u) & ~7u;
+      for (unsigned u = tid >> 3; u < upad; u += TBP / 8) {
+        const bool live = u < nu;
+        const unsigned rep = live ? sm.ulist[u] : 0u;
+        const long long key = sm.bkey[rep];
+        unsigned r = 0;
+        bool isnew = false;
+        if (live && lane8 == 0) r = table_find_or_insert(a.tv, key, &isnew);
+        r = __shfl(r, 0, 8);
+        isnew = __shfl((int)isnew, 0, 8) != 0;
+        bool big = false;
+        if (live && r != 0) {
+          float* row = row_ptr(a.tv, r);
+          if (isnew) big = init_row_coop(a.tv, key, row, lane8, 8);
+          else
+            for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
+        }
+        const unsigned long long m = __ballot(big);
+        const bool any = ((m >> ((tid & 63) & ~7)) & 0xFFull) != 0;
+        if (live && r != 0 && lane8 == 0) {
+          // find_func / insert_func: lo16 = sat_add(lo16, batch count), hi16 = today,
+          // UpdateUnderThreshold (kv_variable.h:320-363)
+          unsigned* fp = freq_ptr(a.tv, r);
+          const unsigned cnt = sm.rsum[rep];
+          unsigned lo = (isnew ? 0u : (*fp & 0xFFFFu)) + (cnt > 65535u ? 65535u : cnt);
+          if (lo > 65535u) lo = 65535u;
+          *fp = (a.day << 16) | lo;
+          unsigned char* fl = flags_ptr(a.tv, r);
+          const unsigned black = isnew ? 0u : (*fl & FLAG_BLACK);
+          *fl = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
+        }
+        if (live && lane8 == 0) sm.rrow[rep] = r;
+      }
+      __syncthreads();
+      for (unsigned e = tid; e < Er; e += TBP) w.ent_b[sm.bloc[e]] = sm.rrow[sm.erep[e]];
+    } else if constexpr (MODE == MODE_SCATTER || MODE == MODE_MARK) {
+      // ScatterUpdate kv_variable.h:616-734 ; InsertOrUpdate :423-485 ; import marks
+      const int lane8 = tid & 7;
+      const unsigned upad = (nu + 7u) & ~7u;
+      for (unsigned u = tid >> 3; u < upad; u += TBP / 8) {
+        const bool live = u < nu;
+        const unsigned rep = live ? sm.ulist[u] : 0u;
+        const long long key = sm.bkey[rep];
+        unsigned r = 0;
+        bool isnew = false;
+        if (live && lane8 == 0) {
+          r = table_find_or_insert(a.tv, key, &isnew);
+          if (r && isnew) { *freq_ptr(a.tv, r) = 1u; *flags_ptr(a.tv, r) = 0; }
+        }
+        r = __shfl(r, 0, 8);
+        isnew = __shfl((int)isnew, 0, 8) != 0;
+        bool big = false, touch = false;
+        if (live && r != 0) {
+          float* row = row_ptr(a.tv, r);
+          if (isnew) init_row_coop(a.tv, key, row, lane8, 8);
+          const unsigned fl = isnew ? 0u : *flags_ptr(a.tv, r);
+          if (MODE == MODE_MARK) {
+            if (a.mark_what == 0) {
+              for (int e = lane8; e < D; e += 8) row[e] = 0.f;
+              if (lane8 == 0) *flags_ptr(a.tv, r) = (unsigned char)(FLAG_BLACK | FLAG_UNDER);
+            } else if (lane8 == 0) {
+              *freq_ptr(a.tv, r) = a.fvals[sm.ba[rep]];
+            }
+          } else {
+            // scatter leaves blacklisted rows alone (:690); insert overwrites
+            touch = a.is_insert || !(fl & FLAG_BLACK);
+            const float* src = a.grad + (size_t)sm.ba[rep] * D;
+            if (touch) {
+              for (int e = lane8; e < D; e += 8) {
+                const float l = row[e], v = src[e];
+                float o;
+                switch (a.scatter_op) {
+                  case KV_SCATTER_ADD: o = l + v; break;
+                  case KV_SCATTER_SUB: o = l - v; break;
+                  case KV_SCATTER_MUL: o = l * v; break;
+                  case KV_SCATTER_DIV: o = l / v; break;
+                  case KV_SCATTER_MIN: o = fminf(l, v); break;
+                  case KV_SCATTER_MAX: o = fmaxf(l, v); break;
+                  default: o = v;
+                }
+                row[e] = o;
+                big |= fabsf(o) >= CUTOFF;
+              }
+            } else if (isnew) {
+              for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
+            }
+          }
+        }
+        const unsigned long long m = __ballot(big);
+        const bool any = ((m >> ((tid & 63) & ~7)) & 0xFFull) != 0;
+        if (MODE == MODE_SCATTER && live && r != 0 && lane8 == 0 && (touch || isnew)) {
+          unsigned char* fp = flags_ptr(a.tv, r);
+          const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
+          *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
+        }
+      }
+    } else {
+      // MODE_APPLY / MODE_DEDUP: sum the key's contributions, then update / emit.
+      if (MODE == MODE_DEDUP) {
+        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block
+        __syncthreads();
+      }
+      // (a) keys spread over many tiles: the whole block folds slices, the first group finishes
+      for (unsigned u = 0; u < nu; ++u) {
+        const unsigned rep = sm.ulist[u];
+        const unsigned cnt = sm.rcnt[rep];
+        if (cnt <= (unsigned)HEAVY) continue;  // block-uniform
+        const unsigned o = sm.rsum[rep];
+        const unsigned per = (cnt + GPB - 1) / GPB;
+        float gv[K][V];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+        sum_contribs<V, LPR, K>(sm, w, a.grad, D, o, min(cnt, grp * per), min(cnt, (grp + 1) * per), lane, gv);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) stv<V>(sm.red + (size_t)grp * D + e0, gv[k]);
+        }
+        __syncthreads();
+        if (tid < 64) {  // first wave: group 0 sums the slices (fixed order) and finishes the key
+          const bool live = grp == 0;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+          if (live) {
+            for (unsigned g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const int e0 = (lane + k * LPR) * V;
+                if (e0 < D) {
+                  float t4[V];
+                  ldv<V>(sm.red + (size_t)g2 * D + e0, t4);
+#pragma unroll
+                  for (int c = 0; c < V; ++c) gv[k][c] += t4[c];
+                }
+              }
+            }
+          }
+          const long long key = sm.bkey[rep];
+          if (MODE == MODE_APPLY) {
+            unsigned tag = 0;
+            bool isnew = false;
+            if (live && lane == 0) tag = var_find_or_insert_for_apply(a.tv, key, &isnew);
+            tag = __shfl(tag, 0, LPR);
+            isnew = __shfl((int)isnew, 0, LPR) != 0;
+            if (live && isnew && (tag & ROW_MASK)) {
+              const bool big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
+              const bool any = group_any<LPR>(big);
+              if (lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
+            } else {
+              (void)group_any<LPR>(false);
+            }
+            opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live, gv, a.opt, a.day, lane);
+          } else if (live) {
+            const unsigned dense = lbase + u;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const int e0 = (lane + k * LPR) * V;
+              if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
+            }
+            if (lane == 0) { a.out_keys[dense] = key; sm.rrow[rep] = dense; }
+          }
+        }
+        __syncthreads();
+      }
+      // (b) everything else: one group per key
+      const unsigned upad = (nu + GPB - 1) / GPB * GPB;
+      for (unsigned u = grp; u < upad; u += GPB) {
+        const unsigned rep = u < nu ? sm.ulist[u] : 0u;
+        const unsigned cnt = u < nu ? sm.rcnt[rep] : 0u;
+        const bool live = u < nu && cnt <= (unsigned)HEAVY;
+        const long long key = sm.bkey[rep];
+        float gv[K][V];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+        if (live) sum_contribs<V, LPR, K>(sm, w, a.grad, D, sm.rsum[rep], 0, cnt, lane, gv);
+        if (MODE == MODE_APPLY) {
+          unsigned tag = 0;
+          bool isnew = false;
+          if (live && lane == 0) tag = var_find_or_insert_for_apply(a.tv, key, &isnew);
+          tag = __shfl(tag, 0, LPR);
+          isnew = __shfl((int)isnew, 0, LPR) != 0;
+          bool big = false;
+          if (live && isnew && (tag & ROW_MASK))
+            big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
+          const bool any = group_any<LPR>(big);
+          if (live && isnew && (tag & ROW_MASK) && lane == 0)
+            *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
+          opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live, gv, a.opt, a.day, lane);
+        } else if (live) {
+          const unsigned dense = lbase + u;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int e0 = (lane + k * LPR) * V;
+            if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
+          }
+          if (lane == 0) { a.out_keys[dense] = key; sm.rrow[rep] = dense; }
+        }
+      }
+      if (MODE == MODE_DEDUP) {
+        __syncthreads();
+        for (unsigned e = tid; e < Er; e += TBP) w.ent_b[sm.bloc[e]] = sm.rrow[sm.erep[e]];
+      }
+    }
+    __syncthreads();
+    KV_STAMP(3);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gather: out[i, :] = rows[ent_b[slot_of_id[i]]]
+// ------------------------------------------------------------------------------------------
+// VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out,
+                                               long long n) {
+  if constexpr (VQ > 0) {
+    constexpr int RPB = TB / VQ;  // rows per block per step
+    const int v = threadIdx.x % VQ;
+    const long long r0 = (long long)blockIdx.x * RPB + threadIdx.x / VQ;
+    const long long stride = (long long)gridDim.x * RPB;
+    constexpr int UNR = 4;
+    for (long long i = r0; i < n; i += stride * UNR) {
+      unsigned sl[UNR], rr[UNR];
+      float4 val[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const long long ii = i + k * stride;
+        sl[k] = ii < n ? w.slot_of_id[ii] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const long long ii = i + k * stride;
+        rr[k] = ii < n ? w.ent_b[sl[k]] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k)
+        val[k] = reinterpret_cast<const float4*>(row_ptr(t, rr[k]))[v];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const long long ii = i + k * stride;
+        if (ii < n) reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4))[v] = val[k];
+      }
+    }
+  } else {
+    const int D = t.dim;
+    const long long total = n * D;
+    for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += (long long)gridDim.x * TB) {
+      const long long i = x / D;
+      const int e = (int)(x - i * D);
+      out[x] = row_ptr(t, w.ent_b[w.slot_of_id[i]])[e];
+    }
+  }
+}
+
+// KvVariableGatherOrZeros: read-only, no dedup needed (no writes, repeated keys hit cache).
+// FindOrZeros kv_variable.h:239-254 / BatchGetWithFn table_manager.h:112-154.
+template <typename IdT>
+__global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* __restrict__ ids,
+                                                        float* __restrict__ out, long long n) {
+  const int D = t.dim;
+  const int lane8 = threadIdx.x & 7;
+  for (long long i = (long long)blockIdx.x * (TB / 8) + (threadIdx.x >> 3); i < n;
+       i += (long long)gridDim.x * (TB / 8)) {
+    const unsigned r = table_find(t, load_id(ids, (size_t)i));
+    const float* row = row_ptr(t, r);  // blacklisted rows are stored as zeros; row 0 is zeros
+    float* o = out + (size_t)i * D;
+    if ((D & 3) == 0) {
+      for (int q = lane8; q < (D >> 2); q += 8)
+        reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
+    } else {
+      for (int e = lane8; e < D; e += 8) o[e] = row[e];
+    }
+  }
+}
+
+// kv_dedup_segment_sum: inverse[i] = dense unique index of input position i
+__global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    inverse[i] = (int)w.ent_b[w.slot_of_id[i]];
+}

@@ -355,8 +355,7 @@ def kv_reserve(table_handle, capacity):
   _lib.check(_lib.lib().kv_reserve(table_handle.ptr, int(capacity)))
 
 
-PROF_KINDS = ("lookup_dedup_find", "lookup_gather", "apply_dedup_find", "apply_accumulate",
-              "apply_update")
+PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_gather", "apply_tile", "apply_part")
 
 
 def kv_profile_enable(table_handle, max_launches):
