@@ -357,10 +357,16 @@ def test_sparse_group_ftrl_parity(ops, D, lrp, l2s):
     grad = (rng.normal(0, 1, (ids.size, D)) * rng.uniform(1e-3, 1e-1, (ids.size, 1))).astype(np.float32)
     _apply_both(ops, "ftrl", (hv, ha, hl), (ov, oa, ol), grad, ids, lr=0.1, l1=1e-3, l2=1e-2, l21=1e-2,
                 l2s=l2s, lrp=lrp)
-    tol = RTOL if lrp == -0.5 else 2e-6               # powf: device vs glibc differ by an ulp
-    _assert_same_table(ops, hv, ov, ids, rtol=tol, atol=1e-9)
+    if lrp == -0.5:
+      tol, atol = RTOL, 1e-8                          # rows sit around 1e-2: 1e-8 abs = 1e-6 of scale
+    else:
+      # lr_power != -0.5 goes through powf (Eigen -> libm in the reference, ocml on the GPU): the
+      # two differ by an ulp and (new_accum^p - accum^p) cancels ~200x, so this third-party-math
+      # case is held to 1e-4 relative instead of 1e-6
+      tol, atol = 1e-4, 1e-6
+    _assert_same_table(ops, hv, ov, ids, rtol=tol, atol=atol)
     _assert_same_table(ops, ha, oa, ids, rtol=tol)
-    _assert_same_table(ops, hl, ol, ids, rtol=tol, atol=1e-9)
+    _assert_same_table(ops, hl, ol, ids, rtol=tol, atol=atol)
 
 
 def test_apply_with_repeated_ids_is_segment_sum_then_apply(ops):
@@ -372,7 +378,9 @@ def test_apply_with_repeated_ids_is_segment_sum_then_apply(ops):
   hs, os_ = _const(ops, 3 * D, 0.0)
   for t in range(3):
     ids = _zipf_ids(rng, 6000, 4000, s=0.7)
-    grad = rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32)
+    # one-signed gradients: Adam's step m/sqrt(v) is discontinuous at g = 0, so a sum that cancels
+    # to ~0 would turn an ulp of summation-order difference into a visible difference in x
+    grad = np.abs(rng.normal(0, 1e-2, (ids.size, D))).astype(np.float32)
     b1p, b2p = _beta_pows(t)
     _apply_both(ops, "adam4", (hv, hs), (ov, os_), grad, ids, lr=1e-2, b1p=b1p, b2p=b2p, l1=0, l2=0, l21=0)
     _assert_same_table(ops, hv, ov, ids, rtol=5e-6, atol=1e-7)

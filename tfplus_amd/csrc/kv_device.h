@@ -7,6 +7,7 @@
 constexpr long long EMPTY_KEY = (long long)0x8000000000000000ULL;
 constexpr unsigned FLAG_BLACK = 1u;   // EmbeddingValue::in_black_   (embedding_value.h:225)
 constexpr unsigned FLAG_UNDER = 2u;   // EmbeddingValue::under_threshold_
+constexpr unsigned FLAG_DIRTY = 4u;   // row changed since under_threshold was computed (Adagrad: no CoverUpdate)
 constexpr float CUTOFF = 1.0e-20f;    // DEFAULT_CUTOFF_VALUE (kv_variable_interface.h:55)
 constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < enter_threshold
 constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
@@ -314,32 +315,19 @@ __device__ __forceinline__ bool group_any(bool p) {
 // One unique key's fused optimizer update, executed by LPR cooperating lanes (lane = 0..LPR-1).
 // `tag` = var row id | ROW_FILTERED; gv = the key's summed gradient, element e at lane
 // (e / V) % LPR, step (e / V) / LPR.  All LPR lanes of every group in the wave must call it
-// (shuffles inside); `live` masks groups without a key.
+// (shuffles inside); `live` masks groups without a key.  r0 / r1 (+ new flags) are the slot-table
+// rows the group leader probed (probe_for_apply).
 // Restates the per-id body of KvVariableGroupSparseApplyAdamV4Op / V3Op / SparseApplyAdagradOp /
 // SparseGroupSparseApplyFtrlOp (training_ops.cc:7142-7197, 5871-5927, 1455-1486, 684-763).
 template <int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDev& ts0,
                                                const TableDev& ts1, long long key, unsigned tag,
+                                               unsigned r0, bool new0, unsigned r1, bool new1,
                                                bool live, const float (&gv)[K][V], const OptArgs& a,
-                                               unsigned day, int lane) {
+                                               int lane) {
   const int D = tv.dim;
   const bool skip = !live || (tag & ROW_FILTERED) || (tag & ROW_MASK) == 0u;  // training_ops.cc:7150-7152
   const unsigned rv = tag & ROW_MASK;
-
-  // slot tables (leader probes, group shares the row id)
-  unsigned r0 = 0, r1 = 0;
-  bool new0 = false, new1 = false;
-  if (!skip && lane == 0) {
-    // FTRL probes linear (ts1) before accum (ts0): training_ops.cc:701-704
-    if (OPT == OPT_FTRL) r1 = slot_find_or_insert(ts1, key, day, &new1);
-    r0 = slot_find_or_insert(ts0, key, day, &new0);
-  }
-  r0 = __shfl(r0, 0, LPR);
-  new0 = __shfl((int)new0, 0, LPR) != 0;
-  if (OPT == OPT_FTRL) {
-    r1 = __shfl(r1, 0, LPR);
-    new1 = __shfl((int)new1, 0, LPR) != 0;
-  }
   const bool act = !skip && r0 != 0 && (OPT != OPT_FTRL || r1 != 0);
 
   float* xrow = row_ptr(tv, act ? rv : 0u);
@@ -452,7 +440,12 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
       }
     }
     const bool anys = group_any<LPR>(sbig);
-    if (act && new0 && lane == 0) *flags_ptr(ts0, r0) = (unsigned char)(anys ? 0u : FLAG_UNDER);
+    if (act && lane == 0) {
+      // the reference does not refresh under_threshold here; a later lookup does (FLAG_DIRTY)
+      *flags_ptr(tv, rv) |= (unsigned char)FLAG_DIRTY;
+      if (new0) *flags_ptr(ts0, r0) = (unsigned char)((anys ? 0u : FLAG_UNDER) | (a.update_slots ? FLAG_DIRTY : 0u));
+      else if (a.update_slots) *flags_ptr(ts0, r0) |= (unsigned char)FLAG_DIRTY;
+    }
   } else {
     // OPT_FTRL: training_ops.cc:713-751 with has_l2_shrinkage; ts0 = accum, ts1 = linear
     float x[K][V], ac[K][V], z[K][V], uu[K][V];

@@ -354,50 +354,8 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
 }
 
 // ------------------------------------------------------------------------------------------
-// k_part
+// partition pass
 // ------------------------------------------------------------------------------------------
-struct PartSmem {
-  long long* bkey;       // [CAPB]
-  unsigned* ba;          // [CAPB] ent_a
-  unsigned* bb;          // [CAPB] ent_b (apply / dedup) or the global entry index (lookup / dedup out)
-  unsigned* bloc;        // [CAPB] global entry index (modes that write results back per entry)
-  unsigned* hslot;       // [HS]   entry index + 1 of the key's representative
-  unsigned short* erep;  // [CAPB] representative entry of each entry
-  unsigned* rcnt;        // [CAPB] (at rep) entries of the key
-  unsigned* rsum;        // [CAPB] (at rep) lookup: summed count; apply: offset into perm
-  unsigned* rrow;        // [CAPB] (at rep) result (row id / dense index)
-  unsigned short* ulist; // [CAPB] representatives, dense
-  unsigned short* perm;  // [CAPB] entries grouped by key
-  unsigned* wtot;        // [16]
-  float* red;            // [TBP / LPR][dim] block fold scratch (apply / dedup)
-};
-
-__host__ __device__ inline size_t part_smem_bytes(int mode, int D, int lpr) {
-  size_t b = (size_t)CAPB * 8 + (size_t)CAPB * 4 * 6 + (size_t)HS * 4 + (size_t)CAPB * 2 * 3 + 64 + 16 * 12;
-  if (mode == MODE_APPLY || mode == MODE_DEDUP) b += (size_t)(TBP / lpr) * D * 4 + 16;
-  return b;
-}
-
-__device__ __forceinline__ PartSmem carve_part(char* base, int mode, int D, int lpr) {
-  PartSmem s;
-  auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
-  s.bkey = reinterpret_cast<long long*>(take((size_t)CAPB * 8));
-  s.ba = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.bb = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.bloc = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.hslot = reinterpret_cast<unsigned*>(take((size_t)HS * 4));
-  s.rcnt = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.rsum = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.rrow = reinterpret_cast<unsigned*>(take((size_t)CAPB * 4));
-  s.erep = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
-  s.ulist = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
-  s.perm = reinterpret_cast<unsigned short*>(take((size_t)CAPB * 2));
-  s.wtot = reinterpret_cast<unsigned*>(take(64));
-  s.red = (mode == MODE_APPLY || mode == MODE_DEDUP)
-              ? reinterpret_cast<float*>(take((size_t)(TBP / lpr) * D * 4)) : nullptr;
-  return s;
-}
-
 struct PartArgs {
   TableDev tv, ts0, ts1;      // var table; optimizer slot tables (apply)
   OptArgs opt;
@@ -410,252 +368,149 @@ struct PartArgs {
   float* out_sum;
 };
 
-// sum of one key's per-tile contributions: entries perm[o .. o + cnt) of the partition block,
-// element layout of opt_update_row (V, LPR, K).  slice = [j0, j1) within the key's entries.
-template <int V, int LPR, int K>
-__device__ __forceinline__ void sum_contribs(const PartSmem& sm, const WsDev& w, const float* grad,
-                                             int D, unsigned o, unsigned j0, unsigned j1, int lane,
-                                             float (&gv)[K][V]) {
-  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-  for (unsigned jb = j0; jb < j1; jb += RB) {
-    float val[RB][K][V];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
-      if (jb + r < j1) {
-        const unsigned loc = sm.bb[sm.perm[o + jb + r]];
-        const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
-                                            : grad + (size_t)loc * D;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) ldv<V>(src + e0, val[r][k]);
-        }
-      }
+// round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
+__device__ __forceinline__ bool in_round(long long key, unsigned R, unsigned round) {
+  return R == 1 || ((mix64((unsigned long long)key) >> 20) & (R - 1)) == round;
+}
+
+// LDS hash of the partition's unique keys: 64-bit CAS on the key, slot HSL = the EMPTY_KEY key.
+// Returns the slot; *first = this call inserted the key.
+template <int HSL>
+__device__ __forceinline__ unsigned lds_key_slot(long long* hkey, unsigned* sent, long long key,
+                                                 bool insert, bool* first) {
+  *first = false;
+  if (key == EMPTY_KEY) {
+    if (insert) *first = atomicCAS(sent, 0u, 1u) == 0u;
+    return HSL;
+  }
+  unsigned h = (unsigned)(mix64((unsigned long long)key) >> 8) & (HSL - 1);
+  for (;;) {
+    if (insert) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&hkey[h]),
+                                               (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+      if (old == (unsigned long long)EMPTY_KEY) { *first = true; return h; }
+      if (old == (unsigned long long)key) return h;
+    } else if (hkey[h] == key) {
+      return h;
     }
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
+    h = (h + 1) & (HSL - 1);
   }
 }
 
-// var-table side of one unique key for the optimizer ops:
-// KvVariable::FindOrInsertUnsafe(filter_out != nullptr) kv_variable.h:382-408 (+ table_manager.h:359-372).
-// Leader lane only.  Returns row | ROW_FILTERED; *isnew when the row must be initialised.
-__device__ __forceinline__ unsigned var_find_or_insert_for_apply(const TableDev& t, long long key,
-                                                                 bool* isnew) {
-  unsigned r = table_find_or_insert(t, key, isnew);
-  if (r == 0) return 0;
-  if (*isnew) {
-    *freq_ptr(t, r) = 1u;  // EmbeddingValue ctor value, day 0 (table_manager.h:94)
-    *flags_ptr(t, r) = 0;
-    return r;
-  }
-  const unsigned f = *freq_ptr(t, r);
-  if ((f & 0xFFFFu) < t.enter_threshold) return r | ROW_FILTERED;  // HasLowFrequency kv_variable.h:910
-  unsigned char* fl = flags_ptr(t, r);
-  if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;  // RemoveBlacklistUnsafe: fresh zero row (ours already is)
-  return r;
-}
+// ---- k_part_keys: MODE_LOOKUP / MODE_SCATTER / MODE_MARK ---------------------------------------
+// Streams the partition's entries twice and keeps only the unique keys in LDS, so a key that
+// occurs in every tile costs nothing extra.  256 threads, ~33 KB LDS, 4 blocks per CU.
+constexpr int TBK = 256;
+constexpr int HSK = 2048;          // LDS hash slots
+constexpr int UCAPK = HSK * 3 / 4; // unique keys per round
 
-template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBP) k_part(WsDev w, PartArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int D = a.tv.dim;
-  PartSmem sm = carve_part(smem_raw, MODE, D, LPR);
-  __shared__ unsigned lnu, lbase;
+template <int MODE>
+__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
+  __shared__ long long hkey[HSK + 1];
+  __shared__ unsigned hval[HSK + 1];   // lookup: summed count; scatter / mark: an input position
+  __shared__ unsigned hrow[HSK + 1];   // row id of the key
+  __shared__ unsigned short lnew[UCAPK + 8];  // slots whose row was inserted now / needs a row scan
+  __shared__ unsigned lnu, lsent, lnnew;
 
   const int tid = threadIdx.x;
   const unsigned p = blockIdx.x;
   const unsigned P = w.P, NT = w.ntiles;
-  constexpr bool SUMS = (MODE == MODE_APPLY || MODE == MODE_DEDUP);
-  constexpr unsigned GPB = TBP / LPR;
-  const int lane = tid % LPR;
-  const unsigned grp = tid / LPR;
+  const int D = a.tv.dim;
   KV_STAMP(0);
 
-  // ---- how many entries does this partition hold?  more than CAPB -> rounds by sub-hash -----
-  unsigned mine = 0;
-  for (unsigned t = tid; t < NT; t += TBP) {
-    const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-    mine += (unsigned)to[1] - (unsigned)to[0];
-  }
-  unsigned E;
-  block_excl_scan<TBP / 64>(mine, sm.wtot, &E);
-  if (E == 0) return;
   unsigned R = 1;
-  while ((E + R - 1) / R > (unsigned)(CAPB * 3 / 4) && R < 4096) R <<= 1;
-
   for (unsigned round = 0; round < R; ++round) {
-    // ---- phase 1: copy this round's entries into LDS (deterministic order) -----------------
-    unsigned cnt = 0;
-    for (unsigned t = tid; t < NT; t += TBP) {
-      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-      const unsigned s0 = to[0], s1 = to[1];
-      if (R == 1) cnt += s1 - s0;
-      else
-        for (unsigned e = s0; e < s1; ++e)
-          cnt += (((mix64((unsigned long long)w.ent_key[(size_t)t * TILE + e]) >> 20) & (R - 1)) == round);
-    }
-    unsigned Er;
-    unsigned pos = block_excl_scan<TBP / 64>(cnt, sm.wtot, &Er);
-    if (Er > (unsigned)CAPB) {
-      // unlucky split: double the rounds and start over (block-uniform decision)
-      R <<= 1;
-      round = (unsigned)-1;
-      __syncthreads();
-      continue;
-    }
-    for (int s = tid; s < HS; s += TBP) sm.hslot[s] = 0;
-    for (unsigned t = tid; t < NT; t += TBP) {
+    for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
+    if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
+    __syncthreads();
+    // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
+    for (unsigned t = tid; t < NT; t += TBK) {
       const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
       const unsigned s0 = to[0], s1 = to[1];
       for (unsigned e = s0; e < s1; ++e) {
         const size_t ge = (size_t)t * TILE + e;
         const long long key = w.ent_key[ge];
-        if (R > 1 && ((mix64((unsigned long long)key) >> 20) & (R - 1)) != round) continue;
-        sm.bkey[pos] = key;
-        sm.ba[pos] = w.ent_a[ge];
-        if (SUMS) sm.bb[pos] = w.ent_b[ge];
-        sm.bloc[pos] = (unsigned)ge;
-        sm.rcnt[pos] = 0;
-        sm.rsum[pos] = 0;
-        ++pos;
+        if (!in_round(key, R, round)) continue;
+        if (lnu >= (unsigned)UCAPK) break;  // overflow: this round is abandoned below
+        bool first;
+        const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, true, &first);
+        if (first) atomicAdd(&lnu, 1u);
+        if (MODE == MODE_LOOKUP) atomicAdd(&hval[h], w.ent_a[ge]);
+        else if (first) hval[h] = w.ent_a[ge];
       }
     }
-    if (tid == 0) lnu = 0;
     __syncthreads();
+    if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split by sub-hash and redo
+      R = R * 2;
+      round = (unsigned)-1;
+      __syncthreads();
+      continue;
+    }
     KV_STAMP(1);
 
-    // ---- phase 2: group the entries by key (LDS hash of representatives) -------------------
-    unsigned myrank[(CAPB + TBP - 1) / TBP];
-#pragma unroll
-    for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
-      const unsigned e = tid + q * TBP;
-      myrank[q] = 0;
-      if (e < Er) {
-        const long long key = sm.bkey[e];
-        unsigned h = (unsigned)(mix64((unsigned long long)key) >> 8) & (HS - 1);
-        unsigned rep;
-        for (;;) {
-          const unsigned old = atomicCAS(&sm.hslot[h], 0u, e + 1u);
-          if (old == 0u) { rep = e; break; }
-          if (sm.bkey[old - 1u] == key) { rep = old - 1u; break; }
-          h = (h + 1) & (HS - 1);
-        }
-        sm.erep[e] = (unsigned short)rep;
-        myrank[q] = atomicAdd(&sm.rcnt[rep], 1u);
-        if (MODE == MODE_LOOKUP) atomicAdd(&sm.rsum[rep], sm.ba[e]);
-        if (rep == e) sm.ulist[atomicAdd(&lnu, 1u)] = (unsigned short)e;
+    // ---- owner work: one thread per unique key ------------------------------------------------
+    for (int s = tid; s <= HSK; s += TBK) {
+      const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
+      if (!occ) continue;
+      const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+      bool isnew;
+      const unsigned r = table_find_or_insert(a.tv, key, &isnew);
+      hrow[s] = r;
+      if (r == 0) continue;
+      unsigned* fp = freq_ptr(a.tv, r);
+      unsigned char* fl = flags_ptr(a.tv, r);
+      if (MODE == MODE_LOOKUP) {
+        // find_func / insert_func (kv_variable.h:320-363): lo16 = sat_add(lo16, batch count),
+        // hi16 = today; UpdateUnderThreshold only has work to do when the row changed since the
+        // flag was computed (FLAG_DIRTY) or the row is new — every other writer keeps it current
+        const unsigned cnt = hval[s];
+        unsigned lo = (isnew ? 0u : (*fp & 0xFFFFu)) + (cnt > 65535u ? 65535u : cnt);
+        if (lo > 65535u) lo = 65535u;
+        *fp = (a.day << 16) | lo;
+        const unsigned f = isnew ? FLAG_DIRTY : *fl;
+        if (isnew) *fl = (unsigned char)FLAG_DIRTY;
+        if (f & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
+      } else {
+        if (isnew) { *fp = 1u; *fl = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
+        lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
       }
     }
     __syncthreads();
-    const unsigned nu = lnu;
-    if constexpr (SUMS) {
-      // entries of each key contiguous in perm: offsets by a scan over the unique list
-      unsigned c[(CAPB + TBP - 1) / TBP];
-      unsigned sum = 0;
-#pragma unroll
-      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
-        const unsigned u = tid * ((CAPB + TBP - 1) / TBP) + q;
-        c[q] = u < nu ? sm.rcnt[sm.ulist[u]] : 0u;
-        sum += c[q];
-      }
-      unsigned tot;
-      unsigned run = block_excl_scan<TBP / 64>(sum, sm.wtot, &tot);
-#pragma unroll
-      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
-        const unsigned u = tid * ((CAPB + TBP - 1) / TBP) + q;
-        if (u < nu) { sm.rsum[sm.ulist[u]] = run; run += c[q]; }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < (CAPB + TBP - 1) / TBP; ++q) {
-        const unsigned e = tid + q * TBP;
-        if (e < Er) sm.perm[sm.rsum[sm.erep[e]] + myrank[q]] = (unsigned short)e;
-      }
-      __syncthreads();
-    }
     KV_STAMP(2);
 
-    // ---- phase 3: owner work, one group of lanes per unique key ---------------------------
-    if constexpr (MODE == MODE_LOOKUP) {
-      // FindOrInsertLocally kv_variable.h:287-380 per unique key; 8 lanes per key
+    // ---- rows that need lanes: init of new rows, flag recompute, scatter / mark bodies ---------
+    {
       const int lane8 = tid & 7;
-      const unsigned upad = (nu + 7u) & ~7u;
-      for (unsigned u = tid >> 3; u < upad; u += TBP / 8) {
-        const bool live = u < nu;
-        const unsigned rep = live ? sm.ulist[u] : 0u;
-        const long long key = sm.bkey[rep];
-        unsigned r = 0;
-        bool isnew = false;
-        if (live && lane8 == 0) r = table_find_or_insert(a.tv, key, &isnew);
-        r = __shfl(r, 0, 8);
-        isnew = __shfl((int)isnew, 0, 8) != 0;
-        bool big = false;
-        if (live && r != 0) {
-          float* row = row_ptr(a.tv, r);
-          if (isnew) big = init_row_coop(a.tv, key, row, lane8, 8);
-          else
-            for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
-        }
-        const unsigned long long m = __ballot(big);
-        const bool any = ((m >> ((tid & 63) & ~7)) & 0xFFull) != 0;
-        if (live && r != 0 && lane8 == 0) {
-          // find_func / insert_func: lo16 = sat_add(lo16, batch count), hi16 = today,
-          // UpdateUnderThreshold (kv_variable.h:320-363)
-          unsigned* fp = freq_ptr(a.tv, r);
-          const unsigned cnt = sm.rsum[rep];
-          unsigned lo = (isnew ? 0u : (*fp & 0xFFFFu)) + (cnt > 65535u ? 65535u : cnt);
-          if (lo > 65535u) lo = 65535u;
-          *fp = (a.day << 16) | lo;
-          unsigned char* fl = flags_ptr(a.tv, r);
-          const unsigned black = isnew ? 0u : (*fl & FLAG_BLACK);
-          *fl = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
-        }
-        if (live && lane8 == 0) sm.rrow[rep] = r;
-      }
-      __syncthreads();
-      for (unsigned e = tid; e < Er; e += TBP) w.ent_b[sm.bloc[e]] = sm.rrow[sm.erep[e]];
-    } else if constexpr (MODE == MODE_SCATTER || MODE == MODE_MARK) {
-      // ScatterUpdate kv_variable.h:616-734 ; InsertOrUpdate :423-485 ; import marks
-      const int lane8 = tid & 7;
-      const unsigned upad = (nu + 7u) & ~7u;
-      for (unsigned u = tid >> 3; u < upad; u += TBP / 8) {
-        const bool live = u < nu;
-        const unsigned rep = live ? sm.ulist[u] : 0u;
-        const long long key = sm.bkey[rep];
-        unsigned r = 0;
-        bool isnew = false;
-        if (live && lane8 == 0) {
-          r = table_find_or_insert(a.tv, key, &isnew);
-          if (r && isnew) { *freq_ptr(a.tv, r) = 1u; *flags_ptr(a.tv, r) = 0; }
-        }
-        r = __shfl(r, 0, 8);
-        isnew = __shfl((int)isnew, 0, 8) != 0;
+      const unsigned nn = lnnew;
+      const unsigned npad = (nn + 7u) & ~7u;
+      for (unsigned j = tid >> 3; j < npad; j += TBK / 8) {
+        const bool live = j < nn;
+        const unsigned sv = live ? lnew[j] : 0u;
+        const unsigned s = sv & 0x7FFFu;
+        const bool isnew = (sv & 0x8000u) != 0;
+        const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+        const unsigned r = live ? hrow[s] : 0u;
+        float* row = row_ptr(a.tv, r);
         bool big = false, touch = false;
         if (live && r != 0) {
-          float* row = row_ptr(a.tv, r);
-          if (isnew) init_row_coop(a.tv, key, row, lane8, 8);
-          const unsigned fl = isnew ? 0u : *flags_ptr(a.tv, r);
-          if (MODE == MODE_MARK) {
+          if (isnew) big = init_row_coop(a.tv, key, row, lane8, 8);
+          if (MODE == MODE_LOOKUP) {
+            if (!isnew)
+              for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
+          } else if (MODE == MODE_MARK) {
             if (a.mark_what == 0) {
               for (int e = lane8; e < D; e += 8) row[e] = 0.f;
-              if (lane8 == 0) *flags_ptr(a.tv, r) = (unsigned char)(FLAG_BLACK | FLAG_UNDER);
             } else if (lane8 == 0) {
-              *freq_ptr(a.tv, r) = a.fvals[sm.ba[rep]];
+              *freq_ptr(a.tv, r) = a.fvals[hval[s]];
             }
           } else {
-            // scatter leaves blacklisted rows alone (:690); insert overwrites
+            // ScatterUpdate kv_variable.h:616-734 leaves blacklisted rows alone (:690);
+            // InsertOrUpdate :423-485 overwrites
+            const unsigned fl = isnew ? 0u : *flags_ptr(a.tv, r);
             touch = a.is_insert || !(fl & FLAG_BLACK);
-            const float* src = a.grad + (size_t)sm.ba[rep] * D;
+            const float* src = a.grad + (size_t)hval[s] * D;
             if (touch) {
+              big = false;
               for (int e = lane8; e < D; e += 8) {
                 const float l = row[e], v = src[e];
                 float o;
@@ -671,134 +526,355 @@ __global__ void __launch_bounds__(TBP) k_part(WsDev w, PartArgs a) {
                 row[e] = o;
                 big |= fabsf(o) >= CUTOFF;
               }
-            } else if (isnew) {
-              for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
             }
           }
         }
         const unsigned long long m = __ballot(big);
         const bool any = ((m >> ((tid & 63) & ~7)) & 0xFFull) != 0;
-        if (MODE == MODE_SCATTER && live && r != 0 && lane8 == 0 && (touch || isnew)) {
+        if (live && r != 0 && lane8 == 0) {
           unsigned char* fp = flags_ptr(a.tv, r);
-          const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
-          *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
-        }
-      }
-    } else {
-      // MODE_APPLY / MODE_DEDUP: sum the key's contributions, then update / emit.
-      if (MODE == MODE_DEDUP) {
-        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block
-        __syncthreads();
-      }
-      // (a) keys spread over many tiles: the whole block folds slices, the first group finishes
-      for (unsigned u = 0; u < nu; ++u) {
-        const unsigned rep = sm.ulist[u];
-        const unsigned cnt = sm.rcnt[rep];
-        if (cnt <= (unsigned)HEAVY) continue;  // block-uniform
-        const unsigned o = sm.rsum[rep];
-        const unsigned per = (cnt + GPB - 1) / GPB;
-        float gv[K][V];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-        sum_contribs<V, LPR, K>(sm, w, a.grad, D, o, min(cnt, grp * per), min(cnt, (grp + 1) * per), lane, gv);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) stv<V>(sm.red + (size_t)grp * D + e0, gv[k]);
-        }
-        __syncthreads();
-        if (tid < 64) {  // first wave: group 0 sums the slices (fixed order) and finishes the key
-          const bool live = grp == 0;
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-          if (live) {
-            for (unsigned g2 = 0; g2 < GPB; ++g2) {
-#pragma unroll
-              for (int k = 0; k < K; ++k) {
-                const int e0 = (lane + k * LPR) * V;
-                if (e0 < D) {
-                  float t4[V];
-                  ldv<V>(sm.red + (size_t)g2 * D + e0, t4);
-#pragma unroll
-                  for (int c = 0; c < V; ++c) gv[k][c] += t4[c];
-                }
-              }
-            }
-          }
-          const long long key = sm.bkey[rep];
-          if (MODE == MODE_APPLY) {
-            unsigned tag = 0;
-            bool isnew = false;
-            if (live && lane == 0) tag = var_find_or_insert_for_apply(a.tv, key, &isnew);
-            tag = __shfl(tag, 0, LPR);
-            isnew = __shfl((int)isnew, 0, LPR) != 0;
-            if (live && isnew && (tag & ROW_MASK)) {
-              const bool big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
-              const bool any = group_any<LPR>(big);
-              if (lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
-            } else {
-              (void)group_any<LPR>(false);
-            }
-            opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live, gv, a.opt, a.day, lane);
-          } else if (live) {
-            const unsigned dense = lbase + u;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const int e0 = (lane + k * LPR) * V;
-              if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
-            }
-            if (lane == 0) { a.out_keys[dense] = key; sm.rrow[rep] = dense; }
+          if (MODE == MODE_LOOKUP) {
+            const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
+            *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
+          } else if (MODE == MODE_MARK) {
+            if (a.mark_what == 0) *fp = (unsigned char)(FLAG_BLACK | FLAG_UNDER);
+            else if (isnew) *fp = (unsigned char)(any ? 0u : FLAG_UNDER);
+          } else if (touch || isnew) {
+            const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
+            *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
           }
         }
-        __syncthreads();
       }
-      // (b) everything else: one group per key
-      const unsigned upad = (nu + GPB - 1) / GPB * GPB;
-      for (unsigned u = grp; u < upad; u += GPB) {
-        const unsigned rep = u < nu ? sm.ulist[u] : 0u;
-        const unsigned cnt = u < nu ? sm.rcnt[rep] : 0u;
-        const bool live = u < nu && cnt <= (unsigned)HEAVY;
-        const long long key = sm.bkey[rep];
-        float gv[K][V];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-        if (live) sum_contribs<V, LPR, K>(sm, w, a.grad, D, sm.rsum[rep], 0, cnt, lane, gv);
-        if (MODE == MODE_APPLY) {
-          unsigned tag = 0;
-          bool isnew = false;
-          if (live && lane == 0) tag = var_find_or_insert_for_apply(a.tv, key, &isnew);
-          tag = __shfl(tag, 0, LPR);
-          isnew = __shfl((int)isnew, 0, LPR) != 0;
-          bool big = false;
-          if (live && isnew && (tag & ROW_MASK))
-            big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
-          const bool any = group_any<LPR>(big);
-          if (live && isnew && (tag & ROW_MASK) && lane == 0)
-            *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
-          opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live, gv, a.opt, a.day, lane);
-        } else if (live) {
-          const unsigned dense = lbase + u;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const int e0 = (lane + k * LPR) * V;
-            if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
-          }
-          if (lane == 0) { a.out_keys[dense] = key; sm.rrow[rep] = dense; }
+    }
+    KV_STAMP(3);
+
+    // ---- pass 2 (lookup): every entry learns its key's row ------------------------------------
+    if (MODE == MODE_LOOKUP) {
+      for (unsigned t = tid; t < NT; t += TBK) {
+        const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+        const unsigned s0 = to[0], s1 = to[1];
+        for (unsigned e = s0; e < s1; ++e) {
+          const size_t ge = (size_t)t * TILE + e;
+          const long long key = w.ent_key[ge];
+          if (!in_round(key, R, round)) continue;
+          bool first;
+          w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
         }
-      }
-      if (MODE == MODE_DEDUP) {
-        __syncthreads();
-        for (unsigned e = tid; e < Er; e += TBP) w.ent_b[sm.bloc[e]] = sm.rrow[sm.erep[e]];
       }
     }
     __syncthreads();
+    KV_STAMP(4);
+#ifdef KV_STAMPS
+    if (tid == 0) { w.dbg[(size_t)blockIdx.x * 16 + 8] = lnu; w.dbg[(size_t)blockIdx.x * 16 + 9] = R; w.dbg[(size_t)blockIdx.x * 16 + 10] = lnnew; }
+#endif
+  }
+}
+
+// ---- k_part_sum: MODE_APPLY / MODE_DEDUP ---------------------------------------------------------
+// Keeps 6-10 bytes per entry in LDS to group the per-tile contributions of each key, sums them in
+// registers (whole block for keys spread over many tiles) and runs the fused row update.
+constexpr int TBS = 256;
+constexpr int HSS = 2048;
+constexpr int UCAPS = HSS * 3 / 4;
+constexpr int ECAPS = 2560;
+
+__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int D, int lpr) {
+  size_t b = (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16;  // hkey, hval
+  b += (size_t)ECAPS * 4 + 16 + (size_t)ECAPS * 2 * 2 + 32;            // eb, eslot, perm
+  b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
+  b += (size_t)(TBS / lpr) * D * 4 + 16;                               // red
+  if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16 + (size_t)(HSS + 1) * 4 + 16;  // eloc, hrow
+  return b;
+}
+
+// leader lane: var + slot table probes of one key, issued together.
+// FindOrInsertUnsafe(var, filter_out != nullptr) kv_variable.h:382-408 and
+// FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear before accum (training_ops.cc:701-704)
+template <int OPT>
+__device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
+                                                bool* vnew, unsigned* r0, bool* new0, unsigned* r1,
+                                                bool* new1) {
+  // read-only probes first: independent loads overlap; inserts (rare) afterwards
+  unsigned rv = table_find(a.tv, key);
+  unsigned s0 = table_find(a.ts0, key);
+  unsigned s1 = (OPT == OPT_FTRL) ? table_find(a.ts1, key) : 0u;
+  *vnew = false; *new0 = false; *new1 = false;
+  if (rv == 0) {
+    rv = table_find_or_insert(a.tv, key, vnew);
+    if (rv && *vnew) { *freq_ptr(a.tv, rv) = 1u; *flags_ptr(a.tv, rv) = 0; }
+  }
+  *tag = rv;
+  *r0 = 0; *r1 = 0;
+  if (rv == 0) return;
+  if (!*vnew) {
+    const unsigned f = *freq_ptr(a.tv, rv);
+    if ((f & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
+    unsigned char* fl = flags_ptr(a.tv, rv);
+    if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;  // RemoveBlacklistUnsafe: fresh zero row (ours already is)
+  }
+  if (OPT == OPT_FTRL) {
+    if (s1 == 0) s1 = table_find_or_insert(a.ts1, key, new1);
+    if (s1) {
+      unsigned* fp = freq_ptr(a.ts1, s1);
+      if (*new1) *fp = 1u;
+      else { unsigned lo = (*fp & 0xFFFFu) + 1u; if (lo > 65535u) lo = 65535u; *fp = (a.day << 16) | lo; }
+    }
+    *r1 = s1;
+  }
+  if (s0 == 0) s0 = table_find_or_insert(a.ts0, key, new0);
+  if (s0) {
+    unsigned* fp = freq_ptr(a.ts0, s0);
+    if (*new0) *fp = 1u;
+    else { unsigned lo = (*fp & 0xFFFFu) + 1u; if (lo > 65535u) lo = 65535u; *fp = (a.day << 16) | lo; }
+  }
+  *r0 = s0;
+}
+
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int D = a.tv.dim;
+  char* sp = smem_raw;
+  auto take = [&](size_t bytes) { char* q = sp; sp += (bytes + 15) & ~(size_t)15; return q; };
+  long long* hkey = reinterpret_cast<long long*>(take((size_t)(HSS + 1) * 8));
+  unsigned* hval = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));  // entries, then perm offset
+  unsigned* eb = reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4));        // gradient locator
+  unsigned short* eslot = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));
+  unsigned short* perm = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));  // rank, then grouped entries
+  unsigned short* ulist = reinterpret_cast<unsigned short*>(take((size_t)UCAPS * 2));
+  unsigned* wtot = reinterpret_cast<unsigned*>(take(64));
+  float* red = reinterpret_cast<float*>(take((size_t)(TBS / LPR) * D * 4));
+  unsigned* eloc = nullptr;
+  unsigned* hrow = nullptr;
+  if (MODE == MODE_DEDUP) {
+    eloc = reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4));
+    hrow = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));
+  }
+  __shared__ unsigned lnu, lsent, lbase, lovf;
+
+  const int tid = threadIdx.x;
+  const unsigned p = blockIdx.x;
+  const unsigned P = w.P, NT = w.ntiles;
+  constexpr unsigned GPB = TBS / LPR;
+  const int lane = tid % LPR;
+  const unsigned grp = tid / LPR;
+  KV_STAMP(0);
+
+  unsigned R = 1;
+  for (unsigned round = 0; round < R; ++round) {
+    // ---- entries of this round: count, then copy in a deterministic order ---------------------
+    unsigned cnt = 0;
+    for (unsigned t = tid; t < NT; t += TBS) {
+      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+      const unsigned s0 = to[0], s1 = to[1];
+      if (R == 1) cnt += s1 - s0;
+      else
+        for (unsigned e = s0; e < s1; ++e) cnt += in_round(w.ent_key[(size_t)t * TILE + e], R, round);
+    }
+    unsigned Er;
+    unsigned pos = block_excl_scan<TBS / 64>(cnt, wtot, &Er);
+    if (Er == 0) { if (R == 1) return; __syncthreads(); continue; }
+    if (Er > (unsigned)ECAPS) {  // block-uniform
+      R = R * 2;
+      round = (unsigned)-1;
+      __syncthreads();
+      continue;
+    }
+    for (int s = tid; s <= HSS; s += TBS) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
+    if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
+    __syncthreads();
+    for (unsigned t = tid; t < NT; t += TBS) {
+      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+      const unsigned s0 = to[0], s1 = to[1];
+      for (unsigned e = s0; e < s1; ++e) {
+        const size_t ge = (size_t)t * TILE + e;
+        const long long key = w.ent_key[ge];
+        if (!in_round(key, R, round)) continue;
+        if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
+        bool first;
+        const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
+        if (first) ulist[atomicAdd(&lnu, 1u)] = (unsigned short)h;
+        eb[pos] = w.ent_b[ge];
+        if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
+        eslot[pos] = (unsigned short)h;
+        perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
+        ++pos;
+      }
+    }
+    __syncthreads();
+    if (lovf) {  // too many distinct keys for the LDS hash: split further
+      R = R * 2;
+      round = (unsigned)-1;
+      __syncthreads();
+      continue;
+    }
+    KV_STAMP(1);
+    const unsigned nu = lnu;
+    // ---- group the entries by key: offsets by a scan over the unique list ----------------------
+    {
+      constexpr int PER = (UCAPS + TBS - 1) / TBS;
+      unsigned c[PER];
+      unsigned sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const unsigned u = tid * PER + q;
+        c[q] = u < nu ? hval[ulist[u]] : 0u;
+        sum += c[q];
+      }
+      unsigned tot;
+      unsigned run = block_excl_scan<TBS / 64>(sum, wtot, &tot);
+      unsigned rank[(ECAPS + TBS - 1) / TBS];
+#pragma unroll
+      for (int q = 0; q < (ECAPS + TBS - 1) / TBS; ++q) {
+        const unsigned e = tid + q * TBS;
+        rank[q] = e < Er ? perm[e] : 0u;
+      }
+      __syncthreads();
+      // hval: count -> (count << 16 | offset) would not fit; keep counts in the high half of a
+      // second pass instead: offsets go to hval, counts are recovered as off[next] - off
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const unsigned u = tid * PER + q;
+        if (u < nu) { hval[ulist[u]] = (c[q] << 16) | run; run += c[q]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (ECAPS + TBS - 1) / TBS; ++q) {
+        const unsigned e = tid + q * TBS;
+        if (e < Er) perm[(hval[eslot[e]] & 0xFFFFu) + rank[q]] = (unsigned short)e;
+      }
+      __syncthreads();
+    }
+    KV_STAMP(2);
+    if (MODE == MODE_DEDUP) {
+      if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
+      __syncthreads();
+    }
+
+    auto sum_slice = [&](unsigned o, unsigned j0, unsigned j1, float (&gv)[K][V]) {
+      constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+      for (unsigned jb = j0; jb < j1; jb += RB) {
+        float val[RB][K][V];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
+          if (jb + r < j1) {
+            const unsigned loc = eb[perm[o + jb + r]];
+            const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
+                                                : a.grad + (size_t)loc * D;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const int e0 = (lane + k * LPR) * V;
+              if (e0 < D) ldv<V>(src + e0, val[r][k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
+      }
+    };
+    // finish one key: optimizer update, or emit (dedup)
+    auto finish = [&](unsigned u, unsigned h, bool live, float (&gv)[K][V]) {
+      const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
+      if (MODE == MODE_APPLY) {
+        unsigned tag = 0, r0 = 0, r1 = 0;
+        bool vnew = false, new0 = false, new1 = false;
+        if (live && lane == 0) probe_for_apply<OPT>(a, key, &tag, &vnew, &r0, &new0, &r1, &new1);
+        tag = __shfl(tag, 0, LPR);
+        r0 = __shfl(r0, 0, LPR);
+        r1 = __shfl(r1, 0, LPR);
+        const unsigned nb = __shfl((unsigned)vnew | ((unsigned)new0 << 1) | ((unsigned)new1 << 2), 0, LPR);
+        vnew = nb & 1u; new0 = (nb >> 1) & 1u; new1 = (nb >> 2) & 1u;
+        bool big = false;
+        const bool doinit = live && vnew && (tag & ROW_MASK);
+        if (doinit) big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
+        const bool any = group_any<LPR>(big);
+        if (doinit && lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
+        opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, r0, new0, r1, new1, live, gv, a.opt, lane);
+      } else if (live) {
+        const unsigned dense = lbase + u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
+        }
+        if (lane == 0) { a.out_keys[dense] = key; hrow[h] = dense; }
+      }
+    };
+
+    // (a) keys spread over many tiles: the whole block folds slices, the first group finishes
+    for (unsigned u = 0; u < nu; ++u) {
+      const unsigned h = ulist[u];
+      const unsigned cn = hval[h] >> 16;
+      if (cn <= (unsigned)HEAVY) continue;  // block-uniform
+      const unsigned o = hval[h] & 0xFFFFu;
+      const unsigned per = (cn + GPB - 1) / GPB;
+      float gv[K][V];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+      sum_slice(o, min(cn, grp * per), min(cn, (grp + 1) * per), gv);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) stv<V>(red + (size_t)grp * D + e0, gv[k]);
+      }
+      __syncthreads();
+      if (tid < 64) {  // first wave: group 0 adds the slices in a fixed order and finishes the key
+        const bool live = grp == 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+        if (live) {
+          for (unsigned g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const int e0 = (lane + k * LPR) * V;
+              if (e0 < D) {
+                float t4[V];
+                ldv<V>(red + (size_t)g2 * D + e0, t4);
+#pragma unroll
+                for (int c = 0; c < V; ++c) gv[k][c] += t4[c];
+              }
+            }
+          }
+        }
+        finish(u, h, live, gv);
+      }
+      __syncthreads();
+    }
+    // (b) everything else: one group per key
+    const unsigned upad = (nu + GPB - 1) / GPB * GPB;
+    for (unsigned u = grp; u < upad; u += GPB) {
+      const unsigned h = u < nu ? ulist[u] : 0u;
+      const unsigned cn = u < nu ? (hval[h] >> 16) : 0u;
+      const bool live = u < nu && cn <= (unsigned)HEAVY;
+      float gv[K][V];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+      if (live) sum_slice(hval[h] & 0xFFFFu, 0, cn, gv);
+      finish(u, h, live, gv);
+    }
+    if (MODE == MODE_DEDUP) {
+      __syncthreads();
+      for (unsigned e = tid; e < Er; e += TBS) w.ent_b[eloc[e]] = hrow[eslot[e]];
+    }
+    __syncthreads();
     KV_STAMP(3);
+#ifdef KV_STAMPS
+    if (tid == 0) { w.dbg[(size_t)blockIdx.x * 16 + 8] = Er; w.dbg[(size_t)blockIdx.x * 16 + 9] = R; w.dbg[(size_t)blockIdx.x * 16 + 10] = nu; }
+#endif
   }
 }
 

@@ -299,9 +299,10 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
   return KV_OK;
 }
 
-// partitions for a batch of n ids: ~2048 input positions per partition block, a power of two
+// partitions for a batch of n ids: ~1024 input positions (so at most ~1024 distinct keys) per
+// partition block, a power of two
 unsigned pick_partitions(long long n) {
-  unsigned long long want = (unsigned long long)((n + 2047) / 2048);
+  unsigned long long want = (unsigned long long)((n + 1023) / 1024);
   unsigned P = 1;
   while (P < want && P < (unsigned)MAX_P) P <<= 1;
   return P;
@@ -413,37 +414,41 @@ template <int MODE, int OPT>
 int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
   const int D = pa.tv.dim;
   const int grid = (int)wd.P;
-#define KV_PART(V, LPR, K)                                                            \
-  do {                                                                                \
-    k_part<MODE, OPT, V, LPR, K><<<grid, TBP, part_smem_bytes(MODE, D, LPR), s>>>(wd, pa); \
-    return KV_OK;                                                                     \
-  } while (0)
-  if (MODE != MODE_APPLY && MODE != MODE_DEDUP) KV_PART(1, 8, 1);  // geometry unused
-  if ((D & 3) == 0) {
-    const int q = D / 4;
-    if (q <= 1) KV_PART(4, 1, 1);
-    if (q <= 2) KV_PART(4, 2, 1);
-    if (q <= 4) KV_PART(4, 4, 1);
-    if (q <= 8) KV_PART(4, 8, 1);
-    if (q <= 16) KV_PART(4, 16, 1);
-    if (q <= 32) KV_PART(4, 32, 1);
-    if (q <= 64) KV_PART(4, 64, 1);
-    if (q <= 128) KV_PART(4, 64, 2);
-    if (q <= 256) KV_PART(4, 64, 4);
+  if constexpr (MODE != MODE_APPLY && MODE != MODE_DEDUP) {
+    k_part_keys<MODE><<<grid, TBK, 0, s>>>(wd, pa);
+    return KV_OK;
   } else {
-    if (D <= 1) KV_PART(1, 1, 1);
-    if (D <= 2) KV_PART(1, 2, 1);
-    if (D <= 4) KV_PART(1, 4, 1);
-    if (D <= 8) KV_PART(1, 8, 1);
-    if (D <= 16) KV_PART(1, 16, 1);
-    if (D <= 32) KV_PART(1, 32, 1);
-    if (D <= 64) KV_PART(1, 64, 1);
-    if (D <= 128) KV_PART(1, 64, 2);
-    if (D <= 256) KV_PART(1, 64, 4);
-  }
+#define KV_PART(V, LPR, K)                                                                       \
+  do {                                                                                           \
+    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, D, LPR), s>>>(wd, pa); \
+    return KV_OK;                                                                                \
+  } while (0)
+    if ((D & 3) == 0) {
+      const int q = D / 4;
+      if (q <= 1) KV_PART(4, 1, 1);
+      if (q <= 2) KV_PART(4, 2, 1);
+      if (q <= 4) KV_PART(4, 4, 1);
+      if (q <= 8) KV_PART(4, 8, 1);
+      if (q <= 16) KV_PART(4, 16, 1);
+      if (q <= 32) KV_PART(4, 32, 1);
+      if (q <= 64) KV_PART(4, 64, 1);
+      if (q <= 128) KV_PART(4, 64, 2);
+      if (q <= 256) KV_PART(4, 64, 4);
+    } else {
+      if (D <= 1) KV_PART(1, 1, 1);
+      if (D <= 2) KV_PART(1, 2, 1);
+      if (D <= 4) KV_PART(1, 4, 1);
+      if (D <= 8) KV_PART(1, 8, 1);
+      if (D <= 16) KV_PART(1, 16, 1);
+      if (D <= 32) KV_PART(1, 32, 1);
+      if (D <= 64) KV_PART(1, 64, 1);
+      if (D <= 128) KV_PART(1, 64, 2);
+      if (D <= 256) KV_PART(1, 64, 4);
+    }
 #undef KV_PART
-  return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
-              "(multiples of 4 up to 1024, any dim up to 256)", D);
+    return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
+                "(multiples of 4 up to 1024, any dim up to 256)", D);
+  }
 }
 
 bool dim_supported(int D) { return (D & 3) == 0 ? D <= 1024 : D <= 256; }
