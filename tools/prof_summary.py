@@ -1,0 +1,45 @@
+"""Condenses a scripts_prof.sh output directory into the per-kernel table kept under profiles/."""
+import collections, csv, glob, json, os, sys
+out = sys.argv[1]
+KEYS = {"k_tile<0": "lookup_tile  k_tile<LOOKUP>", "k_part_keys<0": "lookup_part  k_part_keys<LOOKUP>",
+        "k_gather<8>": "lookup_gather k_gather<8>", "k_tile<1": "apply_tile   k_tile<APPLY>",
+        "k_part_sum<1": "apply_part   k_part_sum<APPLY,ADAM_V4>"}
+def name_of(k):
+  for a, b in KEYS.items():
+    if a in k: return b
+  return None
+tr = glob.glob(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
+dur = collections.defaultdict(list)
+if tr:
+  for r in csv.DictReader(open(tr[0])):
+    n = name_of(r["Kernel_Name"])
+    if n: dur[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("rocprofv3 --kernel-trace --stats  (bench.py --steps 20 --warmup 3; last 20 launches of each kernel)")
+print("%-44s %8s %10s %10s %10s" % ("kernel", "calls", "avg_us", "min_us", "max_us"))
+for n, v in dur.items():
+  v = v[-20:]
+  print("%-44s %8d %10.1f %10.1f %10.1f" % (n, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
+pm = collections.defaultdict(dict)
+for f in sorted(glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv"))):
+  agg = collections.defaultdict(lambda: collections.defaultdict(list))
+  for r in csv.DictReader(open(f)):
+    n = name_of(r["Kernel_Name"])
+    if n: agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+  for n, v in agg.items():
+    for c, vals in v.items():
+      pm[n][c] = sum(vals[-3:]) / len(vals[-3:])
+print()
+print("rocprofv3 --pmc (separate passes; mean of the last 3 launches).  FETCH_SIZE / WRITE_SIZE are KiB;")
+print("hbm_read_MB doubles FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM).")
+for n, v in pm.items():
+  fs, ws = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+  extra = ""
+  if fs is not None and ws is not None:
+    extra = "  hbm_read_MB %.1f  hbm_write_MB %.1f" % (2 * fs * 1024 / 1e6, ws * 1024 / 1e6)
+  print("%-44s%s" % (n, extra))
+  for c in sorted(v): print("      %-24s %16.1f" % (c, v[c]))
+try:
+  b = json.load(open(os.path.join(out, "bench_under_trace.json")))
+  print(); print("bench.py line of the traced run:"); print(json.dumps({k: b[k] for k in ("ms_per_step", "kernels_ms", "roofline")}))
+except Exception as e:
+  print("no bench json:", e)
