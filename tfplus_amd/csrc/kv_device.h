@@ -44,6 +44,7 @@ struct Chunk {
 
 // device view of one table; passed to kernels by value
 struct TableDev {
+  Chunk c0;                 // chunk 0 by value: the common single-chunk table needs no table hop
   Entry* entries;
   unsigned long long mask;  // cap - 1; entries[cap] = sentinel-key home
   Chunk* chunks;
@@ -78,8 +79,10 @@ struct WsDev {
 // block stores s_memtime at phase boundaries into a buffer nothing else reads.
 #ifdef KV_STAMPS
 #define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); } while (0)
+#define KV_STAMPP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = clock64(); } while (0)
 #else
 #define KV_STAMP(slot) do { } while (0)
+#define KV_STAMPP(slot) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -100,16 +103,20 @@ __device__ __forceinline__ unsigned long long pick64(unsigned long long x) {
 }
 
 __device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
+  if ((r >> t.chunk_bits) == 0) return t.c0.rows + (size_t)r * t.dim;
   const Chunk& c = t.chunks[r >> t.chunk_bits];
   return c.rows + (size_t)(r & ((1u << t.chunk_bits) - 1)) * t.dim;
 }
 __device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) {
+  if ((r >> t.chunk_bits) == 0) return t.c0.freq + r;
   return t.chunks[r >> t.chunk_bits].freq + (r & ((1u << t.chunk_bits) - 1));
 }
 __device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) {
+  if ((r >> t.chunk_bits) == 0) return t.c0.flags + r;
   return t.chunks[r >> t.chunk_bits].flags + (r & ((1u << t.chunk_bits) - 1));
 }
 __device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) {
+  if ((r >> t.chunk_bits) == 0) return t.c0.keys + r;
   return t.chunks[r >> t.chunk_bits].keys + (r & ((1u << t.chunk_bits) - 1));
 }
 

@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
     for (int s = tid; s <= LS; s += TB)
       if (sm.lcnt[s] >= 2u) sm.mlist[sm.lpart[s]] = (unsigned short)s;
     __syncthreads();
+    KV_STAMP(4);
     const unsigned npart = lnpart;
     const int lane8 = tid & 7;
     const int grp = tid >> 3;
@@ -312,31 +313,42 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
           if (q < NV) dst[q] = acc[v];
         }
       }
-      // tile-hot keys: every group folds a slice, the slices meet in LDS (no atomics)
-      for (unsigned k = 0; k < npart; ++k) {
-        const unsigned s = sm.mlist[k];
+      KV_STAMP(5);
+      // tile-hot keys: every group folds a slice of every hot key; the slices meet in LDS
+      // accumulators (one ds_add_f32 row per group and key), then ONE barrier for all of them
+      __shared__ unsigned short hotk[TILE / HOT_MIN];
+      __shared__ unsigned lnhot;
+      if (tid == 0) lnhot = 0;
+      __syncthreads();
+      for (unsigned k = tid; k < npart; k += TB)
+        if (sm.lcnt[sm.mlist[k]] > (unsigned)HOT_MIN) hotk[atomicAdd(&lnhot, 1u)] = (unsigned short)k;
+      __syncthreads();
+      const unsigned nhot = lnhot;
+      for (unsigned x = tid; x < nhot * (unsigned)D; x += TB) sm.red[x] = 0.f;
+      __syncthreads();
+      for (unsigned j = 0; j < nhot; ++j) {
+        const unsigned s = sm.mlist[hotk[j]];
         const unsigned cnt = sm.lcnt[s];
-        if (cnt <= (unsigned)HOT_MIN) continue;  // block-uniform
         const unsigned per = (cnt + TB / 8 - 1) / (TB / 8);
         const unsigned e0 = sm.lfirst[s] + min(cnt, grp * per), e1 = sm.lfirst[s] + min(cnt, (grp + 1) * per);
+        if (e0 >= e1) continue;
         float4 acc[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         fold_rows<VPL>(grad, base, D, sm.perm, e0, e1, lane8, acc);
-        float4* rd = reinterpret_cast<float4*>(sm.red + (size_t)grp * D);
+        float* rd = sm.red + (size_t)j * D;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
           const int q = lane8 + 8 * v;
-          if (q < NV) rd[q] = acc[v];
+          if (q < NV) {
+            atomicAdd(&rd[4 * q + 0], acc[v].x); atomicAdd(&rd[4 * q + 1], acc[v].y);
+            atomicAdd(&rd[4 * q + 2], acc[v].z); atomicAdd(&rd[4 * q + 3], acc[v].w);
+          }
         }
-        __syncthreads();
-        for (int e = tid; e < D; e += TB) {
-          float sum = 0.f;
-          for (int g2 = 0; g2 < TB / 8; ++g2) sum += sm.red[(size_t)g2 * D + e];
-          prow0[(size_t)k * D + e] = sum;
-        }
-        __syncthreads();
       }
+      __syncthreads();
+      for (unsigned x = tid; x < nhot * (unsigned)D; x += TB)
+        prow0[(size_t)hotk[x / D] * D + (x % D)] = sm.red[x];
     } else {
       // any dim: one thread per element, rows in sorted order
       for (unsigned k = 0; k < npart; ++k) {
@@ -350,7 +362,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
       }
     }
   }
-  KV_STAMP(4);
+  KV_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,7 +428,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   const unsigned p = blockIdx.x;
   const unsigned P = w.P, NT = w.ntiles;
   const int D = a.tv.dim;
-  KV_STAMP(0);
+  KV_STAMPP(0);
 
   unsigned R = 1;
   for (unsigned round = 0; round < R; ++round) {
@@ -424,9 +436,22 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
     __syncthreads();
     // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
-    for (unsigned t = tid; t < NT; t += TBK) {
-      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-      const unsigned s0 = to[0], s1 = to[1];
+    // (segment bounds of up to 8 of this thread's tiles are loaded together: independent loads)
+    for (unsigned tb = tid; tb < NT; tb += TBK * 8) {
+      unsigned so[8][2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned t = tb + q * TBK;
+        so[q][0] = so[q][1] = 0;
+        if (t < NT) {
+          const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+          so[q][0] = to[0]; so[q][1] = to[1];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+      const unsigned t = tb + q * TBK;
+      const unsigned s0 = so[q][0], s1 = so[q][1];
       for (unsigned e = s0; e < s1; ++e) {
         const size_t ge = (size_t)t * TILE + e;
         const long long key = w.ent_key[ge];
@@ -438,6 +463,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
         if (MODE == MODE_LOOKUP) atomicAdd(&hval[h], w.ent_a[ge]);
         else if (first) hval[h] = w.ent_a[ge];
       }
+      }
     }
     __syncthreads();
     if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split by sub-hash and redo
@@ -446,7 +472,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
       __syncthreads();
       continue;
     }
-    KV_STAMP(1);
+    KV_STAMPP(1);
 
     // ---- owner work: one thread per unique key ------------------------------------------------
     for (int s = tid; s <= HSK; s += TBK) {
@@ -476,7 +502,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
       }
     }
     __syncthreads();
-    KV_STAMP(2);
+    KV_STAMPP(2);
 
     // ---- rows that need lanes: init of new rows, flag recompute, scatter / mark bodies ---------
     {
@@ -546,26 +572,38 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
         }
       }
     }
-    KV_STAMP(3);
+    KV_STAMPP(3);
 
     // ---- pass 2 (lookup): every entry learns its key's row ------------------------------------
     if (MODE == MODE_LOOKUP) {
-      for (unsigned t = tid; t < NT; t += TBK) {
-        const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-        const unsigned s0 = to[0], s1 = to[1];
-        for (unsigned e = s0; e < s1; ++e) {
-          const size_t ge = (size_t)t * TILE + e;
-          const long long key = w.ent_key[ge];
-          if (!in_round(key, R, round)) continue;
-          bool first;
-          w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
+      for (unsigned tb = tid; tb < NT; tb += TBK * 8) {
+        unsigned so[8][2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned t = tb + q * TBK;
+          so[q][0] = so[q][1] = 0;
+          if (t < NT) {
+            const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+            so[q][0] = to[0]; so[q][1] = to[1];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned t = tb + q * TBK;
+          for (unsigned e = so[q][0]; e < so[q][1]; ++e) {
+            const size_t ge = (size_t)t * TILE + e;
+            const long long key = w.ent_key[ge];
+            if (!in_round(key, R, round)) continue;
+            bool first;
+            w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
+          }
         }
       }
     }
     __syncthreads();
-    KV_STAMP(4);
+    KV_STAMPP(4);
 #ifdef KV_STAMPS
-    if (tid == 0) { w.dbg[(size_t)blockIdx.x * 16 + 8] = lnu; w.dbg[(size_t)blockIdx.x * 16 + 9] = R; w.dbg[(size_t)blockIdx.x * 16 + 10] = lnnew; }
+    if (tid == 0) { w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 8] = lnu; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 9] = R; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 10] = lnnew; }
 #endif
   }
 }
@@ -577,12 +615,15 @@ constexpr int TBS = 256;
 constexpr int HSS = 2048;
 constexpr int UCAPS = HSS * 3 / 4;
 constexpr int ECAPS = 2560;
+constexpr int HMAXS = 16;                  // pre-summed heavy keys per round kept in LDS
+constexpr unsigned LOC_LDS = 0xFFFFFFF0u;  // gradient locator: row of the block's LDS hsum
 
 __host__ __device__ inline size_t part_sum_smem_bytes(int mode, int D, int lpr) {
   size_t b = (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16;  // hkey, hval
   b += (size_t)ECAPS * 4 + 16 + (size_t)ECAPS * 2 * 2 + 32;            // eb, eslot, perm
   b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
   b += (size_t)(TBS / lpr) * D * 4 + 16;                               // red
+  b += (size_t)HMAXS * D * 4 + 16;                                     // hsum
   if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16 + (size_t)(HSS + 1) * 4 + 16;  // eloc, hrow
   return b;
 }
@@ -644,6 +685,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
   unsigned short* ulist = reinterpret_cast<unsigned short*>(take((size_t)UCAPS * 2));
   unsigned* wtot = reinterpret_cast<unsigned*>(take(64));
   float* red = reinterpret_cast<float*>(take((size_t)(TBS / LPR) * D * 4));
+  float* hsum = reinterpret_cast<float*>(take((size_t)HMAXS * D * 4));
   unsigned* eloc = nullptr;
   unsigned* hrow = nullptr;
   if (MODE == MODE_DEDUP) {
@@ -658,7 +700,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
   constexpr unsigned GPB = TBS / LPR;
   const int lane = tid % LPR;
   const unsigned grp = tid / LPR;
-  KV_STAMP(0);
+  KV_STAMPP(0);
 
   unsigned R = 1;
   for (unsigned round = 0; round < R; ++round) {
@@ -708,7 +750,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
       __syncthreads();
       continue;
     }
-    KV_STAMP(1);
+    KV_STAMPP(1);
     const unsigned nu = lnu;
     // ---- group the entries by key: offsets by a scan over the unique list ----------------------
     {
@@ -745,7 +787,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
       }
       __syncthreads();
     }
-    KV_STAMP(2);
+    KV_STAMPP(2);
     if (MODE == MODE_DEDUP) {
       if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
       __syncthreads();
@@ -763,12 +805,21 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
             for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
           if (jb + r < j1) {
             const unsigned loc = eb[perm[o + jb + r]];
-            const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
-                                                : a.grad + (size_t)loc * D;
+            if (loc >= LOC_LDS) {  // a heavy key the block pre-summed
+              const float* src = hsum + (size_t)(loc - LOC_LDS) * D;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const int e0 = (lane + k * LPR) * V;
-              if (e0 < D) ldv<V>(src + e0, val[r][k]);
+              for (int k = 0; k < K; ++k) {
+                const int e0 = (lane + k * LPR) * V;
+                if (e0 < D) ldv<V>(src + e0, val[r][k]);
+              }
+            } else {
+              const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
+                                                  : a.grad + (size_t)loc * D;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const int e0 = (lane + k * LPR) * V;
+                if (e0 < D) ldv<V>(src + e0, val[r][k]);
+              }
             }
           }
         }
@@ -809,7 +860,10 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
       }
     };
 
-    // (a) keys spread over many tiles: the whole block folds slices, the first group finishes
+    // (a) keys spread over many tiles: the whole block folds slices into one LDS row and the key
+    //     then looks like a key with a single contribution; phase (b) finishes it in parallel
+    //     with the others (beyond HMAXS such keys per round the first wave finishes in place)
+    unsigned nheavy = 0;
     for (unsigned u = 0; u < nu; ++u) {
       const unsigned h = ulist[u];
       const unsigned cn = hval[h] >> 16;
@@ -828,7 +882,18 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
         if (e0 < D) stv<V>(red + (size_t)grp * D + e0, gv[k]);
       }
       __syncthreads();
-      if (tid < 64) {  // first wave: group 0 adds the slices in a fixed order and finishes the key
+      if (nheavy < (unsigned)HMAXS) {
+        for (int e = tid; e < D; e += TBS) {
+          float sum = 0.f;
+          for (unsigned g2 = 0; g2 < GPB; ++g2) sum += red[(size_t)g2 * D + e];  // fixed order
+          hsum[(size_t)nheavy * D + e] = sum;
+        }
+        if (tid == 0) {
+          eb[perm[o]] = LOC_LDS + nheavy;
+          hval[h] = (1u << 16) | o;
+        }
+        ++nheavy;
+      } else if (tid < 64) {
         const bool live = grp == 0;
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -849,15 +914,17 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
           }
         }
         finish(u, h, live, gv);
+        if (tid == 0) hval[h] = 0xFFFFu << 16;  // done: phase (b) must skip it
       }
       __syncthreads();
     }
+    KV_STAMPP(3);
     // (b) everything else: one group per key
     const unsigned upad = (nu + GPB - 1) / GPB * GPB;
     for (unsigned u = grp; u < upad; u += GPB) {
       const unsigned h = u < nu ? ulist[u] : 0u;
       const unsigned cn = u < nu ? (hval[h] >> 16) : 0u;
-      const bool live = u < nu && cn <= (unsigned)HEAVY;
+      const bool live = u < nu && cn != 0xFFFFu;
       float gv[K][V];
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -871,9 +938,9 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
       for (unsigned e = tid; e < Er; e += TBS) w.ent_b[eloc[e]] = hrow[eslot[e]];
     }
     __syncthreads();
-    KV_STAMP(3);
+    KV_STAMPP(4);
 #ifdef KV_STAMPS
-    if (tid == 0) { w.dbg[(size_t)blockIdx.x * 16 + 8] = Er; w.dbg[(size_t)blockIdx.x * 16 + 9] = R; w.dbg[(size_t)blockIdx.x * 16 + 10] = nu; }
+    if (tid == 0) { w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 8] = Er; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 9] = R; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 10] = nu; }
 #endif
   }
 }

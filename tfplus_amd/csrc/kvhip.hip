@@ -223,6 +223,7 @@ struct DeviceGuard {
 
 TableDev dev_view(const kv_table* t) {
   TableDev d;
+  d.c0 = t->chunks.empty() ? Chunk{} : t->chunks[0];
   d.entries = t->entries;
   d.mask = t->cap - 1;
   d.chunks = t->d_chunks;
@@ -329,7 +330,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
 #ifdef KV_STAMPS
     hipFree(w.dbg);
-    HIP_TRY(hipMalloc(&w.dbg, (nt + MAX_P + 1) * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&w.dbg, (size_t)8192 * 16 * sizeof(unsigned long long)));
 #endif
     w.cap_n = cap;
     w.capP = capP;

@@ -1,0 +1,43 @@
+"""Diagnostic: phase shares of k_tile<APPLY> and k_part_sum<APPLY> (-DKV_STAMPS build)."""
+import ctypes, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from tfplus_amd import _lib
+_lib.SO_PATH = os.path.join(_lib.CSRC, "libkvhip_stamps.so")
+from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+L = _lib.lib()
+dev = torch.device("cuda", 0)
+K, N, D = 5_000_000, 1_000_000, 32
+gen = torch.Generator(device=dev).manual_seed(1)
+var = ops.kv_variable([D], capacity_hint=K + 4 * N)
+slot = ops.kv_variable([3 * D], capacity_hint=K + 4 * N)
+ops.init_kv_variable_v2(var, torch.randn(1000, D, device=dev))
+ops.init_kv_variable_v2(slot, torch.zeros(4, 3 * D, device=dev))
+st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+buf = torch.empty((1 << 21, 3 * D), device=dev)
+for i in range(0, K, 1 << 21):
+  keys = bench.splitmix64(torch.arange(i + 1, min(i + (1 << 21), K) + 1, device=dev))
+  _lib.check(L.kv_gather_or_insert(var.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), st))
+  _lib.check(L.kv_gather_or_insert(slot.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), st))
+z = bench.Zipf(K, 1.2, dev)
+for rep in range(3):
+  ids = bench.splitmix64(z.sample(N, gen))
+  grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
+  _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0., 0., 0., 4, st))
+a = np.zeros((8192, 16), np.uint64)
+L.kv_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+L.kv_debug_read_stamps(var.ptr, a.ctypes.data, 8192)
+def rep(t, names, label):
+  t = t.astype(np.int64)
+  print(label, "blocks", len(t))
+  for k, nm in enumerate(names):
+    d = t[:, k + 1] - t[:, k]
+    print("   %-34s median %8.0f  p90 %8.0f  max %8.0f" % (nm, np.median(d), np.percentile(d, 90), d.max()))
+  tot = t[:, len(names)] - t[:, 0]
+  print("   block total median %.0f p90 %.0f max %.0f ; kernel span %.0f cycles" % (np.median(tot), np.percentile(tot, 90), tot.max(), t[:, len(names)].max() - t[:, 0].min()))
+nt = (N + 1023) // 1024
+rep(a[:nt, :7], ["init + LDS hash insert", "compact + partition sort + entries", "slot_of_id writes", "multi-key offsets + perm", "fold small keys (1 group each)", "fold tile-hot keys + store"], "k_tile<APPLY>")
+pt = a[4096:4096 + 1024]
+rep(pt[:, :5], ["count + copy entries + hash", "group entries by key", "heavy keys (block fold)", "per-key sum + probes + update"], "k_part_sum<APPLY>")
+print("   entries/round median %d max %d ; rounds max %d ; uniques median %d max %d" % (np.median(pt[:, 8]), pt[:, 8].max(), pt[:, 9].max(), np.median(pt[:, 10]), pt[:, 10].max()))
