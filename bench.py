@@ -165,9 +165,9 @@ def main():
     ids = splitmix64(z.sample(N, gen))
     grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
     U = int(torch.unique(ids).numel())
-    # rows whose key occurs once inside its 1024-id tile (read by the partition pass, not the tile pass)
-    pad = (-N) % 1024
-    tiles = torch.cat([ids, torch.full((pad,), ids.min().item() - 1, device=dev, dtype=ids.dtype)]).view(-1, 1024)
+    # rows whose key occurs once inside its 2048-id tile (TILE in kv_device.h) (read by the partition pass, not the tile pass)
+    pad = (-N) % 2048
+    tiles = torch.cat([ids, torch.full((pad,), ids.min().item() - 1, device=dev, dtype=ids.dtype)]).view(-1, 2048)
     srt = torch.sort(tiles, dim=1).values
     eq_prev = torch.zeros_like(srt, dtype=torch.bool)
     eq_prev[:, 1:] = srt[:, 1:] == srt[:, :-1]

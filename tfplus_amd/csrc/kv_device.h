@@ -13,9 +13,12 @@ constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < ente
 constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
 constexpr unsigned PART_BIT = 0x80000000u;      // gradient locator: partial-sum row, not an input row
 
-constexpr int TB = 256;          // threads per block of the tile / gather kernels
+constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
+constexpr int TBT = 512;         // threads per block of the tile kernel
 constexpr int IPT = 4;           // ids per thread in the tile kernel
-constexpr int TILE = TB * IPT;   // ids per tile (1024)
+constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every tile contributes
+                                 // N / 2048 entries to its partition, which keeps the partition
+                                 // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
 constexpr int HOT_MIN = 32;      // rows of one key in one tile above which the whole block folds it

@@ -33,16 +33,18 @@
 struct TileSmem {
   long long* lkeys;        // [LS + 1]   (slot LS: the key that equals EMPTY_KEY)
   unsigned* lcnt;          // [LS + 1]
-  unsigned* lfirst;        // [LS + 1]   (not MODE_LOOKUP) later: sorted-row offset of the key
+  unsigned short* lfirst;  // [LS + 1]   (not MODE_LOOKUP) tile-local position of one occurrence; later:
+                           //            sorted-row offset of the key
   unsigned short* lpos;    // [LS + 1]   entry position of the slot's key
   unsigned short* lwork;   // [TILE + 1] occupied slots
   unsigned* hist;          // [MAX_P + 1]
   unsigned* wtot;          // [8]
-  unsigned short* lpart;   // [LS + 1]   partial row of the slot's key (apply / dedup)
+  unsigned short* lpart;   // [LS + 1]   partial row of the slot's key (apply / dedup); ALIASES lwork + hist,
+                           //            written once those are dead
   // aliases of lkeys, valid after the entries are written:
   unsigned short* perm;    // [TILE]     tile rows grouped by key
-  unsigned short* mlist;   // [PARTCAP]  partial row -> slot
-  float* red;              // [TB / 8][dim] block fold scratch
+  unsigned short* pslot;   // [TILE]     slot (key) of each sorted row
+  float* red;              // [TBT / 8][dim] sums of keys whose rows span two groups' chunks
 };
 
 __host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
@@ -52,10 +54,10 @@ __host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
   b += (size_t)(TILE + 1) * 2 + 16;            // lwork
   b += (size_t)(MAX_P + 1) * 4 + 16;           // hist
   b += 64;                                     // wtot
-  if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 4 + 16;  // lfirst
+  if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 2 + 16;  // lfirst
   if (mode == MODE_APPLY || mode == MODE_DEDUP) {
-    b += (size_t)(LS + 1) * 2 + 16;            // lpart
-    const size_t alias = (size_t)TILE * 2 + (size_t)PARTCAP * 2 + (size_t)(TB / 8) * D * 4 + 64;
+    // lpart aliases lwork + hist ((TILE + 1) * 2 + (MAX_P + 1) * 4 >= (LS + 1) * 2)
+    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + (size_t)(TBT / 8) * D * 4 + 64;
     const size_t lk = (size_t)(LS + 1) * 8 + 16;
     if (alias > lk) b += alias - lk;           // big dims: the fold scratch outgrows lkeys
   }
@@ -69,67 +71,34 @@ __device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
   char* lk = take((size_t)(LS + 1) * 8);
   s.lkeys = reinterpret_cast<long long*>(lk);
   if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-    const size_t alias = (size_t)TILE * 2 + (size_t)PARTCAP * 2 + (size_t)(TB / 8) * D * 4 + 64;
+    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + (size_t)(TBT / 8) * D * 4 + 64;
     const size_t lkb = ((size_t)(LS + 1) * 8 + 15) & ~(size_t)15;
     if (alias > lkb) take(alias - lkb);
     s.perm = reinterpret_cast<unsigned short*>(lk);
-    s.mlist = reinterpret_cast<unsigned short*>(lk + (size_t)TILE * 2);
-    s.red = reinterpret_cast<float*>(lk + (size_t)TILE * 2 + (size_t)PARTCAP * 2 + 32);
+    s.pslot = reinterpret_cast<unsigned short*>(lk + (size_t)TILE * 2);
+    s.red = reinterpret_cast<float*>(lk + (size_t)TILE * 4 + 32);
   } else {
-    s.perm = nullptr; s.mlist = nullptr; s.red = nullptr;
+    s.perm = nullptr; s.pslot = nullptr; s.red = nullptr;
   }
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
   s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
-  s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
+  char* lw = take((size_t)(TILE + 1) * 2);
+  s.lwork = reinterpret_cast<unsigned short*>(lw);
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
+  static_assert(((TILE + 1) * 2 + 15) / 16 * 16 + (MAX_P + 1) * 4 >= (LS + 1) * 2, "lpart alias");
   s.wtot = reinterpret_cast<unsigned*>(take(64));
-  s.lfirst = (MODE != MODE_LOOKUP) ? reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4)) : nullptr;
-  s.lpart = (MODE == MODE_APPLY || MODE == MODE_DEDUP)
-                ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
+  s.lfirst = (MODE != MODE_LOOKUP) ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
+  s.lpart = (MODE == MODE_APPLY || MODE == MODE_DEDUP) ? reinterpret_cast<unsigned short*>(lw) : nullptr;
   return s;
 }
 
-// fold rows [e0, e1) of the tile's sorted row list into acc (8 lanes per row, lane8 = 0..7)
-template <int VPL>
-__device__ __forceinline__ void fold_rows(const float* __restrict__ grad, long long base, int D,
-                                          const unsigned short* perm, unsigned e0, unsigned e1,
-                                          int lane8, float4 (&acc)[VPL > 0 ? VPL : 1]) {
-  constexpr int RB = VPL > 0 ? (8 / VPL > 0 ? 8 / VPL : 1) : 1;  // rows loaded together
-  const int NV = D >> 2;
-  for (unsigned eb = e0; eb < e1; eb += RB) {
-    float4 val[RB][VPL > 0 ? VPL : 1];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const unsigned e = eb + r;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < e1) {
-        const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + perm[e]) * D);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int q = lane8 + 8 * v;
-          if (q < NV) val[r][v] = g4[q];
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
-        acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
-      }
-    }
-  }
-}
-
 template <int MODE, typename IdT, int VPL>
-__global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ ids,
+__global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ ids,
                                              const int* __restrict__ counts,
                                              const float* __restrict__ grad, long long n, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TileSmem sm = carve_tile<MODE>(smem_raw, D);
-  __shared__ unsigned lnwork, lsent, lnpart;
+  __shared__ unsigned lnwork, lsent, lnpart, lM;
 
   const int tid = threadIdx.x;
   const unsigned tile = blockIdx.x;
@@ -137,11 +106,11 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
   const unsigned P = w.P;
   KV_STAMP(0);
 
-  for (int s = tid; s <= LS; s += TB) {
+  for (int s = tid; s <= LS; s += TBT) {
     sm.lkeys[s] = EMPTY_KEY;
     sm.lcnt[s] = 0;
   }
-  for (unsigned p = tid; p <= P; p += TB) sm.hist[p] = 0;
+  for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
   if (tid == 0) { lnwork = 0; lsent = 0; lnpart = 0; }
   __syncthreads();
 
@@ -149,7 +118,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
   unsigned tslot[IPT], myrank[IPT];
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
-    const long long i = base + (long long)k * TB + tid;
+    const long long i = base + (long long)k * TBT + tid;
     tslot[k] = 0xFFFFFFFFu;
     myrank[k] = 0;
     if (i < n) {
@@ -163,7 +132,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
       unsigned h;
       if (key == EMPTY_KEY) {
         h = LS;
-        if (atomicCAS(&lsent, 0u, 1u) == 0u && MODE != MODE_LOOKUP) sm.lfirst[LS] = (unsigned)i;
+        if (atomicCAS(&lsent, 0u, 1u) == 0u && MODE != MODE_LOOKUP) sm.lfirst[LS] = (unsigned short)(k * TBT + tid);
       } else {
         h = (unsigned)(mix64((unsigned long long)key) >> 40) & (LS - 1);
         for (;;) {
@@ -171,7 +140,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
               atomicCAS(reinterpret_cast<unsigned long long*>(&sm.lkeys[h]),
                         (unsigned long long)EMPTY_KEY, (unsigned long long)key);
           if (old == (unsigned long long)EMPTY_KEY) {
-            if (MODE != MODE_LOOKUP) sm.lfirst[h] = (unsigned)i;
+            if (MODE != MODE_LOOKUP) sm.lfirst[h] = (unsigned short)(k * TBT + tid);
             break;
           }
           if (old == (unsigned long long)key) break;
@@ -186,18 +155,18 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
   KV_STAMP(1);
 
   // ---- phase 2: compact the occupied slots into a work list ------------------------------
-  for (int s = tid; s < LS; s += TB)
+  for (int s = tid; s < LS; s += TBT)
     if (sm.lkeys[s] != EMPTY_KEY) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)s;
   if (tid == 0 && lsent) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)LS;
   __syncthreads();
   const unsigned nwork = lnwork;
 
   // ---- phase 3: counting sort of the tile's unique keys by owning partition ---------------
-  constexpr int WPT = (TILE + 1 + TB - 1) / TB;  // work items per thread (5)
+  constexpr int WPT = (TILE + 1 + TBT - 1) / TBT;  // work items per thread (5)
   unsigned wp[WPT], wr[WPT];
 #pragma unroll
   for (int q = 0; q < WPT; ++q) {
-    const unsigned wi = tid + q * TB;
+    const unsigned wi = tid + q * TBT;
     wp[q] = 0; wr[q] = 0;
     if (wi < nwork) {
       const unsigned s = sm.lwork[wi];
@@ -208,21 +177,23 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
   }
   __syncthreads();
   {
-    const unsigned per = (P + TB - 1) / TB;
+    const unsigned per = (P + TBT - 1) / TBT;
     const unsigned p0 = tid * per, p1 = min(p0 + per, P);
     unsigned sum = 0;
     for (unsigned p = p0; p < p1; ++p) sum += sm.hist[p];
     unsigned tot;
-    unsigned run = block_excl_scan<TB / 64>(sum, sm.wtot, &tot);
+    unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
     for (unsigned p = p0; p < p1; ++p) { const unsigned c = sm.hist[p]; sm.hist[p] = run; run += c; }
     if (tid == 0) sm.hist[P] = nwork;
   }
   __syncthreads();
   unsigned short* toff = w.toff + (size_t)tile * (P + 1);
-  for (unsigned p = tid; p <= P; p += TB) toff[p] = (unsigned short)sm.hist[p];
+  for (unsigned p = tid; p <= P; p += TBT) toff[p] = (unsigned short)sm.hist[p];
+  unsigned short wk[WPT];  // partial row of this thread's work items (lpart aliases lwork / hist)
 #pragma unroll
   for (int q = 0; q < WPT; ++q) {
-    const unsigned wi = tid + q * TB;
+    wk[q] = 0xFFFFu;
+    const unsigned wi = tid + q * TBT;
     if (wi < nwork) {
       const unsigned s = sm.lwork[wi];
       const long long key = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
@@ -234,27 +205,37 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
         const unsigned c = sm.lcnt[s];
         w.ent_a[e] = c > 65535u ? 65535u : c;  // saturating add is order independent: clamp early
       } else {
-        w.ent_a[e] = sm.lfirst[s];
+        const unsigned first = (unsigned)base + sm.lfirst[s];
+        w.ent_a[e] = first;
         if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
           if (sm.lcnt[s] >= 2u) {
             const unsigned k = atomicAdd(&lnpart, 1u);
-            sm.lpart[s] = (unsigned short)k;
+            wk[q] = (unsigned short)k;
             w.ent_b[e] = PART_BIT | (tile * PARTCAP + k);
           } else {
-            sm.lpart[s] = 0xFFFFu;
-            w.ent_b[e] = sm.lfirst[s];
+            w.ent_b[e] = first;
           }
         }
       }
     }
   }
   __syncthreads();
+  if constexpr (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
+    unsigned short ws[WPT];
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) ws[q] = (tid + q * TBT) < nwork ? sm.lwork[tid + q * TBT] : (unsigned short)0xFFFF;
+    __syncthreads();  // lwork / hist are dead now: lpart takes their place
+#pragma unroll
+    for (int q = 0; q < WPT; ++q)
+      if (ws[q] != 0xFFFFu) sm.lpart[ws[q]] = wk[q];
+    __syncthreads();
+  }
   KV_STAMP(2);
 
   // ---- phase 4: every input position learns its key's entry -------------------------------
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
-    const long long i = base + (long long)k * TB + tid;
+    const long long i = base + (long long)k * TBT + tid;
     if (i < n) w.slot_of_id[i] = tile * TILE + sm.lpos[tslot[k]];
   }
   KV_STAMP(3);
@@ -263,7 +244,7 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
   if constexpr (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
     // offsets of the multi-row keys in the sorted row list (lfirst is free now)
     {
-      constexpr int PER = (LS + 1 + TB - 1) / TB;  // 9
+      constexpr int PER = (LS + 1 + TBT - 1) / TBT;  // 9
       unsigned c[PER];
       unsigned sum = 0;
 #pragma unroll
@@ -273,92 +254,123 @@ __global__ void __launch_bounds__(TB) k_tile(WsDev w, const IdT* __restrict__ id
         sum += c[q];
       }
       unsigned tot;
-      unsigned run = block_excl_scan<TB / 64>(sum, sm.wtot, &tot);
+      unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int s = tid * PER + q;
-        if (s <= LS) { sm.lfirst[s] = run; run += c[q]; }
+        if (s <= LS) { sm.lfirst[s] = (unsigned short)run; run += c[q]; }
       }
-      (void)tot;
+      if (tid == 0) lM = tot;
     }
-    __syncthreads();  // lkeys is dead from here on: perm / mlist / red alias it
+    __syncthreads();  // lkeys is dead from here on: perm / pslot / red alias it
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-      if (tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] >= 2u)
-        sm.perm[sm.lfirst[tslot[k]] + myrank[k]] = (unsigned short)(k * TB + tid);
+      if (tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] >= 2u) {
+        const unsigned pos = sm.lfirst[tslot[k]] + myrank[k];
+        sm.perm[pos] = (unsigned short)(k * TBT + tid);
+        sm.pslot[pos] = (unsigned short)tslot[k];
+      }
     }
-    for (int s = tid; s <= LS; s += TB)
-      if (sm.lcnt[s] >= 2u) sm.mlist[sm.lpart[s]] = (unsigned short)s;
+    constexpr unsigned G = TBT / 8;  // 8-lane groups
+    for (unsigned x = tid; x < G * (unsigned)D; x += TBT) sm.red[x] = 0.f;
     __syncthreads();
     KV_STAMP(4);
-    const unsigned npart = lnpart;
+    const unsigned M = lM;
     const int lane8 = tid & 7;
-    const int grp = tid >> 3;
+    const unsigned grp = tid >> 3;
     float* prow0 = w.part + (size_t)tile * PARTCAP * D;
+    const unsigned C = (M + G - 1) / G;  // sorted rows per group
     if constexpr (VPL > 0) {
+      // Each group folds one contiguous chunk of the sorted row list in registers, rows loaded
+      // RB at a time (independent 16-byte loads).  A key whose rows lie inside the chunk is
+      // stored once; a key that spans chunks (tile-hot keys) meets in the LDS row of the chunk
+      // it starts in — at most one such key per chunk, so red[G][D] always suffices.
       const int NV = D >> 2;
-      // keys with few rows: one 8-lane group folds all of them, one plain store
-      for (unsigned k = grp; k < npart; k += TB / 8) {
-        const unsigned s = sm.mlist[k];
-        const unsigned cnt = sm.lcnt[s];
-        if (cnt > (unsigned)HOT_MIN) continue;
-        float4 acc[VPL];
+      constexpr int RB = 16 / VPL;
+      const unsigned c0 = min(M, grp * C), c1 = min(M, (grp + 1) * C);
+      unsigned cur = 0xFFFFFFFFu;
+      float4 acc[VPL];
+      auto flush = [&]() {
+        if (cur == 0xFFFFFFFFu) return;
+        const unsigned st = sm.lfirst[cur], en = st + sm.lcnt[cur];
+        if (st >= c0 && en <= c1) {
+          float4* dst = reinterpret_cast<float4*>(prow0 + (size_t)sm.lpart[cur] * D);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        fold_rows<VPL>(grad, base, D, sm.perm, sm.lfirst[s], sm.lfirst[s] + cnt, lane8, acc);
-        float4* dst = reinterpret_cast<float4*>(prow0 + (size_t)k * D);
+          for (int v = 0; v < VPL; ++v) {
+            const int q = lane8 + 8 * v;
+            if (q < NV) dst[q] = acc[v];
+          }
+        } else {
+          float* rd = sm.red + (size_t)(st / C) * D;
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int q = lane8 + 8 * v;
-          if (q < NV) dst[q] = acc[v];
+          for (int v = 0; v < VPL; ++v) {
+            const int q = lane8 + 8 * v;
+            if (q < NV) {
+              atomicAdd(&rd[4 * q + 0], acc[v].x); atomicAdd(&rd[4 * q + 1], acc[v].y);
+              atomicAdd(&rd[4 * q + 2], acc[v].z); atomicAdd(&rd[4 * q + 3], acc[v].w);
+            }
+          }
         }
-      }
-      KV_STAMP(5);
-      // tile-hot keys: every group folds a slice of every hot key; the slices meet in LDS
-      // accumulators (one ds_add_f32 row per group and key), then ONE barrier for all of them
-      __shared__ unsigned short hotk[TILE / HOT_MIN];
-      __shared__ unsigned lnhot;
-      if (tid == 0) lnhot = 0;
-      __syncthreads();
-      for (unsigned k = tid; k < npart; k += TB)
-        if (sm.lcnt[sm.mlist[k]] > (unsigned)HOT_MIN) hotk[atomicAdd(&lnhot, 1u)] = (unsigned short)k;
-      __syncthreads();
-      const unsigned nhot = lnhot;
-      for (unsigned x = tid; x < nhot * (unsigned)D; x += TB) sm.red[x] = 0.f;
-      __syncthreads();
-      for (unsigned j = 0; j < nhot; ++j) {
-        const unsigned s = sm.mlist[hotk[j]];
-        const unsigned cnt = sm.lcnt[s];
-        const unsigned per = (cnt + TB / 8 - 1) / (TB / 8);
-        const unsigned e0 = sm.lfirst[s] + min(cnt, grp * per), e1 = sm.lfirst[s] + min(cnt, (grp + 1) * per);
-        if (e0 >= e1) continue;
-        float4 acc[VPL];
+      };
+      for (unsigned eb = c0; eb < c1; eb += RB) {
+        float4 val[RB][VPL];
+        unsigned ks[RB];
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        fold_rows<VPL>(grad, base, D, sm.perm, e0, e1, lane8, acc);
-        float* rd = sm.red + (size_t)j * D;
+        for (int r = 0; r < RB; ++r) {
+          const unsigned e = eb + r;
+          ks[r] = 0xFFFFFFFFu;
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int q = lane8 + 8 * v;
-          if (q < NV) {
-            atomicAdd(&rd[4 * q + 0], acc[v].x); atomicAdd(&rd[4 * q + 1], acc[v].y);
-            atomicAdd(&rd[4 * q + 2], acc[v].z); atomicAdd(&rd[4 * q + 3], acc[v].w);
+          for (int v = 0; v < VPL; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < c1) {
+            ks[r] = sm.pslot[e];
+            const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + sm.perm[e]) * D);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+              const int q = lane8 + 8 * v;
+              if (q < NV) val[r][v] = g4[q];
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          if (ks[r] == 0xFFFFFFFFu) continue;
+          if (ks[r] != cur) {
+            flush();
+            cur = ks[r];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = val[r][v];
+          } else {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+              acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
+              acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
+            }
           }
         }
       }
+      flush();
       __syncthreads();
-      for (unsigned x = tid; x < nhot * (unsigned)D; x += TB)
-        prow0[(size_t)hotk[x / D] * D + (x % D)] = sm.red[x];
+      KV_STAMP(5);
+      // keys that span chunks: the chunk they start in owns their LDS row
+      for (unsigned x = tid; x < G * (unsigned)D; x += TBT) {
+        const unsigned b = x / D, e = x % D;
+        const unsigned bend = min(M, (b + 1) * C);
+        if (b * C >= M || bend == 0) continue;
+        const unsigned sl = sm.pslot[bend - 1];
+        const unsigned st = sm.lfirst[sl], en = st + sm.lcnt[sl];
+        if (en > bend && st / C == b) prow0[(size_t)sm.lpart[sl] * D + e] = sm.red[x];
+      }
     } else {
-      // any dim: one thread per element, rows in sorted order
-      for (unsigned k = 0; k < npart; ++k) {
-        const unsigned s = sm.mlist[k];
-        const unsigned cnt = sm.lcnt[s], o = sm.lfirst[s];
-        for (int e = tid; e < D; e += TB) {
+      // any dim: one thread per element of one key at a time, rows in sorted order
+      for (unsigned e0 = 0; e0 < M;) {
+        const unsigned sl = sm.pslot[e0];
+        const unsigned cnt = sm.lcnt[sl];
+        for (int e = tid; e < D; e += TBT) {
           float sum = 0.f;
-          for (unsigned r = 0; r < cnt; ++r) sum += grad[(size_t)(base + sm.perm[o + r]) * D + e];
-          prow0[(size_t)k * D + e] = sum;
+          for (unsigned r = 0; r < cnt; ++r) sum += grad[(size_t)(base + sm.perm[e0 + r]) * D + e];
+          prow0[(size_t)sm.lpart[sl] * D + e] = sum;
         }
+        e0 += cnt;
       }
     }
   }
@@ -430,8 +442,16 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   const int D = a.tv.dim;
   KV_STAMPP(0);
 
-  unsigned R = 1;
-  for (unsigned round = 0; round < R; ++round) {
+  // work list of (R, round) sub-hash classes; an overflowing class is split in two and each
+  // class is processed exactly once (block-uniform control flow)
+  __shared__ unsigned stkR[24], stkr[24];
+  __shared__ int sp;
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
+  __syncthreads();
+  while (sp > 0) {
+    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+    __syncthreads();
+    if (tid == 0) --sp;
     for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
     if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
     __syncthreads();
@@ -466,9 +486,12 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
       }
     }
     __syncthreads();
-    if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split by sub-hash and redo
-      R = R * 2;
-      round = (unsigned)-1;
+    if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split the class, nothing applied yet
+      __syncthreads();
+      if (tid == 0 && sp + 2 <= 24) {
+        stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+        stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+      }
       __syncthreads();
       continue;
     }
@@ -609,89 +632,93 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
 }
 
 // ---- k_part_sum: MODE_APPLY / MODE_DEDUP ---------------------------------------------------------
-// Keeps 6-10 bytes per entry in LDS to group the per-tile contributions of each key, sums them in
-// registers (whole block for keys spread over many tiles) and runs the fused row update.
+// Per partition: (1) copy the entries (8 B each) into LDS and hash their keys, (2) group the
+// entries by key (counting sort), (3) ONE thread per unique key probes the var and slot tables
+// (so every row address is known before any row is touched), (4) each LPR-lane group walks a
+// contiguous chunk of the grouped contribution list: contributions are loaded RB at a time and
+// summed in registers; when a key ends inside the chunk its rows are updated on the spot; a key
+// that spans chunks (present in many tiles) meets in the LDS row of the chunk it starts in and
+// is finished after a barrier.  Work is balanced by contributions, not by keys.
 constexpr int TBS = 256;
-constexpr int HSS = 2048;
+constexpr int HSS = 1024;
 constexpr int UCAPS = HSS * 3 / 4;
-constexpr int ECAPS = 2560;
-constexpr int HMAXS = 16;                  // pre-summed heavy keys per round kept in LDS
-constexpr unsigned LOC_LDS = 0xFFFFFFF0u;  // gradient locator: row of the block's LDS hsum
+constexpr int ECAPS = 1792;
+constexpr int TPT = 8;  // tiles per thread whose segment bounds are kept in registers
+constexpr int HMAXS = 16;                  // heavy keys per round folded by the whole block (the rest
+                                           // are summed by single groups)
+constexpr unsigned LOC_LDS = 0xFFFFFFE0u;  // gradient locator: row of the block's LDS hsum
 
-__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int D, int lpr) {
-  size_t b = (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16;  // hkey, hval
+__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, int lpr) {
+  size_t b = (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16 + (size_t)(HSS + 1) * 2 + 16;  // hkey, hval, hu
   b += (size_t)ECAPS * 4 + 16 + (size_t)ECAPS * 2 * 2 + 32;            // eb, eslot, perm
   b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
-  b += (size_t)(TBS / lpr) * D * 4 + 16;                               // red
+  b += (size_t)UCAPS * 4 * 2 + 32 + (size_t)UCAPS + 16;                // utag, ur0, unew
+  if (opt == OPT_FTRL) b += (size_t)UCAPS * 4 + 16;                    // ur1
   b += (size_t)HMAXS * D * 4 + 16;                                     // hsum
-  if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16 + (size_t)(HSS + 1) * 4 + 16;  // eloc, hrow
+  if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16;                 // eloc
   return b;
 }
 
-// leader lane: var + slot table probes of one key, issued together.
+// one thread: var + slot table probes of one key, read-only probes first so the loads overlap.
 // FindOrInsertUnsafe(var, filter_out != nullptr) kv_variable.h:382-408 and
 // FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear before accum (training_ops.cc:701-704)
 template <int OPT>
 __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
-                                                bool* vnew, unsigned* r0, bool* new0, unsigned* r1,
-                                                bool* new1) {
-  // read-only probes first: independent loads overlap; inserts (rare) afterwards
+                                                unsigned* r0, unsigned* r1, unsigned* newbits) {
   unsigned rv = table_find(a.tv, key);
   unsigned s0 = table_find(a.ts0, key);
   unsigned s1 = (OPT == OPT_FTRL) ? table_find(a.ts1, key) : 0u;
-  *vnew = false; *new0 = false; *new1 = false;
+  bool vnew = false, new0 = false, new1 = false;
   if (rv == 0) {
-    rv = table_find_or_insert(a.tv, key, vnew);
-    if (rv && *vnew) { *freq_ptr(a.tv, rv) = 1u; *flags_ptr(a.tv, rv) = 0; }
+    rv = table_find_or_insert(a.tv, key, &vnew);
+    if (rv && vnew) { *freq_ptr(a.tv, rv) = 1u; *flags_ptr(a.tv, rv) = 0; }  // table_manager.h:94
   }
-  *tag = rv;
-  *r0 = 0; *r1 = 0;
+  *tag = rv; *r0 = 0; *r1 = 0; *newbits = vnew ? 1u : 0u;
   if (rv == 0) return;
-  if (!*vnew) {
+  if (!vnew) {
     const unsigned f = *freq_ptr(a.tv, rv);
     if ((f & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
     unsigned char* fl = flags_ptr(a.tv, rv);
     if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;  // RemoveBlacklistUnsafe: fresh zero row (ours already is)
   }
+  auto touch = [&](const TableDev& t, unsigned r, bool isnew) {
+    unsigned* fp = freq_ptr(t, r);
+    if (isnew) { *fp = 1u; return; }
+    unsigned lo = (*fp & 0xFFFFu) + 1u;   // AddFrequency(1, today) kv_variable.h:409-414
+    if (lo > 65535u) lo = 65535u;
+    *fp = (a.day << 16) | lo;
+  };
   if (OPT == OPT_FTRL) {
-    if (s1 == 0) s1 = table_find_or_insert(a.ts1, key, new1);
-    if (s1) {
-      unsigned* fp = freq_ptr(a.ts1, s1);
-      if (*new1) *fp = 1u;
-      else { unsigned lo = (*fp & 0xFFFFu) + 1u; if (lo > 65535u) lo = 65535u; *fp = (a.day << 16) | lo; }
-    }
+    if (s1 == 0) s1 = table_find_or_insert(a.ts1, key, &new1);
+    if (s1) touch(a.ts1, s1, new1);
     *r1 = s1;
   }
-  if (s0 == 0) s0 = table_find_or_insert(a.ts0, key, new0);
-  if (s0) {
-    unsigned* fp = freq_ptr(a.ts0, s0);
-    if (*new0) *fp = 1u;
-    else { unsigned lo = (*fp & 0xFFFFu) + 1u; if (lo > 65535u) lo = 65535u; *fp = (a.day << 16) | lo; }
-  }
+  if (s0 == 0) s0 = table_find_or_insert(a.ts0, key, &new0);
+  if (s0) touch(a.ts0, s0, new0);
   *r0 = s0;
+  *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
 }
 
 template <int MODE, int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.tv.dim;
-  char* sp = smem_raw;
-  auto take = [&](size_t bytes) { char* q = sp; sp += (bytes + 15) & ~(size_t)15; return q; };
+  char* smp = smem_raw;
+  auto take = [&](size_t bytes) { char* q = smp; smp += (bytes + 15) & ~(size_t)15; return q; };
   long long* hkey = reinterpret_cast<long long*>(take((size_t)(HSS + 1) * 8));
-  unsigned* hval = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));  // entries, then perm offset
+  unsigned* hval = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));  // entries, then cnt<<16 | offset
+  unsigned short* hu = reinterpret_cast<unsigned short*>(take((size_t)(HSS + 1) * 2));  // slot -> unique idx
   unsigned* eb = reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4));        // gradient locator
   unsigned short* eslot = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));
   unsigned short* perm = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));  // rank, then grouped entries
   unsigned short* ulist = reinterpret_cast<unsigned short*>(take((size_t)UCAPS * 2));
   unsigned* wtot = reinterpret_cast<unsigned*>(take(64));
-  float* red = reinterpret_cast<float*>(take((size_t)(TBS / LPR) * D * 4));
-  float* hsum = reinterpret_cast<float*>(take((size_t)HMAXS * D * 4));
-  unsigned* eloc = nullptr;
-  unsigned* hrow = nullptr;
-  if (MODE == MODE_DEDUP) {
-    eloc = reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4));
-    hrow = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));
-  }
+  unsigned* utag = reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4));  // dedup: dense output index
+  unsigned* ur0 = reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4));
+  unsigned* ur1 = (OPT == OPT_FTRL) ? reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4)) : ur0;
+  unsigned char* unew = reinterpret_cast<unsigned char*>(take((size_t)UCAPS));
+  float* hsum = reinterpret_cast<float*>(take((size_t)HMAXS * D * 4));  // sums of the heavy keys
+  unsigned* eloc = (MODE == MODE_DEDUP) ? reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4)) : nullptr;
   __shared__ unsigned lnu, lsent, lbase, lovf;
 
   const int tid = threadIdx.x;
@@ -702,52 +729,91 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
   const unsigned grp = tid / LPR;
   KV_STAMPP(0);
 
-  unsigned R = 1;
-  for (unsigned round = 0; round < R; ++round) {
-    // ---- entries of this round: count, then copy in a deterministic order ---------------------
-    unsigned cnt = 0;
-    for (unsigned t = tid; t < NT; t += TBS) {
+  // segment bounds of this thread's tiles, loaded together (independent loads) and kept
+  unsigned short so[TPT][2];
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const unsigned t = tid + q * TBS;
+    so[q][0] = so[q][1] = 0;
+    if (t < NT) {
       const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-      const unsigned s0 = to[0], s1 = to[1];
-      if (R == 1) cnt += s1 - s0;
+      so[q][0] = to[0]; so[q][1] = to[1];
+    }
+  }
+
+  __shared__ unsigned stkR[24], stkr[24];
+  __shared__ int sp;
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
+  __syncthreads();
+  auto split = [&](unsigned R, unsigned round) {  // replace class (R, round) by its two halves
+    __syncthreads();
+    if (tid == 0 && sp + 2 <= 24) {
+      stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+      stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+    }
+    __syncthreads();
+  };
+  while (sp > 0) {
+    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+    __syncthreads();
+    if (tid == 0) --sp;
+    // ---- entries of this class: count, then copy in a deterministic order ---------------------
+    unsigned cnt = 0;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      if (R == 1) cnt += (unsigned)so[q][1] - (unsigned)so[q][0];
       else
-        for (unsigned e = s0; e < s1; ++e) cnt += in_round(w.ent_key[(size_t)t * TILE + e], R, round);
+        for (unsigned e = so[q][0]; e < so[q][1]; ++e)
+          cnt += in_round(w.ent_key[(size_t)(tid + q * TBS) * TILE + e], R, round);
     }
     unsigned Er;
     unsigned pos = block_excl_scan<TBS / 64>(cnt, wtot, &Er);
-    if (Er == 0) { if (R == 1) return; __syncthreads(); continue; }
-    if (Er > (unsigned)ECAPS) {  // block-uniform
-      R = R * 2;
-      round = (unsigned)-1;
-      __syncthreads();
+    if (Er == 0) { __syncthreads(); continue; }
+    if (Er > (unsigned)ECAPS) {  // block-uniform; nothing of this class has been applied yet
+      split(R, round);
       continue;
     }
     for (int s = tid; s <= HSS; s += TBS) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
+    for (unsigned x = tid; x < (unsigned)HMAXS * (unsigned)D; x += TBS) hsum[x] = 0.f;
     if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
     __syncthreads();
-    for (unsigned t = tid; t < NT; t += TBS) {
-      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-      const unsigned s0 = to[0], s1 = to[1];
-      for (unsigned e = s0; e < s1; ++e) {
-        const size_t ge = (size_t)t * TILE + e;
-        const long long key = w.ent_key[ge];
-        if (!in_round(key, R, round)) continue;
-        if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
-        bool first;
-        const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
-        if (first) ulist[atomicAdd(&lnu, 1u)] = (unsigned short)h;
-        eb[pos] = w.ent_b[ge];
-        if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
-        eslot[pos] = (unsigned short)h;
-        perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
-        ++pos;
+    {
+      // first entry of every segment is fetched eagerly (most segments hold 0 or 1 entries)
+      long long k0[TPT];
+      unsigned b0[TPT];
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        k0[q] = 0; b0[q] = 0;
+        if (so[q][0] < so[q][1]) {
+          const size_t ge = (size_t)(tid + q * TBS) * TILE + so[q][0];
+          k0[q] = w.ent_key[ge];
+          b0[q] = w.ent_b[ge];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        for (unsigned e = so[q][0]; e < so[q][1]; ++e) {
+          const size_t ge = (size_t)(tid + q * TBS) * TILE + e;
+          const long long key = (e == so[q][0]) ? k0[q] : w.ent_key[ge];
+          if (!in_round(key, R, round)) continue;
+          if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
+          bool first;
+          const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
+          if (first) {
+            const unsigned u = atomicAdd(&lnu, 1u);
+            if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
+          }
+          eb[pos] = (e == so[q][0]) ? b0[q] : w.ent_b[ge];
+          if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
+          eslot[pos] = (unsigned short)h;
+          perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
+          ++pos;
+        }
       }
     }
     __syncthreads();
-    if (lovf) {  // too many distinct keys for the LDS hash: split further
-      R = R * 2;
-      round = (unsigned)-1;
-      __syncthreads();
+    if (lovf || lnu > (unsigned)UCAPS) {  // too many distinct keys for the LDS hash: split the class
+      split(R, round);
       continue;
     }
     KV_STAMPP(1);
@@ -772,8 +838,6 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
         rank[q] = e < Er ? perm[e] : 0u;
       }
       __syncthreads();
-      // hval: count -> (count << 16 | offset) would not fit; keep counts in the high half of a
-      // second pass instead: offsets go to hval, counts are recovered as off[next] - off
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const unsigned u = tid * PER + q;
@@ -785,34 +849,111 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
         const unsigned e = tid + q * TBS;
         if (e < Er) perm[(hval[eslot[e]] & 0xFFFFu) + rank[q]] = (unsigned short)e;
       }
-      __syncthreads();
     }
-    KV_STAMPP(2);
+    // ---- one thread per unique key: table probes (apply) / output slots (dedup) ----------------
     if (MODE == MODE_DEDUP) {
       if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
       __syncthreads();
+      for (unsigned u = tid; u < nu; u += TBS) {
+        utag[u] = lbase + u;
+        const unsigned h = ulist[u];
+        a.out_keys[lbase + u] = (h == HSS) ? EMPTY_KEY : hkey[h];
+      }
+    } else {
+      for (unsigned u = tid; u < nu; u += TBS) {
+        const unsigned h = ulist[u];
+        unsigned tag, r0, r1, nb;
+        probe_for_apply<OPT>(a, (h == HSS) ? EMPTY_KEY : hkey[h], &tag, &r0, &r1, &nb);
+        utag[u] = tag; ur0[u] = r0; unew[u] = (unsigned char)nb;
+        if (OPT == OPT_FTRL) ur1[u] = r1;
+      }
     }
+    __syncthreads();
+    KV_STAMPP(2);
 
-    auto sum_slice = [&](unsigned o, unsigned j0, unsigned j1, float (&gv)[K][V]) {
-      constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-      for (unsigned jb = j0; jb < j1; jb += RB) {
-        float val[RB][K][V];
+    // finish one key whose summed gradient is in gv: optimizer update, or emit (dedup)
+    auto finish = [&](unsigned h, bool live, float (&gv)[K][V]) {
+      const unsigned u = live ? hu[h] : 0u;
+      if (MODE == MODE_APPLY) {
+        const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
+        const unsigned tag = live ? utag[u] : 0u;
+        const unsigned nb = live ? unew[u] : 0u;
+        bool big = false;
+        const bool doinit = live && (nb & 1u) && (tag & ROW_MASK);
+        if (doinit) big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
+        const bool any = group_any<LPR>(big);
+        if (doinit && lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
+        opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live ? ur0[u] : 0u, (nb & 2u) != 0,
+                                       live ? ur1[u] : 0u, (nb & 4u) != 0, live, gv, a.opt, lane);
+      } else if (live) {
+        const unsigned dense = utag[u];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
+        }
+      }
+    };
+
+    // ---- (a) keys present in many tiles (> HEAVY entries): their contributions, concatenated,
+    //      are folded by ALL groups (chunks with run detection); partial sums meet in one LDS row
+    //      per heavy key (ds_add_f32), one barrier for all of them.  Afterwards such a key looks
+    //      like a key with a single contribution (LOC_LDS) and phase (b) finishes it.
+    {
+      __shared__ unsigned short hk[HMAXS];      // slot of heavy key j
+      __shared__ unsigned hpre[HMAXS + 1];      // prefix of their entry counts
+      __shared__ unsigned lnh;
+      if (tid == 0) {
+        unsigned n = 0, run = 0;
+        for (unsigned u = 0; u < nu && n < (unsigned)HMAXS; ++u) {
+          const unsigned h = ulist[u];
+          const unsigned cn = hval[h] >> 16;
+          if (cn > (unsigned)HEAVY) { hk[n] = (unsigned short)h; hpre[n] = run; run += cn; ++n; }
+        }
+        hpre[n] = run;
+        lnh = n;
+      }
+      __syncthreads();
+      const unsigned nh = lnh;
+      if (nh > 0) {  // block-uniform
+        const unsigned Hn = hpre[nh];
+        const unsigned C = (Hn + GPB - 1) / GPB;
+        const unsigned c0 = min(Hn, grp * C), c1 = min(Hn, (grp + 1) * C);
+        constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+        unsigned j = 0;
+        while (j + 1 < nh && hpre[j + 1] <= c0) ++j;
+        float gv[K][V];
 #pragma unroll
-          for (int k = 0; k < K; ++k)
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
-          if (jb + r < j1) {
-            const unsigned loc = eb[perm[o + jb + r]];
-            if (loc >= LOC_LDS) {  // a heavy key the block pre-summed
-              const float* src = hsum + (size_t)(loc - LOC_LDS) * D;
+          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
+        auto flush = [&](unsigned jj) {
+          float* rd = hsum + (size_t)jj * D;
 #pragma unroll
-              for (int k = 0; k < K; ++k) {
-                const int e0 = (lane + k * LPR) * V;
-                if (e0 < D) ldv<V>(src + e0, val[r][k]);
-              }
-            } else {
+          for (int k = 0; k < K; ++k) {
+            const int e0 = (lane + k * LPR) * V;
+            if (e0 < D) {
+#pragma unroll
+              for (int c = 0; c < V; ++c) { atomicAdd(&rd[e0 + c], gv[k][c]); gv[k][c] = 0.f; }
+            }
+          }
+        };
+        for (unsigned vb = c0; vb < c1; vb += RB) {
+          float val[RB][K][V];
+          unsigned kj[RB];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            kj[r] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
+            const unsigned vi = vb + r;
+            if (vi < c1) {
+              unsigned jj = j;
+              while (hpre[jj + 1] <= vi) ++jj;
+              kj[r] = jj;
+              const unsigned loc = eb[perm[(hval[hk[jj]] & 0xFFFFu) + (vi - hpre[jj])]];
               const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
                                                   : a.grad + (size_t)loc * D;
 #pragma unroll
@@ -822,120 +963,101 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
               }
             }
           }
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            if (kj[r] == 0xFFFFFFFFu) continue;
+            if (kj[r] != j) { flush(j); j = kj[r]; }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
+          }
         }
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
-      }
-    };
-    // finish one key: optimizer update, or emit (dedup)
-    auto finish = [&](unsigned u, unsigned h, bool live, float (&gv)[K][V]) {
-      const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
-      if (MODE == MODE_APPLY) {
-        unsigned tag = 0, r0 = 0, r1 = 0;
-        bool vnew = false, new0 = false, new1 = false;
-        if (live && lane == 0) probe_for_apply<OPT>(a, key, &tag, &vnew, &r0, &new0, &r1, &new1);
-        tag = __shfl(tag, 0, LPR);
-        r0 = __shfl(r0, 0, LPR);
-        r1 = __shfl(r1, 0, LPR);
-        const unsigned nb = __shfl((unsigned)vnew | ((unsigned)new0 << 1) | ((unsigned)new1 << 2), 0, LPR);
-        vnew = nb & 1u; new0 = (nb >> 1) & 1u; new1 = (nb >> 2) & 1u;
-        bool big = false;
-        const bool doinit = live && vnew && (tag & ROW_MASK);
-        if (doinit) big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
-        const bool any = group_any<LPR>(big);
-        if (doinit && lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
-        opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, r0, new0, r1, new1, live, gv, a.opt, lane);
-      } else if (live) {
-        const unsigned dense = lbase + u;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
-        }
-        if (lane == 0) { a.out_keys[dense] = key; hrow[h] = dense; }
-      }
-    };
-
-    // (a) keys spread over many tiles: the whole block folds slices into one LDS row and the key
-    //     then looks like a key with a single contribution; phase (b) finishes it in parallel
-    //     with the others (beyond HMAXS such keys per round the first wave finishes in place)
-    unsigned nheavy = 0;
-    for (unsigned u = 0; u < nu; ++u) {
-      const unsigned h = ulist[u];
-      const unsigned cn = hval[h] >> 16;
-      if (cn <= (unsigned)HEAVY) continue;  // block-uniform
-      const unsigned o = hval[h] & 0xFFFFu;
-      const unsigned per = (cn + GPB - 1) / GPB;
-      float gv[K][V];
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-      sum_slice(o, min(cn, grp * per), min(cn, (grp + 1) * per), gv);
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int e0 = (lane + k * LPR) * V;
-        if (e0 < D) stv<V>(red + (size_t)grp * D + e0, gv[k]);
-      }
-      __syncthreads();
-      if (nheavy < (unsigned)HMAXS) {
-        for (int e = tid; e < D; e += TBS) {
-          float sum = 0.f;
-          for (unsigned g2 = 0; g2 < GPB; ++g2) sum += red[(size_t)g2 * D + e];  // fixed order
-          hsum[(size_t)nheavy * D + e] = sum;
-        }
-        if (tid == 0) {
-          eb[perm[o]] = LOC_LDS + nheavy;
+        if (c0 < c1) flush(j);
+        __syncthreads();
+        for (unsigned jj = tid; jj < nh; jj += TBS) {
+          const unsigned h = hk[jj];
+          const unsigned o = hval[h] & 0xFFFFu;
+          eb[perm[o]] = LOC_LDS + jj;
           hval[h] = (1u << 16) | o;
         }
-        ++nheavy;
-      } else if (tid < 64) {
-        const bool live = grp == 0;
+        __syncthreads();
+      }
+    }
+    KV_STAMPP(3);
+    // ---- (b) one group per key, keys in converged rounds: contributions and state rows are
+    //      loaded together (all addresses known), then the fused update -------------------------
+    {
+      const unsigned upad = (nu + GPB - 1) / GPB * GPB;
+      for (unsigned u = grp; u < upad; u += GPB) {
+        const bool live = u < nu;
+        const unsigned h = live ? ulist[u] : 0u;
+        const unsigned cn = live ? (hval[h] >> 16) : 0u;
+        const unsigned o = hval[h] & 0xFFFFu;
+        float gv[K][V];
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
           for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-        if (live) {
-          for (unsigned g2 = 0; g2 < GPB; ++g2) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const int e0 = (lane + k * LPR) * V;
-              if (e0 < D) {
-                float t4[V];
-                ldv<V>(red + (size_t)g2 * D + e0, t4);
-#pragma unroll
-                for (int c = 0; c < V; ++c) gv[k][c] += t4[c];
-              }
+        // touch this lane's part of the state rows now, so the update's real loads (issued after
+        // the contribution sum) hit cache instead of paying a second HBM round trip
+        float touch = 0.f;
+        if (MODE == MODE_APPLY && live) {
+          const unsigned tg = utag[hu[h]];
+          if (!(tg & ROW_FILTERED) && (tg & ROW_MASK)) {
+            const int e0 = lane * V;
+            if (e0 < D) {
+              const float* xr = row_ptr(a.tv, tg & ROW_MASK);
+              const float* sr = row_ptr(a.ts0, ur0[hu[h]]);
+              touch = xr[e0] + sr[e0];
+              if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
+              if (OPT == OPT_FTRL) touch += row_ptr(a.ts1, ur1[hu[h]])[e0];
             }
           }
         }
-        finish(u, h, live, gv);
-        if (tid == 0) hval[h] = 0xFFFFu << 16;  // done: phase (b) must skip it
+        constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+        for (unsigned jb = 0; jb < cn; jb += RB) {
+          float val[RB][K][V];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
+            if (jb + r < cn) {
+              const unsigned loc = eb[perm[o + jb + r]];
+              if (loc >= LOC_LDS) {
+                const float* src = hsum + (size_t)(loc - LOC_LDS) * D;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const int e0 = (lane + k * LPR) * V;
+                  if (e0 < D) ldv<V>(src + e0, val[r][k]);
+                }
+              } else {
+                const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
+                                                    : a.grad + (size_t)loc * D;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const int e0 = (lane + k * LPR) * V;
+                  if (e0 < D) ldv<V>(src + e0, val[r][k]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
+        }
+        asm volatile("" ::"v"(touch));  // keep the touch loads
+        finish(h, live, gv);
       }
-      __syncthreads();
-    }
-    KV_STAMPP(3);
-    // (b) everything else: one group per key
-    const unsigned upad = (nu + GPB - 1) / GPB * GPB;
-    for (unsigned u = grp; u < upad; u += GPB) {
-      const unsigned h = u < nu ? ulist[u] : 0u;
-      const unsigned cn = u < nu ? (hval[h] >> 16) : 0u;
-      const bool live = u < nu && cn != 0xFFFFu;
-      float gv[K][V];
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-      if (live) sum_slice(hval[h] & 0xFFFFu, 0, cn, gv);
-      finish(u, h, live, gv);
     }
     if (MODE == MODE_DEDUP) {
       __syncthreads();
-      for (unsigned e = tid; e < Er; e += TBS) w.ent_b[eloc[e]] = hrow[eslot[e]];
+      for (unsigned e = tid; e < Er; e += TBS) w.ent_b[eloc[e]] = utag[hu[eslot[e]]];
     }
     __syncthreads();
     KV_STAMPP(4);

@@ -395,7 +395,7 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
   constexpr bool FOLD = (MODE == MODE_APPLY || MODE == MODE_DEDUP);
   int vpl = 0;
   if (FOLD && (D & 3) == 0 && D <= 256) vpl = D <= 32 ? 1 : D <= 64 ? 2 : D <= 128 ? 4 : 8;
-#define KV_TILE(IDT, VPL) k_tile<MODE, IDT, VPL><<<grid, TB, sh, s>>>(wd, (const IDT*)ids, counts, grad, n, D)
+#define KV_TILE(IDT, VPL) k_tile<MODE, IDT, VPL><<<grid, TBT, sh, s>>>(wd, (const IDT*)ids, counts, grad, n, D)
 #define KV_TILE_V(IDT)                                        \
   do {                                                        \
     if (!FOLD || vpl == 0) KV_TILE(IDT, 0);                   \
@@ -421,7 +421,7 @@ int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
   } else {
 #define KV_PART(V, LPR, K)                                                                       \
   do {                                                                                           \
-    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, D, LPR), s>>>(wd, pa); \
+    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, OPT, D, LPR), s>>>(wd, pa); \
     return KV_OK;                                                                                \
   } while (0)
     if ((D & 3) == 0) {

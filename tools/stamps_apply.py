@@ -36,8 +36,8 @@ def rep(t, names, label):
     print("   %-34s median %8.0f  p90 %8.0f  max %8.0f" % (nm, np.median(d), np.percentile(d, 90), d.max()))
   tot = t[:, len(names)] - t[:, 0]
   print("   block total median %.0f p90 %.0f max %.0f ; kernel span %.0f cycles" % (np.median(tot), np.percentile(tot, 90), tot.max(), t[:, len(names)].max() - t[:, 0].min()))
-nt = (N + 1023) // 1024
-rep(a[:nt, :7], ["init + LDS hash insert", "compact + partition sort + entries", "slot_of_id writes", "multi-key offsets + perm", "fold small keys (1 group each)", "fold tile-hot keys + store"], "k_tile<APPLY>")
+nt = (N + 2047) // 2048
+rep(a[:nt, :7], ["init + LDS hash insert", "compact + partition sort + entries", "slot_of_id writes", "multi-key offsets + perm", "chunk fold (all multi rows)", "spanning keys store"], "k_tile<APPLY>")
 pt = a[4096:4096 + 1024]
-rep(pt[:, :5], ["count + copy entries + hash", "group entries by key", "heavy keys (block fold)", "per-key sum + probes + update"], "k_part_sum<APPLY>")
+rep(pt[:, :5], ["count + copy entries + hash", "group + probes (1 thread/key)", "heavy keys (flattened fold)", "per-key rows + update"], "k_part_sum<APPLY>")
 print("   entries/round median %d max %d ; rounds max %d ; uniques median %d max %d" % (np.median(pt[:, 8]), pt[:, 8].max(), pt[:, 9].max(), np.median(pt[:, 10]), pt[:, 10].max()))

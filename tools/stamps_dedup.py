@@ -22,7 +22,7 @@ out = torch.empty((N, D), device=dev)
 for rep in range(3):
   ids = bench.splitmix64(z.sample(N, gen))
   _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), st))
-nb = (N + 1023) // 1024
+nb = (N + 2047) // 2048
 a = np.zeros((nb, 16), np.uint64)
 L.kv_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
 L.kv_debug_read_stamps(var.ptr, a.ctypes.data, nb)
