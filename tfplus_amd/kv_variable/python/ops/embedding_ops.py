@@ -1,0 +1,170 @@
+"""embedding_lookup / embedding_lookup_sparse / safe_embedding_lookup_sparse on KvVariables —
+tfplus/kv_variable/python/ops/embedding_ops.py:48-628 restated on torch tensors.
+
+Single shard: flatten ids -> KvVariable.sparse_read_with_counts -> reshape (:80-108).
+Several shards: floor-mod partition `ids % np`, per-shard lookup, stitch back in the original
+order (:115-204).  Duplicates are NOT merged by embedding_lookup (every occurrence counts towards
+the frequency); embedding_lookup_sparse merges them with unique[_with_counts] first (:364-372).
+"""
+import collections
+
+import torch
+
+from tfplus_amd.kv_variable.python.ops import kv_variable_ops
+from tfplus_amd.kv_variable.python.ops.variable_scope import PartitionedKvVariable
+
+SparseTensor = collections.namedtuple("SparseTensor", ["indices", "values", "dense_shape"])
+
+
+def _clip(params, ids, max_norm):
+  """tf embedding_ops._clip: clip_by_norm over the embedding axes."""
+  if max_norm is None:
+    return params
+  flat = params.reshape(params.shape[0] if params.dim() > 1 else 1, -1) if params.dim() <= 2 else params
+  norm = torch.linalg.vector_norm(params, dim=-1, keepdim=True)
+  return params * torch.clamp(max_norm / torch.clamp(norm, min=1e-30), max=1.0)
+
+
+def _as_list(params):
+  if params is None or params in ((), []):
+    raise ValueError("Need at least one param")
+  if isinstance(params, PartitionedKvVariable):
+    params = list(params)
+  if not isinstance(params, (list, tuple)):
+    params = [params]
+  if not all(isinstance(p, kv_variable_ops.KvVariable) for p in params):
+    raise ValueError("All params should be KvVariable")
+  return list(params)
+
+
+def _embedding_lookup_and_transform(params, ids, partition_strategy="mod", name=None, max_norm=None,
+                                    transform_fn=None, counts=None):
+  params = _as_list(params)
+  np_ = len(params)
+  dev = params[0].device
+  ids = torch.as_tensor(ids).to(dev)
+  if np_ == 1:
+    flat = ids.reshape(-1)
+    res = params[0].sparse_read_with_counts(flat, None if counts is None else torch.as_tensor(counts).reshape(-1))
+    res = _clip(res, flat, max_norm)
+    if transform_fn:
+      res = transform_fn(res)
+    return res.reshape(tuple(ids.shape) + tuple(res.shape[1:]))
+  flat = ids.reshape(-1)
+  if counts is not None:
+    counts = torch.as_tensor(counts).reshape(-1).to(dev)
+  # "We use mod strategy for kv_variable": p = flat_ids % np, floor semantics (utility.h:90-100)
+  assign = torch.remainder(flat, np_)
+  out = None
+  for p in range(np_):
+    pidx = torch.nonzero(assign == p, as_tuple=False).reshape(-1)   # dynamic_partition keeps order
+    pids = flat.index_select(0, pidx)
+    pc = None if counts is None else counts.index_select(0, pidx)
+    res = params[p].sparse_read_with_counts(pids, pc)
+    if transform_fn:
+      res = transform_fn(_clip(res, pids, max_norm))
+    if out is None:
+      out = torch.zeros((flat.numel(),) + tuple(res.shape[1:]), dtype=res.dtype, device=dev)
+    out = out.index_copy(0, pidx, res)                               # parallel_dynamic_stitch
+  out = out.reshape(tuple(ids.shape) + tuple(out.shape[1:]))
+  if not transform_fn:
+    out = _clip(out, ids, max_norm)
+  return out
+
+
+def embedding_lookup(params, ids, partition_strategy="mod", name=None, validate_indices=True,
+                     max_norm=None):
+  """embedding_ops.py:242-276."""
+  return _embedding_lookup_and_transform(params, ids, partition_strategy, name, max_norm, None)
+
+
+def _segment_sum(data, segment_ids, n):
+  out = torch.zeros((n,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
+  return out.index_add(0, segment_ids, data)
+
+
+def embedding_lookup_sparse(params, sp_ids, sp_weights, partition_strategy="mod", name=None,
+                            combiner=None, max_norm=None):
+  """embedding_ops.py:279-441: unique ids -> lookup -> (weighted) segment sum / mean / sqrtn."""
+  if combiner is None:
+    combiner = "mean"
+  if combiner not in ("mean", "sqrtn", "sum"):
+    raise ValueError("combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  plist = _as_list(params)
+  if not isinstance(sp_ids, SparseTensor):
+    raise TypeError("sp_ids must be SparseTensor")
+  if sp_weights is not None and not isinstance(sp_weights, SparseTensor):
+    raise TypeError("sp_weights must be either None or SparseTensor")
+  dev = plist[0].device
+  seg = torch.as_tensor(sp_ids.indices).to(dev)[:, 0].to(torch.int64)
+  ids = torch.as_tensor(sp_ids.values).to(dev)
+  need_counts = plist[0].enter_threshold > 0
+  uniq, idx, cnt = torch.unique(ids, return_inverse=True, return_counts=True)
+  emb = _embedding_lookup_and_transform(plist, uniq, partition_strategy, max_norm=max_norm,
+                                        counts=cnt.to(torch.int32) if need_counts else None)
+  emb = emb.index_select(0, idx)
+  nseg = int(seg.max().item()) + 1 if seg.numel() else 0
+  if sp_weights is not None:
+    wts = torch.as_tensor(sp_weights.values, dtype=emb.dtype).to(dev).reshape(-1, 1)
+  else:
+    wts = torch.ones((ids.numel(), 1), dtype=emb.dtype, device=dev)
+  summed = _segment_sum(emb * wts, seg, nseg)
+  if combiner == "sum":
+    return summed
+  if combiner == "mean":
+    return summed / _segment_sum(wts, seg, nseg)
+  return summed / torch.sqrt(_segment_sum(wts * wts, seg, nseg))
+
+
+def safe_embedding_lookup_sparse(embedding_weights, sparse_ids, sparse_weights=None, combiner=None,
+                                 default_id=None, name=None, partition_strategy="mod", max_norm=None):
+  """embedding_ops.py:444-628.  For KvVariables ids < 0 are ordinary keys and are NOT pruned
+  (:552-556); non-positive weights are pruned unless combiner == "sum" (:557-560); empty rows are
+  filled with default_id (or read as zeros); the leading shape is restored."""
+  plist = _as_list(embedding_weights)
+  dev = plist[0].device
+  idx = torch.as_tensor(sparse_ids.indices).to(dev)
+  vals = torch.as_tensor(sparse_ids.values).to(dev)
+  shape = [int(x) for x in sparse_ids.dense_shape]
+  w = None if sparse_weights is None else torch.as_tensor(sparse_weights.values, dtype=torch.float32).to(dev)
+  # flatten all but the last dimension into rows
+  rows = 1
+  for d in shape[:-1]:
+    rows *= d
+  mult = torch.ones(len(shape) - 1, dtype=torch.int64, device=dev)
+  for i in range(len(shape) - 3, -1, -1):
+    mult[i] = mult[i + 1] * shape[i + 1]
+  row = (idx[:, :-1] * mult).sum(1)
+  keep = torch.ones_like(vals, dtype=torch.bool)
+  if w is not None and combiner != "sum":
+    keep &= w > 0
+  row, vals = row[keep], vals[keep]
+  w = None if w is None else w[keep]
+  present = torch.zeros(rows, dtype=torch.bool, device=dev)
+  present[row] = True
+  empty = torch.nonzero(~present).reshape(-1)
+  fill = 0 if default_id is None else default_id
+  row = torch.cat([row, empty])
+  vals = torch.cat([vals, torch.full((empty.numel(),), fill, dtype=vals.dtype, device=dev)])
+  if w is not None:
+    w = torch.cat([w, torch.ones(empty.numel(), device=dev)])
+  order = torch.argsort(row, stable=True)
+  row, vals = row[order], vals[order]
+  w = None if w is None else w[order]
+  ind2 = torch.stack([row, torch.zeros_like(row)], 1)
+  res = embedding_lookup_sparse(plist, SparseTensor(ind2, vals, [rows, shape[-1]]),
+                                None if w is None else SparseTensor(ind2, w, [rows, shape[-1]]),
+                                partition_strategy, name, combiner, max_norm)
+  if res.shape[0] < rows:
+    res = torch.cat([res, torch.zeros((rows - res.shape[0],) + tuple(res.shape[1:]), device=dev)])
+  if default_id is None and empty.numel():
+    res = res.index_fill(0, empty, 0.0)
+  return res.reshape(tuple(shape[:-1]) + tuple(res.shape[1:]))
+
+
+def embedding_lookup_unique(params, ids, partition_strategy="mod", name=None):
+  """embedding_ops.py:644-697: look up each distinct id once, then gather back."""
+  ids = torch.as_tensor(ids)
+  uniq, idx = torch.unique(ids.reshape(-1), return_inverse=True)
+  emb = embedding_lookup(params, uniq, partition_strategy, name)
+  return emb.index_select(0, idx.to(emb.device)).reshape(tuple(ids.shape) + tuple(emb.shape[1:]))

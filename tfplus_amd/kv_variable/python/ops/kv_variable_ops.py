@@ -1,0 +1,201 @@
+"""KvVariable — the host-side object of the reference's
+tfplus/kv_variable/python/ops/kv_variable_ops.py:539-1517, on torch tensors.
+
+A KvVariable owns one HBM hash table (gen_kv_variable_ops.kv_variable) and its [rows, dim] init
+table; lookups go through KvVariableGatherOrInsertV2 / GatherOrZerosV2 exactly as the reference's
+sparse_read does (:1057-1113), including the module-level IS_TRAINING switch (:95).  Gradients of
+a lookup come back as IndexedSlices (ids with repeats, one row per occurrence) like the registered
+gradient _GatherGrad (:1829-1856); torch.autograd carries them instead of the TF graph.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops
+
+IS_TRAINING = True  # kv_variable_ops.py:95
+
+IndexedSlices = collections.namedtuple("IndexedSlices", ["values", "indices", "dense_shape"])
+
+
+def set_training(flag):
+  global IS_TRAINING
+  IS_TRAINING = bool(flag)
+
+
+class _GatherGrad(torch.autograd.Function):
+  """KvVariableGatherOrInsertV2 with the reference's gradient: IndexedSlices(values = grad
+  reshaped [N, D], indices = ids reshaped [N]) accumulated on the variable."""
+
+  @staticmethod
+  def forward(ctx, anchor, var, ids, counts):
+    ctx.var, ctx.ids = var, ids
+    if counts is not None:
+      return gen_kv_variable_ops.kv_variable_gather_or_insert_with_counts(var.handle, ids, counts)
+    return gen_kv_variable_ops.kv_variable_gather_or_insert_v2(var.handle, ids)
+
+  @staticmethod
+  def backward(ctx, grad):
+    var, ids = ctx.var, ctx.ids
+    var._pending_grads.append(
+        IndexedSlices(grad.reshape(-1, var.embedding_dim).contiguous(), ids.reshape(-1), None))
+    return None, None, None, None
+
+
+class KvVariable(object):
+  """tfplus KvVariable(ResourceVariable) — kv_variable_ops.py:539."""
+
+  def __init__(self, initial_value=None, name=None, embedding_dim=None, key_dtype=torch.int64,
+               value_dtype=torch.float32, trainable=True, enter_threshold=0, capacity_hint=0,
+               device=None):
+    if initial_value is None:
+      raise ValueError("initial_value must be specified.")  # kv_variable_ops.py:732
+    self._name = name or "KvVariable"
+    table = torch.as_tensor(initial_value, dtype=torch.float32)
+    if table.dim() != 2:
+      raise ValueError("initial value of a KvVariable must be a [rows, embedding_dim] table")
+    self._embedding_dim = int(embedding_dim if embedding_dim is not None else table.shape[1])
+    if table.shape[1] != self._embedding_dim:
+      raise ValueError("initial value has dim %d, embedding_dim is %d" % (table.shape[1], self._embedding_dim))
+    self._key_dtype, self._dtype = key_dtype, value_dtype
+    self._trainable = bool(trainable)
+    self._enter_threshold = int(enter_threshold)
+    self.num_concat_opt_vars = 1          # kv_variable_ops.py:974-980
+    self._pending_grads = []
+    # handle = KvVariable op, initializer = InitKvVariableV2 (kv_variable_ops.py:422-444, 841-848)
+    self._handle = gen_kv_variable_ops.kv_variable(
+        [self._embedding_dim], key_dtype=key_dtype, value_dtype=value_dtype,
+        enter_threshold=enter_threshold, shared_name=self._name, capacity_hint=capacity_hint, device=device)
+    self._initial_value = table
+    self._device = torch.device("cuda", self._handle.device)
+    self._anchor = torch.zeros((), device=self._device, requires_grad=True)
+    self.initializer()
+
+  # -- graph-element look-alikes ---------------------------------------------------------------
+  def initializer(self):
+    gen_kv_variable_ops.init_kv_variable_v2(self._handle, self._initial_value)
+
+  @property
+  def handle(self):
+    return self._handle
+
+  @property
+  def name(self):
+    return self._name
+
+  @property
+  def key_dtype(self):
+    return self._key_dtype
+
+  @property
+  def dtype(self):
+    return self._dtype
+
+  @property
+  def trainable(self):
+    return self._trainable
+
+  @property
+  def enter_threshold(self):
+    return self._enter_threshold
+
+  @property
+  def embedding_dim(self):
+    return self._embedding_dim
+
+  @property
+  def device(self):
+    return self._device
+
+  @property
+  def shape(self):
+    """[keys in the table, dim] — KvVariableShapeV2."""
+    return gen_kv_variable_ops.kv_variable_shape_v2(self._handle)
+
+  def get_shape(self):
+    return [None, self._embedding_dim]
+
+  def is_initialized(self, name=None):
+    return gen_kv_variable_ops.kv_variable_is_initialized_v2(self._handle)
+
+  @property
+  def total_count(self):      # kv_variable_ops.py:992-997
+    return gen_kv_variable_ops.kv_variable_size_v2(self._handle)
+
+  @property
+  def total_freq(self):       # kv_variable_ops.py:999-1002
+    return gen_kv_variable_ops.kv_variable_frequency(self._handle)
+
+  def _read_variable_op(self):
+    """(keys, values) of the exported table — ReadKvVariableOpV2 (kv_variable_ops.py:1004-1009)."""
+    return gen_kv_variable_ops.read_kv_variable_op_v2(self._handle)
+
+  value = _read_variable_op
+  read_value = _read_variable_op
+
+  def export(self, first_n=6):
+    return gen_kv_variable_ops.kv_variable_export(self._handle, first_n=first_n)
+
+  # -- lookups ---------------------------------------------------------------------------------------
+  def sparse_read(self, indices, name=None):
+    return self.sparse_read_with_counts(indices, None, name)
+
+  def sparse_read_with_counts(self, indices, counts=None, name=None):
+    """kv_variable_ops.py:1082-1113: GatherOrInsert[WithCounts] when training, GatherOrZeros else."""
+    ids = torch.as_tensor(indices).to(self._device)
+    if not IS_TRAINING:
+      return gen_kv_variable_ops.kv_variable_gather_or_zeros_v2(self._handle, ids)
+    if self._trainable and torch.is_grad_enabled():
+      return _GatherGrad.apply(self._anchor, self, ids, counts)
+    if counts is not None:
+      return gen_kv_variable_ops.kv_variable_gather_or_insert_with_counts(self._handle, ids, counts)
+    return gen_kv_variable_ops.kv_variable_gather_or_insert_v2(self._handle, ids)
+
+  def pop_gradients(self):
+    """All IndexedSlices produced by backward passes since the last call, concatenated."""
+    g, self._pending_grads = self._pending_grads, []
+    if not g:
+      return None
+    return IndexedSlices(torch.cat([x.values for x in g]), torch.cat([x.indices for x in g]), None)
+
+  # -- scatter family (kv_variable_ops.py:1263-1338) ----------------------------------------------------
+  def _scatter(self, fn, sparse_delta):
+    if not hasattr(sparse_delta, "indices"):
+      raise TypeError("sparse_delta is not IndexedSlices: %s" % (sparse_delta,))
+    fn(self._handle, sparse_delta.indices, sparse_delta.values)
+    return self
+
+  def scatter_update(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_update_v2, sparse_delta)
+
+  def scatter_add(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_add_v2, sparse_delta)
+
+  def scatter_sub(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_sub_v2, sparse_delta)
+
+  def scatter_mul(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_mul_v2, sparse_delta)
+
+  def scatter_div(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_div_v2, sparse_delta)
+
+  def scatter_min(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_min_v2, sparse_delta)
+
+  def scatter_max(self, sparse_delta, use_locking=False, name=None):
+    return self._scatter(gen_kv_variable_ops.kv_variable_scatter_max_v2, sparse_delta)
+
+
+# module-level state_ops look-alikes (kv_variable_ops.py:1877-1923)
+def scatter_update(ref, indices, updates, use_locking=True, name=None):
+  return ref.scatter_update(IndexedSlices(updates, indices, None))
+
+
+def scatter_add(ref, indices, updates, use_locking=True, name=None):
+  return ref.scatter_add(IndexedSlices(updates, indices, None))
+
+
+def scatter_sub(ref, indices, updates, use_locking=True, name=None):
+  return ref.scatter_sub(IndexedSlices(updates, indices, None))
