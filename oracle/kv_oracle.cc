@@ -624,6 +624,104 @@ void kvo_export(void* h, int first_n, int64_t* counts, int64_t* keys, float* val
   counts[0] = nr; counts[1] = nb; counts[2] = nf;
 }
 
+// ScatterUpdate kv_variable.h:616-734.  op: 0 assign, 1 add, 2 sub, 3 mul, 4 div, 5 min, 6 max
+// (kv_variable_interface.h:44-52).  Existing key: row = op(row, update) unless blacklisted,
+// UpdateUnderThreshold, frequency untouched.  Missing key: insert (freq word 1) with the init rule,
+// then the op.
+void kvo_scatter_update(void* h, const int64_t* ids, const float* upd, int64_t n, int op) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  auto apply = [&](float* row, const float* u) {
+    for (int e = 0; e < D; ++e) {
+      float l = row[e], v = u[e], o;
+      switch (op) {
+        case 1: o = l + v; break;
+        case 2: o = l - v; break;
+        case 3: o = l * v; break;
+        case 4: o = l / v; break;
+        case 5: o = std::min(l, v); break;
+        case 6: o = std::max(l, v); break;
+        default: o = v;
+      }
+      row[e] = o;
+    }
+  };
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(ids[i])];
+    auto it = sg.map.find(ids[i]);
+    if (it != sg.map.end()) {
+      Meta* m = &it->second;
+      if (!m->in_black) { apply(m->row, upd + i * D); t->UpdateUnderThreshold(m); }
+    } else {
+      Meta m;
+      m.row = t->NewRow();
+      t->GenerateRandomInitialValue(ids[i], m.row);
+      apply(m.row, upd + i * D);
+      t->UpdateUnderThreshold(&m);
+      sg.map.insert_or_assign(ids[i], m);
+    }
+  }
+}
+
+// InsertOrUpdate kv_variable.h:423-485 (no filter / blacklist inputs): existing key: copy the
+// values (a blacklisted key stays blacklisted and keeps reading zeros), UpdateUnderThreshold;
+// missing key: insert with freq word 1 and the values.
+void kvo_insert(void* h, const int64_t* ids, const float* vals, int64_t n) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(ids[i])];
+    auto it = sg.map.find(ids[i]);
+    if (it != sg.map.end()) {
+      Meta* m = &it->second;
+      if (!m->in_black) std::memcpy(m->row, vals + i * D, sizeof(float) * size_t(D));
+      t->UpdateUnderThreshold(m);
+    } else {
+      Meta m;
+      m.row = t->NewRow();
+      std::memcpy(m.row, vals + i * D, sizeof(float) * size_t(D));
+      t->UpdateUnderThreshold(&m);
+      sg.map.insert_or_assign(ids[i], m);
+    }
+  }
+}
+
+// ImportValues dynamic_restore.hpp:176-262: clear; insert keys/values (freq word 1,
+// under_threshold left false); blacklist keys are marked (absent ones inserted as blacklisted);
+// frequency words are set on keys that exist; the table counts as initialised.
+void kvo_import(void* h, const int64_t* keys, const float* vals, int64_t n, const int64_t* black,
+                int64_t nb, const int64_t* fkeys, const uint32_t* fvals, int64_t nf) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  for (int s = 0; s < kSegments; ++s) {
+    for (auto& kv : t->seg[s].map) std::free(kv.second.row);
+    t->seg[s].map.clear();
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    Meta m;
+    m.row = t->NewRow();
+    std::memcpy(m.row, vals + i * D, sizeof(float) * size_t(D));
+    t->seg[t->SegId(keys[i])].map.insert_or_assign(keys[i], m);
+  }
+  for (int64_t i = 0; i < nb; ++i) {
+    Segment& sg = t->seg[t->SegId(black[i])];
+    auto it = sg.map.find(black[i]);
+    if (it == sg.map.end()) {
+      Meta m;
+      m.in_black = true;  // EmbeddingValue(nullptr, true, 1, ...) table_manager.h:343-346
+      sg.map.insert_or_assign(black[i], m);
+    } else {
+      t->MarkBlacklist(&it->second);
+    }
+  }
+  for (int64_t i = 0; i < nf; ++i) {
+    Segment& sg = t->seg[t->SegId(fkeys[i])];
+    auto it = sg.map.find(fkeys[i]);
+    if (it != sg.map.end()) it->second.freq = fvals[i];
+  }
+  t->initialized = true;
+}
+
 // test helper: meta of one key. returns 0 if absent.
 int kvo_get_meta(void* h, int64_t key, uint32_t* freq, int* in_black, int* under_threshold) {
   Table* t = static_cast<Table*>(h);

@@ -62,6 +62,10 @@ def lib():
     getattr(L, f).restype = ctypes.c_int64
     getattr(L, f).argtypes = [ctypes.c_void_p]
   L.kvo_export.argtypes = [ctypes.c_void_p, ctypes.c_int, _i64p, _i64p, _f32p, _i64p, _i64p, _u32p]
+  L.kvo_scatter_update.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64, ctypes.c_int]
+  L.kvo_insert.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64]
+  L.kvo_import.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64, _i64p, ctypes.c_int64, _i64p,
+                           _u32p, ctypes.c_int64]
   L.kvo_get_meta.restype = ctypes.c_int
   L.kvo_get_meta.argtypes = [ctypes.c_void_p, ctypes.c_int64, _u32p, ctypes.POINTER(ctypes.c_int),
                              ctypes.POINTER(ctypes.c_int)]
@@ -127,6 +131,21 @@ class OracleKv:
     out = np.empty((ids.size, self.dim), np.float32)
     lib().kvo_gather_or_zeros(self._h, _p(ids, _i64p), ids.size, _p(out, _f32p), self.threads)
     return out.reshape(shape + (self.dim,))
+
+  def scatter_update(self, ids, updates, op=0):
+    i, u = _ids(ids), _f32(updates)
+    lib().kvo_scatter_update(self._h, _p(i, _i64p), _p(u, _f32p), i.size, int(op))
+
+  def insert(self, ids, values):
+    i, v = _ids(ids), _f32(values)
+    lib().kvo_insert(self._h, _p(i, _i64p), _p(v, _f32p), i.size)
+
+  def import_(self, keys, values, blacklist=(), freq_keys=(), freq_values=()):
+    k, v = _ids(keys), _f32(values)
+    b, fk = _ids(blacklist), _ids(freq_keys)
+    fv = np.ascontiguousarray(np.asarray(freq_values).reshape(-1), dtype=np.uint32)
+    lib().kvo_import(self._h, _p(k, _i64p), _p(v, _f32p), k.size, _p(b, _i64p), b.size, _p(fk, _i64p),
+                     _p(fv, _u32p), fk.size)
 
   def size(self):
     return int(lib().kvo_size(self._h))

@@ -1,0 +1,150 @@
+"""scatter family, insert, import / export — oracle KATs on the CPU,
+parity on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import kv_oracle as ko
+
+DAY = 20000
+# KvVariableTest.ScatterUpdate (kernels/kv_variable_test.cc:226-357): keys 0..9, dim 64, random
+# init table; assign 1 -> 1; add 1 -> 2; sub 1 -> 1; mul 2 -> 2; div 2 -> 1; min 2 -> 1; max 2 -> 2
+S1_CHAIN = [(0, 1.0, 1.0), (1, 1.0, 2.0), (2, 1.0, 1.0), (3, 2.0, 2.0), (4, 2.0, 1.0), (5, 2.0, 1.0), (6, 2.0, 2.0)]
+
+
+def test_S1_scatter_chain_oracle():
+  rng = np.random.default_rng(0)
+  kv = ko.OracleKv(64, 0, rng.random((1024, 64)).astype(np.float32), day=DAY)
+  keys = np.arange(10)
+  for op, upd, want in S1_CHAIN:
+    kv.scatter_update(keys, np.full((10, 64), upd, np.float32), op)
+    np.testing.assert_array_equal(kv.gather_or_zeros(keys), np.full((10, 64), want, np.float32))
+  assert kv.map_size() == 10 and kv.sum_freq() == 10      # inserted with freq word 1, never bumped
+
+
+def test_import_export_roundtrip_oracle():
+  rng = np.random.default_rng(1)
+  a = ko.OracleKv(8, 2, rng.standard_normal((64, 8)).astype(np.float32), day=DAY)
+  a.gather_or_insert(rng.integers(0, 50, 400))
+  s = ko.OracleKv(24, 0, np.zeros((4, 24), np.float32), day=DAY)
+  g = (rng.standard_normal((50, 8)) * rng.uniform(1e-4, 3e-2, (50, 1))).astype(np.float32)
+  ko.apply_group_adam(a, s, g, np.arange(50), 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8, 1e-4, 1e-2, 4e-3)  # some rows blacklist
+  k, v, bl, fk, fv = a.export(first_n=6)
+  assert len(bl) > 0 and len(k) > 0
+  b = ko.OracleKv(8, 2, np.zeros((4, 8), np.float32), day=DAY)
+  b.import_(k, v, bl, fk, fv)
+  k2, v2, bl2, fk2, fv2 = b.export(first_n=6)
+  assert dict(zip(k, map(bytes, v))) == dict(zip(k2, map(bytes, v2)))
+  assert sorted(bl) == sorted(bl2) and dict(zip(fk, fv)) == dict(zip(fk2, fv2))
+  assert a.size() == b.size() and a.sum_freq() == b.sum_freq()
+
+
+# ----------------------------------------------------------------------------------------------------
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+def _pair(ops, D, thr=0, seed=3, rows=64):
+  table = np.random.default_rng(seed).standard_normal((rows, D)).astype(np.float32)
+  h = ops.kv_variable([D], enter_threshold=thr)
+  ops.kv_set_clock_days(h, DAY)
+  ops.kv_set_seed(h, seed)
+  ops.init_kv_variable_v2(h, table)
+  return h, ko.OracleKv(D, thr, table, day=DAY, picker=1, seed=seed)
+
+
+def _same(ops, h, o, keys):
+  keys = np.unique(np.asarray(keys, np.int64))
+  np.testing.assert_array_equal(ops.kv_variable_gather_or_zeros_v2(h, keys).cpu().numpy(), o.gather_or_zeros(keys))
+  assert ops.kv_get_meta(h, keys) == [o.meta(int(k)) for k in keys]
+  assert ops.kv_variable_shape_v2(h) == [o.map_size(), o.dim]
+  assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_frequency(h) == o.sum_freq()
+
+
+@pytest.mark.gpu
+def test_S1_scatter_chain_gpu(ops):
+  h, _ = _pair(ops, 64, rows=1024)
+  keys = np.arange(10)
+  fns = [ops.kv_variable_scatter_update_v2, ops.kv_variable_scatter_add_v2, ops.kv_variable_scatter_sub_v2,
+         ops.kv_variable_scatter_mul_v2, ops.kv_variable_scatter_div_v2, ops.kv_variable_scatter_min_v2,
+         ops.kv_variable_scatter_max_v2]
+  for (op, upd, want), fn in zip(S1_CHAIN, fns):
+    fn(h, keys, np.full((10, 64), upd, np.float32))
+    assert bool((ops.kv_variable_gather_or_zeros_v2(h, keys) == want).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [1, 8, 32, 50])
+def test_scatter_and_insert_parity(ops, D):
+  rng = np.random.default_rng(70 + D)
+  h, o = _pair(ops, D, thr=2)
+  warm = rng.integers(0, 300, 2000)
+  ops.kv_variable_gather_or_insert_v2(h, warm)
+  o.gather_or_insert(warm)
+  seen = [warm]
+  for op in range(7):
+    ids = rng.choice(600, 250, replace=False).astype(np.int64)      # hits and fresh keys
+    upd = rng.uniform(0.5, 2.0, (ids.size, D)).astype(np.float32)
+    ops._scatter(op)(h, ids, upd)
+    o.scatter_update(ids, upd, op)
+    seen.append(ids)
+    _same(ops, h, o, np.concatenate(seen))
+  ids = rng.choice(900, 400, replace=False).astype(np.int64)
+  vals = rng.standard_normal((ids.size, D)).astype(np.float32)
+  vals[::7] = 0.0                                                   # all-zero rows -> under_threshold
+  ops.kv_variable_insert_v2(h, ids, vals)
+  o.insert(ids, vals)
+  _same(ops, h, o, np.concatenate(seen + [ids]))
+
+
+@pytest.mark.gpu
+def test_import_export_parity(ops):
+  rng = np.random.default_rng(5)
+  D = 16
+  hv, ov = _pair(ops, D, thr=2)
+  hs, os_ = _pair(ops, 3 * D, seed=9)
+  for t in (hs, os_):
+    pass
+  ids = rng.integers(0, 400, 3000)
+  ops.kv_variable_gather_or_insert_v2(hv, ids)
+  ov.gather_or_insert(ids)
+  u = np.unique(ids)
+  g = (rng.standard_normal((u.size, D)) * rng.uniform(1e-4, 3e-2, (u.size, 1))).astype(np.float32)
+  hz = ops.kv_variable([3 * D]); ops.init_kv_variable_v2(hz, np.zeros((4, 3 * D), np.float32)); ops.kv_set_clock_days(hz, DAY)
+  oz = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
+  ops.kv_variable_group_sparse_apply_adam_v4(hv, hz, g, u, 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8, 1e-4, 1e-2, 5e-3)
+  ko.apply_group_adam(ov, oz, g, u, 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8, 1e-4, 1e-2, 5e-3)
+  for first_n in (2, 3, 4, 6):
+    gk, gv, gb, gfk, gfv = [x.cpu().numpy() for x in ops.kv_variable_export(hv, first_n=first_n)]
+    ok, ovv, ob, ofk, ofv = ov.export(first_n=first_n)
+    assert sorted(gk) == sorted(ok) and sorted(gb) == sorted(ob)
+    assert dict(zip(gfk, gfv.view(np.uint32))) == dict(zip(ofk, ofv))
+    got, exp = dict(zip(gk, gv)), dict(zip(ok, ovv))
+    for k in ok:
+      np.testing.assert_allclose(got[k], exp[k], rtol=1e-3, atol=1e-8)  # group-lasso scale amplifies ulps (see test_gpu_parity)
+  assert len(gb) > 20 and len(gk) > 20                # both populations present
+  # import what the GPU exported into a fresh GPU table and into a fresh oracle table
+  h2 = ops.kv_variable([D], enter_threshold=2); ops.kv_set_clock_days(h2, DAY)
+  o2 = ko.OracleKv(D, 2, np.zeros((4, D), np.float32), day=DAY)
+  assert not ops.kv_variable_is_initialized_v2(h2)
+  ops.kv_variable_import(h2, gk, gv, gb, gfk, gfv.view(np.uint32))
+  o2.import_(gk, gv, gb, gfk, gfv.view(np.uint32))
+  assert ops.kv_variable_is_initialized_v2(h2)
+  keys = np.concatenate([gk, gb, np.array([10**6])])
+  _same(ops, h2, o2, keys)
+  k3, v3, b3, fk3, fv3 = [x.cpu().numpy() for x in ops.kv_variable_export(h2, first_n=6)]
+  assert dict(zip(k3, map(bytes, v3))) == dict(zip(gk, map(bytes, gv))) and sorted(b3) == sorted(gb)
+  # keys below enter_threshold are in neither keys nor blacklist, so their frequency words have no
+  # key to land on (UpdateWithFn finds nothing, dynamic_restore.hpp:232-246): compare with the oracle
+  _, _, _, ofk3, ofv3 = o2.export(first_n=6)
+  assert dict(zip(fk3, fv3.view(np.uint32))) == dict(zip(ofk3, ofv3))
+  assert set(fk3) <= set(gfk)
+  # importing again replaces the content (table_->clear(), dynamic_restore.hpp:178)
+  ops.kv_variable_import(h2, gk[:5], gv[:5])
+  assert ops.kv_variable_shape_v2(h2) == [5, D]

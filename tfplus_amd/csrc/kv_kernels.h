@@ -502,8 +502,10 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
       const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
       if (!occ) continue;
       const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
-      bool isnew;
-      const unsigned r = table_find_or_insert(a.tv, key, &isnew);
+      bool isnew = false;
+      // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
+      const unsigned r = (MODE == MODE_MARK && a.mark_what == 1) ? table_find(a.tv, key)
+                                                                 : table_find_or_insert(a.tv, key, &isnew);
       hrow[s] = r;
       if (r == 0) continue;
       unsigned* fp = freq_ptr(a.tv, r);
@@ -553,10 +555,11 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
               *freq_ptr(a.tv, r) = a.fvals[hval[s]];
             }
           } else {
-            // ScatterUpdate kv_variable.h:616-734 leaves blacklisted rows alone (:690);
-            // InsertOrUpdate :423-485 overwrites
+            // ScatterUpdate kv_variable.h:616-734 leaves blacklisted rows alone (:690).
+            // InsertOrUpdate :423-485 copies the values but the key stays blacklisted and keeps
+            // reading zeros (table_manager.h:224-226), so the zeroed row is left as it is too.
             const unsigned fl = isnew ? 0u : *flags_ptr(a.tv, r);
-            touch = a.is_insert || !(fl & FLAG_BLACK);
+            touch = !(fl & FLAG_BLACK);
             const float* src = a.grad + (size_t)hval[s] * D;
             if (touch) {
               big = false;
@@ -586,8 +589,11 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
             const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
             *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
           } else if (MODE == MODE_MARK) {
-            if (a.mark_what == 0) *fp = (unsigned char)(FLAG_BLACK | FLAG_UNDER);
-            else if (isnew) *fp = (unsigned char)(any ? 0u : FLAG_UNDER);
+            // a key first seen by the blacklist is inserted blacklisted with under_threshold
+            // still false (EmbeddingValue(nullptr, true, 1, ...), table_manager.h:343-346)
+            if (a.mark_what == 0) *fp = (unsigned char)(isnew ? FLAG_BLACK : (FLAG_BLACK | FLAG_UNDER));
+          } else if (a.is_insert == 2) {
+            if (isnew) *fp = 0;  // ImportValues does not evaluate under_threshold (dynamic_restore.hpp:183-194)
           } else if (touch || isnew) {
             const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
             *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));

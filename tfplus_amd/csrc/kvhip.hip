@@ -575,7 +575,8 @@ int kv_init_table(kv_handle_t t, const float* table, int64_t rows, kv_stream_t s
   if (!table || rows <= 0) return fail(KV_INVALID_ARGUMENT, "random_initializer must be a non-empty [rows, dim] matrix");
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  if (t->initialized) return KV_OK;  // "re-initialization ignored" kv_variable.h:188-193
+  if (t->initialized && t->init_rows > 1) return KV_OK;  // "re-initialization ignored" kv_variable.h:188-193
+  if (t->init_table) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); hipFree(t->init_table); t->init_table = nullptr; }
   HIP_TRY(hipMalloc(&t->init_table, (size_t)rows * t->dim * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(t->init_table, table, (size_t)rows * t->dim * sizeof(float),
                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1025,12 +1026,21 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   // clear(): dynamic_restore.hpp:60-62
   HIP_TRY(hipStreamSynchronize(s));
   unsigned init[2] = {1, 0};
-  HIP_TRY(hipMemcpyAsync(t->d_counters, init, sizeof init, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpy(t->d_counters, init, sizeof init, hipMemcpyHostToDevice));  // stack source: synchronous
   k_fill_entries<<<nblocks((long long)t->cap + 1, TB, 8192), TB, 0, s>>>(t->entries, t->cap + 1);
   t->rows_ub = 1;
-  if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 1, -1, nullptr, s))) return rc;
+  if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 2, -1, nullptr, s))) return rc;
   if (n_black > 0 && (rc = scatter_like(t, blacklist, nullptr, n_black, 0, 1, 0, nullptr, s))) return rc;
   if (n_freq > 0 && (rc = scatter_like(t, fkeys, nullptr, n_freq, 0, 1, 1, fvals, s))) return rc;
+  if (!t->init_table) {
+    // the import marks the variable initialised (dynamic_restore.hpp:249-255).  The checkpoint's
+    // init table is the caller's to pass through kv_init_table; without one, keys inserted later
+    // start from a one-row zero table instead of dereferencing nothing.
+    HIP_TRY(hipMalloc(&t->init_table, (size_t)t->dim * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(t->init_table, 0, (size_t)t->dim * sizeof(float), s));
+    t->init_rows = 1;
+  }
+  t->initialized = true;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
