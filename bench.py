@@ -118,6 +118,8 @@ def main():
   ap.add_argument("--cpu-keys", type=int, default=2_000_000)
   ap.add_argument("--cpu-steps", type=int, default=3)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--force-sharded", action="store_true",
+                  help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -128,20 +130,26 @@ def main():
       sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
-  if world > 1:
+  shard_path = world > 1 or args.force_sharded
+  if shard_path:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
   from tfplus_amd import _lib
   from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
   L = _lib.lib()
 
-  D, N, K = args.dim, args.batch, args.keys
+  D, N = args.dim, args.batch
+  # weak scaling: every rank owns ~args.keys keys of a table of args.keys * world keys, sharded by
+  # floor_mod(key, world) (the reference's partition rule), and feeds its own batch of N ids
+  K = args.keys * world
+  K_local = args.keys if world == 1 else int(args.keys * 1.05) + 1024
   gen = torch.Generator(device=dev).manual_seed(SEED + rank)
-  table = (torch.randn(10000, D, device=dev, generator=gen) * 0.05)
-  var = ops.kv_variable([D], capacity_hint=K + 4 * N, device=local)
-  slot = ops.kv_variable([3 * D], capacity_hint=K + 4 * N, device=local)
+  table = (torch.randn(10000, D, device=dev, generator=torch.Generator(device=dev).manual_seed(SEED)) * 0.05)
+  var = ops.kv_variable([D], capacity_hint=K_local + 4 * N, device=local)
+  slot = ops.kv_variable([3 * D], capacity_hint=K_local + 4 * N, device=local)
   ops.init_kv_variable_v2(var, table)
   ops.init_kv_variable_v2(slot, torch.zeros(16, 3 * D, device=dev))
   stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -149,14 +157,20 @@ def main():
   # ---- pre-insert K keys (ids = splitmix64(rank)); optimizer state rows too: steady state ----
   CH = 1 << 22
   buf = torch.empty((CH, 3 * D), dtype=torch.float32, device=dev)
+  owned = 0
   for i in range(0, K, CH):
     r = torch.arange(i + 1, min(i + CH, K) + 1, dtype=torch.int64, device=dev)
     keys = splitmix64(r)
+    if world > 1:
+      keys = keys[torch.remainder(keys, world) == rank].contiguous()
+    owned += keys.numel()
+    if keys.numel() == 0:
+      continue
     _lib.check(L.kv_gather_or_insert(var.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), stream))
     _lib.check(L.kv_gather_or_insert(slot.ptr, keys.data_ptr(), None, keys.numel(), buf.data_ptr(), stream))
   torch.cuda.synchronize()
   del buf
-  assert ops.kv_variable_shape_v2(var)[0] == K, ops.kv_variable_shape_v2(var)
+  assert ops.kv_variable_shape_v2(var)[0] == owned, (ops.kv_variable_shape_v2(var), owned)
 
   # ---- synthetic batches, resident in HBM ----
   z = Zipf(K, args.zipf, dev)
@@ -181,12 +195,40 @@ def main():
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
+  class LocalShard(object):
+    """The rank's table behind the calls ShardedKvVariable makes (C ABI, no allocation per step
+    beyond the served-rows buffer)."""
+
+    def sparse_read_with_counts(self, served, counts=None):
+      rows = torch.empty((served.numel(), D), dtype=torch.float32, device=dev)
+      if served.numel():
+        cp = None if counts is None else ctypes.c_void_p(counts.data_ptr())
+        _lib.check(L.kv_gather_or_insert(var.ptr, served.data_ptr(), cp, served.numel(), rows.data_ptr(), stream))
+      return rows
+
+    def apply(self, g, served):
+      if served.numel():
+        _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, g.data_ptr(), served.data_ptr(), served.numel(), 1e-3,
+                                         float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
+                                         0.0, 4, stream))
+
+  if shard_path:
+    from tfplus_amd.kv_variable.python.ops import sharded
+    skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
+                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
+                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g))
+
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
-    _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), stream))
-    _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
-                                     float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
-                                     0.0, 4, stream))
+    if not shard_path:
+      _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), stream))
+      _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
+                                       float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
+                                       0.0, 4, stream))
+    else:
+      # ids -> owners (all_to_all over xGMI) -> rows back; then (ids, grads) -> owners -> fused apply
+      skv.lookup(ids)
+      skv.apply_gradients(lambda sh, g, served: sh.apply(g, served), grad, ids)
     state["b1p"] = np.float32(state["b1p"] * np.float32(0.9))      # TF-core Adam _finish
     state["b2p"] = np.float32(state["b2p"] * np.float32(0.999))
 
@@ -250,10 +292,12 @@ def main():
       "vs_baseline": None,
       "dtype": "f32",
       "data": "synthetic",
-      "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d, %d ids/batch Zipf(%.1f), lookup + sparse "
-                             "GroupAdam apply" % (K // 1_000_000, D, N, args.zipf),
-                 "keys": K, "dim": D, "batch": N, "unique_per_batch": Ub, "tile_single_rows_per_batch": Sb,
-                 "parallelism": "1 table shard per GPU" if world > 1 else "single GPU"},
+      "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d per GPU, %d ids/batch per GPU Zipf(%.1f), "
+                             "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
+                 "keys": K, "dim": D, "batch": N, "global_batch": N * world, "unique_per_batch": Ub,
+                 "tile_single_rows_per_batch": Sb,
+                 "parallelism": ("table hash-sharded over %d GPUs (id mod G), all_to_all id/row/grad exchange "
+                                 "over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]},
@@ -272,7 +316,7 @@ def main():
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
     print(json.dumps(res))
-  if world > 1:
+  if shard_path:
     dist.destroy_process_group()
 
 

@@ -170,6 +170,24 @@ int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv
 int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
                       kv_stream_t stream);
 
+/* tf.unique_with_counts on the GPU (what embedding_lookup_sparse runs before the lookup,
+ * python/ops/embedding_ops.py:362-372, and what the sharded path runs before the exchange):
+ * uniq [n] / uniq_counts [n] (may be NULL; per-occurrence `counts` or 1 each, summed, saturating at
+ * 65535 like the frequency they feed) are filled for the first *num_unique entries, inverse [n]
+ * (may be NULL) maps input positions to them.  Order unspecified.  Synchronous. */
+int kv_unique(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq,
+              int32_t* uniq_counts, int32_t* inverse, int64_t* num_unique, kv_stream_t stream);
+
+/* ---- multi-GPU routing helper (new design; the reference has no communication
+ * layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
+ * kernels/utility.h:90-107 ModKeyImpl, kept here) ----------------------------------------------
+ * Counting sort of `ids` [n] by owner rank floor_mod(id, world): out_ids [n] holds the ids grouped
+ * by owner (rank 0's first), perm[j] = input position of out_ids[j], counts_dev[world] (device,
+ * int64) = ids per owner — the send counts of the all-to-all.  `h` supplies device, key dtype and
+ * scratch only. */
+int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, int world, int64_t* out_ids,
+                       int32_t* perm, int64_t* counts_dev, kv_stream_t stream);
+
 /* ---- measurement hooks (no reference counterpart; the reference only VLOGs wall time,
  * kernels/training_ops.cc:6989,7211) -----------------------------------------------------------
  * kv_profile_enable(h, max_launches > 0) brackets every kernel this table launches with a pair

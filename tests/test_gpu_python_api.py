@@ -159,3 +159,17 @@ def test_minimize_through_autograd_matches_manual_apply(api):
   api.kv.set_training(False)
   assert torch.equal(api.eo.embedding_lookup(kv1, probe), api.eo.embedding_lookup(kv2, probe))
   assert o1.get_slot(kv1, "m_v_linear").shape[0] == 3 and kv1.num_concat_opt_vars == 3
+
+
+def test_bucket_by_owner_matches_floor_mod(api):
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  h = g.kv_variable([4])
+  rng = np.random.default_rng(2)
+  for world in (1, 2, 3, 8):
+    ids = torch.from_numpy(rng.integers(-10**12, 10**12, 5000))
+    out, perm, counts = g.kv_bucket_by_owner(h, ids, world)
+    own = np.mod(ids.numpy(), world)                     # numpy mod is floor-mod like utility.h:90-107
+    assert counts.cpu().tolist() == np.bincount(own, minlength=world).tolist()
+    o, p = out.cpu().numpy(), perm.cpu().numpy()
+    assert sorted(p.tolist()) == list(range(5000)) and np.array_equal(o, ids.numpy()[p])
+    assert np.all(np.diff(np.mod(o, world)) >= 0)        # grouped by owner, rank 0 first

@@ -225,4 +225,7 @@ def test_multithreaded_matches_single_thread():
   ko.apply_group_adam(a, sa, s, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
   ko.apply_group_adam(b, sb, s, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
   np.testing.assert_array_equal(a.gather_or_zeros(u), b.gather_or_zeros(u))
-  assert a.sum_freq() == b.sum_freq() == ids.size
+  # the reference bumps the frequency under a SHARED segment lock (kv_variable.h:320-332 inside
+  # table_manager.h:167-190), so concurrent hits on one key can lose counts: only the
+  # single-threaded sum is exact
+  assert a.sum_freq() == ids.size and b.sum_freq() <= ids.size

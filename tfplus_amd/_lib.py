@@ -55,6 +55,8 @@ SIGNATURES = {
     "kv_import": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "kv_unique": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
+    "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "kv_profile_enable": (_i32, [_vp, _i32]),
     "kv_profile_read": (_i32, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i32]),
 }

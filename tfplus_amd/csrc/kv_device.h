@@ -29,7 +29,7 @@ constexpr int HS = 4096;         // its LDS hash slots
 constexpr int HEAVY = 32;        // entries of one key in one partition above which the block folds it
 constexpr int MAX_CHUNKS = 1024;
 
-enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4 };
+enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4, MODE_UNIQUE = 5 };
 enum Opt { OPT_ADAM_V4 = 0, OPT_ADAM_V3 = 1, OPT_ADAGRAD = 2, OPT_FTRL = 3 };
 
 struct __attribute__((aligned(16))) Entry {

@@ -388,8 +388,9 @@ struct PartArgs {
   int scatter_op, is_insert;  // MODE_SCATTER
   int mark_what;              // MODE_MARK: 0 = blacklist, 1 = frequency words (in fvals)
   const unsigned* fvals;
-  long long* out_keys;        // MODE_DEDUP
+  long long* out_keys;        // MODE_DEDUP / MODE_UNIQUE
   float* out_sum;
+  int* out_counts;            // MODE_UNIQUE: occurrences (saturating) of each unique key
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
         bool first;
         const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, true, &first);
         if (first) atomicAdd(&lnu, 1u);
-        if (MODE == MODE_LOOKUP) atomicAdd(&hval[h], w.ent_a[ge]);
+        if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], w.ent_a[ge]);
         else if (first) hval[h] = w.ent_a[ge];
       }
       }
@@ -498,7 +499,22 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     KV_STAMPP(1);
 
     // ---- owner work: one thread per unique key ------------------------------------------------
-    for (int s = tid; s <= HSK; s += TBK) {
+    if (MODE == MODE_UNIQUE) {
+      // tf.unique_with_counts: dense index = block base (ONE global atomic per block) + local rank
+      __shared__ unsigned lbase, lrank;
+      if (tid == 0) { lbase = atomicAdd(&w.ctr[0], lnu); lrank = 0; }
+      __syncthreads();
+      for (int s = tid; s <= HSK; s += TBK) {
+        const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
+        if (!occ) continue;
+        const unsigned dense = lbase + atomicAdd(&lrank, 1u);
+        hrow[s] = dense;
+        a.out_keys[dense] = (s == HSK) ? EMPTY_KEY : hkey[s];
+        if (a.out_counts) a.out_counts[dense] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
+      }
+      __syncthreads();
+    }
+    for (int s = tid; s <= HSK && MODE != MODE_UNIQUE; s += TBK) {
       const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
       if (!occ) continue;
       const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
@@ -603,8 +619,8 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     }
     KV_STAMPP(3);
 
-    // ---- pass 2 (lookup): every entry learns its key's row ------------------------------------
-    if (MODE == MODE_LOOKUP) {
+    // ---- pass 2 (lookup / unique): every entry learns its key's row / dense index --------------
+    if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) {
       for (unsigned tb = tid; tb < NT; tb += TBK * 8) {
         unsigned so[8][2];
 #pragma unroll
@@ -1145,4 +1161,71 @@ __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
     inverse[i] = (int)w.ent_b[w.slot_of_id[i]];
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU routing: stable-by-tile counting sort of ids by owner rank = floor_mod(id, world)
+// (kernels/utility.h:90-107).  world <= 64.  hist is [world][ntiles] (owner-major for the scan).
+// ------------------------------------------------------------------------------------------
+constexpr int RT = 1024;  // ids per routing tile (256 threads x 4)
+constexpr int MAXW = 64;
+
+__device__ __forceinline__ unsigned owner_rank(long long id, int world) {
+  long long m = id % world;
+  return (unsigned)(m < 0 ? m + world : m);
+}
+
+template <typename IdT>
+__global__ void __launch_bounds__(TB) k_owner_hist(const IdT* __restrict__ ids, long long n, int world,
+                                                   unsigned ntiles, unsigned* __restrict__ hist) {
+  __shared__ unsigned h[MAXW];
+  if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RT;
+#pragma unroll
+  for (int k = 0; k < RT / TB; ++k) {
+    const long long i = base + k * TB + threadIdx.x;
+    if (i < n) atomicAdd(&h[owner_rank(load_id(ids, (size_t)i), world)], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < world) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// one block: exclusive scan of hist in (owner, tile) order -> base offsets; counts[w] = ids owned by w
+__global__ void __launch_bounds__(1024) k_owner_scan(unsigned* __restrict__ hist, unsigned total,
+                                                     unsigned ntiles, int world, long long* __restrict__ counts) {
+  __shared__ unsigned wtot[17];
+  const unsigned per = (total + 1023) / 1024;
+  const unsigned b0 = min(total, threadIdx.x * per), b1 = min(total, b0 + per);
+  unsigned sum = 0;
+  for (unsigned i = b0; i < b1; ++i) sum += hist[i];
+  unsigned tot;
+  unsigned run = block_excl_scan<16>(sum, wtot, &tot);
+  for (unsigned i = b0; i < b1; ++i) { const unsigned c = hist[i]; hist[i] = run; run += c; }
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
+    const unsigned lo = hist[(size_t)threadIdx.x * ntiles];
+    const unsigned hi = ((int)threadIdx.x + 1 < world) ? hist[(size_t)(threadIdx.x + 1) * ntiles] : tot;
+    counts[threadIdx.x] = (long long)hi - (long long)lo;
+  }
+}
+
+template <typename IdT>
+__global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ ids, long long n, int world,
+                                                      unsigned ntiles, const unsigned* __restrict__ base_off,
+                                                      long long* __restrict__ out_ids, int* __restrict__ perm) {
+  __shared__ unsigned h[MAXW];
+  if ((int)threadIdx.x < world) h[threadIdx.x] = base_off[(size_t)threadIdx.x * ntiles + blockIdx.x];
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RT;
+#pragma unroll
+  for (int k = 0; k < RT / TB; ++k) {
+    const long long i = base + k * TB + threadIdx.x;
+    if (i < n) {
+      const long long id = load_id(ids, (size_t)i);
+      const unsigned pos = atomicAdd(&h[owner_rank(id, world)], 1u);
+      out_ids[pos] = id;
+      perm[pos] = (int)i;
+    }
+  }
 }

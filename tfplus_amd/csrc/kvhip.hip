@@ -188,6 +188,8 @@ struct kv_table {
   Workspace ws;
   unsigned long long* d_stat = nullptr;  // [4]
   std::mutex mu;
+  unsigned* route_hist = nullptr;  // kv_bucket_by_owner scratch
+  size_t route_hist_cap = 0;
   // optional per-kernel timing (kv_profile_*): event pairs recorded on the op's stream
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -548,6 +550,7 @@ int kv_destroy(kv_handle_t t) {
   for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.freq); hipFree(c.flags); hipFree(c.keys); }
   hipFree(t->entries); hipFree(t->d_chunks); hipFree(t->d_counters); hipFree(t->d_stat);
   hipFree(t->init_table);
+  hipFree(t->route_hist);
   for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.toff); hipFree(w.slot_of_id);
@@ -879,6 +882,71 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *num_unique = U;
+  return KV_OK;
+}
+
+int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq, int32_t* uniq_counts,
+              int32_t* inverse, int64_t* num_unique, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!num_unique) return fail(KV_INVALID_ARGUMENT, "num_unique is null");
+  *num_unique = 0;
+  if (n == 0) return KV_OK;
+  if (n < 0 || !ids || !uniq) return fail(KV_INVALID_ARGUMENT, "bad arguments");
+  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = ensure_workspace(t, n, false, s))) return rc;
+  const WsDev wd = ws_view(t, n);
+  HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
+  launch_tile<MODE_LOOKUP>(t, wd, ids, counts, nullptr, n, s);   // ent_a = saturating count per tile
+  PartArgs pa{};
+  pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+  pa.out_keys = (long long*)uniq;
+  pa.out_counts = uniq_counts;
+  if ((rc = launch_part<MODE_UNIQUE, 0>(wd, pa, s))) return rc;
+  if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
+  unsigned U = 0;
+  HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *num_unique = U;
+  return KV_OK;
+}
+
+int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, int world, int64_t* out_ids, int32_t* perm,
+                       int64_t* counts_dev, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (world < 1 || world > MAXW) return fail(KV_INVALID_ARGUMENT, "world %d: 1..%d ranks", world, MAXW);
+  if (n < 0 || n > (1ll << 31) - 1 || (n > 0 && (!ids || !out_ids || !perm)) || !counts_dev)
+    return fail(KV_INVALID_ARGUMENT, "bad arguments");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned ntiles = (unsigned)((n + RT - 1) / RT);
+  const size_t need = (size_t)std::max(1u, ntiles) * world;
+  if (t->route_hist_cap < need) {
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(t->route_hist);
+    HIP_TRY(hipMalloc(&t->route_hist, need * sizeof(unsigned)));
+    t->route_hist_cap = need;
+  }
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)world * sizeof(long long), s));
+    return KV_OK;
+  }
+  if (t->key_dtype == KV_DT_INT32) {
+    k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist);
+    k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
+    k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (long long*)out_ids, perm);
+  } else {
+    k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist);
+    k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
+    k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
+                                                     (long long*)out_ids, perm);
+  }
+  HIP_TRY(hipGetLastError());
   return KV_OK;
 }
 

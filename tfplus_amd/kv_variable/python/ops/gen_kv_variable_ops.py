@@ -369,3 +369,31 @@ def kv_profile_read(table_handle):
   cnt = (ctypes.c_int64 * n)()
   _lib.check(_lib.lib().kv_profile_read(table_handle.ptr, ms, cnt, n))
   return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
+
+
+def kv_bucket_by_owner(table_handle, indices, world):
+  """Counting sort of the ids by owner rank floor_mod(id, world) on the GPU.
+  Returns (ids grouped by owner, perm [n] int32 of input positions, counts [world] int64 on device)."""
+  ids = _ids(table_handle, indices).reshape(-1)
+  dev = _dev(table_handle)
+  out = torch.empty(ids.numel(), dtype=torch.int64, device=dev)
+  perm = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
+  counts = torch.empty(int(world), dtype=torch.int64, device=dev)
+  _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), int(world), _p(out), _p(perm),
+                                           ctypes.c_void_p(counts.data_ptr()), _stream(table_handle)))
+  return out, perm, counts
+
+
+def kv_unique(table_handle, indices, counts=None):
+  """tf.unique_with_counts on the GPU: (unique ids [U], counts [U] int32, inverse [n] int32)."""
+  ids = _ids(table_handle, indices).reshape(-1)
+  n = ids.numel()
+  dev = _dev(table_handle)
+  cnt = None if counts is None else torch.as_tensor(counts, dtype=torch.int32).to(dev).reshape(-1).contiguous()
+  uniq = torch.empty(n, dtype=torch.int64, device=dev)
+  ucnt = torch.empty(n, dtype=torch.int32, device=dev)
+  inv = torch.empty(n, dtype=torch.int32, device=dev)
+  nu = ctypes.c_int64()
+  _lib.check(_lib.lib().kv_unique(table_handle.ptr, _p(ids), _p(cnt), n, _p(uniq), _p(ucnt), _p(inv),
+                                  ctypes.byref(nu), _stream(table_handle)))
+  return uniq[:nu.value], ucnt[:nu.value], inv
