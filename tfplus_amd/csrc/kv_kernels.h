@@ -429,6 +429,40 @@ constexpr int TBK = 256;
 constexpr int HSK = 2048;          // LDS hash slots
 constexpr int UCAPK = HSK * 3 / 4; // unique keys per round
 
+// per-partition segment directory in LDS: tpre[t] = entries of tiles < t, tstart[t] = first entry of
+// tile t's segment.  Entry x of the partition (0 <= x < E) lives at tile t = last tpre[t] <= x.
+// Filled by seg_directory(); lets every thread take entries x = tid, tid + T, ... whatever the number
+// of tiles (one tile with 1000 entries is as parallel as 1000 tiles with one entry).
+template <int T, int NW>
+__device__ __forceinline__ unsigned seg_directory(const WsDev& w, unsigned p, unsigned short* tpre,
+                                                  unsigned short* tstart, unsigned* wtot) {
+  const unsigned NT = w.ntiles, P = w.P;
+  const unsigned per = (NT + T - 1) / T;
+  const unsigned t0 = min(NT, threadIdx.x * per), t1 = min(NT, t0 + per);
+  unsigned sum = 0;
+  for (unsigned t = t0; t < t1; ++t) {
+    const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
+    const unsigned s0 = to[0], s1 = to[1];
+    tstart[t] = (unsigned short)s0;
+    tpre[t] = (unsigned short)(s1 - s0);  // length for now
+    sum += s1 - s0;
+  }
+  unsigned E;
+  unsigned run = block_excl_scan<NW>(sum, wtot, &E);
+  for (unsigned t = t0; t < t1; ++t) { const unsigned len = tpre[t]; tpre[t] = (unsigned short)min(run, 65535u); run += len; }
+  __syncthreads();
+  return E;
+}
+__device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const unsigned short* tstart,
+                                            unsigned NT, unsigned x) {
+  unsigned lo = 0, hi = NT;  // last t with tpre[t] <= x
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (tpre[mid] <= x) lo = mid; else hi = mid;
+  }
+  return (size_t)lo * TILE + tstart[lo] + (x - tpre[lo]);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   __shared__ long long hkey[HSK + 1];
@@ -436,12 +470,19 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   __shared__ unsigned hrow[HSK + 1];   // row id of the key
   __shared__ unsigned short lnew[UCAPK + 8];  // slots whose row was inserted now / needs a row scan
   __shared__ unsigned lnu, lsent, lnnew;
+  __shared__ unsigned wtot[8];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short* tpre = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* tstart = tpre + w.ntiles;
 
   const int tid = threadIdx.x;
   const unsigned p = blockIdx.x;
-  const unsigned P = w.P, NT = w.ntiles;
+  const unsigned NT = w.ntiles;
   const int D = a.tv.dim;
   KV_STAMPP(0);
+  const unsigned E = seg_directory<TBK, TBK / 64>(w, p, tpre, tstart, wtot);
+  if (E == 0) return;
+  const bool wide = E > 65535u;  // cannot happen with TILE * ntiles / P this small; guard anyway
 
   // work list of (R, round) sub-hash classes; an overflowing class is split in two and each
   // class is processed exactly once (block-uniform control flow)
@@ -449,6 +490,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   __shared__ int sp;
   if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
   __syncthreads();
+  if (wide) return;
   while (sp > 0) {
     const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
     __syncthreads();
@@ -457,34 +499,16 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
     __syncthreads();
     // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
-    // (segment bounds of up to 8 of this thread's tiles are loaded together: independent loads)
-    for (unsigned tb = tid; tb < NT; tb += TBK * 8) {
-      unsigned so[8][2];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const unsigned t = tb + q * TBK;
-        so[q][0] = so[q][1] = 0;
-        if (t < NT) {
-          const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-          so[q][0] = to[0]; so[q][1] = to[1];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-      const unsigned t = tb + q * TBK;
-      const unsigned s0 = so[q][0], s1 = so[q][1];
-      for (unsigned e = s0; e < s1; ++e) {
-        const size_t ge = (size_t)t * TILE + e;
-        const long long key = w.ent_key[ge];
-        if (!in_round(key, R, round)) continue;
-        if (lnu >= (unsigned)UCAPK) break;  // overflow: this round is abandoned below
-        bool first;
-        const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, true, &first);
-        if (first) atomicAdd(&lnu, 1u);
-        if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], w.ent_a[ge]);
-        else if (first) hval[h] = w.ent_a[ge];
-      }
-      }
+    for (unsigned x = tid; x < E; x += TBK) {
+      const size_t ge = seg_entry(tpre, tstart, NT, x);
+      const long long key = w.ent_key[ge];
+      if (!in_round(key, R, round)) continue;
+      if (lnu >= (unsigned)UCAPK) break;  // overflow: this class is split below
+      bool first;
+      const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, true, &first);
+      if (first) atomicAdd(&lnu, 1u);
+      if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], w.ent_a[ge]);
+      else if (first) hval[h] = w.ent_a[ge];
     }
     __syncthreads();
     if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split the class, nothing applied yet
@@ -621,28 +645,12 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
 
     // ---- pass 2 (lookup / unique): every entry learns its key's row / dense index --------------
     if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) {
-      for (unsigned tb = tid; tb < NT; tb += TBK * 8) {
-        unsigned so[8][2];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const unsigned t = tb + q * TBK;
-          so[q][0] = so[q][1] = 0;
-          if (t < NT) {
-            const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-            so[q][0] = to[0]; so[q][1] = to[1];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const unsigned t = tb + q * TBK;
-          for (unsigned e = so[q][0]; e < so[q][1]; ++e) {
-            const size_t ge = (size_t)t * TILE + e;
-            const long long key = w.ent_key[ge];
-            if (!in_round(key, R, round)) continue;
-            bool first;
-            w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
-          }
-        }
+      for (unsigned x = tid; x < E; x += TBK) {
+        const size_t ge = seg_entry(tpre, tstart, NT, x);
+        const long long key = w.ent_key[ge];
+        if (!in_round(key, R, round)) continue;
+        bool first;
+        w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
       }
     }
     __syncthreads();
@@ -664,14 +672,15 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
 constexpr int TBS = 256;
 constexpr int HSS = 1024;
 constexpr int UCAPS = HSS * 3 / 4;
-constexpr int ECAPS = 1792;
+constexpr int ECAPS = 1600;
 constexpr int TPT = 8;  // tiles per thread whose segment bounds are kept in registers
 constexpr int HMAXS = 16;                  // heavy keys per round folded by the whole block (the rest
                                            // are summed by single groups)
 constexpr unsigned LOC_LDS = 0xFFFFFFE0u;  // gradient locator: row of the block's LDS hsum
 
-__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, int lpr) {
-  size_t b = (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16 + (size_t)(HSS + 1) * 2 + 16;  // hkey, hval, hu
+__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, int lpr, unsigned ntiles) {
+  size_t b = (size_t)ntiles * 4 + 32;  // tpre, tstart
+  b += (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16 + (size_t)(HSS + 1) * 2 + 16;  // hkey, hval, hu
   b += (size_t)ECAPS * 4 + 16 + (size_t)ECAPS * 2 * 2 + 32;            // eb, eslot, perm
   b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
   b += (size_t)UCAPS * 4 * 2 + 32 + (size_t)UCAPS + 16;                // utag, ur0, unew
@@ -745,26 +754,20 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
 
   const int tid = threadIdx.x;
   const unsigned p = blockIdx.x;
-  const unsigned P = w.P, NT = w.ntiles;
+  const unsigned NT = w.ntiles;
   constexpr unsigned GPB = TBS / LPR;
   const int lane = tid % LPR;
   const unsigned grp = tid / LPR;
   KV_STAMPP(0);
 
-  // segment bounds of this thread's tiles, loaded together (independent loads) and kept
-  unsigned short so[TPT][2];
-#pragma unroll
-  for (int q = 0; q < TPT; ++q) {
-    const unsigned t = tid + q * TBS;
-    so[q][0] = so[q][1] = 0;
-    if (t < NT) {
-      const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-      so[q][0] = to[0]; so[q][1] = to[1];
-    }
-  }
+  unsigned short* tpre = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
+  unsigned short* tstart = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
+  const unsigned E = seg_directory<TBS, TBS / 64>(w, p, tpre, tstart, wtot);
+  if (E == 0 || E > 65535u) return;
 
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
+  __shared__ unsigned lcls;
   if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
   __syncthreads();
   auto split = [&](unsigned R, unsigned round) {  // replace class (R, round) by its two halves
@@ -778,18 +781,19 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
   while (sp > 0) {
     const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
     __syncthreads();
-    if (tid == 0) --sp;
-    // ---- entries of this class: count, then copy in a deterministic order ---------------------
-    unsigned cnt = 0;
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) {
-      if (R == 1) cnt += (unsigned)so[q][1] - (unsigned)so[q][0];
-      else
-        for (unsigned e = so[q][0]; e < so[q][1]; ++e)
-          cnt += in_round(w.ent_key[(size_t)(tid + q * TBS) * TILE + e], R, round);
+    if (tid == 0) { --sp; lcls = 0; }
+    __syncthreads();
+    // ---- entries of this class ------------------------------------------------------------------
+    unsigned Er = E;
+    if (R > 1) {
+      unsigned c = 0;
+      for (unsigned x = tid; x < E; x += TBS) c += in_round(w.ent_key[seg_entry(tpre, tstart, NT, x)], R, round);
+      if (c) atomicAdd(&lcls, c);
+      __syncthreads();
+      Er = lcls;
+      __syncthreads();
+      if (tid == 0) lcls = 0;
     }
-    unsigned Er;
-    unsigned pos = block_excl_scan<TBS / 64>(cnt, wtot, &Er);
     if (Er == 0) { __syncthreads(); continue; }
     if (Er > (unsigned)ECAPS) {  // block-uniform; nothing of this class has been applied yet
       split(R, round);
@@ -799,39 +803,23 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
     for (unsigned x = tid; x < (unsigned)HMAXS * (unsigned)D; x += TBS) hsum[x] = 0.f;
     if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
     __syncthreads();
-    {
-      // first entry of every segment is fetched eagerly (most segments hold 0 or 1 entries)
-      long long k0[TPT];
-      unsigned b0[TPT];
-#pragma unroll
-      for (int q = 0; q < TPT; ++q) {
-        k0[q] = 0; b0[q] = 0;
-        if (so[q][0] < so[q][1]) {
-          const size_t ge = (size_t)(tid + q * TBS) * TILE + so[q][0];
-          k0[q] = w.ent_key[ge];
-          b0[q] = w.ent_b[ge];
-        }
+    // every thread takes entries x = tid, tid + TBS, ...: balanced whatever the number of tiles
+    for (unsigned x = tid; x < E; x += TBS) {
+      const size_t ge = seg_entry(tpre, tstart, NT, x);
+      const long long key = w.ent_key[ge];
+      if (!in_round(key, R, round)) continue;
+      if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
+      const unsigned pos = (R == 1) ? x : atomicAdd(&lcls, 1u);  // R == 1: deterministic order
+      bool first;
+      const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
+      if (first) {
+        const unsigned u = atomicAdd(&lnu, 1u);
+        if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
       }
-#pragma unroll
-      for (int q = 0; q < TPT; ++q) {
-        for (unsigned e = so[q][0]; e < so[q][1]; ++e) {
-          const size_t ge = (size_t)(tid + q * TBS) * TILE + e;
-          const long long key = (e == so[q][0]) ? k0[q] : w.ent_key[ge];
-          if (!in_round(key, R, round)) continue;
-          if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
-          bool first;
-          const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
-          if (first) {
-            const unsigned u = atomicAdd(&lnu, 1u);
-            if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
-          }
-          eb[pos] = (e == so[q][0]) ? b0[q] : w.ent_b[ge];
-          if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
-          eslot[pos] = (unsigned short)h;
-          perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
-          ++pos;
-        }
-      }
+      eb[pos] = w.ent_b[ge];
+      if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
+      eslot[pos] = (unsigned short)h;
+      perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
     }
     __syncthreads();
     if (lovf || lnu > (unsigned)UCAPS) {  // too many distinct keys for the LDS hash: split the class

@@ -418,12 +418,12 @@ int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
   const int D = pa.tv.dim;
   const int grid = (int)wd.P;
   if constexpr (MODE != MODE_APPLY && MODE != MODE_DEDUP) {
-    k_part_keys<MODE><<<grid, TBK, 0, s>>>(wd, pa);
+    k_part_keys<MODE><<<grid, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
     return KV_OK;
   } else {
 #define KV_PART(V, LPR, K)                                                                       \
   do {                                                                                           \
-    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, OPT, D, LPR), s>>>(wd, pa); \
+    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, OPT, D, LPR, wd.ntiles), s>>>(wd, pa); \
     return KV_OK;                                                                                \
   } while (0)
     if ((D & 3) == 0) {
