@@ -216,7 +216,8 @@ def main():
     from tfplus_amd.kv_variable.python.ops import sharded
     skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
                                     unique_fn=lambda i, c: ops.kv_unique(var, i, c),
-                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g))
+                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
+                                    take_fn=ops.kv_take_rows)
 
   def step(k):
     ids, grad = pool[k % len(pool)][:2]

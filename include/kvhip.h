@@ -188,6 +188,14 @@ int kv_unique(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n, 
 int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, int world, int64_t* out_ids,
                        int32_t* perm, int64_t* counts_dev, kv_stream_t stream);
 
+/* Row permutation for the exchange (no handle: plain device buffers).  scatter == 0:
+ * out[i] = src[index[i]]; scatter == 1: out[index[i]] = src[i]; rows of row_bytes (a multiple of
+ * 4) bytes, index [n] int32.  Replaces the tf.gather / tf.dynamic_stitch the reference's
+ * partitioned lookup uses to undo its `ids % num_shards` split (python/ops/embedding_ops.py:
+ * 150-204). */
+int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, int64_t row_bytes,
+                 int scatter, void* out, kv_stream_t stream);
+
 /* ---- measurement hooks (no reference counterpart; the reference only VLOGs wall time,
  * kernels/training_ops.cc:6989,7211) -----------------------------------------------------------
  * kv_profile_enable(h, max_launches > 0) brackets every kernel this table launches with a pair

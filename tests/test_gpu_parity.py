@@ -443,8 +443,19 @@ def test_full_size_batch_properties(ops):
   alpha = float(np.float32(1e-3)) * np.sqrt(omb2) / omb1
   expect = x0 - alpha * (omb1 * gsum) / ((omb2 * gsum * gsum).sqrt() + float(np.float32(1e-8)))
   got = ops.kv_variable_gather_or_zeros_v2(h, uniq).double()
-  err = (got - expect).abs().max().item()
-  assert err < 2e-6, err
+  # fp32 summation in any order is off the exact sum by at most (count-1) * 2^-24 * sum|g_i|; where
+  # the summed gradient cancels to ~epsilon the Adam quotient amplifies that by
+  # d(update)/dg = alpha*omb1*eps / (sqrt(omb2)|g| + eps)^2, so the bound is per element
+  cnt = torch.bincount(inv).double().unsqueeze(1)
+  gabs = torch.zeros_like(gsum).index_add_(0, inv, grad.double().abs())
+  dg = (cnt - 1).clamp(min=0) * 2.0 ** -24 * gabs
+  eps32 = float(np.float32(1e-8))
+  gmin = (gsum.abs() - dg).clamp(min=0)
+  slope = alpha * omb1 * eps32 / (np.sqrt(omb2) * gmin + eps32) ** 2
+  bound = 1e-6 + slope * dg
+  excess = ((got - expect).abs() - bound).max().item()
+  assert excess < 0, excess
+  assert (bound > 2e-6).double().mean().item() < 1e-4     # the amplified cases are rare
   # export round trip: every key once, rows equal to a lookup
   k, vals = ops.read_kv_variable_op_v2(h)
   assert k.numel() == uniq.numel() and torch.equal(torch.sort(k).values, uniq)

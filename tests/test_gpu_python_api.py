@@ -173,3 +173,19 @@ def test_bucket_by_owner_matches_floor_mod(api):
     o, p = out.cpu().numpy(), perm.cpu().numpy()
     assert sorted(p.tolist()) == list(range(5000)) and np.array_equal(o, ids.numpy()[p])
     assert np.all(np.diff(np.mod(o, world)) >= 0)        # grouped by owner, rank 0 first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((1000, 32), torch.float32), ((777, 5), torch.float32),
+                                         ((513,), torch.int32), ((300, 3), torch.int64)])
+def test_take_rows_gather_and_scatter(shape, dtype):
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  g = torch.Generator().manual_seed(3)
+  src = (torch.randn(shape, generator=g) * 100).to(dtype).cuda()
+  perm = torch.randperm(shape[0], generator=g).cuda()
+  assert torch.equal(ops.kv_take_rows(src, perm), src[perm])
+  back = ops.kv_take_rows(src[perm], perm, scatter=True)
+  assert torch.equal(back, src)
+  idx = torch.randint(0, shape[0], (2500,), generator=g).cuda()       # expand with repeats
+  assert torch.equal(ops.kv_take_rows(src, idx), src[idx])
+  assert ops.kv_take_rows(src, idx[:0]).shape[0] == 0

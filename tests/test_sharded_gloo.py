@@ -49,7 +49,8 @@ def _worker(rank, world, port, q):
       batches = [torch.from_numpy(rng.integers(-50, 200, 64 + 13 * r)) for r in range(world)]
       grads = [torch.from_numpy(rng.standard_normal((b.numel(), D)).astype(np.float32)) for b in batches]
       mine = batches[rank]
-      out = sh.lookup(mine.reshape(-1, 1)).reshape(-1, D)      # 2-D ids keep their shape
+      mine2d = mine.reshape(-1, 1)
+      out = sh.lookup(mine2d).reshape(-1, D)                   # 2-D ids keep their shape
       want_all = ref.sparse_read_with_counts(torch.cat(batches))
       off = sum(b.numel() for b in batches[:rank])
       # bit-equal on the first step (rows are copies); later steps carry the optimizer state, whose
@@ -59,7 +60,10 @@ def _worker(rank, world, port, q):
         assert torch.equal(out, want), "lookup rows differ from the unsharded table"
       else:
         torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-6)
-      sh.apply_gradients(lambda shard, g, i: shard.apply(g, i), grads[rank], mine.reshape(-1, 1))
+      # even steps hand the apply the very tensor the lookup saw (bucket sizes reused, no size
+      # exchange); odd steps a fresh view (sizes exchanged again)
+      sh.apply_gradients(lambda shard, g, i: shard.apply(g, i), grads[rank],
+                         mine2d if step % 2 == 0 else mine.reshape(-1, 1))
       ref.apply(torch.cat(grads), torch.cat(batches))
       # ownership: this rank's shard holds exactly the keys with floor_mod(key, world) == rank
       keys, vals, *_ = sh.shard.var.export(2)

@@ -1217,3 +1217,23 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
     }
   }
 }
+// ---------------------------------------------------------------------------------------------
+// k_take_rows: out[i] = src[idx[i]] (SCATTER = 0) or out[idx[i]] = src[i] (SCATTER = 1) over rows of
+// `nu` units of type U (float4 when the row is a multiple of 16 bytes).  The exchange's permute /
+// un-permute / expand steps of the sharded path.
+template <typename U, int SCATTER>
+__global__ void __launch_bounds__(TB) k_take_rows(const U* __restrict__ src, const int* __restrict__ idx,
+                                                  long long n, unsigned nu, int sh, U* __restrict__ out) {
+  const long long total = n * nu;
+  const long long stride = (long long)gridDim.x * TB;
+  for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += stride) {
+    long long i;
+    unsigned e;
+    if (sh >= 0) { i = x >> sh; e = (unsigned)(x & (nu - 1)); }
+    else { i = x / nu; e = (unsigned)(x - i * nu); }
+    const long long j = idx[i];
+    if (SCATTER) out[j * nu + e] = src[x];
+    else out[x] = src[j * nu + e];
+  }
+}
+

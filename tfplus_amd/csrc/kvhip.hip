@@ -302,10 +302,10 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
   return KV_OK;
 }
 
-// partitions for a batch of n ids: ~1024 input positions (so at most ~1024 distinct keys) per
-// partition block, a power of two
+// partitions for a batch of n ids: ~512 input positions per partition block (so an all-distinct
+// batch still fits the partition kernels' LDS key tables), a power of two, at most MAX_P
 unsigned pick_partitions(long long n) {
-  unsigned long long want = (unsigned long long)((n + 1023) / 1024);
+  unsigned long long want = (unsigned long long)((n + 511) / 512);
   unsigned P = 1;
   while (P < want && P < (unsigned)MAX_P) P <<= 1;
   return P;
@@ -945,6 +945,29 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, int world, int
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
     k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
                                                      (long long*)out_ids, perm);
+  }
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, int64_t row_bytes, int scatter,
+                 void* out, kv_stream_t stream) {
+  if (n < 0 || row_bytes <= 0 || row_bytes % 4 || (n > 0 && (!src || !index || !out)))
+    return fail(KV_INVALID_ARGUMENT, "kv_take_rows: n %lld, row_bytes %lld (a positive multiple of 4)",
+                (long long)n, (long long)row_bytes);
+  if (n == 0) return KV_OK;
+  DeviceGuard dg(device);
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = row_bytes % 16 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const unsigned nu = (unsigned)(row_bytes / (wide ? 16 : 4));
+  const int sh = (nu & (nu - 1)) == 0 ? ilog2(nu) : -1;
+  const int grid = nblocks(n * nu, TB * 4, 8192);
+  if (wide) {
+    if (scatter) k_take_rows<float4, 1><<<grid, TB, 0, s>>>((const float4*)src, index, n, nu, sh, (float4*)out);
+    else k_take_rows<float4, 0><<<grid, TB, 0, s>>>((const float4*)src, index, n, nu, sh, (float4*)out);
+  } else {
+    if (scatter) k_take_rows<float, 1><<<grid, TB, 0, s>>>((const float*)src, index, n, nu, sh, (float*)out);
+    else k_take_rows<float, 0><<<grid, TB, 0, s>>>((const float*)src, index, n, nu, sh, (float*)out);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;

@@ -384,6 +384,26 @@ def kv_bucket_by_owner(table_handle, indices, world):
   return out, perm, counts
 
 
+def kv_take_rows(src, index, scatter=False, num_rows=None):
+  """out[i] = src[index[i]] (gather, default) or out[index[i]] = src[i] (scatter=True; index must be
+  a permutation onto `num_rows` rows).  Any 4-byte-multiple row type; index int32 on the GPU."""
+  src = src.contiguous()
+  idx = index.to(torch.int32).contiguous()
+  n = idx.numel()
+  tail = tuple(src.shape[1:])
+  row_bytes = src.element_size()
+  for d in tail:
+    row_bytes *= int(d)
+  if scatter and src.shape[0] != n:
+    raise _lib.InvalidArgumentError("kv_take_rows: scatter needs one index per source row")
+  rows_out = (src.shape[0] if num_rows is None else int(num_rows)) if scatter else n
+  out = torch.empty((rows_out,) + tail, dtype=src.dtype, device=src.device)
+  stream = ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+  _lib.check(_lib.lib().kv_take_rows(src.device.index or 0, _p(src), _p(idx), n, row_bytes, int(bool(scatter)),
+                                     _p(out), stream))
+  return out
+
+
 def kv_unique(table_handle, indices, counts=None):
   """tf.unique_with_counts on the GPU: (unique ids [U], counts [U] int32, inverse [n] int32)."""
   ids = _ids(table_handle, indices).reshape(-1)

@@ -35,19 +35,24 @@ def owner_of(ids, world):
   return torch.remainder(ids, world)
 
 
-def route(ids, group=None, bucket_fn=None):
+def route(ids, group=None, bucket_fn=None, known_counts=None):
   """Buckets a flat id tensor by owner rank and exchanges the bucket sizes.  `bucket_fn(ids, world)`
   -> (bucketed ids, perm, counts) is the GPU counting sort (kv_bucket_by_owner); without it the
-  same thing is done with torch ops (CPU tests)."""
+  same thing is done with torch ops (CPU tests).  known_counts = (send, recv) python lists skips
+  the size exchange and its host sync: valid when `ids` is a re-ordering of a set routed before
+  (the backward pass of a lookup), since bucket sizes depend only on the set."""
   world = dist.get_world_size(group)
   bucketed = None
   if bucket_fn is not None:
     bucketed, perm, send = bucket_fn(ids, world)
-    perm = perm.to(torch.int64)
   else:
     own = owner_of(ids, world)
     perm = torch.argsort(own, stable=True)
     send = torch.bincount(own, minlength=world).to(torch.int64)
+  if known_counts is not None:
+    rt = Routing(perm, list(known_counts[0]), list(known_counts[1]))
+    rt.bucketed_ids = bucketed
+    return rt
   recv = torch.empty_like(send)
   dist.all_to_all_single(recv, send, group=group)
   both = torch.stack([send, recv]).tolist()      # one device -> host sync for both count vectors
@@ -56,13 +61,24 @@ def route(ids, group=None, bucket_fn=None):
   return rt
 
 
-def exchange(rt, payload, reverse=False, group=None, presorted=None):
+def _take(payload, index, take_fn, scatter=False):
+  if take_fn is not None:
+    return take_fn(payload, index, scatter)
+  if not scatter:
+    return payload.index_select(0, index.to(torch.int64)).contiguous()
+  out = torch.empty_like(payload)
+  out.index_copy_(0, index.to(torch.int64), payload)
+  return out
+
+
+def exchange(rt, payload, reverse=False, group=None, presorted=None, take_fn=None):
   """all_to_all of per-id rows.  Forward: `payload` is in local order, the result is what this
   rank must serve (grouped by source rank).  reverse=True: `payload` is in served order, the
-  result is back in local order."""
+  result is back in local order.  take_fn(rows, index, scatter) is the GPU row permutation
+  (kv_take_rows); torch indexing otherwise."""
   tail = tuple(payload.shape[1:])
   if not reverse:
-    src = presorted if presorted is not None else payload.index_select(0, rt.perm).contiguous()
+    src = presorted if presorted is not None else _take(payload, rt.perm, take_fn)
     out = torch.empty((rt.n_recv,) + tail, dtype=payload.dtype, device=payload.device)
     dist.all_to_all_single(out, src, output_split_sizes=rt.recv_counts, input_split_sizes=rt.send_counts,
                            group=group)
@@ -70,9 +86,7 @@ def exchange(rt, payload, reverse=False, group=None, presorted=None):
   back = torch.empty((rt.n_local,) + tail, dtype=payload.dtype, device=payload.device)
   dist.all_to_all_single(back, payload.contiguous(), output_split_sizes=rt.send_counts,
                          input_split_sizes=rt.recv_counts, group=group)
-  out = torch.empty_like(back)
-  out.index_copy_(0, rt.perm, back)
-  return out
+  return _take(back, rt.perm, take_fn, scatter=True)
 
 
 class ShardedKvVariable(object):
@@ -88,10 +102,12 @@ class ShardedKvVariable(object):
   are the GPU kernels (gen_kv_variable_ops.kv_unique / kv_dedup_segment_sum); bucket_fn is
   kv_bucket_by_owner.  Without them torch ops do the same (CPU tests)."""
 
-  def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None):
+  def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None, take_fn=None):
     self.shard = shard          # the rank-local table (KvVariable, or any stand-in with the same calls)
     self.group = group
     self.bucket_fn, self.unique_fn, self.segsum_fn = bucket_fn, unique_fn, segsum_fn
+    self.take_fn = take_fn
+    self._last = None           # (ids tensor, its version, send counts, recv counts) of the last lookup
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
 
@@ -116,11 +132,12 @@ class ShardedKvVariable(object):
     flat = ids.reshape(-1)
     uniq, ucnt, inv = self._unique(flat, counts)
     rt = route(uniq, self.group, self.bucket_fn)
+    self._last = (ids, ids._version, rt.send_counts, rt.recv_counts)
     served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids)
-    sc = exchange(rt, ucnt, group=self.group)
+    sc = exchange(rt, ucnt, group=self.group, take_fn=self.take_fn)
     rows = self.shard.sparse_read_with_counts(served, sc)
-    urows = exchange(rt, rows, reverse=True, group=self.group)
-    out = urows.index_select(0, inv.to(torch.int64))
+    urows = exchange(rt, rows, reverse=True, group=self.group, take_fn=self.take_fn)
+    out = _take(urows, inv, self.take_fn)
     return out.reshape(tuple(ids.shape) + tuple(out.shape[1:]))
 
   def apply_gradients(self, apply_fn, grad, ids):
@@ -128,7 +145,10 @@ class ShardedKvVariable(object):
     apply_fn(shard, grad, ids) once — its fused dedup + segment-sum + row update."""
     flat = ids.reshape(-1)
     uniq, summed = self._segsum(flat, grad.reshape(flat.numel(), -1))
-    rt = route(uniq, self.group, self.bucket_fn)
-    served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids)
-    g = exchange(rt, summed, group=self.group)
+    known = None
+    if self._last is not None and self._last[0] is ids and self._last[1] == ids._version:
+      known = self._last[2:]      # same id set as the forward pass: same bucket sizes, no size exchange
+    rt = route(uniq, self.group, self.bucket_fn, known_counts=known)
+    served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids, take_fn=self.take_fn)
+    g = exchange(rt, summed, group=self.group, take_fn=self.take_fn)
     apply_fn(self.shard, g, served)
