@@ -201,7 +201,9 @@ int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, i
  * kv_profile_enable(h, max_launches > 0) brackets every kernel this table launches with a pair
  * of hipEvents on the op's own stream (0 turns it off and frees the events).  kv_profile_read
  * (synchronous) sums the elapsed milliseconds per kernel kind since the last read.
- * For the optimizer ops the events belong to the `var` table. */
+ * For the optimizer ops the events belong to the `var` table.  kv_profile_select(h, mask) limits
+ * the bracketing to the kinds whose bit (1 << KV_PROF_*) is set (default: all) — an event pair
+ * costs a few microseconds of stream time, so a throughput measurement brackets one kernel. */
 #define KV_PROF_LOOKUP_TILE 0   /* k_tile<LOOKUP>: tile dedup + partition sort */
 #define KV_PROF_LOOKUP_PART 1   /* k_part<LOOKUP>: find / insert / frequency */
 #define KV_PROF_LOOKUP_GATHER 2 /* k_gather */
@@ -210,6 +212,7 @@ int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, i
 #define KV_PROF_KINDS 5
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
+int kv_profile_select(kv_handle_t h, unsigned kind_mask);
 
 #ifdef __cplusplus
 }

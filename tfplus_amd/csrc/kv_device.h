@@ -38,11 +38,19 @@ struct __attribute__((aligned(16))) Entry {
   unsigned pad;
 };
 
+// per-row metadata next to each other (one 16-byte record, so a key's frequency word and flags
+// arrive with one memory transaction and an insert writes one line): embedding_value.h:225-235
+struct RowMeta {
+  long long key;
+  unsigned freq;          // (day << 16) | saturating u16 count
+  unsigned char flags;    // FLAG_*
+  unsigned char pad[3];
+};
+static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
+
 struct Chunk {
   float* rows;
-  unsigned* freq;
-  unsigned char* flags;
-  long long* keys;
+  RowMeta* meta;
 };
 
 // device view of one table; passed to kernels by value
@@ -81,8 +89,8 @@ struct WsDev {
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
 // block stores s_memtime at phase boundaries into a buffer nothing else reads.
 #ifdef KV_STAMPS
-#define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); } while (0)
-#define KV_STAMPP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = clock64(); } while (0)
+#define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#define KV_STAMPP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define KV_STAMP(slot) do { } while (0)
 #define KV_STAMPP(slot) do { } while (0)
@@ -110,17 +118,16 @@ __device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
   const Chunk& c = t.chunks[r >> t.chunk_bits];
   return c.rows + (size_t)(r & ((1u << t.chunk_bits) - 1)) * t.dim;
 }
-__device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) {
-  if ((r >> t.chunk_bits) == 0) return t.c0.freq + r;
-  return t.chunks[r >> t.chunk_bits].freq + (r & ((1u << t.chunk_bits) - 1));
+__device__ __forceinline__ RowMeta* meta_ptr(const TableDev& t, unsigned r) {
+  if ((r >> t.chunk_bits) == 0) return t.c0.meta + r;
+  return t.chunks[r >> t.chunk_bits].meta + (r & ((1u << t.chunk_bits) - 1));
 }
-__device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) {
-  if ((r >> t.chunk_bits) == 0) return t.c0.flags + r;
-  return t.chunks[r >> t.chunk_bits].flags + (r & ((1u << t.chunk_bits) - 1));
-}
-__device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) {
-  if ((r >> t.chunk_bits) == 0) return t.c0.keys + r;
-  return t.chunks[r >> t.chunk_bits].keys + (r & ((1u << t.chunk_bits) - 1));
+__device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->freq; }
+__device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->flags; }
+__device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->key; }
+// frequency word and flags of a row with ONE 8-byte load: .x = freq word, .y & 0xFF = flags
+__device__ __forceinline__ uint2 load_freq_flags(const TableDev& t, unsigned r) {
+  return *reinterpret_cast<const uint2*>(&meta_ptr(t, r)->freq);
 }
 
 __device__ __forceinline__ Entry load_entry(const Entry* e) {
@@ -145,6 +152,22 @@ __device__ __forceinline__ unsigned table_find(const TableDev& t, long long key)
     if (e.key == EMPTY_KEY) return 0u;
     p = (p + 1) & t.mask;
   }
+}
+
+// read-only probe continuing from an entry the caller already loaded (so the first loads of
+// several tables can be in flight together)
+__device__ __forceinline__ unsigned table_find_from(const TableDev& t, long long key, unsigned long long p,
+                                                   Entry e) {
+  if (key == EMPTY_KEY) return e.key == 0 ? e.row : 0u;
+  for (;;) {
+    if (e.key == key) return e.row;
+    if (e.key == EMPTY_KEY) return 0u;
+    p = (p + 1) & t.mask;
+    e = load_entry(&t.entries[p]);
+  }
+}
+__device__ __forceinline__ unsigned long long home_of(const TableDev& t, long long key, unsigned long long h) {
+  return key == EMPTY_KEY ? t.mask + 1 : (h & t.mask);
 }
 
 // Find or insert.  The caller is the ONLY lane of the launch that handles `key` (batch

@@ -424,9 +424,10 @@ __device__ __forceinline__ unsigned lds_key_slot(long long* hkey, unsigned* sent
 
 // ---- k_part_keys: MODE_LOOKUP / MODE_SCATTER / MODE_MARK ---------------------------------------
 // Streams the partition's entries twice and keeps only the unique keys in LDS, so a key that
-// occurs in every tile costs nothing extra.  256 threads, ~33 KB LDS, 4 blocks per CU.
+// occurs in every tile costs nothing extra.  256 threads, ~21 KB LDS, so every block of a
+// 1024-partition launch is resident at once (4 per CU needs < 40 KB).
 constexpr int TBK = 256;
-constexpr int HSK = 2048;          // LDS hash slots
+constexpr int HSK = 1024;          // LDS hash slots
 constexpr int UCAPK = HSK * 3 / 4; // unique keys per round
 
 // per-partition segment directory in LDS: tpre[t] = entries of tiles < t, tstart[t] = first entry of
@@ -469,6 +470,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
   __shared__ unsigned hval[HSK + 1];   // lookup: summed count; scatter / mark: an input position
   __shared__ unsigned hrow[HSK + 1];   // row id of the key
   __shared__ unsigned short lnew[UCAPK + 8];  // slots whose row was inserted now / needs a row scan
+  __shared__ unsigned short ulist[UCAPK + 8]; // slots of the unique keys, in order of first sight
   __shared__ unsigned lnu, lsent, lnnew;
   __shared__ unsigned wtot[8];
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -499,16 +501,42 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
     __syncthreads();
     // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
-    for (unsigned x = tid; x < E; x += TBK) {
-      const size_t ge = seg_entry(tpre, tstart, NT, x);
-      const long long key = w.ent_key[ge];
-      if (!in_round(key, R, round)) continue;
-      if (lnu >= (unsigned)UCAPK) break;  // overflow: this class is split below
-      bool first;
-      const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, true, &first);
-      if (first) atomicAdd(&lnu, 1u);
-      if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], w.ent_a[ge]);
-      else if (first) hval[h] = w.ent_a[ge];
+    // entries are taken EB per thread at a time with all their global loads in flight together (a
+    // partition that holds a key present in every tile has ~5x the median number of entries); the
+    // slot and position of the first EB entries stay in registers for pass 2
+    constexpr int EB = 8;
+    unsigned cge[EB];
+    unsigned short cslot[EB];
+    const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
+    for (unsigned x0 = 0; x0 < E; x0 += EB * TBK) {
+      unsigned ge[EB];
+      long long key[EB];
+      unsigned ea[EB];
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const unsigned x = x0 + k * TBK + tid;
+        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        key[k] = 0; ea[k] = 0;
+        if (ge[k] != 0xFFFFFFFFu) { key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; }
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if (x0 == 0) { cge[k] = ge[k]; cslot[k] = 0; }
+        if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
+        if (lnu >= (unsigned)UCAPK) continue;  // overflow: this class is split below
+        bool first;
+        const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key[k], true, &first);
+        if (first) {
+          const unsigned u = atomicAdd(&lnu, 1u);
+          if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
+        }
+        if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], ea[k]);
+        else if (first) hval[h] = ea[k];
+        if (x0 == 0) cslot[k] = (unsigned short)h;
+      }
     }
     __syncthreads();
     if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split the class, nothing applied yet
@@ -523,24 +551,25 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
     KV_STAMPP(1);
 
     // ---- owner work: one thread per unique key ------------------------------------------------
+    const unsigned nu = lnu;
     if (MODE == MODE_UNIQUE) {
       // tf.unique_with_counts: dense index = block base (ONE global atomic per block) + local rank
-      __shared__ unsigned lbase, lrank;
-      if (tid == 0) { lbase = atomicAdd(&w.ctr[0], lnu); lrank = 0; }
+      __shared__ unsigned lbase;
+      if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);
       __syncthreads();
-      for (int s = tid; s <= HSK; s += TBK) {
-        const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
-        if (!occ) continue;
-        const unsigned dense = lbase + atomicAdd(&lrank, 1u);
+      for (unsigned u = tid; u < nu; u += TBK) {
+        const unsigned s = ulist[u];
+        const unsigned dense = lbase + u;
         hrow[s] = dense;
         a.out_keys[dense] = (s == HSK) ? EMPTY_KEY : hkey[s];
         if (a.out_counts) a.out_counts[dense] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
       }
       __syncthreads();
     }
-    for (int s = tid; s <= HSK && MODE != MODE_UNIQUE; s += TBK) {
-      const bool occ = (s == HSK) ? (lsent != 0) : (hkey[s] != EMPTY_KEY);
-      if (!occ) continue;
+    // one thread per unique key, all keys of the partition at once: probe, then frequency word and
+    // flags with a single load (RowMeta)
+    for (unsigned u = tid; u < nu && MODE != MODE_UNIQUE; u += TBK) {
+      const unsigned s = ulist[u];
       const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
       bool isnew = false;
       // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
@@ -548,21 +577,21 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
                                                                  : table_find_or_insert(a.tv, key, &isnew);
       hrow[s] = r;
       if (r == 0) continue;
-      unsigned* fp = freq_ptr(a.tv, r);
-      unsigned char* fl = flags_ptr(a.tv, r);
+      RowMeta* mp = meta_ptr(a.tv, r);
       if (MODE == MODE_LOOKUP) {
         // find_func / insert_func (kv_variable.h:320-363): lo16 = sat_add(lo16, batch count),
         // hi16 = today; UpdateUnderThreshold only has work to do when the row changed since the
         // flag was computed (FLAG_DIRTY) or the row is new — every other writer keeps it current
+        uint2 m = make_uint2(0u, (unsigned)FLAG_DIRTY);
+        if (!isnew) m = *reinterpret_cast<const uint2*>(&mp->freq);
         const unsigned cnt = hval[s];
-        unsigned lo = (isnew ? 0u : (*fp & 0xFFFFu)) + (cnt > 65535u ? 65535u : cnt);
+        unsigned lo = (m.x & 0xFFFFu) + (cnt > 65535u ? 65535u : cnt);
         if (lo > 65535u) lo = 65535u;
-        *fp = (a.day << 16) | lo;
-        const unsigned f = isnew ? FLAG_DIRTY : *fl;
-        if (isnew) *fl = (unsigned char)FLAG_DIRTY;
-        if (f & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
+        mp->freq = (a.day << 16) | lo;
+        if (isnew) mp->flags = (unsigned char)FLAG_DIRTY;
+        if (m.y & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
       } else {
-        if (isnew) { *fp = 1u; *fl = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
+        if (isnew) { mp->freq = 1u; mp->flags = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
         lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
       }
     }
@@ -645,12 +674,18 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
 
     // ---- pass 2 (lookup / unique): every entry learns its key's row / dense index --------------
     if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) {
-      for (unsigned x = tid; x < E; x += TBK) {
-        const size_t ge = seg_entry(tpre, tstart, NT, x);
-        const long long key = w.ent_key[ge];
-        if (!in_round(key, R, round)) continue;
-        bool first;
-        w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+          if (cge[k] != 0xFFFFFFFFu) w.ent_b[cge[k]] = hrow[cslot[k]];
+      } else {
+        for (unsigned x = tid; x < E; x += TBK) {
+          const size_t ge = seg_entry(tpre, tstart, NT, x);
+          const long long key = w.ent_key[ge];
+          if (!in_round(key, R, round)) continue;
+          bool first;
+          w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
+        }
       }
     }
     __syncthreads();
@@ -696,36 +731,47 @@ __host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, 
 template <int OPT>
 __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
                                                 unsigned* r0, unsigned* r1, unsigned* newbits) {
-  unsigned rv = table_find(a.tv, key);
-  unsigned s0 = table_find(a.ts0, key);
-  unsigned s1 = (OPT == OPT_FTRL) ? table_find(a.ts1, key) : 0u;
+  // hop 1: the home entries of every table, together
+  const unsigned long long hh = mix64((unsigned long long)key);
+  const unsigned long long pv = home_of(a.tv, key, hh), p0 = home_of(a.ts0, key, hh);
+  const unsigned long long p1 = (OPT == OPT_FTRL) ? home_of(a.ts1, key, hh) : 0ull;
+  const Entry ev = load_entry(&a.tv.entries[pv]);
+  const Entry e0 = load_entry(&a.ts0.entries[p0]);
+  Entry e1 = e0;
+  if (OPT == OPT_FTRL) e1 = load_entry(&a.ts1.entries[p1]);
+  unsigned rv = table_find_from(a.tv, key, pv, ev);
+  unsigned s0 = table_find_from(a.ts0, key, p0, e0);
+  unsigned s1 = (OPT == OPT_FTRL) ? table_find_from(a.ts1, key, p1, e1) : 0u;
+  // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too)
+  const uint2 mv = load_freq_flags(a.tv, rv);
+  const unsigned f0 = meta_ptr(a.ts0, s0)->freq;
+  const unsigned f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
   bool vnew = false, new0 = false, new1 = false;
   if (rv == 0) {
     rv = table_find_or_insert(a.tv, key, &vnew);
-    if (rv && vnew) { *freq_ptr(a.tv, rv) = 1u; *flags_ptr(a.tv, rv) = 0; }  // table_manager.h:94
+    if (rv && vnew) { RowMeta* m = meta_ptr(a.tv, rv); m->freq = 1u; m->flags = 0; }  // table_manager.h:94
   }
   *tag = rv; *r0 = 0; *r1 = 0; *newbits = vnew ? 1u : 0u;
   if (rv == 0) return;
   if (!vnew) {
-    const unsigned f = *freq_ptr(a.tv, rv);
-    if ((f & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
-    unsigned char* fl = flags_ptr(a.tv, rv);
-    if (*fl & FLAG_BLACK) *fl = FLAG_UNDER;  // RemoveBlacklistUnsafe: fresh zero row (ours already is)
+    if ((mv.x & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
+    // RemoveBlacklistUnsafe: fresh zero row (ours already is)
+    if (mv.y & FLAG_BLACK) meta_ptr(a.tv, rv)->flags = FLAG_UNDER;
   }
-  auto touch = [&](const TableDev& t, unsigned r, bool isnew) {
+  auto touch = [&](const TableDev& t, unsigned r, bool isnew, unsigned fold) {
     unsigned* fp = freq_ptr(t, r);
     if (isnew) { *fp = 1u; return; }
-    unsigned lo = (*fp & 0xFFFFu) + 1u;   // AddFrequency(1, today) kv_variable.h:409-414
+    unsigned lo = (fold & 0xFFFFu) + 1u;   // AddFrequency(1, today) kv_variable.h:409-414
     if (lo > 65535u) lo = 65535u;
     *fp = (a.day << 16) | lo;
   };
   if (OPT == OPT_FTRL) {
     if (s1 == 0) s1 = table_find_or_insert(a.ts1, key, &new1);
-    if (s1) touch(a.ts1, s1, new1);
+    if (s1) touch(a.ts1, s1, new1, f1);
     *r1 = s1;
   }
   if (s0 == 0) s0 = table_find_or_insert(a.ts0, key, &new0);
-  if (s0) touch(a.ts0, s0, new0);
+  if (s0) touch(a.ts0, s0, new0, f0);
   *r0 = s0;
   *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
 }
@@ -803,23 +849,38 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
     for (unsigned x = tid; x < (unsigned)HMAXS * (unsigned)D; x += TBS) hsum[x] = 0.f;
     if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
     __syncthreads();
-    // every thread takes entries x = tid, tid + TBS, ...: balanced whatever the number of tiles
-    for (unsigned x = tid; x < E; x += TBS) {
-      const size_t ge = seg_entry(tpre, tstart, NT, x);
-      const long long key = w.ent_key[ge];
-      if (!in_round(key, R, round)) continue;
-      if (lnu >= (unsigned)UCAPS) { lovf = 1; break; }
-      const unsigned pos = (R == 1) ? x : atomicAdd(&lcls, 1u);  // R == 1: deterministic order
-      bool first;
-      const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key, true, &first);
-      if (first) {
-        const unsigned u = atomicAdd(&lnu, 1u);
-        if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
+    // every thread takes entries x = tid, tid + TBS, ...: balanced whatever the number of tiles;
+    // EB at a time so their global loads are in flight together
+    constexpr int EB = (ECAPS + TBS - 1) / TBS;
+    for (unsigned x0 = 0; x0 < E; x0 += EB * TBS) {
+      unsigned ge[EB], lb[EB];
+      long long key[EB];
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const unsigned x = x0 + k * TBS + tid;
+        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
       }
-      eb[pos] = w.ent_b[ge];
-      if (MODE == MODE_DEDUP) eloc[pos] = (unsigned)ge;
-      eslot[pos] = (unsigned short)h;
-      perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        key[k] = 0; lb[k] = 0;
+        if (ge[k] != 0xFFFFFFFFu) { key[k] = w.ent_key[ge[k]]; lb[k] = w.ent_b[ge[k]]; }
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
+        if (lnu >= (unsigned)UCAPS) { lovf = 1; continue; }
+        const unsigned pos = (R == 1) ? (x0 + k * TBS + tid) : atomicAdd(&lcls, 1u);  // R == 1: deterministic order
+        bool first;
+        const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key[k], true, &first);
+        if (first) {
+          const unsigned u = atomicAdd(&lnu, 1u);
+          if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
+        }
+        eb[pos] = lb[k];
+        if (MODE == MODE_DEDUP) eloc[pos] = ge[k];
+        eslot[pos] = (unsigned short)h;
+        perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
+      }
     }
     __syncthreads();
     if (lovf || lnu > (unsigned)UCAPS) {  // too many distinct keys for the LDS hash: split the class
@@ -913,13 +974,20 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
       __shared__ unsigned short hk[HMAXS];      // slot of heavy key j
       __shared__ unsigned hpre[HMAXS + 1];      // prefix of their entry counts
       __shared__ unsigned lnh;
-      if (tid == 0) {
-        unsigned n = 0, run = 0;
-        for (unsigned u = 0; u < nu && n < (unsigned)HMAXS; ++u) {
-          const unsigned h = ulist[u];
-          const unsigned cn = hval[h] >> 16;
-          if (cn > (unsigned)HEAVY) { hk[n] = (unsigned short)h; hpre[n] = run; run += cn; ++n; }
+      if (tid == 0) lnh = 0;
+      __syncthreads();
+      for (unsigned u = tid; u < nu; u += TBS) {
+        const unsigned h = ulist[u];
+        if ((hval[h] >> 16) > (unsigned)HEAVY) {
+          const unsigned j = atomicAdd(&lnh, 1u);
+          if (j < (unsigned)HMAXS) hk[j] = (unsigned short)h;
         }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned n = min(lnh, (unsigned)HMAXS);
+        unsigned run = 0;
+        for (unsigned j = 0; j < n; ++j) { hpre[j] = run; run += hval[hk[j]] >> 16; }
         hpre[n] = run;
         lnh = n;
       }

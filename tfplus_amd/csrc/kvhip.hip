@@ -192,6 +192,7 @@ struct kv_table {
   size_t route_hist_cap = 0;
   // optional per-kernel timing (kv_profile_*): event pairs recorded on the op's stream
   bool prof = false;
+  unsigned prof_mask = 0xFFFFFFFFu;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_kind;
   size_t ev_used = 0;
@@ -245,14 +246,11 @@ int add_chunk(kv_table* t, hipStream_t s) {
   const size_t R = (size_t)1 << t->chunk_bits;
   Chunk c{};
   HIP_TRY(hipMalloc(&c.rows, R * t->dim * sizeof(float)));
-  HIP_TRY(hipMalloc(&c.freq, R * sizeof(unsigned)));
-  HIP_TRY(hipMalloc(&c.flags, R));
-  HIP_TRY(hipMalloc(&c.keys, R * sizeof(long long)));
+  HIP_TRY(hipMalloc(&c.meta, R * sizeof(RowMeta)));
   if (t->chunks.empty()) {
     // row 0: the permanent zero row
     HIP_TRY(hipMemsetAsync(c.rows, 0, (size_t)t->dim * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(c.freq, 0, sizeof(unsigned), s));
-    HIP_TRY(hipMemsetAsync(c.flags, 0, 1, s));
+    HIP_TRY(hipMemsetAsync(c.meta, 0, sizeof(RowMeta), s));
   }
   t->chunks.push_back(c);
   HIP_TRY(hipMemcpyAsync(t->d_chunks + (t->chunks.size() - 1), &t->chunks.back(), sizeof(Chunk),
@@ -368,7 +366,7 @@ struct ProfScope {
   hipStream_t s;
   bool on;
   ProfScope(kv_table* t_, int kind, hipStream_t s_) : t(t_), s(s_), on(false) {
-    if (t->prof && t->ev_used + 2 <= t->ev.size()) {
+    if (t->prof && ((t->prof_mask >> kind) & 1u) && t->ev_used + 2 <= t->ev.size()) {
       on = true;
       t->ev_kind[t->ev_used / 2] = kind;
       hipEventRecord(t->ev[t->ev_used], s);
@@ -547,7 +545,7 @@ int kv_destroy(kv_handle_t t) {
   if (!t) return KV_OK;
   DeviceGuard dg(t->device);
   hipDeviceSynchronize();
-  for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.freq); hipFree(c.flags); hipFree(c.keys); }
+  for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.meta); }
   hipFree(t->entries); hipFree(t->d_chunks); hipFree(t->d_counters); hipFree(t->d_stat);
   hipFree(t->init_table);
   hipFree(t->route_hist);
@@ -989,6 +987,14 @@ int kv_profile_enable(kv_handle_t t, int max_launches) {
     t->ev.push_back(e);
   }
   t->ev_kind.assign((size_t)std::max(max_launches, 0), 0);
+  return KV_OK;
+}
+
+int kv_profile_select(kv_handle_t t, unsigned kind_mask) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  std::lock_guard<std::mutex> l(t->mu);
+  t->prof_mask = kind_mask;
   return KV_OK;
 }
 

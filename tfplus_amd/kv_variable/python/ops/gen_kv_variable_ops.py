@@ -362,6 +362,12 @@ def kv_profile_enable(table_handle, max_launches):
   _lib.check(_lib.lib().kv_profile_enable(table_handle.ptr, int(max_launches)))
 
 
+def kv_profile_select(table_handle, kinds=None):
+  """Brackets only the named kernel kinds (None = all)."""
+  mask = 0xFFFFFFFF if kinds is None else sum(1 << PROF_KINDS.index(k) for k in kinds)
+  _lib.check(_lib.lib().kv_profile_select(table_handle.ptr, mask))
+
+
 def kv_profile_read(table_handle):
   """{kernel kind: (total ms, launches)} from the HIP events recorded since the last read."""
   n = len(PROF_KINDS)

@@ -35,9 +35,16 @@ def rep(t, names, label):
     d = t[:, k + 1] - t[:, k]
     print("   %-34s median %8.0f  p90 %8.0f  max %8.0f" % (nm, np.median(d), np.percentile(d, 90), d.max()))
   tot = t[:, len(names)] - t[:, 0]
-  print("   block total median %.0f p90 %.0f max %.0f ; kernel span %.0f cycles" % (np.median(tot), np.percentile(tot, 90), tot.max(), t[:, len(names)].max() - t[:, 0].min()))
+  print("   block total median %.0f p90 %.0f max %.0f ; kernel span %.0f ticks(10ns)" % (np.median(tot), np.percentile(tot, 90), tot.max(), t[:, len(names)].max() - t[:, 0].min()))
 nt = (N + 2047) // 2048
 rep(a[:nt, :7], ["init + LDS hash insert", "compact + partition sort + entries", "slot_of_id writes", "multi-key offsets + perm", "chunk fold (all multi rows)", "spanning keys store"], "k_tile<APPLY>")
 pt = a[4096:4096 + 1024]
+bid = np.nonzero(pt[:, 4] > 0)[0]
+pt = pt[pt[:, 4] > 0]
+t0 = pt[:, 0].astype(np.int64); t4 = pt[:, 4].astype(np.int64)
+o = np.arange(len(t0)); cl = bid % 8     # workgroups are dealt round-robin to the 8 XCDs, one clock each
+for c in range(cl.max() + 1):
+  m = o[cl == c]; b = t0[m].min()
+  print("  clock domain %d: %4d blocks, start skew median %6d p90 %6d max %6d ; last end %6d" % (c, len(m), np.median(t0[m] - b), np.percentile(t0[m] - b, 90), (t0[m] - b).max(), (t4[m] - b).max()))
 rep(pt[:, :5], ["count + copy entries + hash", "group + probes (1 thread/key)", "heavy keys (flattened fold)", "per-key rows + update"], "k_part_sum<APPLY>")
 print("   entries/round median %d max %d ; rounds max %d ; uniques median %d max %d" % (np.median(pt[:, 8]), pt[:, 8].max(), pt[:, 9].max(), np.median(pt[:, 10]), pt[:, 10].max()))

@@ -23,15 +23,25 @@ for rep in range(3):
   ids = bench.splitmix64(z.sample(N, gen))
   _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), st))
 nb = 1024
-a = np.zeros((nb, 16), np.uint64)
+a = np.zeros((8192, 16), np.uint64)
 L.kv_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
-L.kv_debug_read_stamps(var.ptr, a.ctypes.data, nb)
+L.kv_debug_read_stamps(var.ptr, a.ctypes.data, 8192)
+tt = a[:(N + 2047) // 2048, :4].astype(np.int64)
+print("k_tile<LOOKUP> phases (median ticks(10ns)):", [int(np.median(tt[:, k + 1] - tt[:, k])) for k in range(3)])
+a = a[4096:4096 + nb]
+bid = np.nonzero(a[:, 4] > 0)[0]
+a = a[a[:, 4] > 0]
+t0 = a[:, 0].astype(np.int64); t4 = a[:, 4].astype(np.int64)
+o = np.arange(len(t0)); cl = bid % 8     # workgroups are dealt round-robin to the 8 XCDs, one clock each
+for c in range(cl.max() + 1):
+  m = o[cl == c]; b = t0[m].min()
+  print("  clock domain %d: %4d blocks, start skew median %6d p90 %6d max %6d ; last end %6d" % (c, len(m), np.median(t0[m] - b), np.percentile(t0[m] - b, 90), (t0[m] - b).max(), (t4[m] - b).max()))
 t = a[:, :8].astype(np.int64)
 E = a[:, 8].astype(np.int64); R = a[:, 9].astype(np.int64); NU = a[:, 10].astype(np.int64)
 names = ["pass1 stream+hash", "owner (1 thread/key)", "lane work (new/dirty)", "pass2 writeback"]
 for k in range(4):
   d = t[:, k + 1] - t[:, k]
-  print("%-18s median %8.0f  p90 %8.0f  max %8.0f cycles" % (names[k], np.median(d), np.percentile(d, 90), d.max()))
+  print("%-18s median %8.0f  p90 %8.0f  max %8.0f ticks(10ns)" % (names[k], np.median(d), np.percentile(d, 90), d.max()))
 tot = t[:, 4] - t[:, 0]
 print("block total: median %.0f p90 %.0f max %.0f; kernel span %.0f" % (np.median(tot), np.percentile(tot, 90), tot.max(), t[:, 4].max() - t[:, 0].min()))
 print("uniques: median %d max %d ; rounds max %d ; lane-work rows median %d max %d" % (np.median(E), E.max(), R.max(), np.median(NU), NU.max()))
