@@ -306,6 +306,13 @@ __device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
     o[0] = p[0];
   }
 }
+// same, for data this launch reads exactly once (gradient rows): streaming load, so the table rows
+// and the partition lists keep the L2 / infinity cache
+template <int V>
+__device__ __forceinline__ void ldv_stream(const float* p, float (&o)[V]) {
+#pragma unroll
+  for (int c = 0; c < V; ++c) o[c] = __builtin_nontemporal_load(p + c);
+}
 template <int V>
 __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
   if (V == 4) {

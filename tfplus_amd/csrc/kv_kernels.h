@@ -327,7 +327,11 @@ __global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ i
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
               const int q = lane8 + 8 * v;
-              if (q < NV) val[r][v] = g4[q];
+              if (q < NV) {  // read once: streaming load
+                const float* gp = reinterpret_cast<const float*>(g4 + q);
+                val[r][v] = make_float4(__builtin_nontemporal_load(gp), __builtin_nontemporal_load(gp + 1),
+                                        __builtin_nontemporal_load(gp + 2), __builtin_nontemporal_load(gp + 3));
+              }
             }
           }
         }
@@ -1037,7 +1041,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
 #pragma unroll
               for (int k = 0; k < K; ++k) {
                 const int e0 = (lane + k * LPR) * V;
-                if (e0 < D) ldv<V>(src + e0, val[r][k]);
+                if (e0 < D) ldv_stream<V>(src + e0, val[r][k]);
               }
             }
           }
@@ -1117,7 +1121,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                   const int e0 = (lane + k * LPR) * V;
-                  if (e0 < D) ldv<V>(src + e0, val[r][k]);
+                  if (e0 < D) ldv_stream<V>(src + e0, val[r][k]);
                 }
               }
             }
@@ -1152,33 +1156,55 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
 template <int VQ>
 __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out,
                                                long long n) {
-  if constexpr (VQ > 0) {
-    constexpr int RPB = TB / VQ;  // rows per block per step
+  if constexpr (VQ > 0 && VQ <= 64) {
+    // One wave takes 64 consecutive output rows per step.  Lane l resolves row l's table row id
+    // (slot_of_id -> ent_b: two dependent loads, 64 rows in flight per wave and no redundancy);
+    // then the wave copies the rows VQ lanes per row, 64 / VQ rows per instruction, CH
+    // instructions in flight, the row ids passed between lanes with ds_bpermute.
+    constexpr int RW = 64 / VQ;            // rows per copy instruction
+    constexpr int CH = VQ < 8 ? VQ : 8;    // copy instructions in flight
+    const int lane = threadIdx.x & 63;
+    const int v = lane % VQ, sub = lane / VQ;
+    const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (TB / 64);
+    // software pipeline over the wave's steps: while step i copies rows, step i+1's row ids and
+    // step i+2's slots are already in flight (the three dependent hops overlap across steps)
+    const long long stride = nwaves * 64;
+    long long r0 = wave * 64;
+    unsigned sl1 = 0, sl2 = 0, rr = 0;
+    if (r0 + lane < n) rr = w.ent_b[__builtin_nontemporal_load(&w.slot_of_id[r0 + lane])];
+    if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_of_id[r0 + stride + lane]);
+    for (; r0 < n; r0 += stride) {
+      unsigned rr1 = 0;
+      if (r0 + stride + lane < n) rr1 = w.ent_b[sl1];
+      if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_of_id[r0 + 2 * stride + lane]);
+#pragma unroll
+      for (int j0 = 0; j0 < VQ; j0 += CH) {
+        float4 val[CH];
+        unsigned rj[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const long long ii = r0 + (j0 + j) * RW + sub;
+          if (ii < n) {  // the output is not read again by this launch: streaming store, keep L2 for the rows
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+            __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+            __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+          }
+        }
+      }
+      rr = rr1;
+      sl1 = sl2;
+    }
+  } else if constexpr (VQ > 64) {
+    constexpr int RPB = TB / VQ;  // rows per block per step (VQ = 128, 256)
     const int v = threadIdx.x % VQ;
-    const long long r0 = (long long)blockIdx.x * RPB + threadIdx.x / VQ;
-    const long long stride = (long long)gridDim.x * RPB;
-    constexpr int UNR = 4;
-    for (long long i = r0; i < n; i += stride * UNR) {
-      unsigned sl[UNR], rr[UNR];
-      float4 val[UNR];
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        const long long ii = i + k * stride;
-        sl[k] = ii < n ? w.slot_of_id[ii] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        const long long ii = i + k * stride;
-        rr[k] = ii < n ? w.ent_b[sl[k]] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < UNR; ++k)
-        val[k] = reinterpret_cast<const float4*>(row_ptr(t, rr[k]))[v];
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        const long long ii = i + k * stride;
-        if (ii < n) reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4))[v] = val[k];
-      }
+    for (long long i = (long long)blockIdx.x * RPB + threadIdx.x / VQ; i < n; i += (long long)gridDim.x * RPB) {
+      const unsigned r = w.ent_b[w.slot_of_id[i]];
+      reinterpret_cast<float4*>(out + (size_t)i * (VQ * 4))[v] = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
     }
   } else {
     const int D = t.dim;

@@ -705,7 +705,8 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
     const int q = (D % 4 == 0) ? D / 4 : 0;
     const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= TB;
     const long long rows_per_block = vec ? TB / q : 1;
-    const int grid = vec ? nblocks((m + 3) / 4, (int)rows_per_block, 4096) : nblocks(m * D, TB, 4096);
+    constexpr int gcap = 8192;  // one 64-row step per wave at 1M rows: residency, not a loop, hides the hops
+    const int grid = vec ? nblocks(m, q <= 64 ? TB : (int)rows_per_block, gcap) : nblocks(m * D, TB, 4096);
     switch (vec ? q : 0) {
       case 1: k_gather<1><<<grid, TB, 0, s>>>(td, wd, op, m); break;
       case 2: k_gather<2><<<grid, TB, 0, s>>>(td, wd, op, m); break;
