@@ -306,6 +306,18 @@ def main():
   lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)
   apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D
 
+  # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+  # figure is the one collected by scripts_prof.sh (rocprofv3 --pmc passes of this same command) and
+  # committed under profiles/; null when that file is absent or was taken on another workload.
+  traffic, traffic_src = None, None
+  try:
+    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+    if tj.get("workload") == [K, N, D, args.zipf] and dom in tj["kernels"]:
+      traffic = tj["kernels"][dom]["hbm_bytes"]
+      traffic_src = "profiles/r01_traffic.json: " + tj["source"]
+  except (OSError, ValueError, KeyError):
+    pass
+
   res = {
       "metric": "lookups+GroupAdam-applies/sec and HBM GB/s, 1M int64 ids x dim32",
       "value": value,
@@ -326,7 +338,7 @@ def main():
                  "parallelism": ("table hash-sharded over %d GPUs (id mod G), all_to_all id/row/grad exchange "
                                  "over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
                    "launches_timed": int(timed[dom][1]),
                    "measured": "hipEvent pairs on the op's stream around every launch of this kernel inside "

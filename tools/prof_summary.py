@@ -38,6 +38,16 @@ for n, v in pm.items():
     extra = "  hbm_read_MB %.1f  hbm_write_MB %.1f" % (2 * fs * 1024 / 1e6, ws * 1024 / 1e6)
   print("%-44s%s" % (n, extra))
   for c in sorted(v): print("      %-24s %16.1f" % (c, v[c]))
+# machine-readable HBM traffic per launch for bench.py's roofline.traffic (bytes; reads = 2 x FETCH_SIZE)
+traffic = {}
+for n, v in pm.items():
+  fs, ws = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+  if fs is not None and ws is not None:
+    traffic[n.split()[0]] = {"hbm_bytes": 2 * fs * 1024 + ws * 1024, "read_bytes": 2 * fs * 1024, "write_bytes": ws * 1024,
+                             "fetch_size_kib_raw": fs, "write_size_kib_raw": ws}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean of the last 3 launches; "
+                     "reads = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B)", "kernels": traffic},
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)
 try:
   b = json.load(open(os.path.join(out, "bench_under_trace.json")))
   print(); print("bench.py line of the traced run:"); print(json.dumps({k: b[k] for k in ("ms_per_step", "kernels_ms", "roofline")}))
