@@ -300,10 +300,11 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
   return KV_OK;
 }
 
-// partitions for a batch of n ids: ~512 input positions per partition block (so an all-distinct
-// batch still fits the partition kernels' LDS key tables), a power of two, at most MAX_P
+// partitions for a batch of n ids: a power of two <= MAX_P.  Large batches get MAX_P (all blocks
+// resident at once, <= ~1000 ids each at 1 M); small batches are cut fine (~32 ids per block) so
+// a 2048-id op still spreads over 64 CUs instead of running 4 long blocks
 unsigned pick_partitions(long long n) {
-  unsigned long long want = (unsigned long long)((n + 511) / 512);
+  unsigned long long want = (unsigned long long)((n + 31) / 32);
   unsigned P = 1;
   while (P < want && P < (unsigned)MAX_P) P <<= 1;
   return P;

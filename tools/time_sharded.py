@@ -25,7 +25,14 @@ t, served = T(lambda: sharded.exchange(rt, uniq, presorted=rt.bucketed_ids)); pr
 t, sc = T(lambda: sharded.exchange(rt, ucnt)); print("exchange counts        %.3f ms" % t)
 t, rows = T(lambda: ops.kv_variable_gather_or_insert_with_counts(var, served, sc)); print("owner lookup           %.3f ms" % t)
 t, urows = T(lambda: sharded.exchange(rt, rows, reverse=True)); print("exchange rows back     %.3f ms" % t)
-t, out = T(lambda: urows.index_select(0, inv.to(torch.int64))); print("expand (index_select)  %.3f ms" % t)
+t, out = T(lambda: ops.kv_take_rows(urows, inv)); print("expand (kv_take_rows)   %.3f ms" % t)
 t, (u2, summed, _) = T(lambda: ops.kv_dedup_segment_sum(var, ids, grad)); print("kv_dedup_segment_sum   %.3f ms" % t)
 t, g = T(lambda: sharded.exchange(rt, summed[:uniq.numel()])); print("exchange grads         %.3f ms" % t)
+slot = ops.kv_variable([3 * D], capacity_hint=K + 4 * N); ops.init_kv_variable_v2(slot, torch.zeros(4, 3 * D, device=dev))
+t, _ = T(lambda: ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, served, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0., 0., 0.)); print("owner apply            %.3f ms" % t)
+skv = sharded.ShardedKvVariable(type("S", (), {"sparse_read_with_counts": lambda self, i, c: ops.kv_variable_gather_or_insert_with_counts(var, i, c)})(),
+                                bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w), unique_fn=lambda i, c: ops.kv_unique(var, i, c),
+                                segsum_fn=lambda i, gg: ops.kv_dedup_segment_sum(var, i, gg), take_fn=ops.kv_take_rows)
+t, _ = T(lambda: skv.lookup(ids)); print("sharded lookup total   %.3f ms" % t)
+t, _ = T(lambda: skv.apply_gradients(lambda sh, gg, sv: ops.kv_variable_group_sparse_apply_adam_v4(var, slot, gg, sv, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0., 0., 0.), grad, ids)); print("sharded apply total    %.3f ms" % t)
 dist.destroy_process_group()
