@@ -178,6 +178,21 @@ int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int6
 int kv_unique(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq,
               int32_t* uniq_counts, int32_t* inverse, int64_t* num_unique, kv_stream_t stream);
 
+/* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
+ * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->
+ * segment_sum / sparse_segment_{sum,mean,sqrt_n}.  ids [n] are sp_ids.values, segment_ids [n] are
+ * sp_ids.indices[:, 0] (ascending, int32 or int64 = segment_dtype), weights [n] = sp_weights.values
+ * or NULL.  out [num_segments, dim]; a segment without ids is a zero row (weighted: 0/0 as in the
+ * reference).  Missing keys are inserted; count_occurrences != 0 adds every occurrence of a key to
+ * its frequency (the WithCounts path taken when enter_threshold > 0, embedding_ops.py:373-382),
+ * 0 adds 1 per distinct key.  n <= 2^21 per call. */
+#define KV_COMBINER_SUM 0
+#define KV_COMBINER_MEAN 1
+#define KV_COMBINER_SQRTN 2
+int kv_lookup_sparse(kv_handle_t h, const void* ids, const void* segment_ids, int segment_dtype,
+                     const float* weights, int64_t n, int64_t num_segments, int combiner,
+                     int count_occurrences, float* out, kv_stream_t stream);
+
 /* ---- multi-GPU routing helper (new design; the reference has no communication
  * layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
  * kernels/utility.h:90-107 ModKeyImpl, kept here) ----------------------------------------------

@@ -27,6 +27,7 @@ KV_DT_FLOAT = 1
 KV_DT_INT32 = 3
 KV_DT_INT64 = 9
 KV_DT_UINT64 = 23
+KV_COMBINER_SUM, KV_COMBINER_MEAN, KV_COMBINER_SQRTN = 0, 1, 2
 
 # every symbol include/kvhip.h declares (tests/test_abi.py checks the header against this)
 _c = ctypes
@@ -57,6 +58,7 @@ SIGNATURES = {
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kv_unique": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "kv_lookup_sparse": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "kv_take_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "kv_profile_enable": (_i32, [_vp, _i32]),
     "kv_profile_select": (_i32, [_vp, _c.c_uint32]),

@@ -395,6 +395,7 @@ struct PartArgs {
   long long* out_keys;        // MODE_DEDUP / MODE_UNIQUE
   float* out_sum;
   int* out_counts;            // MODE_UNIQUE: occurrences (saturating) of each unique key
+  int count_once;             // MODE_LOOKUP: frequency += 1 per unique key instead of per occurrence
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
         // flag was computed (FLAG_DIRTY) or the row is new — every other writer keeps it current
         uint2 m = make_uint2(0u, (unsigned)FLAG_DIRTY);
         if (!isnew) m = *reinterpret_cast<const uint2*>(&mp->freq);
-        const unsigned cnt = hval[s];
+        const unsigned cnt = a.count_once ? 1u : hval[s];
         unsigned lo = (m.x & 0xFFFFu) + (cnt > 65535u ? 65535u : cnt);
         if (lo > 65535u) lo = 65535u;
         mp->freq = (a.day << 16) | lo;
@@ -1311,6 +1312,71 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
     }
   }
 }
+// ---------------------------------------------------------------------------------------------
+// embedding_lookup_sparse (python/ops/embedding_ops.py:279-441) fused behind the lookup index:
+//   k_seg_offsets   CSR offsets of the sorted segment ids: off[s] = first position of segment s
+//   k_seg_combine   out[s] = combine_j( w_j * rows[row(id_j)] ) over the segment's positions, in
+//                   position order (tf.segment_sum order); mean: / sum w, sqrtn: / sqrt(sum w^2)
+// Segment ids outside [prev, num_segments) are clamped (memory safety only; TF rejects them).
+template <typename SegT>
+__global__ void __launch_bounds__(TB) k_seg_offsets(const SegT* __restrict__ seg, long long n, long long nseg,
+                                                    unsigned* __restrict__ off) {
+  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i <= n; i += (long long)gridDim.x * TB) {
+    long long prev = i > 0 ? (long long)seg[i - 1] : -1;
+    long long cur = i < n ? (long long)seg[i] : nseg;
+    prev = prev < -1 ? -1 : (prev > nseg ? nseg : prev);
+    cur = cur < 0 ? 0 : (cur > nseg ? nseg : cur);
+    for (long long sgi = prev + 1; sgi <= cur; ++sgi) off[sgi] = (unsigned)i;
+  }
+}
+
+// VQ = float4 lanes per row (dim / 4, power of two <= 64) or 0 = one thread per element.
+// has_w: sp_weights given (the reference multiplies, sums and divides by the weight sums);
+// otherwise tf.sparse_segment_{sum,mean,sqrt_n} (empty segment -> zeros).
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_seg_combine(TableDev t, WsDev w, const unsigned* __restrict__ off,
+                                                    const float* __restrict__ wts, long long nseg,
+                                                    int combiner, float* __restrict__ out) {
+  const int D = t.dim;
+  constexpr int LPS = VQ > 0 ? VQ : 1;          // lanes per segment
+  const int v = threadIdx.x % LPS;
+  const long long g0 = ((long long)blockIdx.x * TB + threadIdx.x) / LPS;
+  const long long gstride = (long long)gridDim.x * TB / LPS;
+  for (long long sgi = g0; sgi < nseg; sgi += gstride) {
+    const unsigned lo = off[sgi], hi = off[sgi + 1];
+    float wsum = 0.f, w2 = 0.f;
+    if constexpr (VQ > 0) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (unsigned j = lo; j < hi; ++j) {
+        const unsigned r = w.ent_b[w.slot_of_id[j]];
+        const float wj = wts ? wts[j] : 1.f;
+        const float4 x = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
+        acc.x += x.x * wj; acc.y += x.y * wj; acc.z += x.z * wj; acc.w += x.w * wj;
+        wsum += wj; w2 += wj * wj;
+      }
+      float den = 1.f;
+      if (combiner == 1) den = wsum; else if (combiner == 2) den = sqrtf(w2);
+      if (combiner != 0 && (wts || hi > lo)) { acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den; }
+      reinterpret_cast<float4*>(out + (size_t)sgi * D)[v] = acc;
+    } else {
+      for (int e = 0; e < D; ++e) {
+        float acc = 0.f;
+        wsum = 0.f; w2 = 0.f;
+        for (unsigned j = lo; j < hi; ++j) {
+          const unsigned r = w.ent_b[w.slot_of_id[j]];
+          const float wj = wts ? wts[j] : 1.f;
+          acc += row_ptr(t, r)[e] * wj;
+          wsum += wj; w2 += wj * wj;
+        }
+        float den = 1.f;
+        if (combiner == 1) den = wsum; else if (combiner == 2) den = sqrtf(w2);
+        if (combiner != 0 && (wts || hi > lo)) acc /= den;
+        out[(size_t)sgi * D + e] = acc;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_take_rows: out[i] = src[idx[i]] (SCATTER = 0) or out[idx[i]] = src[i] (SCATTER = 1) over rows of
 // `nu` units of type U (float4 when the row is a multiple of 16 bytes).  The exchange's permute /

@@ -159,6 +159,8 @@ struct Workspace {
   float* part = nullptr;
   long long part_elems = 0;
   unsigned* ctr = nullptr;
+  unsigned* seg_off = nullptr;   // kv_lookup_sparse: CSR offsets [seg_cap + 1]
+  long long seg_cap = 0;
   unsigned long long* dbg = nullptr;
 };
 
@@ -720,6 +722,74 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
       case 256: k_gather<256><<<grid, TB, 0, s>>>(td, wd, op, m); break;
       default: k_gather<0><<<grid, TB, 0, s>>>(td, wd, op, m); break;
     }
+  }
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, int segment_dtype,
+                     const float* weights, int64_t n, int64_t num_segments, int combiner, int count_occurrences,
+                     float* out, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (combiner < KV_COMBINER_SUM || combiner > KV_COMBINER_SQRTN)
+    return fail(KV_INVALID_ARGUMENT, "combiner must be one of 'mean', 'sqrtn' or 'sum'");  // embedding_ops.py:345
+  if (segment_dtype != KV_DT_INT32 && segment_dtype != KV_DT_INT64)
+    return fail(KV_INVALID_ARGUMENT, "segment ids must be int32 or int64");
+  if (n < 0 || n > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "sp_ids: %lld values (at most 2^21 per call)", (long long)n);
+  if (num_segments < 0 || num_segments > (1ll << 31) - 2) return fail(KV_INVALID_ARGUMENT, "bad num_segments");
+  if (num_segments == 0) return KV_OK;
+  if (!out || (n > 0 && (!ids || !segment_ids))) return fail(KV_INVALID_ARGUMENT, "ids / segment ids / output pointer is null");
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = t->dim;
+  if (n == 0) {  // every segment is empty
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * D * sizeof(float), s));
+    return KV_OK;
+  }
+  if ((rc = ensure_capacity(t, n, s))) return rc;
+  if ((rc = ensure_workspace(t, n, false, s))) return rc;
+  Workspace& ws = t->ws;
+  if (ws.seg_cap < num_segments) {
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(ws.seg_off);
+    ws.seg_cap = std::max<long long>(num_segments, ws.seg_cap * 2);
+    HIP_TRY(hipMalloc(&ws.seg_off, (size_t)(ws.seg_cap + 1) * sizeof(unsigned)));
+  }
+  const TableDev td = dev_view(t);
+  const WsDev wd = ws_view(t, n);
+  PartArgs pa{};
+  pa.tv = td; pa.ts0 = td; pa.ts1 = td;
+  pa.day = today(t);
+  pa.count_once = count_occurrences ? 0 : 1;
+  {
+    ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
+    launch_tile<MODE_LOOKUP>(t, wd, ids, nullptr, nullptr, n, s);
+  }
+  {
+    ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
+    if ((rc = launch_part<MODE_LOOKUP, 0>(wd, pa, s))) return rc;
+  }
+  ProfScope ps_gather(t, KV_PROF_LOOKUP_GATHER, s);
+  if (segment_dtype == KV_DT_INT32)
+    k_seg_offsets<int><<<nblocks(n + 1, TB, 2048), TB, 0, s>>>((const int*)segment_ids, n, num_segments, ws.seg_off);
+  else
+    k_seg_offsets<long long><<<nblocks(n + 1, TB, 2048), TB, 0, s>>>((const long long*)segment_ids, n, num_segments, ws.seg_off);
+  const int q = (D % 4 == 0) ? D / 4 : 0;
+  const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= 64;
+  const int grid = nblocks(num_segments * (vec ? q : 1), TB, 8192);
+  switch (vec ? q : 0) {
+    case 1: k_seg_combine<1><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 2: k_seg_combine<2><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 4: k_seg_combine<4><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 8: k_seg_combine<8><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 16: k_seg_combine<16><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 32: k_seg_combine<32><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    case 64: k_seg_combine<64><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
+    default: k_seg_combine<0><<<grid, TB, 0, s>>>(td, wd, ws.seg_off, weights, num_segments, combiner, out); break;
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;

@@ -99,11 +99,16 @@ def embedding_lookup_sparse(params, sp_ids, sp_weights, partition_strategy="mod"
   seg = torch.as_tensor(sp_ids.indices).to(dev)[:, 0].to(torch.int64)
   ids = torch.as_tensor(sp_ids.values).to(dev)
   need_counts = plist[0].enter_threshold > 0
+  nseg = int(seg.max().item()) + 1 if seg.numel() else 0
+  if (len(plist) == 1 and max_norm is None and kv_variable_ops.IS_TRAINING and hasattr(plist[0], "lookup_sparse")
+      and 0 < ids.numel() <= (1 << 21)):
+    # one table, training: the whole chain is one fused call (dedup + lookup + combine on the GPU)
+    return plist[0].lookup_sparse(ids, seg, None if sp_weights is None else sp_weights.values, nseg, combiner,
+                                  need_counts)
   uniq, idx, cnt = torch.unique(ids, return_inverse=True, return_counts=True)
   emb = _embedding_lookup_and_transform(plist, uniq, partition_strategy, max_norm=max_norm,
                                         counts=cnt.to(torch.int32) if need_counts else None)
   emb = emb.index_select(0, idx)
-  nseg = int(seg.max().item()) + 1 if seg.numel() else 0
   if sp_weights is not None:
     wts = torch.as_tensor(sp_weights.values, dtype=emb.dtype).to(dev).reshape(-1, 1)
   else:

@@ -390,6 +390,34 @@ def kv_bucket_by_owner(table_handle, indices, world):
   return out, perm, counts
 
 
+_COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}
+
+
+def kv_variable_lookup_sparse(table_handle, ids, segment_ids, weights, num_segments, combiner="mean",
+                              count_occurrences=False):
+  """embedding_lookup_sparse on one KvVariable in a single call: unique_with_counts ->
+  GatherOrInsert[WithCounts] -> weighted segment sum / mean / sqrtn (embedding_ops.py:279-441).
+  segment_ids ascending (sp_ids.indices[:, 0]); returns [num_segments, dim]."""
+  if combiner not in _COMBINERS:
+    raise ValueError("combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  ids = _ids(table_handle, ids).reshape(-1)
+  dev = _dev(table_handle)
+  seg = torch.as_tensor(segment_ids).to(dev).reshape(-1)
+  if seg.dtype not in _TORCH_KEY:
+    seg = seg.to(torch.int64)
+  seg = seg.contiguous()
+  if seg.numel() != ids.numel():
+    raise _lib.InvalidArgumentError("segment_ids and ids must have the same length")
+  w = None if weights is None else _f32(table_handle, weights).reshape(-1)
+  if w is not None and w.numel() != ids.numel():
+    raise _lib.InvalidArgumentError("sp_weights and sp_ids must have the same number of values")
+  out = torch.empty((int(num_segments), table_handle.dim), dtype=torch.float32, device=dev)
+  _lib.check(_lib.lib().kv_lookup_sparse(table_handle.ptr, _p(ids), _p(seg), _TORCH_KEY[seg.dtype], _p(w),
+                                         ids.numel(), int(num_segments), _COMBINERS[combiner],
+                                         int(bool(count_occurrences)), _p(out), _stream(table_handle)))
+  return out
+
+
 def kv_take_rows(src, index, scatter=False, num_rows=None):
   """out[i] = src[index[i]] (gather, default) or out[index[i]] = src[i] (scatter=True; index must be
   a permutation onto `num_rows` rows).  Any 4-byte-multiple row type; index int32 on the GPU."""

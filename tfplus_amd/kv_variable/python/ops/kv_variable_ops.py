@@ -43,6 +43,36 @@ class _GatherGrad(torch.autograd.Function):
     return None, None, None, None
 
 
+class _SparseLookupGrad(torch.autograd.Function):
+  """Fused embedding_lookup_sparse.  Gradient as TF builds it through gather / multiply /
+  segment_sum: IndexedSlices(values[j] = scale_j * grad[segment_j], indices = ids) with scale_j =
+  w_j (sum), w_j / sum_segment(w) (mean), w_j / sqrt(sum_segment(w^2)) (sqrtn); no gradient flows
+  to sp_weights here."""
+
+  @staticmethod
+  def forward(ctx, anchor, var, ids, seg, weights, nseg, combiner, count_occurrences):
+    ctx.var, ctx.ids, ctx.seg, ctx.weights, ctx.nseg, ctx.combiner = var, ids, seg, weights, nseg, combiner
+    return gen_kv_variable_ops.kv_variable_lookup_sparse(var.handle, ids, seg, weights, nseg, combiner,
+                                                         count_occurrences)
+
+  @staticmethod
+  def backward(ctx, grad):
+    var, ids, seg, w = ctx.var, ctx.ids, ctx.seg.to(torch.int64), ctx.weights
+    n = ids.numel()
+    wj = torch.ones(n, dtype=grad.dtype, device=grad.device) if w is None else w.to(grad.dtype)
+    if ctx.combiner == "mean":
+      den = torch.zeros(ctx.nseg, dtype=grad.dtype, device=grad.device).index_add_(0, seg, wj)
+      scale = wj / den.index_select(0, seg)
+    elif ctx.combiner == "sqrtn":
+      den = torch.zeros(ctx.nseg, dtype=grad.dtype, device=grad.device).index_add_(0, seg, wj * wj).sqrt()
+      scale = wj / den.index_select(0, seg)
+    else:
+      scale = wj
+    vals = grad.reshape(ctx.nseg, -1).index_select(0, seg) * scale.unsqueeze(1)
+    var._pending_grads.append(IndexedSlices(vals.contiguous(), ids.reshape(-1), None))
+    return None, None, None, None, None, None, None, None
+
+
 class KvVariable(object):
   """tfplus KvVariable(ResourceVariable) — kv_variable_ops.py:539."""
 
@@ -151,6 +181,17 @@ class KvVariable(object):
     if counts is not None:
       return gen_kv_variable_ops.kv_variable_gather_or_insert_with_counts(self._handle, ids, counts)
     return gen_kv_variable_ops.kv_variable_gather_or_insert_v2(self._handle, ids)
+
+  def lookup_sparse(self, ids, segment_ids, weights, num_segments, combiner, count_occurrences):
+    """embedding_lookup_sparse on this table in one fused call (training mode only)."""
+    ids = torch.as_tensor(ids).to(self._device).reshape(-1)
+    seg = torch.as_tensor(segment_ids).to(self._device).reshape(-1)
+    w = None if weights is None else torch.as_tensor(weights, dtype=torch.float32).to(self._device).reshape(-1)
+    if self._trainable and torch.is_grad_enabled():
+      return _SparseLookupGrad.apply(self._anchor, self, ids, seg, w, int(num_segments), combiner,
+                                     bool(count_occurrences))
+    return gen_kv_variable_ops.kv_variable_lookup_sparse(self._handle, ids, seg, w, num_segments, combiner,
+                                                         count_occurrences)
 
   def pop_gradients(self):
     """All IndexedSlices produced by backward passes since the last call, concatenated."""
