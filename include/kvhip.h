@@ -178,6 +178,24 @@ int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int6
 int kv_unique(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq,
               int32_t* uniq_counts, int32_t* inverse, int64_t* num_unique, kv_stream_t stream);
 
+/* ---- table hygiene ------------------------------------------------------
+ * KvVariableGetCountV2 (ops/kv_variable_ops.cc:349-358 -> KvVariable::GetCount kv_variable.h:503-524):
+ * counts[i] = frequency (low 16 bits) of ids[i], 0 when absent.
+ * KvVariableGetTimeStamp (ops :688-697 -> GetTimeStamp kv_variable.h:526-561): days[i] = day stamp
+ * (high 16 bits) of ids[i], today's day number when absent.  Both asynchronous. */
+int kv_get_count(kv_handle_t h, const void* ids, int64_t n, int32_t* counts, kv_stream_t stream);
+int kv_get_timestamp(kv_handle_t h, const void* ids, int64_t n, uint32_t* days, kv_stream_t stream);
+/* KvVariableDelete (ops :681-685 -> KvVariable::Delete kv_variable.h:737-755 -> DeleteKey
+ * table_manager.h:405-416): the keys disappear from the table (absent keys are ignored); their
+ * rows are recycled by later inserts.  *num_deleted (may be NULL) = keys actually removed.
+ * KvVariableDeleteWithTimestamp (ops :699-707 -> kv_variable.h:757-789): removes every key whose
+ * day stamp is > 0 and at least (uint16) threshold days before today.  dry_run != 0 only counts
+ * (*count); dry_run == 0 removes and writes the removed keys to delete_keys [>= that count].
+ * Both synchronous. */
+int kv_delete(kv_handle_t h, const void* ids, int64_t n, int64_t* num_deleted, kv_stream_t stream);
+int kv_delete_with_timestamp(kv_handle_t h, int threshold, int dry_run, int64_t* delete_keys,
+                             int64_t* count, kv_stream_t stream);
+
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
  * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->
  * segment_sum / sparse_segment_{sum,mean,sqrt_n}.  ids [n] are sp_ids.values, segment_ids [n] are

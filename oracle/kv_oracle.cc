@@ -686,6 +686,57 @@ void kvo_insert(void* h, const int64_t* ids, const float* vals, int64_t n) {
   }
 }
 
+// GetCount kv_variable.h:503-524 / GetTimeStamp :526-561
+void kvo_get_count(void* h, const int64_t* ids, int64_t n, int32_t* out) {
+  Table* t = static_cast<Table*>(h);
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(ids[i])];
+    auto it = sg.map.find(ids[i]);
+    out[i] = it == sg.map.end() ? 0 : int32_t(it->second.freq & 0xFFFF);
+  }
+}
+void kvo_get_timestamp(void* h, const int64_t* ids, int64_t n, uint32_t* out) {
+  Table* t = static_cast<Table*>(h);
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(ids[i])];
+    auto it = sg.map.find(ids[i]);
+    out[i] = it == sg.map.end() ? uint32_t(t->Today()) : uint32_t(it->second.freq >> 16);
+  }
+}
+
+// Delete kv_variable.h:737-755 -> DeleteKey table_manager.h:405-416 (Evict + erase)
+int64_t kvo_delete(void* h, const int64_t* ids, int64_t n) {
+  Table* t = static_cast<Table*>(h);
+  int64_t gone = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(ids[i])];
+    auto it = sg.map.find(ids[i]);
+    if (it == sg.map.end()) continue;
+    std::free(it->second.row);
+    sg.map.erase(it);
+    ++gone;
+  }
+  return gone;
+}
+
+// DeleteWithTimestamp kv_variable.h:757-789: key_time > 0 && current_time - key_time >=
+// uint16(threshold).  Returns the number of deleted keys; out (may be null) receives them.
+int64_t kvo_delete_with_timestamp(void* h, int threshold, int64_t* out) {
+  Table* t = static_cast<Table*>(h);
+  const int now = t->Today();
+  std::vector<int64_t> dl;
+  for (int s = 0; s < kSegments; ++s)
+    for (auto& kv : t->seg[s].map) {
+      const int kt = int(kv.second.freq >> 16);
+      if (kt > 0 && now - kt >= int(uint16_t(threshold))) dl.push_back(kv.first);
+    }
+  if (out) {
+    for (size_t i = 0; i < dl.size(); ++i) out[i] = dl[i];
+    kvo_delete(h, dl.data(), int64_t(dl.size()));
+  }
+  return int64_t(dl.size());
+}
+
 // ImportValues dynamic_restore.hpp:176-262: clear; insert keys/values (freq word 1,
 // under_threshold left false); blacklist keys are marked (absent ones inserted as blacklisted);
 // frequency words are set on keys that exist; the table counts as initialised.

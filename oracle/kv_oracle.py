@@ -66,6 +66,12 @@ def lib():
   L.kvo_insert.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64]
   L.kvo_import.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64, _i64p, ctypes.c_int64, _i64p,
                            _u32p, ctypes.c_int64]
+  L.kvo_get_count.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, _i32p]
+  L.kvo_get_timestamp.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, _u32p]
+  L.kvo_delete.restype = ctypes.c_int64
+  L.kvo_delete.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64]
+  L.kvo_delete_with_timestamp.restype = ctypes.c_int64
+  L.kvo_delete_with_timestamp.argtypes = [ctypes.c_void_p, ctypes.c_int, _i64p]
   L.kvo_get_meta.restype = ctypes.c_int
   L.kvo_get_meta.argtypes = [ctypes.c_void_p, ctypes.c_int64, _u32p, ctypes.POINTER(ctypes.c_int),
                              ctypes.POINTER(ctypes.c_int)]
@@ -146,6 +152,32 @@ class OracleKv:
     fv = np.ascontiguousarray(np.asarray(freq_values).reshape(-1), dtype=np.uint32)
     lib().kvo_import(self._h, _p(k, _i64p), _p(v, _f32p), k.size, _p(b, _i64p), b.size, _p(fk, _i64p),
                      _p(fv, _u32p), fk.size)
+
+  def get_count(self, ids):
+    i = _ids(ids)
+    out = np.empty(i.size, np.int32)
+    lib().kvo_get_count(self._h, _p(i, _i64p), i.size, _p(out, _i32p))
+    return out.reshape(np.asarray(ids).shape)
+
+  def get_timestamp(self, ids):
+    i = _ids(ids)
+    out = np.empty(i.size, np.uint32)
+    lib().kvo_get_timestamp(self._h, _p(i, _i64p), i.size, _p(out, _u32p))
+    return out.reshape(np.asarray(ids).shape)
+
+  def delete(self, ids):
+    i = _ids(ids)
+    return int(lib().kvo_delete(self._h, _p(i, _i64p), i.size))
+
+  def delete_with_timestamp(self, threshold):
+    n = int(lib().kvo_delete_with_timestamp(self._h, int(threshold), None))
+    out = np.empty(n, np.int64)
+    if n:
+      lib().kvo_delete_with_timestamp(self._h, int(threshold), _p(out, _i64p))
+    return out
+
+  def set_day(self, day):
+    lib().kvo_set_day(self._h, int(day))
 
   def size(self):
     return int(lib().kvo_size(self._h))

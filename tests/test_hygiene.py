@@ -1,0 +1,150 @@
+"""GetCount / GetTimeStamp / Delete / DeleteWithTimestamp
+(kv_variable.h:503-561,737-789) — oracle known answers on the CPU, parity on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import kv_oracle as ko
+
+DAY = 20000
+
+
+def _oracle(D=8, thr=0, seed=3, rows=64, day=DAY):
+  table = np.random.default_rng(seed).standard_normal((rows, D)).astype(np.float32)
+  return table, ko.OracleKv(D, thr, table, day=day, picker=1, seed=seed)
+
+
+def test_oracle_count_timestamp_delete():
+  _, o = _oracle()
+  o.gather_or_insert([1, 2, 2, 3, 3, 3])
+  np.testing.assert_array_equal(o.get_count([1, 2, 3, 4]), [1, 2, 3, 0])          # absent -> 0
+  np.testing.assert_array_equal(o.get_timestamp([1, 4]), [DAY, DAY])               # absent -> today
+  assert o.delete([2, 2, 99]) == 1 and o.map_size() == 2
+  np.testing.assert_array_equal(o.get_count([2]), [0])
+  assert float(np.abs(o.gather_or_zeros([2])).sum()) == 0.0
+  o.gather_or_insert([2])                                                           # comes back as a new key
+  np.testing.assert_array_equal(o.get_count([2]), [1])
+
+
+def test_oracle_delete_with_timestamp():
+  _, o = _oracle()
+  o.gather_or_insert([1, 2])
+  o.set_day(DAY + 3)
+  o.gather_or_insert([3])
+  o.insert([4], np.ones((1, 8), np.float32))               # InsertOrUpdate: day stamp 0 -> never expires
+  o.set_day(DAY + 7)
+  assert sorted(o.delete_with_timestamp(7).tolist()) == [1, 2]     # 7 days old: >= threshold
+  assert sorted(o.as_dict()) == [3, 4]
+  assert o.delete_with_timestamp(7).size == 0
+
+
+# ----------------------------------------------------------------------------------------------------
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+def _pair(ops, D=8, thr=0, seed=3, rows=64, cap=0):
+  table, o = _oracle(D, thr, seed, rows)
+  h = ops.kv_variable([D], enter_threshold=thr, capacity_hint=cap)
+  ops.kv_set_clock_days(h, DAY)
+  ops.kv_set_seed(h, seed)
+  ops.init_kv_variable_v2(h, table)
+  return h, o
+
+
+def _same_table(ops, h, o):
+  k, v = ops.read_kv_variable_op_v2(h)
+  got = dict(zip(k.cpu().numpy().tolist(), map(bytes, v.cpu().numpy())))
+  assert got == {kk: bytes(vv) for kk, vv in o.as_dict().items()}
+  assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_frequency(h) == o.sum_freq()
+  assert ops.kv_variable_shape_v2(h)[0] == o.map_size()
+
+
+@pytest.mark.gpu
+def test_count_and_timestamp_parity(ops):
+  h, o = _pair(ops)
+  rng = np.random.default_rng(0)
+  ids = rng.integers(-30, 30, 500)
+  ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+  q = np.arange(-40, 40).reshape(8, 10)                     # output keeps the shape of indices
+  c = ops.kv_variable_get_count_v2(h, q)
+  assert c.dtype == torch.int32 and tuple(c.shape) == (8, 10)
+  np.testing.assert_array_equal(c.cpu().numpy(), o.get_count(q))
+  np.testing.assert_array_equal(ops.kv_variable_get_time_stamp(h, q).cpu().numpy(), o.get_timestamp(q))
+  assert ops.kv_variable_get_count_v2(h, np.zeros((0,), np.int64)).numel() == 0
+
+
+@pytest.mark.gpu
+def test_delete_parity_and_row_recycling(ops):
+  h, o = _pair(ops, D=16, cap=4096)
+  s_h, s_o = _pair(ops, D=48, seed=4, cap=4096)
+  rng = np.random.default_rng(1)
+  for rnd in range(6):
+    ids = rng.integers(-300, 300, 700)
+    np.testing.assert_array_equal(ops.kv_variable_gather_or_insert_v2(h, ids).cpu().numpy(), o.gather_or_insert(ids))
+    g = rng.normal(0, 1e-2, (ids.size, 16)).astype(np.float32)
+    ops.kv_variable_group_sparse_apply_adam_v4(h, s_h, g, ids, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    u, inv = np.unique(ids, return_inverse=True)
+    uu, summed, _ = ko.dedup_segment_sum(ids, g)
+    ko.apply_group_adam(o, s_o, summed, uu, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
+    dele = rng.integers(-300, 300, 150)                     # with repeats and absent keys
+    n_gpu = ops.kv_variable_delete(h, dele)
+    assert n_gpu == o.delete(dele)
+    assert ops.kv_variable_delete(s_h, dele[:50]) == s_o.delete(dele[:50])
+    assert float(ops.kv_variable_gather_or_zeros_v2(h, dele).abs().sum()) == 0.0
+    np.testing.assert_array_equal(ops.kv_variable_get_count_v2(h, dele).cpu().numpy(), 0)
+  # rows were recycled: the slab never grew past the largest live set (+ one batch)
+  k, v = ops.read_kv_variable_op_v2(h)
+  got = {int(a): b for a, b in zip(k.cpu().numpy(), v.cpu().numpy())}
+  want = o.as_dict()
+  assert set(got) == set(want)
+  for kk in want:
+    np.testing.assert_allclose(got[kk], want[kk], rtol=2e-6, atol=1e-7)
+  assert ops.kv_variable_shape_v2(h)[0] == o.map_size() and ops.kv_variable_frequency(h) == o.sum_freq()
+  assert ops.kv_variable_shape_v2(s_h)[0] == s_o.map_size()
+
+
+@pytest.mark.gpu
+def test_delete_then_index_rebuild_and_growth(ops):
+  """Tombstones must not survive a rebuild, freed rows must not be re-indexed, and a table that
+  keeps deleting and inserting fresh keys keeps working past its initial capacity."""
+  h, o = _pair(ops, D=4, cap=256)
+  nxt = 0
+  for rnd in range(40):
+    ids = np.arange(nxt, nxt + 200); nxt += 200
+    ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+    kill = ids[::2] if rnd % 3 else ids                    # some rounds delete everything they added
+    assert ops.kv_variable_delete(h, kill) == o.delete(kill)
+  _same_table(ops, h, o)
+  probe = np.arange(0, nxt, 7)
+  np.testing.assert_array_equal(ops.kv_variable_gather_or_zeros_v2(h, probe).cpu().numpy(), o.gather_or_zeros(probe))
+  # the EMPTY-sentinel key and a revived key
+  big = np.array([np.iinfo(np.int64).min, 5, 5], np.int64)
+  ops.kv_variable_gather_or_insert_v2(h, big); o.gather_or_insert(big)
+  assert ops.kv_variable_delete(h, big) == o.delete(big)
+  ops.kv_variable_gather_or_insert_v2(h, big); o.gather_or_insert(big)
+  _same_table(ops, h, o)
+
+
+@pytest.mark.gpu
+def test_delete_with_timestamp_parity(ops):
+  h, o = _pair(ops, D=8)
+  ops.kv_variable_gather_or_insert_v2(h, np.arange(0, 100)); o.gather_or_insert(np.arange(0, 100))
+  ops.kv_set_clock_days(h, DAY + 4); o.set_day(DAY + 4)
+  ops.kv_variable_gather_or_insert_v2(h, np.arange(50, 150)); o.gather_or_insert(np.arange(50, 150))
+  vals = np.ones((10, 8), np.float32)
+  ops.kv_variable_insert_v2(h, np.arange(200, 210), vals); o.insert(np.arange(200, 210), vals)   # day 0: kept
+  ops.kv_set_clock_days(h, DAY + 9); o.set_day(DAY + 9)
+  gone = ops.kv_variable_delete_with_timestamp(h, 7)
+  assert sorted(gone.cpu().numpy().tolist()) == sorted(o.delete_with_timestamp(7).tolist()) == list(range(0, 50))
+  _same_table(ops, h, o)
+  assert ops.kv_variable_delete_with_timestamp(h, 7).numel() == 0
+  gone = ops.kv_variable_delete_with_timestamp(h, 5)
+  assert sorted(gone.cpu().numpy().tolist()) == sorted(o.delete_with_timestamp(5).tolist()) == list(range(50, 150))
+  _same_table(ops, h, o)

@@ -9,6 +9,9 @@ constexpr unsigned FLAG_BLACK = 1u;   // EmbeddingValue::in_black_   (embedding_
 constexpr unsigned FLAG_UNDER = 2u;   // EmbeddingValue::under_threshold_
 constexpr unsigned FLAG_DIRTY = 4u;   // row changed since under_threshold was computed (Adagrad: no CoverUpdate)
 constexpr float CUTOFF = 1.0e-20f;    // DEFAULT_CUTOFF_VALUE (kv_variable_interface.h:55)
+constexpr unsigned FLAG_FREE = 8u;    // row released by Delete (table_manager.h:405-416): skipped by scans, reusable
+constexpr unsigned ROW_TOMB = 0xFFFFFFFFu;  // index entry of a deleted key (kept so probe chains stay intact;
+                                            // the same key revives it, an index rebuild drops it)
 constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < enter_threshold
 constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
 constexpr unsigned PART_BIT = 0x80000000u;      // gradient locator: partial-sum row, not an input row
@@ -60,7 +63,8 @@ struct TableDev {
   unsigned long long mask;  // cap - 1; entries[cap] = sentinel-key home
   Chunk* chunks;
   int chunk_bits;
-  unsigned* counters;  // [0] next_row  [1] error flag (row overflow)
+  unsigned* counters;  // [0] next_row  [1] error flag (row overflow)  [2] (int) rows on the free list
+  const unsigned* free_rows;  // rows released by Delete, popped by inserts (nullptr: none known)
   unsigned max_rows;
   const float* init_table;
   unsigned init_rows;
@@ -143,12 +147,12 @@ __device__ __forceinline__ Entry load_entry(const Entry* e) {
 __device__ __forceinline__ unsigned table_find(const TableDev& t, long long key) {
   if (key == EMPTY_KEY) {
     Entry e = load_entry(&t.entries[t.mask + 1]);
-    return e.key == 0 ? e.row : 0u;
+    return (e.key == 0 && e.row != ROW_TOMB) ? e.row : 0u;
   }
   unsigned long long p = mix64((unsigned long long)key) & t.mask;
   for (;;) {
     Entry e = load_entry(&t.entries[p]);
-    if (e.key == key) return e.row;
+    if (e.key == key) return e.row != ROW_TOMB ? e.row : 0u;
     if (e.key == EMPTY_KEY) return 0u;
     p = (p + 1) & t.mask;
   }
@@ -158,9 +162,9 @@ __device__ __forceinline__ unsigned table_find(const TableDev& t, long long key)
 // several tables can be in flight together)
 __device__ __forceinline__ unsigned table_find_from(const TableDev& t, long long key, unsigned long long p,
                                                    Entry e) {
-  if (key == EMPTY_KEY) return e.key == 0 ? e.row : 0u;
+  if (key == EMPTY_KEY) return (e.key == 0 && e.row != ROW_TOMB) ? e.row : 0u;
   for (;;) {
-    if (e.key == key) return e.row;
+    if (e.key == key) return e.row != ROW_TOMB ? e.row : 0u;
     if (e.key == EMPTY_KEY) return 0u;
     p = (p + 1) & t.mask;
     e = load_entry(&t.entries[p]);
@@ -184,14 +188,20 @@ __device__ __forceinline__ unsigned table_find_or_insert(const TableDev& t, long
     slot = &t.entries[t.mask + 1];
     stored = 0;  // the sentinel's home holds 0 when occupied
     Entry e = load_entry(slot);
-    if (e.key == stored) return e.row;
+    if (e.key == stored) {
+      if (e.row != ROW_TOMB) return e.row;
+      goto claimed;  // deleted earlier: the entry is still this key's, give it a row again
+    }
   } else {
     stored = key;
     unsigned long long p = mix64((unsigned long long)key) & t.mask;
     for (;;) {
       slot = &t.entries[p];
       Entry e = load_entry(slot);
-      if (e.key == key) return e.row;
+      if (e.key == key) {
+        if (e.row != ROW_TOMB) return e.row;
+        goto claimed;
+      }
       if (e.key == EMPTY_KEY) {
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slot->key),
                                            (unsigned long long)EMPTY_KEY, (unsigned long long)key);
@@ -207,11 +217,20 @@ __device__ __forceinline__ unsigned table_find_or_insert(const TableDev& t, long
     if (old != (unsigned long long)EMPTY_KEY) return load_entry(slot).row;  // cannot happen (single owner)
   }
 claimed:
-  unsigned r = atomicAdd(&t.counters[0], 1u);
-  if (r >= t.max_rows) {
-    atomicExch(&t.counters[1], 1u);
-    slot->row = 0;
-    return 0u;
+  unsigned r = 0;
+  bool have = false;
+  if (t.free_rows) {  // rows released by Delete first (pops only: Delete never runs beside an insert)
+    const int f = atomicSub(reinterpret_cast<int*>(&t.counters[2]), 1);
+    if (f > 0) { r = t.free_rows[f - 1]; have = true; }
+    else atomicAdd(reinterpret_cast<int*>(&t.counters[2]), 1);
+  }
+  if (!have) {
+    r = atomicAdd(&t.counters[0], 1u);
+    if (r >= t.max_rows) {
+      atomicExch(&t.counters[1], 1u);
+      slot->row = 0;
+      return 0u;
+    }
   }
   slot->row = r;
   *key_ptr(t, r) = key;

@@ -765,7 +765,7 @@ __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key
   }
   auto touch = [&](const TableDev& t, unsigned r, bool isnew, unsigned fold) {
     unsigned* fp = freq_ptr(t, r);
-    if (isnew) { *fp = 1u; return; }
+    if (isnew) { *fp = 1u; *flags_ptr(t, r) = 0; return; }
     unsigned lo = (fold & 0xFFFFu) + 1u;   // AddFrequency(1, today) kv_variable.h:409-414
     if (lo > 65535u) lo = 65535u;
     *fp = (a.day << 16) | lo;

@@ -58,6 +58,7 @@ __global__ void k_fill_i64(long long* p, long long v, unsigned long long count) 
 // re-insert rows [1, next_row) into a fresh index
 __global__ void k_rehash(TableDev t, unsigned nrows) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    if (*flags_ptr(t, r) & FLAG_FREE) continue;  // released by Delete: no index entry
     const long long key = *key_ptr(t, r);
     if (key == EMPTY_KEY) {
       Entry* s = &t.entries[t.mask + 1];
@@ -80,7 +81,7 @@ __global__ void k_stats(TableDev t, unsigned nrows, unsigned long long* out) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     const unsigned fl = *flags_ptr(t, r);
     const unsigned fr = *freq_ptr(t, r) & 0xFFFFu;
-    if (!(fl & FLAG_BLACK) && fr >= t.enter_threshold) { c += 1; f += fr; }
+    if (!(fl & (FLAG_BLACK | FLAG_FREE)) && fr >= t.enter_threshold) { c += 1; f += fr; }
   }
   for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); f += __shfl_xor(f, o); }
   if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], c); atomicAdd(&out[1], f); }
@@ -96,6 +97,62 @@ __global__ void k_get_meta(TableDev t, const IdT* ids, long long n, unsigned* fw
   }
 }
 
+// GetCount kv_variable.h:503-524 (absent -> 0, else the low 16 bits) and GetTimeStamp :526-561
+// (absent -> today, else the high 16 bits = day stamp of the last training lookup)
+template <typename IdT>
+__global__ void k_get_count_ts(TableDev t, const IdT* ids, long long n, int what, unsigned today, unsigned* out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const unsigned r = table_find(t, load_id(ids, (size_t)i));
+    const unsigned fw = r ? *freq_ptr(t, r) : 0u;
+    out[i] = what == 0 ? (r ? (fw & 0xFFFFu) : 0u) : (r ? (fw >> 16) : today);
+  }
+}
+
+// releases one key: its index entry becomes a tombstone, its row goes to the free list
+// (TableManager::DeleteKey table_manager.h:405-416: Evict + erase).  A key listed twice is
+// released once (the second probe finds the tombstone).
+__device__ __forceinline__ bool release_key(const TableDev& t, long long key, unsigned* free_rows) {
+  Entry* slot;
+  if (key == EMPTY_KEY) {
+    slot = &t.entries[t.mask + 1];
+    if (load_entry(slot).key != 0) return false;
+  } else {
+    unsigned long long p = mix64((unsigned long long)key) & t.mask;
+    for (;;) {
+      slot = &t.entries[p];
+      const Entry e = load_entry(slot);
+      if (e.key == key) break;
+      if (e.key == EMPTY_KEY) return false;
+      p = (p + 1) & t.mask;
+    }
+  }
+  const unsigned r = atomicExch(&slot->row, ROW_TOMB);   // duplicates of the key race here: one wins
+  if (r == ROW_TOMB || r == 0u) return false;
+  *flags_ptr(t, r) = (unsigned char)FLAG_FREE;
+  free_rows[atomicAdd(&t.counters[2], 1u)] = r;
+  return true;
+}
+template <typename IdT>
+__global__ void k_delete(TableDev t, const IdT* ids, long long n, unsigned* free_rows, unsigned long long* cnt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    if (release_key(t, load_id(ids, (size_t)i), free_rows)) atomicAdd(&cnt[0], 1ull);
+}
+// DeleteWithTimestamp kv_variable.h:757-789: keys whose day stamp is > 0 and at least `threshold`
+// days old.  fill == 0 only counts; fill == 1 releases them and lists their keys.
+__global__ void k_delete_by_time(TableDev t, unsigned nrows, unsigned today, unsigned threshold, int fill,
+                                 unsigned* free_rows, unsigned long long* cnt, long long* out_keys) {
+  for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    if (*flags_ptr(t, r) & FLAG_FREE) continue;
+    const unsigned kt = *freq_ptr(t, r) >> 16;
+    if (kt == 0 || (int)today - (int)kt < (int)threshold) continue;
+    const long long key = *key_ptr(t, r);
+    if (!fill) { atomicAdd(&cnt[0], 1ull); continue; }
+    if (release_key(t, key, free_rows)) out_keys[atomicAdd(&cnt[0], 1ull)] = key;
+  }
+}
+
 // ExportValues dynamic_save.hpp:47-195.  cnt[0..2] = rows, blacklist, freq.  fill != 0 writes.
 __global__ void k_export(TableDev t, unsigned nrows, int first_n, int fill, unsigned long long* cnt,
                          long long* keys, float* values, long long* blacklist, long long* fkeys,
@@ -105,6 +162,7 @@ __global__ void k_export(TableDev t, unsigned nrows, int first_n, int fill, unsi
     const unsigned fl = *flags_ptr(t, r);
     const unsigned fw = *freq_ptr(t, r);
     const long long key = *key_ptr(t, r);
+    if (fl & FLAG_FREE) continue;
     if (fl & FLAG_BLACK) {
       if (first_n > 3) {
         unsigned long long p = atomicAdd(&cnt[1], 1ull);
@@ -180,7 +238,15 @@ struct kv_table {
   int chunk_bits = 16;
   std::vector<Chunk> chunks;
   Chunk* d_chunks = nullptr;
-  unsigned* d_counters = nullptr;  // [0] next_row [1] error
+  unsigned* d_counters = nullptr;  // [0] next_row [1] error [2] rows on the free list
+  unsigned* free_rows = nullptr;   // rows released by Delete (device stack, rows_cap entries)
+  unsigned long long free_cap = 0;
+  long long free_known = 0;        // free-list length at the last sync (> 0: inserts pop from it)
+  unsigned long long idx_ub = 0;   // upper bound of claimed index entries (live keys + tombstones)
+  // exact claimed entries at a sync = idx_base + (next_row - bump_base) + free-list pops since the
+  // last index rebuild, pops = pushes_since - (free_now - free_base)   (revivals make it an upper bound)
+  unsigned long long idx_base = 0, bump_base = 1, pushes_since = 0;
+  long long free_base = 0;
   unsigned long long rows_cap = 0;  // chunks.size() << chunk_bits
   unsigned long long rows_ub = 1;   // upper bound of next_row
   // init table
@@ -234,6 +300,7 @@ TableDev dev_view(const kv_table* t) {
   d.chunks = t->d_chunks;
   d.chunk_bits = t->chunk_bits;
   d.counters = t->d_counters;
+  d.free_rows = t->free_known > 0 ? t->free_rows : nullptr;
   d.max_rows = (unsigned)std::min<unsigned long long>(t->rows_cap, 0x7FFFFFFFull);
   d.init_table = t->init_table;
   d.init_rows = (unsigned)t->init_rows;
@@ -276,29 +343,45 @@ int build_index(kv_table* t, unsigned long long newcap, unsigned nrows, hipStrea
   return KV_OK;
 }
 
-// make room for `extra` more keys (worst case: every id of the batch is new)
+// make room for `extra` more keys (worst case: every id of the batch is new).  rows_ub bounds the
+// bump allocator, idx_ub the claimed index entries (a key inserted into a row taken from the free
+// list claims a new entry while the deleted key's tombstone stays until the next rebuild).
 int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
   unsigned long long need = t->rows_ub + (unsigned long long)extra;
-  if (need > t->rows_cap || need * 2 > t->cap) {
-    // refresh the exact row count before deciding to grow
-    unsigned c[2];
+  unsigned long long need_idx = t->idx_ub + (unsigned long long)extra;
+  if (need > t->rows_cap || need_idx * 2 > t->cap) {
+    // refresh the exact counts before deciding to grow
+    unsigned c[3];
     HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (c[1]) return fail(KV_INTERNAL, "row slab overflow detected on device");
+    const long long freed = std::max(0, (int)c[2]);
     t->rows_ub = c[0];
+    t->free_known = freed;
+    t->idx_ub = t->idx_base + (c[0] - t->bump_base) +
+                (unsigned long long)std::max<long long>(0, (long long)t->pushes_since - (freed - t->free_base));
     need = t->rows_ub + (unsigned long long)extra;
+    need_idx = t->idx_ub + (unsigned long long)extra;
     if (need >= 0x7FFFFFFFull) return fail(KV_RESOURCE_EXHAUSTED, "more than 2^31 rows in one table");
     while (need > t->rows_cap) {
       int rc = add_chunk(t, s);
       if (rc) return rc;
     }
-    if (need * 2 > t->cap) {
-      unsigned long long nc = pow2ceil(std::max(need * 2, t->cap * 2));
+    if (need_idx * 2 > t->cap) {
+      // rebuild from the live rows: tombstones vanish, so the live count decides the size
+      const unsigned long long live = t->rows_ub - 1 - (unsigned long long)freed;
+      unsigned long long nc = pow2ceil(std::max<unsigned long long>((live + (unsigned long long)extra) * 2, 1024));
+      if (nc < t->cap && (live + (unsigned long long)extra) * 4 > t->cap) nc = t->cap;  // no shrink thrash
       int rc = build_index(t, nc, (unsigned)t->rows_ub, s);
       if (rc) return rc;
+      t->idx_ub = t->idx_base = live;
+      t->bump_base = t->rows_ub;
+      t->free_base = freed;
+      t->pushes_since = 0;
     }
   }
   t->rows_ub += (unsigned long long)extra;
+  t->idx_ub += (unsigned long long)extra;
   return KV_OK;
 }
 
@@ -549,7 +632,7 @@ int kv_destroy(kv_handle_t t) {
   DeviceGuard dg(t->device);
   hipDeviceSynchronize();
   for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.meta); }
-  hipFree(t->entries); hipFree(t->d_chunks); hipFree(t->d_counters); hipFree(t->d_stat);
+  hipFree(t->entries); hipFree(t->d_chunks); hipFree(t->d_counters); hipFree(t->d_stat); hipFree(t->free_rows);
   hipFree(t->init_table);
   hipFree(t->route_hist);
   for (auto e : t->ev) hipEventDestroy(e);
@@ -565,11 +648,12 @@ int kv_reserve(kv_handle_t t, int64_t capacity) {
   if ((rc = check_table(t))) return rc;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  unsigned long long save = t->rows_ub;
+  unsigned long long save = t->rows_ub, save_idx = t->idx_ub;
   long long extra = capacity + 1 - (long long)t->rows_ub;
   if (extra <= 0) return KV_OK;
   rc = ensure_capacity(t, extra, nullptr);
-  t->rows_ub = std::min(save, t->rows_ub);  // reserve does not consume the bound
+  t->rows_ub = std::min(save, t->rows_ub);  // reserve does not consume the bounds
+  t->idx_ub = std::min(save_idx, t->idx_ub);
   return rc;
 }
 
@@ -610,11 +694,12 @@ int kv_set_seed(kv_handle_t t, uint64_t seed) {
 }
 
 static int stats(kv_handle_t t, hipStream_t s, unsigned long long out[2], unsigned* nrows_out) {
-  unsigned c[2];
+  unsigned c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (c[1]) return fail(KV_INTERNAL, "row slab overflow detected on device");
   t->rows_ub = c[0];
+  t->free_known = std::max(0, (int)c[2]);
   if (nrows_out) *nrows_out = c[0];
   if (out) {
     HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
@@ -652,7 +737,7 @@ int kv_map_size(kv_handle_t t, int64_t* out, kv_stream_t stream) {
   std::lock_guard<std::mutex> l(t->mu);
   unsigned nrows = 1;
   if ((rc = stats(t, (hipStream_t)stream, nullptr, &nrows))) return rc;
-  *out = (int64_t)nrows - 1;
+  *out = (int64_t)nrows - 1 - t->free_known;
   return KV_OK;
 }
 
@@ -1020,6 +1105,113 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, int world, int
   return KV_OK;
 }
 
+// the free-list stack must hold every row of the slab
+static int ensure_free_list(kv_table* t, hipStream_t s) {
+  if (t->free_cap >= t->rows_cap) return KV_OK;
+  unsigned* nf = nullptr;
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMalloc(&nf, (size_t)t->rows_cap * sizeof(unsigned)));
+  if (t->free_rows) {
+    HIP_TRY(hipMemcpy(nf, t->free_rows, (size_t)t->free_cap * sizeof(unsigned), hipMemcpyDeviceToDevice));
+    hipFree(t->free_rows);
+  }
+  t->free_rows = nf;
+  t->free_cap = t->rows_cap;
+  return KV_OK;
+}
+
+// after a kernel that pushed rows: read the counters, account the pushes (synchronous)
+static int after_release(kv_table* t, hipStream_t s, unsigned long long* released) {
+  unsigned c[3];
+  unsigned long long n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, t->d_stat, sizeof n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  t->pushes_since += n;
+  t->free_known = std::max(0, (int)c[2]);
+  t->rows_ub = c[0];
+  *released = n;
+  return KV_OK;
+}
+
+int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (num_deleted) *num_deleted = 0;
+  if (n < 0 || (n > 0 && !ids)) return fail(KV_INVALID_ARGUMENT, "indices pointer is null");
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  if (n == 0) return KV_OK;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = ensure_free_list(t, s))) return rc;
+  HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
+  const TableDev td = dev_view(t);
+  if (t->key_dtype == KV_DT_INT32)
+    k_delete<int><<<nblocks(n, TB, 4096), TB, 0, s>>>(td, (const int*)ids, n, t->free_rows, t->d_stat);
+  else
+    k_delete<long long><<<nblocks(n, TB, 4096), TB, 0, s>>>(td, (const long long*)ids, n, t->free_rows, t->d_stat);
+  HIP_TRY(hipGetLastError());
+  unsigned long long rel = 0;
+  if ((rc = after_release(t, s, &rel))) return rc;
+  if (num_deleted) *num_deleted = (int64_t)rel;
+  return KV_OK;
+}
+
+int kv_delete_with_timestamp(kv_handle_t t, int threshold, int dry_run, int64_t* out_keys, int64_t* count,
+                             kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!count || (!dry_run && !out_keys)) return fail(KV_INVALID_ARGUMENT, "count / delete_keys pointer is null");
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned nrows = 1;
+  if ((rc = stats(t, s, nullptr, &nrows))) return rc;
+  if (!dry_run && (rc = ensure_free_list(t, s))) return rc;
+  HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
+  const unsigned thr = (unsigned)(threshold & 0xFFFF);  // static_cast<uint16_t>(threshold), kv_variable.h:771
+  k_delete_by_time<<<nblocks(nrows, TB, 4096), TB, 0, s>>>(dev_view(t), nrows, today(t), thr, dry_run ? 0 : 1,
+                                                        t->free_rows, t->d_stat, (long long*)out_keys);
+  HIP_TRY(hipGetLastError());
+  unsigned long long rel = 0;
+  if (dry_run) {
+    HIP_TRY(hipMemcpyAsync(&rel, t->d_stat, sizeof rel, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else if ((rc = after_release(t, s, &rel))) {
+    return rc;
+  }
+  *count = (int64_t)rel;
+  return KV_OK;
+}
+
+static int count_or_ts(kv_handle_t t, const void* ids, int64_t n, int what, uint32_t* out, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (n < 0 || (n > 0 && (!ids || !out))) return fail(KV_INVALID_ARGUMENT, "indices / output pointer is null");
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  if (n == 0) return KV_OK;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if (t->key_dtype == KV_DT_INT32)
+    k_get_count_ts<int><<<nblocks(n, TB, 4096), TB, 0, s>>>(dev_view(t), (const int*)ids, n, what, today(t), out);
+  else
+    k_get_count_ts<long long><<<nblocks(n, TB, 4096), TB, 0, s>>>(dev_view(t), (const long long*)ids, n, what, today(t), out);
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+int kv_get_count(kv_handle_t t, const void* ids, int64_t n, int32_t* counts, kv_stream_t stream) {
+  return count_or_ts(t, ids, n, 0, (uint32_t*)counts, stream);
+}
+int kv_get_timestamp(kv_handle_t t, const void* ids, int64_t n, uint32_t* days, kv_stream_t stream) {
+  return count_or_ts(t, ids, n, 1, days, stream);
+}
+
 int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, int64_t row_bytes, int scatter,
                  void* out, kv_stream_t stream) {
   if (n < 0 || row_bytes <= 0 || row_bytes % 4 || (n > 0 && (!src || !index || !out)))
@@ -1194,10 +1386,11 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   if (t->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "import with int32 keys");
   // clear(): dynamic_restore.hpp:60-62
   HIP_TRY(hipStreamSynchronize(s));
-  unsigned init[2] = {1, 0};
+  unsigned init[3] = {1, 0, 0};
   HIP_TRY(hipMemcpy(t->d_counters, init, sizeof init, hipMemcpyHostToDevice));  // stack source: synchronous
   k_fill_entries<<<nblocks((long long)t->cap + 1, TB, 8192), TB, 0, s>>>(t->entries, t->cap + 1);
   t->rows_ub = 1;
+  t->idx_ub = t->idx_base = 0; t->bump_base = 1; t->pushes_since = 0; t->free_base = 0; t->free_known = 0;
   if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 2, -1, nullptr, s))) return rc;
   if (n_black > 0 && (rc = scatter_like(t, blacklist, nullptr, n_black, 0, 1, 0, nullptr, s))) return rc;
   if (n_freq > 0 && (rc = scatter_like(t, fkeys, nullptr, n_freq, 0, 1, 1, fvals, s))) return rc;

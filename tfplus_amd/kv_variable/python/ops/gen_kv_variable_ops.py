@@ -390,6 +390,43 @@ def kv_bucket_by_owner(table_handle, indices, world):
   return out, perm, counts
 
 
+def kv_variable_get_count_v2(table_handle, indices):
+  """KvVariableGetCountV2: int32 frequency of every id (0 when absent), shaped like indices."""
+  ids = _ids(table_handle, indices)
+  out = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
+  _lib.check(_lib.lib().kv_get_count(table_handle.ptr, _p(ids), ids.numel(), _p(out), _stream(table_handle)))
+  return out
+
+
+def kv_variable_get_time_stamp(table_handle, indices):
+  """KvVariableGetTimeStamp: day stamp of every id (today when absent); uint32 in the reference,
+  carried as int64 here (torch has no uint32 arithmetic)."""
+  ids = _ids(table_handle, indices)
+  out = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
+  _lib.check(_lib.lib().kv_get_timestamp(table_handle.ptr, _p(ids), ids.numel(), _p(out), _stream(table_handle)))
+  return out.to(torch.int64) & 0xFFFFFFFF
+
+
+def kv_variable_delete(table_handle, indices):
+  """KvVariableDelete: removes the keys (absent ones are ignored)."""
+  ids = _ids(table_handle, indices).reshape(-1)
+  n = ctypes.c_int64()
+  _lib.check(_lib.lib().kv_delete(table_handle.ptr, _p(ids), ids.numel(), ctypes.byref(n), _stream(table_handle)))
+  return int(n.value)
+
+
+def kv_variable_delete_with_timestamp(table_handle, threshold=7):
+  """KvVariableDeleteWithTimestamp: removes keys last touched >= threshold days ago; returns them."""
+  n = ctypes.c_int64()
+  st = _stream(table_handle)
+  _lib.check(_lib.lib().kv_delete_with_timestamp(table_handle.ptr, int(threshold), 1, None, ctypes.byref(n), st))
+  keys = torch.empty(n.value, dtype=torch.int64, device=_dev(table_handle))
+  if n.value:
+    _lib.check(_lib.lib().kv_delete_with_timestamp(table_handle.ptr, int(threshold), 0, _p(keys), ctypes.byref(n), st))
+    keys = keys[:n.value]
+  return keys.to(table_handle.key_dtype) if table_handle.key_dtype != torch.int64 else keys
+
+
 _COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}
 
 

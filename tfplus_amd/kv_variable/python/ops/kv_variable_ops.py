@@ -193,6 +193,19 @@ class KvVariable(object):
     return gen_kv_variable_ops.kv_variable_lookup_sparse(self._handle, ids, seg, w, num_segments, combiner,
                                                          count_occurrences)
 
+  # -- table hygiene (kv_variable_ops.py:1129-1131, 1499-1518) -------------------------------------
+  def get_counting(self, indices, name=None):
+    return gen_kv_variable_ops.kv_variable_get_count_v2(self._handle, indices)
+
+  def delete(self, indices, name=None):
+    return gen_kv_variable_ops.kv_variable_delete(self._handle, indices)
+
+  def get_timestamp(self, indices, name=None):
+    return gen_kv_variable_ops.kv_variable_get_time_stamp(self._handle, indices)
+
+  def delete_with_timestamp(self, threshold, name=None):
+    return gen_kv_variable_ops.kv_variable_delete_with_timestamp(self._handle, threshold)
+
   def pop_gradients(self):
     """All IndexedSlices produced by backward passes since the last call, concatenated."""
     g, self._pending_grads = self._pending_grads, []
