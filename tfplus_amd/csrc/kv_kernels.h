@@ -577,9 +577,11 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
       const unsigned s = ulist[u];
       const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
       bool isnew = false;
+      // warm path: a read-only probe; the insert (atomics, row allocation) is a cold branch.
       // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
-      const unsigned r = (MODE == MODE_MARK && a.mark_what == 1) ? table_find(a.tv, key)
-                                                                 : table_find_or_insert(a.tv, key, &isnew);
+      unsigned r = table_find(a.tv, key);
+      if (__builtin_expect(r == 0u, 0) && !(MODE == MODE_MARK && a.mark_what == 1))
+        r = table_find_or_insert(a.tv, key, &isnew);
       hrow[s] = r;
       if (r == 0) continue;
       RowMeta* mp = meta_ptr(a.tv, r);
@@ -747,36 +749,47 @@ __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key
   unsigned rv = table_find_from(a.tv, key, pv, ev);
   unsigned s0 = table_find_from(a.ts0, key, p0, e0);
   unsigned s1 = (OPT == OPT_FTRL) ? table_find_from(a.ts1, key, p1, e1) : 0u;
+  // cold block (a key that is new to one of the tables; rare once the table is warm): ALL inserts
+  // happen here, so the steady-state path below is free of atomics and insert code
+  bool vnew = false, new0 = false, new1 = false;
+  if (__builtin_expect(rv == 0u || s0 == 0u || (OPT == OPT_FTRL && s1 == 0u), 0)) {
+    if (rv == 0u) {
+      rv = table_find_or_insert(a.tv, key, &vnew);
+      if (rv && vnew) { RowMeta* m = meta_ptr(a.tv, rv); m->freq = 1u; m->flags = 0; }  // table_manager.h:94
+    }
+    // slot rows are only created for keys the update will touch (kv_variable.h:910: filtered keys return first)
+    const bool filtered = rv == 0u || (!vnew && (meta_ptr(a.tv, rv)->freq & 0xFFFFu) < a.tv.enter_threshold);
+    if (!filtered) {
+      if (OPT == OPT_FTRL && s1 == 0u) {
+        s1 = table_find_or_insert(a.ts1, key, &new1);
+        if (s1 && new1) { RowMeta* m = meta_ptr(a.ts1, s1); m->freq = 1u; m->flags = 0; }
+      }
+      if (s0 == 0u) {
+        s0 = table_find_or_insert(a.ts0, key, &new0);
+        if (s0 && new0) { RowMeta* m = meta_ptr(a.ts0, s0); m->freq = 1u; m->flags = 0; }
+      }
+    }
+  }
   // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too)
   const uint2 mv = load_freq_flags(a.tv, rv);
   const unsigned f0 = meta_ptr(a.ts0, s0)->freq;
   const unsigned f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
-  bool vnew = false, new0 = false, new1 = false;
-  if (rv == 0) {
-    rv = table_find_or_insert(a.tv, key, &vnew);
-    if (rv && vnew) { RowMeta* m = meta_ptr(a.tv, rv); m->freq = 1u; m->flags = 0; }  // table_manager.h:94
-  }
   *tag = rv; *r0 = 0; *r1 = 0; *newbits = vnew ? 1u : 0u;
-  if (rv == 0) return;
+  if (rv == 0u) return;
   if (!vnew) {
     if ((mv.x & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
     // RemoveBlacklistUnsafe: fresh zero row (ours already is)
     if (mv.y & FLAG_BLACK) meta_ptr(a.tv, rv)->flags = FLAG_UNDER;
   }
+  // AddFrequency(1, today) on the slot rows that already existed (kv_variable.h:409-414); new ones keep freq word 1
   auto touch = [&](const TableDev& t, unsigned r, bool isnew, unsigned fold) {
-    unsigned* fp = freq_ptr(t, r);
-    if (isnew) { *fp = 1u; *flags_ptr(t, r) = 0; return; }
-    unsigned lo = (fold & 0xFFFFu) + 1u;   // AddFrequency(1, today) kv_variable.h:409-414
+    if (r == 0u || isnew) return;
+    unsigned lo = (fold & 0xFFFFu) + 1u;
     if (lo > 65535u) lo = 65535u;
-    *fp = (a.day << 16) | lo;
+    *freq_ptr(t, r) = (a.day << 16) | lo;
   };
-  if (OPT == OPT_FTRL) {
-    if (s1 == 0) s1 = table_find_or_insert(a.ts1, key, &new1);
-    if (s1) touch(a.ts1, s1, new1, f1);
-    *r1 = s1;
-  }
-  if (s0 == 0) s0 = table_find_or_insert(a.ts0, key, &new0);
-  if (s0) touch(a.ts0, s0, new0, f0);
+  if (OPT == OPT_FTRL) { touch(a.ts1, s1, new1, f1); *r1 = s1; }  // FTRL probes linear before accum (training_ops.cc:701-704)
+  touch(a.ts0, s0, new0, f0);
   *r0 = s0;
   *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
 }
