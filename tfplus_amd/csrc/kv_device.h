@@ -17,7 +17,7 @@ constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
 constexpr unsigned PART_BIT = 0x80000000u;      // gradient locator: partial-sum row, not an input row
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
-constexpr int TBT = 512;         // threads per block of the tile kernel
+constexpr int TBT = 512;  // threads per block of the tile kernel
 constexpr int IPT = 4;           // ids per thread in the tile kernel
 constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every tile contributes
                                  // N / 2048 entries to its partition, which keeps the partition

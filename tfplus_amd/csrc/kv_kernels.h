@@ -47,6 +47,9 @@ struct TileSmem {
   float* red;              // [TBT / 8][dim] sums of keys whose rows span two groups' chunks
 };
 
+// lpart may reuse lwork + hist once those are dead, if they are big enough
+constexpr bool LPART_ALIAS = ((TILE + 1) * 2 + 15) / 16 * 16 + (MAX_P + 1) * 4 >= (LS + 1) * 2;
+
 __host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
   size_t b = (size_t)(LS + 1) * 8 + 16;        // lkeys
   b += (size_t)(LS + 1) * 4 + 16;              // lcnt
@@ -56,7 +59,7 @@ __host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
   b += 64;                                     // wtot
   if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 2 + 16;  // lfirst
   if (mode == MODE_APPLY || mode == MODE_DEDUP) {
-    // lpart aliases lwork + hist ((TILE + 1) * 2 + (MAX_P + 1) * 4 >= (LS + 1) * 2)
+    if (!LPART_ALIAS) b += (size_t)(LS + 1) * 2 + 16;  // lpart
     const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + (size_t)(TBT / 8) * D * 4 + 64;
     const size_t lk = (size_t)(LS + 1) * 8 + 16;
     if (alias > lk) b += alias - lk;           // big dims: the fold scratch outgrows lkeys
@@ -85,10 +88,11 @@ __device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
   char* lw = take((size_t)(TILE + 1) * 2);
   s.lwork = reinterpret_cast<unsigned short*>(lw);
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
-  static_assert(((TILE + 1) * 2 + 15) / 16 * 16 + (MAX_P + 1) * 4 >= (LS + 1) * 2, "lpart alias");
   s.wtot = reinterpret_cast<unsigned*>(take(64));
   s.lfirst = (MODE != MODE_LOOKUP) ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
-  s.lpart = (MODE == MODE_APPLY || MODE == MODE_DEDUP) ? reinterpret_cast<unsigned short*>(lw) : nullptr;
+  s.lpart = nullptr;
+  if (MODE == MODE_APPLY || MODE == MODE_DEDUP)
+    s.lpart = LPART_ALIAS ? reinterpret_cast<unsigned short*>(lw) : reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
   return s;
 }
 
