@@ -219,7 +219,8 @@ def main():
     skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
                                     unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                     segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
-                                    take_fn=ops.kv_take_rows)
+                                    take_fn=ops.kv_take_rows,
+                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n))
 
   def step(k):
     ids, grad = pool[k % len(pool)][:2]

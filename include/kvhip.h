@@ -211,6 +211,14 @@ int kv_lookup_sparse(kv_handle_t h, const void* ids, const void* segment_ids, in
                      const float* weights, int64_t n, int64_t num_segments, int combiner,
                      int count_occurrences, float* out, kv_stream_t stream);
 
+/* tf.unsorted_segment_sum(data [n, dim], segment_ids [n] int32, num_segments) on the batch pipeline
+ * (no float atomics: a segment named by 100 000 rows costs the same as 100 000 segments): out
+ * [num_segments, dim]; segments nobody names are zero rows, ids outside [0, num_segments) are
+ * dropped.  `h` supplies device, dim and workspace.  Used by the sharded backward pass to sum
+ * gradients in the order the forward pass already exchanged.  Asynchronous.  n <= 2^21. */
+int kv_unsorted_segment_sum(kv_handle_t h, const int32_t* segment_ids, const float* data, int64_t n,
+                            int64_t num_segments, float* out, kv_stream_t stream);
+
 /* ---- multi-GPU routing helper (new design; the reference has no communication
  * layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
  * kernels/utility.h:90-107 ModKeyImpl, kept here) ----------------------------------------------

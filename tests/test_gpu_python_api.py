@@ -189,3 +189,27 @@ def test_take_rows_gather_and_scatter(shape, dtype):
   idx = torch.randint(0, shape[0], (2500,), generator=g).cuda()       # expand with repeats
   assert torch.equal(ops.kv_take_rows(src, idx), src[idx])
   assert ops.kv_take_rows(src, idx[:0]).shape[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [32, 8, 5])
+def test_unsorted_segment_sum(D):
+  """tf.unsorted_segment_sum on the batch pipeline: hot segments (tens of thousands of rows), empty
+  segments, out-of-range ids dropped."""
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  g = torch.Generator().manual_seed(5)
+  h = ops.kv_variable([D])
+  n, nseg = 200_000, 5000
+  seg = (torch.rand(n, generator=g) ** 6 * nseg).to(torch.int32)          # heavy head
+  seg[:7] = torch.tensor([-1, nseg, nseg + 5, 2**31 - 1, -2**31, nseg - 1, 0], dtype=torch.int32)
+  data = torch.randn(n, D, generator=g)
+  out = ops.kv_unsorted_segment_sum(h, data.cuda(), seg.cuda(), nseg).cpu()
+  ok = (seg >= 0) & (seg < nseg)
+  want = torch.zeros(nseg, D, dtype=torch.float64).index_add_(0, seg[ok].long(), data[ok].double())
+  absum = torch.zeros(nseg, D, dtype=torch.float64).index_add_(0, seg[ok].long(), data[ok].double().abs())
+  cnt = torch.bincount(seg[ok].long(), minlength=nseg).double().unsqueeze(1)
+  bound = (cnt - 1).clamp(min=0) * 2.0 ** -24 * absum + 1e-30             # any-order fp32 summation bound
+  assert bool(((out.double() - want).abs() <= bound).all())
+  empty = cnt.squeeze(1) == 0
+  assert empty.any() and float(out[empty].abs().sum()) == 0.0
+  assert ops.kv_unsorted_segment_sum(h, data[:0].cuda(), seg[:0].cuda(), 3).abs().sum().item() == 0.0

@@ -56,7 +56,8 @@ def _worker(rank, world, port, q):
     sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
-                                   take_fn=ops.kv_take_rows)
+                                   take_fn=ops.kv_take_rows,
+                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n))
     ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)          # the unsharded truth, same on every rank
     rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
     for step in range(4):

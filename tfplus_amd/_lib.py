@@ -63,6 +63,7 @@ SIGNATURES = {
     "kv_delete": (_i32, [_vp, _vp, _i64, _c.POINTER(_i64), _vp]),
     "kv_delete_with_timestamp": (_i32, [_vp, _i32, _i32, _vp, _c.POINTER(_i64), _vp]),
     "kv_lookup_sparse": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "kv_unsorted_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "kv_take_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "kv_profile_enable": (_i32, [_vp, _i32]),
     "kv_profile_select": (_i32, [_vp, _c.c_uint32]),

@@ -400,6 +400,8 @@ struct PartArgs {
   float* out_sum;
   int* out_counts;            // MODE_UNIQUE: occurrences (saturating) of each unique key
   int count_once;             // MODE_LOOKUP: frequency += 1 per unique key instead of per occurrence
+  long long direct_rows;      // MODE_DEDUP, > 0: keys ARE output row indices in [0, direct_rows)
+                              // (tf.unsorted_segment_sum): out_sum[key] = sum, no key list, no counter
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -945,12 +947,20 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
     }
     // ---- one thread per unique key: table probes (apply) / output slots (dedup) ----------------
     if (MODE == MODE_DEDUP) {
-      if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
-      __syncthreads();
-      for (unsigned u = tid; u < nu; u += TBS) {
-        utag[u] = lbase + u;
-        const unsigned h = ulist[u];
-        a.out_keys[lbase + u] = (h == HSS) ? EMPTY_KEY : hkey[h];
+      if (a.direct_rows > 0) {
+        for (unsigned u = tid; u < nu; u += TBS) {
+          const unsigned h = ulist[u];
+          const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
+          utag[u] = (key >= 0 && key < a.direct_rows) ? (unsigned)key : 0xFFFFFFFFu;  // out of range: dropped
+        }
+      } else {
+        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
+        __syncthreads();
+        for (unsigned u = tid; u < nu; u += TBS) {
+          utag[u] = lbase + u;
+          const unsigned h = ulist[u];
+          a.out_keys[lbase + u] = (h == HSS) ? EMPTY_KEY : hkey[h];
+        }
       }
     } else {
       for (unsigned u = tid; u < nu; u += TBS) {
@@ -978,7 +988,7 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
         if (doinit && lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
         opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live ? ur0[u] : 0u, (nb & 2u) != 0,
                                        live ? ur1[u] : 0u, (nb & 4u) != 0, live, gv, a.opt, lane);
-      } else if (live) {
+      } else if (live && utag[u] != 0xFFFFFFFFu) {
         const unsigned dense = utag[u];
 #pragma unroll
         for (int k = 0; k < K; ++k) {

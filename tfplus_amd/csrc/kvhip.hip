@@ -474,7 +474,8 @@ unsigned today(const kv_table* t) {
 // tile pass.  vpl: float4 per lane per row for the gradient fold (0 = scalar lanes / no fold)
 template <int MODE>
 void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* counts, const float* grad,
-                 long long n, hipStream_t s) {
+                 long long n, hipStream_t s, int ids_int32 = -1) {
+  if (ids_int32 < 0) ids_int32 = t->key_dtype == KV_DT_INT32;
   const int D = t->dim;
   const int grid = (int)wd.ntiles;
   const size_t sh = tile_smem_bytes(MODE, D);
@@ -490,7 +491,7 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
     else if (vpl == 4) KV_TILE(IDT, (FOLD ? 4 : 0));          \
     else KV_TILE(IDT, (FOLD ? 8 : 0));                        \
   } while (0)
-  if (t->key_dtype == KV_DT_INT32) KV_TILE_V(int);
+  if (ids_int32) KV_TILE_V(int);
   else KV_TILE_V(long long);
 #undef KV_TILE_V
 #undef KV_TILE
@@ -1037,6 +1038,34 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *num_unique = U;
+  return KV_OK;
+}
+
+int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const float* data, int64_t n,
+                            int64_t num_segments, float* out, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (n < 0 || num_segments < 0 || num_segments > 0x7FFFFFFFll || (n > 0 && (!segment_ids || !data)) ||
+      (num_segments > 0 && !out))
+    return fail(KV_INVALID_ARGUMENT, "bad arguments");
+  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld rows in one call (limit 2^21)", (long long)n);
+  if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
+  if (num_segments == 0) return KV_OK;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * t->dim * sizeof(float), s));  // segments nobody names
+  if (n == 0) return KV_OK;
+  if ((rc = ensure_workspace(t, n, true, s))) return rc;
+  const WsDev wd = ws_view(t, n);
+  launch_tile<MODE_DEDUP>(t, wd, segment_ids, nullptr, data, n, s, 1);
+  PartArgs pa{};
+  pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+  pa.grad = data;
+  pa.out_sum = out;
+  pa.direct_rows = num_segments;
+  if ((rc = launch_part<MODE_DEDUP, 0>(wd, pa, s))) return rc;
+  HIP_TRY(hipGetLastError());
   return KV_OK;
 }
 

@@ -455,6 +455,18 @@ def kv_variable_lookup_sparse(table_handle, ids, segment_ids, weights, num_segme
   return out
 
 
+def kv_unsorted_segment_sum(table_handle, data, segment_ids, num_segments):
+  """tf.unsorted_segment_sum on the GPU batch pipeline: [num_segments, dim] fp32."""
+  d = _f32(table_handle, data).reshape(-1, table_handle.dim)
+  seg = torch.as_tensor(segment_ids).to(_dev(table_handle)).reshape(-1).to(torch.int32).contiguous()
+  if seg.numel() != d.shape[0]:
+    raise _lib.InvalidArgumentError("segment_ids and data must have the same number of rows")
+  out = torch.empty((int(num_segments), table_handle.dim), dtype=torch.float32, device=d.device)
+  _lib.check(_lib.lib().kv_unsorted_segment_sum(table_handle.ptr, _p(seg), _p(d), seg.numel(), int(num_segments),
+                                                _p(out), _stream(table_handle)))
+  return out
+
+
 def kv_take_rows(src, index, scatter=False, num_rows=None):
   """out[i] = src[index[i]] (gather, default) or out[index[i]] = src[i] (scatter=True; index must be
   a permutation onto `num_rows` rows).  Any 4-byte-multiple row type; index int32 on the GPU."""

@@ -7,10 +7,12 @@ partitioned variables with `ids % num_shards` (python/ops/embedding_ops.py:115-2
 kernels/utility.h:90-107).  The same floor-mod rule decides ownership here, so a checkpoint
 partitioned by the reference maps shard-for-shard onto ranks.
 
-Per lookup and rank:  local unique-with-counts -> bucket the unique ids by owner -> all_to_all
-(counts) -> all_to_all(ids, occurrence counts) -> owner-side GatherOrInsertWithCounts on its shard
--> all_to_all(rows) back -> un-permute -> expand to the input order.  The apply mirrors it with
-(unique ids, locally summed grads) to the owner and one fused optimizer call there.
+Per lookup and rank:  local unique-with-counts -> bucket the unique ids by owner -> all_to_all of
+bucket sizes (the one host sync) -> all_to_all of (id, occurrence count) pairs -> owner-side
+GatherOrInsertWithCounts on its shard -> all_to_all of rows back -> expand straight from the
+exchange order to the input order.  The apply of the same batch sums gradients into that exchange
+order (unsorted_segment_sum by position) and sends them: one all_to_all, one fused optimizer call
+at the owner, which still holds the ids it served.
 
 The exchange is written against torch.distributed only (works on CPU/gloo for the tests and on
 GPU/RCCL in production); the shard itself is any object with the KvVariable lookup/apply calls.
@@ -71,22 +73,23 @@ def _take(payload, index, take_fn, scatter=False):
   return out
 
 
-def exchange(rt, payload, reverse=False, group=None, presorted=None, take_fn=None):
-  """all_to_all of per-id rows.  Forward: `payload` is in local order, the result is what this
-  rank must serve (grouped by source rank).  reverse=True: `payload` is in served order, the
-  result is back in local order.  take_fn(rows, index, scatter) is the GPU row permutation
+def exchange(rt, payload, reverse=False, group=None, presorted=None, take_fn=None, unpermute=True):
+  """all_to_all of per-id rows.  Forward: `payload` is in local order (or `presorted` already in
+  exchange order = grouped by owner), the result is what this rank must serve (grouped by source
+  rank).  reverse=True: `payload` is in served order, the result is back in exchange order, or in
+  local order when unpermute.  take_fn(rows, index, scatter) is the GPU row permutation
   (kv_take_rows); torch indexing otherwise."""
-  tail = tuple(payload.shape[1:])
   if not reverse:
     src = presorted if presorted is not None else _take(payload, rt.perm, take_fn)
-    out = torch.empty((rt.n_recv,) + tail, dtype=payload.dtype, device=payload.device)
-    dist.all_to_all_single(out, src, output_split_sizes=rt.recv_counts, input_split_sizes=rt.send_counts,
+    out = torch.empty((rt.n_recv,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_to_all_single(out, src.contiguous(), output_split_sizes=rt.recv_counts, input_split_sizes=rt.send_counts,
                            group=group)
     return out
+  tail = tuple(payload.shape[1:])
   back = torch.empty((rt.n_local,) + tail, dtype=payload.dtype, device=payload.device)
   dist.all_to_all_single(back, payload.contiguous(), output_split_sizes=rt.send_counts,
                          input_split_sizes=rt.recv_counts, group=group)
-  return _take(back, rt.perm, take_fn, scatter=True)
+  return _take(back, rt.perm, take_fn, scatter=True) if unpermute else back
 
 
 class ShardedKvVariable(object):
@@ -98,18 +101,27 @@ class ShardedKvVariable(object):
   unique id (tf.unique + unsorted_segment_sum, the TF-core step, done per rank) and the owner's
   fused apply sums once more across ranks.
 
-  unique_fn(ids, counts) -> (uniq, counts, inverse) and segsum_fn(ids, grad) -> (uniq, summed)
-  are the GPU kernels (gen_kv_variable_ops.kv_unique / kv_dedup_segment_sum); bucket_fn is
-  kv_bucket_by_owner.  Without them torch ops do the same (CPU tests)."""
+  Collectives per step: lookup = bucket sizes, (ids, counts) packed in one payload, rows back;
+  apply of the batch that was just looked up = summed gradients only — the owner still holds the
+  ids it served and the sender still knows where each id sits in the exchange order, so neither
+  ids nor sizes travel again.  Every rank must make the same calls in the same order (SPMD); the
+  short backward path is taken when `ids` is the very tensor the last lookup saw, so all ranks
+  must either reuse their tensor or not.
 
-  def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None, take_fn=None):
+  unique_fn(ids, counts) -> (uniq, counts, inverse), segsum_fn(ids, grad) -> (uniq, summed),
+  index_sum_fn(grad, index, num) -> [num, D] (unsorted_segment_sum), bucket_fn and take_fn are the
+  GPU kernels (gen_kv_variable_ops.kv_unique / kv_dedup_segment_sum / kv_unsorted_segment_sum /
+  kv_bucket_by_owner / kv_take_rows).  Without them torch ops do the same (CPU tests)."""
+
+  def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None, take_fn=None,
+               index_sum_fn=None):
     self.shard = shard          # the rank-local table (KvVariable, or any stand-in with the same calls)
     self.group = group
     self.bucket_fn, self.unique_fn, self.segsum_fn = bucket_fn, unique_fn, segsum_fn
-    self.take_fn = take_fn
-    self._last = None           # (ids tensor, its version, send counts, recv counts) of the last lookup
+    self.take_fn, self.index_sum_fn = take_fn, index_sum_fn
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
+    self._last = None           # what the last lookup left behind for its backward pass
 
   def _unique(self, flat, counts):
     if self.unique_fn is not None:
@@ -127,28 +139,45 @@ class ShardedKvVariable(object):
     summed = torch.zeros((uniq.numel(), grad.shape[1]), dtype=grad.dtype, device=grad.device).index_add_(0, inv, grad)
     return uniq, summed
 
+  def _index_sum(self, grad, index, num):
+    if self.index_sum_fn is not None:
+      return self.index_sum_fn(grad, index, num)
+    return torch.zeros((num, grad.shape[1]), dtype=grad.dtype, device=grad.device).index_add_(0, index.to(torch.int64), grad)
+
   def lookup(self, ids, counts=None):
     """embedding_lookup over the sharded table; returns rows in the order of `ids`."""
     flat = ids.reshape(-1)
     uniq, ucnt, inv = self._unique(flat, counts)
+    U = int(uniq.numel())
     rt = route(uniq, self.group, self.bucket_fn)
-    self._last = (ids, ids._version, rt.send_counts, rt.recv_counts)
-    served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids)
-    sc = exchange(rt, ucnt, group=self.group, take_fn=self.take_fn)
-    rows = self.shard.sparse_read_with_counts(served, sc)
-    urows = exchange(rt, rows, reverse=True, group=self.group, take_fn=self.take_fn)
-    out = _take(urows, inv, self.take_fn)
+    bids = rt.bucketed_ids if rt.bucketed_ids is not None else _take(uniq, rt.perm, self.take_fn)
+    bcnt = _take(ucnt, rt.perm, self.take_fn)
+    # one payload for ids and their occurrence counts
+    got = exchange(rt, None, group=self.group, presorted=torch.stack([bids.to(torch.int64), bcnt.to(torch.int64)], 1))
+    served = got[:, 0].contiguous().to(uniq.dtype)
+    rows = self.shard.sparse_read_with_counts(served, got[:, 1].to(torch.int32))
+    back = exchange(rt, rows, reverse=True, group=self.group, unpermute=False)       # in exchange order
+    # where each input id sits in the exchange order: pos[perm[j]] = j, then through the inverse
+    pos = _take(torch.arange(U, dtype=torch.int32, device=flat.device), rt.perm, self.take_fn, scatter=True)
+    where = _take(pos, inv, self.take_fn)
+    self._last = (ids, ids._version, rt, where, U, served)
+    out = _take(back, where, self.take_fn)
     return out.reshape(tuple(ids.shape) + tuple(out.shape[1:]))
 
   def apply_gradients(self, apply_fn, grad, ids):
-    """Sends (unique ids, locally summed grads) to the owners; each owner runs
+    """Sends one summed gradient row per unique id to its owner; each owner runs
     apply_fn(shard, grad, ids) once — its fused dedup + segment-sum + row update."""
     flat = ids.reshape(-1)
-    uniq, summed = self._segsum(flat, grad.reshape(flat.numel(), -1))
-    known = None
-    if self._last is not None and self._last[0] is ids and self._last[1] == ids._version:
-      known = self._last[2:]      # same id set as the forward pass: same bucket sizes, no size exchange
-    rt = route(uniq, self.group, self.bucket_fn, known_counts=known)
+    g2 = grad.reshape(flat.numel(), -1)
+    last = self._last
+    if last is not None and last[0] is ids and last[1] == ids._version:
+      # backward of the last lookup: sum straight into the exchange order it established
+      _, _, rt, where, U, served = last
+      g = exchange(rt, None, group=self.group, presorted=self._index_sum(g2, where, U))
+      apply_fn(self.shard, g, served)
+      return
+    uniq, summed = self._segsum(flat, g2)
+    rt = route(uniq, self.group, self.bucket_fn)
     served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids, take_fn=self.take_fn)
     g = exchange(rt, summed, group=self.group, take_fn=self.take_fn)
     apply_fn(self.shard, g, served)
