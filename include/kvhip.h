@@ -196,6 +196,13 @@ int kv_delete(kv_handle_t h, const void* ids, int64_t n, int64_t* num_deleted, k
 int kv_delete_with_timestamp(kv_handle_t h, int threshold, int dry_run, int64_t* delete_keys,
                              int64_t* count, kv_stream_t stream);
 
+/* BatchKvVariableGatherOrZerosV2 (ops/kv_variable_ops.cc:297-308, kernels/kv_variable_ops.cc:431-470):
+ * outs[i] [ns[i], dim_i] = GatherOrZeros(tables[i], ids[i] [ns[i]]) for i < num_tables, all tables
+ * on one device, dims free to differ — one kernel launch for the whole batch of tables (the
+ * reference loops).  Asynchronous. */
+int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                             const int64_t* ns, float* const* outs, kv_stream_t stream);
+
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
  * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->
  * segment_sum / sparse_segment_{sum,mean,sqrt_n}.  ids [n] are sp_ids.values, segment_ids [n] are

@@ -148,3 +148,22 @@ def test_delete_with_timestamp_parity(ops):
   gone = ops.kv_variable_delete_with_timestamp(h, 5)
   assert sorted(gone.cpu().numpy().tolist()) == sorted(o.delete_with_timestamp(5).tolist()) == list(range(50, 150))
   _same_table(ops, h, o)
+
+
+@pytest.mark.gpu
+def test_batch_gather_or_zeros(ops):
+  """BatchKvVariableGatherOrZerosV2 == per-table GatherOrZeros, mixed dims / key types / shapes."""
+  rng = np.random.default_rng(8)
+  hs, idl, want = [], [], []
+  for j, (D, kd, n) in enumerate([(8, torch.int64, 300), (64, torch.int64, 2048), (5, torch.int32, 77), (128, torch.int64, 0),
+                                  (32, torch.int64, 1)]):
+    h = ops.kv_variable([D], key_dtype=kd)
+    ops.init_kv_variable_v2(h, rng.standard_normal((32, D)).astype(np.float32))
+    ops.kv_variable_gather_or_insert_v2(h, np.arange(-20, 60))
+    ids = rng.integers(-40, 90, (n,)) if n != 300 else rng.integers(-40, 90, (10, 30))
+    hs.append(h); idl.append(ids); want.append(ops.kv_variable_gather_or_zeros_v2(h, ids))
+  for rep in range(3):                                    # the descriptor staging buffer is reused
+    got = ops.batch_kv_variable_gather_or_zeros_v2(hs, idl)
+    assert [tuple(g.shape) for g in got] == [tuple(w.shape) for w in want]
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+  assert ops.kv_variable_frequency(hs[0]) == 80           # inference lookups count nothing

@@ -62,6 +62,7 @@ SIGNATURES = {
     "kv_get_timestamp": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_delete": (_i32, [_vp, _vp, _i64, _c.POINTER(_i64), _vp]),
     "kv_delete_with_timestamp": (_i32, [_vp, _i32, _i32, _vp, _c.POINTER(_i64), _vp]),
+    "kv_batch_gather_or_zeros": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "kv_lookup_sparse": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "kv_unsorted_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "kv_take_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),

@@ -1266,6 +1266,37 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
   }
 }
 
+// BatchKvVariableGatherOrZerosV2 (kernels/kv_variable_ops.cc:431-470): N tables, N id lists, N
+// outputs — the reference loops over the tables; here ONE launch covers them all (blockIdx.y =
+// table, tables may differ in dim), which is what a 26-feature serving step needs.
+struct BatchGatherDesc {
+  TableDev t;
+  const void* ids;
+  float* out;
+  long long n;
+  int ids_int32;
+};
+__global__ void __launch_bounds__(TB) k_batch_gather_or_zeros(const BatchGatherDesc* __restrict__ descs) {
+  const BatchGatherDesc& d = descs[blockIdx.y];
+  const TableDev t = d.t;
+  const int D = t.dim;
+  const int lane8 = threadIdx.x & 7;
+  for (long long i = (long long)blockIdx.x * (TB / 8) + (threadIdx.x >> 3); i < d.n;
+       i += (long long)gridDim.x * (TB / 8)) {
+    const long long key = d.ids_int32 ? (long long)reinterpret_cast<const int*>(d.ids)[i]
+                                      : reinterpret_cast<const long long*>(d.ids)[i];
+    const unsigned r = table_find(t, key);
+    const float* row = row_ptr(t, r);
+    float* o = d.out + (size_t)i * D;
+    if ((D & 3) == 0) {
+      for (int q = lane8; q < (D >> 2); q += 8)
+        reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
+    } else {
+      for (int e = lane8; e < D; e += 8) o[e] = row[e];
+    }
+  }
+}
+
 // kv_dedup_segment_sum: inverse[i] = dense unique index of input position i
 __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;

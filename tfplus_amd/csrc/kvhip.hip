@@ -549,7 +549,8 @@ int check_table(kv_handle_t h) {
 // locks tables in address order like MaybeLockVariableInputMutexesInOrder (training_ops.cc:96-184)
 struct MultiLock {
   std::vector<kv_table*> ts;
-  explicit MultiLock(std::initializer_list<kv_table*> l) : ts(l) {
+  explicit MultiLock(std::initializer_list<kv_table*> l) : MultiLock(std::vector<kv_table*>(l)) {}
+  explicit MultiLock(std::vector<kv_table*> l) : ts(std::move(l)) {
     std::sort(ts.begin(), ts.end());
     ts.erase(std::unique(ts.begin(), ts.end()), ts.end());
     for (auto* t : ts) t->mu.lock();
@@ -895,6 +896,66 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   else
     k_gather_or_zeros<long long><<<nblocks(n, TB / 8, 8192), TB, 0, s>>>(td, (const long long*)ids, out, n);
   HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+// descriptor staging for the batched launches: one pinned host ring + device buffer per device
+namespace {
+struct BatchStage {
+  std::mutex mu;
+  BatchGatherDesc* host = nullptr;   // pinned
+  BatchGatherDesc* dev = nullptr;
+  int cap = 0;
+  hipEvent_t consumed = nullptr;     // the last launch has read `dev`
+};
+BatchStage g_stage[64];
+}  // namespace
+
+int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                             const int64_t* ns, float* const* outs, kv_stream_t stream) {
+  int rc;
+  if (num_tables < 1) return fail(KV_INVALID_ARGUMENT, "N must be >= 1");  // Attr("N: int >= 1")
+  if (!tables || !ids || !ns || !outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  for (int i = 0; i < num_tables; ++i) {
+    if ((rc = check_table(tables[i]))) return rc;
+    if (tables[i]->device != tables[0]->device) return fail(KV_INVALID_ARGUMENT, "tables live on different devices");
+    if (ns[i] < 0 || (ns[i] > 0 && (!ids[i] || !outs[i]))) return fail(KV_INVALID_ARGUMENT, "indices / output pointer is null");
+  }
+  const int device = tables[0]->device;
+  if (device < 0 || device >= 64) return fail(KV_INVALID_ARGUMENT, "device index");
+  DeviceGuard dg(device);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<kv_table*> lk(tables, tables + num_tables);
+  MultiLock lock(lk);
+  BatchStage& st = g_stage[device];
+  std::lock_guard<std::mutex> sl(st.mu);
+  if (st.cap < num_tables) {
+    if (st.consumed) HIP_TRY(hipEventSynchronize(st.consumed));
+    if (st.host) hipHostFree(st.host);
+    if (st.dev) hipFree(st.dev);
+    st.cap = std::max(num_tables, 64);
+    HIP_TRY(hipHostMalloc(&st.host, (size_t)st.cap * sizeof(BatchGatherDesc)));
+    HIP_TRY(hipMalloc(&st.dev, (size_t)st.cap * sizeof(BatchGatherDesc)));
+    if (!st.consumed) HIP_TRY(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+  } else if (st.consumed) {
+    HIP_TRY(hipEventSynchronize(st.consumed));  // the previous launch must be done with the descriptors
+  }
+  long long nmax = 0;
+  for (int i = 0; i < num_tables; ++i) {
+    BatchGatherDesc& d = st.host[i];
+    d.t = dev_view(tables[i]);
+    d.ids = ids[i];
+    d.out = outs[i];
+    d.n = ns[i];
+    d.ids_int32 = tables[i]->key_dtype == KV_DT_INT32;
+    nmax = std::max<long long>(nmax, ns[i]);
+  }
+  if (nmax == 0) return KV_OK;
+  HIP_TRY(hipMemcpyAsync(st.dev, st.host, (size_t)num_tables * sizeof(BatchGatherDesc), hipMemcpyHostToDevice, s));
+  dim3 grid((unsigned)nblocks(nmax, TB / 8, 2048), (unsigned)num_tables);
+  k_batch_gather_or_zeros<<<grid, TB, 0, s>>>(st.dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(st.consumed, s));
   return KV_OK;
 }
 

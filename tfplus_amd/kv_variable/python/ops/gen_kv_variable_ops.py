@@ -427,6 +427,22 @@ def kv_variable_delete_with_timestamp(table_handle, threshold=7):
   return keys.to(table_handle.key_dtype) if table_handle.key_dtype != torch.int64 else keys
 
 
+def batch_kv_variable_gather_or_zeros_v2(table_handles, indices):
+  """BatchKvVariableGatherOrZerosV2: [GatherOrZeros(t, i) for t, i in zip(table_handles, indices)] with
+  one kernel launch for all tables; each output is indices[i].shape + [dim_i]."""
+  if len(table_handles) < 1 or len(table_handles) != len(indices):
+    raise _lib.InvalidArgumentError("table_handles and indices must be equally long, N >= 1")
+  n = len(table_handles)
+  ids = [_ids(h, i) for h, i in zip(table_handles, indices)]
+  outs = [torch.empty(tuple(i.shape) + (h.dim,), dtype=torch.float32, device=i.device) for h, i in zip(table_handles, ids)]
+  hp = (ctypes.c_void_p * n)(*[h.ptr for h in table_handles])
+  ip = (ctypes.c_void_p * n)(*[i.data_ptr() for i in ids])
+  op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+  ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
+  _lib.check(_lib.lib().kv_batch_gather_or_zeros(n, hp, ip, ns, op, _stream(table_handles[0])))
+  return outs
+
+
 _COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}
 
 
