@@ -203,6 +203,22 @@ int kv_delete_with_timestamp(kv_handle_t h, int threshold, int dry_run, int64_t*
 int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const void* const* ids,
                              const int64_t* ns, float* const* outs, kv_stream_t stream);
 
+/* ---- many tables, one launch per pipeline stage (new: the reference runs one op per table; a CTR
+ * step has tens of small lookups / applies, e.g. example/dcn/train.py:219-300 with 26 features) ---
+ * kv_multi_gather_or_insert == kv_gather_or_insert(tables[i], ids[i], counts ? counts[i] : NULL,
+ * ns[i], outs[i]) for every i, and kv_multi_apply_group_adam == kv_apply_group_adam(vars[i],
+ * slots[i], grads[i], ids[i], ns[i], <shared scalars>, version) for every i, but with 3 resp. 2
+ * kernel launches in total (grid.y = table).  All tables of one call: same device, same dim, same
+ * key dtype, listed once; dims must be multiples of 4 for the optimizer.  Asynchronous. */
+int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                              const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                              kv_stream_t stream);
+int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                              const float* const* grads, const void* const* ids, const int64_t* ns,
+                              float lr, float beta1_power, float beta2_power, float beta1, float beta2,
+                              float epsilon, float l1, float l2, float l21, int version,
+                              kv_stream_t stream);
+
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
  * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->
  * segment_sum / sparse_segment_{sum,mean,sqrt_n}.  ids [n] are sp_ids.values, segment_ids [n] are

@@ -1,0 +1,101 @@
+"""Batched launches over many tables (kv_multi_gather_or_insert / kv_multi_apply_group_adam): the
+same kernels with grid.y = table, so every table must end bit-identical to one driven by the
+single-table ops, and the first table is additionally checked against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import kv_oracle as ko
+
+torch = pytest.importorskip("torch")
+DAY = 20000
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+def _tables(ops, n, D, seed):
+  rng = np.random.default_rng(seed)
+  out = []
+  for j in range(n):
+    table = rng.standard_normal((64, D)).astype(np.float32)
+    pair = []
+    for dim, tab in ((D, table), (3 * D, np.zeros((4, 3 * D), np.float32))):
+      h = ops.kv_variable([dim])
+      ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3 + j); ops.init_kv_variable_v2(h, tab)
+      pair.append(h)
+    out.append((pair[0], pair[1], table))
+  return out
+
+
+def _dump(ops, h):
+  k, v = ops.read_kv_variable_op_v2(h)
+  o = torch.argsort(k)
+  return k[o].cpu(), v[o].cpu(), ops.kv_variable_frequency(h), ops.kv_variable_size_v2(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,sizes", [(32, [2048] * 6), (64, [2048, 1, 0, 5000, 300]), (8, [70000, 100])])
+def test_multi_ops_equal_single_ops(ops, D, sizes):
+  T = len(sizes)
+  A = _tables(ops, T, D, seed=1)        # driven by the batched ops
+  B = _tables(ops, T, D, seed=1)        # driven table by table
+  ref = ko.OracleKv(D, 0, A[0][2], day=DAY, picker=1, seed=3)
+  rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
+  rng = np.random.default_rng(2)
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  for step in range(3):
+    ids = [rng.integers(-500, 500, n) for n in sizes]
+    ids[0] = ids[0].reshape(-1, 1)                                   # output keeps the shape of indices
+    # one-signed gradients: sums of repeated ids never cancel to ~epsilon, where Adam's quotient would
+    # amplify the (order-dependent) fp32 rounding of the sum
+    grads = [(rng.uniform(0.5, 1.5, (i.size, D)) * 1e-2 * rng.choice([-1, 1], (1, D))).astype(np.float32) for i in ids]
+    outs = ops.kv_multi_gather_or_insert([a[0] for a in A], ids)
+    for j in range(T):
+      want = ops.kv_variable_gather_or_insert_v2(B[j][0], ids[j])
+      assert tuple(outs[j].shape) == tuple(np.shape(ids[j])) + (D,)
+      if step == 0:
+        assert torch.equal(outs[j], want), (step, j)               # rows are copies of the same init rows
+      else:                                                        # after an apply: fp32 sums of repeated ids
+        torch.testing.assert_close(outs[j], want, rtol=2e-5, atol=2e-6)   # are not order-deterministic
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.gather_or_insert(ids[0]), rtol=2e-5, atol=2e-6)
+    ops.kv_multi_group_sparse_apply_adam([a[0] for a in A], [a[1] for a in A], grads, ids, 1e-2, b1p, b2p, 0.9, 0.999,
+                                         1e-8, 0, 0, 0)
+    for j in range(T):
+      ops.kv_variable_group_sparse_apply_adam_v4(B[j][0], B[j][1], grads[j], ids[j].reshape(-1), 1e-2, b1p, b2p, 0.9,
+                                                 0.999, 1e-8, 0, 0, 0)
+    u, sm, _ = ko.dedup_segment_sum(ids[0].reshape(-1), grads[0])
+    ko.apply_group_adam(ref, rslot, sm, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+    b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+  for j in range(T):
+    for which in (0, 1):
+      ka, va, fa, sa = _dump(ops, A[j][which])
+      kb, vb, fb, sb = _dump(ops, B[j][which])
+      assert torch.equal(ka, kb) and fa == fb and sa == sb
+      torch.testing.assert_close(va, vb, rtol=2e-5, atol=2e-6)       # same kernels; fp32 sums may reorder
+  k0, v0, _, _ = _dump(ops, A[0][0])
+  want = ref.as_dict()
+  assert sorted(want) == k0.tolist()
+  np.testing.assert_allclose(v0.numpy(), np.stack([want[k] for k in k0.tolist()]), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_multi_ops_argument_checks(ops):
+  from tfplus_amd import _lib
+  (v8, s8, _), = _tables(ops, 1, 8, seed=5)
+  (v16, s16, _), = _tables(ops, 1, 16, seed=5)
+  with pytest.raises(_lib.InvalidArgumentError):
+    ops.kv_multi_gather_or_insert([v8, v16], [[1], [2]])             # dims differ
+  with pytest.raises(_lib.InvalidArgumentError):
+    ops.kv_multi_gather_or_insert([v8, v8], [[1], [2]])              # listed twice
+  with pytest.raises(_lib.InvalidArgumentError):
+    ops.kv_multi_group_sparse_apply_adam([v8], [s16], [np.zeros((1, 8), np.float32)], [[1]], 0.1, 0.9, 0.999, 0.9, 0.999,
+                                         1e-8, 0, 0, 0)
+  raw = ops.kv_variable([8])
+  with pytest.raises(_lib.FailedPreconditionError):
+    ops.kv_multi_gather_or_insert([raw], [[1]])
+  assert ops.kv_multi_gather_or_insert([v8], [np.zeros((0,), np.int64)])[0].shape == (0, 8)

@@ -62,7 +62,10 @@ def _worker(rank, world, port, q):
     rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
     for step in range(4):
       batches = [rng.integers(-400, 400, 3000 + 517 * r) for r in range(world)]   # heavy repeats, negative ids
-      grads = [rng.normal(0, 1e-2, (b.size, D)).astype(np.float32) for b in batches]
+      # one-signed gradients: the summed gradient of a repeated id never cancels to ~epsilon, where
+      # Adam's quotient would amplify the order-dependent fp32 rounding of the per-rank partial sums
+      sign = rng.choice([-1.0, 1.0], (1, D))
+      grads = [(rng.uniform(0.5, 1.5, (b.size, D)) * 1e-2 * sign).astype(np.float32) for b in batches]
       mine = torch.from_numpy(batches[rank]).cuda()
       out = sh.lookup(mine).cpu().numpy()
       want_all = ref.gather_or_insert(np.concatenate(batches))

@@ -63,6 +63,8 @@ SIGNATURES = {
     "kv_delete": (_i32, [_vp, _vp, _i64, _c.POINTER(_i64), _vp]),
     "kv_delete_with_timestamp": (_i32, [_vp, _i32, _i32, _vp, _c.POINTER(_i64), _vp]),
     "kv_batch_gather_or_zeros": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp]),
+    "kv_multi_gather_or_insert": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kv_multi_apply_group_adam": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 9 + [_i32, _vp]),
     "kv_lookup_sparse": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "kv_unsorted_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "kv_take_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),

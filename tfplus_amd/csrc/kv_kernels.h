@@ -97,9 +97,9 @@ __device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
 }
 
 template <int MODE, typename IdT, int VPL>
-__global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ ids,
-                                             const int* __restrict__ counts,
-                                             const float* __restrict__ grad, long long n, int D) {
+__device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict__ ids,
+                                          const int* __restrict__ counts,
+                                          const float* __restrict__ grad, long long n, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TileSmem sm = carve_tile<MODE>(smem_raw, D);
   __shared__ unsigned lnwork, lsent, lnpart, lM;
@@ -385,6 +385,16 @@ __global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ i
   KV_STAMP(6);
 }
 
+// One op on one table (arguments by value) or the same op on many tables in one launch
+// (blockIdx.y = table; arguments from a descriptor array in device memory, see MultiDesc below).
+struct MultiDesc;
+template <int MODE, typename IdT, int VPL>
+__global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ ids,
+                                             const int* __restrict__ counts,
+                                             const float* __restrict__ grad, long long n, int D) {
+  tile_body<MODE, IdT, VPL>(w, ids, counts, grad, n, D);
+}
+
 // ------------------------------------------------------------------------------------------
 // partition pass
 // ------------------------------------------------------------------------------------------
@@ -476,7 +486,7 @@ __device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const un
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) {
+__device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a) {
   __shared__ long long hkey[HSK + 1];
   __shared__ unsigned hval[HSK + 1];   // lookup: summed count; scatter / mark: an input position
   __shared__ unsigned hrow[HSK + 1];   // row id of the key
@@ -801,7 +811,7 @@ __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key
 }
 
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
+__device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.tv.dim;
   char* smp = smem_raw;
@@ -1182,8 +1192,8 @@ __global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) {
 // ------------------------------------------------------------------------------------------
 // VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
 template <int VQ>
-__global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out,
-                                               long long n) {
+__device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, float* __restrict__ out,
+                                            long long n) {
   if constexpr (VQ > 0 && VQ <= 64) {
     // One wave takes 64 consecutive output rows per step.  Lane l resolves row l's table row id
     // (slot_of_id -> ent_b: two dependent loads, 64 rows in flight per wave and no redundancy);
@@ -1243,6 +1253,49 @@ __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __res
       out[x] = row_ptr(t, w.ent_b[w.slot_of_id[i]])[e];
     }
   }
+}
+
+// ---- kernel entry points: single table (by value) and many tables (descriptor array) ------------
+struct MultiDesc {
+  WsDev w;
+  PartArgs a;            // a.tv is the table of this entry (lookup) / the var table (apply)
+  const void* ids;
+  const int* counts;
+  float* out;            // lookup output rows
+  long long n;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) { part_sum_body<MODE, OPT, V, LPR, K>(w, a); }
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
+  gather_body<VQ>(t, w, out, n);
+}
+
+template <int MODE, typename IdT, int VPL>
+__global__ void __launch_bounds__(TBT) k_tile_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.ntiles) return;
+  tile_body<MODE, IdT, VPL>(m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.a.grad, m.n, m.a.tv.dim);
+}
+template <int MODE>
+__global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  part_keys_body<MODE>(m.w, m.a);
+}
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS) k_part_sum_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  part_sum_body<MODE, OPT, V, LPR, K>(m.w, m.a);
+}
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_gather_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  gather_body<VQ>(m.a.tv, m.w, m.out, m.n);
 }
 
 // KvVariableGatherOrZeros: read-only, no dedup needed (no writes, repeated keys hit cache).

@@ -473,8 +473,11 @@ unsigned today(const kv_table* t) {
 
 // tile pass.  vpl: float4 per lane per row for the gradient fold (0 = scalar lanes / no fold)
 template <int MODE>
+// md != nullptr: the same launch over `ntab` tables (grid.y), arguments from the descriptor array
+// md, grid.x = gx (the largest table's tile count)
 void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* counts, const float* grad,
-                 long long n, hipStream_t s, int ids_int32 = -1) {
+                 long long n, hipStream_t s, int ids_int32 = -1, const MultiDesc* md = nullptr, int ntab = 0,
+                 unsigned gx = 0) {
   if (ids_int32 < 0) ids_int32 = t->key_dtype == KV_DT_INT32;
   const int D = t->dim;
   const int grid = (int)wd.ntiles;
@@ -482,7 +485,11 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
   constexpr bool FOLD = (MODE == MODE_APPLY || MODE == MODE_DEDUP);
   int vpl = 0;
   if (FOLD && (D & 3) == 0 && D <= 256) vpl = D <= 32 ? 1 : D <= 64 ? 2 : D <= 128 ? 4 : 8;
-#define KV_TILE(IDT, VPL) k_tile<MODE, IDT, VPL><<<grid, TBT, sh, s>>>(wd, (const IDT*)ids, counts, grad, n, D)
+#define KV_TILE(IDT, VPL)                                                                          \
+  do {                                                                                             \
+    if (md) k_tile_multi<MODE, IDT, VPL><<<dim3(gx, (unsigned)ntab), TBT, sh, s>>>(md);             \
+    else k_tile<MODE, IDT, VPL><<<grid, TBT, sh, s>>>(wd, (const IDT*)ids, counts, grad, n, D);    \
+  } while (0)
 #define KV_TILE_V(IDT)                                        \
   do {                                                        \
     if (!FOLD || vpl == 0) KV_TILE(IDT, 0);                   \
@@ -497,17 +504,62 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
 #undef KV_TILE
 }
 
+// out[i] = rows[row of ids[i]] after the lookup index passes; md: many tables in one launch
+void launch_gather(const TableDev& td, const WsDev& wd, float* op, long long m, hipStream_t s,
+                   const MultiDesc* md = nullptr, int ntab = 0) {
+  const int D = td.dim;
+  const int q = (D % 4 == 0) ? D / 4 : 0;
+  const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= TB;
+  const long long rows_per_block = vec ? TB / q : 1;
+  constexpr int gcap = 8192;  // one 64-row step per wave at 1M rows: residency, not a loop, hides the hops
+  const int grid = vec ? nblocks(m, q <= 64 ? TB : (int)rows_per_block, gcap) : nblocks(m * D, TB, 4096);
+#define KV_GATHER(VQ)                                                                        \
+  do {                                                                                       \
+    if (md) k_gather_multi<VQ><<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);       \
+    else k_gather<VQ><<<grid, TB, 0, s>>>(td, wd, op, m);                                    \
+  } while (0)
+  switch (vec ? q : 0) {
+    case 1: KV_GATHER(1); break;
+    case 2: KV_GATHER(2); break;
+    case 4: KV_GATHER(4); break;
+    case 8: KV_GATHER(8); break;
+    case 16: KV_GATHER(16); break;
+    case 32: KV_GATHER(32); break;
+    case 64: KV_GATHER(64); break;
+    case 128: KV_GATHER(128); break;
+    case 256: KV_GATHER(256); break;
+    default: KV_GATHER(0); break;
+  }
+#undef KV_GATHER
+}
+
 // partition pass, dispatched on the row geometry: D % 4 == 0 -> float4 lanes, else scalar lanes
+// multi (md != nullptr): wd carries the LARGEST ntiles / P of the batch of tables (LDS sizing, grid.x);
+// only MODE_LOOKUP and MODE_APPLY on float4 rows are instantiated for it
 template <int MODE, int OPT>
-int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
+int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = pa.tv.dim;
   const int grid = (int)wd.P;
   if constexpr (MODE != MODE_APPLY && MODE != MODE_DEDUP) {
+    if constexpr (MODE == MODE_LOOKUP) {
+      if (md) {
+        k_part_keys_multi<MODE><<<dim3((unsigned)grid, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
+        return KV_OK;
+      }
+    }
     k_part_keys<MODE><<<grid, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
     return KV_OK;
   } else {
 #define KV_PART(V, LPR, K)                                                                       \
   do {                                                                                           \
+    if constexpr (MODE == MODE_APPLY && V == 4) {                                                \
+      if (md) {                                                                                  \
+        k_part_sum_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS,      \
+            part_sum_smem_bytes(MODE, OPT, D, LPR, wd.ntiles), s>>>(md);                         \
+        return KV_OK;                                                                            \
+      }                                                                                          \
+    }                                                                                            \
+    if (md) return fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D); \
     k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, OPT, D, LPR, wd.ntiles), s>>>(wd, pa); \
     return KV_OK;                                                                                \
   } while (0)
@@ -791,24 +843,7 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
       if ((rc = launch_part<MODE_LOOKUP, 0>(wd, pa, s))) return rc;
     }
     ProfScope ps_gather(t, KV_PROF_LOOKUP_GATHER, s);
-    const int D = t->dim;
-    const int q = (D % 4 == 0) ? D / 4 : 0;
-    const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= TB;
-    const long long rows_per_block = vec ? TB / q : 1;
-    constexpr int gcap = 8192;  // one 64-row step per wave at 1M rows: residency, not a loop, hides the hops
-    const int grid = vec ? nblocks(m, q <= 64 ? TB : (int)rows_per_block, gcap) : nblocks(m * D, TB, 4096);
-    switch (vec ? q : 0) {
-      case 1: k_gather<1><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 2: k_gather<2><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 4: k_gather<4><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 8: k_gather<8><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 16: k_gather<16><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 32: k_gather<32><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 64: k_gather<64><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 128: k_gather<128><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      case 256: k_gather<256><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-      default: k_gather<0><<<grid, TB, 0, s>>>(td, wd, op, m); break;
-    }
+    launch_gather(td, wd, op, m, s);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -899,50 +934,82 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   return KV_OK;
 }
 
-// descriptor staging for the batched launches: one pinned host ring + device buffer per device
+// descriptor staging for the batched launches: one pinned host buffer + device buffer per device
+// and descriptor kind; the next upload waits until the previous launch has consumed the buffer
 namespace {
-struct BatchStage {
-  std::mutex mu;
-  BatchGatherDesc* host = nullptr;   // pinned
-  BatchGatherDesc* dev = nullptr;
-  int cap = 0;
-  hipEvent_t consumed = nullptr;     // the last launch has read `dev`
+struct StageSlot {
+  char* host = nullptr;   // pinned
+  char* dev = nullptr;
+  size_t cap = 0;
+  hipEvent_t consumed = nullptr;
 };
-BatchStage g_stage[64];
+struct BatchStage {       // a small ring, so the host can prepare call k+1 while call k still runs
+  std::mutex mu;
+  StageSlot slot[4];
+  unsigned cursor = 0;
+};
+BatchStage g_stage[64][2];   // [device][0 = inference gather, 1 = training ops]
+
+// returns with st.mu HELD (released by StageRelease after `consumed` is recorded on the stream)
+int stage_acquire(BatchStage& st, size_t bytes, StageSlot** out) {
+  st.mu.lock();
+  StageSlot& sl = st.slot[st.cursor++ & 3u];
+  if (sl.consumed && hipEventSynchronize(sl.consumed) != hipSuccess) {
+    st.mu.unlock();
+    return fail(KV_INTERNAL, "descriptor staging: event sync failed");
+  }
+  if (sl.cap < bytes) {
+    if (sl.host) hipHostFree(sl.host);
+    if (sl.dev) hipFree(sl.dev);
+    sl.host = sl.dev = nullptr;
+    sl.cap = std::max<size_t>(bytes, 64 * 1024);
+    if (hipHostMalloc(&sl.host, sl.cap) != hipSuccess || hipMalloc(&sl.dev, sl.cap) != hipSuccess ||
+        (!sl.consumed && hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming) != hipSuccess)) {
+      sl.cap = 0;
+      st.mu.unlock();
+      return fail(KV_RESOURCE_EXHAUSTED, "descriptor staging: allocation failed");
+    }
+  }
+  *out = &sl;
+  return KV_OK;
+}
+struct StageRelease {   // unlocks (and marks the slot busy until the stream gets there) on scope exit
+  BatchStage& st; StageSlot* sl; hipStream_t s; bool launched = false;
+  ~StageRelease() { if (launched) hipEventRecord(sl->consumed, s); st.mu.unlock(); }
+};
+
+int check_same_shape(int num_tables, const kv_handle_t* tables, const char* what) {
+  int rc;
+  if (num_tables < 1) return fail(KV_INVALID_ARGUMENT, "N must be >= 1");
+  if (!tables) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  for (int i = 0; i < num_tables; ++i) {
+    if ((rc = check_table(tables[i]))) return rc;
+    if (tables[i]->device != tables[0]->device) return fail(KV_INVALID_ARGUMENT, "%s live on different devices", what);
+  }
+  if (tables[0]->device < 0 || tables[0]->device >= 64) return fail(KV_INVALID_ARGUMENT, "device index");
+  return KV_OK;
+}
 }  // namespace
 
 int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const void* const* ids,
                              const int64_t* ns, float* const* outs, kv_stream_t stream) {
   int rc;
-  if (num_tables < 1) return fail(KV_INVALID_ARGUMENT, "N must be >= 1");  // Attr("N: int >= 1")
-  if (!tables || !ids || !ns || !outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
-  for (int i = 0; i < num_tables; ++i) {
-    if ((rc = check_table(tables[i]))) return rc;
-    if (tables[i]->device != tables[0]->device) return fail(KV_INVALID_ARGUMENT, "tables live on different devices");
+  if ((rc = check_same_shape(num_tables, tables, "tables"))) return rc;  // Attr("N: int >= 1")
+  if (!ids || !ns || !outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  for (int i = 0; i < num_tables; ++i)
     if (ns[i] < 0 || (ns[i] > 0 && (!ids[i] || !outs[i]))) return fail(KV_INVALID_ARGUMENT, "indices / output pointer is null");
-  }
   const int device = tables[0]->device;
-  if (device < 0 || device >= 64) return fail(KV_INVALID_ARGUMENT, "device index");
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
-  std::vector<kv_table*> lk(tables, tables + num_tables);
-  MultiLock lock(lk);
-  BatchStage& st = g_stage[device];
-  std::lock_guard<std::mutex> sl(st.mu);
-  if (st.cap < num_tables) {
-    if (st.consumed) HIP_TRY(hipEventSynchronize(st.consumed));
-    if (st.host) hipHostFree(st.host);
-    if (st.dev) hipFree(st.dev);
-    st.cap = std::max(num_tables, 64);
-    HIP_TRY(hipHostMalloc(&st.host, (size_t)st.cap * sizeof(BatchGatherDesc)));
-    HIP_TRY(hipMalloc(&st.dev, (size_t)st.cap * sizeof(BatchGatherDesc)));
-    if (!st.consumed) HIP_TRY(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
-  } else if (st.consumed) {
-    HIP_TRY(hipEventSynchronize(st.consumed));  // the previous launch must be done with the descriptors
-  }
+  MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  BatchStage& st = g_stage[device][0];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(BatchGatherDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  BatchGatherDesc* hd = reinterpret_cast<BatchGatherDesc*>(sl->host);
   long long nmax = 0;
   for (int i = 0; i < num_tables; ++i) {
-    BatchGatherDesc& d = st.host[i];
+    BatchGatherDesc& d = hd[i];
     d.t = dev_view(tables[i]);
     d.ids = ids[i];
     d.out = outs[i];
@@ -951,11 +1018,160 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
     nmax = std::max<long long>(nmax, ns[i]);
   }
   if (nmax == 0) return KV_OK;
-  HIP_TRY(hipMemcpyAsync(st.dev, st.host, (size_t)num_tables * sizeof(BatchGatherDesc), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(BatchGatherDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
   dim3 grid((unsigned)nblocks(nmax, TB / 8, 2048), (unsigned)num_tables);
-  k_batch_gather_or_zeros<<<grid, TB, 0, s>>>(st.dev);
+  k_batch_gather_or_zeros<<<grid, TB, 0, s>>>(reinterpret_cast<const BatchGatherDesc*>(sl->dev));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(st.consumed, s));
+  return KV_OK;
+}
+
+// ---- many tables, one launch per pipeline stage (26-feature CTR step: 5 launches, not 130) ------
+// All tables: same device, same dim, same key dtype; each batch <= 2^21 ids.
+static int multi_common(int num_tables, const kv_handle_t* tables, const void* const* ids, const int64_t* ns) {
+  int rc;
+  if ((rc = check_same_shape(num_tables, tables, "tables"))) return rc;
+  if (!ids || !ns) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  for (int i = 0; i < num_tables; ++i) {
+    if (tables[i]->dim != tables[0]->dim || tables[i]->key_dtype != tables[0]->key_dtype)
+      return fail(KV_INVALID_ARGUMENT, "batched op: tables must share dim and key dtype (group them by shape)");
+    if (ns[i] < 0 || ns[i] > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "indices: bad length %lld", (long long)ns[i]);
+    if (ns[i] > 0 && !ids[i]) return fail(KV_INVALID_ARGUMENT, "indices pointer is null");
+    if (!tables[i]->initialized)
+      return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+    for (int j = 0; j < i; ++j)
+      if (tables[j] == tables[i]) return fail(KV_INVALID_ARGUMENT, "batched op: table listed twice");
+  }
+  return KV_OK;
+}
+
+int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                              const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                              kv_stream_t stream) {
+  int rc;
+  if ((rc = multi_common(num_tables, tables, ids, ns))) return rc;
+  if (!outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  const int device = tables[0]->device;
+  DeviceGuard dg(device);
+  hipStream_t s = (hipStream_t)stream;
+  MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  long long nmax = 0;
+  for (int i = 0; i < num_tables; ++i) {
+    if (ns[i] > 0 && !outs[i]) return fail(KV_INVALID_ARGUMENT, "output pointer is null");
+    if ((rc = ensure_capacity(tables[i], ns[i], s))) return rc;
+    if ((rc = ensure_workspace(tables[i], std::max<long long>(ns[i], 1), false, s))) return rc;
+    nmax = std::max<long long>(nmax, ns[i]);
+  }
+  if (nmax == 0) return KV_OK;
+  BatchStage& st = g_stage[device][1];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(MultiDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  MultiDesc* hd = reinterpret_cast<MultiDesc*>(sl->host);
+  WsDev wmax{};
+  for (int i = 0; i < num_tables; ++i) {
+    MultiDesc& d = hd[i];
+    std::memset(&d, 0, sizeof d);
+    d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
+    d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
+    d.a.day = today(tables[i]);
+    d.ids = ids[i];
+    d.counts = counts ? counts[i] : nullptr;
+    d.out = outs[i];
+    d.n = ns[i];
+    if (ns[i] == 0) d.w.ntiles = 0;
+    wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
+    wmax.P = std::max(wmax.P, d.w.P);
+  }
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
+  const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
+  kv_table* t0 = tables[0];
+  launch_tile<MODE_LOOKUP>(t0, wmax, nullptr, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  if ((rc = launch_part<MODE_LOOKUP, 0>(wmax, hd[0].a, s, md, num_tables))) return rc;
+  launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                              const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                              float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
+                              int version, kv_stream_t stream) {
+  int rc;
+  if ((rc = multi_common(num_tables, vars, ids, ns))) return rc;
+  if ((rc = check_same_shape(num_tables, slots, "slot tables"))) return rc;
+  if (!grads) return fail(KV_INVALID_ARGUMENT, "null argument array");
+  if (version != 3 && version != 4) return fail(KV_INVALID_ARGUMENT, "GroupAdam version %d: 3 or 4", version);
+  if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
+  if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
+  if (!(l2 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 regularization strength is not a non-negative scalar: %g", l2);
+  if (!(l21 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l21 regularization strength is not a non-negative scalar: %g", l21);
+  const int D = vars[0]->dim;
+  if ((D & 3) != 0 || !dim_supported(D))
+    return fail(KV_UNIMPLEMENTED, "batched GroupAdam: embedding dim %d (multiples of 4 up to 1024)", D);
+  std::vector<kv_table*> all;
+  for (int i = 0; i < num_tables; ++i) {
+    if (!slots[i]->initialized) return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: m_v_linear");
+    if (slots[i]->dim != 3 * D || slots[i]->device != vars[0]->device || slots[i]->key_dtype != vars[0]->key_dtype)
+      return fail(KV_INVALID_ARGUMENT, "kv_variable and linear do not have the same shape (m_v_linear must be 3x, same device / key dtype)");
+    if (ns[i] > 0 && !grads[i]) return fail(KV_INVALID_ARGUMENT, "grad pointer is null");
+    all.push_back(vars[i]); all.push_back(slots[i]);
+  }
+  {
+    std::vector<kv_table*> u(all);
+    std::sort(u.begin(), u.end());
+    if (std::adjacent_find(u.begin(), u.end()) != u.end())
+      return fail(KV_INVALID_ARGUMENT, "batched op: a table is listed twice (var or slot)");
+  }
+  const int device = vars[0]->device;
+  DeviceGuard dg(device);
+  hipStream_t s = (hipStream_t)stream;
+  MultiLock lock(all);
+  long long nmax = 0;
+  for (int i = 0; i < num_tables; ++i) {
+    if ((rc = ensure_capacity(vars[i], ns[i], s))) return rc;
+    if ((rc = ensure_capacity(slots[i], ns[i], s))) return rc;
+    if ((rc = ensure_workspace(vars[i], std::max<long long>(ns[i], 1), true, s))) return rc;
+    nmax = std::max<long long>(nmax, ns[i]);
+  }
+  if (nmax == 0) return KV_OK;
+  OptArgs a{};
+  a.lr = lr; a.b1p = b1p; a.b2p = b2p; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  if (version == 4) {  // training_ops.cc:7111-7120
+    a.l1 = l1 * lr; a.l2 = l2 * lr; a.l21 = l21 * lr;
+    a.alpha = lr * std::sqrt(1.f - b2p) / (1.f - b1p);
+  } else {             // :5840-5849
+    a.l1 = l1; a.l2 = l2; a.l21 = l21;
+    a.alpha = std::sqrt(1.f - b2p) / (1.f - b1p);
+  }
+  a.l21_norm = a.l21 * std::sqrt((float)D);
+  BatchStage& st = g_stage[device][1];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(MultiDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  MultiDesc* hd = reinterpret_cast<MultiDesc*>(sl->host);
+  WsDev wmax{};
+  for (int i = 0; i < num_tables; ++i) {
+    MultiDesc& d = hd[i];
+    std::memset(&d, 0, sizeof d);
+    d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
+    d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots[i]); d.a.ts1 = d.a.ts0;
+    d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
+    d.ids = ids[i];
+    d.n = ns[i];
+    if (ns[i] == 0) d.w.ntiles = 0;
+    wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
+    wmax.P = std::max(wmax.P, d.w.P);
+  }
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
+  const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
+  launch_tile<MODE_APPLY>(vars[0], wmax, nullptr, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  rc = version == 4 ? launch_part<MODE_APPLY, OPT_ADAM_V4>(wmax, hd[0].a, s, md, num_tables)
+                    : launch_part<MODE_APPLY, OPT_ADAM_V3>(wmax, hd[0].a, s, md, num_tables);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
   return KV_OK;
 }
 

@@ -443,6 +443,46 @@ def batch_kv_variable_gather_or_zeros_v2(table_handles, indices):
   return outs
 
 
+def _ptr_array(tensors):
+  return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def kv_multi_gather_or_insert(table_handles, indices, counts=None):
+  """[KvVariableGatherOrInsertV2 / ...WithCounts(t, i) for t, i in zip(...)] with three kernel launches
+  for all tables (same dim and key dtype).  Each output is indices[i].shape + [dim]."""
+  n = len(table_handles)
+  if n < 1 or n != len(indices) or (counts is not None and len(counts) != n):
+    raise _lib.InvalidArgumentError("table_handles, indices (and counts) must be equally long, N >= 1")
+  ids = [_ids(h, i) for h, i in zip(table_handles, indices)]
+  cnt = None if counts is None else [None if c is None else torch.as_tensor(c, dtype=torch.int32).to(i.device).reshape(-1).contiguous()
+                                     for c, i in zip(counts, ids)]
+  outs = [torch.empty(tuple(i.shape) + (h.dim,), dtype=torch.float32, device=i.device) for h, i in zip(table_handles, ids)]
+  hp = (ctypes.c_void_p * n)(*[h.ptr for h in table_handles])
+  ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
+  _lib.check(_lib.lib().kv_multi_gather_or_insert(n, hp, _ptr_array(ids), None if cnt is None else _ptr_array(cnt), ns,
+                                                  _ptr_array(outs), _stream(table_handles[0])))
+  return outs
+
+
+def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, indices, lr, beta1_power, beta2_power,
+                                     beat1, beta2, epsilon, l1, l2, l21, version=4):
+  """KvVariableGroupSparseApplyAdamV4 (V3) on many (var, m_v_linear) pairs with two kernel launches."""
+  n = len(var_handles)
+  if n < 1 or not (n == len(m_v_linear_handles) == len(grads) == len(indices)):
+    raise _lib.InvalidArgumentError("vars, slots, grads and indices must be equally long, N >= 1")
+  ids = [_ids(h, i).reshape(-1) for h, i in zip(var_handles, indices)]
+  gr = [_f32(h, g).reshape(-1, h.dim) for h, g in zip(var_handles, grads)]
+  for g, i in zip(gr, ids):
+    if g.shape[0] != i.numel():
+      raise _lib.InvalidArgumentError("grad must be the same size as indices in the first dimension.")
+  vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles])
+  sp = (ctypes.c_void_p * n)(*[h.ptr for h in m_v_linear_handles])
+  ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
+  sc = [ctypes.c_float(_scalar(x)) for x in (lr, beta1_power, beta2_power, beat1, beta2, epsilon, l1, l2, l21)]
+  _lib.check(_lib.lib().kv_multi_apply_group_adam(n, vp, sp, _ptr_array(gr), _ptr_array(ids), ns, *sc, int(version),
+                                                  _stream(var_handles[0])))
+
+
 _COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}
 
 

@@ -25,6 +25,16 @@ def step():
   for t in range(T_):
     v, s = tabs[t]
     _lib.check(L.kv_apply_group_adam(v.ptr, s.ptr, grads[t].data_ptr(), ids[t].data_ptr(), N, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0., 0., 0., 4, sts[t % NS]))
+if len(sys.argv) > 3 and sys.argv[3] == "multi":
+  # one batched call per op kind: 3 + 2 launches for all tables
+  vp = (ctypes.c_void_p * T_)(*[t[0].ptr for t in tabs]); sp = (ctypes.c_void_p * T_)(*[t[1].ptr for t in tabs])
+  ip = (ctypes.c_void_p * T_)(*[i.data_ptr() for i in ids]); gp = (ctypes.c_void_p * T_)(*[g_.data_ptr() for g_ in grads])
+  op = (ctypes.c_void_p * T_)(*[o.data_ptr() for o in outs]); nsz = (ctypes.c_int64 * T_)(*([N] * T_))
+  f = ctypes.c_float
+  def step():
+    _lib.check(L.kv_multi_gather_or_insert(T_, vp, ip, None, nsz, op, sts[0]))
+    _lib.check(L.kv_multi_apply_group_adam(T_, vp, sp, gp, ip, nsz, f(1e-3), f(0.9), f(0.999), f(0.9), f(0.999), f(1e-8),
+                                           f(0), f(0), f(0), 4, sts[0]))
 for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 50
