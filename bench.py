@@ -356,6 +356,16 @@ def main():
                                    "applies_per_s": N / (apply_ms * 1e-3),
                                    "unique_applies_per_s": Ub / (apply_ms * 1e-3)}},
   }
+  if shard_path:
+    # On the sharded path every rank runs the same kernels on what the exchange hands it (unique
+    # ids per source rank; sizes change with every batch), so the per-launch byte model above does
+    # not describe those launches: the kernels are characterised by the N = 1 line, this line
+    # carries the measured launch time only.
+    res["roofline"].update({"achieved": None, "frac": None, "traffic": None, "traffic_source": None,
+                            "algorithmic_bytes_per_launch": None,
+                            "note": "sharded path: kernel byte model is reported on the single-GPU line "
+                                    "(launch sizes here depend on the exchanged unique ids)"})
+    res.pop("ops", None)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
