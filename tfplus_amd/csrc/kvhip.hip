@@ -569,8 +569,8 @@ int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiD
       if (q <= 2) KV_PART(4, 2, 1);
       if (q <= 4) KV_PART(4, 4, 1);
       if (q <= 8) KV_PART(4, 8, 1);
-      if (q <= 16) KV_PART(4, 16, 1);
-      if (q <= 32) KV_PART(4, 32, 1);
+      if (q <= 16) KV_PART(4, 8, 2);    // dims 36..64: 8 lanes x 2 float4 (measured: 139 -> 120 us at D = 64)
+      if (q <= 32) KV_PART(4, 16, 2);   // dims 68..128: 16 lanes x 2 float4 (225 -> 183 us at D = 128)
       if (q <= 64) KV_PART(4, 64, 1);
       if (q <= 128) KV_PART(4, 64, 2);
       if (q <= 256) KV_PART(4, 64, 4);
