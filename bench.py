@@ -99,7 +99,16 @@ def cpu_baseline(args, D):
     ko.apply_group_adam(var, slot, s, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
     times.append(time.perf_counter() - t0)
   t = float(np.median(times[1:]))                      # first step inserts the slot rows
-  return {"value": N / t, "unit": "ids/s", "cores": cores, "kind": "port",
+  # the same step on ONE thread (SURVEY.md §8d asks for both): one more batch, warm tables
+  var.threads = 1
+  ids = splitmix64(z.sample(N, g)).numpy()
+  grad = rng.normal(0, 1e-2, (N, D)).astype(np.float32)
+  t0 = time.perf_counter()
+  var.gather_or_insert(ids)
+  u, s, _ = ko.dedup_segment_sum(ids, grad)
+  ko.apply_group_adam(var, slot, s, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
+  t1 = time.perf_counter() - t0
+  return {"value": N / t, "unit": "ids/s", "cores": cores, "kind": "port", "value_1_thread": N / t1,
           "sample": "oracle/kv_oracle.cc, %d threads, %d-key table (not 50M), %d steps of %d Zipf(%.1f) ids: "
                     "lookup + tf.unique/segment_sum + GroupAdamV4; median %.3f s/step; table build %.1f s"
                     % (cores, K, steps, N, args.zipf, t, build_s)}
