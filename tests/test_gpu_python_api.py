@@ -213,3 +213,26 @@ def test_unsorted_segment_sum(D):
   empty = cnt.squeeze(1) == 0
   assert empty.any() and float(out[empty].abs().sum()) == 0.0
   assert ops.kv_unsorted_segment_sum(h, data[:0].cuda(), seg[:0].cuda(), 3).abs().sum().item() == 0.0
+
+
+@pytest.mark.gpu
+def test_kv_variable_whole_table_methods(api):
+  """value / read_value / assign (KvVariable only) and the methods the reference refuses
+  (kv_variable_ops.py:1011-1030, 1199-1246, 1350-1373)."""
+  a = api
+  v = a.vs.get_kv_variable("wt_src", embedding_dim=4, initializer=a.vs.ones_initializer())
+  w = a.vs.get_kv_variable("wt_dst/part_3", embedding_dim=4, initializer=a.vs.zeros_initializer())
+  v.sparse_read(torch.arange(10))
+  v.scatter_update(a.kv.IndexedSlices(torch.arange(10.).reshape(10, 1).repeat(1, 4) + 1, torch.arange(10), None))
+  assert tuple(v.value().shape) == (10, 4) and torch.equal(v.read_value().sum(1).sort().values.cpu(), torch.arange(1., 11) * 4)
+  w.assign(v)
+  assert torch.equal(w.sparse_read(torch.arange(10)).cpu(), v.sparse_read(torch.arange(10)).cpu())
+  with pytest.raises(ValueError):
+    w.assign(torch.zeros(3))
+  for call in (lambda: v.assign_add(1), lambda: v.assign_sub(1), lambda: v.count_up_to(3), lambda: int(v),
+               lambda: v.scatter_nd_update(None, None), lambda: v.set_shape([1])):
+    with pytest.raises(RuntimeError):
+      call()
+  assert w.get_name_info() == ("wt_dst", ":0", 3) and w.get_generic_name() == "wt_dst"
+  with pytest.raises(NotImplementedError):
+    v.increase_counting([1], [1])

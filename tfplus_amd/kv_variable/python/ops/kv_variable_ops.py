@@ -12,6 +12,7 @@ import collections
 import numpy as np
 import torch
 
+from tfplus_amd import _lib
 from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops
 
 IS_TRAINING = True  # kv_variable_ops.py:95
@@ -192,6 +193,70 @@ class KvVariable(object):
                                      bool(count_occurrences))
     return gen_kv_variable_ops.kv_variable_lookup_sparse(self._handle, ids, seg, w, num_segments, combiner,
                                                          count_occurrences)
+
+  # -- whole-table reads / assignment (kv_variable_ops.py:1011-1030, 1220-1246) -----------------------
+  def value(self):
+    """ReadKvVariableOpV2's values output: the rows of every exported key, [keys, dim]."""
+    return gen_kv_variable_ops.read_kv_variable_op_v2(self._handle)[1]
+
+  def read_value(self):
+    return self.value()
+
+  def assign(self, value, use_locking=None, name=None, read_value=True):
+    """Only KvVariable -> KvVariable: import(export(first_n = 4)) as in the reference."""
+    if not isinstance(value, KvVariable):
+      raise ValueError("KvVariable does not implement assign() for type %s" % type(value))
+    k, v, bl, fk, fv = gen_kv_variable_ops.kv_variable_export(value.handle, first_n=4)
+    gen_kv_variable_ops.kv_variable_import(self._handle, k, v, bl, fk, fv, first_n=4)
+    return self
+
+  def assign_sub(self, delta, use_locking=None, name=None, read_value=True):
+    raise RuntimeError("KvVariable does not implement assign_sub")
+
+  def assign_add(self, delta, use_locking=None, name=None, read_value=True):
+    raise RuntimeError("KvVariable does not implement assign_add")
+
+  def count_up_to(self, limit):
+    raise RuntimeError("KvVariable does not implement count_up_to")
+
+  def _ref(self):
+    raise RuntimeError("KvVariable does not implement _ref")
+
+  def set_shape(self, shape):
+    raise RuntimeError("KvVariable does not implement set_shape")
+
+  def scatter_nd_sub(self, indices, updates, name=None):
+    raise RuntimeError("KvVariable does not implement scatter_nd_sub")
+
+  def scatter_nd_add(self, indices, updates, name=None):
+    raise RuntimeError("KvVariable does not implement scatter_nd_add")
+
+  def scatter_nd_update(self, indices, updates, name=None):
+    raise RuntimeError("KvVariable does not implement scatter_nd_update")
+
+  def __int__(self):
+    raise RuntimeError("KvVariable int(value) not supported")
+
+  def get_name_info(self, var_name=None):
+    """(prefix, suffix, partition index) of `scope/name/part_3:0`-style names (kv_variable_ops.py:1384-1398)."""
+    import re
+    name = var_name if var_name else (self._name if self._name.endswith(":0") else self._name + ":0")
+    match = re.search(r"/part_\d+", name, 0)
+    if match is None:
+      return name[:-2], ":0", 0
+    span = match.span()
+    return name[:span[0]], name[span[1]:], int(name[span[0] + 6:span[1]])
+
+  def get_generic_name(self, var_name=None):
+    prefix, suffix, _ = self.get_name_info(var_name)
+    return prefix + suffix[:len(suffix) - 2]
+
+  def increase_counting(self, indices, counts, name=None):
+    """KvVariableIncreaseCountV2 is declared (ops/kv_variable_ops.cc:342-347) but has no kernel in the
+    reference; training mode fails the same way here, prediction mode is the reference's no-op."""
+    if IS_TRAINING:
+      raise _lib.UnimplementedError("KvVariableIncreaseCountV2: no kernel is registered for this op in the reference")
+    return None
 
   # -- table hygiene (kv_variable_ops.py:1129-1131, 1499-1518) -------------------------------------
   def get_counting(self, indices, name=None):
