@@ -24,11 +24,7 @@ constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every 
                                  // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
-constexpr int HOT_MIN = 32;      // rows of one key in one tile above which the whole block folds it
 constexpr int MAX_P = 1024;      // partitions (power of two)
-constexpr int TBP = 512;         // threads per block of the partition kernel
-constexpr int CAPB = 1536;       // entries a partition block holds in LDS per round
-constexpr int HS = 4096;         // its LDS hash slots
 constexpr int HEAVY = 32;        // entries of one key in one partition above which the block folds it
 constexpr int MAX_CHUNKS = 1024;
 

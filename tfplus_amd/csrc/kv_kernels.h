@@ -3,24 +3,28 @@
 // Why this shape.  The first version de-duplicated a batch through a global scratch hash with
 // atomics.  On MI355X a returning or non-returning device-scope atomic on ONE address costs
 // ~40 ns and same-address atomics serialise; a Zipf(1.2) batch of 1M ids has ~100 keys that
-// occur in (nearly) every 1024-id tile, so each of those addresses took ~1000 serial atomics
-// (in-kernel stamps: 73 % of the dedup kernel).  fp32 atomic accumulation of gradient rows hit
-// the same wall.  This pipeline has NO global atomics on the data path:
+// occur in (nearly) every tile, so each of those addresses took ~1000 serial atomics (in-kernel
+// stamps: 73 % of the dedup kernel).  fp32 atomic accumulation of gradient rows hit the same
+// wall.  This pipeline has NO global atomics on the data path:
 //
-//   k_tile  one block per 1024 input positions: LDS hash dedup of the tile; the tile's unique
-//           keys ("entries") are counting-sorted by the key's hash partition and written with
-//           plain coalesced stores (ent_*), with the partition boundaries in toff[tile][0..P].
-//           Optimizer ops also fold the gradient rows of keys that repeat inside the tile into
-//           one partial-sum row (registers; whole block for tile-hot keys).
-//   k_part  one block per partition p: gathers partition p's entries from EVERY tile, so it sees
-//           all occurrences of its keys: exact counts, exclusive ownership of the table rows
-//           (find / insert / frequency / flags), and for optimizer ops the sum of the per-tile
-//           contributions in registers followed by the fused row update.  Results that input
-//           positions need (row ids) are written back per entry.
-//   k_gather  out[i] = rows[ent_b[slot_of_id[i]]], 16 bytes per lane.
+//   k_tile       one block (TBT threads) per TILE input positions: LDS hash dedup of the tile; the
+//                tile's unique keys ("entries") are counting-sorted by the key's hash partition and
+//                written with plain coalesced stores (ent_*), with the partition boundaries in
+//                toff[tile][0..P].  Optimizer ops also fold the gradient rows of keys that repeat
+//                inside the tile into one partial-sum row (sorted-run register sums).
+//   k_part_keys  (lookup / scatter / import marks / unique) and
+//   k_part_sum   (optimizers / dedup): one block per partition p: takes partition p's entries from
+//                EVERY tile, so it sees all occurrences of its keys: exact counts, exclusive
+//                ownership of the table rows (find / insert / frequency / flags), and for optimizer
+//                ops the sum of the per-tile contributions in registers followed by the fused row
+//                update.  Results that input positions need (row ids) are written back per entry.
+//   k_gather     out[i] = rows[ent_b[slot_of_id[i]]], one wave per 64 output rows.
 //
-// Summation order of repeated ids is deterministic (tile order inside a partition, sorted-run
-// order inside a tile up to the LDS-atomic rank; no float atomics in global memory).
+// Every kernel body is a __device__ function with two entry points: one table (arguments by
+// value) and many tables in one launch (grid.y = table, arguments from a MultiDesc array).
+//
+// Summation order of repeated ids depends on LDS-atomic ranks (not run-to-run deterministic);
+// there are no float atomics in global memory.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
@@ -731,7 +735,6 @@ constexpr int TBS = 256;
 constexpr int HSS = 1024;
 constexpr int UCAPS = HSS * 3 / 4;
 constexpr int ECAPS = 1600;
-constexpr int TPT = 8;  // tiles per thread whose segment bounds are kept in registers
 constexpr int HMAXS = 16;                  // heavy keys per round folded by the whole block (the rest
                                            // are summed by single groups)
 constexpr unsigned LOC_LDS = 0xFFFFFFE0u;  // gradient locator: row of the block's LDS hsum
