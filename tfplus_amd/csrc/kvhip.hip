@@ -5,19 +5,21 @@
 //   index    Entry[cap+1]   16 B {int64 key, u32 row, u32 pad}, open addressing, linear
 //                           probing, cap = 2^k >= 2 * rows (load <= 0.5).  Entry[cap] is the
 //                           home of the one key that equals the EMPTY sentinel.
-//   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32, freq[r] u32
-//            ((day << 16) | saturating u16 frequency), flags[r] u8 (bit0 blacklist,
-//            bit1 under_threshold), keys[r] int64.  Row ids are dense (bump allocated),
-//            row 0 is a permanent all-zero row (misses / nothing).
+//   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32 and RowMeta[r] 16 B {int64 key,
+//            u32 freq = (day << 16) | saturating u16 frequency, u8 flags (bit0 blacklist, bit1
+//            under_threshold, bit2 under_threshold stale, bit3 released by Delete)}.  Row ids are
+//            dense (bump allocated; rows released by Delete are recycled from a device free
+//            list), row 0 is a permanent all-zero row (misses / nothing).
 //   workspace per-batch entry lists (ent_key / ent_a / ent_b, toff, slot_of_id, part): plain
 //            stores only, rewritten by every op — nothing to clean.
 //
 // Kernel pipeline (kv_kernels.h explains why; DESIGN.md has the byte accounting):
-//   lookup : k_tile<LOOKUP>  LDS dedup per 1024-id tile, entries sorted by hash partition
-//            k_part<LOOKUP>  one block owns a partition's keys: find / insert, frequency, flags
-//            k_gather        coalesced 16 B/lane row gather
-//   apply  : k_tile<APPLY>   same + in-tile fold of repeated ids' gradient rows
-//            k_part<APPLY>   per key: sum of the per-tile contributions + fused row update
+//   lookup : k_tile<LOOKUP>      LDS dedup per 2048-id tile, entries sorted by hash partition
+//            k_part_keys<LOOKUP> one block owns a partition's keys: find / insert, frequency, flags
+//            k_gather            one wave per 64 output rows, 16 B per lane
+//   apply  : k_tile<APPLY>       same + in-tile fold of repeated ids' gradient rows
+//            k_part_sum<OPT>     per key: sum of the per-tile contributions + fused row update
+//   many tables in one launch: the *_multi entry points (grid.y = table)
 //
 // Reference semantics restated per function with file:line (relative to the tfplus tree).
 
