@@ -51,6 +51,17 @@ def tf_adagrad_step(var, acc, g, lr):
   return var, acc
 
 
+def tf_ftrl_v2_step(var, accum, linear, g, lr, l1, l2, l2_shrinkage, lr_power):
+  """TF-core ResourceSparseApplyFtrlV2 (FtrlCompute with l2 shrinkage), float64."""
+  g_s = g + 2.0 * l2_shrinkage * var
+  new_accum = accum + g * g
+  p = -lr_power
+  linear = linear + g_s - (new_accum**p - accum**p) / lr * var
+  quadratic = new_accum**p / lr + 2.0 * l2
+  var = np.where(np.abs(linear) > l1, (np.sign(linear) * l1 - linear) / quadratic, 0.0)
+  return var, new_accum, linear
+
+
 def main():
   rng = np.random.Generator(np.random.PCG64(SEED))
 
@@ -92,6 +103,18 @@ def main():
   np.savez(os.path.join(HERE, "F1_freq_word.npz"),
            hi=np.array([65534, 18303], np.uint32), lo=np.array([65535, 7], np.uint32),
            word=np.array([(65534 << 16) | 65535, (18303 << 16) | 7], np.uint32))
+
+  # A4: test_kv_variable_sparse_apply_ftrl (test_training_ops.py:68-205): one FTRL-V2 step on 300
+  # ids x dim 64, var = .03, accum = .1, linear = 0, lr = .01, l1 = l2 = l2_shrinkage = 0,
+  # lr_power = -.5, grad ~ N(0, 1); asserted equal to TF's ResourceSparseApplyFtrlV2, atol 1e-8.
+  # (The op under test there is the plain FTRL; KvVariableSparseGroupSparseApplyFtrlV2 with
+  # l21 = 0 is the same update — training_ops.cc:532-801 — which is what this vector pins.)
+  rng4 = np.random.Generator(np.random.PCG64(SEED + 4))      # own stream: earlier fixtures stay byte-identical
+  g = rng4.standard_normal((300, 64)).astype(np.float32)
+  var, acc, lin = tf_ftrl_v2_step(np.full((300, 64), np.float64(np.float32(0.03))), np.full((300, 64), np.float64(np.float32(0.1))),
+                                  np.zeros((300, 64)), g.astype(np.float64), float(np.float32(0.01)), 0.0, 0.0, 0.0, -0.5)
+  np.savez(os.path.join(HERE, "A4_ftrl_v2.npz"), ids=np.arange(300, dtype=np.int64), grad=g,
+           expect_var=var.astype(np.float32), expect_accum=acc.astype(np.float32), expect_linear=lin.astype(np.float32))
 
 
 if __name__ == "__main__":

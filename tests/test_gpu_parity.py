@@ -144,6 +144,19 @@ def test_A2_adagrad_equals_tf_adagrad(ops, golden_dir):
                              rtol=1e-6)
 
 
+def test_A4_ftrl_v2_equals_tf_ftrl(ops, golden_dir):
+  g = np.load(os.path.join(golden_dir, "A4_ftrl_v2.npz"))
+  var, _ = _const(ops, 64, 0.03)
+  acc, _ = _const(ops, 64, 0.1)
+  lin, _ = _const(ops, 64, 0.0)
+  ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var, acc, lin, g["grad"], g["ids"], 0.01, 0.0, 0.0, 0.0, 0.0, -0.5)
+  np.testing.assert_allclose(_np(ops.kv_variable_gather_or_zeros_v2(var, g["ids"])), g["expect_var"],
+                             rtol=1e-5, atol=1e-8)
+  np.testing.assert_allclose(_np(ops.kv_variable_gather_or_zeros_v2(acc, g["ids"])), g["expect_accum"], rtol=1e-6)
+  np.testing.assert_allclose(_np(ops.kv_variable_gather_or_zeros_v2(lin, g["ids"])), g["expect_linear"],
+                             rtol=1e-5, atol=1e-6)
+
+
 # ---------------------------------------------------------------------------------------------
 # lookup parity vs the oracle
 # ---------------------------------------------------------------------------------------------

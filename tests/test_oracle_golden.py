@@ -140,6 +140,16 @@ def test_A3_sparse_group_ftrl_runs_and_differs(D):
   np.testing.assert_allclose(acc.gather_or_zeros(ids), na, rtol=1e-6)
 
 
+# --- A4: test_training_ops.py:68-205: one FTRL-V2 step, 300 ids x 64, equals TF's FTRL -----
+def test_A4_ftrl_v2_equals_tf_ftrl(golden_dir):
+  g = _load(golden_dir, "A4_ftrl_v2.npz")
+  var, acc, lin = _mk(64, 0.03), _mk(64, 0.1), _mk(64, 0.0)
+  ko.apply_sparse_group_ftrl(var, acc, lin, g["grad"], g["ids"], 0.01, 0.0, 0.0, 0.0, 0.0, -0.5)
+  np.testing.assert_allclose(var.gather_or_zeros(g["ids"]), g["expect_var"], rtol=1e-5, atol=1e-8)
+  np.testing.assert_allclose(acc.gather_or_zeros(g["ids"]), g["expect_accum"], rtol=1e-6)
+  np.testing.assert_allclose(lin.gather_or_zeros(g["ids"]), g["expect_linear"], rtol=1e-5, atol=1e-6)
+
+
 # --- closed-form cases authored from the kernels ("additional fixtures") ---
 def test_group_lasso_blacklist_cycle():
   """training_ops.cc:7182-7192 + kv_variable.h:404-408 + table_manager.h:335-372"""
