@@ -165,8 +165,10 @@ int kv_import(kv_handle_t h, const int64_t* keys, const float* values, int64_t n
 int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv_stream_t stream);
 /* Replaces KvVariableScatter{Update,Add,Sub,Mul,Div,Min,Max}V2 (kernels/kv_variable_ops.cc:
  * 1097-1161) -> ScatterUpdate (kernels/kv_variable.h:616-734): row = row <op> updates[i]; missing
- * keys are inserted with the init rule first; blacklisted rows are left untouched. ids must
- * be unique within one call (the reference races on duplicates). */
+ * keys are inserted with the init rule first; blacklisted rows are left untouched.  Repeated
+ * ids: add / sub apply the SUM of their update rows (the reference applies each occurrence in
+ * turn; int64 keys, n <= 2^21 — this step is synchronous), the other operations apply one of the
+ * occurrences (the reference's result depends on its thread interleaving there). */
 int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
                       kv_stream_t stream);
 

@@ -125,6 +125,30 @@ def test_group_adam_optimizer_equals_adam(api, D):
   np.testing.assert_allclose(res, want, rtol=1e-5, atol=1e-8)
 
 
+def test_adam_optimizer_equals_tf_adam(api):
+  """test_training_ops.py:395-416: tfplus AdamOptimizer (gather + scatter ops, one m_v slot) == TF Adam;
+  two steps, the second with repeated ids."""
+  opt = api.tr.AdamOptimizer(learning_rate=0.1)
+  res, g = _train_pair(api, 64, opt)
+  b1, b2, eps = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-8))
+  lr_t = 0.1 * np.sqrt(1 - b2) / (1 - b1)
+  m1, v1 = (1 - b1) * g, (1 - b2) * g * g
+  x1 = 1.0 - lr_t * m1 / (np.sqrt(v1) + eps)
+  np.testing.assert_allclose(res, x1, rtol=1e-5, atol=1e-8)
+  assert opt.get_slot_names() == ["m_v"]
+
+
+def test_gradient_descent_optimizer_adds_every_occurrence(api):
+  """gradient_descent.py:31-33: scatter_add(-grad * lr) on the raw indices; repeated ids accumulate."""
+  kv = api.vs.get_kv_variable("sgd", embedding_dim=8, initializer=api.vs.ones_initializer())
+  ids = torch.tensor([4, 9, 4, 4, -2, 9])
+  g = torch.arange(48, dtype=torch.float32).reshape(6, 8) / 10
+  api.tr.GradientDescentOptimizer(0.5).apply_gradients([(api.kv.IndexedSlices(g.cuda(), ids.cuda(), None), kv)])
+  want = {4: 1 - 0.5 * (g[0] + g[2] + g[3]), 9: 1 - 0.5 * (g[1] + g[5]), -2: 1 - 0.5 * g[4]}
+  for k, w in want.items():
+    torch.testing.assert_close(kv.sparse_read(torch.tensor([k]))[0].cpu(), w, rtol=1e-6, atol=1e-6)
+
+
 def test_adagrad_optimizer_equals_tf_adagrad(api):
   res, g = _train_pair(api, 64, api.tr.AdagradOptimizer(0.5))
   np.testing.assert_allclose(res, 1.0 - 0.5 * g / np.sqrt(0.1 + g * g), rtol=1e-5, atol=1e-8)

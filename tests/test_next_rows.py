@@ -148,3 +148,20 @@ def test_import_export_parity(ops):
   # importing again replaces the content (table_->clear(), dynamic_restore.hpp:178)
   ops.kv_variable_import(h2, gk[:5], gv[:5])
   assert ops.kv_variable_shape_v2(h2) == [5, D]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", [1, 2])                     # ScatterAdd / ScatterSub
+def test_scatter_add_sub_repeated_ids_accumulate(ops, op):
+  """ScatterUpdate walks the indices one by one (kv_variable.h:616-734): repeated ids add up."""
+  h, o = _pair(ops, 16)
+  rng = np.random.default_rng(21)
+  ids = rng.integers(-20, 20, 3000)                         # ~75 occurrences per id
+  ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+  upd = rng.uniform(0.5, 1.5, (ids.size, 16)).astype(np.float32)
+  (ops.kv_variable_scatter_add_v2 if op == 1 else ops.kv_variable_scatter_sub_v2)(h, ids, upd)
+  o.scatter_update(ids, upd, op)
+  q = np.arange(-20, 20)
+  np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q),
+                             rtol=2e-6, atol=1e-6)
+  assert ops.kv_variable_frequency(h) == o.sum_freq()

@@ -219,6 +219,9 @@ struct Workspace {
   float* part = nullptr;
   long long part_elems = 0;
   unsigned* ctr = nullptr;
+  long long* scat_keys = nullptr;  // kv_scatter_update add / sub: de-duplicated ids and summed updates
+  float* scat_sum = nullptr;
+  long long scat_cap = 0;          // rows
   unsigned* seg_off = nullptr;   // kv_lookup_sparse: CSR offsets [seg_cap + 1]
   long long seg_cap = 0;
   unsigned long long* dbg = nullptr;
@@ -694,7 +697,7 @@ int kv_destroy(kv_handle_t t) {
   for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.toff); hipFree(w.slot_of_id);
-  hipFree(w.part); hipFree(w.ctr); hipFree(w.dbg);
+  hipFree(w.part); hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   delete t;
   return KV_OK;
 }
@@ -1289,19 +1292,10 @@ int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, 
   return KV_OK;
 }
 
-int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int64_t n, int64_t* uniq,
-                         float* summed, int32_t* inverse, int64_t* num_unique, kv_stream_t stream) {
+// tf.unique + unsorted_segment_sum on the batch pipeline; the table's mutex is held by the caller
+static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t n, int64_t* uniq,
+                        float* summed, int32_t* inverse, int64_t* num_unique, hipStream_t s) {
   int rc;
-  if ((rc = check_table(t))) return rc;
-  if (!num_unique) return fail(KV_INVALID_ARGUMENT, "num_unique is null");
-  *num_unique = 0;
-  if (n == 0) return KV_OK;
-  if (n < 0 || !ids || !grad || !uniq || !summed) return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
-  if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
-  DeviceGuard dg(t->device);
-  std::lock_guard<std::mutex> l(t->mu);
-  hipStream_t s = (hipStream_t)stream;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
   const WsDev wd = ws_view(t, n);
   HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
@@ -1318,6 +1312,21 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   HIP_TRY(hipStreamSynchronize(s));
   *num_unique = U;
   return KV_OK;
+}
+
+int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int64_t n, int64_t* uniq,
+                         float* summed, int32_t* inverse, int64_t* num_unique, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!num_unique) return fail(KV_INVALID_ARGUMENT, "num_unique is null");
+  *num_unique = 0;
+  if (n == 0) return KV_OK;
+  if (n < 0 || !ids || !grad || !uniq || !summed) return fail(KV_INVALID_ARGUMENT, "bad arguments");
+  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
+  if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  return dedup_locked(t, ids, grad, n, uniq, summed, inverse, num_unique, (hipStream_t)stream);
 }
 
 int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const float* data, int64_t n,
@@ -1680,7 +1689,25 @@ int kv_scatter_update(kv_handle_t t, const void* ids, const float* updates, int6
   if (op < KV_SCATTER_ASSIGN || op > KV_SCATTER_MAX) return fail(KV_INVALID_ARGUMENT, "unsupported update operation %d", op);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  return scatter_like(t, ids, updates, n, op, 0, -1, nullptr, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if ((op == KV_SCATTER_ADD || op == KV_SCATTER_SUB) && n > 1 && n <= (1ll << 21) && ids && updates &&
+      dim_supported(t->dim) && t->key_dtype != KV_DT_INT32) {
+    // ScatterUpdate applies every occurrence of an id in turn (kv_variable.h:616-734), so repeated
+    // ids add up: sum them first (one row per distinct id), then apply once
+    Workspace& w = t->ws;
+    if (w.scat_cap < n) {
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(w.scat_keys); hipFree(w.scat_sum);
+      w.scat_keys = nullptr; w.scat_sum = nullptr;
+      w.scat_cap = std::max<long long>(n, w.scat_cap * 2);
+      HIP_TRY(hipMalloc(&w.scat_keys, (size_t)w.scat_cap * sizeof(long long)));
+      HIP_TRY(hipMalloc(&w.scat_sum, (size_t)w.scat_cap * t->dim * sizeof(float)));
+    }
+    int64_t U = 0;
+    if ((rc = dedup_locked(t, ids, updates, n, (int64_t*)w.scat_keys, w.scat_sum, nullptr, &U, s))) return rc;
+    return scatter_like(t, w.scat_keys, w.scat_sum, U, op, 0, -1, nullptr, s);
+  }
+  return scatter_like(t, ids, updates, n, op, 0, -1, nullptr, s);
 }
 
 int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n, const int64_t* blacklist,
