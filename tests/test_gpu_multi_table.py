@@ -99,3 +99,16 @@ def test_multi_ops_argument_checks(ops):
   with pytest.raises(_lib.FailedPreconditionError):
     ops.kv_multi_gather_or_insert([raw], [[1]])
   assert ops.kv_multi_gather_or_insert([v8], [np.zeros((0,), np.int64)])[0].shape == (0, 8)
+
+
+@pytest.mark.gpu
+def test_dcn_example_trains(ops):
+  """configs[2] shape end to end: 26 KvVariables behind the batched ops + a torch dense tower."""
+  import importlib.util
+  import os
+  spec = importlib.util.spec_from_file_location(
+      "dcn_train", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "dcn_train.py"))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  losses = mod.main(["--steps", "120", "--batch_size", "1024"])
+  assert np.isfinite(losses).all() and losses[-1] < 0.95 * losses[0], losses
