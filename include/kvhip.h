@@ -220,6 +220,16 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
                               float lr, float beta1_power, float beta2_power, float beta1, float beta2,
                               float epsilon, float l1, float l2, float l21, int version,
                               kv_stream_t stream);
+/* the same for kv_apply_adagrad and kv_apply_sparse_group_ftrl (config 5 mixes GroupAdam and
+ * SparseGroupFtrl tables: one call per (optimizer, dim) group) */
+int kv_multi_apply_adagrad(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                           const float* const* grads, const void* const* ids, const int64_t* ns,
+                           int update_slots, kv_stream_t stream);
+int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                     const kv_handle_t* linears, const float* const* grads,
+                                     const void* const* ids, const int64_t* ns, float lr, float l1,
+                                     float l2, float l21, float l2_shrinkage, float lr_power,
+                                     kv_stream_t stream);
 
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
  * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->

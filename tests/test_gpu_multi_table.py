@@ -112,3 +112,43 @@ def test_dcn_example_trains(ops):
   spec.loader.exec_module(mod)
   losses = mod.main(["--steps", "120", "--batch_size", "1024"])
   assert np.isfinite(losses).all() and losses[-1] < 0.95 * losses[0], losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["adagrad", "ftrl"])
+def test_multi_adagrad_and_ftrl_equal_single_ops(ops, which):
+  D, sizes = 16, [700, 2048, 3, 0, 5000]
+  rng = np.random.default_rng(7)
+
+  def make():
+    out = []
+    for j in range(len(sizes)):
+      hs = []
+      for val in ((None, 0.1, 0.0) if which == "ftrl" else (None, 0.1)):
+        h = ops.kv_variable([D])
+        ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 11 + j)
+        tab = np.random.default_rng(50 + j).standard_normal((32, D)).astype(np.float32) if val is None \
+            else np.full((4, D), val, np.float32)
+        ops.init_kv_variable_v2(h, tab)
+        hs.append(h)
+      out.append(hs)
+    return out
+  A, B = make(), make()
+  for step in range(3):
+    ids = [rng.integers(-300, 300, n) for n in sizes]
+    grads = [(rng.uniform(0.5, 1.5, (i.size, D)) * 1e-1).astype(np.float32) for i in ids]
+    if which == "adagrad":
+      ops.kv_multi_sparse_apply_adagrad([a[0] for a in A], [a[1] for a in A], 0.05, grads, ids)
+      for b, g, i in zip(B, grads, ids):
+        ops.kv_variable_sparse_apply_adagrad(b[0], b[1], 0.05, g, i, use_locking=True)
+    else:
+      ops.kv_multi_sparse_group_sparse_apply_ftrl([a[0] for a in A], [a[1] for a in A], [a[2] for a in A], grads, ids,
+                                                  0.05, 1e-3, 1e-3, 1e-4, 0.0, -0.5)
+      for b, g, i in zip(B, grads, ids):
+        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(b[0], b[1], b[2], g, i, 0.05, 1e-3, 1e-3, 1e-4, 0.0, -0.5)
+  for a, b in zip(A, B):
+    for ha, hb in zip(a, b):
+      ka, va, fa, sa = _dump(ops, ha)
+      kb, vb, fb, sb = _dump(ops, hb)
+      assert torch.equal(ka, kb) and fa == fb and sa == sb
+      torch.testing.assert_close(va, vb, rtol=2e-5, atol=2e-6)

@@ -1099,29 +1099,31 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
   return KV_OK;
 }
 
-int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
-                              const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
-                              float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
-                              int version, kv_stream_t stream) {
+// shared body of the batched optimizer ops: opt = OPT_*; slots1 only for FTRL (linear); slot_mult =
+// slot dim / var dim
+static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots0,
+                              const kv_handle_t* slots1, int slot_mult, const float* const* grads,
+                              const void* const* ids, const int64_t* ns, const OptArgs& a, int opt,
+                              kv_stream_t stream) {
   int rc;
   if ((rc = multi_common(num_tables, vars, ids, ns))) return rc;
-  if ((rc = check_same_shape(num_tables, slots, "slot tables"))) return rc;
+  if ((rc = check_same_shape(num_tables, slots0, "slot tables"))) return rc;
+  if (slots1 && (rc = check_same_shape(num_tables, slots1, "slot tables"))) return rc;
   if (!grads) return fail(KV_INVALID_ARGUMENT, "null argument array");
-  if (version != 3 && version != 4) return fail(KV_INVALID_ARGUMENT, "GroupAdam version %d: 3 or 4", version);
-  if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
-  if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
-  if (!(l2 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 regularization strength is not a non-negative scalar: %g", l2);
-  if (!(l21 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l21 regularization strength is not a non-negative scalar: %g", l21);
   const int D = vars[0]->dim;
   if ((D & 3) != 0 || !dim_supported(D))
-    return fail(KV_UNIMPLEMENTED, "batched GroupAdam: embedding dim %d (multiples of 4 up to 1024)", D);
+    return fail(KV_UNIMPLEMENTED, "batched optimizer op: embedding dim %d (multiples of 4 up to 1024)", D);
   std::vector<kv_table*> all;
   for (int i = 0; i < num_tables; ++i) {
-    if (!slots[i]->initialized) return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: m_v_linear");
-    if (slots[i]->dim != 3 * D || slots[i]->device != vars[0]->device || slots[i]->key_dtype != vars[0]->key_dtype)
-      return fail(KV_INVALID_ARGUMENT, "kv_variable and linear do not have the same shape (m_v_linear must be 3x, same device / key dtype)");
+    for (const kv_handle_t* sl : {slots0, slots1}) {
+      if (!sl) continue;
+      if (!sl[i]->initialized) return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: optimizer slot");
+      if (sl[i]->dim != slot_mult * D || sl[i]->device != vars[0]->device || sl[i]->key_dtype != vars[0]->key_dtype)
+        return fail(KV_INVALID_ARGUMENT, "var and slot do not have matching shapes (slot dim must be %d x var dim, same device / key dtype)", slot_mult);
+      all.push_back(sl[i]);
+    }
     if (ns[i] > 0 && !grads[i]) return fail(KV_INVALID_ARGUMENT, "grad pointer is null");
-    all.push_back(vars[i]); all.push_back(slots[i]);
+    all.push_back(vars[i]);
   }
   {
     std::vector<kv_table*> u(all);
@@ -1136,21 +1138,12 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
   long long nmax = 0;
   for (int i = 0; i < num_tables; ++i) {
     if ((rc = ensure_capacity(vars[i], ns[i], s))) return rc;
-    if ((rc = ensure_capacity(slots[i], ns[i], s))) return rc;
+    if ((rc = ensure_capacity(slots0[i], ns[i], s))) return rc;
+    if (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))) return rc;
     if ((rc = ensure_workspace(vars[i], std::max<long long>(ns[i], 1), true, s))) return rc;
     nmax = std::max<long long>(nmax, ns[i]);
   }
   if (nmax == 0) return KV_OK;
-  OptArgs a{};
-  a.lr = lr; a.b1p = b1p; a.b2p = b2p; a.b1 = b1; a.b2 = b2; a.eps = eps;
-  if (version == 4) {  // training_ops.cc:7111-7120
-    a.l1 = l1 * lr; a.l2 = l2 * lr; a.l21 = l21 * lr;
-    a.alpha = lr * std::sqrt(1.f - b2p) / (1.f - b1p);
-  } else {             // :5840-5849
-    a.l1 = l1; a.l2 = l2; a.l21 = l21;
-    a.alpha = std::sqrt(1.f - b2p) / (1.f - b1p);
-  }
-  a.l21_norm = a.l21 * std::sqrt((float)D);
   BatchStage& st = g_stage[device][1];
   StageSlot* sl = nullptr;
   if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(MultiDesc), &sl))) return rc;
@@ -1161,7 +1154,7 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
     MultiDesc& d = hd[i];
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
-    d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots[i]); d.a.ts1 = d.a.ts0;
+    d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
     d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
     d.ids = ids[i];
     d.n = ns[i];
@@ -1173,11 +1166,64 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   launch_tile<MODE_APPLY>(vars[0], wmax, nullptr, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
-  rc = version == 4 ? launch_part<MODE_APPLY, OPT_ADAM_V4>(wmax, hd[0].a, s, md, num_tables)
-                    : launch_part<MODE_APPLY, OPT_ADAM_V3>(wmax, hd[0].a, s, md, num_tables);
+  switch (opt) {
+    case OPT_ADAM_V4: rc = launch_part<MODE_APPLY, OPT_ADAM_V4>(wmax, hd[0].a, s, md, num_tables); break;
+    case OPT_ADAM_V3: rc = launch_part<MODE_APPLY, OPT_ADAM_V3>(wmax, hd[0].a, s, md, num_tables); break;
+    case OPT_ADAGRAD: rc = launch_part<MODE_APPLY, OPT_ADAGRAD>(wmax, hd[0].a, s, md, num_tables); break;
+    default: rc = launch_part<MODE_APPLY, OPT_FTRL>(wmax, hd[0].a, s, md, num_tables); break;
+  }
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
+}
+
+int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                              const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                              float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
+                              int version, kv_stream_t stream) {
+  if (version != 3 && version != 4) return fail(KV_INVALID_ARGUMENT, "GroupAdam version %d: 3 or 4", version);
+  if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
+  if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
+  if (!(l2 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 regularization strength is not a non-negative scalar: %g", l2);
+  if (!(l21 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l21 regularization strength is not a non-negative scalar: %g", l21);
+  if (num_tables < 1 || !vars || !vars[0]) return fail(KV_INVALID_ARGUMENT, "N must be >= 1");
+  OptArgs a{};
+  a.lr = lr; a.b1p = b1p; a.b2p = b2p; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  if (version == 4) {  // training_ops.cc:7111-7120
+    a.l1 = l1 * lr; a.l2 = l2 * lr; a.l21 = l21 * lr;
+    a.alpha = lr * std::sqrt(1.f - b2p) / (1.f - b1p);
+  } else {             // :5840-5849
+    a.l1 = l1; a.l2 = l2; a.l21 = l21;
+    a.alpha = std::sqrt(1.f - b2p) / (1.f - b1p);
+  }
+  a.l21_norm = a.l21 * std::sqrt((float)vars[0]->dim);
+  return multi_apply_common(num_tables, vars, slots, nullptr, 3, grads, ids, ns, a,
+                            version == 4 ? OPT_ADAM_V4 : OPT_ADAM_V3, stream);
+}
+
+int kv_multi_apply_adagrad(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                           const float* const* grads, const void* const* ids, const int64_t* ns,
+                           int update_slots, kv_stream_t stream) {
+  OptArgs a{};
+  a.lr = lr; a.update_slots = update_slots;
+  return multi_apply_common(num_tables, vars, accums, nullptr, 1, grads, ids, ns, a, OPT_ADAGRAD, stream);
+}
+
+int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                     const kv_handle_t* linears, const float* const* grads,
+                                     const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
+                                     float l21, float l2s, float lr_power, kv_stream_t stream) {
+  if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
+  if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
+  if (!(l2 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 regularization strength is not a non-negative scalar: %g", l2);
+  if (!(l21 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l21 regularization strength is not a non-negative scalar: %g", l21);
+  if (!(lr_power <= 0.f)) return fail(KV_INVALID_ARGUMENT, "lr_power is not a non-positive scalar: %g", lr_power);
+  if (!(l2s >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 shrinkage regularization strength is not a non-negative scalar: %g", l2s);
+  if (num_tables < 1 || !vars || !vars[0] || !linears) return fail(KV_INVALID_ARGUMENT, "N must be >= 1");
+  OptArgs a{};
+  a.lr = lr; a.l1 = l1; a.l2 = l2; a.l21 = l21; a.l2s = l2s; a.lr_power = lr_power;
+  a.l21_norm = l21 * std::sqrt((float)vars[0]->dim);  // training_ops.cc:728
+  return multi_apply_common(num_tables, vars, accums, linears, 1, grads, ids, ns, a, OPT_FTRL, stream);
 }
 
 int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const void* ids, int64_t n,

@@ -483,6 +483,41 @@ def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, ind
                                                   _stream(var_handles[0])))
 
 
+def _multi_prep(var_handles, grads, indices):
+  ids = [_ids(h, i).reshape(-1) for h, i in zip(var_handles, indices)]
+  gr = [_f32(h, g).reshape(-1, h.dim) for h, g in zip(var_handles, grads)]
+  for g, i in zip(gr, ids):
+    if g.shape[0] != i.numel():
+      raise _lib.InvalidArgumentError("grad must be the same size as indices in the first dimension.")
+  n = len(var_handles)
+  return ids, gr, (ctypes.c_int64 * n)(*[i.numel() for i in ids])
+
+
+def kv_multi_sparse_apply_adagrad(var_handles, accum_handles, lr, grads, indices, update_slots=True):
+  """KvVariableSparseApplyAdagrad on many (var, accum) pairs with two kernel launches."""
+  n = len(var_handles)
+  if n < 1 or not (n == len(accum_handles) == len(grads) == len(indices)):
+    raise _lib.InvalidArgumentError("vars, accums, grads and indices must be equally long, N >= 1")
+  ids, gr, ns = _multi_prep(var_handles, grads, indices)
+  vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
+  _lib.check(_lib.lib().kv_multi_apply_adagrad(n, vp, ap, ctypes.c_float(_scalar(lr)), _ptr_array(gr), _ptr_array(ids), ns,
+                                               int(bool(update_slots)), _stream(var_handles[0])))
+
+
+def kv_multi_sparse_group_sparse_apply_ftrl(var_handles, accum_handles, linear_handles, grads, indices, lr, l1, l2, l21,
+                                            l2_shrinkage, lr_power):
+  """KvVariableSparseGroupSparseApplyFtrlV2 on many (var, accum, linear) triples with two launches."""
+  n = len(var_handles)
+  if n < 1 or not (n == len(accum_handles) == len(linear_handles) == len(grads) == len(indices)):
+    raise _lib.InvalidArgumentError("vars, accums, linears, grads and indices must be equally long, N >= 1")
+  ids, gr, ns = _multi_prep(var_handles, grads, indices)
+  vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
+  lp = (ctypes.c_void_p * n)(*[h.ptr for h in linear_handles])
+  sc = [ctypes.c_float(_scalar(x)) for x in (lr, l1, l2, l21, l2_shrinkage, lr_power)]
+  _lib.check(_lib.lib().kv_multi_apply_sparse_group_ftrl(n, vp, ap, lp, _ptr_array(gr), _ptr_array(ids), ns, *sc,
+                                                         _stream(var_handles[0])))
+
+
 _COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}
 
 

@@ -1,0 +1,67 @@
+"""BASELINE.json configs[4] shape on ONE GPU's share: 256 tables over 8 GPUs = 32 tables per GPU
+(table-wise placement, no collective), dims cycled over {8, 16, 32, 64, 128}, cardinalities
+log-uniform in [1e2, 4e7] (capped so 32 tables fit), half GroupAdam, half SparseGroupFtrl(lr .1,
+accum .1) — SURVEY.md §8(d).  One step = lookup + apply on every table with --batch ids each,
+through the batched ops grouped by (optimizer, dim): 10 groups x 5 launches."""
+import argparse, ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tables", type=int, default=32)
+ap.add_argument("--batch", type=int, default=32768)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--max-keys", type=float, default=4e6, help="cap of the log-uniform cardinalities (4e7 in the config)")
+ap.add_argument("--per-table", action="store_true", help="baseline: one op per table instead of the batched ops")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(20250215)
+gen = torch.Generator(device=dev).manual_seed(5)
+DIMS = [8, 16, 32, 64, 128]
+groups = {}
+total_keys = 0
+for t in range(args.tables):
+  D = DIMS[t % 5]
+  opt = "adam" if (t // 5) % 2 == 0 else "ftrl"
+  K = int(np.exp(rng.uniform(np.log(1e2), np.log(args.max_keys))))
+  total_keys += K
+  var = ops.kv_variable([D], capacity_hint=K + args.batch)
+  ops.init_kv_variable_v2(var, torch.randn(1000, D, device=dev, generator=gen) * 0.05)
+  if opt == "adam":
+    slots = [ops.kv_variable([3 * D], capacity_hint=K + args.batch)]
+    ops.init_kv_variable_v2(slots[0], torch.zeros(4, 3 * D, device=dev))
+  else:
+    slots = [ops.kv_variable([D], capacity_hint=K + args.batch), ops.kv_variable([D], capacity_hint=K + args.batch)]
+    ops.init_kv_variable_v2(slots[0], torch.full((4, D), 0.1, device=dev))
+    ops.init_kv_variable_v2(slots[1], torch.zeros(4, D, device=dev))
+  z = bench.Zipf(K, 1.1, dev)
+  ids = [bench.splitmix64(z.sample(args.batch, gen)) for _ in range(4)]
+  grads = [torch.randn(args.batch, D, device=dev, generator=gen) * 1e-2 for _ in range(2)]
+  groups.setdefault((opt, D), []).append((var, slots, ids, grads))
+
+def step(k):
+  for (opt, D), ms in groups.items():
+    vs = [m[0] for m in ms]; ids = [m[2][k % 4] for m in ms]; gr = [m[3][k % 2] for m in ms]
+    if args.per_table:
+      for m, i, g in zip(ms, ids, gr):
+        ops.kv_variable_gather_or_insert_v2(m[0], i)
+        if opt == "adam":
+          ops.kv_variable_group_sparse_apply_adam_v4(m[0], m[1][0], g, i, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+        else:
+          ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(m[0], m[1][0], m[1][1], g, i, 0.1, 0, 0, 0, 0, -0.5)
+      continue
+    ops.kv_multi_gather_or_insert(vs, ids)
+    if opt == "adam":
+      ops.kv_multi_group_sparse_apply_adam(vs, [m[1][0] for m in ms], gr, ids, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    else:
+      ops.kv_multi_sparse_group_sparse_apply_ftrl(vs, [m[1][0] for m in ms], [m[1][1] for m in ms], gr, ids, 0.1, 0, 0, 0, 0, -0.5)
+
+for k in range(6): step(k)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for k in range(args.steps): step(k)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+print("%s: %d tables (%d groups), %d ids each, key space %.1f M: %.3f ms/step, %.1f M ids/s (lookup + apply)" % (
+    "per-table ops" if args.per_table else "batched ops", args.tables, len(groups), args.batch, total_keys / 1e6, dt * 1e3,
+    args.tables * args.batch / dt / 1e6))
