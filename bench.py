@@ -225,11 +225,12 @@ def main():
 
   if shard_path:
     from tfplus_amd.kv_variable.python.ops import sharded
-    skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
+    skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w, nd=None: ops.kv_bucket_by_owner(var, i, w, nd),
                                     unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                     segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
                                     take_fn=ops.kv_take_rows,
-                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n))
+                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n),
+                                    unique_async_fn=lambda i, c: ops.kv_unique(var, i, c, sync=False))
 
   def step(k):
     ids, grad = pool[k % len(pool)][:2]

@@ -176,9 +176,12 @@ int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int6
  * python/ops/embedding_ops.py:362-372, and what the sharded path runs before the exchange):
  * uniq [n] / uniq_counts [n] (may be NULL; per-occurrence `counts` or 1 each, summed, saturating at
  * 65535 like the frequency they feed) are filled for the first *num_unique entries, inverse [n]
- * (may be NULL) maps input positions to them.  Order unspecified.  Synchronous. */
+ * (may be NULL) maps input positions to them.  Order unspecified.  num_unique (host) makes the
+ * call synchronous; pass NULL and num_unique_dev (device, int64) to leave the count on the device
+ * and keep the stream running (kv_bucket_by_owner takes it as n_dev). */
 int kv_unique(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq,
-              int32_t* uniq_counts, int32_t* inverse, int64_t* num_unique, kv_stream_t stream);
+              int32_t* uniq_counts, int32_t* inverse, int64_t* num_unique, int64_t* num_unique_dev,
+              kv_stream_t stream);
 
 /* ---- table hygiene ------------------------------------------------------
  * KvVariableGetCountV2 (ops/kv_variable_ops.cc:349-358 -> KvVariable::GetCount kv_variable.h:503-524):
@@ -259,10 +262,11 @@ int kv_unsorted_segment_sum(kv_handle_t h, const int32_t* segment_ids, const flo
  * kernels/utility.h:90-107 ModKeyImpl, kept here) ----------------------------------------------
  * Counting sort of `ids` [n] by owner rank floor_mod(id, world): out_ids [n] holds the ids grouped
  * by owner (rank 0's first), perm[j] = input position of out_ids[j], counts_dev[world] (device,
- * int64) = ids per owner — the send counts of the all-to-all.  `h` supplies device, key dtype and
+ * int64) = ids per owner — the send counts of the all-to-all.  n_dev (device, may be NULL): the
+ * real length min(n, *n_dev) when it is still on the device.  `h` supplies device, key dtype and
  * scratch only. */
-int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, int world, int64_t* out_ids,
-                       int32_t* perm, int64_t* counts_dev, kv_stream_t stream);
+int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t* n_dev, int world,
+                       int64_t* out_ids, int32_t* perm, int64_t* counts_dev, kv_stream_t stream);
 
 /* Row permutation for the exchange (no handle: plain device buffers).  scatter == 0:
  * out[i] = src[index[i]]; scatter == 1: out[index[i]] = src[i]; rows of row_bytes (a multiple of

@@ -53,11 +53,12 @@ def _worker(rank, world, port, q):
       def apply(self, g, ids):
         ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
 
-    sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w: ops.kv_bucket_by_owner(var, i, w),
+    sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w, nd=None: ops.kv_bucket_by_owner(var, i, w, nd),
                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
                                    take_fn=ops.kv_take_rows,
-                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n))
+                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n),
+                                    unique_async_fn=lambda i, c: ops.kv_unique(var, i, c, sync=False))
     ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)          # the unsharded truth, same on every rank
     rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
     for step in range(4):

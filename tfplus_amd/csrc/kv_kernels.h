@@ -1353,6 +1353,8 @@ __global__ void __launch_bounds__(TB) k_batch_gather_or_zeros(const BatchGatherD
   }
 }
 
+__global__ void k_store_count(const unsigned* ctr, long long* out) { *out = (long long)*ctr; }
+
 // kv_dedup_segment_sum: inverse[i] = dense unique index of input position i
 __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1374,7 +1376,9 @@ __device__ __forceinline__ unsigned owner_rank(long long id, int world) {
 
 template <typename IdT>
 __global__ void __launch_bounds__(TB) k_owner_hist(const IdT* __restrict__ ids, long long n, int world,
-                                                   unsigned ntiles, unsigned* __restrict__ hist) {
+                                                   unsigned ntiles, unsigned* __restrict__ hist,
+                                                   const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);   // the list's length is still on the device (kv_unique without a sync)
   __shared__ unsigned h[MAXW];
   if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
   __syncthreads();
@@ -1410,7 +1414,9 @@ __global__ void __launch_bounds__(1024) k_owner_scan(unsigned* __restrict__ hist
 template <typename IdT>
 __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ ids, long long n, int world,
                                                       unsigned ntiles, const unsigned* __restrict__ base_off,
-                                                      long long* __restrict__ out_ids, int* __restrict__ perm) {
+                                                      long long* __restrict__ out_ids, int* __restrict__ perm,
+                                                      const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   __shared__ unsigned h[MAXW];
   if ((int)threadIdx.x < world) h[threadIdx.x] = base_off[(size_t)threadIdx.x * ntiles + blockIdx.x];
   __syncthreads();

@@ -1404,12 +1404,15 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
 }
 
 int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, int64_t* uniq, int32_t* uniq_counts,
-              int32_t* inverse, int64_t* num_unique, kv_stream_t stream) {
+              int32_t* inverse, int64_t* num_unique, int64_t* num_unique_dev, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
-  if (!num_unique) return fail(KV_INVALID_ARGUMENT, "num_unique is null");
-  *num_unique = 0;
-  if (n == 0) return KV_OK;
+  if (!num_unique && !num_unique_dev) return fail(KV_INVALID_ARGUMENT, "num_unique and num_unique_dev are both null");
+  if (num_unique) *num_unique = 0;
+  if (n == 0) {
+    if (num_unique_dev) HIP_TRY(hipMemsetAsync(num_unique_dev, 0, sizeof(int64_t), (hipStream_t)stream));
+    return KV_OK;
+  }
   if (n < 0 || !ids || !uniq) return fail(KV_INVALID_ARGUMENT, "bad arguments");
   if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
   DeviceGuard dg(t->device);
@@ -1425,15 +1428,19 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   pa.out_counts = uniq_counts;
   if ((rc = launch_part<MODE_UNIQUE, 0>(wd, pa, s))) return rc;
   if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
-  unsigned U = 0;
-  HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  *num_unique = U;
+  if (num_unique_dev) k_store_count<<<1, 1, 0, s>>>(wd.ctr, (long long*)num_unique_dev);
+  HIP_TRY(hipGetLastError());
+  if (num_unique) {   // synchronous form
+    unsigned U = 0;
+    HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *num_unique = U;
+  }
   return KV_OK;
 }
 
-int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, int world, int64_t* out_ids, int32_t* perm,
-                       int64_t* counts_dev, kv_stream_t stream) {
+int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t* n_dev, int world, int64_t* out_ids,
+                       int32_t* perm, int64_t* counts_dev, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (world < 1 || world > MAXW) return fail(KV_INVALID_ARGUMENT, "world %d: 1..%d ranks", world, MAXW);
@@ -1455,14 +1462,16 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, int world, int
     return KV_OK;
   }
   if (t->key_dtype == KV_DT_INT32) {
-    k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist);
+    k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
-    k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (long long*)out_ids, perm);
+    k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (long long*)out_ids, perm,
+                                               (const long long*)n_dev);
   } else {
-    k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist);
+    k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
+                                                  (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
     k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
-                                                     (long long*)out_ids, perm);
+                                                     (long long*)out_ids, perm, (const long long*)n_dev);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;

@@ -377,16 +377,17 @@ def kv_profile_read(table_handle):
   return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 
-def kv_bucket_by_owner(table_handle, indices, world):
+def kv_bucket_by_owner(table_handle, indices, world, n_dev=None):
   """Counting sort of the ids by owner rank floor_mod(id, world) on the GPU.
-  Returns (ids grouped by owner, perm [n] int32 of input positions, counts [world] int64 on device)."""
+  Returns (ids grouped by owner, perm [n] int32 of input positions, counts [world] int64 on device).
+  n_dev (1-element int64 device tensor): the list's real length when it is still on the device."""
   ids = _ids(table_handle, indices).reshape(-1)
   dev = _dev(table_handle)
   out = torch.empty(ids.numel(), dtype=torch.int64, device=dev)
   perm = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
   counts = torch.empty(int(world), dtype=torch.int64, device=dev)
-  _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), int(world), _p(out), _p(perm),
-                                           ctypes.c_void_p(counts.data_ptr()), _stream(table_handle)))
+  _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), _p(n_dev), int(world), _p(out),
+                                           _p(perm), ctypes.c_void_p(counts.data_ptr()), _stream(table_handle)))
   return out, perm, counts
 
 
@@ -578,8 +579,10 @@ def kv_take_rows(src, index, scatter=False, num_rows=None):
   return out
 
 
-def kv_unique(table_handle, indices, counts=None):
-  """tf.unique_with_counts on the GPU: (unique ids [U], counts [U] int32, inverse [n] int32)."""
+def kv_unique(table_handle, indices, counts=None, sync=True):
+  """tf.unique_with_counts on the GPU: (unique ids [U], counts [U] int32, inverse [n] int32).
+  sync=False leaves U on the device: returns (ids [n] of which the first U are valid, counts [n],
+  inverse [n], U as a 1-element int64 device tensor) without waiting for the stream."""
   ids = _ids(table_handle, indices).reshape(-1)
   n = ids.numel()
   dev = _dev(table_handle)
@@ -587,7 +590,12 @@ def kv_unique(table_handle, indices, counts=None):
   uniq = torch.empty(n, dtype=torch.int64, device=dev)
   ucnt = torch.empty(n, dtype=torch.int32, device=dev)
   inv = torch.empty(n, dtype=torch.int32, device=dev)
+  if not sync:
+    nu_dev = torch.empty(1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().kv_unique(table_handle.ptr, _p(ids), _p(cnt), n, _p(uniq), _p(ucnt), _p(inv), None, _p(nu_dev),
+                                    _stream(table_handle)))
+    return uniq, ucnt, inv, nu_dev
   nu = ctypes.c_int64()
   _lib.check(_lib.lib().kv_unique(table_handle.ptr, _p(ids), _p(cnt), n, _p(uniq), _p(ucnt), _p(inv),
-                                  ctypes.byref(nu), _stream(table_handle)))
+                                  ctypes.byref(nu), None, _stream(table_handle)))
   return uniq[:nu.value], ucnt[:nu.value], inv

@@ -37,16 +37,17 @@ def owner_of(ids, world):
   return torch.remainder(ids, world)
 
 
-def route(ids, group=None, bucket_fn=None, known_counts=None):
-  """Buckets a flat id tensor by owner rank and exchanges the bucket sizes.  `bucket_fn(ids, world)`
-  -> (bucketed ids, perm, counts) is the GPU counting sort (kv_bucket_by_owner); without it the
-  same thing is done with torch ops (CPU tests).  known_counts = (send, recv) python lists skips
-  the size exchange and its host sync: valid when `ids` is a re-ordering of a set routed before
-  (the backward pass of a lookup), since bucket sizes depend only on the set."""
+def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None):
+  """Buckets a flat id tensor by owner rank and exchanges the bucket sizes.  `bucket_fn(ids, world
+  [, n_dev])` -> (bucketed ids, perm, counts) is the GPU counting sort (kv_bucket_by_owner); without
+  it the same thing is done with torch ops (CPU tests).  known_counts = (send, recv) python lists
+  skips the size exchange and its host sync.  n_dev (1-element int64 device tensor): only the first
+  n_dev[0] ids are real and that number is not on the host yet — it comes back with the bucket sizes
+  in the SAME device->host copy, so the lookup has one sync instead of two; returns (routing, n)."""
   world = dist.get_world_size(group)
   bucketed = None
   if bucket_fn is not None:
-    bucketed, perm, send = bucket_fn(ids, world)
+    bucketed, perm, send = bucket_fn(ids, world) if n_dev is None else bucket_fn(ids, world, n_dev)
   else:
     own = owner_of(ids, world)
     perm = torch.argsort(own, stable=True)
@@ -57,6 +58,12 @@ def route(ids, group=None, bucket_fn=None, known_counts=None):
     return rt
   recv = torch.empty_like(send)
   dist.all_to_all_single(recv, send, group=group)
+  if n_dev is not None:
+    host = torch.cat([send, recv, n_dev.reshape(1)]).tolist()    # the one device -> host sync of a lookup
+    n = int(host[-1])
+    rt = Routing(perm[:n], [int(x) for x in host[:world]], [int(x) for x in host[world:2 * world]])
+    rt.bucketed_ids = None if bucketed is None else bucketed[:n]
+    return rt, n
   both = torch.stack([send, recv]).tolist()      # one device -> host sync for both count vectors
   rt = Routing(perm, [int(x) for x in both[0]], [int(x) for x in both[1]])
   rt.bucketed_ids = bucketed
@@ -114,11 +121,14 @@ class ShardedKvVariable(object):
   kv_bucket_by_owner / kv_take_rows).  Without them torch ops do the same (CPU tests)."""
 
   def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None, take_fn=None,
-               index_sum_fn=None):
+               index_sum_fn=None, unique_async_fn=None):
     self.shard = shard          # the rank-local table (KvVariable, or any stand-in with the same calls)
     self.group = group
     self.bucket_fn, self.unique_fn, self.segsum_fn = bucket_fn, unique_fn, segsum_fn
     self.take_fn, self.index_sum_fn = take_fn, index_sum_fn
+    # unique_async_fn(ids, counts) -> (uniq [n], counts [n], inverse, U on the device): no host sync
+    # (gen_kv_variable_ops.kv_unique(sync=False)); bucket_fn must then accept (ids, world, n_dev)
+    self.unique_async_fn = unique_async_fn
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
     self._last = None           # what the last lookup left behind for its backward pass
@@ -147,9 +157,14 @@ class ShardedKvVariable(object):
   def lookup(self, ids, counts=None):
     """embedding_lookup over the sharded table; returns rows in the order of `ids`."""
     flat = ids.reshape(-1)
-    uniq, ucnt, inv = self._unique(flat, counts)
-    U = int(uniq.numel())
-    rt = route(uniq, self.group, self.bucket_fn)
+    if self.unique_async_fn is not None and self.bucket_fn is not None and flat.numel() > 0:
+      uniq, ucnt, inv, nu_dev = self.unique_async_fn(flat, counts)
+      rt, U = route(uniq, self.group, self.bucket_fn, n_dev=nu_dev)
+      uniq, ucnt = uniq[:U], ucnt[:U]
+    else:
+      uniq, ucnt, inv = self._unique(flat, counts)
+      U = int(uniq.numel())
+      rt = route(uniq, self.group, self.bucket_fn)
     bids = rt.bucketed_ids if rt.bucketed_ids is not None else _take(uniq, rt.perm, self.take_fn)
     bcnt = _take(ucnt, rt.perm, self.take_fn)
     # one payload for ids and their occurrence counts
