@@ -263,10 +263,13 @@ int kv_unsorted_segment_sum(kv_handle_t h, const int32_t* segment_ids, const flo
  * Counting sort of `ids` [n] by owner rank floor_mod(id, world): out_ids [n] holds the ids grouped
  * by owner (rank 0's first), perm[j] = input position of out_ids[j], counts_dev[world] (device,
  * int64) = ids per owner — the send counts of the all-to-all.  n_dev (device, may be NULL): the
- * real length min(n, *n_dev) when it is still on the device.  `h` supplies device, key dtype and
- * scratch only. */
+ * real length min(n, *n_dev) when it is still on the device.  Optional extras (NULL to skip):
+ * pairs_out [n][2] int64 = (id, id_counts[i] or 1) in bucket order — the lookup's exchange payload;
+ * pos_out [n] int32 = position of input i in the bucket order (inverse of perm).  `h` supplies
+ * device, key dtype and scratch only. */
 int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t* n_dev, int world,
-                       int64_t* out_ids, int32_t* perm, int64_t* counts_dev, kv_stream_t stream);
+                       int64_t* out_ids, int32_t* perm, int64_t* counts_dev, const int32_t* id_counts,
+                       int64_t* pairs_out, int32_t* pos_out, kv_stream_t stream);
 
 /* Row permutation for the exchange (no handle: plain device buffers).  scatter == 0:
  * out[i] = src[index[i]]; scatter == 1: out[index[i]] = src[i]; rows of row_bytes (a multiple of

@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
       def apply(self, g, ids):
         ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
 
-    sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w, nd=None: ops.kv_bucket_by_owner(var, i, w, nd),
+    sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None),
                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
                                    take_fn=ops.kv_take_rows,

@@ -57,7 +57,7 @@ SIGNATURES = {
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kv_unique": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _vp]),
-    "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kv_get_count": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_get_timestamp": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_delete": (_i32, [_vp, _vp, _i64, _c.POINTER(_i64), _vp]),

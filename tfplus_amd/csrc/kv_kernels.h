@@ -1415,7 +1415,9 @@ template <typename IdT>
 __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ ids, long long n, int world,
                                                       unsigned ntiles, const unsigned* __restrict__ base_off,
                                                       long long* __restrict__ out_ids, int* __restrict__ perm,
-                                                      const long long* __restrict__ n_dev) {
+                                                      const long long* __restrict__ n_dev,
+                                                      const int* __restrict__ counts_in,
+                                                      long long* __restrict__ pairs_out, int* __restrict__ pos_out) {
   if (n_dev) n = min(n, *n_dev);
   __shared__ unsigned h[MAXW];
   if ((int)threadIdx.x < world) h[threadIdx.x] = base_off[(size_t)threadIdx.x * ntiles + blockIdx.x];
@@ -1429,6 +1431,10 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
       const unsigned pos = atomicAdd(&h[owner_rank(id, world)], 1u);
       out_ids[pos] = id;
       perm[pos] = (int)i;
+      // optional extras of the sharded lookup: the exchange payload (id, occurrence count) in
+      // bucket order, and where input position i went (the inverse of perm)
+      if (pairs_out) { pairs_out[2 * (size_t)pos] = id; pairs_out[2 * (size_t)pos + 1] = counts_in ? (long long)counts_in[i] : 1ll; }
+      if (pos_out) pos_out[i] = (int)pos;
     }
   }
 }

@@ -1440,7 +1440,8 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
 }
 
 int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t* n_dev, int world, int64_t* out_ids,
-                       int32_t* perm, int64_t* counts_dev, kv_stream_t stream) {
+                       int32_t* perm, int64_t* counts_dev, const int32_t* id_counts, int64_t* pairs_out,
+                       int32_t* pos_out, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (world < 1 || world > MAXW) return fail(KV_INVALID_ARGUMENT, "world %d: 1..%d ranks", world, MAXW);
@@ -1465,13 +1466,14 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t*
     k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
     k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (long long*)out_ids, perm,
-                                               (const long long*)n_dev);
+                                               (const long long*)n_dev, id_counts, (long long*)pairs_out, pos_out);
   } else {
     k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
                                                   (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
     k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
-                                                     (long long*)out_ids, perm, (const long long*)n_dev);
+                                                     (long long*)out_ids, perm, (const long long*)n_dev, id_counts,
+                                                     (long long*)pairs_out, pos_out);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;

@@ -377,18 +377,26 @@ def kv_profile_read(table_handle):
   return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 
-def kv_bucket_by_owner(table_handle, indices, world, n_dev=None):
+def kv_bucket_by_owner(table_handle, indices, world, n_dev=None, id_counts=None, with_payload=False):
   """Counting sort of the ids by owner rank floor_mod(id, world) on the GPU.
   Returns (ids grouped by owner, perm [n] int32 of input positions, counts [world] int64 on device).
-  n_dev (1-element int64 device tensor): the list's real length when it is still on the device."""
+  n_dev (1-element int64 device tensor): the list's real length when it is still on the device.
+  with_payload: two more results — pairs [n, 2] int64 = (id, id_counts[i] or 1) in bucket order and
+  pos [n] int32 = where input i went (the inverse of perm)."""
   ids = _ids(table_handle, indices).reshape(-1)
   dev = _dev(table_handle)
   out = torch.empty(ids.numel(), dtype=torch.int64, device=dev)
   perm = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
   counts = torch.empty(int(world), dtype=torch.int64, device=dev)
+  pairs = pos = cin = None
+  if with_payload:
+    pairs = torch.empty((ids.numel(), 2), dtype=torch.int64, device=dev)
+    pos = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
+    cin = None if id_counts is None else id_counts.to(torch.int32).contiguous()
   _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), _p(n_dev), int(world), _p(out),
-                                           _p(perm), ctypes.c_void_p(counts.data_ptr()), _stream(table_handle)))
-  return out, perm, counts
+                                           _p(perm), ctypes.c_void_p(counts.data_ptr()), _p(cin), _p(pairs), _p(pos),
+                                           _stream(table_handle)))
+  return (out, perm, counts, pairs, pos) if with_payload else (out, perm, counts)
 
 
 def kv_variable_get_count_v2(table_handle, indices):

@@ -23,11 +23,12 @@ import torch.distributed as dist
 
 class Routing(object):
   """Where each local id goes and how to undo it."""
-  __slots__ = ("perm", "send_counts", "recv_counts", "n_local", "n_recv", "bucketed_ids")
+  __slots__ = ("perm", "send_counts", "recv_counts", "n_local", "n_recv", "bucketed_ids", "pairs", "pos")
 
   def __init__(self, perm, send_counts, recv_counts):
     self.perm, self.send_counts, self.recv_counts = perm, send_counts, recv_counts
     self.bucketed_ids = None
+    self.pairs = self.pos = None     # optional extras of the GPU bucket kernel (see route)
     self.n_local = int(perm.numel())
     self.n_recv = int(sum(recv_counts))
 
@@ -37,7 +38,7 @@ def owner_of(ids, world):
   return torch.remainder(ids, world)
 
 
-def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None):
+def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None, id_counts=None):
   """Buckets a flat id tensor by owner rank and exchanges the bucket sizes.  `bucket_fn(ids, world
   [, n_dev])` -> (bucketed ids, perm, counts) is the GPU counting sort (kv_bucket_by_owner); without
   it the same thing is done with torch ops (CPU tests).  known_counts = (send, recv) python lists
@@ -45,9 +46,12 @@ def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None):
   n_dev[0] ids are real and that number is not on the host yet — it comes back with the bucket sizes
   in the SAME device->host copy, so the lookup has one sync instead of two; returns (routing, n)."""
   world = dist.get_world_size(group)
-  bucketed = None
+  bucketed = pairs = pos = None
   if bucket_fn is not None:
-    bucketed, perm, send = bucket_fn(ids, world) if n_dev is None else bucket_fn(ids, world, n_dev)
+    res = bucket_fn(ids, world) if n_dev is None else bucket_fn(ids, world, n_dev, id_counts)
+    bucketed, perm, send = res[:3]
+    if len(res) == 5:                 # (id, count) pairs in bucket order + inverse of perm, from the same kernel
+      pairs, pos = res[3], res[4]
   else:
     own = owner_of(ids, world)
     perm = torch.argsort(own, stable=True)
@@ -63,6 +67,8 @@ def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None):
     n = int(host[-1])
     rt = Routing(perm[:n], [int(x) for x in host[:world]], [int(x) for x in host[world:2 * world]])
     rt.bucketed_ids = None if bucketed is None else bucketed[:n]
+    rt.pairs = None if pairs is None else pairs[:n]
+    rt.pos = pos
     return rt, n
   both = torch.stack([send, recv]).tolist()      # one device -> host sync for both count vectors
   rt = Routing(perm, [int(x) for x in both[0]], [int(x) for x in both[1]])
@@ -159,21 +165,25 @@ class ShardedKvVariable(object):
     flat = ids.reshape(-1)
     if self.unique_async_fn is not None and self.bucket_fn is not None and flat.numel() > 0:
       uniq, ucnt, inv, nu_dev = self.unique_async_fn(flat, counts)
-      rt, U = route(uniq, self.group, self.bucket_fn, n_dev=nu_dev)
+      rt, U = route(uniq, self.group, self.bucket_fn, n_dev=nu_dev, id_counts=ucnt)
       uniq, ucnt = uniq[:U], ucnt[:U]
     else:
       uniq, ucnt, inv = self._unique(flat, counts)
       U = int(uniq.numel())
       rt = route(uniq, self.group, self.bucket_fn)
-    bids = rt.bucketed_ids if rt.bucketed_ids is not None else _take(uniq, rt.perm, self.take_fn)
-    bcnt = _take(ucnt, rt.perm, self.take_fn)
     # one payload for ids and their occurrence counts
-    got = exchange(rt, None, group=self.group, presorted=torch.stack([bids.to(torch.int64), bcnt.to(torch.int64)], 1))
+    if rt.pairs is not None:
+      payload = rt.pairs
+    else:
+      bids = rt.bucketed_ids if rt.bucketed_ids is not None else _take(uniq, rt.perm, self.take_fn)
+      payload = torch.stack([bids.to(torch.int64), _take(ucnt, rt.perm, self.take_fn).to(torch.int64)], 1)
+    got = exchange(rt, None, group=self.group, presorted=payload)
     served = got[:, 0].contiguous().to(uniq.dtype)
     rows = self.shard.sparse_read_with_counts(served, got[:, 1].to(torch.int32))
     back = exchange(rt, rows, reverse=True, group=self.group, unpermute=False)       # in exchange order
     # where each input id sits in the exchange order: pos[perm[j]] = j, then through the inverse
-    pos = _take(torch.arange(U, dtype=torch.int32, device=flat.device), rt.perm, self.take_fn, scatter=True)
+    pos = rt.pos if rt.pos is not None else \
+        _take(torch.arange(U, dtype=torch.int32, device=flat.device), rt.perm, self.take_fn, scatter=True)
     where = _take(pos, inv, self.take_fn)
     self._last = (ids, ids._version, rt, where, U, served)
     out = _take(back, where, self.take_fn)

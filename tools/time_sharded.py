@@ -31,7 +31,7 @@ t, g = T(lambda: sharded.exchange(rt, summed[:uniq.numel()])); print("exchange g
 slot = ops.kv_variable([3 * D], capacity_hint=K + 4 * N); ops.init_kv_variable_v2(slot, torch.zeros(4, 3 * D, device=dev))
 t, _ = T(lambda: ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, served, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0., 0., 0.)); print("owner apply            %.3f ms" % t)
 skv = sharded.ShardedKvVariable(type("S", (), {"sparse_read_with_counts": lambda self, i, c: ops.kv_variable_gather_or_insert_with_counts(var, i, c)})(),
-                                bucket_fn=lambda i, w, nd=None: ops.kv_bucket_by_owner(var, i, w, nd), unique_fn=lambda i, c: ops.kv_unique(var, i, c),
+                                bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None), unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                 segsum_fn=lambda i, gg: ops.kv_dedup_segment_sum(var, i, gg), take_fn=ops.kv_take_rows,
                                     index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n),
                                     unique_async_fn=lambda i, c: ops.kv_unique(var, i, c, sync=False))
