@@ -167,3 +167,32 @@ def test_batch_gather_or_zeros(ops):
     assert [tuple(g.shape) for g in got] == [tuple(w.shape) for w in want]
     assert all(torch.equal(g, w) for g, w in zip(got, want))
   assert ops.kv_variable_frequency(hs[0]) == 80           # inference lookups count nothing
+
+
+@pytest.mark.gpu
+def test_create_use_destroy_releases_device_memory(ops):
+  """Every buffer a table owns (index, slab chunks, workspace, free list, scratch) goes away with it."""
+  import gc
+  rng = np.random.default_rng(0)
+
+  def cycle():
+    h = ops.kv_variable([32], capacity_hint=200_000)
+    s = ops.kv_variable([96], capacity_hint=200_000)
+    ops.init_kv_variable_v2(h, rng.standard_normal((16, 32)).astype(np.float32))
+    ops.init_kv_variable_v2(s, np.zeros((4, 96), np.float32))
+    ids = rng.integers(0, 300_000, 100_000)
+    ops.kv_variable_gather_or_insert_v2(h, ids)
+    ops.kv_variable_group_sparse_apply_adam_v4(h, s, rng.standard_normal((ids.size, 32)).astype(np.float32), ids, 1e-3, 0.9,
+                                               0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    ops.kv_variable_scatter_add_v2(h, ids[:1000], np.ones((1000, 32), np.float32))
+    ops.kv_variable_delete(h, ids[:5000])
+    ops.kv_variable_lookup_sparse(h, ids[:4000], np.repeat(np.arange(1000), 4), None, 1000, "mean")
+    del h, s
+  cycle()
+  gc.collect(); torch.cuda.synchronize()
+  free0 = torch.cuda.mem_get_info()[0]
+  for _ in range(20):
+    cycle()
+  gc.collect(); torch.cuda.synchronize()
+  free1 = torch.cuda.mem_get_info()[0]
+  assert free0 - free1 < 64 << 20, (free0, free1)          # one cycle holds ~250 MB
