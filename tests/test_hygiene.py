@@ -196,3 +196,49 @@ def test_create_use_destroy_releases_device_memory(ops):
   gc.collect(); torch.cuda.synchronize()
   free1 = torch.cuda.mem_get_info()[0]
   assert free0 - free1 < 64 << 20, (free0, free1)          # one cycle holds ~250 MB
+
+
+@pytest.mark.gpu
+def test_concurrent_host_threads_on_separate_tables_and_streams(ops):
+  """OpKernel::Compute may run on several inter-op threads at once (SURVEY §8b): tables are
+  independent, the library takes a per-table lock, errors are thread-local."""
+  import threading
+  rng = np.random.default_rng(3)
+  T, D, STEPS = 4, 16, 25
+  data = [[(rng.integers(-200, 200, 3000), (rng.uniform(0.5, 1.5, (3000, D)) * 1e-2).astype(np.float32))
+           for _ in range(STEPS)] for _ in range(T)]
+
+  def make(j):
+    v, s = ops.kv_variable([D]), ops.kv_variable([3 * D])
+    ops.kv_set_seed(v, j); ops.kv_set_clock_days(v, DAY); ops.kv_set_clock_days(s, DAY)
+    ops.init_kv_variable_v2(v, np.random.default_rng(j).standard_normal((32, D)).astype(np.float32))
+    ops.init_kv_variable_v2(s, np.zeros((4, 3 * D), np.float32))
+    return v, s
+
+  def run(j, tabs, stream, errs):
+    try:
+      with torch.cuda.stream(stream):
+        v, s = tabs
+        for ids, g in data[j]:
+          ops.kv_variable_gather_or_insert_v2(v, ids)
+          ops.kv_variable_group_sparse_apply_adam_v4(v, s, g, ids, 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+        stream.synchronize()
+    except Exception as e:  # pragma: no cover
+      errs.append(repr(e))
+  par = [make(j) for j in range(T)]
+  seq = [make(j) for j in range(T)]
+  errs = []
+  th = [threading.Thread(target=run, args=(j, par[j], torch.cuda.Stream(), errs)) for j in range(T)]
+  for t in th:
+    t.start()
+  for t in th:
+    t.join()
+  assert not errs, errs
+  for j in range(T):
+    run(j, seq[j], torch.cuda.current_stream(), errs)
+  assert not errs, errs
+  for (pv, _), (sv, _) in zip(par, seq):
+    kp, vp = ops.read_kv_variable_op_v2(pv); ks, vs = ops.read_kv_variable_op_v2(sv)
+    op_, os_ = torch.argsort(kp), torch.argsort(ks)
+    assert torch.equal(kp[op_], ks[os_]) and ops.kv_variable_frequency(pv) == ops.kv_variable_frequency(sv)
+    torch.testing.assert_close(vp[op_], vs[os_], rtol=2e-4, atol=2e-6)   # fp32 sums of repeated ids reorder run to run
