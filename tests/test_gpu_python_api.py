@@ -260,3 +260,35 @@ def test_kv_variable_whole_table_methods(api):
   assert w.get_name_info() == ("wt_dst", ":0", 3) and w.get_generic_name() == "wt_dst"
   with pytest.raises(NotImplementedError):
     v.increase_counting([1], [1])
+
+
+@pytest.mark.gpu
+def test_save_and_load_roundtrip(api, tmp_path):
+  a = api
+  src = a.vs.get_kv_variable("ck_src", embedding_dim=8, initializer=a.vs.random_normal_initializer(seed=2), enter_threshold=2)
+  slot = a.vs.get_kv_variable("ck_slot", embedding_dim=24, initializer=a.vs.zeros_initializer())
+  ids = torch.randint(-50, 50, (600,))
+  src.sparse_read(ids)
+  a.tr.GroupAdamOptimizer(0.05, l1_regularization_strength=1e-4, l21_regularization_strength=4e-3).apply_gradients(
+      [(a.kv.IndexedSlices(torch.randn(600, 8) * 0.02, ids, None), src)])     # some rows end up blacklisted
+  path = str(tmp_path / "table")
+  src.save(path)
+  dst = a.vs.get_kv_variable("ck_dst", embedding_dim=8, initializer=a.vs.zeros_initializer(), enter_threshold=2)
+  dst.load(path)
+  es, ed = src.export(6), dst.export(6)
+  # keys below enter_threshold are not part of a checkpoint (dynamic_save.hpp:77-84): compare the
+  # saved keys and the blacklisted ones (which read zeros on both sides)
+  q = torch.cat([es[0], es[2]])
+  a.kv.set_training(False)
+  try:
+    assert torch.equal(dst.sparse_read(q).cpu(), src.sparse_read(q).cpu())     # inference reads: no side effects
+  finally:
+    a.kv.set_training(True)
+  assert len(es[0]) > 0
+  # frequency words are restored only for keys that came back (dynamic_restore.hpp:232-246), so the
+  # freq lists differ by the low-frequency keys; keys / values / blacklist must be identical
+  assert set(ed[3].tolist()) <= set(es[3].tolist())
+  for x, y in zip(es[:3], ed[:3]):
+    assert x.shape == y.shape
+    if x.numel():
+      assert torch.equal(torch.sort(x.reshape(x.shape[0], -1), 0).values, torch.sort(y.reshape(y.shape[0], -1), 0).values)

@@ -194,6 +194,27 @@ class KvVariable(object):
     return gen_kv_variable_ops.kv_variable_lookup_sparse(self._handle, ids, seg, w, num_segments, combiner,
                                                          count_occurrences)
 
+  # -- checkpoint payload -----------------------------------------------------------------------------
+  def save(self, path, first_n=6):
+    """Writes what KvVariableExport hands the saver (kv_variable_ops.py:1599-1648: keys, values,
+    init_table, blacklist, freq_keys, freq_values) to one .npz; the TF bundle format, sharded saves
+    and delta exports are outside this build."""
+    k, v, bl, fk, fv = gen_kv_variable_ops.kv_variable_export(self._handle, first_n=first_n)
+    np.savez(path, keys=k.cpu().numpy(), values=v.cpu().numpy(), init_table=self._initial_value.cpu().numpy(),
+             blacklist=bl.cpu().numpy(), freq_keys=fk.cpu().numpy(), freq_values=fv.cpu().numpy().view(np.uint32),
+             embedding_dim=np.int64(self._embedding_dim), enter_threshold=np.int64(self._enter_threshold))
+
+  def load(self, path):
+    """KvVariableImport of a file written by save(): the table is cleared and refilled."""
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+    if int(z["embedding_dim"]) != self._embedding_dim:
+      raise ValueError("checkpoint has dim %d, variable has %d" % (int(z["embedding_dim"]), self._embedding_dim))
+    self._initial_value = torch.from_numpy(z["init_table"])
+    gen_kv_variable_ops.kv_variable_import(self._handle, z["keys"], z["values"], z["blacklist"], z["freq_keys"],
+                                           z["freq_values"])
+    gen_kv_variable_ops.init_kv_variable_v2(self._handle, self._initial_value)
+    return self
+
   # -- whole-table reads / assignment (kv_variable_ops.py:1011-1030, 1220-1246) -----------------------
   def value(self):
     """ReadKvVariableOpV2's values output: the rows of every exported key, [keys, dim]."""
