@@ -735,7 +735,14 @@ constexpr int TBS = 256;
 constexpr int HSS = 1024;
 constexpr int UCAPS = HSS * 3 / 4;
 constexpr int ECAPS = 1600;
-constexpr int HMAXS = 16;                  // heavy keys per round folded by the whole block (the rest
+// heavy keys per round folded by the whole block: their LDS sum rows are capped at 2 KB so that
+// four blocks still fit a CU's 160 KB at every dim (D = 64 with 16 rows: 41.5 KB per block -> 3 per CU,
+// a quarter of the 1024 blocks then starts late)
+__host__ __device__ inline int heavy_rows(int D) {
+  int r = 2048 / (4 * D);
+  return r < 1 ? 1 : (r > 16 ? 16 : r);
+}
+constexpr int HMAXS = 16;                  // upper bound of heavy_rows() (the rest
                                            // are summed by single groups)
 constexpr unsigned LOC_LDS = 0xFFFFFFE0u;  // gradient locator: row of the block's LDS hsum
 
@@ -746,7 +753,7 @@ __host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, 
   b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
   b += (size_t)UCAPS * 4 * 2 + 32 + (size_t)UCAPS + 16;                // utag, ur0, unew
   if (opt == OPT_FTRL) b += (size_t)UCAPS * 4 + 16;                    // ur1
-  b += (size_t)HMAXS * D * 4 + 16;                                     // hsum
+  b += (size_t)heavy_rows(D) * D * 4 + 16;                             // hsum
   if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16;                 // eloc
   return b;
 }
@@ -831,7 +838,8 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
   unsigned* ur0 = reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4));
   unsigned* ur1 = (OPT == OPT_FTRL) ? reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4)) : ur0;
   unsigned char* unew = reinterpret_cast<unsigned char*>(take((size_t)UCAPS));
-  float* hsum = reinterpret_cast<float*>(take((size_t)HMAXS * D * 4));  // sums of the heavy keys
+  const unsigned hmax = (unsigned)heavy_rows(D);
+  float* hsum = reinterpret_cast<float*>(take((size_t)hmax * D * 4));  // sums of the heavy keys
   unsigned* eloc = (MODE == MODE_DEDUP) ? reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4)) : nullptr;
   __shared__ unsigned lnu, lsent, lbase, lovf;
 
@@ -883,7 +891,7 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
       continue;
     }
     for (int s = tid; s <= HSS; s += TBS) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
-    for (unsigned x = tid; x < (unsigned)HMAXS * (unsigned)D; x += TBS) hsum[x] = 0.f;
+    for (unsigned x = tid; x < hmax * (unsigned)D; x += TBS) hsum[x] = 0.f;
     if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
     __syncthreads();
     // every thread takes entries x = tid, tid + TBS, ...: balanced whatever the number of tiles;
@@ -1025,12 +1033,12 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
         const unsigned h = ulist[u];
         if ((hval[h] >> 16) > (unsigned)HEAVY) {
           const unsigned j = atomicAdd(&lnh, 1u);
-          if (j < (unsigned)HMAXS) hk[j] = (unsigned short)h;
+          if (j < hmax) hk[j] = (unsigned short)h;
         }
       }
       __syncthreads();
       if (tid == 0) {
-        const unsigned n = min(lnh, (unsigned)HMAXS);
+        const unsigned n = min(lnh, hmax);
         unsigned run = 0;
         for (unsigned j = 0; j < n; ++j) { hpre[j] = run; run += hval[hk[j]] >> 16; }
         hpre[n] = run;
