@@ -733,7 +733,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
 // is finished after a barrier.  Work is balanced by contributions, not by keys.
 constexpr int TBS = 256;
 constexpr int HSS = 1024;
-constexpr int UCAPS = HSS * 3 / 4;
+constexpr int UCAPS = HSS / 2;   // 512 keys per round: keeps FTRL (one more row-id list) and 2M-id batches (4 KB directory) at 4 blocks per CU
 constexpr int ECAPS = 1600;
 // heavy keys per round folded by the whole block: their LDS sum rows are capped at 2 KB so that
 // four blocks still fit a CU's 160 KB at every dim (D = 64 with 16 rows: 41.5 KB per block -> 3 per CU,
@@ -754,7 +754,6 @@ __host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, 
   b += (size_t)UCAPS * 4 * 2 + 32 + (size_t)UCAPS + 16;                // utag, ur0, unew
   if (opt == OPT_FTRL) b += (size_t)UCAPS * 4 + 16;                    // ur1
   b += (size_t)heavy_rows(D) * D * 4 + 16;                             // hsum
-  if (mode == MODE_DEDUP) b += (size_t)ECAPS * 4 + 16;                 // eloc
   return b;
 }
 
@@ -840,7 +839,6 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
   unsigned char* unew = reinterpret_cast<unsigned char*>(take((size_t)UCAPS));
   const unsigned hmax = (unsigned)heavy_rows(D);
   float* hsum = reinterpret_cast<float*>(take((size_t)hmax * D * 4));  // sums of the heavy keys
-  unsigned* eloc = (MODE == MODE_DEDUP) ? reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4)) : nullptr;
   __shared__ unsigned lnu, lsent, lbase, lovf;
 
   const int tid = threadIdx.x;
@@ -922,7 +920,6 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
           if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
         }
         eb[pos] = lb[k];
-        if (MODE == MODE_DEDUP) eloc[pos] = ge[k];
         eslot[pos] = (unsigned short)h;
         perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
       }
@@ -1188,7 +1185,15 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
     }
     if (MODE == MODE_DEDUP) {
       __syncthreads();
-      for (unsigned e = tid; e < Er; e += TBS) w.ent_b[eloc[e]] = utag[hu[eslot[e]]];
+      // every entry learns its key's dense index: a second pass over the entries with a read-only
+      // LDS hash lookup (an entry-position list in LDS would cost 6.4 KB and the fourth block per CU)
+      for (unsigned x = tid; x < E; x += TBS) {
+        const size_t ge = seg_entry(tpre, tstart, NT, x);
+        const long long key = w.ent_key[ge];
+        if (!in_round(key, R, round)) continue;
+        bool first;
+        w.ent_b[ge] = utag[hu[lds_key_slot<HSS>(hkey, &lsent, key, false, &first)]];
+      }
     }
     __syncthreads();
     KV_STAMPP(4);
