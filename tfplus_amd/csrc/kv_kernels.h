@@ -48,8 +48,16 @@ struct TileSmem {
   // aliases of lkeys, valid after the entries are written:
   unsigned short* perm;    // [TILE]     tile rows grouped by key
   unsigned short* pslot;   // [TILE]     slot (key) of each sorted row
-  float* red;              // [TBT / 8][dim] sums of keys whose rows span two groups' chunks
+  float* red;              // [TBT / fold_lanes][dim] sums of keys whose rows span two groups' chunks
 };
+
+// gradient fold geometry: lanes per row (8 up to dim 64, 16 up to 128, 32 up to 256) so that the
+// LDS rows of chunk-spanning keys, red[TBT / lanes][dim], stay <= 16 KB and always fit in the dead
+// lkeys region: every dim keeps two 512-thread tile blocks per CU (dim 128 with 8 lanes: 81 KB -> one)
+__host__ __device__ inline int fold_lanes(int D) { return D <= 64 ? 8 : (D <= 128 ? 16 : 32); }
+__host__ __device__ inline size_t fold_red_bytes(int D) {
+  return ((D & 3) == 0 && D <= 256) ? (size_t)(TBT / fold_lanes(D)) * D * 4 : 0;   // scalar path: no LDS rows
+}
 
 // lpart may reuse lwork + hist once those are dead, if they are big enough
 constexpr bool LPART_ALIAS = ((TILE + 1) * 2 + 15) / 16 * 16 + (MAX_P + 1) * 4 >= (LS + 1) * 2;
@@ -64,7 +72,7 @@ __host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
   if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 2 + 16;  // lfirst
   if (mode == MODE_APPLY || mode == MODE_DEDUP) {
     if (!LPART_ALIAS) b += (size_t)(LS + 1) * 2 + 16;  // lpart
-    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + (size_t)(TBT / 8) * D * 4 + 64;
+    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + fold_red_bytes(D) + 64;
     const size_t lk = (size_t)(LS + 1) * 8 + 16;
     if (alias > lk) b += alias - lk;           // big dims: the fold scratch outgrows lkeys
   }
@@ -78,7 +86,7 @@ __device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
   char* lk = take((size_t)(LS + 1) * 8);
   s.lkeys = reinterpret_cast<long long*>(lk);
   if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + (size_t)(TBT / 8) * D * 4 + 64;
+    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + fold_red_bytes(D) + 64;
     const size_t lkb = ((size_t)(LS + 1) * 8 + 15) & ~(size_t)15;
     if (alias > lkb) take(alias - lkb);
     s.perm = reinterpret_cast<unsigned short*>(lk);
@@ -279,13 +287,17 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
         sm.pslot[pos] = (unsigned short)tslot[k];
       }
     }
-    constexpr unsigned G = TBT / 8;  // 8-lane groups
-    for (unsigned x = tid; x < G * (unsigned)D; x += TBT) sm.red[x] = 0.f;
+    // VPL (host's row width class: 1, 2, 4, 8 float4 per 8 lanes) -> LPF lanes per row x VPF float4 per lane
+    constexpr int LPF = VPL <= 2 ? 8 : (VPL == 4 ? 16 : 32);
+    constexpr int VPF = VPL <= 2 ? (VPL > 0 ? VPL : 1) : 2;
+    constexpr unsigned G = TBT / LPF;  // row groups
+    if constexpr (VPL > 0)
+      for (unsigned x = tid; x < G * (unsigned)D; x += TBT) sm.red[x] = 0.f;
     __syncthreads();
     KV_STAMP(4);
     const unsigned M = lM;
-    const int lane8 = tid & 7;
-    const unsigned grp = tid >> 3;
+    const int lane8 = tid % LPF;
+    const unsigned grp = tid / LPF;
     float* prow0 = w.part + (size_t)tile * PARTCAP * D;
     const unsigned C = (M + G - 1) / G;  // sorted rows per group
     if constexpr (VPL > 0) {
@@ -294,25 +306,25 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
       // stored once; a key that spans chunks (tile-hot keys) meets in the LDS row of the chunk
       // it starts in — at most one such key per chunk, so red[G][D] always suffices.
       const int NV = D >> 2;
-      constexpr int RB = 16 / VPL;
+      constexpr int RB = 16 / VPF;
       const unsigned c0 = min(M, grp * C), c1 = min(M, (grp + 1) * C);
       unsigned cur = 0xFFFFFFFFu;
-      float4 acc[VPL];
+      float4 acc[VPF];
       auto flush = [&]() {
         if (cur == 0xFFFFFFFFu) return;
         const unsigned st = sm.lfirst[cur], en = st + sm.lcnt[cur];
         if (st >= c0 && en <= c1) {
           float4* dst = reinterpret_cast<float4*>(prow0 + (size_t)sm.lpart[cur] * D);
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int q = lane8 + 8 * v;
+          for (int v = 0; v < VPF; ++v) {
+            const int q = lane8 + LPF * v;
             if (q < NV) dst[q] = acc[v];
           }
         } else {
           float* rd = sm.red + (size_t)(st / C) * D;
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int q = lane8 + 8 * v;
+          for (int v = 0; v < VPF; ++v) {
+            const int q = lane8 + LPF * v;
             if (q < NV) {
               atomicAdd(&rd[4 * q + 0], acc[v].x); atomicAdd(&rd[4 * q + 1], acc[v].y);
               atomicAdd(&rd[4 * q + 2], acc[v].z); atomicAdd(&rd[4 * q + 3], acc[v].w);
@@ -321,20 +333,20 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
         }
       };
       for (unsigned eb = c0; eb < c1; eb += RB) {
-        float4 val[RB][VPL];
+        float4 val[RB][VPF];
         unsigned ks[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const unsigned e = eb + r;
           ks[r] = 0xFFFFFFFFu;
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int v = 0; v < VPF; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (e < c1) {
             ks[r] = sm.pslot[e];
             const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + sm.perm[e]) * D);
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-              const int q = lane8 + 8 * v;
+            for (int v = 0; v < VPF; ++v) {
+              const int q = lane8 + LPF * v;
               if (q < NV) {  // read once: streaming load
                 const float* gp = reinterpret_cast<const float*>(g4 + q);
                 val[r][v] = make_float4(__builtin_nontemporal_load(gp), __builtin_nontemporal_load(gp + 1),
@@ -350,10 +362,10 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
             flush();
             cur = ks[r];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) acc[v] = val[r][v];
+            for (int v = 0; v < VPF; ++v) acc[v] = val[r][v];
           } else {
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) {
+            for (int v = 0; v < VPF; ++v) {
               acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
               acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
             }
