@@ -24,7 +24,7 @@ constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every 
                                  // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
-constexpr int MAX_P = 1024;      // partitions (power of two)
+constexpr int MAX_P = 2048;      // partitions (power of two); 1024 up to 1 M ids, 2048 for 2 M
 constexpr int HEAVY = 16;        // entries of one key in one partition above which the block folds it (16: -2 us vs 32)
 constexpr int MAX_CHUNKS = 1024;
 

@@ -390,11 +390,14 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
   return KV_OK;
 }
 
-// partitions for a batch of n ids: a power of two <= MAX_P.  Large batches get MAX_P (all blocks
-// resident at once, <= ~1000 ids each at 1 M); small batches are cut fine (~32 ids per block) so
-// a 2048-id op still spreads over 64 CUs instead of running 4 long blocks
+// partitions for a batch of n ids: a power of two <= MAX_P.  Up to 1 M ids: min(1024, n / 32) —
+// small batches are cut fine (~32 ids per block) so a 2048-id op still spreads over 64 CUs, large ones
+// get 1024 blocks = one resident wave of blocks.  Above 1 M ids: ~1024 ids per partition (2 M ids ->
+// 2048 blocks in two waves; with 1024 the hot partitions overflow the LDS entry lists and split:
+// measured 331 us vs 2 x 70)
 unsigned pick_partitions(long long n) {
-  unsigned long long want = (unsigned long long)((n + 31) / 32);
+  unsigned long long want = std::min<unsigned long long>(1024, (unsigned long long)((n + 31) / 32));
+  want = std::max<unsigned long long>(want, (unsigned long long)((n + 1023) / 1024));
   unsigned P = 1;
   while (P < want && P < (unsigned)MAX_P) P <<= 1;
   return P;
