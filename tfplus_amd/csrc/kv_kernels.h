@@ -1228,7 +1228,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     // then the wave copies the rows VQ lanes per row, 64 / VQ rows per instruction, CH
     // instructions in flight, the row ids passed between lanes with ds_bpermute.
     constexpr int RW = 64 / VQ;            // rows per copy instruction
-    constexpr int CH = VQ < 8 ? VQ : 8;    // copy instructions in flight
+    constexpr int CH = VQ < 16 ? VQ : 16;  // copy instructions in flight
     const int lane = threadIdx.x & 63;
     const int v = lane % VQ, sub = lane / VQ;
     const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
