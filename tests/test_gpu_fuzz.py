@@ -1,0 +1,113 @@
+"""Randomised differential test: a random program of KvVariable ops runs on the GPU table and on the
+oracle side by side; after every op the observable state must agree (key set, frequency words,
+sizes: exactly; rows and optimizer state: 1e-4 relative — fp32 sums of repeated ids reorder)."""
+import numpy as np
+import pytest
+
+from oracle import kv_oracle as ko
+
+torch = pytest.importorskip("torch")
+DAY0 = 20000
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+class Pair(object):
+  def __init__(self, ops, D, thr, table, seed):
+    self.ops, self.D = ops, D
+    self.h = ops.kv_variable([D], enter_threshold=thr, capacity_hint=64)     # tiny hint: growth + rebuilds happen
+    ops.kv_set_seed(self.h, seed); ops.init_kv_variable_v2(self.h, table)
+    self.o = ko.OracleKv(D, thr, table, day=DAY0, picker=1, seed=seed)
+    self.set_day(DAY0)
+
+  def set_day(self, day):
+    self.ops.kv_set_clock_days(self.h, day); self.o.set_day(day)
+
+  def check(self, rng, keyspace, tag):
+    ops, h, o = self.ops, self.h, self.o
+    assert ops.kv_variable_shape_v2(h)[0] == o.map_size(), tag
+    assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_frequency(h) == o.sum_freq(), tag
+    q = rng.integers(-keyspace - 5, keyspace + 5, 200)
+    np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q),
+                               rtol=1e-4, atol=2e-5, err_msg=tag)   # atol: FTRL's linear slot is a difference of O(10) terms
+    np.testing.assert_array_equal(ops.kv_variable_get_count_v2(h, q).cpu().numpy(), o.get_count(q), err_msg=tag)
+    np.testing.assert_array_equal(ops.kv_variable_get_time_stamp(h, q).cpu().numpy(), o.get_timestamp(q), err_msg=tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_random_program_matches_oracle(ops, seed):
+  rng = np.random.default_rng(1000 + seed)
+  D = int(rng.choice([4, 8, 20, 32, 64]))
+  thr = int(rng.choice([0, 0, 2]))
+  opt = ["adam", "adagrad", "ftrl"][seed % 3]
+  keyspace = int(rng.choice([50, 400, 5000]))
+  table = rng.standard_normal((32, D)).astype(np.float32)
+  var = Pair(ops, D, thr, table, seed)
+  slots = {"adam": [(3 * D, 0.0)], "adagrad": [(D, 0.1)], "ftrl": [(D, 0.1), (D, 0.0)]}[opt]
+  sl = [Pair(ops, d, 0, np.full((4, d), v, np.float32), seed) for d, v in slots]
+  day = DAY0
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  for step in range(40):
+    op = rng.choice(["lookup", "lookup_counts", "apply", "apply", "scatter", "insert", "delete", "expire", "roundtrip"],
+                    p=[.2, .1, .2, .15, .1, .05, .1, .05, .05])
+    n = int(rng.choice([1, 7, 300, 3000]))
+    ids = rng.integers(-keyspace, keyspace, n)
+    tag = "seed %d step %d %s n=%d D=%d" % (seed, step, op, n, D)
+    if op == "lookup":
+      got = ops.kv_variable_gather_or_insert_v2(var.h, ids).cpu().numpy()
+      np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=1e-4, atol=1e-6, err_msg=tag)
+    elif op == "lookup_counts":
+      c = rng.integers(1, 40000, n).astype(np.int32)
+      got = ops.kv_variable_gather_or_insert_with_counts(var.h, ids, c).cpu().numpy()
+      np.testing.assert_allclose(got, var.o.gather_or_insert(ids, c), rtol=1e-4, atol=1e-6, err_msg=tag)
+    elif op == "apply":
+      g = (rng.uniform(0.5, 1.5, (n, D)) * 1e-2 * rng.choice([-1.0, 1.0], (1, D))).astype(np.float32)
+      u, s, _ = ko.dedup_segment_sum(ids, g)
+      if opt == "adam":
+        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, g, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+        ko.apply_group_adam(var.o, sl[0].o, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8)
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+      elif opt == "adagrad":
+        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, g, ids, use_locking=True)
+        ko.apply_adagrad(var.o, sl[0].o, 0.05, s, u)
+      else:
+        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, g, ids, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
+        ko.apply_sparse_group_ftrl(var.o, sl[0].o, sl[1].o, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
+    elif op == "scatter":
+      uids = np.unique(ids)
+      upd = rng.uniform(0.5, 2.0, (uids.size, D)).astype(np.float32)
+      which = int(rng.integers(0, 7))
+      fn = [ops.kv_variable_scatter_update_v2, ops.kv_variable_scatter_add_v2, ops.kv_variable_scatter_sub_v2,
+            ops.kv_variable_scatter_mul_v2, ops.kv_variable_scatter_div_v2, ops.kv_variable_scatter_min_v2,
+            ops.kv_variable_scatter_max_v2][which]
+      fn(var.h, uids, upd); var.o.scatter_update(uids, upd, which)
+    elif op == "insert":
+      uids = np.unique(ids)
+      vals = rng.standard_normal((uids.size, D)).astype(np.float32)
+      ops.kv_variable_insert_v2(var.h, uids, vals); var.o.insert(uids, vals)
+    elif op == "delete":
+      for p in [var] + sl:
+        assert ops.kv_variable_delete(p.h, ids) == p.o.delete(ids), tag
+    elif op == "expire":
+      day += int(rng.integers(1, 5))
+      for p in [var] + sl:
+        p.set_day(day)
+      thr_days = int(rng.integers(2, 8))
+      assert sorted(ops.kv_variable_delete_with_timestamp(var.h, thr_days).cpu().numpy().tolist()) == \
+          sorted(var.o.delete_with_timestamp(thr_days).tolist()), tag
+    else:   # export -> import into the same table (clear + reload)
+      k, v, bl, fk, fv = ops.kv_variable_export(var.h, first_n=6)
+      ok, ov, obl, ofk, ofv = var.o.export(6)
+      assert sorted(k.cpu().numpy().tolist()) == sorted(ok.tolist()) and sorted(bl.cpu().numpy().tolist()) == sorted(obl.tolist()), tag
+      ops.kv_variable_import(var.h, k, v, bl, fk, fv)
+      var.o.import_(ok, ov, obl, ofk, ofv)
+    var.check(rng, keyspace, tag)
+    for i, p in enumerate(sl):
+      p.check(rng, keyspace, tag + " slot%d" % i)
