@@ -139,6 +139,12 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+  # KV_BENCH_ONE_GPU=1 (debugging only, never a measurement): every rank shares cuda:0 and the
+  # collectives are staged through gloo on the host, so the N > 1 control flow of this file can be
+  # exercised on a 1-GPU box (RCCL refuses two ranks on one device)
+  one_gpu_debug = os.environ.get("KV_BENCH_ONE_GPU") == "1" and world > 1
+  if one_gpu_debug:
+    local = 0
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
   shard_path = world > 1 or args.force_sharded
@@ -146,7 +152,29 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if one_gpu_debug:
+      dist.init_process_group("gloo", rank=rank, world_size=world)
+      from tfplus_amd.kv_variable.python.ops import sharded as _sh
+      _real_a2a, _real_allreduce = dist.all_to_all_single, dist.all_reduce
+
+      def _a2a_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        _real_a2a(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        out.copy_(o)
+
+      def _allreduce_host(t, op=dist.ReduceOp.SUM, group=None):
+        c = t.cpu()
+        _real_allreduce(c, op=op, group=group)
+        t.copy_(c)
+
+      class _Dist(object):
+        get_world_size = staticmethod(dist.get_world_size)
+        get_rank = staticmethod(dist.get_rank)
+        all_to_all_single = staticmethod(_a2a_host)
+      _sh.dist = _Dist
+      dist.all_reduce = _allreduce_host
+    else:
+      dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
   from tfplus_amd import _lib
   from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops

@@ -1,0 +1,50 @@
+"""bench.py's contract: the default single-GPU line carries every required key, and the N > 1
+control flow runs (two ranks on one GPU, collectives staged through gloo — a debugging mode of
+bench.py; real runs use RCCL with one rank per GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _line(out):
+  rows = [l for l in out.splitlines() if l.startswith("{")]
+  assert len(rows) == 1, out[-2000:]
+  return json.loads(rows[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--keys", "2000000", "--cpu-keys", "100000",
+                      "--cpu-steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = _line(r.stdout)
+  assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0
+  rf = d["roofline"]
+  assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+  cb = d["cpu_baseline"]
+  assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, KV_BENCH_ONE_GPU="1")
+  r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                      "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                      "--keys", "1000000", "--batch", "200000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+  d = _line(r.stdout)
+  assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 400000 and d["value"] > 0
