@@ -245,6 +245,13 @@ def main():
         _lib.check(L.kv_gather_or_insert(var.ptr, served.data_ptr(), cp, served.numel(), rows.data_ptr(), stream))
       return rows
 
+    def sparse_read_pairs(self, pairs):
+      rows = torch.empty((pairs.shape[0], D), dtype=torch.float32, device=dev)
+      if pairs.shape[0]:
+        p = pairs.contiguous()
+        _lib.check(L.kv_gather_or_insert_pairs(var.ptr, p.data_ptr(), p.shape[0], rows.data_ptr(), stream))
+      return rows
+
     def apply(self, g, served):
       if served.numel():
         _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, g.data_ptr(), served.data_ptr(), served.numel(), 1e-3,

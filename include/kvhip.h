@@ -102,6 +102,12 @@ int kv_get_meta(kv_handle_t h, const int64_t* ids, int64_t n, uint32_t* freq_wor
  * would have to be inserted (the reference dereferences an empty tensor there). */
 int kv_gather_or_insert(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n,
                         float* out, kv_stream_t stream);
+/* kv_gather_or_insert with the ids and their occurrence counts interleaved as int64 pairs
+ * (id, count) [n][2] — the payload kv_bucket_by_owner builds and the all-to-all delivers, used
+ * as is by the owner of a sharded table (counts saturate at 65535 like WithCounts). */
+int kv_gather_or_insert_pairs(kv_handle_t h, const int64_t* id_count_pairs, int64_t n, float* out,
+                              kv_stream_t stream);
+
 /* Replaces KvVariableGatherOrZerosOp::Compute (kernels/kv_variable_ops.cc:348-405) -> FindOrZeros
  * (kernels/kv_variable.h:239-254): no insert, no frequency change, misses read as zeros. */
 int kv_gather_or_zeros(kv_handle_t h, const void* ids, int64_t n, float* out, kv_stream_t stream);
@@ -273,11 +279,12 @@ int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t*
 
 /* Row permutation for the exchange (no handle: plain device buffers).  scatter == 0:
  * out[i] = src[index[i]]; scatter == 1: out[index[i]] = src[i]; rows of row_bytes (a multiple of
- * 4) bytes, index [n] int32.  Replaces the tf.gather / tf.dynamic_stitch the reference's
+ * 4) bytes, index [n] int32; index_outer (may be NULL, gather only): out[i] =
+ * src[index[index_outer[i]]] for i < n = len(index_outer).  Replaces the tf.gather / tf.dynamic_stitch the reference's
  * partitioned lookup uses to undo its `ids % num_shards` split (python/ops/embedding_ops.py:
  * 150-204). */
-int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, int64_t row_bytes,
-                 int scatter, void* out, kv_stream_t stream);
+int kv_take_rows(int device, const void* src, const int32_t* index, const int32_t* index_outer, int64_t n,
+                 int64_t row_bytes, int scatter, void* out, kv_stream_t stream);
 
 /* ---- measurement hooks (no reference counterpart; the reference only VLOGs wall time,
  * kernels/training_ops.cc:6989,7211) -----------------------------------------------------------

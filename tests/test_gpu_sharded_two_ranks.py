@@ -50,6 +50,9 @@ def _worker(rank, world, port, q):
         return ops.kv_variable_gather_or_insert_with_counts(var, ids, counts) if counts is not None \
             else ops.kv_variable_gather_or_insert_v2(var, ids)
 
+      def sparse_read_pairs(self, pairs):
+        return ops.kv_variable_gather_or_insert_pairs(var, pairs)
+
       def apply(self, g, ids):
         ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
 

@@ -69,7 +69,8 @@ SIGNATURES = {
     "kv_multi_apply_sparse_group_ftrl": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 6 + [_vp]),
     "kv_lookup_sparse": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "kv_unsorted_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
-    "kv_take_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "kv_take_rows": (_i32, [_i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "kv_gather_or_insert_pairs": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_profile_enable": (_i32, [_vp, _i32]),
     "kv_profile_select": (_i32, [_vp, _c.c_uint32]),
     "kv_profile_read": (_i32, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i32]),

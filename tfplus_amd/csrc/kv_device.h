@@ -286,6 +286,10 @@ template <typename IdT>
 __device__ __forceinline__ long long load_id(const IdT* ids, size_t i) {
   return (long long)ids[i];
 }
+// (id, occurrence count) pairs as the sharded exchange delivers them (kv_bucket_by_owner pairs_out)
+struct IdCount { long long id, count; };
+template <>
+__device__ __forceinline__ long long load_id<IdCount>(const IdCount* ids, size_t i) { return ids[i].id; }
 
 
 struct OptArgs {

@@ -140,7 +140,10 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     if (i < n) {
       const long long key = load_id(ids, (size_t)i);
       unsigned c = 1;
-      if (MODE == MODE_LOOKUP && counts != nullptr) {
+      if constexpr (std::is_same<IdT, IdCount>::value) {
+        const long long ci = ids[i].count;             // counts travel with the ids
+        c = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      } else if (MODE == MODE_LOOKUP && counts != nullptr) {
         // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
         const int ci = counts[i];
         c = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
@@ -1534,7 +1537,8 @@ __global__ void __launch_bounds__(TB) k_seg_combine(TableDev t, WsDev w, const u
 // un-permute / expand steps of the sharded path.
 template <typename U, int SCATTER>
 __global__ void __launch_bounds__(TB) k_take_rows(const U* __restrict__ src, const int* __restrict__ idx,
-                                                  long long n, unsigned nu, int sh, U* __restrict__ out) {
+                                                  long long n, unsigned nu, int sh, U* __restrict__ out,
+                                                  const int* __restrict__ idx_outer = nullptr) {
   const long long total = n * nu;
   const long long stride = (long long)gridDim.x * TB;
   for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += stride) {
@@ -1542,7 +1546,7 @@ __global__ void __launch_bounds__(TB) k_take_rows(const U* __restrict__ src, con
     unsigned e;
     if (sh >= 0) { i = x >> sh; e = (unsigned)(x & (nu - 1)); }
     else { i = x / nu; e = (unsigned)(x - i * nu); }
-    const long long j = idx[i];
+    const long long j = idx_outer ? idx[idx_outer[i]] : idx[i];   // two-level gather: src[idx[idx_outer[i]]]
     if (SCATTER) out[j * nu + e] = src[x];
     else out[x] = src[j * nu + e];
   }

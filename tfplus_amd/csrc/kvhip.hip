@@ -34,6 +34,7 @@
 #include <ctime>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/kvhip.h"
@@ -506,7 +507,9 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
     else if (vpl == 4) KV_TILE(IDT, (FOLD ? 4 : 0));          \
     else KV_TILE(IDT, (FOLD ? 8 : 0));                        \
   } while (0)
-  if (ids_int32) KV_TILE_V(int);
+  if (ids_int32 == 2) {   // (id, count) pairs: lookups only
+    if constexpr (MODE == MODE_LOOKUP) KV_TILE(IdCount, 0);
+  } else if (ids_int32) KV_TILE_V(int);
   else KV_TILE_V(long long);
 #undef KV_TILE_V
 #undef KV_TILE
@@ -814,8 +817,21 @@ int kv_get_meta(kv_handle_t t, const int64_t* ids, int64_t n, uint32_t* fw, uint
   return KV_OK;
 }
 
+static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
+                                 kv_stream_t stream, int pairs);
+
 int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
                         kv_stream_t stream) {
+  return gather_or_insert_impl(t, ids, counts, n, out, stream, 0);
+}
+int kv_gather_or_insert_pairs(kv_handle_t t, const int64_t* id_count_pairs, int64_t n, float* out,
+                              kv_stream_t stream) {
+  if (t && t->key_dtype == KV_DT_INT32) return fail(KV_INVALID_ARGUMENT, "id/count pairs carry int64 ids");
+  return gather_or_insert_impl(t, id_count_pairs, nullptr, n, out, stream, 1);
+}
+
+static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
+                                 kv_stream_t stream, int pairs) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (n == 0) return KV_OK;  // kv_variable_ops.cc:530-532
@@ -829,7 +845,7 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
   // pass: the frequency adds saturate identically and rows are inserted by the first chunk)
   const long long CH = 1ll << 21;
-  const size_t idsz = t->key_dtype == KV_DT_INT32 ? 4 : 8;
+  const size_t idsz = pairs ? 16 : (t->key_dtype == KV_DT_INT32 ? 4 : 8);
   for (long long off = 0; off < n; off += CH) {
     const long long m = std::min(CH, (long long)n - off);
     const void* idp = (const char*)ids + (size_t)off * idsz;
@@ -844,7 +860,7 @@ int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, i
     pa.day = today(t);
     {
       ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-      launch_tile<MODE_LOOKUP>(t, wd, idp, cp, nullptr, m, s);
+      launch_tile<MODE_LOOKUP>(t, wd, idp, cp, nullptr, m, s, pairs ? 2 : -1);
     }
     {
       ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
@@ -1589,8 +1605,9 @@ int kv_get_timestamp(kv_handle_t t, const void* ids, int64_t n, uint32_t* days, 
   return count_or_ts(t, ids, n, 1, days, stream);
 }
 
-int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, int64_t row_bytes, int scatter,
-                 void* out, kv_stream_t stream) {
+int kv_take_rows(int device, const void* src, const int32_t* index, const int32_t* index_outer, int64_t n,
+                 int64_t row_bytes, int scatter, void* out, kv_stream_t stream) {
+  if (index_outer && scatter) return fail(KV_INVALID_ARGUMENT, "kv_take_rows: the two-level index is gather only");
   if (n < 0 || row_bytes <= 0 || row_bytes % 4 || (n > 0 && (!src || !index || !out)))
     return fail(KV_INVALID_ARGUMENT, "kv_take_rows: n %lld, row_bytes %lld (a positive multiple of 4)",
                 (long long)n, (long long)row_bytes);
@@ -1603,10 +1620,10 @@ int kv_take_rows(int device, const void* src, const int32_t* index, int64_t n, i
   const int grid = nblocks(n * nu, TB * 4, 8192);
   if (wide) {
     if (scatter) k_take_rows<float4, 1><<<grid, TB, 0, s>>>((const float4*)src, index, n, nu, sh, (float4*)out);
-    else k_take_rows<float4, 0><<<grid, TB, 0, s>>>((const float4*)src, index, n, nu, sh, (float4*)out);
+    else k_take_rows<float4, 0><<<grid, TB, 0, s>>>((const float4*)src, index, n, nu, sh, (float4*)out, index_outer);
   } else {
     if (scatter) k_take_rows<float, 1><<<grid, TB, 0, s>>>((const float*)src, index, n, nu, sh, (float*)out);
-    else k_take_rows<float, 0><<<grid, TB, 0, s>>>((const float*)src, index, n, nu, sh, (float*)out);
+    else k_take_rows<float, 0><<<grid, TB, 0, s>>>((const float*)src, index, n, nu, sh, (float*)out, index_outer);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;

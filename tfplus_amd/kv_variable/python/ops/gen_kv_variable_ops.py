@@ -567,12 +567,14 @@ def kv_unsorted_segment_sum(table_handle, data, segment_ids, num_segments):
   return out
 
 
-def kv_take_rows(src, index, scatter=False, num_rows=None):
+def kv_take_rows(src, index, scatter=False, num_rows=None, index_outer=None):
   """out[i] = src[index[i]] (gather, default) or out[index[i]] = src[i] (scatter=True; index must be
-  a permutation onto `num_rows` rows).  Any 4-byte-multiple row type; index int32 on the GPU."""
+  a permutation onto `num_rows` rows).  index_outer: out[i] = src[index[index_outer[i]]] (gather).
+  Any 4-byte-multiple row type; indices int32 on the GPU."""
   src = src.contiguous()
   idx = index.to(torch.int32).contiguous()
-  n = idx.numel()
+  outer = None if index_outer is None else index_outer.to(torch.int32).contiguous()
+  n = idx.numel() if outer is None else outer.numel()
   tail = tuple(src.shape[1:])
   row_bytes = src.element_size()
   for d in tail:
@@ -582,8 +584,18 @@ def kv_take_rows(src, index, scatter=False, num_rows=None):
   rows_out = (src.shape[0] if num_rows is None else int(num_rows)) if scatter else n
   out = torch.empty((rows_out,) + tail, dtype=src.dtype, device=src.device)
   stream = ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
-  _lib.check(_lib.lib().kv_take_rows(src.device.index or 0, _p(src), _p(idx), n, row_bytes, int(bool(scatter)),
+  _lib.check(_lib.lib().kv_take_rows(src.device.index or 0, _p(src), _p(idx), _p(outer), n, row_bytes, int(bool(scatter)),
                                      _p(out), stream))
+  return out
+
+
+def kv_variable_gather_or_insert_pairs(table_handle, id_count_pairs):
+  """KvVariableGatherOrInsertWithCounts fed with int64 (id, count) pairs [n, 2] (the sharded exchange payload)."""
+  p = torch.as_tensor(id_count_pairs, dtype=torch.int64).to(_dev(table_handle)).contiguous()
+  if p.dim() != 2 or p.shape[1] != 2:
+    raise _lib.InvalidArgumentError("id_count_pairs must be [n, 2] int64")
+  out = torch.empty((p.shape[0], table_handle.dim), dtype=torch.float32, device=p.device)
+  _lib.check(_lib.lib().kv_gather_or_insert_pairs(table_handle.ptr, _p(p), p.shape[0], _p(out), _stream(table_handle)))
   return out
 
 

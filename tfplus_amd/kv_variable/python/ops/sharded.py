@@ -178,8 +178,11 @@ class ShardedKvVariable(object):
       bids = rt.bucketed_ids if rt.bucketed_ids is not None else _take(uniq, rt.perm, self.take_fn)
       payload = torch.stack([bids.to(torch.int64), _take(ucnt, rt.perm, self.take_fn).to(torch.int64)], 1)
     got = exchange(rt, None, group=self.group, presorted=payload)
-    served = got[:, 0].contiguous().to(uniq.dtype)
-    rows = self.shard.sparse_read_with_counts(served, got[:, 1].to(torch.int32))
+    served = got[:, 0].contiguous().to(uniq.dtype)       # kept for the backward pass of this batch
+    if hasattr(self.shard, "sparse_read_pairs"):          # the shard takes the (id, count) payload as it arrived
+      rows = self.shard.sparse_read_pairs(got)
+    else:
+      rows = self.shard.sparse_read_with_counts(served, got[:, 1].to(torch.int32))
     back = exchange(rt, rows, reverse=True, group=self.group, unpermute=False)       # in exchange order
     # where each input id sits in the exchange order: pos[perm[j]] = j, then through the inverse
     pos = rt.pos if rt.pos is not None else \
