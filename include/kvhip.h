@@ -173,7 +173,7 @@ int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv
  * 1097-1161) -> ScatterUpdate (kernels/kv_variable.h:616-734): row = row <op> updates[i]; missing
  * keys are inserted with the init rule first; blacklisted rows are left untouched.  Repeated
  * ids: add / sub apply the SUM of their update rows (the reference applies each occurrence in
- * turn; int64 keys, n <= 2^21 — this step is synchronous), the other operations apply one of the
+ * turn; n <= 2^21 — this step is synchronous), the other operations apply one of the
  * occurrences (the reference's result depends on its thread interleaving there). */
 int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
                       kv_stream_t stream);

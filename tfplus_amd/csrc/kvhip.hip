@@ -58,6 +58,19 @@ __global__ void k_fill_i64(long long* p, long long v, unsigned long long count) 
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (unsigned long long)gridDim.x * blockDim.x) p[i] = v;
 }
+// int64 list -> int32 list in place (one block: element i is read before any thread can overwrite
+// it, because writes land at half the byte offset and the loop is barrier-stepped)
+__global__ void k_narrow_keys(long long* keys, long long n) {
+  int* out = reinterpret_cast<int*>(keys);
+  for (long long base = 0; base < n; base += blockDim.x) {
+    const long long i = base + threadIdx.x;
+    const long long v = i < n ? keys[i] : 0;
+    __syncthreads();
+    if (i < n) out[i] = (int)v;
+    __syncthreads();
+  }
+}
+
 // re-insert rows [1, next_row) into a fresh index
 __global__ void k_rehash(TableDev t, unsigned nrows) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
@@ -1768,7 +1781,7 @@ int kv_scatter_update(kv_handle_t t, const void* ids, const float* updates, int6
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   if ((op == KV_SCATTER_ADD || op == KV_SCATTER_SUB) && n > 1 && n <= (1ll << 21) && ids && updates &&
-      dim_supported(t->dim) && t->key_dtype != KV_DT_INT32) {
+      dim_supported(t->dim)) {
     // ScatterUpdate applies every occurrence of an id in turn (kv_variable.h:616-734), so repeated
     // ids add up: sum them first (one row per distinct id), then apply once
     Workspace& w = t->ws;
@@ -1782,6 +1795,8 @@ int kv_scatter_update(kv_handle_t t, const void* ids, const float* updates, int6
     }
     int64_t U = 0;
     if ((rc = dedup_locked(t, ids, updates, n, (int64_t*)w.scat_keys, w.scat_sum, nullptr, &U, s))) return rc;
+    if (t->key_dtype == KV_DT_INT32 && U > 0)   // the unique list is int64; the table's ops take its own key type
+      k_narrow_keys<<<1, 1024, 0, s>>>(w.scat_keys, U);
     return scatter_like(t, w.scat_keys, w.scat_sum, U, op, 0, -1, nullptr, s);
   }
   return scatter_like(t, ids, updates, n, op, 0, -1, nullptr, s);
