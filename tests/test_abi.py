@@ -58,3 +58,18 @@ def test_product_never_imports_the_oracle():
         if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) or "kv_oracle.py" in s:
           bad.append(os.path.join(d, f))
   assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_c_host_program_over_the_abi(tmp_path):
+  """A C++ program that includes only include/kvhip.h + HIP (no Python, no torch) drives the table."""
+  import shutil
+  import subprocess
+  hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+  exe = str(tmp_path / "c_abi_smoke")
+  csrc = os.path.join(ROOT, "tfplus_amd", "csrc")
+  subprocess.check_call([hipcc, "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.cc"), "-L", csrc, "-lkvhip",
+                         "-Wl,-rpath," + csrc, "-o", exe])
+  r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0 and "C ABI OK" in r.stdout, (r.stdout, r.stderr)
