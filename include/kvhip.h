@@ -166,6 +166,17 @@ int kv_import(kv_handle_t h, const int64_t* keys, const float* values, int64_t n
               const int64_t* blacklist, int64_t n_blacklist, const int64_t* freq_keys,
               const uint32_t* freq_values, int64_t n_freq, kv_stream_t stream);
 
+/* Replaces the delta branch of KvVariableFullOrDeltaImport[V2] (ops/kv_variable_ops.cc:576-631,
+ * kernels/kv_variable_ops.cc:854-939 -> DeltaImport kernels/dynamic_restore.hpp:29-155): the table
+ * is NOT cleared; keys are inserted or overwritten (their blacklist mark is lifted and
+ * under_threshold re-evaluated), blacklist keys are marked (first_n > 3) or removed (first_n <= 3,
+ * the inference load mode), frequency words are set on keys that exist, delete_keys are removed.
+ * need_full_import == true is kv_import. */
+int kv_import_delta(kv_handle_t h, const int64_t* keys, const float* values, int64_t n,
+                    const int64_t* blacklist, int64_t n_blacklist, const int64_t* freq_keys,
+                    const uint32_t* freq_values, int64_t n_freq, const int64_t* delete_keys,
+                    int64_t n_delete, int first_n, kv_stream_t stream);
+
 /* Replaces KvVariableInsertV2 (kernels/kv_variable_ops.cc:703-747) -> InsertOrUpdate
  * (kernels/kv_variable.h:423-485): row(ids[i]) = values[i, :] (insert or overwrite). */
 int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv_stream_t stream);

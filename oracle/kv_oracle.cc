@@ -737,6 +737,53 @@ int64_t kvo_delete_with_timestamp(void* h, int threshold, int64_t* out) {
   return int64_t(dl.size());
 }
 
+// DeltaImport dynamic_restore.hpp:29-155: no clear; keys inserted or overwritten with RemoveBlacklist +
+// UpdateUnderThreshold; blacklist marked (first_n > 3) or deleted; frequency words on existing keys;
+// delete_keys removed; the table counts as initialised.
+int64_t kvo_delete(void* h, const int64_t* ids, int64_t n);
+void kvo_import_delta(void* h, const int64_t* keys, const float* vals, int64_t n, const int64_t* black,
+                      int64_t nb, const int64_t* fkeys, const uint32_t* fvals, int64_t nf,
+                      const int64_t* dkeys, int64_t nd, int first_n) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  for (int64_t i = 0; i < n; ++i) {
+    Segment& sg = t->seg[t->SegId(keys[i])];
+    auto it = sg.map.find(keys[i]);
+    if (it == sg.map.end()) {
+      Meta m;
+      m.row = t->NewRow();
+      it = sg.map.insert_or_assign(keys[i], m).first;
+    }
+    Meta* m = &it->second;
+    if (m->row == nullptr) m->row = t->NewRow();          // UpdateValue on a blacklisted key allocates again
+    std::memcpy(m->row, vals + i * D, sizeof(float) * size_t(D));
+    m->in_black = false;
+    t->UpdateUnderThreshold(m);
+  }
+  if (first_n > 3) {
+    for (int64_t i = 0; i < nb; ++i) {
+      Segment& sg = t->seg[t->SegId(black[i])];
+      auto it = sg.map.find(black[i]);
+      if (it == sg.map.end()) {                            // table_manager.h:343-346
+        Meta m;
+        m.in_black = true;
+        sg.map.insert_or_assign(black[i], m);
+      } else {
+        t->MarkBlacklist(&it->second);
+      }
+    }
+  } else {
+    kvo_delete(h, black, nb);
+  }
+  for (int64_t i = 0; i < nf; ++i) {
+    Segment& sg = t->seg[t->SegId(fkeys[i])];
+    auto it = sg.map.find(fkeys[i]);
+    if (it != sg.map.end()) it->second.freq = fvals[i];
+  }
+  kvo_delete(h, dkeys, nd);
+  t->initialized = true;
+}
+
 // ImportValues dynamic_restore.hpp:176-262: clear; insert keys/values (freq word 1,
 // under_threshold left false); blacklist keys are marked (absent ones inserted as blacklisted);
 // frequency words are set on keys that exist; the table counts as initialised.

@@ -72,6 +72,8 @@ def lib():
   L.kvo_delete.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64]
   L.kvo_delete_with_timestamp.restype = ctypes.c_int64
   L.kvo_delete_with_timestamp.argtypes = [ctypes.c_void_p, ctypes.c_int, _i64p]
+  L.kvo_import_delta.argtypes = [ctypes.c_void_p, _i64p, _f32p, ctypes.c_int64, _i64p, ctypes.c_int64, _i64p, _u32p,
+                                 ctypes.c_int64, _i64p, ctypes.c_int64, ctypes.c_int]
   L.kvo_get_meta.restype = ctypes.c_int
   L.kvo_get_meta.argtypes = [ctypes.c_void_p, ctypes.c_int64, _u32p, ctypes.POINTER(ctypes.c_int),
                              ctypes.POINTER(ctypes.c_int)]
@@ -178,6 +180,13 @@ class OracleKv:
 
   def set_day(self, day):
     lib().kvo_set_day(self._h, int(day))
+
+  def import_delta(self, keys, values, blacklist=(), freq_keys=(), freq_values=(), delete_keys=(), first_n=6):
+    k, v = _ids(keys), _f32(values)
+    b, fk, dk = _ids(blacklist), _ids(freq_keys), _ids(delete_keys)
+    fv = np.ascontiguousarray(np.asarray(freq_values).reshape(-1), dtype=np.uint32)
+    lib().kvo_import_delta(self._h, _p(k, _i64p), _p(v, _f32p), k.size, _p(b, _i64p), b.size, _p(fk, _i64p),
+                           _p(fv, _u32p), fk.size, _p(dk, _i64p), dk.size, int(first_n))
 
   def size(self):
     return int(lib().kvo_size(self._h))

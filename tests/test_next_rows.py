@@ -165,3 +165,52 @@ def test_scatter_add_sub_repeated_ids_accumulate(ops, op):
   np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q),
                              rtol=2e-6, atol=1e-6)
   assert ops.kv_variable_frequency(h) == o.sum_freq()
+
+
+def test_delta_import_oracle_semantics():
+  """DeltaImport (dynamic_restore.hpp:29-155): no clear, blacklist lifted on re-imported keys,
+  blacklist marked or (first_n <= 3) deleted, frequency only on existing keys, delete_keys removed."""
+  kv = ko.OracleKv(4, 0, np.zeros((4, 4), np.float32), day=DAY)
+  kv.import_([1, 2, 3], np.ones((3, 4), np.float32), blacklist=[3, 9])
+  assert sorted(kv.as_dict()) == [1, 2] and kv.map_size() == 4
+  kv.import_delta([3, 7], np.full((2, 4), 5, np.float32), blacklist=[2], freq_keys=[1, 7, 100], freq_values=[(5 << 16) | 9, 11, 12],
+                  delete_keys=[1, 55])
+  d = kv.as_dict()
+  assert sorted(d) == [3, 7] and float(d[3][0]) == 5.0       # 3 came back from the blacklist, 1 deleted, 2 blacklisted
+  assert kv.meta(7)["freq"] == 11 and kv.meta(100) is None and kv.meta(2)["blacklist"] and kv.meta(9)["blacklist"]
+  kv.import_delta([], np.zeros((0, 4), np.float32), blacklist=[9, 3], first_n=3)    # inference mode: blacklist keys vanish
+  assert kv.meta(9) is None and kv.meta(3) is None and sorted(kv.as_dict()) == [7]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first_n", [6, 3])
+def test_delta_import_parity(ops, first_n):
+  h, o = _pair(ops, 8, thr=2)
+  rng = np.random.default_rng(31)
+  ids = rng.integers(-60, 60, 500)
+  ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+  s_h, s_o = _pair(ops, 24, seed=4)
+  g = (rng.standard_normal((60, 8)) * rng.uniform(1e-4, 3e-2, (60, 1))).astype(np.float32)
+  uids = np.arange(-30, 30)
+  ops.kv_variable_group_sparse_apply_adam_v4(h, s_h, g, uids, 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8, 1e-4, 1e-2, 4e-3)
+  ko.apply_group_adam(o, s_o, g, uids, 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8, 1e-4, 1e-2, 4e-3)          # some rows blacklist
+  keys = rng.integers(-80, 80, 90); keys = np.unique(keys)
+  vals = rng.standard_normal((keys.size, 8)).astype(np.float32)
+  vals[::7] = 0.0                                                                                     # under_threshold rows
+  bl = np.unique(rng.integers(-80, 120, 25)); bl = bl[~np.isin(bl, keys)]
+  fk = np.unique(rng.integers(-100, 100, 40)); fv = rng.integers(1, 2**31, fk.size).astype(np.uint32)
+  dk = np.unique(rng.integers(-100, 100, 30)); dk = dk[~np.isin(dk, keys)]
+  ops.kv_variable_full_or_delta_import(h, keys, vals, bl, fk, fv, need_full_import=False, delete_keys=dk, first_n=first_n)
+  o.import_delta(keys, vals, bl, fk, fv, dk, first_n=first_n)
+  k2, v2, bl2, fk2, fv2 = ops.kv_variable_export(h, first_n=6)
+  ok, ov, obl, ofk, ofv = o.export(6)
+  assert dict(zip(k2.cpu().numpy().tolist(), map(bytes, v2.cpu().numpy()))) == dict(zip(ok.tolist(), map(bytes, ov)))
+  assert sorted(bl2.cpu().numpy().tolist()) == sorted(obl.tolist())
+  assert dict(zip(fk2.cpu().numpy().tolist(), fv2.cpu().numpy().view(np.uint32).tolist())) == dict(zip(ofk.tolist(), ofv.tolist()))
+  assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_shape_v2(h)[0] == o.map_size()
+  # a full import through the same op clears first
+  ops.kv_variable_full_or_delta_import(h, keys[:5], vals[:5], need_full_import=True); o.import_(keys[:5], vals[:5])
+  assert ops.kv_variable_shape_v2(h)[0] == o.map_size() == 5
+  with pytest.raises(NotImplementedError):
+    ops.kv_variable_full_or_delta_export(h, do_full_export=False)
+  assert ops.kv_variable_full_or_delta_export(h, True)[5] is True

@@ -54,6 +54,7 @@ SIGNATURES = {
     "kv_export_count": (_i32, [_vp, _i32, _c.POINTER(_i64), _vp]),
     "kv_export_fill": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kv_import": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "kv_import_delta": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kv_unique": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _vp]),

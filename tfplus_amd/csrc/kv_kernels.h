@@ -670,7 +670,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
             // InsertOrUpdate :423-485 copies the values but the key stays blacklisted and keeps
             // reading zeros (table_manager.h:224-226), so the zeroed row is left as it is too.
             const unsigned fl = isnew ? 0u : *flags_ptr(a.tv, r);
-            touch = !(fl & FLAG_BLACK);
+            // DeltaImport (is_insert == 3) overwrites the value and lifts the blacklist (dynamic_restore.hpp:65-75)
+            touch = !(fl & FLAG_BLACK) || a.is_insert == 3;
             const float* src = a.grad + (size_t)hval[s] * D;
             if (touch) {
               big = false;
@@ -705,6 +706,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
             if (a.mark_what == 0) *fp = (unsigned char)(isnew ? FLAG_BLACK : (FLAG_BLACK | FLAG_UNDER));
           } else if (a.is_insert == 2) {
             if (isnew) *fp = 0;  // ImportValues does not evaluate under_threshold (dynamic_restore.hpp:183-194)
+          } else if (a.is_insert == 3) {
+            *fp = (unsigned char)(any ? 0u : FLAG_UNDER);  // RemoveBlacklist + UpdateUnderThreshold
           } else if (touch || isnew) {
             const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
             *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));

@@ -1540,6 +1540,8 @@ static int after_release(kv_table* t, hipStream_t s, unsigned long long* release
   return KV_OK;
 }
 
+static int delete_locked(kv_table* t, const void* ids, int64_t n, int64_t* num_deleted, hipStream_t s);
+
 int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
@@ -1550,7 +1552,11 @@ int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, k
   if (n == 0) return KV_OK;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  hipStream_t s = (hipStream_t)stream;
+  return delete_locked(t, ids, n, num_deleted, (hipStream_t)stream);
+}
+
+static int delete_locked(kv_table* t, const void* ids, int64_t n, int64_t* num_deleted, hipStream_t s) {
+  int rc;
   if ((rc = ensure_free_list(t, s))) return rc;
   HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
   const TableDev td = dev_view(t);
@@ -1802,6 +1808,48 @@ int kv_scatter_update(kv_handle_t t, const void* ids, const float* updates, int6
   return scatter_like(t, ids, updates, n, op, 0, -1, nullptr, s);
 }
 
+// placeholder init table for tables that are marked initialised by an import
+static int ensure_init_placeholder(kv_table* t, hipStream_t s) {
+  if (!t->init_table) {
+    // the import marks the variable initialised (dynamic_restore.hpp:249-255).  The checkpoint's
+    // init table is the caller's to pass through kv_init_table; without one, keys inserted later
+    // start from a one-row zero table instead of dereferencing nothing.
+    HIP_TRY(hipMalloc(&t->init_table, (size_t)t->dim * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(t->init_table, 0, (size_t)t->dim * sizeof(float), s));
+    t->init_rows = 1;
+  }
+  return KV_OK;
+}
+
+int kv_import_delta(kv_handle_t t, const int64_t* keys, const float* values, int64_t n, const int64_t* blacklist,
+                    int64_t n_black, const int64_t* fkeys, const uint32_t* fvals, int64_t n_freq,
+                    const int64_t* delete_keys, int64_t n_delete, int first_n, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if (t->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "import with int32 keys");
+  // Stage 1 (dynamic_restore.hpp:58-77): insert or overwrite, lift the blacklist, re-evaluate under_threshold
+  if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 3, -1, nullptr, s))) return rc;
+  // Stage 2 (:92-112): first_n > 3 marks the blacklist, otherwise (inference load) those keys are removed
+  if (n_black > 0) {
+    if (first_n > 3) {
+      if ((rc = scatter_like(t, blacklist, nullptr, n_black, 0, 1, 0, nullptr, s))) return rc;
+    } else if ((rc = delete_locked(t, blacklist, n_black, nullptr, s))) {
+      return rc;
+    }
+  }
+  // Stage 3/4 (:114-135): frequency words of keys that exist
+  if (n_freq > 0 && (rc = scatter_like(t, fkeys, nullptr, n_freq, 0, 1, 1, fvals, s))) return rc;
+  // Stage 5 (:137-145): keys deleted since the checkpoint this delta follows
+  if (n_delete > 0 && (rc = delete_locked(t, delete_keys, n_delete, nullptr, s))) return rc;
+  if ((rc = ensure_init_placeholder(t, s))) return rc;
+  t->initialized = true;
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
 int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n, const int64_t* blacklist,
               int64_t n_black, const int64_t* fkeys, const uint32_t* fvals, int64_t n_freq,
               kv_stream_t stream) {
@@ -1821,14 +1869,7 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 2, -1, nullptr, s))) return rc;
   if (n_black > 0 && (rc = scatter_like(t, blacklist, nullptr, n_black, 0, 1, 0, nullptr, s))) return rc;
   if (n_freq > 0 && (rc = scatter_like(t, fkeys, nullptr, n_freq, 0, 1, 1, fvals, s))) return rc;
-  if (!t->init_table) {
-    // the import marks the variable initialised (dynamic_restore.hpp:249-255).  The checkpoint's
-    // init table is the caller's to pass through kv_init_table; without one, keys inserted later
-    // start from a one-row zero table instead of dereferencing nothing.
-    HIP_TRY(hipMalloc(&t->init_table, (size_t)t->dim * sizeof(float)));
-    HIP_TRY(hipMemsetAsync(t->init_table, 0, (size_t)t->dim * sizeof(float), s));
-    t->init_rows = 1;
-  }
+  if ((rc = ensure_init_placeholder(t, s))) return rc;
   t->initialized = true;
   HIP_TRY(hipGetLastError());
   return KV_OK;

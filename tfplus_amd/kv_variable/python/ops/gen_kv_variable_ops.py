@@ -297,6 +297,40 @@ def kv_variable_import(table_handle, keys, values, blacklist=None, freq_keys=Non
                                   0 if fk is None else fk.numel(), _stream(table_handle)))
 
 
+def kv_variable_full_or_delta_import(table_handle, keys, values, blacklist=None, freq_keys=None, freq_values=None,
+                                     need_full_import=True, delete_keys=None, first_n=6, name=None):
+  """REGISTER_OP("KvVariableFullOrDeltaImport") ops/kv_variable_ops.cc:576-602: need_full_import ->
+  ImportValues (the table is cleared first), otherwise DeltaImport (dynamic_restore.hpp:29-155)."""
+  if need_full_import:
+    return kv_variable_import(table_handle, keys, values, blacklist, freq_keys, freq_values, first_n)
+  dev = _dev(table_handle)
+  k = torch.as_tensor(keys, dtype=torch.int64).to(dev).contiguous()
+  v = _f32(table_handle, values)
+  if v.numel() != k.numel() * table_handle.dim:
+    raise _lib.InvalidArgumentError("number of keys (%d) and number of values (%d) do not match" %
+                                    (k.numel(), v.numel() // max(table_handle.dim, 1)))
+  def i64(x):
+    return None if x is None else torch.as_tensor(x, dtype=torch.int64).to(dev).contiguous()
+  bl, fk, dk = i64(blacklist), i64(freq_keys), i64(delete_keys)
+  fv = None
+  if freq_values is not None:
+    fv = torch.as_tensor(np.asarray(freq_values).astype(np.uint32).view(np.int32)
+                         if not isinstance(freq_values, torch.Tensor) else freq_values).to(dev).contiguous()
+  n = lambda t: 0 if t is None else t.numel()
+  _lib.check(_lib.lib().kv_import_delta(table_handle.ptr, _p(k), _p(v), k.numel(), _p(bl), n(bl), _p(fk), _p(fv), n(fk),
+                                        _p(dk), n(dk), int(first_n), _stream(table_handle)))
+
+
+def kv_variable_full_or_delta_export(table_handle, do_full_export=True, first_n=3, enable_cutoff=False, cutoff_value=0.0):
+  """REGISTER_OP("KvVariableFullOrDeltaExport") ops/kv_variable_ops.cc:633-660.  Full exports only:
+  (keys, values, blacklist, freq_keys, freq_values, need_full_import=True, delete_keys=[]).  The delta
+  list behind do_full_export=False (SUPPORT_DELTA_EXPORT, kv_variable.h:103-111) is not tracked here."""
+  if not do_full_export:
+    raise _lib.UnimplementedError("delta export: the train/prediction delta lists (SUPPORT_DELTA_EXPORT) are not tracked")
+  k, v, bl, fk, fv = kv_variable_export(table_handle, first_n=first_n)
+  return k, v, bl, fk, fv, True, torch.empty(0, dtype=torch.int64, device=k.device)
+
+
 def kv_variable_insert_v2(table_handle, indices, values, name=None):
   """REGISTER_OP("KvVariableInsertV2") ops/kv_variable_ops.cc:334-347."""
   ids = _ids(table_handle, indices)
