@@ -145,6 +145,9 @@ def main():
   one_gpu_debug = os.environ.get("KV_BENCH_ONE_GPU") == "1" and world > 1
   if one_gpu_debug:
     local = 0
+  ndev = torch.cuda.device_count()
+  if ndev > 0:
+    local %= ndev          # a launcher that masks devices per rank leaves one visible GPU: index 0
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
   shard_path = world > 1 or args.force_sharded
