@@ -1198,6 +1198,9 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
               for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
         }
         asm volatile("" ::"v"(touch));  // keep the touch loads
+#ifdef KV_STAMPS
+        if (tid == 0 && u / GPB < 4) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 11 + (u / GPB)] = wall_clock64();
+#endif
         finish(h, live, gv);
       }
     }

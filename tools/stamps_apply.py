@@ -48,3 +48,8 @@ for c in range(cl.max() + 1):
   print("  clock domain %d: %4d blocks, start skew median %6d p90 %6d max %6d ; last end %6d" % (c, len(m), np.median(t0[m] - b), np.percentile(t0[m] - b, 90), (t0[m] - b).max(), (t4[m] - b).max()))
 rep(pt[:, :5], ["count + copy entries + hash", "group + probes (1 thread/key)", "heavy keys (flattened fold)", "per-key rows + update"], "k_part_sum<APPLY>")
 print("   entries/round median %d max %d ; rounds max %d ; uniques median %d max %d" % (np.median(pt[:, 8]), pt[:, 8].max(), pt[:, 9].max(), np.median(pt[:, 10]), pt[:, 10].max()))
+
+r = pt[:, 11:15].astype(np.int64); t3 = pt[:, 3].astype(np.int64); t4 = pt[:, 4].astype(np.int64)
+ok = (r[:, 0] > 0) & (r[:, 2] > 0)
+print("   group 0 of each block, rows phase: start -> grads of round 0 summed %d ; round 0 -> 1 %d ; round 1 -> 2 %d ; last sum -> phase end %d (median ticks)" % (
+    np.median(r[ok, 0] - t3[ok]), np.median(r[ok, 1] - r[ok, 0]), np.median(r[ok, 2] - r[ok, 1]), np.median(t4[ok] - r[ok, 2])))
