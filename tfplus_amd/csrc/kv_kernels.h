@@ -122,6 +122,25 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
   const unsigned P = w.P;
   KV_STAMP(0);
 
+  // the tile's ids (and counts) are requested first: their HBM latency runs under the LDS clearing
+  long long kreg[IPT];
+  unsigned creg[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const long long i = base + (long long)k * TBT + tid;
+    kreg[k] = 0; creg[k] = 1;
+    if (i < n) {
+      kreg[k] = load_id(ids, (size_t)i);
+      if constexpr (std::is_same<IdT, IdCount>::value) {
+        const long long ci = ids[i].count;             // counts travel with the ids
+        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      } else if (MODE == MODE_LOOKUP && counts != nullptr) {
+        // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
+        const int ci = counts[i];
+        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      }
+    }
+  }
   for (int s = tid; s <= LS; s += TBT) {
     sm.lkeys[s] = EMPTY_KEY;
     sm.lcnt[s] = 0;
@@ -138,16 +157,8 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     tslot[k] = 0xFFFFFFFFu;
     myrank[k] = 0;
     if (i < n) {
-      const long long key = load_id(ids, (size_t)i);
-      unsigned c = 1;
-      if constexpr (std::is_same<IdT, IdCount>::value) {
-        const long long ci = ids[i].count;             // counts travel with the ids
-        c = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
-      } else if (MODE == MODE_LOOKUP && counts != nullptr) {
-        // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
-        const int ci = counts[i];
-        c = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
-      }
+      const long long key = kreg[k];
+      const unsigned c = creg[k];
       unsigned h;
       if (key == EMPTY_KEY) {
         h = LS;
