@@ -115,3 +115,28 @@ def test_random_program_matches_oracle(ops, seed):
     var.check(rng, keyspace, tag)
     for i, p in enumerate(sl):
       p.check(rng, keyspace, tag + " slot%d" % i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,keyspace,D", [(150_000, 2_000, 8), (150_000, 10_000_000, 64), (700_000, 600_000, 4)])
+def test_large_batches_match_oracle(ops, n, keyspace, D):
+  """Multi-tile batches: keys present in every tile (block-wide folds), and ~700 distinct keys per
+  partition (LDS key tables overflow and the partition splits into sub-hash classes)."""
+  rng = np.random.default_rng(n + D)
+  table = rng.standard_normal((32, D)).astype(np.float32)
+  var = Pair(ops, D, 0, table, 5)
+  slot = Pair(ops, 3 * D, 0, np.zeros((4, 3 * D), np.float32), 5)
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  for step in range(3):
+    ids = rng.integers(-keyspace, keyspace, n)
+    got = ops.kv_variable_gather_or_insert_v2(var.h, ids).cpu().numpy()
+    np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=1e-4, atol=2e-5)
+    g = (rng.uniform(0.5, 1.5, (n, D)) * 1e-2 * rng.choice([-1.0, 1.0], (1, D))).astype(np.float32)
+    ops.kv_variable_group_sparse_apply_adam_v4(var.h, slot.h, g, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+    u, s, _ = ko.dedup_segment_sum(ids, g)
+    ko.apply_group_adam(var.o, slot.o, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8)
+    b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+    kill = rng.integers(-keyspace, keyspace, n // 10)
+    assert ops.kv_variable_delete(var.h, kill) == var.o.delete(kill)
+    var.check(rng, keyspace, "large step %d" % step)
+    slot.check(rng, keyspace, "large slot step %d" % step)
