@@ -65,6 +65,9 @@ def test_c_host_program_over_the_abi(tmp_path):
   """A C++ program that includes only include/kvhip.h + HIP (no Python, no torch) drives the table."""
   import shutil
   import subprocess
+  torch = pytest.importorskip("torch")
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
   hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
   exe = str(tmp_path / "c_abi_smoke")
   csrc = os.path.join(ROOT, "tfplus_amd", "csrc")

@@ -105,12 +105,12 @@ _BY_CODE = {c.code: c for c in (InvalidArgumentError, FailedPreconditionError,
 
 def build(force=False):
   """hipcc build of the extension, in-tree (tfplus_amd/csrc/libkvhip.so)."""
-  srcs = [os.path.join(CSRC, f) for f in ("kvhip.hip", "kv_device.h", "kv_kernels.h")]
+  srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
   srcs.append(os.path.join(_HERE, "..", "include", "kvhip.h"))
   stale = (not os.path.exists(SO_PATH)
            or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs))
   if force or stale:
-    subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
   return SO_PATH
 
 

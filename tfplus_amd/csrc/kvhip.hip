@@ -39,6 +39,10 @@
 
 #include "../../include/kvhip.h"
 
+// k_part_sum dispatch, compiled in two other translation units (kv_part_launch.h)
+extern "C" int kvp_launch_part_sum_a(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab);
+extern "C" int kvp_launch_part_sum_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab);
+
 namespace {
 
 #include "kv_device.h"
@@ -574,44 +578,18 @@ int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiD
     k_part_keys<MODE><<<grid, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
     return KV_OK;
   } else {
-#define KV_PART(V, LPR, K)                                                                       \
-  do {                                                                                           \
-    if constexpr (MODE == MODE_APPLY && V == 4) {                                                \
-      if (md) {                                                                                  \
-        k_part_sum_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS,      \
-            part_sum_smem_bytes(MODE, OPT, D, LPR, wd.ntiles), s>>>(md);                         \
-        return KV_OK;                                                                            \
-      }                                                                                          \
-    }                                                                                            \
-    if (md) return fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D); \
-    k_part_sum<MODE, OPT, V, LPR, K><<<grid, TBS, part_sum_smem_bytes(MODE, OPT, D, LPR, wd.ntiles), s>>>(wd, pa); \
-    return KV_OK;                                                                                \
-  } while (0)
-    if ((D & 3) == 0) {
-      const int q = D / 4;
-      if (q <= 1) KV_PART(4, 1, 1);
-      if (q <= 2) KV_PART(4, 2, 1);
-      if (q <= 4) KV_PART(4, 4, 1);
-      if (q <= 8) KV_PART(4, 8, 1);
-      if (q <= 16) KV_PART(4, 8, 2);    // dims 36..64: 8 lanes x 2 float4 (measured: 139 -> 120 us at D = 64)
-      if (q <= 32) KV_PART(4, 16, 2);   // dims 68..128: 16 lanes x 2 float4 (225 -> 183 us at D = 128)
-      if (q <= 64) KV_PART(4, 64, 1);
-      if (q <= 128) KV_PART(4, 64, 2);
-      if (q <= 256) KV_PART(4, 64, 4);
-    } else {
-      if (D <= 1) KV_PART(1, 1, 1);
-      if (D <= 2) KV_PART(1, 2, 1);
-      if (D <= 4) KV_PART(1, 4, 1);
-      if (D <= 8) KV_PART(1, 8, 1);
-      if (D <= 16) KV_PART(1, 16, 1);
-      if (D <= 32) KV_PART(1, 32, 1);
-      if (D <= 64) KV_PART(1, 64, 1);
-      if (D <= 128) KV_PART(1, 64, 2);
-      if (D <= 256) KV_PART(1, 64, 4);
-    }
-#undef KV_PART
-    return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
-                "(multiples of 4 up to 1024, any dim up to 256)", D);
+    // the k_part_sum instantiations live in kv_part_sum_a.hip / kv_part_sum_b.hip (parallel build)
+    int rc;
+    if (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3))
+      rc = kvp_launch_part_sum_a(MODE, OPT, &wd, &pa, (void*)s, md, ntab);
+    else
+      rc = kvp_launch_part_sum_b(MODE, OPT, &wd, &pa, (void*)s, md, ntab);
+    if (rc == KV_UNIMPLEMENTED)
+      return md ? fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D)
+                : fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
+                       "(multiples of 4 up to 1024, any dim up to 256)", D);
+    if (rc) return fail(rc, "partition pass: no kernel for mode %d / optimizer %d", MODE, OPT);
+    return KV_OK;
   }
 }
 
