@@ -138,6 +138,42 @@ def test_adam_optimizer_equals_tf_adam(api):
   assert opt.get_slot_names() == ["m_v"]
 
 
+def test_rectified_adam_optimizer_closed_form(api):
+  """rectified_adam.py:278-363 restated in float64: 7 steps (the rectified branch starts at step 6
+  with beta2 = .999: sma_t >= 5), repeated ids summed first, amsgrad + weight decay on."""
+  D = 8
+  kv = api.vs.get_kv_variable("radam", embedding_dim=D, initializer=api.vs.ones_initializer())
+  opt = api.tr.RectifiedAdamOptimizer(learning_rate=0.01, amsgrad=True, weight_decay=0.01)
+  rng = np.random.default_rng(5)
+  x = {k: np.ones(D) for k in range(6)}
+  m = {k: np.zeros(D) for k in range(6)}; v = {k: np.zeros(D) for k in range(6)}; vh = {k: np.zeros(D) for k in range(6)}
+  b1, b2, eps = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-7))
+  b1p, b2p = b1, b2
+  for step in range(1, 8):
+    ids = rng.integers(0, 6, 20)
+    g = rng.uniform(0.5, 1.5, (20, D)).astype(np.float32)
+    opt.apply_gradients([(api.kv.IndexedSlices(torch.from_numpy(g).cuda(), torch.from_numpy(ids).cuda(), None), kv)])
+    sma_inf = 2.0 / (1.0 - b2) - 1.0
+    sma_t = sma_inf - 2.0 * step * b2p / (1.0 - b2p)
+    for k in np.unique(ids):
+      gk = g[ids == k].astype(np.float64).sum(0)
+      m[k] = b1 * m[k] + (1 - b1) * gk
+      v[k] = b2 * v[k] + (1 - b2) * gk * gk
+      vh[k] = np.maximum(v[k], vh[k])
+      m_corr, v_corr = m[k] / (1 - b1p), np.sqrt(vh[k] / (1 - b2p))
+      if sma_t >= 5.0:
+        r_t = np.sqrt((sma_t - 4) / (sma_inf - 4) * (sma_t - 2) / (sma_inf - 2) * sma_inf / sma_t)
+        upd = r_t * m_corr / (v_corr + eps)
+      else:
+        upd = m_corr
+      upd = upd + float(np.float32(0.01)) * x[k]
+      x[k] = x[k] - upd * float(np.float32(0.01))
+    b1p, b2p = float(np.float32(b1p * b1)), float(np.float32(b2p * b2))
+  got = kv.sparse_read(torch.arange(6)).detach().cpu().numpy()
+  np.testing.assert_allclose(got, np.stack([x[k] for k in range(6)]), rtol=2e-5, atol=1e-6)
+  assert opt.get_slot_names() == ["m", "v", "vhat"]
+
+
 def test_gradient_descent_optimizer_adds_every_occurrence(api):
   """gradient_descent.py:31-33: scatter_add(-grad * lr) on the raw indices; repeated ids accumulate."""
   kv = api.vs.get_kv_variable("sgd", embedding_dim=8, initializer=api.vs.ones_initializer())
