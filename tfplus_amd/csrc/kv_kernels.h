@@ -535,7 +535,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   KV_STAMPP(0);
   const unsigned E = seg_directory<TBK, TBK / 64>(w, p, tpre, tstart, wtot);
   if (E == 0) return;
-  const bool wide = E > 65535u;  // cannot happen with TILE * ntiles / P this small; guard anyway
+  const bool wide = E > 65535u;  // needs a key set crafted against the partition hash; guarded, not handled
 
   // work list of (R, round) sub-hash classes; an overflowing class is split in two and each
   // class is processed exactly once (block-uniform control flow)
@@ -543,7 +543,10 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   __shared__ int sp;
   if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
   __syncthreads();
-  if (wide) return;
+  if (wide) {  // never silent: the next synchronous call on the table reports it
+    if (tid == 0) atomicExch(&a.tv.counters[1], 2u);
+    return;
+  }
   while (sp > 0) {
     const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
     __syncthreads();
@@ -881,7 +884,11 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
   unsigned short* tpre = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
   unsigned short* tstart = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
   const unsigned E = seg_directory<TBS, TBS / 64>(w, p, tpre, tstart, wtot);
-  if (E == 0 || E > 65535u) return;
+  if (E == 0) return;
+  if (E > 65535u) {  // a key set crafted against the partition hash; reported by the next synchronous call
+    if (tid == 0) atomicExch(&a.tv.counters[1], 2u);
+    return;
+  }
 
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;

@@ -377,7 +377,10 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
     unsigned c[3];
     HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (c[1]) return fail(KV_INTERNAL, "row slab overflow detected on device");
+    if (c[1])
+    return fail(KV_INTERNAL, c[1] == 2 ? "a hash partition received more than 65535 entries in one batch "
+                                         "(key set crafted against the partition hash); that batch was not applied"
+                                       : "row slab overflow detected on device");
     const long long freed = std::max(0, (int)c[2]);
     t->rows_ub = c[0];
     t->free_known = freed;
@@ -753,7 +756,10 @@ static int stats(kv_handle_t t, hipStream_t s, unsigned long long out[2], unsign
   unsigned c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (c[1]) return fail(KV_INTERNAL, "row slab overflow detected on device");
+  if (c[1])
+    return fail(KV_INTERNAL, c[1] == 2 ? "a hash partition received more than 65535 entries in one batch "
+                                         "(key set crafted against the partition hash); that batch was not applied"
+                                       : "row slab overflow detected on device");
   t->rows_ub = c[0];
   t->free_known = std::max(0, (int)c[2]);
   if (nrows_out) *nrows_out = c[0];
