@@ -595,9 +595,13 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     __syncthreads();
     if (lnu >= (unsigned)UCAPK) {  // block-uniform: too many keys -> split the class, nothing applied yet
       __syncthreads();
-      if (tid == 0 && sp + 2 <= 24) {
-        stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
-        stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+      if (tid == 0) {
+        if (sp + 2 <= 24) {
+          stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+          stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+        } else {
+          atomicExch(&a.tv.counters[1], 2u);   // keys that no sub-hash separates: reported, not applied
+        }
       }
       __syncthreads();
       continue;
@@ -897,9 +901,13 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
   __syncthreads();
   auto split = [&](unsigned R, unsigned round) {  // replace class (R, round) by its two halves
     __syncthreads();
-    if (tid == 0 && sp + 2 <= 24) {
-      stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
-      stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+    if (tid == 0) {
+      if (sp + 2 <= 24) {
+        stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+        stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+      } else {
+        atomicExch(&a.tv.counters[1], 2u);   // keys that no sub-hash separates: reported, not applied
+      }
     }
     __syncthreads();
   };
