@@ -625,34 +625,62 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
       __syncthreads();
     }
     // one thread per unique key, all keys of the partition at once: probe, then frequency word and
-    // flags with a single load (RowMeta)
-    for (unsigned u = tid; u < nu && MODE != MODE_UNIQUE; u += TBK) {
-      const unsigned s = ulist[u];
-      const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
-      bool isnew = false;
-      // warm path: a read-only probe; the insert (atomics, row allocation) is a cold branch.
-      // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
-      unsigned r = table_find(a.tv, key);
-      if (__builtin_expect(r == 0u, 0) && !(MODE == MODE_MARK && a.mark_what == 1))
-        r = table_find_or_insert(a.tv, key, &isnew);
-      hrow[s] = r;
-      if (r == 0) continue;
-      RowMeta* mp = meta_ptr(a.tv, r);
-      if (MODE == MODE_LOOKUP) {
-        // find_func / insert_func (kv_variable.h:320-363): lo16 = sat_add(lo16, batch count),
-        // hi16 = today; UpdateUnderThreshold only has work to do when the row changed since the
-        // flag was computed (FLAG_DIRTY) or the row is new — every other writer keeps it current
-        uint2 m = make_uint2(0u, (unsigned)FLAG_DIRTY);
-        if (!isnew) m = *reinterpret_cast<const uint2*>(&mp->freq);
-        const unsigned cnt = a.count_once ? 1u : hval[s];
-        unsigned lo = (m.x & 0xFFFFu) + (cnt > 65535u ? 65535u : cnt);
-        if (lo > 65535u) lo = 65535u;
-        mp->freq = (a.day << 16) | lo;
-        if (isnew) mp->flags = (unsigned char)FLAG_DIRTY;
-        if (m.y & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
-      } else {
-        if (isnew) { mp->freq = 1u; mp->flags = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
-        lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew ? 0x8000u : 0u));
+    // flags with a single load (RowMeta).  A thread that owns several keys (more than 256 distinct
+    // keys in the partition: low-skew batches) takes them OB at a time with their probes in flight
+    // together, so it pays the two dependent hops once per batch, not once per key.
+    constexpr int OB = 4;
+    for (unsigned u0 = tid; u0 < nu && MODE != MODE_UNIQUE; u0 += OB * TBK) {
+      unsigned sl[OB], r[OB];
+      long long key[OB];
+      unsigned long long pp[OB];
+      Entry en[OB];
+      bool isnew[OB];
+#pragma unroll
+      for (int k = 0; k < OB; ++k) {
+        const unsigned u = u0 + k * TBK;
+        sl[k] = 0xFFFFFFFFu; r[k] = 0; isnew[k] = false; key[k] = 0; pp[k] = 0;
+        if (u < nu) {
+          sl[k] = ulist[u];
+          key[k] = (sl[k] == HSK) ? EMPTY_KEY : hkey[sl[k]];
+          pp[k] = home_of(a.tv, key[k], mix64((unsigned long long)key[k]));
+          en[k] = load_entry(&a.tv.entries[pp[k]]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < OB; ++k) {
+        if (sl[k] == 0xFFFFFFFFu) continue;
+        // warm path: a read-only probe; the insert (atomics, row allocation) is a cold branch.
+        // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
+        r[k] = table_find_from(a.tv, key[k], pp[k], en[k]);
+        if (__builtin_expect(r[k] == 0u, 0) && !(MODE == MODE_MARK && a.mark_what == 1))
+          r[k] = table_find_or_insert(a.tv, key[k], &isnew[k]);
+        hrow[sl[k]] = r[k];
+      }
+      uint2 m[OB];
+#pragma unroll
+      for (int k = 0; k < OB; ++k) {
+        m[k] = make_uint2(0u, (unsigned)FLAG_DIRTY);
+        if (MODE == MODE_LOOKUP && sl[k] != 0xFFFFFFFFu && r[k] != 0u && !isnew[k]) m[k] = load_freq_flags(a.tv, r[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < OB; ++k) {
+        if (sl[k] == 0xFFFFFFFFu || r[k] == 0u) continue;
+        const unsigned s = sl[k];
+        RowMeta* mp = meta_ptr(a.tv, r[k]);
+        if (MODE == MODE_LOOKUP) {
+          // find_func / insert_func (kv_variable.h:320-363): lo16 = sat_add(lo16, batch count),
+          // hi16 = today; UpdateUnderThreshold only has work to do when the row changed since the
+          // flag was computed (FLAG_DIRTY) or the row is new — every other writer keeps it current
+          const unsigned cnt = a.count_once ? 1u : hval[s];
+          unsigned lo = (m[k].x & 0xFFFFu) + (cnt > 65535u ? 65535u : cnt);
+          if (lo > 65535u) lo = 65535u;
+          mp->freq = (a.day << 16) | lo;
+          if (isnew[k]) mp->flags = (unsigned char)FLAG_DIRTY;
+          if (m[k].y & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew[k] ? 0x8000u : 0u));
+        } else {
+          if (isnew[k]) { mp->freq = 1u; mp->flags = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
+          lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew[k] ? 0x8000u : 0u));
+        }
       }
     }
     __syncthreads();
