@@ -473,6 +473,15 @@ __device__ __forceinline__ unsigned lds_key_slot(long long* hkey, unsigned* sent
   }
 }
 
+// Partition of a workgroup.  Workgroups go round-robin over the 8 XCDs (workgroup b runs on XCD
+// b % 8), each with its own L2, and a partition's entries are short runs (~1 entry per tile) inside
+// lines that hold the runs of ~20 neighbouring partitions: with p = b every XCD ends up fetching
+// nearly every line of the entry arrays (8x the bytes).  So an XCD takes a CONTIGUOUS range of
+// partitions; P/8 = 128 partitions are resident together on its 32 CUs, so each line is fetched once.
+__device__ __forceinline__ unsigned xcd_partition(unsigned b, unsigned P) {
+  return P >= 8u ? (b & 7u) * (P >> 3) + (b >> 3) : b;
+}
+
 // ---- k_part_keys: MODE_LOOKUP / MODE_SCATTER / MODE_MARK ---------------------------------------
 // Streams the partition's entries twice and keeps only the unique keys in LDS, so a key that
 // occurs in every tile costs nothing extra.  256 threads, ~21 KB LDS, so every block of a
@@ -529,7 +538,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   unsigned short* tstart = tpre + w.ntiles;
 
   const int tid = threadIdx.x;
-  const unsigned p = blockIdx.x;
+  const unsigned p = xcd_partition(blockIdx.x, w.P);
   const unsigned NT = w.ntiles;
   const int D = a.tv.dim;
   KV_STAMPP(0);
@@ -906,7 +915,7 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
   __shared__ unsigned lnu, lsent, lbase, lovf;
 
   const int tid = threadIdx.x;
-  const unsigned p = blockIdx.x;
+  const unsigned p = xcd_partition(blockIdx.x, w.P);
   const unsigned NT = w.ntiles;
   constexpr unsigned GPB = TBS / LPR;
   const int lane = tid % LPR;
