@@ -26,7 +26,7 @@ constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
 constexpr int MAX_P = 2048;      // partitions (power of two); 1024 up to 1 M ids, 2048 for 2 M
 constexpr int HEAVY = 16;        // entries of one key in one partition above which the block folds it (16: -2 us vs 32)
-constexpr int MAX_CHUNKS = 16384;   // 2^16-row chunks (no capacity hint) still reach 2^30 rows
+constexpr int MAX_CHUNKS = 32768;   // 2^16-row chunks (no capacity hint) still reach the 2^31-row limit
 
 enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4, MODE_UNIQUE = 5 };
 enum Opt { OPT_ADAM_V4 = 0, OPT_ADAM_V3 = 1, OPT_ADAGRAD = 2, OPT_FTRL = 3 };
