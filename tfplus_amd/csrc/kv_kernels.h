@@ -834,16 +834,25 @@ __host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, 
 // FindOrInsertUnsafe(var, filter_out != nullptr) kv_variable.h:382-408 and
 // FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear before accum (training_ops.cc:701-704)
 template <int OPT>
-__device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
-                                                unsigned* r0, unsigned* r1, unsigned* newbits) {
+__device__ __forceinline__ void probe_issue(const PartArgs& a, long long key, Entry* ev, Entry* e0, Entry* e1) {
   // hop 1: the home entries of every table, together
+  const unsigned long long hh = mix64((unsigned long long)key);
+  *ev = load_entry(&a.tv.entries[home_of(a.tv, key, hh)]);
+  *e0 = load_entry(&a.ts0.entries[home_of(a.ts0, key, hh)]);
+  *e1 = *e0;
+  if (OPT == OPT_FTRL) *e1 = load_entry(&a.ts1.entries[home_of(a.ts1, key, hh)]);
+}
+struct ProbeMid {  // between the two halves of a probe: rows found / created, hop-2 words in flight
+  unsigned rv, s0, s1, nb;
+  uint2 mv;
+  unsigned f0, f1;
+};
+template <int OPT>
+__device__ __forceinline__ void probe_rows(const PartArgs& a, long long key, const Entry& ev, const Entry& e0,
+                                           const Entry& e1, ProbeMid* pm) {
   const unsigned long long hh = mix64((unsigned long long)key);
   const unsigned long long pv = home_of(a.tv, key, hh), p0 = home_of(a.ts0, key, hh);
   const unsigned long long p1 = (OPT == OPT_FTRL) ? home_of(a.ts1, key, hh) : 0ull;
-  const Entry ev = load_entry(&a.tv.entries[pv]);
-  const Entry e0 = load_entry(&a.ts0.entries[p0]);
-  Entry e1 = e0;
-  if (OPT == OPT_FTRL) e1 = load_entry(&a.ts1.entries[p1]);
   unsigned rv = table_find_from(a.tv, key, pv, ev);
   unsigned s0 = table_find_from(a.ts0, key, p0, e0);
   unsigned s1 = (OPT == OPT_FTRL) ? table_find_from(a.ts1, key, p1, e1) : 0u;
@@ -869,9 +878,18 @@ __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key
     }
   }
   // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too)
-  const uint2 mv = load_freq_flags(a.tv, rv);
-  const unsigned f0 = meta_ptr(a.ts0, s0)->freq;
-  const unsigned f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
+  pm->mv = load_freq_flags(a.tv, rv);
+  pm->f0 = meta_ptr(a.ts0, s0)->freq;
+  pm->f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
+  pm->rv = rv; pm->s0 = s0; pm->s1 = s1;
+  pm->nb = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
+}
+template <int OPT>
+__device__ __forceinline__ void probe_commit(const PartArgs& a, const ProbeMid& pm, unsigned* tag, unsigned* r0,
+                                             unsigned* r1, unsigned* newbits) {
+  const unsigned rv = pm.rv, s0 = pm.s0, s1 = pm.s1, f0 = pm.f0, f1 = pm.f1;
+  const uint2 mv = pm.mv;
+  const bool vnew = pm.nb & 1u, new0 = pm.nb & 2u, new1 = pm.nb & 4u;
   *tag = rv; *r0 = 0; *r1 = 0; *newbits = vnew ? 1u : 0u;
   if (rv == 0u) return;
   if (!vnew) {
@@ -890,6 +908,15 @@ __device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key
   touch(a.ts0, s0, new0, f0);
   *r0 = s0;
   *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
+}
+template <int OPT>
+__device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
+                                                unsigned* r0, unsigned* r1, unsigned* newbits) {
+  Entry ev, e0, e1;
+  ProbeMid pm;
+  probe_issue<OPT>(a, key, &ev, &e0, &e1);
+  probe_rows<OPT>(a, key, ev, e0, e1, &pm);
+  probe_commit<OPT>(a, pm, tag, r0, r1, newbits);
 }
 
 template <int MODE, int OPT, int V, int LPR, int K>
@@ -1012,6 +1039,16 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
     }
     KV_STAMPP(1);
     const unsigned nu = lnu;
+    // apply: the first key of every thread has its home entries (hop 1 of the probes) requested
+    // here and used after the grouping and the heavy-key fold below, which hide that round trip
+    Entry pev, pe0, pe1;
+    long long pkey = 0;
+    constexpr bool EARLY = (MODE == MODE_APPLY) && K == 1;  // K = 2 rows have no registers to spare (occupancy)
+    if (EARLY && (unsigned)tid < nu) {
+      const unsigned h = ulist[tid];
+      pkey = (h == HSS) ? EMPTY_KEY : hkey[h];
+      probe_issue<OPT>(a, pkey, &pev, &pe0, &pe1);
+    }
     // ---- group the entries by key: offsets by a scan over the unique list ----------------------
     {
       constexpr int PER = (UCAPS + TBS - 1) / TBS;
@@ -1061,15 +1098,23 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
           a.out_keys[lbase + u] = (h == HSS) ? EMPTY_KEY : hkey[h];
         }
       }
-    } else {
+    }
+    auto finish_probes = [&]() {
+      if (MODE != MODE_APPLY) return;
       for (unsigned u = tid; u < nu; u += TBS) {
-        const unsigned h = ulist[u];
         unsigned tag, r0, r1, nb;
-        probe_for_apply<OPT>(a, (h == HSS) ? EMPTY_KEY : hkey[h], &tag, &r0, &r1, &nb);
+        if (EARLY && u == (unsigned)tid) {
+          ProbeMid pm;  // (starting hop 2 before the fold as well measured no further gain)
+          probe_rows<OPT>(a, pkey, pev, pe0, pe1, &pm);
+          probe_commit<OPT>(a, pm, &tag, &r0, &r1, &nb);
+        } else {
+          const unsigned h = ulist[u];
+          probe_for_apply<OPT>(a, (h == HSS) ? EMPTY_KEY : hkey[h], &tag, &r0, &r1, &nb);
+        }
         utag[u] = tag; ur0[u] = r0; unew[u] = (unsigned char)nb;
         if (OPT == OPT_FTRL) ur1[u] = r1;
       }
-    }
+    };
     __syncthreads();
     KV_STAMPP(2);
 
@@ -1193,6 +1238,8 @@ __device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a)
         __syncthreads();
       }
     }
+    finish_probes();
+    __syncthreads();
     KV_STAMPP(3);
     // ---- (b) one group per key, keys in converged rounds: contributions and state rows are
     //      loaded together (all addresses known), then the fused update -------------------------
@@ -1368,7 +1415,7 @@ struct MultiDesc {
 template <int MODE>
 __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS) k_part_sum(WsDev w, PartArgs a) { part_sum_body<MODE, OPT, V, LPR, K>(w, a); }
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_part_sum(WsDev w, PartArgs a) { part_sum_body<MODE, OPT, V, LPR, K>(w, a); }
 template <int VQ>
 __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
   gather_body<VQ>(t, w, out, n);
@@ -1387,7 +1434,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __rest
   part_keys_body<MODE>(m.w, m.a);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS) k_part_sum_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_part_sum_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
   part_sum_body<MODE, OPT, V, LPR, K>(m.w, m.a);

@@ -53,3 +53,11 @@ r = pt[:, 11:15].astype(np.int64); t3 = pt[:, 3].astype(np.int64); t4 = pt[:, 4]
 ok = (r[:, 0] > 0) & (r[:, 2] > 0)
 print("   group 0 of each block, rows phase: start -> grads of round 0 summed %d ; round 0 -> 1 %d ; round 1 -> 2 %d ; last sum -> phase end %d (median ticks)" % (
     np.median(r[ok, 0] - t3[ok]), np.median(r[ok, 1] - r[ok, 0]), np.median(r[ok, 2] - r[ok, 1]), np.median(t4[ok] - r[ok, 2])))
+# blocks by entry count: where the tail comes from
+E = pt[:, 8].astype(np.int64); ph = np.diff(pt[:, :5].astype(np.int64), axis=1); tot = ph.sum(1)
+print("   by entries in the partition (the hottest keys add one entry per tile):")
+for lo, hi in ((0, 400), (400, 700), (700, 1000), (1000, 1300), (1300, 10**6)):
+  m = (E >= lo) & (E < hi)
+  if m.any():
+    print("     E in [%4d,%5s): %4d blocks  phases (median) %s  total median %d max %d" % (
+        lo, hi if hi < 10**6 else "inf", m.sum(), np.median(ph[m], axis=0).astype(int).tolist(), np.median(tot[m]), tot[m].max()))
