@@ -382,7 +382,7 @@ def main():
       "data": "synthetic",
       "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d per GPU, %d ids/batch per GPU Zipf(%.1f), "
                              "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
-                 "keys": K, "dim": D, "batch": N, "global_batch": N * world, "unique_per_batch": Ub,
+                 "keys": K, "dim": D, "batch": N, "zipf": args.zipf, "global_batch": N * world, "unique_per_batch": Ub,
                  "tile_single_rows_per_batch": Sb,
                  "parallelism": ("table hash-sharded over %d GPUs (id mod G), all_to_all id/row/grad exchange "
                                  "over RCCL" % world) if world > 1 else "single GPU"},

@@ -45,8 +45,18 @@ for n, v in pm.items():
   if fs is not None and ws is not None:
     traffic[n.split()[0]] = {"hbm_bytes": 2 * fs * 1024 + ws * 1024, "read_bytes": 2 * fs * 1024, "write_bytes": ws * 1024,
                              "fetch_size_kib_raw": fs, "write_size_kib_raw": ws}
+# the workload the counters were taken on (bench.py only reports traffic for the same one)
+workload = None
+try:
+  for line in open(os.path.join(out, "bench_under_trace.json")):
+    if line.startswith("{"):
+      c = json.loads(line)["config"]
+      workload = [c["keys"], c["batch"], c["dim"], c["zipf"]]
+except (OSError, ValueError, KeyError):
+  pass
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean of the last 3 launches; "
-                     "reads = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B)", "kernels": traffic},
+                     "reads = 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B)", "kernels": traffic,
+           "workload": workload},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
 try:
   b = json.load(open(os.path.join(out, "bench_under_trace.json")))
