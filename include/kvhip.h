@@ -159,6 +159,23 @@ int kv_dedup_segment_sum(kv_handle_t h, const void* ids, const float* grad, int6
 int kv_export_count(kv_handle_t h, int first_n, int64_t* counts, kv_stream_t stream);
 int kv_export_fill(kv_handle_t h, int first_n, int64_t* keys, float* values, int64_t* blacklist,
                    int64_t* freq_keys, uint32_t* freq_values, kv_stream_t stream);
+/* Delta lists.  Replaces the SUPPORT_DELTA_EXPORT / SUPPORT_PREDICTION_DELTA_EXPORT environment
+ * switches read by the KvVariable constructor (kernels/kv_variable.h:100-111): while on, training
+ * lookups, scatters / inserts, optimizer applies (keys the update reaches, on the var and every slot
+ * table) and deletes remember their keys (kv_variable.h:316,451,685,747,772,791-799).  Off by default. */
+int kv_set_delta_tracking(kv_handle_t h, int support_delta_export, int support_prediction_delta_export);
+/* Replaces KvVariableFullOrDeltaExport with need_full_export = false (kernels/kv_variable_ops.cc:
+ * 1064-1095) -> DeltaExport (kernels/dynamic_save.hpp:198-451).  Two-phase like kv_export_*:
+ * counts[4] = {num_rows, blacklist_nums, freq_nums, delete_nums}; then keys [num_rows], values
+ * [num_rows, dim], blacklist, freq_keys / freq_values (uint32 words; 0 for deleted keys), delete_keys.
+ * first_n <= 3 (prediction export) reads train + prediction lists and moves blacklisted keys to
+ * delete_keys; first_n > 4 adds the frequency words of every listed key.  The fill ends the export:
+ * the lists are emptied / handed on as dynamic_save.hpp:432-443 does (kv_export_fill with first_n > 2
+ * does the same, :179-192; kv_import empties both, dynamic_restore.hpp:258-259). */
+int kv_export_delta_count(kv_handle_t h, int first_n, int64_t* counts, kv_stream_t stream);
+int kv_export_delta_fill(kv_handle_t h, int first_n, int64_t* keys, float* values, int64_t* blacklist,
+                         int64_t* freq_keys, uint32_t* freq_values, int64_t* delete_keys,
+                         kv_stream_t stream);
 /* Replaces KvVariableImport (kernels/kv_variable_ops.cc:862-940) -> ImportValues
  * (kernels/dynamic_restore.hpp:29-195): clears the table, then loads keys/values, the
  * blacklist and the frequency words (NULL / 0 to skip). */

@@ -46,6 +46,8 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <mutex>
+#include <unordered_set>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -188,6 +190,20 @@ struct Table {
   int32_t fixed_day = -1;  // <0: wall clock (utility.cc:38-40)
   std::vector<float> zero_row;
   Segment* seg;
+  // train_deltalist_ / prediction_deltalist_ (kv_variable.h:870-873; tbb concurrent sets there)
+  bool track_delta = false, track_pred = false;
+  std::mutex delta_mu;
+  std::unordered_set<int64_t> train_delta, pred_delta;
+  void Mark(int64_t key) {  // if (NeedDeltaInfo()) train_deltalist_.insert(key)
+    if (!track_delta) return;
+    std::lock_guard<std::mutex> l(delta_mu);
+    train_delta.insert(key);
+  }
+  void AfterExport(int first_n) {  // dynamic_save.hpp:179-192 and :432-443
+    if (first_n <= 3) { pred_delta.clear(); return; }
+    if (track_pred) pred_delta.insert(train_delta.begin(), train_delta.end());
+    train_delta.clear();
+  }
 
   Table(int d, int thr) : dim(d), enter_threshold(SaturateMaxFrequency(thr)), zero_row(d, 0.f) {
     seg = new Segment[kSegments];
@@ -318,6 +334,7 @@ void kvo_gather_or_insert(void* h, const int64_t* ids, const int32_t* counts, in
   Shard(nthreads, n, [&](int64_t s, int64_t e) {
     for (int64_t i = s; i < e; ++i) {
       const int64_t key = ids[i];
+      t->Mark(key);  // kv_variable.h:316
       Segment& sg = t->seg[t->SegId(key)];
       sg.mu.lock_read();
       bool writer = false;
@@ -396,6 +413,7 @@ int kvo_apply_group_adam(void* hv, void* hs, const float* grad, const int64_t* i
       Meta* mv = tv->FindOrInsertUnsafe(key, &should_filter);   // :7148
       if (should_filter) { sg.mu.unlock(); continue; }          // :7150-7152
       Meta* ms = ts->FindOrInsertUnsafe(key, nullptr);          // :7155 (slot map not locked)
+      tv->Mark(key); ts->Mark(key);                             // MarkAsDeltaListElements :7196-7201
       float* x = mv->row;
       float* m = ms->row;
       float* v = ms->row + D;
@@ -456,6 +474,7 @@ int kvo_apply_adagrad(void* hv, void* ha, float lr, const float* grad, const int
       Meta* mv = tv->FindOrInsertUnsafe(key, &should_filter);
       if (should_filter) { sg.mu.unlock(); continue; }
       Meta* ma = ta->FindOrInsertUnsafe(key, nullptr);
+      tv->Mark(key); ta->Mark(key);  // training_ops.cc:1487-1488
       float* x = mv->row;
       float* a = ma->row;
       const float* g = grad + i * D;
@@ -498,6 +517,7 @@ int kvo_apply_sparse_group_ftrl(void* hv, void* ha, void* hl, const float* grad,
       if (should_filter) { sg.mu.unlock(); continue; }
       Meta* ml = tl->FindOrInsertUnsafe(key, nullptr);          // :701-702
       Meta* ma = ta->FindOrInsertUnsafe(key, nullptr);          // :703-704
+      tv->Mark(key); ta->Mark(key); tl->Mark(key);              // :765-767
       float* x = mv->row;
       float* z = ml->row;
       float* a = ma->row;
@@ -623,6 +643,56 @@ void kvo_export(void* h, int first_n, int64_t* counts, int64_t* keys, float* val
   }
   counts[0] = nr; counts[1] = nb; counts[2] = nf;
 }
+// end of a FullExport with first_n > 2 (dynamic_save.hpp:179-192); the caller's filling call is the export
+void kvo_after_export(void* h, int first_n) {
+  if (first_n > 2) static_cast<Table*>(h)->AfterExport(first_n);
+}
+
+void kvo_set_delta_tracking(void* h, int on, int pred_on) {
+  Table* t = static_cast<Table*>(h);
+  t->track_delta = on != 0; t->track_pred = pred_on != 0;
+}
+
+// DeltaExport dynamic_save.hpp:198-451.  counts[4] = {rows, blacklist, freq, delete}.  fill == 0
+// only counts; the filling call also ends the export (lists emptied / handed on, :432-443).
+void kvo_export_delta(void* h, int first_n, int fill, int64_t* counts, int64_t* keys, float* values,
+                      int64_t* blacklist, int64_t* freq_keys, uint32_t* freq_values, int64_t* delete_keys) {
+  Table* t = static_cast<Table*>(h);
+  const int D = t->dim;
+  std::unordered_set<int64_t> all(t->train_delta.begin(), t->train_delta.end());
+  if (first_n <= 3) all.insert(t->pred_delta.begin(), t->pred_delta.end());   // :222-228
+  std::vector<int64_t> upd, black, del;
+  for (int64_t key : all) {
+    Segment& sg = t->seg[t->SegId(key)];
+    auto it = sg.map.find(key);
+    if (it == sg.map.end()) { del.push_back(key); continue; }
+    if (t->LowFreq(it->second.freq)) continue;
+    if (it->second.in_black) { black.push_back(key); continue; }
+    upd.push_back(key);
+  }
+  if (first_n <= 3) { del.insert(del.end(), black.begin(), black.end()); black.clear(); }  // :345-351
+  counts[0] = int64_t(upd.size()); counts[1] = int64_t(black.size());
+  counts[2] = first_n > 4 ? int64_t(all.size()) : 0; counts[3] = int64_t(del.size());
+  if (!fill) return;
+  for (size_t i = 0; i < upd.size(); ++i) {
+    keys[i] = upd[i];
+    const Meta& m = t->seg[t->SegId(upd[i])].map.find(upd[i])->second;
+    std::memcpy(values + i * D, m.row, sizeof(float) * size_t(D));
+  }
+  for (size_t i = 0; i < black.size(); ++i) blacklist[i] = black[i];
+  for (size_t i = 0; i < del.size(); ++i) delete_keys[i] = del[i];
+  if (first_n > 4) {  // ExportFrequencyDelta kv_variable.h:937-957
+    size_t j = 0;
+    for (int64_t key : all) {
+      Segment& sg = t->seg[t->SegId(key)];
+      auto it = sg.map.find(key);
+      freq_keys[j] = key;
+      freq_values[j] = it == sg.map.end() ? 0u : it->second.freq;
+      ++j;
+    }
+  }
+  t->AfterExport(first_n);
+}
 
 // ScatterUpdate kv_variable.h:616-734.  op: 0 assign, 1 add, 2 sub, 3 mul, 4 div, 5 min, 6 max
 // (kv_variable_interface.h:44-52).  Existing key: row = op(row, update) unless blacklisted,
@@ -647,6 +717,7 @@ void kvo_scatter_update(void* h, const int64_t* ids, const float* upd, int64_t n
     }
   };
   for (int64_t i = 0; i < n; ++i) {
+    t->Mark(ids[i]);  // kv_variable.h:685
     Segment& sg = t->seg[t->SegId(ids[i])];
     auto it = sg.map.find(ids[i]);
     if (it != sg.map.end()) {
@@ -670,6 +741,7 @@ void kvo_insert(void* h, const int64_t* ids, const float* vals, int64_t n) {
   Table* t = static_cast<Table*>(h);
   const int D = t->dim;
   for (int64_t i = 0; i < n; ++i) {
+    t->Mark(ids[i]);  // kv_variable.h:451
     Segment& sg = t->seg[t->SegId(ids[i])];
     auto it = sg.map.find(ids[i]);
     if (it != sg.map.end()) {
@@ -705,10 +777,10 @@ void kvo_get_timestamp(void* h, const int64_t* ids, int64_t n, uint32_t* out) {
 }
 
 // Delete kv_variable.h:737-755 -> DeleteKey table_manager.h:405-416 (Evict + erase)
-int64_t kvo_delete(void* h, const int64_t* ids, int64_t n) {
-  Table* t = static_cast<Table*>(h);
+static int64_t DeleteKeys(Table* t, const int64_t* ids, int64_t n, bool mark) {
   int64_t gone = 0;
   for (int64_t i = 0; i < n; ++i) {
+    if (mark) t->Mark(ids[i]);  // kv_variable.h:747,772 (DeltaImport's DeleteKey calls do not, dynamic_restore.hpp:137-142)
     Segment& sg = t->seg[t->SegId(ids[i])];
     auto it = sg.map.find(ids[i]);
     if (it == sg.map.end()) continue;
@@ -718,6 +790,7 @@ int64_t kvo_delete(void* h, const int64_t* ids, int64_t n) {
   }
   return gone;
 }
+int64_t kvo_delete(void* h, const int64_t* ids, int64_t n) { return DeleteKeys(static_cast<Table*>(h), ids, n, true); }
 
 // DeleteWithTimestamp kv_variable.h:757-789: key_time > 0 && current_time - key_time >=
 // uint16(threshold).  Returns the number of deleted keys; out (may be null) receives them.
@@ -773,14 +846,14 @@ void kvo_import_delta(void* h, const int64_t* keys, const float* vals, int64_t n
       }
     }
   } else {
-    kvo_delete(h, black, nb);
+    DeleteKeys(t, black, nb, false);
   }
   for (int64_t i = 0; i < nf; ++i) {
     Segment& sg = t->seg[t->SegId(fkeys[i])];
     auto it = sg.map.find(fkeys[i]);
     if (it != sg.map.end()) it->second.freq = fvals[i];
   }
-  kvo_delete(h, dkeys, nd);
+  DeleteKeys(t, dkeys, nd, false);
   t->initialized = true;
 }
 
@@ -795,6 +868,7 @@ void kvo_import(void* h, const int64_t* keys, const float* vals, int64_t n, cons
     for (auto& kv : t->seg[s].map) std::free(kv.second.row);
     t->seg[s].map.clear();
   }
+  t->train_delta.clear(); t->pred_delta.clear();  // dynamic_restore.hpp:258-259
   for (int64_t i = 0; i < n; ++i) {
     Meta m;
     m.row = t->NewRow();

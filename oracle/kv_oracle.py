@@ -68,6 +68,9 @@ def lib():
                            _u32p, ctypes.c_int64]
   L.kvo_get_count.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, _i32p]
   L.kvo_get_timestamp.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, _u32p]
+  L.kvo_after_export.argtypes = [ctypes.c_void_p, ctypes.c_int]
+  L.kvo_set_delta_tracking.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+  L.kvo_export_delta.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _f32p, _i64p, _i64p, _u32p, _i64p]
   L.kvo_delete.restype = ctypes.c_int64
   L.kvo_delete.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64]
   L.kvo_delete_with_timestamp.restype = ctypes.c_int64
@@ -207,7 +210,25 @@ class OracleKv:
     fv = np.empty(cnt[2], np.uint32)
     lib().kvo_export(self._h, first_n, _p(cnt, _i64p), _p(keys, _i64p), _p(vals, _f32p),
                      _p(bl, _i64p), _p(fk, _i64p), _p(fv, _u32p))
+    lib().kvo_after_export(self._h, first_n)
     return keys, vals, bl, fk, fv
+
+  def set_delta_tracking(self, on=True, pred_on=False):
+    lib().kvo_set_delta_tracking(self._h, int(on), int(pred_on))
+
+  def export_delta(self, first_n=6):
+    """DeltaExport (dynamic_save.hpp:198-451): (keys, values, blacklist, freq_keys, freq_values, delete_keys)."""
+    cnt = np.zeros(4, np.int64)
+    lib().kvo_export_delta(self._h, first_n, 0, _p(cnt, _i64p), None, None, None, None, None, None)
+    keys = np.empty(cnt[0], np.int64)
+    vals = np.empty((cnt[0], self.dim), np.float32)
+    bl = np.empty(cnt[1], np.int64)
+    fk = np.empty(cnt[2], np.int64)
+    fv = np.empty(cnt[2], np.uint32)
+    dk = np.empty(cnt[3], np.int64)
+    lib().kvo_export_delta(self._h, first_n, 1, _p(cnt, _i64p), _p(keys, _i64p), _p(vals, _f32p), _p(bl, _i64p),
+                           _p(fk, _i64p), _p(fv, _u32p), _p(dk, _i64p))
+    return keys, vals, bl, fk, fv, dk
 
   def as_dict(self):
     k, v, *_ = self.export(2)

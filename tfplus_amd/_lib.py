@@ -53,6 +53,9 @@ SIGNATURES = {
     "kv_dedup_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     "kv_export_count": (_i32, [_vp, _i32, _c.POINTER(_i64), _vp]),
     "kv_export_fill": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kv_set_delta_tracking": (_i32, [_vp, _i32, _i32]),
+    "kv_export_delta_count": (_i32, [_vp, _i32, _c.POINTER(_i64), _vp]),
+    "kv_export_delta_fill": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kv_import": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "kv_import_delta": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),

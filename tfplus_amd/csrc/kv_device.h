@@ -43,7 +43,9 @@ struct RowMeta {
   long long key;
   unsigned freq;          // (day << 16) | saturating u16 count
   unsigned char flags;    // FLAG_*
-  unsigned char pad[3];
+  unsigned char delta_train;  // key is in train_deltalist_ (kv_variable.h:870; set only while the table tracks deltas)
+  unsigned char delta_pred;   // key is in prediction_deltalist_ (:871)
+  unsigned char pad;
 };
 static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
 
@@ -67,6 +69,7 @@ struct TableDev {
   int dim;
   unsigned enter_threshold;
   unsigned long long seed;
+  unsigned track_delta;     // NeedDeltaInfo() kv_variable.h:816: touched keys are remembered for DeltaExport
 };
 
 // device view of the per-batch workspace (kv_kernels.h explains the pipeline)
@@ -125,6 +128,11 @@ __device__ __forceinline__ RowMeta* meta_ptr(const TableDev& t, unsigned r) {
 __device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->freq; }
 __device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->flags; }
 __device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->key; }
+// train_deltalist_.insert(key) (kv_variable.h:316,451,685; MarkAsDeltaListElements :791-799): one byte in the
+// row's own RowMeta record, a plain store by the key's single owner thread
+__device__ __forceinline__ void mark_delta(const TableDev& t, unsigned r) {
+  if (t.track_delta) meta_ptr(t, r)->delta_train = 1;
+}
 // frequency word and flags of a row with ONE 8-byte load: .x = freq word, .y & 0xFF = flags
 __device__ __forceinline__ uint2 load_freq_flags(const TableDev& t, unsigned r) {
   return *reinterpret_cast<const uint2*>(&meta_ptr(t, r)->freq);
@@ -230,6 +238,7 @@ claimed:
   }
   slot->row = r;
   *key_ptr(t, r) = key;
+  { RowMeta* nm = meta_ptr(t, r); nm->delta_train = 0; nm->delta_pred = 0; }  // fresh (or recycled) row: in no delta list yet
   *inserted = true;
   return r;
 }

@@ -676,6 +676,9 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         if (sl[k] == 0xFFFFFFFFu || r[k] == 0u) continue;
         const unsigned s = sl[k];
         RowMeta* mp = meta_ptr(a.tv, r[k]);
+        // FindOrInsert / ScatterUpdate / InsertOrUpdate remember every key they see (kv_variable.h:316,451,685);
+        // the import paths (is_insert 2, 3) and the blacklist / frequency marks do not
+        if (MODE == MODE_LOOKUP || (MODE == MODE_SCATTER && a.is_insert < 2)) mark_delta(a.tv, r[k]);
         if (MODE == MODE_LOOKUP) {
           // find_func / insert_func (kv_variable.h:320-363): lo16 = sat_add(lo16, batch count),
           // hi16 = today; UpdateUnderThreshold only has work to do when the row changed since the
@@ -906,6 +909,12 @@ __device__ __forceinline__ void probe_commit(const PartArgs& a, const ProbeMid& 
   };
   if (OPT == OPT_FTRL) { touch(a.ts1, s1, new1, f1); *r1 = s1; }  // FTRL probes linear before accum (training_ops.cc:701-704)
   touch(a.ts0, s0, new0, f0);
+  // MarkAsDeltaListElements on every table of the op, for the keys the update reaches (training_ops.cc:7196-7201)
+  if (__builtin_expect(a.tv.track_delta | a.ts0.track_delta | (OPT == OPT_FTRL ? a.ts1.track_delta : 0u), 0)) {
+    mark_delta(a.tv, rv);
+    if (s0) mark_delta(a.ts0, s0);
+    if (OPT == OPT_FTRL && s1) mark_delta(a.ts1, s1);
+  }
   *r0 = s0;
   *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
 }

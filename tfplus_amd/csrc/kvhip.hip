@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 #include <ctime>
 #include <mutex>
 #include <string>
@@ -203,6 +204,56 @@ __global__ void k_export(TableDev t, unsigned nrows, int first_n, int fill, unsi
   }
 }
 
+// DeltaExport dynamic_save.hpp:198-451 over the rows whose delta bytes are set (train list, plus the
+// prediction list when first_n <= 3).  cnt[0] = update rows, [1] = blacklisted keys, [2] = all delta rows.
+// Order per key as in :231-248: low frequency -> only in the frequency list; blacklisted -> black list
+// (the caller hands the delete list as `black` when first_n <= 3, :345-351); else key + row.
+__global__ void k_export_delta(TableDev t, unsigned nrows, int first_n, int fill, unsigned long long* cnt,
+                               long long* keys, float* values, long long* black, long long* fkeys,
+                               unsigned* fvals) {
+  const int D = t.dim;
+  for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    const RowMeta m = *meta_ptr(t, r);
+    if (m.flags & FLAG_FREE) continue;
+    if (!(m.delta_train || (first_n <= 3 && m.delta_pred))) continue;
+    if (first_n > 4) {  // ExportFrequencyDelta kv_variable.h:937-957: the whole 32-bit word
+      unsigned long long p = atomicAdd(&cnt[2], 1ull);
+      if (fill && fkeys) { fkeys[p] = m.key; fvals[p] = m.freq; }
+    }
+    if ((m.freq & 0xFFFFu) < t.enter_threshold) continue;
+    if (m.flags & FLAG_BLACK) {
+      unsigned long long p = atomicAdd(&cnt[1], 1ull);
+      if (fill && black) black[p] = m.key;
+      continue;
+    }
+    unsigned long long p = atomicAdd(&cnt[0], 1ull);
+    if (fill) {
+      keys[p] = m.key;
+      const float* row = row_ptr(t, r);
+      for (int e = 0; e < D; ++e) values[p * D + e] = row[e];
+    }
+  }
+}
+// keys recorded by Delete: one that has a row again is a live member of the list (its row carries the
+// byte from here on), one without stays a "deleted" member.  which: 0 train list, 1 prediction list
+__global__ void k_delta_resolve(TableDev t, const long long* keys, long long n, int which, unsigned char* present) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const unsigned r = table_find(t, keys[i]);
+    present[i] = r ? 1 : 0;
+    if (r) { if (which == 0) meta_ptr(t, r)->delta_train = 1; else meta_ptr(t, r)->delta_pred = 1; }
+  }
+}
+// end of an export (dynamic_save.hpp:179-192, 432-443).  mode 0 (training export): the train list moves
+// to the prediction list (if kept) and empties; mode 1 (prediction export): the prediction list empties
+__global__ void k_delta_clear(TableDev t, unsigned nrows, int mode, int keep_pred) {
+  for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    RowMeta* m = meta_ptr(t, r);
+    if (mode == 1) { if (m->delta_pred) m->delta_pred = 0; continue; }
+    if (m->delta_train) { if (keep_pred) m->delta_pred = 1; m->delta_train = 0; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -277,6 +328,10 @@ struct kv_table {
   long long init_rows = 0;
   bool initialized = false;
   Workspace ws;
+  // delta lists (SUPPORT_DELTA_EXPORT / SUPPORT_PREDICTION_DELTA_EXPORT, kv_variable.h:100-111): live keys
+  // carry a byte in their RowMeta; keys recorded by Delete have no row and wait here
+  bool track_delta = false, track_pred = false;
+  std::vector<long long> del_train, del_pred;
   unsigned long long* d_stat = nullptr;  // [4]
   std::mutex mu;
   unsigned* route_hist = nullptr;  // kv_bucket_by_owner scratch
@@ -330,6 +385,7 @@ TableDev dev_view(const kv_table* t) {
   d.dim = t->dim;
   d.enter_threshold = t->enter_threshold;
   d.seed = t->seed;
+  d.track_delta = t->track_delta ? 1u : 0u;
   return d;
 }
 
@@ -417,6 +473,8 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
 // 2048 blocks in two waves; with 1024 the hot partitions overflow the LDS entry lists and split:
 // measured 331 us vs 2 x 70)
 unsigned pick_partitions(long long n) {
+  static const long long forced = [] { const char* e = getenv("KV_FORCE_P"); return e ? atoll(e) : 0ll; }();
+  if (forced > 0) return (unsigned)forced;  // diagnostic A/B only (tools/)
   unsigned long long want = std::min<unsigned long long>(1024, (unsigned long long)((n + 31) / 32));
   want = std::max<unsigned long long>(want, (unsigned long long)((n + 1023) / 1024));
   unsigned P = 1;
@@ -641,6 +699,77 @@ int apply_prologue(kv_table* v, std::initializer_list<kv_table*> slots, const fl
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// keys recorded by Delete while the table tracks deltas (kv_variable.h:747,772): no row carries them
+static int record_deleted(kv_table* t, const void* ids, int64_t n, bool int32_ids, hipStream_t s) {
+  if (!t->track_delta || n <= 0) return KV_OK;
+  const size_t base = t->del_train.size();
+  t->del_train.resize(base + (size_t)n);
+  if (int32_ids) {
+    std::vector<int> tmp((size_t)n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i) t->del_train[base + (size_t)i] = tmp[(size_t)i];
+  } else {
+    HIP_TRY(hipMemcpyAsync(t->del_train.data() + base, ids, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return KV_OK;
+}
+
+// one recorded list: sorted, unique; keys that have a row again hand their membership to that row
+static int delta_resolve(kv_table* t, std::vector<long long>* list, int which, hipStream_t s) {
+  std::sort(list->begin(), list->end());
+  list->erase(std::unique(list->begin(), list->end()), list->end());
+  const size_t n = list->size();
+  if (n == 0) return KV_OK;
+  long long* dk = nullptr;
+  unsigned char* dp = nullptr;
+  HIP_TRY(hipMalloc(&dk, n * sizeof(long long)));
+  if (hipMalloc(&dp, n) != hipSuccess) { hipFree(dk); return fail(KV_RESOURCE_EXHAUSTED, "delta export scratch"); }
+  std::vector<unsigned char> present(n);
+  hipError_t e = hipMemcpyAsync(dk, list->data(), n * sizeof(long long), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    k_delta_resolve<<<nblocks((long long)n, TB, 4096), TB, 0, s>>>(dev_view(t), dk, (long long)n, which, dp);
+    e = hipMemcpyAsync(present.data(), dp, n, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(dk); hipFree(dp);
+  if (e != hipSuccess) return fail(KV_INTERNAL, "delta export: %s", hipGetErrorString(e));
+  size_t o = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (!present[i]) (*list)[o++] = (*list)[i];
+  list->resize(o);
+  return KV_OK;
+}
+
+// all_delta minus the keys that have rows (dynamic_save.hpp:213-228): the recorded deletions still absent
+static int delta_prepare(kv_table* t, int first_n, hipStream_t s, std::vector<long long>* absent) {
+  int rc;
+  if ((rc = delta_resolve(t, &t->del_train, 0, s))) return rc;
+  *absent = t->del_train;
+  if (first_n <= 3) {
+    if ((rc = delta_resolve(t, &t->del_pred, 1, s))) return rc;
+    std::vector<long long> u;
+    std::set_union(t->del_train.begin(), t->del_train.end(), t->del_pred.begin(), t->del_pred.end(), std::back_inserter(u));
+    absent->swap(u);
+  }
+  return KV_OK;
+}
+
+static int delta_after_export(kv_table* t, int first_n, unsigned nrows, hipStream_t s) {
+  if (!t->track_delta && !t->track_pred && t->del_train.empty() && t->del_pred.empty()) return KV_OK;
+  const int mode = first_n <= 3 ? 1 : 0;
+  k_delta_clear<<<nblocks(nrows, TB, 2048), TB, 0, s>>>(dev_view(t), nrows, mode, t->track_pred ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  if (mode == 1) {
+    t->del_pred.clear();
+  } else {
+    if (t->track_pred) t->del_pred.insert(t->del_pred.end(), t->del_train.begin(), t->del_train.end());
+    t->del_train.clear();
+  }
+  return KV_OK;
+}
+
 extern "C" {
 
 const char* kv_last_error(void) { return g_err.c_str(); }
@@ -1536,6 +1665,7 @@ int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, k
   if (n == 0) return KV_OK;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = record_deleted(t, ids, n, t->key_dtype == KV_DT_INT32, (hipStream_t)stream))) return rc;
   return delete_locked(t, ids, n, num_deleted, (hipStream_t)stream);
 }
 
@@ -1581,6 +1711,7 @@ int kv_delete_with_timestamp(kv_handle_t t, int threshold, int dry_run, int64_t*
     return rc;
   }
   *count = (int64_t)rel;
+  if (!dry_run && (rc = record_deleted(t, out_keys, (int64_t)rel, false, s))) return rc;
   return KV_OK;
 }
 
@@ -1717,7 +1848,78 @@ int kv_export_fill(kv_handle_t t, int first_n, int64_t* keys, float* values, int
                                                    (long long*)keys, values, (long long*)blacklist,
                                                    (long long*)fkeys, fvals);
   HIP_TRY(hipGetLastError());
+  if (first_n > 2 && (rc = delta_after_export(t, first_n, nrows, s))) return rc;  // dynamic_save.hpp:179-192
   return KV_OK;
+}
+
+int kv_set_delta_tracking(kv_handle_t t, int support_delta_export, int support_prediction_delta_export) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  std::lock_guard<std::mutex> l(t->mu);
+  t->track_delta = support_delta_export != 0;
+  t->track_pred = support_prediction_delta_export != 0;
+  return KV_OK;
+}
+
+int kv_export_delta_count(kv_handle_t t, int first_n, int64_t* counts, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!counts) return fail(KV_INVALID_ARGUMENT, "counts pointer is null");
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned nrows = 1;
+  if ((rc = stats(t, s, nullptr, &nrows))) return rc;
+  std::vector<long long> absent;
+  if ((rc = delta_prepare(t, first_n, s, &absent))) return rc;
+  HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
+  k_export_delta<<<nblocks(nrows, TB, 2048), TB, 0, s>>>(dev_view(t), nrows, first_n, 0, t->d_stat, nullptr,
+                                                         nullptr, nullptr, nullptr, nullptr);
+  unsigned long long c[3];
+  HIP_TRY(hipMemcpyAsync(c, t->d_stat, sizeof c, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  counts[0] = (int64_t)c[0];
+  counts[1] = first_n > 3 ? (int64_t)c[1] : 0;
+  counts[2] = first_n > 4 ? (int64_t)(c[2] + absent.size()) : 0;
+  counts[3] = (int64_t)absent.size() + (first_n > 3 ? 0 : (int64_t)c[1]);
+  return KV_OK;
+}
+
+int kv_export_delta_fill(kv_handle_t t, int first_n, int64_t* keys, float* values, int64_t* blacklist,
+                         int64_t* fkeys, uint32_t* fvals, int64_t* delete_keys, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!t->initialized)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned nrows = 1;
+  if ((rc = stats(t, s, nullptr, &nrows))) return rc;
+  std::vector<long long> absent;
+  if ((rc = delta_prepare(t, first_n, s, &absent))) return rc;
+  HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
+  // prediction exports move the blacklisted keys to the delete list (dynamic_save.hpp:345-351)
+  k_export_delta<<<nblocks(nrows, TB, 2048), TB, 0, s>>>(dev_view(t), nrows, first_n, 1, t->d_stat, (long long*)keys,
+                                                         values, (long long*)(first_n > 3 ? blacklist : delete_keys),
+                                                         (long long*)fkeys, fvals);
+  HIP_TRY(hipGetLastError());
+  unsigned long long c[3];
+  HIP_TRY(hipMemcpyAsync(c, t->d_stat, sizeof c, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (!absent.empty()) {  // keys without a row: deleted (:233-236), frequency 0 (kv_variable.h:950)
+    if (!delete_keys) return fail(KV_INVALID_ARGUMENT, "delete_keys pointer is null");
+    const size_t off = first_n > 3 ? 0 : (size_t)c[1];
+    HIP_TRY(hipMemcpyAsync(delete_keys + off, absent.data(), absent.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+    if (first_n > 4 && fkeys && fvals) {
+      HIP_TRY(hipMemcpyAsync(fkeys + c[2], absent.data(), absent.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemsetAsync(fvals + c[2], 0, absent.size() * sizeof(uint32_t), s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // `absent` is the copy source
+  }
+  return delta_after_export(t, first_n, nrows, s);
 }
 
 // insert / scatter / import marks: tile pass (dedup) -> partition pass on the unique keys
@@ -1850,6 +2052,7 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   k_fill_entries<<<nblocks((long long)t->cap + 1, TB, 8192), TB, 0, s>>>(t->entries, t->cap + 1);
   t->rows_ub = 1;
   t->idx_ub = t->idx_base = 0; t->bump_base = 1; t->pushes_since = 0; t->free_base = 0; t->free_known = 0;
+  t->del_train.clear(); t->del_pred.clear();  // dynamic_restore.hpp:258-259 (the rows start over, and so do their bytes)
   if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 2, -1, nullptr, s))) return rc;
   if (n_black > 0 && (rc = scatter_like(t, blacklist, nullptr, n_black, 0, 1, 0, nullptr, s))) return rc;
   if (n_freq > 0 && (rc = scatter_like(t, fkeys, nullptr, n_freq, 0, 1, 1, fvals, s))) return rc;

@@ -321,14 +321,33 @@ def kv_variable_full_or_delta_import(table_handle, keys, values, blacklist=None,
                                         _p(dk), n(dk), int(first_n), _stream(table_handle)))
 
 
+def kv_set_delta_tracking(table_handle, support_delta_export=True, support_prediction_delta_export=False):
+  """The SUPPORT_DELTA_EXPORT / SUPPORT_PREDICTION_DELTA_EXPORT switches of the KvVariable constructor
+  (kernels/kv_variable.h:100-111), per table instead of per process."""
+  _lib.check(_lib.lib().kv_set_delta_tracking(table_handle.ptr, int(bool(support_delta_export)),
+                                              int(bool(support_prediction_delta_export))))
+
+
 def kv_variable_full_or_delta_export(table_handle, do_full_export=True, first_n=3, enable_cutoff=False, cutoff_value=0.0):
-  """REGISTER_OP("KvVariableFullOrDeltaExport") ops/kv_variable_ops.cc:633-660.  Full exports only:
-  (keys, values, blacklist, freq_keys, freq_values, need_full_import=True, delete_keys=[]).  The delta
-  list behind do_full_export=False (SUPPORT_DELTA_EXPORT, kv_variable.h:103-111) is not tracked here."""
-  if not do_full_export:
-    raise _lib.UnimplementedError("delta export: the train/prediction delta lists (SUPPORT_DELTA_EXPORT) are not tracked")
-  k, v, bl, fk, fv = kv_variable_export(table_handle, first_n=first_n)
-  return k, v, bl, fk, fv, True, torch.empty(0, dtype=torch.int64, device=k.device)
+  """REGISTER_OP("KvVariableFullOrDeltaExport") ops/kv_variable_ops.cc:633-660 ->
+  (keys, values, blacklist, freq_keys, freq_values, need_full_import, delete_keys).  do_full_export ->
+  FullExport (need_full_import = True, no delete keys); otherwise DeltaExport (dynamic_save.hpp:198-451):
+  only the keys touched since the last export (kv_set_delta_tracking), need_full_import = False."""
+  if do_full_export:
+    k, v, bl, fk, fv = kv_variable_export(table_handle, first_n=first_n)
+    return k, v, bl, fk, fv, True, torch.empty(0, dtype=torch.int64, device=k.device)
+  cnt = (ctypes.c_int64 * 4)()
+  _lib.check(_lib.lib().kv_export_delta_count(table_handle.ptr, int(first_n), cnt, _stream(table_handle)))
+  dev = _dev(table_handle)
+  keys = torch.empty(cnt[0], dtype=torch.int64, device=dev)
+  vals = torch.empty((cnt[0], table_handle.dim), dtype=torch.float32, device=dev)
+  bl = torch.empty(cnt[1], dtype=torch.int64, device=dev)
+  fk = torch.empty(cnt[2], dtype=torch.int64, device=dev)
+  fv = torch.empty(cnt[2], dtype=torch.int32, device=dev)
+  dk = torch.empty(cnt[3], dtype=torch.int64, device=dev)
+  _lib.check(_lib.lib().kv_export_delta_fill(table_handle.ptr, int(first_n), _p(keys), _p(vals), _p(bl), _p(fk),
+                                             _p(fv), _p(dk), _stream(table_handle)))
+  return keys, vals, bl, fk, fv, False, dk
 
 
 def kv_variable_insert_v2(table_handle, indices, values, name=None):
