@@ -227,7 +227,9 @@ REGISTER_KERNEL_BUILDER(Name("KvVariableGroupSparseApplyAdamV3").Device(DEVICE_C
 
 // KvVariableSparseApplyAdagrad, KvVariableSparseGroupSparseApplyFtrlV2, KvVariableSizeV2,
 // KvVariableFrequency, ReadKvVariableOpV2, KvVariableScatter*V2, KvVariableInsertV2 and
-// KvVariableImport/Export follow the same pattern over kv_apply_adagrad,
-// kv_apply_sparse_group_ftrl, kv_size, kv_sum_freq, kv_export_*, kv_scatter_update, kv_insert,
-// kv_import (INTEGRATION.md lists the one-line mapping for each).
+// KvVariableImport/Export and KvVariableFullOrDeltaImport/Export follow the same pattern over
+// kv_apply_adagrad, kv_apply_sparse_group_ftrl, kv_size, kv_sum_freq, kv_export_*, kv_export_delta_*,
+// kv_scatter_update, kv_insert, kv_import, kv_import_delta (INTEGRATION.md lists the one-line mapping
+// for each); the KvVariable op's kernel calls kv_set_delta_tracking once from SUPPORT_DELTA_EXPORT /
+// SUPPORT_PREDICTION_DELTA_EXPORT, as the reference constructor reads them (kv_variable.h:100-111).
 }  // namespace tfplus_hip
