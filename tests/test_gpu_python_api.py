@@ -347,3 +347,55 @@ def test_pairs_lookup_and_two_level_take():
   i1 = torch.randint(0, 300, (200,), generator=g).cuda()
   i2 = torch.randint(0, 200, (1000,), generator=g).cuda()
   assert torch.equal(ops.kv_take_rows(src, i1, index_outer=i2), src[i1[i2]])
+
+
+@pytest.mark.gpu
+def test_full_then_delta_checkpoints_rebuild_the_table(api, tmp_path):
+  """A full checkpoint followed by delta checkpoints (KvVariableFullOrDeltaExport / Import through
+  KvVariableSaveable, kv_variable_ops.py:1520-1648) must rebuild the table exactly: rows, blacklist,
+  frequency words, and the keys deleted between two deltas stay deleted."""
+  a = api
+  D = 8
+  mk = lambda n, init: a.vs.get_kv_variable(n, embedding_dim=D, initializer=init)
+  src = mk("dc_src", a.vs.random_normal_initializer(seed=3))
+  src.enable_delta_export(True, False)
+  opt = a.tr.GroupAdamOptimizer(0.05, l1_regularization_strength=1e-4, l21_regularization_strength=4e-3)
+  g = torch.Generator().manual_seed(11)
+
+  def train(lo, hi, n):
+    ids = torch.randint(lo, hi, (n,), generator=g)
+    src.sparse_read(ids)
+    opt.apply_gradients([(a.kv.IndexedSlices(torch.randn(n, D, generator=g) * 0.02, ids, None), src)])
+
+  paths = []
+  train(-200, 200, 2000)
+  paths.append(str(tmp_path / "full0")); src.save(paths[-1])                       # full checkpoint
+  train(100, 400, 1500)                                                             # old and new keys
+  paths.append(str(tmp_path / "delta1")); src.save(paths[-1], do_full_export=False)
+  src.delete(torch.arange(-200, -150))
+  train(350, 500, 800)
+  src.delete(torch.arange(480, 500))
+  paths.append(str(tmp_path / "delta2")); src.save(paths[-1], do_full_export=False)
+  z1, z2 = np.load(paths[1] + ".npz"), np.load(paths[2] + ".npz")
+  assert not bool(z1["need_full_import"][0]) and z1["init_table"].shape[0] == 0
+  assert 0 < z1["keys"].size + z1["blacklist"].size <= 300        # only what the second phase touched
+  assert set(range(-200, -150)) <= set(z2["delete_keys"].tolist())
+  # an empty delta when nothing happened since
+  sv = a.kv.KvVariableSaveable(src, "dc_src", do_full_export=False)
+  assert all(sv.tensors["dc_src-" + n].numel() == 0 for n in ("keys", "blacklist", "freq_keys", "delete_keys"))
+  assert list(sv.tensors) == ["dc_src-" + n for n in a.kv.KvVariableSaveable.NAMES]
+
+  dst = mk("dc_dst", a.vs.zeros_initializer())
+  for p in paths:
+    dst.load(p)
+  es, ed = src.export(6), dst.export(6)
+  assert sorted(es[0].tolist()) == sorted(ed[0].tolist()) and len(es[0]) > 0          # keys
+  assert sorted(es[2].tolist()) == sorted(ed[2].tolist())                            # blacklist
+  assert dict(zip(es[3].tolist(), es[4].tolist())) == dict(zip(ed[3].tolist(), ed[4].tolist()))   # frequency words
+  q = torch.arange(-250, 550)
+  a.kv.set_training(False)
+  try:
+    assert torch.equal(dst.sparse_read(q).cpu(), src.sparse_read(q).cpu())
+  finally:
+    a.kv.set_training(True)
+  assert dst.total_count == src.total_count and dst.total_freq == src.total_freq

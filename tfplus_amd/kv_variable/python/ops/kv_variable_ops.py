@@ -195,24 +195,42 @@ class KvVariable(object):
                                                          count_occurrences)
 
   # -- checkpoint payload -----------------------------------------------------------------------------
-  def save(self, path, first_n=6):
-    """Writes what KvVariableExport hands the saver (kv_variable_ops.py:1599-1648: keys, values,
-    init_table, blacklist, freq_keys, freq_values) to one .npz; the TF bundle format, sharded saves
-    and delta exports are outside this build."""
-    k, v, bl, fk, fv = gen_kv_variable_ops.kv_variable_export(self._handle, first_n=first_n)
-    np.savez(path, keys=k.cpu().numpy(), values=v.cpu().numpy(), init_table=self._initial_value.cpu().numpy(),
-             blacklist=bl.cpu().numpy(), freq_keys=fk.cpu().numpy(), freq_values=fv.cpu().numpy().view(np.uint32),
-             embedding_dim=np.int64(self._embedding_dim), enter_threshold=np.int64(self._enter_threshold))
+  def enable_delta_export(self, support_delta_export=True, support_prediction_delta_export=False):
+    """SUPPORT_DELTA_EXPORT / SUPPORT_PREDICTION_DELTA_EXPORT (kernels/kv_variable.h:100-111): from now on the
+    table remembers the keys it touches, so save(do_full_export=False) writes only those."""
+    gen_kv_variable_ops.kv_set_delta_tracking(self._handle, support_delta_export, support_prediction_delta_export)
+
+  def export_tensors(self, name=None, do_full_export=True, saver_mode=1):
+    """KvVariable.export (kv_variable_ops.py:1433-1459): an ordered dict `<name>-keys`, `-values`, `-init_table`,
+    `-blacklist`, `-freq_keys`, `-freq_values`, `-need_full_import`, `-delete_keys` from
+    KvVariableFullOrDeltaExport; saver_mode 0 (inference) exports with first_n = 3, training with 8."""
+    name = name or self._name
+    first_n = 3 if saver_mode == 0 else 8
+    k, v, bl, fk, fv, need_full, dk = gen_kv_variable_ops.kv_variable_full_or_delta_export(
+        self._handle, do_full_export=do_full_export, first_n=first_n)
+    # a delta carries an empty init table (dynamic_save.hpp:318-336)
+    init = self._initial_value if do_full_export else torch.empty((0, self._embedding_dim))
+    vals = (k, v, init, bl, fk, fv, torch.tensor([bool(need_full)]), dk)
+    return collections.OrderedDict((name + "-" + n, t) for n, t in zip(KvVariableSaveable.NAMES, vals))
+
+  def save(self, path, first_n=None, do_full_export=True, saver_mode=1):
+    """Writes what KvVariableSaveable hands the saver (kv_variable_ops.py:1520-1545) to one .npz: a full
+    export, or (do_full_export=False, after enable_delta_export) the keys touched since the last export plus
+    the keys deleted since.  The TF bundle format and sharded saves are outside this build."""
+    sv = KvVariableSaveable(self, "kv", do_full_export=do_full_export, saver_mode=saver_mode)
+    out = {n.split("-")[-1]: (t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)) for n, t in sv.tensors.items()}
+    out["freq_values"] = out["freq_values"].view(np.uint32)
+    np.savez(path, embedding_dim=np.int64(self._embedding_dim), enter_threshold=np.int64(self._enter_threshold),
+             saver_mode=np.int64(saver_mode), **out)
 
   def load(self, path):
-    """KvVariableImport of a file written by save(): the table is cleared and refilled."""
+    """KvVariableFullOrDeltaImport of a file written by save(): a full checkpoint clears and refills the
+    table, a delta checkpoint is applied on top of what is loaded (dynamic_restore.hpp:29-155)."""
     z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
     if int(z["embedding_dim"]) != self._embedding_dim:
       raise ValueError("checkpoint has dim %d, variable has %d" % (int(z["embedding_dim"]), self._embedding_dim))
-    self._initial_value = torch.from_numpy(z["init_table"])
-    gen_kv_variable_ops.kv_variable_import(self._handle, z["keys"], z["values"], z["blacklist"], z["freq_keys"],
-                                           z["freq_values"])
-    gen_kv_variable_ops.init_kv_variable_v2(self._handle, self._initial_value)
+    KvVariableSaveable.restore_into(self, {n: z[n] for n in KvVariableSaveable.NAMES},
+                                    saver_mode=int(z["saver_mode"]) if "saver_mode" in z else 1)
     return self
 
   # -- whole-table reads / assignment (kv_variable_ops.py:1011-1030, 1220-1246) -----------------------
@@ -339,3 +357,44 @@ def scatter_add(ref, indices, updates, use_locking=True, name=None):
 
 def scatter_sub(ref, indices, updates, use_locking=True, name=None):
   return ref.scatter_sub(IndexedSlices(updates, indices, None))
+
+
+class KvVariableSaveable(object):
+  """kv_variable_ops.py:1520-1648: the tensors a KvVariable hands the saver (export at construction, as the
+  reference's SaveableObject does) and the restore that feeds them back through
+  KvVariableFullOrDeltaImport + InitKvVariableV2.  saver_mode 0 (tfplus_saver_mode: inference) keeps only
+  keys / values / init_table (+ the two delta outputs) and restores the rest as empty tensors."""
+  NAMES = ("keys", "values", "init_table", "blacklist", "freq_keys", "freq_values", "need_full_import", "delete_keys")
+
+  def __init__(self, var, name, do_full_export=True, saver_mode=1):
+    self._var, self.name, self._saver_mode = var, name, saver_mode
+    self.tensors = var.export_tensors(name, do_full_export=do_full_export, saver_mode=saver_mode)
+    if saver_mode == 0:      # specs[:3] + specs[6:] are saved, the rest restores as empty (kv_variable_ops.py:1540-1544)
+      for n in self.NAMES[3:6]:
+        self.tensors[name + "-" + n] = self.tensors[name + "-" + n][:0]
+    self.specs = [(n, t) for n, t in self.tensors.items()]
+
+  @property
+  def var(self):
+    return self._var
+
+  def restore(self, restored_tensors):
+    """restored_tensors: the tensors of `specs`, in that order (or a dict by tensor name)."""
+    if not isinstance(restored_tensors, dict):
+      restored_tensors = dict(zip([n for n, _ in self.specs], restored_tensors))
+    by = {n.split("-")[-1]: t for n, t in restored_tensors.items()}
+    return self.restore_into(self._var, by, self._saver_mode)
+
+  @staticmethod
+  def restore_into(var, by, saver_mode=1):
+    first_n = 3 if saver_mode == 0 else 8
+    need_full = bool(np.asarray(by["need_full_import"].cpu() if isinstance(by["need_full_import"], torch.Tensor)
+                                else by["need_full_import"]).reshape(-1)[0])
+    gen_kv_variable_ops.kv_variable_full_or_delta_import(
+        var.handle, by["keys"], by["values"], by["blacklist"], by["freq_keys"], by["freq_values"],
+        need_full_import=need_full, delete_keys=by["delete_keys"], first_n=first_n)
+    init = torch.as_tensor(by["init_table"], dtype=torch.float32)
+    if init.numel():         # a delta checkpoint carries no init table: the variable keeps its own
+      var._initial_value = init.cpu()
+    gen_kv_variable_ops.init_kv_variable_v2(var.handle, var._initial_value)
+    return var
