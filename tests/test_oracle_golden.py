@@ -239,3 +239,35 @@ def test_multithreaded_matches_single_thread():
   # table_manager.h:167-190), so concurrent hits on one key can lose counts: only the
   # single-threaded sum is exact
   assert a.sum_freq() == ids.size and b.sum_freq() <= ids.size
+
+
+def test_delta_export_known_answers():
+  """DeltaExport (dynamic_save.hpp:198-451) of the oracle on a hand-checked sequence: touched keys only, a
+  deleted key is a delete key with frequency 0, exports end the delta period, prediction exports (first_n <= 3)
+  read train + prediction lists and move blacklisted keys to the delete list."""
+  D = 4
+  t = ko.OracleKv(D, 2, np.ones((8, D), np.float32), day=DAY, picker=1, seed=1)
+  t.gather_or_insert(np.arange(10))                      # before tracking: in no list
+  t.set_delta_tracking(True, True)
+  t.gather_or_insert(np.array([1, 2, 3, 2, 11]))         # 11 is new: frequency 1 < enter_threshold 2
+  t.delete(np.array([3, 99]))
+  k, v, bl, fk, fv, dk = t.export_delta(6)
+  assert sorted(k.tolist()) == [1, 2] and bl.size == 0 and sorted(dk.tolist()) == [3, 99]
+  np.testing.assert_array_equal(v, np.ones((2, D), np.float32))
+  assert dict(zip(fk.tolist(), fv.tolist())) == {1: (DAY << 16) | 2, 2: (DAY << 16) | 3, 3: 0, 99: 0, 11: (DAY << 16) | 1}
+  assert all(x.size == 0 for x in t.export_delta(6))     # the training export emptied the train list ...
+  k, v, bl, fk, fv, dk = t.export_delta(3)               # ... into the prediction list (SUPPORT_PREDICTION_DELTA_EXPORT)
+  assert sorted(k.tolist()) == [1, 2] and sorted(dk.tolist()) == [3, 99] and fk.size == 0
+  assert all(x.size == 0 for x in t.export_delta(3))
+  # a key touched by scatter and then blacklisted by a group-lasso apply (key 2: frequency 3 >= enter_threshold)
+  slot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY, picker=1, seed=1)
+  slot.set_delta_tracking(True, False)
+  t.scatter_update(np.array([2, 5]), np.ones((2, D), np.float32), 1)
+  ko.apply_group_adam(t, slot, np.full((1, D), 0.01, np.float32), np.array([2]), 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8,
+                      0.0, 0.0, 10.0)
+  ko.apply_group_adam(t, slot, np.full((1, D), 0.01, np.float32), np.array([11]), 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8)
+  k, v, bl, fk, fv, dk = t.export_delta(4)
+  # 5 (frequency 1) is listed by the scatter but exports nothing; 11 was filtered by the apply: never listed
+  assert k.size == 0 and bl.tolist() == [2] and dk.size == 0 and fk.size == 0
+  assert sorted(slot.export_delta(4)[0].tolist()) == [2]                           # the slot table keeps its own list
+  assert t.export_delta(3)[5].tolist() == [2]                                      # prediction export: blacklisted -> delete
