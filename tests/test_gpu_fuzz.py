@@ -45,7 +45,7 @@ class Pair(object):
 @pytest.mark.parametrize("seed", range(8))
 def test_random_program_matches_oracle(ops, seed):
   rng = np.random.default_rng(1000 + seed)
-  kd = torch.int32 if seed >= 6 else torch.int64        # int32 keys: same values, the narrow id path of every kernel
+  kd = torch.int32 if seed % 4 == 3 else torch.int64    # int32 keys: same values, the narrow id path of every kernel
   D = int(rng.choice([4, 8, 20, 32, 64]))
   thr = int(rng.choice([0, 0, 2]))
   opt = ["adam", "adagrad", "ftrl"][seed % 3]
