@@ -880,8 +880,12 @@ __device__ __forceinline__ void probe_rows(const PartArgs& a, long long key, con
       }
     }
   }
-  // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too)
-  pm->mv = load_freq_flags(a.tv, rv);
+  // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too).
+  // The var record is only needed for the frequency filter: a blacklisted row is all zeros already
+  // (RemoveBlacklistUnsafe hands out a zero row, table_manager.h:359-372) and the group optimizers
+  // rewrite the flags after the update, so with enter_threshold == 0 they never read it
+  const bool need_vmeta = OPT == OPT_ADAGRAD || a.tv.enter_threshold != 0u;
+  pm->mv = need_vmeta ? load_freq_flags(a.tv, rv) : make_uint2(0xFFFFu, 0u);
   pm->f0 = meta_ptr(a.ts0, s0)->freq;
   pm->f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
   pm->rv = rv; pm->s0 = s0; pm->s1 = s1;
