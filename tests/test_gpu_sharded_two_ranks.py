@@ -14,7 +14,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.multiprocessing as mp  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DAY, D = 20000, 16
+DAY = 20000
 
 
 def _a2a_via_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
@@ -24,7 +24,7 @@ def _a2a_via_host(out, inp, output_split_sizes=None, input_split_sizes=None, gro
   out.copy_(o)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, D):
   sys.path.insert(0, ROOT)
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
@@ -102,7 +102,8 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_sharded_world2_on_one_gpu():
+@pytest.mark.parametrize("world,D", [(2, 16), (4, 64)])      # (4, 64): configs[3]'s shape — dim 64, more than two owners
+def test_sharded_world2_on_one_gpu(world, D):
   if not torch.cuda.is_available():
     pytest.skip("needs a GPU")
   s = socket.socket()
@@ -111,7 +112,7 @@ def test_sharded_world2_on_one_gpu():
   s.close()
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
-  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q, D)) for r in range(world)]
   for p in procs:
     p.start()
   res = [q.get(timeout=300) for _ in procs]
