@@ -1479,6 +1479,43 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
   }
 }
 
+// The same op for dims 4·VQ (VQ a power of two <= 64), wave-shaped like k_gather: one wave takes 64
+// consecutive ids per step, lane l probes id l (64 independent probes in flight per wave, none of them
+// repeated by neighbouring lanes), then the wave copies the rows VQ lanes per row, CH copy instructions
+// in flight, row ids handed over by shuffle, streaming stores (the output is not read again here).
+template <typename IdT, int VQ>
+__global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT* __restrict__ ids,
+                                                          float* __restrict__ out, long long n) {
+  constexpr int RW = 64 / VQ;            // rows per copy instruction
+  constexpr int CH = VQ < 16 ? VQ : 16;  // copy instructions in flight
+  const int lane = threadIdx.x & 63;
+  const int v = lane % VQ, sub = lane / VQ;
+  const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (TB / 64) * 64;
+  for (long long r0 = wave * 64; r0 < n; r0 += stride) {
+    unsigned rr = 0;  // row 0 reads zeros: misses, and lanes past the end
+    if (r0 + lane < n) rr = table_find(t, load_id(ids, (size_t)(r0 + lane)));
+#pragma unroll
+    for (int j0 = 0; j0 < VQ; j0 += CH) {
+      float4 val[CH];
+      unsigned rj[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const long long ii = r0 + (j0 + j) * RW + sub;
+        if (ii < n) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+          __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+        }
+      }
+    }
+  }
+}
+
 // BatchKvVariableGatherOrZerosV2 (kernels/kv_variable_ops.cc:431-470): N tables, N id lists, N
 // outputs — the reference loops over the tables; here ONE launch covers them all (blockIdx.y =
 // table, tables may differ in dim), which is what a 26-feature serving step needs.

@@ -1076,10 +1076,25 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   const TableDev td = dev_view(t);
-  if (t->key_dtype == KV_DT_INT32)
+  const int q = t->dim / 4;
+  const bool wave_shaped = (t->dim & 3) == 0 && q >= 1 && q <= 64 && (q & (q - 1)) == 0;
+  const int gw = nblocks(n, TB, 8192);  // a 64-id step per wave at 1 M ids: residency hides the hops
+#define KV_GOZ(IDT, VQ) k_gather_or_zeros_w<IDT, VQ><<<gw, TB, 0, s>>>(td, (const IDT*)ids, out, n)
+#define KV_GOZ_ALL(IDT)                                                                        \
+  switch (q) {                                                                                 \
+    case 1: KV_GOZ(IDT, 1); break;   case 2: KV_GOZ(IDT, 2); break;   case 4: KV_GOZ(IDT, 4); break;    \
+    case 8: KV_GOZ(IDT, 8); break;   case 16: KV_GOZ(IDT, 16); break; case 32: KV_GOZ(IDT, 32); break;  \
+    default: KV_GOZ(IDT, 64); break;                                                           \
+  }
+  if (wave_shaped) {
+    if (t->key_dtype == KV_DT_INT32) { KV_GOZ_ALL(int) } else { KV_GOZ_ALL(long long) }
+  } else if (t->key_dtype == KV_DT_INT32) {
     k_gather_or_zeros<int><<<nblocks(n, TB / 8, 8192), TB, 0, s>>>(td, (const int*)ids, out, n);
-  else
+  } else {
     k_gather_or_zeros<long long><<<nblocks(n, TB / 8, 8192), TB, 0, s>>>(td, (const long long*)ids, out, n);
+  }
+#undef KV_GOZ_ALL
+#undef KV_GOZ
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
