@@ -1483,9 +1483,9 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
 // consecutive ids per step, lane l probes id l (64 independent probes in flight per wave, none of them
 // repeated by neighbouring lanes), then the wave copies the rows VQ lanes per row, CH copy instructions
 // in flight, row ids handed over by shuffle, streaming stores (the output is not read again here).
-template <typename IdT, int VQ>
-__global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT* __restrict__ ids,
-                                                          float* __restrict__ out, long long n) {
+template <int VQ>
+__device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restrict__ ids, bool ids_int32,
+                                         float* __restrict__ out, long long n) {
   constexpr int RW = 64 / VQ;            // rows per copy instruction
   constexpr int CH = VQ < 16 ? VQ : 16;  // copy instructions in flight
   const int lane = threadIdx.x & 63;
@@ -1494,7 +1494,9 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT*
   const long long stride = (long long)gridDim.x * (TB / 64) * 64;
   for (long long r0 = wave * 64; r0 < n; r0 += stride) {
     unsigned rr = 0;  // row 0 reads zeros: misses, and lanes past the end
-    if (r0 + lane < n) rr = table_find(t, load_id(ids, (size_t)(r0 + lane)));
+    if (r0 + lane < n)
+      rr = table_find(t, ids_int32 ? (long long)reinterpret_cast<const int*>(ids)[r0 + lane]
+                                   : reinterpret_cast<const long long*>(ids)[r0 + lane]);
 #pragma unroll
     for (int j0 = 0; j0 < VQ; j0 += CH) {
       float4 val[CH];
@@ -1515,6 +1517,11 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT*
     }
   }
 }
+template <typename IdT, int VQ>
+__global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT* __restrict__ ids,
+                                                          float* __restrict__ out, long long n) {
+  goz_wave<VQ>(t, ids, sizeof(IdT) == 4, out, n);
+}
 
 // BatchKvVariableGatherOrZerosV2 (kernels/kv_variable_ops.cc:431-470): N tables, N id lists, N
 // outputs — the reference loops over the tables; here ONE launch covers them all (blockIdx.y =
@@ -1530,6 +1537,18 @@ __global__ void __launch_bounds__(TB) k_batch_gather_or_zeros(const BatchGatherD
   const BatchGatherDesc& d = descs[blockIdx.y];
   const TableDev t = d.t;
   const int D = t.dim;
+  if ((D & 3) == 0) {  // block-uniform: the wave-shaped body for dims 4, 8, ..., 256
+    switch (D >> 2) {
+      case 1: goz_wave<1>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 2: goz_wave<2>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 4: goz_wave<4>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 8: goz_wave<8>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 16: goz_wave<16>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 32: goz_wave<32>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      case 64: goz_wave<64>(t, d.ids, d.ids_int32, d.out, d.n); return;
+      default: break;
+    }
+  }
   const int lane8 = threadIdx.x & 7;
   for (long long i = (long long)blockIdx.x * (TB / 8) + (threadIdx.x >> 3); i < d.n;
        i += (long long)gridDim.x * (TB / 8)) {
