@@ -1686,12 +1686,29 @@ __global__ void __launch_bounds__(TB) k_seg_combine(TableDev t, WsDev w, const u
     float wsum = 0.f, w2 = 0.f;
     if constexpr (VQ > 0) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (unsigned j = lo; j < hi; ++j) {
-        const unsigned r = w.ent_b[w.slot_of_id[j]];
-        const float wj = wts ? wts[j] : 1.f;
-        const float4 x = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
-        acc.x += x.x * wj; acc.y += x.y * wj; acc.z += x.z * wj; acc.w += x.w * wj;
-        wsum += wj; w2 += wj * wj;
+      // SU ids of the segment at a time: their three dependent hops (slot -> row id -> row) overlap;
+      // the sums are still taken in id order
+      constexpr int SU = 4;
+      for (unsigned j = lo; j < hi; j += SU) {
+        unsigned sl[SU], r[SU];
+        float wj[SU];
+        float4 x[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const bool ok = j + u < hi;
+          sl[u] = ok ? w.slot_of_id[j + u] : 0xFFFFFFFFu;
+          wj[u] = ok ? (wts ? wts[j + u] : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) r[u] = sl[u] != 0xFFFFFFFFu ? w.ent_b[sl[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) x[u] = reinterpret_cast<const float4*>(row_ptr(t, r[u]))[v];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          if (sl[u] == 0xFFFFFFFFu) continue;
+          acc.x += x[u].x * wj[u]; acc.y += x[u].y * wj[u]; acc.z += x[u].z * wj[u]; acc.w += x[u].w * wj[u];
+          wsum += wj[u]; w2 += wj[u] * wj[u];
+        }
       }
       float den = 1.f;
       if (combiner == 1) den = wsum; else if (combiner == 2) den = sqrtf(w2);
