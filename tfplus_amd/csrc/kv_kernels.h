@@ -1487,7 +1487,7 @@ template <int VQ>
 __device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restrict__ ids, bool ids_int32,
                                          float* __restrict__ out, long long n) {
   constexpr int RW = 64 / VQ;            // rows per copy instruction
-  constexpr int CH = VQ < 16 ? VQ : 16;  // copy instructions in flight
+  constexpr int CH = VQ < 4 ? VQ : 4;    // copy instructions in flight
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
   const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
