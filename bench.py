@@ -129,6 +129,8 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-kernel-events", action="store_true",
                   help="diagnostic: do not bracket kernels with HIP events in the timed region (no roofline)")
+  ap.add_argument("--no-token", action="store_true",
+                  help="diagnostic: the apply rebuilds the batch index instead of taking over the lookup's")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -213,6 +215,9 @@ def main():
   torch.cuda.synchronize()
   del buf
   assert ops.kv_variable_shape_v2(var)[0] == owned, (ops.kv_variable_shape_v2(var), owned)
+  # steady state of a trained table: every key the optimizer has applied has its slot row remembered in
+  # the var's index entry (what GroupAdamOptimizer's first apply per key leaves behind)
+  ops.kv_attach_slot(var, slot)
 
   # ---- synthetic batches, resident in HBM ----
   z = Zipf(K, args.zipf, dev)
@@ -221,19 +226,9 @@ def main():
     ids = splitmix64(z.sample(N, gen))
     grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
     U = int(torch.unique(ids).numel())
-    # rows whose key occurs once inside its 2048-id tile (TILE in kv_device.h) (read by the partition pass, not the tile pass)
-    pad = (-N) % 2048
-    tiles = torch.cat([ids, torch.full((pad,), ids.min().item() - 1, device=dev, dtype=ids.dtype)]).view(-1, 2048)
-    srt = torch.sort(tiles, dim=1).values
-    eq_prev = torch.zeros_like(srt, dtype=torch.bool)
-    eq_prev[:, 1:] = srt[:, 1:] == srt[:, :-1]
-    eq_next = torch.zeros_like(srt, dtype=torch.bool)
-    eq_next[:, :-1] = eq_prev[:, 1:]
-    S = int((~(eq_prev | eq_next)).sum().item()) - (1 if pad == 1 else 0)
-    pool.append((ids, grad, U, S))
+    pool.append((ids, grad, U))
   out = torch.empty((N, D), dtype=torch.float32, device=dev)
   U_mean = float(np.mean([p[2] for p in pool]))
-  S_mean = float(np.mean([p[3] for p in pool]))
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
@@ -273,10 +268,12 @@ def main():
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
     if not shard_path:
-      _lib.check(L.kv_gather_or_insert(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), stream))
-      _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
-                                       float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
-                                       0.0, 4, stream))
+      # the lookup names the batch; the apply of the same ids takes its index over (kvhip.h: batch token)
+      tok = ctypes.c_uint64(0)
+      _lib.check(L.kv_gather_or_insert_tok(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), ctypes.byref(tok), stream))
+      _lib.check(L.kv_apply_group_adam_tok(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
+                                           float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
+                                           0.0, 4, tok.value if not args.no_token else 0, stream))
     else:
       # ids -> owners (all_to_all over xGMI) -> rows back; then (ids, grads) -> owners -> fused apply
       skv.lookup(ids)
@@ -300,7 +297,7 @@ def main():
     step(k)
   torch.cuda.synchronize()
   warm = ops.kv_profile_read(var)
-  dom = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if args.warmup > 0 else "apply_part"
+  dom = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if args.warmup > 0 else "apply_sorted"
   ops.kv_profile_enable(var, 0 if args.no_kernel_events else args.steps + 8)
   ops.kv_profile_select(var, [dom])
   barrier()
@@ -318,7 +315,7 @@ def main():
   ops.kv_profile_select(var, None)
   prof = timed
   if not args.no_kernel_events:
-    ops.kv_profile_enable(var, 5 * args.steps + 8)
+    ops.kv_profile_enable(var, 8 * args.steps + 8)
     for k in range(args.steps):
       step(args.warmup + args.steps + k)
     torch.cuda.synchronize()
@@ -336,22 +333,23 @@ def main():
 
   # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch time ----
   # SURVEY.md §8(d) per-step figures, split over the kernels of each op by which kernel moves the
-  # bytes: ids are read by the tile pass; a gradient row is read once, by the
-  # tile pass if its key repeats inside the 1024-id tile (in-tile fold) and by the partition pass
-  # otherwise; probes and optimizer state belong to the partition pass; rows to the gather.
-  Ub, Sb = U_mean, S_mean
+  # bytes: ids are read by the tile pass; the index probe and the output rows belong to
+  # the partition pass (its gather blocks copy the rows); the apply reads every gradient row once and
+  # reads + writes the optimizer state of every unique key in k_apply_sorted.
+  Ub = U_mean
   alg = {
       "lookup_tile": N * 8,
-      "lookup_part": Ub * 16,
-      "lookup_gather": Ub * 4 * D + N * 4 * D,
-      "apply_tile": N * 8 + (N - Sb) * 4 * D,
-      "apply_part": Sb * 4 * D + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,
+      "lookup_part": Ub * (16 + 4 * D) + N * 4 * D,
+      "lookup_order": 0,
+      "apply_index": N * 8 + Ub * 16,
+      "apply_sorted": N * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,
+      "apply_span": 0,
   }
   kern = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items()}
   dom_ms = timed[dom][0] / max(timed[dom][1], 1)      # the dominant kernel, inside the timed region
   achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-  lookup_ms = kern["lookup_tile"] + kern["lookup_part"] + kern["lookup_gather"]
-  apply_ms = kern["apply_tile"] + kern["apply_part"]
+  lookup_ms = kern["lookup_tile"] + kern["lookup_part"] + kern["lookup_order"]
+  apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"]
   lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)
   apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D
 
@@ -360,10 +358,10 @@ def main():
   # committed under profiles/; null when that file is absent or was taken on another workload.
   traffic, traffic_src = None, None
   try:
-    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")))
     if tj.get("workload") == [K, N, D, args.zipf] and dom in tj["kernels"]:
       traffic = tj["kernels"][dom]["hbm_bytes"]
-      traffic_src = "profiles/r01_traffic.json: " + tj["source"]
+      traffic_src = "profiles/r02_traffic.json: " + tj["source"]
   except (OSError, ValueError, KeyError):
     pass
 
@@ -383,7 +381,6 @@ def main():
       "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d per GPU, %d ids/batch per GPU Zipf(%.1f), "
                              "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
                  "keys": K, "dim": D, "batch": N, "zipf": args.zipf, "global_batch": N * world, "unique_per_batch": Ub,
-                 "tile_single_rows_per_batch": Sb,
                  "parallelism": ("table hash-sharded over %d GPUs (id mod G), all_to_all id/row/grad exchange "
                                  "over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

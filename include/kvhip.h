@@ -108,6 +108,17 @@ int kv_gather_or_insert(kv_handle_t h, const void* ids, const int32_t* counts, i
 int kv_gather_or_insert_pairs(kv_handle_t h, const int64_t* id_count_pairs, int64_t n, float* out,
                               kv_stream_t stream);
 
+/* The same lookup, additionally naming the batch: *token (never 0 on success for n <= 2^21) identifies the
+ * index of `ids` that the lookup leaves in the table's workspace — the input positions sorted by key, each
+ * key's row.  A kv_apply_*_tok call on the same table with the same ids, n and token takes that index over
+ * instead of rebuilding it (a training step applies the ids it has just looked up: the TF shim threads the
+ * token from the forward op to the optimizer op).  Any other batch op on the table in between simply makes
+ * the token stale; a stale or zero token means "build the index", never a wrong result.  The caller
+ * guarantees only that `ids` holds the same values at both calls. */
+typedef uint64_t kv_batch_token_t;
+int kv_gather_or_insert_tok(kv_handle_t h, const void* ids, const int32_t* counts, int64_t n,
+                            float* out, kv_batch_token_t* token, kv_stream_t stream);
+
 /* Replaces KvVariableGatherOrZerosOp::Compute (kernels/kv_variable_ops.cc:348-405) -> FindOrZeros
  * (kernels/kv_variable.h:239-254): no insert, no frequency change, misses read as zeros. */
 int kv_gather_or_zeros(kv_handle_t h, const void* ids, int64_t n, float* out, kv_stream_t stream);
@@ -138,6 +149,32 @@ int kv_apply_sparse_group_ftrl(kv_handle_t var, kv_handle_t accum, kv_handle_t l
                                const float* grad, const void* ids, int64_t n, float lr, float l1,
                                float l2, float l21, float l2_shrinkage, float lr_power,
                                kv_stream_t stream);
+
+/* The three optimizer ops with the batch token of the lookup that preceded them (0 = none). */
+int kv_apply_group_adam_tok(kv_handle_t var, kv_handle_t m_v_linear, const float* grad, const void* ids,
+                            int64_t n, float lr, float beta1_power, float beta2_power, float beta1,
+                            float beta2, float epsilon, float l1, float l2, float l21, int version,
+                            kv_batch_token_t token, kv_stream_t stream);
+int kv_apply_adagrad_tok(kv_handle_t var, kv_handle_t accum, float lr, const float* grad, const void* ids,
+                         int64_t n, int update_slots, kv_batch_token_t token, kv_stream_t stream);
+int kv_apply_sparse_group_ftrl_tok(kv_handle_t var, kv_handle_t accum, kv_handle_t linear, const float* grad,
+                                   const void* ids, int64_t n, float lr, float l1, float l2, float l21,
+                                   float l2_shrinkage, float lr_power, kv_batch_token_t token,
+                                   kv_stream_t stream);
+
+/* Optimizer slot tables are KvVariables of their own (python/ops/variable_scope.py:1027-1088, created with
+ * colocate_with(var), training/group_adam.py:142), probed with the var's keys on every apply.  Here a var's
+ * index entry also remembers the key's row in ONE slot table (the first slot of the optimizer: m_v_linear /
+ * accum), so the apply reaches the slot row without a second probe; a remembered row is checked against the
+ * slot row's own key before use.  The first apply that pairs a var with a slot table attaches it; this call
+ * does so explicitly and, in one pass over the var's rows, fills in the rows of the keys both tables
+ * already hold (after a checkpoint restore, or a table filled by kv_insert / kv_gather_or_insert). */
+int kv_attach_slot(kv_handle_t var, kv_handle_t slot, kv_stream_t stream);
+
+/* Deterministic reduction mode (off by default): the gradient rows of a repeated id are then summed in an
+ * order fixed by the input positions alone — in-tile ranks by position instead of LDS-atomic arrival, a
+ * key's tiles in tile order — so the same batch gives bit-identical optimizer state on every run. */
+int kv_set_deterministic(kv_handle_t h, int on);
 
 /* The TF-core step on its own (for callers that want the [U, dim] IndexedSlices):
  * uniq_ids [n], summed [n, dim] are filled for the first *num_unique entries; inverse [n]
@@ -201,8 +238,9 @@ int kv_insert(kv_handle_t h, const void* ids, const float* values, int64_t n, kv
  * 1097-1161) -> ScatterUpdate (kernels/kv_variable.h:616-734): row = row <op> updates[i]; missing
  * keys are inserted with the init rule first; blacklisted rows are left untouched.  Repeated
  * ids: add / sub apply the SUM of their update rows (the reference applies each occurrence in
- * turn; n <= 2^21 — this step is synchronous), the other operations apply one of the
- * occurrences (the reference's result depends on its thread interleaving there). */
+ * turn), mul / div their PRODUCT, min / max their minimum / maximum — every occurrence counts, as in the
+ * reference (this step is synchronous); plain update keeps one of the occurrences (the reference's result
+ * depends on its thread interleaving there). */
 int kv_scatter_update(kv_handle_t h, const void* ids, const float* updates, int64_t n, int op,
                       kv_stream_t stream);
 
@@ -322,12 +360,13 @@ int kv_take_rows(int device, const void* src, const int32_t* index, const int32_
  * For the optimizer ops the events belong to the `var` table.  kv_profile_select(h, mask) limits
  * the bracketing to the kinds whose bit (1 << KV_PROF_*) is set (default: all) — an event pair
  * costs a few microseconds of stream time, so a throughput measurement brackets one kernel. */
-#define KV_PROF_LOOKUP_TILE 0   /* k_tile<LOOKUP>: tile dedup + partition sort */
-#define KV_PROF_LOOKUP_PART 1   /* k_part<LOOKUP>: find / insert / frequency */
-#define KV_PROF_LOOKUP_GATHER 2 /* k_gather */
-#define KV_PROF_APPLY_TILE 3    /* k_tile<APPLY>: dedup + in-tile gradient fold */
-#define KV_PROF_APPLY_PART 4    /* k_part<APPLY>: contribution sum + fused row update */
-#define KV_PROF_KINDS 5
+#define KV_PROF_LOOKUP_TILE 0   /* k_tile: tile dedup + partition sort */
+#define KV_PROF_LOOKUP_PART 1   /* k_part_keys_gather: find / insert / frequency + the probing gather of the rows */
+#define KV_PROF_LOOKUP_ORDER 2  /* k_order: sorted position list + fix-up of rows inserted by the batch */
+#define KV_PROF_INDEX 3         /* the three index kernels of an apply that was not handed a valid token */
+#define KV_PROF_APPLY_SORTED 4  /* k_apply_sorted: segmented gradient sum + fused row update */
+#define KV_PROF_APPLY_SPAN 5    /* k_apply_span: keys that cross chunk boundaries */
+#define KV_PROF_KINDS 6
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
 int kv_profile_select(kv_handle_t h, unsigned kind_mask);

@@ -151,7 +151,12 @@ class OracleKv:
     i, v = _ids(ids), _f32(values)
     lib().kvo_insert(self._h, _p(i, _i64p), _p(v, _f32p), i.size)
 
-  def import_(self, keys, values, blacklist=(), freq_keys=(), freq_values=()):
+  def import_(self, keys, values, blacklist=(), freq_keys=(), freq_values=(), first_n=6):
+    # the op hands ImportValues empty tensors for the lists beyond first_n (kernels/kv_variable_ops.cc:806-822)
+    if first_n <= 3:
+      blacklist = ()
+    if first_n <= 4:
+      freq_keys, freq_values = (), ()
     k, v = _ids(keys), _f32(values)
     b, fk = _ids(blacklist), _ids(freq_keys)
     fv = np.ascontiguousarray(np.asarray(freq_values).reshape(-1), dtype=np.uint32)

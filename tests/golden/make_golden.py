@@ -116,6 +116,21 @@ def main():
   np.savez(os.path.join(HERE, "A4_ftrl_v2.npz"), ids=np.arange(300, dtype=np.int64), grad=g,
            expect_var=var.astype(np.float32), expect_accum=acc.astype(np.float32), expect_linear=lin.astype(np.float32))
 
+  # I1: test_kv_variable_import_v2 (py_ut/tests/test_kv_variable_ops.py:345-435): enter_threshold = 1, keys
+  # 0..4 with values k * ones[64], blacklist [7], frequency table keys 1..5 -> values 1..5 (uint16), imported
+  # with first_n 3, 4, 6 in turn (each import clears the table) and exported with first_n = 6 after each.
+  # The reference asserts the SHAPES of the six outputs: keys [5], values [5, D] every time; blacklist
+  # 0 / 1 / 1 and frequency lists 5 / 6 / 6 entries (first_n 3 drops the blacklist and the frequency table,
+  # kernels/kv_variable_ops.cc:806-822; the blacklisted key 7 is a key of the map, so it is in the frequency
+  # export; frequency key 5 names no key and is dropped, dynamic_restore.hpp:232-246).
+  D = 64
+  np.savez(os.path.join(HERE, "I1_import_v2.npz"), keys=np.arange(5, dtype=np.int64),
+           values=(np.arange(5, dtype=np.float32)[:, None] * np.ones((1, D), np.float32)),
+           blacklist=np.array([7], np.int64), freq_keys=np.arange(1, 6, dtype=np.int64),
+           freq_values=np.arange(1, 6, dtype=np.uint32), first_n=np.array([3, 4, 6], np.int64),
+           expect_rows=np.array([5, 5, 5], np.int64), expect_blacklist=np.array([0, 1, 1], np.int64),
+           expect_freq=np.array([5, 6, 6], np.int64), enter_threshold=np.array([1], np.int64))
+
 
 if __name__ == "__main__":
   main()

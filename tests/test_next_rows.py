@@ -1,5 +1,7 @@
 """scatter family, insert, import / export — oracle KATs on the CPU,
 parity on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -148,6 +150,27 @@ def test_import_export_parity(ops):
   # importing again replaces the content (table_->clear(), dynamic_restore.hpp:178)
   ops.kv_variable_import(h2, gk[:5], gv[:5])
   assert ops.kv_variable_shape_v2(h2) == [5, D]
+
+
+@pytest.mark.gpu
+def test_I1_import_v2_known_answer_gpu(ops, golden_dir):
+  """The reference's own KAT for import / export (py_ut/tests/test_kv_variable_ops.py:345-435), on the GPU
+  table and against the oracle for the contents the reference does not assert."""
+  z = np.load(os.path.join(golden_dir, "I1_import_v2.npz"))
+  D = z["values"].shape[1]
+  thr = int(z["enter_threshold"][0])
+  h = ops.kv_variable([D], enter_threshold=thr); ops.kv_set_clock_days(h, DAY)
+  ops.init_kv_variable_v2(h, np.ones((1024, D), np.float32))
+  o = ko.OracleKv(D, thr, np.ones((1024, D), np.float32), day=DAY)
+  for i, first_n in enumerate(z["first_n"]):
+    ops.kv_variable_import(h, z["keys"], z["values"], z["blacklist"], z["freq_keys"], z["freq_values"], first_n=int(first_n))
+    o.import_(z["keys"], z["values"], z["blacklist"], z["freq_keys"], z["freq_values"], first_n=int(first_n))
+    k, v, b, fk, fv = [x.cpu().numpy() for x in ops.kv_variable_export(h, first_n=6)]
+    assert k.shape == (z["expect_rows"][i],) and v.shape == (z["expect_rows"][i], D)
+    assert b.shape == (z["expect_blacklist"][i],) and fk.shape == fv.shape == (z["expect_freq"][i],)
+    assert dict(zip(k, map(bytes, v))) == dict(zip(z["keys"], map(bytes, z["values"])))     # exact
+    ok, ov, ob, ofk, ofv = o.export(first_n=6)
+    assert sorted(b) == sorted(ob) and dict(zip(fk, fv.view(np.uint32))) == dict(zip(ofk, ofv))
 
 
 @pytest.mark.gpu

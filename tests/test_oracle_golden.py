@@ -271,3 +271,17 @@ def test_delta_export_known_answers():
   assert k.size == 0 and bl.tolist() == [2] and dk.size == 0 and fk.size == 0
   assert sorted(slot.export_delta(4)[0].tolist()) == [2]                           # the slot table keeps its own list
   assert t.export_delta(3)[5].tolist() == [2]                                      # prediction export: blacklisted -> delete
+
+
+def test_I1_import_v2_known_answer(golden_dir):
+  """py_ut/tests/test_kv_variable_ops.py:345-435 (the reference's own KAT for import / export)."""
+  z = np.load(os.path.join(golden_dir, "I1_import_v2.npz"))
+  D = z["values"].shape[1]
+  o = ko.OracleKv(D, int(z["enter_threshold"][0]), np.ones((1024, D), np.float32), day=20000)
+  for i, first_n in enumerate(z["first_n"]):
+    o.import_(z["keys"], z["values"], z["blacklist"], z["freq_keys"], z["freq_values"], first_n=int(first_n))
+    k, v, b, fk, fv = o.export(first_n=6)
+    assert k.shape == (z["expect_rows"][i],) and v.shape == (z["expect_rows"][i], D)
+    assert b.shape == (z["expect_blacklist"][i],) and fk.shape == fv.shape == (z["expect_freq"][i],)
+    assert sorted(k) == list(z["keys"]) and dict(zip(k, map(bytes, v))) == dict(zip(z["keys"], map(bytes, z["values"])))
+    assert list(b) == ([] if first_n <= 3 else list(z["blacklist"]))

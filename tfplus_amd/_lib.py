@@ -46,10 +46,16 @@ SIGNATURES = {
     "kv_sum_freq": (_i32, [_vp, _c.POINTER(_i64), _vp]),
     "kv_get_meta": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "kv_gather_or_insert": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "kv_gather_or_insert_tok": (_i32, [_vp, _vp, _vp, _i64, _vp, _c.POINTER(_c.c_uint64), _vp]),
     "kv_gather_or_zeros": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_apply_group_adam": (_i32, [_vp, _vp, _vp, _vp, _i64] + [_f] * 9 + [_i32, _vp]),
     "kv_apply_adagrad": (_i32, [_vp, _vp, _f, _vp, _vp, _i64, _i32, _vp]),
     "kv_apply_sparse_group_ftrl": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp]),
+    "kv_apply_group_adam_tok": (_i32, [_vp, _vp, _vp, _vp, _i64] + [_f] * 9 + [_i32, _c.c_uint64, _vp]),
+    "kv_apply_adagrad_tok": (_i32, [_vp, _vp, _f, _vp, _vp, _i64, _i32, _c.c_uint64, _vp]),
+    "kv_apply_sparse_group_ftrl_tok": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_c.c_uint64, _vp]),
+    "kv_attach_slot": (_i32, [_vp, _vp, _vp]),
+    "kv_set_deterministic": (_i32, [_vp, _i32]),
     "kv_dedup_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     "kv_export_count": (_i32, [_vp, _i32, _c.POINTER(_i64), _vp]),
     "kv_export_fill": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

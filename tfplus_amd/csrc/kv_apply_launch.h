@@ -1,0 +1,56 @@
+// kv_apply_launch.h — the k_apply_sorted / k_apply_span dispatch on the row geometry, shared by the
+// translation units that instantiate it (kv_apply_a.hip: GroupAdam V4 / V3; kv_apply_b.hip: Adagrad, FTRL,
+// the plain segment fold).  Splitting the instantiations over two files lets `make -j` build them in
+// parallel.  Included inside the anonymous namespace of those files, after kv_device.h and kv_kernels.h.
+//
+// D % 4 == 0 -> float4 lanes, else scalar lanes.  md != nullptr: one launch over `ntab` tables (grid.y),
+// nchunks = the largest table's chunk count; only MODE_APPLY on float4 rows is instantiated for it.
+// span == 0: k_apply_sorted, span == 1: k_apply_span.  Returns KV_OK, or KV_UNIMPLEMENTED for an
+// unsupported dim.
+#pragma once
+
+template <int MODE, int OPT>
+int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md, int ntab,
+                   unsigned nchunks, int span) {
+  const int D = pa.tv.dim;
+  const int grid = (int)nchunks;
+#define KV_APPLY(V, LPR, K)                                                                        \
+  do {                                                                                             \
+    const size_t sh = span ? (size_t)(TBS / LPR + 1) * D * 4 + 32 : apply_smem_bytes(D, LPR);       \
+    if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
+      if (md) {                                                                                    \
+        if (span) k_apply_span_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);   \
+        else k_apply_sorted_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);      \
+        return KV_OK;                                                                              \
+      }                                                                                            \
+    }                                                                                              \
+    if (md) return KV_UNIMPLEMENTED;                                                               \
+    if (span) k_apply_span<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                     \
+    else k_apply_sorted<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                        \
+    return KV_OK;                                                                                  \
+  } while (0)
+  if ((D & 3) == 0) {
+    const int q = D / 4;
+    if (q <= 1) KV_APPLY(4, 1, 1);
+    if (q <= 2) KV_APPLY(4, 2, 1);
+    if (q <= 4) KV_APPLY(4, 4, 1);
+    if (q <= 8) KV_APPLY(4, 8, 1);
+    if (q <= 16) KV_APPLY(4, 8, 2);    // dims 36..64: 8 lanes x 2 float4
+    if (q <= 32) KV_APPLY(4, 16, 2);   // dims 68..128: 16 lanes x 2 float4
+    if (q <= 64) KV_APPLY(4, 64, 1);
+    if (q <= 128) KV_APPLY(4, 64, 2);
+    if (q <= 256) KV_APPLY(4, 64, 4);
+  } else {
+    if (D <= 1) KV_APPLY(1, 1, 1);
+    if (D <= 2) KV_APPLY(1, 2, 1);
+    if (D <= 4) KV_APPLY(1, 4, 1);
+    if (D <= 8) KV_APPLY(1, 8, 1);
+    if (D <= 16) KV_APPLY(1, 16, 1);
+    if (D <= 32) KV_APPLY(1, 32, 1);
+    if (D <= 64) KV_APPLY(1, 64, 1);
+    if (D <= 128) KV_APPLY(1, 64, 2);
+    if (D <= 256) KV_APPLY(1, 64, 4);
+  }
+#undef KV_APPLY
+  return KV_UNIMPLEMENTED;
+}

@@ -14,7 +14,12 @@ constexpr unsigned ROW_TOMB = 0xFFFFFFFFu;  // index entry of a deleted key (kep
                                             // the same key revives it, an index rebuild drops it)
 constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < enter_threshold
 constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
-constexpr unsigned PART_BIT = 0x80000000u;      // gradient locator: partial-sum row, not an input row
+constexpr unsigned HEAD_BIT = 0x80000000u;      // sorted position list / ent_base: first position of its key
+constexpr unsigned NEW_BIT = 0x40000000u;       // ent_base: the key's row was inserted by this batch (lookup fix-up)
+constexpr unsigned BASE_MASK = 0x3FFFFFFFu;
+constexpr int RANK_SHIFT = 21;                  // slot_rank: entry index (21 bits, n <= 2^21) | in-tile occurrence rank << 21
+constexpr unsigned SLOT_MASK = (1u << RANK_SHIFT) - 1u;
+constexpr int CH = 256;                         // sorted positions per chunk of the apply kernel
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
 constexpr int TBT = 512;  // threads per block of the tile kernel
@@ -23,18 +28,19 @@ constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every 
                                  // N / 2048 entries to its partition, which keeps the partition
                                  // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
-constexpr int PARTCAP = TILE / 2;  // a tile has at most TILE/2 keys with >= 2 rows
 constexpr int MAX_P = 2048;      // partitions (power of two); 1024 up to 1 M ids, 2048 for 2 M
-constexpr int HEAVY = 16;        // entries of one key in one partition above which the block folds it (16: -2 us vs 32)
 constexpr int MAX_CHUNKS = 32768;   // 2^16-row chunks (no capacity hint) still reach the 2^31-row limit
 
-enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4, MODE_UNIQUE = 5 };
+// index-pass modes (k_part_keys) and fold modes (k_apply_sorted)
+enum Mode { MODE_LOOKUP = 0, MODE_APPLY = 1, MODE_DEDUP = 2, MODE_SCATTER = 3, MODE_MARK = 4, MODE_UNIQUE = 5,
+            MODE_APPLYIDX = 6 };
 enum Opt { OPT_ADAM_V4 = 0, OPT_ADAM_V3 = 1, OPT_ADAGRAD = 2, OPT_FTRL = 3 };
 
 struct __attribute__((aligned(16))) Entry {
   long long key;
   unsigned row;
-  unsigned pad;
+  unsigned hint;   // row of this key in the table's attached optimizer slot table (0 = not known yet); a
+                   // hint is validated against the slot row's own key before use, so a stale one only costs a probe
 };
 
 // per-row metadata next to each other (one 16-byte record, so a key's frequency word and flags
@@ -70,24 +76,33 @@ struct TableDev {
   unsigned enter_threshold;
   unsigned long long seed;
   unsigned track_delta;     // NeedDeltaInfo() kv_variable.h:816: touched keys are remembered for DeltaExport
+  unsigned* err_host;       // pinned host copy of counters[1] (the host reads it without a synchronisation)
 };
 
 // device view of the per-batch workspace (kv_kernels.h explains the pipeline)
 struct WsDev {
   long long* ent_key;      // [ntiles * TILE] tile t's deduplicated entries, sorted by partition
-  unsigned* ent_a;         // lookup: saturating count of the key in the tile; else: one input
-                           // position of the key in the tile
-  unsigned* ent_b;         // apply / dedup: gradient locator of the tile's contribution (an input
-                           // position, or PART_BIT | partial-sum row).  OUT of the partition pass:
-                           // lookup -> var row id of the key; dedup -> dense unique index
-  unsigned short* toff;    // [ntiles][P + 1] partition boundaries inside each tile's entry list
-  unsigned* slot_of_id;    // [n] entry index of every input position
-  float* part;             // [ntiles * PARTCAP][dim] per-tile partial gradient sums
-  unsigned* ctr;           // [8] op counters ([0]: kv_dedup_segment_sum's unique count); host-zeroed
+  unsigned* ent_a;         // index modes: occurrences of the key in the tile (low 16) | saturating frequency
+                           // count of the tile (high 16); scatter / mark: one input position of the key
+  unsigned* ent_b;         // OUT of the partition pass: var row id of the key (unique: dense index)
+  unsigned* ent_base;      // OUT of the partition pass: where the entry's positions start in the sorted position
+                           // list | HEAD_BIT (first entry of its key) | NEW_BIT (row inserted by this batch)
+  unsigned* toff;          // [ntiles][P + 1] partition boundaries inside each tile: entry prefix (low 16) |
+                           // position prefix (high 16)
+  unsigned* slot_rank;     // [n] entry index of every input position | its rank among the key's occurrences
+                           // in the tile << RANK_SHIFT
+  unsigned* order;         // [n + 1] input positions sorted by key (a key's occurrences are contiguous), first
+                           // one tagged HEAD_BIT; order[n] = HEAD_BIT
+  uint4* ohead;            // [n] at a key's first sorted position: {key lo, key hi, row, slot-row hint}
+  float* cpart;            // [nchunks][2][dim] leading / trailing partial sums of the apply chunks
+  uint4* ctail;            // [nchunks] ohead record of the chunk's trailing (unfinished) key
+  unsigned* cmeta;         // [nchunks] CM_* flags
+  unsigned* ctr;           // [8] op counters ([0]: unique count of kv_unique / kv_dedup_segment_sum); host-zeroed
   unsigned ntiles, P;
   int pshift;              // 64 - log2(P)
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
 };
+constexpr unsigned CM_HAS_HEAD = 1u, CM_LEAD = 2u, CM_TAIL_OPEN = 4u;
 
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
 // block stores s_memtime at phase boundaries into a buffer nothing else reads.
@@ -143,7 +158,7 @@ __device__ __forceinline__ Entry load_entry(const Entry* e) {
   Entry r;
   r.key = (long long)(((unsigned long long)v.y << 32) | v.x);
   r.row = v.z;
-  r.pad = v.w;
+  r.hint = v.w;
   return r;
 }
 
@@ -165,17 +180,45 @@ __device__ __forceinline__ unsigned table_find(const TableDev& t, long long key)
 // read-only probe continuing from an entry the caller already loaded (so the first loads of
 // several tables can be in flight together)
 __device__ __forceinline__ unsigned table_find_from(const TableDev& t, long long key, unsigned long long p,
-                                                   Entry e) {
-  if (key == EMPTY_KEY) return (e.key == 0 && e.row != ROW_TOMB) ? e.row : 0u;
+                                                   Entry e, unsigned* hint = nullptr) {
+  if (key == EMPTY_KEY) {
+    if (hint) *hint = e.hint;
+    return (e.key == 0 && e.row != ROW_TOMB) ? e.row : 0u;
+  }
   for (;;) {
-    if (e.key == key) return e.row != ROW_TOMB ? e.row : 0u;
+    if (e.key == key) {
+      if (hint) *hint = e.hint;
+      return e.row != ROW_TOMB ? e.row : 0u;
+    }
     if (e.key == EMPTY_KEY) return 0u;
     p = (p + 1) & t.mask;
     e = load_entry(&t.entries[p]);
   }
 }
+// index entry of a key that is present (nullptr when absent): where its slot-row hint lives
+__device__ __forceinline__ Entry* table_entry_of(const TableDev& t, long long key) {
+  if (key == EMPTY_KEY) {
+    Entry* s = &t.entries[t.mask + 1];
+    return load_entry(s).key == 0 ? s : nullptr;
+  }
+  unsigned long long p = mix64((unsigned long long)key) & t.mask;
+  for (;;) {
+    Entry* s = &t.entries[p];
+    const Entry e = load_entry(s);
+    if (e.key == key) return s;
+    if (e.key == EMPTY_KEY) return nullptr;
+    p = (p + 1) & t.mask;
+  }
+}
 __device__ __forceinline__ unsigned long long home_of(const TableDev& t, long long key, unsigned long long h) {
   return key == EMPTY_KEY ? t.mask + 1 : (h & t.mask);
+}
+
+// a batch that cannot be processed (see report_deferred_error in kvhip.hip): device flag for the kernels
+// that follow in the same op, pinned host word for the next call
+__device__ __forceinline__ void raise_error(const TableDev& t, unsigned code) {
+  atomicExch(&t.counters[1], code);
+  if (t.err_host) __hip_atomic_store(t.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Find or insert.  The caller is the ONLY lane of the launch that handles `key` (batch
@@ -231,7 +274,7 @@ claimed:
   if (!have) {
     r = atomicAdd(&t.counters[0], 1u);
     if (r >= t.max_rows) {
-      atomicExch(&t.counters[1], 1u);
+      raise_error(t, 1u);
       slot->row = 0;
       return 0u;
     }

@@ -1,125 +1,97 @@
-// kv_kernels.h — the batch pipeline (included by kvhip.hip only).
+// kv_kernels.h — the batch pipeline (included by kvhip.hip and the kv_apply_*.hip units).
 //
-// Why this shape.  The first version de-duplicated a batch through a global scratch hash with
-// atomics.  On MI355X a returning or non-returning device-scope atomic on ONE address costs
-// ~40 ns and same-address atomics serialise; a Zipf(1.2) batch of 1M ids has ~100 keys that
-// occur in (nearly) every tile, so each of those addresses took ~1000 serial atomics (in-kernel
-// stamps: 73 % of the dedup kernel).  fp32 atomic accumulation of gradient rows hit the same
-// wall.  This pipeline has NO global atomics on the data path:
+// Why this shape.  A device-scope atomic on ONE address costs ~40 ns on MI355X and same-address
+// atomics serialise; a Zipf(1.2) batch of 1 M ids has ~100 keys that occur in (nearly) every tile, so
+// a global scratch hash or fp32 atomic accumulation spends its time queueing on those addresses
+// (measured in round 1).  This pipeline has NO global atomics on the data path.  It is built around
+// ONE index of the batch — the input positions sorted by key — that the training lookup builds while
+// the output rows are being copied, and that the optimizer apply of the same batch then consumes:
 //
-//   k_tile       one block (TBT threads) per TILE input positions: LDS hash dedup of the tile; the
-//                tile's unique keys ("entries") are counting-sorted by the key's hash partition and
-//                written with plain coalesced stores (ent_*), with the partition boundaries in
-//                toff[tile][0..P].  Optimizer ops also fold the gradient rows of keys that repeat
-//                inside the tile into one partial-sum row (sorted-run register sums).
-//   k_part_keys  (lookup / scatter / import marks / unique) and
-//   k_part_sum   (optimizers / dedup): one block per partition p: takes partition p's entries from
-//                EVERY tile, so it sees all occurrences of its keys: exact counts, exclusive
-//                ownership of the table rows (find / insert / frequency / flags), and for optimizer
-//                ops the sum of the per-tile contributions in registers followed by the fused row
-//                update.  Results that input positions need (row ids) are written back per entry.
-//   k_gather     out[i] = rows[ent_b[slot_of_id[i]]], one wave per 64 output rows.
+//   k_tile        one block (TBT threads) per TILE input positions: LDS hash dedup of the tile; the
+//                 tile's unique keys ("entries") are counting-sorted by the key's hash partition and
+//                 written with plain coalesced stores (ent_*), partition boundaries in toff[tile][0..P]
+//                 (entries and positions).  Every input position learns its entry and its rank among the
+//                 key's occurrences in the tile (slot_rank).
+//   k_part_keys   one block per partition p: takes partition p's entries from EVERY tile, so it sees
+//                 all occurrences of its keys: exact counts, exclusive ownership of the table rows (find /
+//                 insert / frequency / flags).  It also lays the partition's keys out in the sorted
+//                 position list: partition p starts at sum over tiles of toff[t][p].positions (no scan
+//                 kernel, no atomics), a key at the block-scan prefix of the occurrence counts, an entry at
+//                 its key's start plus the occurrences of the key's entries before it (ent_base); the key's
+//                 record {key, row, slot-row hint} goes to ohead[start].  The blocks past the partitions of
+//                 a training lookup copy the output rows meanwhile (probing gather, bandwidth-bound, next
+//                 to the latency-bound partition work).
+//   k_order       order[ent_base[entry] + rank] = position; positions whose key was inserted by this batch
+//                 get their output row re-copied (the probing gather ran beside the inserts).
+//   k_apply_sorted  one block per CH consecutive sorted positions: segmented sum of the gradient rows
+//                 (a key's occurrences are contiguous) fused with the optimizer row update; a key that
+//                 crosses a chunk boundary leaves partial sums that
+//   k_apply_span  adds up in chunk order and finishes.
 //
 // Every kernel body is a __device__ function with two entry points: one table (arguments by
 // value) and many tables in one launch (grid.y = table, arguments from a MultiDesc array).
 //
-// Summation order of repeated ids depends on LDS-atomic ranks (not run-to-run deterministic);
-// there are no float atomics in global memory.
+// Summation order of repeated ids: position-sorted inside a tile only in deterministic mode; see DESIGN.md.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
 // k_tile
 // ------------------------------------------------------------------------------------------
-// MODE_LOOKUP : ent_a = min(sum of per-occurrence counts, 65535)     (kv_variable.h:320-350)
-// others      : ent_a = one input position of the key in the tile;
-//   MODE_APPLY / MODE_DEDUP additionally ent_b = gradient locator, VPL = float4 per lane per row
-//   (8 lanes per row; VPL = 0 -> scalar lanes for dims that are not multiples of 4)
+// FIRST = false (index modes): ent_a = occurrences of the key in the tile | min(sum of per-occurrence
+//                              counts, 65535) << 16                      (kv_variable.h:320-350)
+// FIRST = true (scatter / mark): ent_a = one input position of the key in the tile
 struct TileSmem {
   long long* lkeys;        // [LS + 1]   (slot LS: the key that equals EMPTY_KEY)
-  unsigned* lcnt;          // [LS + 1]
-  unsigned short* lfirst;  // [LS + 1]   (not MODE_LOOKUP) tile-local position of one occurrence; later:
-                           //            sorted-row offset of the key
+  unsigned* lcnt;          // [LS + 1]   occurrences of the slot's key
+  unsigned short* lfirst;  // [LS + 1]   (FIRST) tile-local position of one occurrence
   unsigned short* lpos;    // [LS + 1]   entry position of the slot's key
   unsigned short* lwork;   // [TILE + 1] occupied slots
-  unsigned* hist;          // [MAX_P + 1]
+  unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); with
+                           //            per-occurrence counts later reused as the entries' frequency sums
   unsigned* wtot;          // [8]
-  unsigned short* lpart;   // [LS + 1]   partial row of the slot's key (apply / dedup); ALIASES lwork + hist,
-                           //            written once those are dead
-  // aliases of lkeys, valid after the entries are written:
-  unsigned short* perm;    // [TILE]     tile rows grouped by key
-  unsigned short* pslot;   // [TILE]     slot (key) of each sorted row
-  float* red;              // [TBT / fold_lanes][dim] sums of keys whose rows span two groups' chunks
 };
+static_assert(MAX_P + 1 >= TILE + 1, "hist doubles as the per-entry frequency sums");
 
-// gradient fold geometry: lanes per row (8 up to dim 64, 16 up to 128, 32 up to 256) so that the
-// LDS rows of chunk-spanning keys, red[TBT / lanes][dim], stay <= 16 KB and always fit in the dead
-// lkeys region: every dim keeps two 512-thread tile blocks per CU (dim 128 with 8 lanes: 81 KB -> one)
-__host__ __device__ inline int fold_lanes(int D) { return D <= 64 ? 8 : (D <= 128 ? 16 : 32); }
-__host__ __device__ inline size_t fold_red_bytes(int D) {
-  return ((D & 3) == 0 && D <= 256) ? (size_t)(TBT / fold_lanes(D)) * D * 4 : 0;   // scalar path: no LDS rows
-}
-
-// lpart may reuse lwork + hist once those are dead, if they are big enough
-constexpr bool LPART_ALIAS = ((TILE + 1) * 2 + 15) / 16 * 16 + (MAX_P + 1) * 4 >= (LS + 1) * 2;
-
-__host__ __device__ inline size_t tile_smem_bytes(int mode, int D) {
+__host__ __device__ inline size_t tile_smem_bytes(bool first) {
   size_t b = (size_t)(LS + 1) * 8 + 16;        // lkeys
   b += (size_t)(LS + 1) * 4 + 16;              // lcnt
   b += (size_t)(LS + 1) * 2 + 16;              // lpos
   b += (size_t)(TILE + 1) * 2 + 16;            // lwork
   b += (size_t)(MAX_P + 1) * 4 + 16;           // hist
   b += 64;                                     // wtot
-  if (mode != MODE_LOOKUP) b += (size_t)(LS + 1) * 2 + 16;  // lfirst
-  if (mode == MODE_APPLY || mode == MODE_DEDUP) {
-    if (!LPART_ALIAS) b += (size_t)(LS + 1) * 2 + 16;  // lpart
-    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + fold_red_bytes(D) + 64;
-    const size_t lk = (size_t)(LS + 1) * 8 + 16;
-    if (alias > lk) b += alias - lk;           // big dims: the fold scratch outgrows lkeys
-  }
+  if (first) b += (size_t)(LS + 1) * 2 + 16;   // lfirst
   return b;
 }
 
-template <int MODE>
-__device__ __forceinline__ TileSmem carve_tile(char* base, int D) {
+template <bool FIRST>
+__device__ __forceinline__ TileSmem carve_tile(char* base) {
   TileSmem s;
   auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
-  char* lk = take((size_t)(LS + 1) * 8);
-  s.lkeys = reinterpret_cast<long long*>(lk);
-  if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-    const size_t alias = (size_t)TILE * 2 + (size_t)TILE * 2 + fold_red_bytes(D) + 64;
-    const size_t lkb = ((size_t)(LS + 1) * 8 + 15) & ~(size_t)15;
-    if (alias > lkb) take(alias - lkb);
-    s.perm = reinterpret_cast<unsigned short*>(lk);
-    s.pslot = reinterpret_cast<unsigned short*>(lk + (size_t)TILE * 2);
-    s.red = reinterpret_cast<float*>(lk + (size_t)TILE * 4 + 32);
-  } else {
-    s.perm = nullptr; s.pslot = nullptr; s.red = nullptr;
-  }
+  s.lkeys = reinterpret_cast<long long*>(take((size_t)(LS + 1) * 8));
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
   s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
-  char* lw = take((size_t)(TILE + 1) * 2);
-  s.lwork = reinterpret_cast<unsigned short*>(lw);
+  s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
   s.wtot = reinterpret_cast<unsigned*>(take(64));
-  s.lfirst = (MODE != MODE_LOOKUP) ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
-  s.lpart = nullptr;
-  if (MODE == MODE_APPLY || MODE == MODE_DEDUP)
-    s.lpart = LPART_ALIAS ? reinterpret_cast<unsigned short*>(lw) : reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.lfirst = FIRST ? reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2)) : nullptr;
   return s;
 }
 
-template <int MODE, typename IdT, int VPL>
+// det != 0: a position's rank among its key's occurrences in the tile follows the input order (the
+// deterministic reduction mode); otherwise it is the arrival order of the LDS atomics.
+template <bool FIRST, typename IdT>
 __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict__ ids,
-                                          const int* __restrict__ counts,
-                                          const float* __restrict__ grad, long long n, int D) {
+                                          const int* __restrict__ counts, long long n, int det) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  TileSmem sm = carve_tile<MODE>(smem_raw, D);
-  __shared__ unsigned lnwork, lsent, lnpart, lM;
+  TileSmem sm = carve_tile<FIRST>(smem_raw);
+  __shared__ unsigned lnwork, lsent;
 
   const int tid = threadIdx.x;
   const unsigned tile = blockIdx.x;
   const long long base = (long long)tile * TILE;
   const unsigned P = w.P;
+  constexpr bool PAIRS = std::is_same<IdT, IdCount>::value;
+  const bool has_counts = !FIRST && (PAIRS || counts != nullptr);
   KV_STAMP(0);
 
   // the tile's ids (and counts) are requested first: their HBM latency runs under the LDS clearing
@@ -131,10 +103,10 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     kreg[k] = 0; creg[k] = 1;
     if (i < n) {
       kreg[k] = load_id(ids, (size_t)i);
-      if constexpr (std::is_same<IdT, IdCount>::value) {
+      if constexpr (PAIRS) {
         const long long ci = ids[i].count;             // counts travel with the ids
         creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
-      } else if (MODE == MODE_LOOKUP && counts != nullptr) {
+      } else if (!FIRST && counts != nullptr) {
         // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
         const int ci = counts[i];
         creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
@@ -146,7 +118,7 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     sm.lcnt[s] = 0;
   }
   for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
-  if (tid == 0) { lnwork = 0; lsent = 0; lnpart = 0; }
+  if (tid == 0) { lnwork = 0; lsent = 0; }
   __syncthreads();
 
   // ---- phase 1: LDS hash insert of this tile's ids --------------------------------------
@@ -158,11 +130,10 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     myrank[k] = 0;
     if (i < n) {
       const long long key = kreg[k];
-      const unsigned c = creg[k];
       unsigned h;
       if (key == EMPTY_KEY) {
         h = LS;
-        if (atomicCAS(&lsent, 0u, 1u) == 0u && MODE != MODE_LOOKUP) sm.lfirst[LS] = (unsigned short)(k * TBT + tid);
+        if (atomicCAS(&lsent, 0u, 1u) == 0u && FIRST) sm.lfirst[LS] = (unsigned short)(k * TBT + tid);
       } else {
         h = (unsigned)(mix64((unsigned long long)key) >> 40) & (LS - 1);
         for (;;) {
@@ -170,14 +141,14 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
               atomicCAS(reinterpret_cast<unsigned long long*>(&sm.lkeys[h]),
                         (unsigned long long)EMPTY_KEY, (unsigned long long)key);
           if (old == (unsigned long long)EMPTY_KEY) {
-            if (MODE != MODE_LOOKUP) sm.lfirst[h] = (unsigned short)(k * TBT + tid);
+            if (FIRST) sm.lfirst[h] = (unsigned short)(k * TBT + tid);
             break;
           }
           if (old == (unsigned long long)key) break;
           h = (h + 1) & (LS - 1);
         }
       }
-      myrank[k] = atomicAdd(&sm.lcnt[h], c);
+      myrank[k] = atomicAdd(&sm.lcnt[h], 1u);
       tslot[k] = h;
     }
   }
@@ -202,7 +173,8 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
       const unsigned s = sm.lwork[wi];
       const long long key = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
       wp[q] = part_of(key, w.pshift);
-      wr[q] = atomicAdd(&sm.hist[wp[q]], 1u);
+      // one entry and lcnt positions for the partition: both halves of the word in one atomic
+      wr[q] = atomicAdd(&sm.hist[wp[q]], 1u | (sm.lcnt[s] << 16)) & 0xFFFFu;
     }
   }
   __syncthreads();
@@ -214,215 +186,96 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     unsigned tot;
     unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
     for (unsigned p = p0; p < p1; ++p) { const unsigned c = sm.hist[p]; sm.hist[p] = run; run += c; }
-    if (tid == 0) sm.hist[P] = nwork;
+    if (tid == 0) sm.hist[P] = tot;
   }
   __syncthreads();
-  unsigned short* toff = w.toff + (size_t)tile * (P + 1);
-  for (unsigned p = tid; p <= P; p += TBT) toff[p] = (unsigned short)sm.hist[p];
-  unsigned short wk[WPT];  // partial row of this thread's work items (lpart aliases lwork / hist)
+  unsigned* toff = w.toff + (size_t)tile * (P + 1);
+  for (unsigned p = tid; p <= P; p += TBT) toff[p] = sm.hist[p];
+  unsigned wpos[WPT];
+  unsigned short wslot[WPT];
 #pragma unroll
   for (int q = 0; q < WPT; ++q) {
-    wk[q] = 0xFFFFu;
+    wpos[q] = 0xFFFFFFFFu; wslot[q] = 0;
     const unsigned wi = tid + q * TBT;
     if (wi < nwork) {
       const unsigned s = sm.lwork[wi];
       const long long key = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
-      const unsigned pos = sm.hist[wp[q]] + wr[q];
+      const unsigned pos = (sm.hist[wp[q]] & 0xFFFFu) + wr[q];
       const size_t e = (size_t)tile * TILE + pos;
+      wpos[q] = pos; wslot[q] = (unsigned short)s;
       sm.lpos[s] = (unsigned short)pos;
       w.ent_key[e] = key;
-      if (MODE == MODE_LOOKUP) {
-        const unsigned c = sm.lcnt[s];
-        w.ent_a[e] = c > 65535u ? 65535u : c;  // saturating add is order independent: clamp early
-      } else {
-        const unsigned first = (unsigned)base + sm.lfirst[s];
-        w.ent_a[e] = first;
-        if (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-          if (sm.lcnt[s] >= 2u) {
-            const unsigned k = atomicAdd(&lnpart, 1u);
-            wk[q] = (unsigned short)k;
-            w.ent_b[e] = PART_BIT | (tile * PARTCAP + k);
-          } else {
-            w.ent_b[e] = first;
-          }
-        }
+      if (FIRST) {
+        w.ent_a[e] = (unsigned)base + sm.lfirst[s];
+      } else if (!has_counts) {
+        const unsigned c = sm.lcnt[s];   // <= TILE: the frequency count equals the occurrences
+        w.ent_a[e] = c | (c << 16);
       }
     }
   }
   __syncthreads();
-  if constexpr (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-    unsigned short ws[WPT];
-#pragma unroll
-    for (int q = 0; q < WPT; ++q) ws[q] = (tid + q * TBT) < nwork ? sm.lwork[tid + q * TBT] : (unsigned short)0xFFFF;
-    __syncthreads();  // lwork / hist are dead now: lpart takes their place
-#pragma unroll
-    for (int q = 0; q < WPT; ++q)
-      if (ws[q] != 0xFFFFu) sm.lpart[ws[q]] = wk[q];
-    __syncthreads();
-  }
   KV_STAMP(2);
 
-  // ---- phase 4: every input position learns its key's entry -------------------------------
+  // ---- phase 4: every input position learns its key's entry and its rank in the tile -----------
+  if (det) {
+    // rank = occurrences of the key at smaller input positions: the thread scans its key's positions
+    // through the LDS hash slot list (O(count) per position; the deterministic mode pays for it)
+    // positions of one slot are found by a pass over the tile's slots kept in registers of all
+    // threads: publish slot per position in lwork's place (TILE entries of 2 bytes cannot hold a slot
+    // index of 13 bits? they can: LS + 1 = 4097 < 65536)
+    unsigned short* pslot = sm.lwork;   // lwork is dead (entries are written)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const int lp = k * TBT + tid;
+      if (base + lp < n) pslot[lp] = (unsigned short)tslot[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const int lp = k * TBT + tid;
+      if (base + lp < n && sm.lcnt[tslot[k]] > 1u) {
+        const unsigned short me = (unsigned short)tslot[k];
+        unsigned r = 0;
+        for (int q = 0; q < lp; ++q) r += pslot[q] == me;
+        myrank[k] = r;
+      } else {
+        myrank[k] = 0;
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     const long long i = base + (long long)k * TBT + tid;
-    if (i < n) w.slot_of_id[i] = tile * TILE + sm.lpos[tslot[k]];
+    if (i < n) w.slot_rank[i] = (tile * TILE + sm.lpos[tslot[k]]) | (myrank[k] << RANK_SHIFT);
+  }
+  // ---- per-occurrence counts: frequency sum per entry (hist is dead: reused as lfreq) -------------
+  if (has_counts) {
+    __syncthreads();
+    for (unsigned e = tid; e <= (unsigned)TILE; e += TBT) sm.hist[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k)
+      if (tslot[k] != 0xFFFFFFFFu) atomicAdd(&sm.hist[sm.lpos[tslot[k]]], creg[k]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+      if (wpos[q] == 0xFFFFFFFFu) continue;
+      const unsigned s = wslot[q];
+      const unsigned f = sm.hist[wpos[q]];
+      // saturating add is order independent: clamp early
+      w.ent_a[(size_t)tile * TILE + wpos[q]] = sm.lcnt[s] | ((f > 65535u ? 65535u : f) << 16);
+    }
   }
   KV_STAMP(3);
-
-  // ---- phase 5 (optimizer ops): fold the rows of keys that repeat inside the tile ---------
-  if constexpr (MODE == MODE_APPLY || MODE == MODE_DEDUP) {
-    // offsets of the multi-row keys in the sorted row list (lfirst is free now)
-    {
-      constexpr int PER = (LS + 1 + TBT - 1) / TBT;  // 9
-      unsigned c[PER];
-      unsigned sum = 0;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int s = tid * PER + q;
-        c[q] = (s <= LS && sm.lcnt[s] >= 2u) ? sm.lcnt[s] : 0u;
-        sum += c[q];
-      }
-      unsigned tot;
-      unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int s = tid * PER + q;
-        if (s <= LS) { sm.lfirst[s] = (unsigned short)run; run += c[q]; }
-      }
-      if (tid == 0) lM = tot;
-    }
-    __syncthreads();  // lkeys is dead from here on: perm / pslot / red alias it
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      if (tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] >= 2u) {
-        const unsigned pos = sm.lfirst[tslot[k]] + myrank[k];
-        sm.perm[pos] = (unsigned short)(k * TBT + tid);
-        sm.pslot[pos] = (unsigned short)tslot[k];
-      }
-    }
-    // VPL (host's row width class: 1, 2, 4, 8 float4 per 8 lanes) -> LPF lanes per row x VPF float4 per lane
-    constexpr int LPF = VPL <= 2 ? 8 : (VPL == 4 ? 16 : 32);
-    constexpr int VPF = VPL <= 2 ? (VPL > 0 ? VPL : 1) : 2;
-    constexpr unsigned G = TBT / LPF;  // row groups
-    if constexpr (VPL > 0)
-      for (unsigned x = tid; x < G * (unsigned)D; x += TBT) sm.red[x] = 0.f;
-    __syncthreads();
-    KV_STAMP(4);
-    const unsigned M = lM;
-    const int lane8 = tid % LPF;
-    const unsigned grp = tid / LPF;
-    float* prow0 = w.part + (size_t)tile * PARTCAP * D;
-    const unsigned C = (M + G - 1) / G;  // sorted rows per group
-    if constexpr (VPL > 0) {
-      // Each group folds one contiguous chunk of the sorted row list in registers, rows loaded
-      // RB at a time (independent 16-byte loads).  A key whose rows lie inside the chunk is
-      // stored once; a key that spans chunks (tile-hot keys) meets in the LDS row of the chunk
-      // it starts in — at most one such key per chunk, so red[G][D] always suffices.
-      const int NV = D >> 2;
-      constexpr int RB = 16 / VPF;
-      const unsigned c0 = min(M, grp * C), c1 = min(M, (grp + 1) * C);
-      unsigned cur = 0xFFFFFFFFu;
-      float4 acc[VPF];
-      auto flush = [&]() {
-        if (cur == 0xFFFFFFFFu) return;
-        const unsigned st = sm.lfirst[cur], en = st + sm.lcnt[cur];
-        if (st >= c0 && en <= c1) {
-          float4* dst = reinterpret_cast<float4*>(prow0 + (size_t)sm.lpart[cur] * D);
-#pragma unroll
-          for (int v = 0; v < VPF; ++v) {
-            const int q = lane8 + LPF * v;
-            if (q < NV) dst[q] = acc[v];
-          }
-        } else {
-          float* rd = sm.red + (size_t)(st / C) * D;
-#pragma unroll
-          for (int v = 0; v < VPF; ++v) {
-            const int q = lane8 + LPF * v;
-            if (q < NV) {
-              atomicAdd(&rd[4 * q + 0], acc[v].x); atomicAdd(&rd[4 * q + 1], acc[v].y);
-              atomicAdd(&rd[4 * q + 2], acc[v].z); atomicAdd(&rd[4 * q + 3], acc[v].w);
-            }
-          }
-        }
-      };
-      for (unsigned eb = c0; eb < c1; eb += RB) {
-        float4 val[RB][VPF];
-        unsigned ks[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const unsigned e = eb + r;
-          ks[r] = 0xFFFFFFFFu;
-#pragma unroll
-          for (int v = 0; v < VPF; ++v) val[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e < c1) {
-            ks[r] = sm.pslot[e];
-            const float4* g4 = reinterpret_cast<const float4*>(grad + (size_t)(base + sm.perm[e]) * D);
-#pragma unroll
-            for (int v = 0; v < VPF; ++v) {
-              const int q = lane8 + LPF * v;
-              if (q < NV) {  // read once: streaming load
-                const float* gp = reinterpret_cast<const float*>(g4 + q);
-                val[r][v] = make_float4(__builtin_nontemporal_load(gp), __builtin_nontemporal_load(gp + 1),
-                                        __builtin_nontemporal_load(gp + 2), __builtin_nontemporal_load(gp + 3));
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          if (ks[r] == 0xFFFFFFFFu) continue;
-          if (ks[r] != cur) {
-            flush();
-            cur = ks[r];
-#pragma unroll
-            for (int v = 0; v < VPF; ++v) acc[v] = val[r][v];
-          } else {
-#pragma unroll
-            for (int v = 0; v < VPF; ++v) {
-              acc[v].x += val[r][v].x; acc[v].y += val[r][v].y;
-              acc[v].z += val[r][v].z; acc[v].w += val[r][v].w;
-            }
-          }
-        }
-      }
-      flush();
-      __syncthreads();
-      KV_STAMP(5);
-      // keys that span chunks: the chunk they start in owns their LDS row
-      for (unsigned x = tid; x < G * (unsigned)D; x += TBT) {
-        const unsigned b = x / D, e = x % D;
-        const unsigned bend = min(M, (b + 1) * C);
-        if (b * C >= M || bend == 0) continue;
-        const unsigned sl = sm.pslot[bend - 1];
-        const unsigned st = sm.lfirst[sl], en = st + sm.lcnt[sl];
-        if (en > bend && st / C == b) prow0[(size_t)sm.lpart[sl] * D + e] = sm.red[x];
-      }
-    } else {
-      // any dim: one thread per element of one key at a time, rows in sorted order
-      for (unsigned e0 = 0; e0 < M;) {
-        const unsigned sl = sm.pslot[e0];
-        const unsigned cnt = sm.lcnt[sl];
-        for (int e = tid; e < D; e += TBT) {
-          float sum = 0.f;
-          for (unsigned r = 0; r < cnt; ++r) sum += grad[(size_t)(base + sm.perm[e0 + r]) * D + e];
-          prow0[(size_t)sm.lpart[sl] * D + e] = sum;
-        }
-        e0 += cnt;
-      }
-    }
-  }
-  KV_STAMP(6);
 }
 
 // One op on one table (arguments by value) or the same op on many tables in one launch
 // (blockIdx.y = table; arguments from a descriptor array in device memory, see MultiDesc below).
 struct MultiDesc;
-template <int MODE, typename IdT, int VPL>
+template <bool FIRST, typename IdT>
 __global__ void __launch_bounds__(TBT) k_tile(WsDev w, const IdT* __restrict__ ids,
-                                             const int* __restrict__ counts,
-                                             const float* __restrict__ grad, long long n, int D) {
-  tile_body<MODE, IdT, VPL>(w, ids, counts, grad, n, D);
+                                             const int* __restrict__ counts, long long n, int det) {
+  tile_body<FIRST, IdT>(w, ids, counts, n, det);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -436,12 +289,24 @@ struct PartArgs {
   int scatter_op, is_insert;  // MODE_SCATTER
   int mark_what;              // MODE_MARK: 0 = blacklist, 1 = frequency words (in fvals)
   const unsigned* fvals;
-  long long* out_keys;        // MODE_DEDUP / MODE_UNIQUE
-  float* out_sum;
+  long long* out_keys;        // MODE_UNIQUE
+  float* out_sum;             // MODE_DEDUP fold: out_sum[row] = the key's sum
   int* out_counts;            // MODE_UNIQUE: occurrences (saturating) of each unique key
   int count_once;             // MODE_LOOKUP: frequency += 1 per unique key instead of per occurrence
-  long long direct_rows;      // MODE_DEDUP, > 0: keys ARE output row indices in [0, direct_rows)
-                              // (tf.unsorted_segment_sum): out_sum[key] = sum, no key list, no counter
+  long long direct_rows;      // MODE_UNIQUE, > 0: keys ARE output row indices in [0, direct_rows)
+                              // (tf.unsorted_segment_sum): no key list, no counter
+  int use_hints;              // apply: ts0 is tv's attached slot table (Entry::hint names ts0's rows)
+  int fold_op;                // MODE_DEDUP fold: KV_SCATTER_ADD (sum) / MUL (product) / MIN / MAX / ASSIGN (last)
+  int det;                    // deterministic reduction mode
+  long long n;                // ids in the batch
+};
+
+// probing gather of the training lookup, run by the blocks past the partitions of k_part_keys
+struct GatherRole {
+  const void* ids;
+  int ids_kind;               // 0 int64, 1 int32, 2 (id, count) int64 pairs
+  float* out;
+  long long n;
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -482,9 +347,9 @@ __device__ __forceinline__ unsigned xcd_partition(unsigned b, unsigned P) {
   return P >= 8u ? (b & 7u) * (P >> 3) + (b >> 3) : b;
 }
 
-// ---- k_part_keys: MODE_LOOKUP / MODE_SCATTER / MODE_MARK ---------------------------------------
+// ---- k_part_keys ---------------------------------------------------------------------------------
 // Streams the partition's entries twice and keeps only the unique keys in LDS, so a key that
-// occurs in every tile costs nothing extra.  256 threads, ~21 KB LDS, so every block of a
+// occurs in every tile costs nothing extra.  256 threads, ~30 KB LDS, so every block of a
 // 1024-partition launch is resident at once (4 per CU needs < 40 KB).
 constexpr int TBK = 256;
 constexpr int HSK = 1024;          // LDS hash slots
@@ -494,24 +359,29 @@ constexpr int UCAPK = HSK * 3 / 4; // unique keys per round
 // tile t's segment.  Entry x of the partition (0 <= x < E) lives at tile t = last tpre[t] <= x.
 // Filled by seg_directory(); lets every thread take entries x = tid, tid + T, ... whatever the number
 // of tiles (one tile with 1000 entries is as parallel as 1000 tiles with one entry).
+// *pbase = input positions that belong to partitions < p = where partition p starts in the sorted list.
 template <int T, int NW>
 __device__ __forceinline__ unsigned seg_directory(const WsDev& w, unsigned p, unsigned short* tpre,
-                                                  unsigned short* tstart, unsigned* wtot) {
+                                                  unsigned short* tstart, unsigned* wtot, unsigned* pbase) {
   const unsigned NT = w.ntiles, P = w.P;
   const unsigned per = (NT + T - 1) / T;
   const unsigned t0 = min(NT, threadIdx.x * per), t1 = min(NT, t0 + per);
-  unsigned sum = 0;
+  unsigned sum = 0, psum = 0;
   for (unsigned t = t0; t < t1; ++t) {
-    const unsigned short* to = w.toff + (size_t)t * (P + 1) + p;
-    const unsigned s0 = to[0], s1 = to[1];
+    const unsigned* to = w.toff + (size_t)t * (P + 1) + p;
+    const unsigned a = to[0], b = to[1];
+    const unsigned s0 = a & 0xFFFFu, s1 = b & 0xFFFFu;
     tstart[t] = (unsigned short)s0;
     tpre[t] = (unsigned short)(s1 - s0);  // length for now
     sum += s1 - s0;
+    psum += a >> 16;
   }
-  unsigned E;
+  unsigned E, PB;
+  block_excl_scan<NW>(psum, wtot, &PB);
   unsigned run = block_excl_scan<NW>(sum, wtot, &E);
   for (unsigned t = t0; t < t1; ++t) { const unsigned len = tpre[t]; tpre[t] = (unsigned short)min(run, 65535u); run += len; }
   __syncthreads();
+  *pbase = PB;
   return E;
 }
 __device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const unsigned short* tstart,
@@ -526,12 +396,16 @@ __device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const un
 
 template <int MODE>
 __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a) {
+  constexpr bool ORD = (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE || MODE == MODE_APPLYIDX);
+  constexpr bool CNT = (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE);
   __shared__ long long hkey[HSK + 1];
-  __shared__ unsigned hval[HSK + 1];   // lookup: summed count; scatter / mark: an input position
-  __shared__ unsigned hrow[HSK + 1];   // row id of the key
+  __shared__ unsigned hval[HSK + 1];   // lookup / unique: summed frequency count; scatter / mark: an input position
+  __shared__ unsigned hrow[HSK + 1];   // row id of the key (bit 31: inserted now); unique: dense index
+  __shared__ unsigned hocc[ORD ? HSK + 1 : 1];   // occurrences of the key, then its start in the sorted list
+  __shared__ unsigned hrun[ORD ? HSK + 1 : 1];   // positions handed to the key's entries so far (pass 2)
   __shared__ unsigned short lnew[UCAPK + 8];  // slots whose row was inserted now / needs a row scan
   __shared__ unsigned short ulist[UCAPK + 8]; // slots of the unique keys, in order of first sight
-  __shared__ unsigned lnu, lsent, lnnew;
+  __shared__ unsigned lnu, lsent, lnnew, lpcur;
   __shared__ unsigned wtot[8];
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* tpre = reinterpret_cast<unsigned short*>(smem_raw);
@@ -542,7 +416,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   const unsigned NT = w.ntiles;
   const int D = a.tv.dim;
   KV_STAMPP(0);
-  const unsigned E = seg_directory<TBK, TBK / 64>(w, p, tpre, tstart, wtot);
+  unsigned pbase;
+  const unsigned E = seg_directory<TBK, TBK / 64>(w, p, tpre, tstart, wtot, &pbase);
   if (E == 0) return;
   const bool wide = E > 65535u;  // needs a key set crafted against the partition hash; guarded, not handled
 
@@ -550,17 +425,20 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   // class is processed exactly once (block-uniform control flow)
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
-  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; }
   __syncthreads();
-  if (wide) {  // never silent: the next synchronous call on the table reports it
-    if (tid == 0) atomicExch(&a.tv.counters[1], 2u);
+  if (wide) {  // never silent: every later kernel of this op sees the flag and does nothing; the next call reports it
+    if (tid == 0) raise_error(a.tv, 2u);
     return;
   }
   while (sp > 0) {
     const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
     __syncthreads();
     if (tid == 0) --sp;
-    for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
+    for (int s = tid; s <= HSK; s += TBK) {
+      hkey[s] = EMPTY_KEY; hval[s] = 0;
+      if constexpr (ORD) { hocc[s] = 0; hrun[s] = 0; }
+    }
     if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
     __syncthreads();
     // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
@@ -569,7 +447,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     // slot and position of the first EB entries stay in registers for pass 2
     constexpr int EB = 8;
     unsigned cge[EB];
-    unsigned short cslot[EB];
+    unsigned short cslot[EB], cocc[EB];
     const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
     for (unsigned x0 = 0; x0 < E; x0 += EB * TBK) {
       unsigned ge[EB];
@@ -587,7 +465,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
       }
 #pragma unroll
       for (int k = 0; k < EB; ++k) {
-        if (x0 == 0) { cge[k] = ge[k]; cslot[k] = 0; }
+        if (x0 == 0) { cge[k] = ge[k]; cslot[k] = 0; cocc[k] = 0; }
         if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
         if (lnu >= (unsigned)UCAPK) continue;  // overflow: this class is split below
         bool first;
@@ -596,9 +474,10 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           const unsigned u = atomicAdd(&lnu, 1u);
           if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
         }
-        if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) atomicAdd(&hval[h], ea[k]);
-        else if (first) hval[h] = ea[k];
-        if (x0 == 0) cslot[k] = (unsigned short)h;
+        if (CNT) atomicAdd(&hval[h], ea[k] >> 16);
+        else if (!ORD && first) hval[h] = ea[k];
+        if constexpr (ORD) atomicAdd(&hocc[h], ea[k] & 0xFFFFu);
+        if (x0 == 0) { cslot[k] = (unsigned short)h; cocc[k] = (unsigned short)(ea[k] & 0xFFFFu); }
       }
     }
     __syncthreads();
@@ -609,27 +488,61 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
           stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
         } else {
-          atomicExch(&a.tv.counters[1], 2u);   // keys that no sub-hash separates: reported, not applied
+          raise_error(a.tv, 2u);   // keys that no sub-hash separates: reported, not applied
         }
       }
       __syncthreads();
       continue;
     }
     KV_STAMPP(1);
+    const unsigned nu = lnu;
+
+    // ---- the class's keys in the sorted position list: start = partition start + keys of the classes
+    //      before + occurrences of the keys before it in this class (block scan over the unique list)
+    if constexpr (ORD) {
+      constexpr int PERU = (UCAPK + TBK - 1) / TBK;
+      unsigned c[PERU];
+      unsigned sum = 0;
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        c[q] = u < nu ? hocc[ulist[u]] : 0u;
+        sum += c[q];
+      }
+      const unsigned cur = lpcur;
+      unsigned tot;
+      unsigned run = cur + block_excl_scan<TBK / 64>(sum, wtot, &tot);
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u < nu) { hocc[ulist[u]] = run; run += c[q]; }
+      }
+      __syncthreads();
+      if (tid == 0) lpcur = cur + tot;
+    }
 
     // ---- owner work: one thread per unique key ------------------------------------------------
-    const unsigned nu = lnu;
-    if (MODE == MODE_UNIQUE) {
-      // tf.unique_with_counts: dense index = block base (ONE global atomic per block) + local rank
+    if constexpr (MODE == MODE_UNIQUE) {
+      // tf.unique_with_counts: dense index = block base (ONE global atomic per block) + local rank;
+      // direct_rows: the keys are the output rows themselves (tf.unsorted_segment_sum)
       __shared__ unsigned lbase;
-      if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);
-      __syncthreads();
+      if (a.direct_rows == 0) {
+        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);
+        __syncthreads();
+      }
       for (unsigned u = tid; u < nu; u += TBK) {
         const unsigned s = ulist[u];
-        const unsigned dense = lbase + u;
+        const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+        unsigned dense;
+        if (a.direct_rows > 0) {
+          dense = (key >= 0 && key < a.direct_rows) ? (unsigned)key : ROW_MASK;   // out of range: dropped
+        } else {
+          dense = lbase + u;
+          a.out_keys[dense] = key;
+          if (a.out_counts) a.out_counts[dense] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
+        }
         hrow[s] = dense;
-        a.out_keys[dense] = (s == HSK) ? EMPTY_KEY : hkey[s];
-        if (a.out_counts) a.out_counts[dense] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
+        w.ohead[hocc[s]] = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), dense, 0u);
       }
       __syncthreads();
     }
@@ -639,7 +552,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     // together, so it pays the two dependent hops once per batch, not once per key.
     constexpr int OB = 4;
     for (unsigned u0 = tid; u0 < nu && MODE != MODE_UNIQUE; u0 += OB * TBK) {
-      unsigned sl[OB], r[OB];
+      unsigned sl[OB], r[OB], hint[OB];
       long long key[OB];
       unsigned long long pp[OB];
       Entry en[OB];
@@ -647,7 +560,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
 #pragma unroll
       for (int k = 0; k < OB; ++k) {
         const unsigned u = u0 + k * TBK;
-        sl[k] = 0xFFFFFFFFu; r[k] = 0; isnew[k] = false; key[k] = 0; pp[k] = 0;
+        sl[k] = 0xFFFFFFFFu; r[k] = 0; isnew[k] = false; key[k] = 0; pp[k] = 0; hint[k] = 0;
         if (u < nu) {
           sl[k] = ulist[u];
           key[k] = (sl[k] == HSK) ? EMPTY_KEY : hkey[sl[k]];
@@ -660,10 +573,17 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         if (sl[k] == 0xFFFFFFFFu) continue;
         // warm path: a read-only probe; the insert (atomics, row allocation) is a cold branch.
         // import frequency words only touch keys that exist (dynamic_restore.hpp:232-246)
-        r[k] = table_find_from(a.tv, key[k], pp[k], en[k]);
-        if (__builtin_expect(r[k] == 0u, 0) && !(MODE == MODE_MARK && a.mark_what == 1))
+        r[k] = table_find_from(a.tv, key[k], pp[k], en[k], &hint[k]);
+        if (__builtin_expect(r[k] == 0u, 0) && !(MODE == MODE_MARK && a.mark_what == 1)) {
           r[k] = table_find_or_insert(a.tv, key[k], &isnew[k]);
-        hrow[sl[k]] = r[k];
+          if (isnew[k]) hint[k] = 0;
+        }
+        hrow[sl[k]] = r[k] | (isnew[k] ? 0x80000000u : 0u);
+        if constexpr (ORD)
+          // bit 31 of the row word: the OPTIMIZER's index pass inserted the key (such a row is neither filtered
+          // by enter_threshold nor counted, FindOrInsertWithFnUnsafe returns false: table_manager.h:192-204)
+          w.ohead[hocc[sl[k]]] = make_uint4((unsigned)key[k], (unsigned)((unsigned long long)key[k] >> 32),
+                                            r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? 0x80000000u : 0u), hint[k]);
       }
       uint2 m[OB];
 #pragma unroll
@@ -689,6 +609,13 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           mp->freq = (a.day << 16) | lo;
           if (isnew[k]) mp->flags = (unsigned char)FLAG_DIRTY;
           if (m[k].y & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew[k] ? 0x8000u : 0u));
+        } else if (MODE == MODE_APPLYIDX) {
+          // FindOrInsertUnsafe (kv_variable.h:382-416): a key the optimizer meets first gets a row from the
+          // init rule, frequency word 1 (EmbeddingValue ctor, table_manager.h:94); existing rows are not touched
+          if (isnew[k]) {
+            mp->freq = 1u; mp->flags = 0;
+            lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | 0x8000u);
+          }
         } else {
           if (isnew[k]) { mp->freq = 1u; mp->flags = 0; }  // EmbeddingValue ctor: freq_val 1, day 0 (table_manager.h:94)
           lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew[k] ? 0x8000u : 0u));
@@ -699,7 +626,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     KV_STAMPP(2);
 
     // ---- rows that need lanes: init of new rows, flag recompute, scatter / mark bodies ---------
-    {
+    if (MODE != MODE_UNIQUE) {
       const int lane8 = tid & 7;
       const unsigned nn = lnnew;
       const unsigned npad = (nn + 7u) & ~7u;
@@ -709,7 +636,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         const unsigned s = sv & 0x7FFFu;
         const bool isnew = (sv & 0x8000u) != 0;
         const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
-        const unsigned r = live ? hrow[s] : 0u;
+        const unsigned r = live ? (hrow[s] & ROW_MASK) : 0u;
         float* row = row_ptr(a.tv, r);
         bool big = false, touch = false;
         if (live && r != 0) {
@@ -717,6 +644,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           if (MODE == MODE_LOOKUP) {
             if (!isnew)
               for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
+          } else if (MODE == MODE_APPLYIDX) {
+            // UpdateUnderThreshold of the fresh row (insert_func, kv_variable.h:398-399)
           } else if (MODE == MODE_MARK) {
             if (a.mark_what == 0) {
               for (int e = lane8; e < D; e += 8) row[e] = 0.f;
@@ -758,6 +687,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           if (MODE == MODE_LOOKUP) {
             const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
             *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
+          } else if (MODE == MODE_APPLYIDX) {
+            *fp = (unsigned char)(any ? 0u : FLAG_UNDER);
           } else if (MODE == MODE_MARK) {
             // a key first seen by the blacklist is inserted blacklisted with under_threshold
             // still false (EmbeddingValue(nullptr, true, 1, ...), table_manager.h:343-346)
@@ -775,19 +706,41 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     }
     KV_STAMPP(3);
 
-    // ---- pass 2 (lookup / unique): every entry learns its key's row / dense index --------------
-    if (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE) {
-      if (cached) {
+    // ---- pass 2: every entry learns its key's row / dense index and where its positions go ------
+    if constexpr (ORD) {
+      auto place = [&](unsigned ge, unsigned h, unsigned occ) {
+        const unsigned off = atomicAdd(&hrun[h], occ);
+        const unsigned rv = hrow[h];
+        w.ent_b[ge] = rv & ROW_MASK;
+        w.ent_base[ge] = (hocc[h] + off) | (off == 0u ? HEAD_BIT : 0u) | ((rv >> 31) ? NEW_BIT : 0u);
+      };
+      if (a.det) {
+        // deterministic mode: a key's entries take their positions in tile order = ascending x; one
+        // thread per key walks the partition's entries (O(E) per key: the mode pays for it)
+        for (unsigned u = tid; u < nu; u += TBK) {
+          const unsigned s = ulist[u];
+          const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+          unsigned off = 0;
+          const unsigned rv = hrow[s];
+          for (unsigned x = 0; x < E; ++x) {
+            const size_t ge = seg_entry(tpre, tstart, NT, x);
+            if (w.ent_key[ge] != key) continue;
+            w.ent_b[ge] = rv & ROW_MASK;
+            w.ent_base[ge] = (hocc[s] + off) | (off == 0u ? HEAD_BIT : 0u) | ((rv >> 31) ? NEW_BIT : 0u);
+            off += w.ent_a[ge] & 0xFFFFu;
+          }
+        }
+      } else if (cached) {
 #pragma unroll
         for (int k = 0; k < EB; ++k)
-          if (cge[k] != 0xFFFFFFFFu) w.ent_b[cge[k]] = hrow[cslot[k]];
+          if (cge[k] != 0xFFFFFFFFu) place(cge[k], cslot[k], cocc[k]);
       } else {
         for (unsigned x = tid; x < E; x += TBK) {
           const size_t ge = seg_entry(tpre, tstart, NT, x);
           const long long key = w.ent_key[ge];
           if (!in_round(key, R, round)) continue;
           bool first;
-          w.ent_b[ge] = hrow[lds_key_slot<HSK>(hkey, &lsent, key, false, &first)];
+          place((unsigned)ge, lds_key_slot<HSK>(hkey, &lsent, key, false, &first), w.ent_a[ge] & 0xFFFFu);
         }
       }
     }
@@ -799,556 +752,427 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   }
 }
 
-// ---- k_part_sum: MODE_APPLY / MODE_DEDUP ---------------------------------------------------------
-// Per partition: (1) copy the entries (8 B each) into LDS and hash their keys, (2) group the
-// entries by key (counting sort), (3) ONE thread per unique key probes the var and slot tables
-// (so every row address is known before any row is touched), (4) each LPR-lane group walks a
-// contiguous chunk of the grouped contribution list: contributions are loaded RB at a time and
-// summed in registers; when a key ends inside the chunk its rows are updated on the spot; a key
-// that spans chunks (present in many tiles) meets in the LDS row of the chunk it starts in and
-// is finished after a barrier.  Work is balanced by contributions, not by keys.
-constexpr int TBS = 256;
-constexpr int HSS = 1024;
-constexpr int UCAPS = HSS / 2;   // 512 keys per round: keeps FTRL (one more row-id list) and 2M-id batches (4 KB directory) at 4 blocks per CU
-constexpr int ECAPS = 1600;
-// heavy keys per round folded by the whole block: their LDS sum rows are capped at 2 KB so that
-// four blocks still fit a CU's 160 KB at every dim (D = 64 with 16 rows: 41.5 KB per block -> 3 per CU,
-// a quarter of the 1024 blocks then starts late)
-__host__ __device__ inline int heavy_rows(int D) {
-  int r = 2048 / (4 * D);
-  return r < 1 ? 1 : (r > 16 ? 16 : r);
-}
-constexpr int HMAXS = 16;                  // upper bound of heavy_rows() (the rest
-                                           // are summed by single groups)
-constexpr unsigned LOC_LDS = 0xFFFFFFE0u;  // gradient locator: row of the block's LDS hsum
-
-__host__ __device__ inline size_t part_sum_smem_bytes(int mode, int opt, int D, int lpr, unsigned ntiles) {
-  size_t b = (size_t)ntiles * 4 + 32;  // tpre, tstart
-  b += (size_t)(HSS + 1) * 8 + 16 + (size_t)(HSS + 1) * 4 + 16 + (size_t)(HSS + 1) * 2 + 16;  // hkey, hval, hu
-  b += (size_t)ECAPS * 4 + 16 + (size_t)ECAPS * 2 * 2 + 32;            // eb, eslot, perm
-  b += (size_t)UCAPS * 2 + 16 + 64;                                    // ulist, wtot
-  b += (size_t)UCAPS * 4 * 2 + 32 + (size_t)UCAPS + 16;                // utag, ur0, unew
-  if (opt == OPT_FTRL) b += (size_t)UCAPS * 4 + 16;                    // ur1
-  b += (size_t)heavy_rows(D) * D * 4 + 16;                             // hsum
-  return b;
-}
-
-// one thread: var + slot table probes of one key, read-only probes first so the loads overlap.
-// FindOrInsertUnsafe(var, filter_out != nullptr) kv_variable.h:382-408 and
-// FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear before accum (training_ops.cc:701-704)
-template <int OPT>
-__device__ __forceinline__ void probe_issue(const PartArgs& a, long long key, Entry* ev, Entry* e0, Entry* e1) {
-  // hop 1: the home entries of every table, together
-  const unsigned long long hh = mix64((unsigned long long)key);
-  *ev = load_entry(&a.tv.entries[home_of(a.tv, key, hh)]);
-  *e0 = load_entry(&a.ts0.entries[home_of(a.ts0, key, hh)]);
-  *e1 = *e0;
-  if (OPT == OPT_FTRL) *e1 = load_entry(&a.ts1.entries[home_of(a.ts1, key, hh)]);
-}
-struct ProbeMid {  // between the two halves of a probe: rows found / created, hop-2 words in flight
-  unsigned rv, s0, s1, nb;
-  uint2 mv;
-  unsigned f0, f1;
-};
-template <int OPT>
-__device__ __forceinline__ void probe_rows(const PartArgs& a, long long key, const Entry& ev, const Entry& e0,
-                                           const Entry& e1, ProbeMid* pm) {
-  const unsigned long long hh = mix64((unsigned long long)key);
-  const unsigned long long pv = home_of(a.tv, key, hh), p0 = home_of(a.ts0, key, hh);
-  const unsigned long long p1 = (OPT == OPT_FTRL) ? home_of(a.ts1, key, hh) : 0ull;
-  unsigned rv = table_find_from(a.tv, key, pv, ev);
-  unsigned s0 = table_find_from(a.ts0, key, p0, e0);
-  unsigned s1 = (OPT == OPT_FTRL) ? table_find_from(a.ts1, key, p1, e1) : 0u;
-  // cold block (a key that is new to one of the tables; rare once the table is warm): ALL inserts
-  // happen here, so the steady-state path below is free of atomics and insert code
-  bool vnew = false, new0 = false, new1 = false;
-  if (__builtin_expect(rv == 0u || s0 == 0u || (OPT == OPT_FTRL && s1 == 0u), 0)) {
-    if (rv == 0u) {
-      rv = table_find_or_insert(a.tv, key, &vnew);
-      if (rv && vnew) { RowMeta* m = meta_ptr(a.tv, rv); m->freq = 1u; m->flags = 0; }  // table_manager.h:94
-    }
-    // slot rows are only created for keys the update will touch (kv_variable.h:910: filtered keys return first)
-    const bool filtered = rv == 0u || (!vnew && (meta_ptr(a.tv, rv)->freq & 0xFFFFu) < a.tv.enter_threshold);
-    if (!filtered) {
-      if (OPT == OPT_FTRL && s1 == 0u) {
-        s1 = table_find_or_insert(a.ts1, key, &new1);
-        if (s1 && new1) { RowMeta* m = meta_ptr(a.ts1, s1); m->freq = 1u; m->flags = 0; }
-      }
-      if (s0 == 0u) {
-        s0 = table_find_or_insert(a.ts0, key, &new0);
-        if (s0 && new0) { RowMeta* m = meta_ptr(a.ts0, s0); m->freq = 1u; m->flags = 0; }
-      }
-    }
-  }
-  // hop 2: the rows' frequency words / flags, together (row 0 always exists, so absent keys load too).
-  // The var record is only needed for the frequency filter: a blacklisted row is all zeros already
-  // (RemoveBlacklistUnsafe hands out a zero row, table_manager.h:359-372) and the group optimizers
-  // rewrite the flags after the update, so with enter_threshold == 0 they never read it
-  const bool need_vmeta = OPT == OPT_ADAGRAD || a.tv.enter_threshold != 0u;
-  pm->mv = need_vmeta ? load_freq_flags(a.tv, rv) : make_uint2(0xFFFFu, 0u);
-  pm->f0 = meta_ptr(a.ts0, s0)->freq;
-  pm->f1 = (OPT == OPT_FTRL) ? meta_ptr(a.ts1, s1)->freq : 0u;
-  pm->rv = rv; pm->s0 = s0; pm->s1 = s1;
-  pm->nb = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
-}
-template <int OPT>
-__device__ __forceinline__ void probe_commit(const PartArgs& a, const ProbeMid& pm, unsigned* tag, unsigned* r0,
-                                             unsigned* r1, unsigned* newbits) {
-  const unsigned rv = pm.rv, s0 = pm.s0, s1 = pm.s1, f0 = pm.f0, f1 = pm.f1;
-  const uint2 mv = pm.mv;
-  const bool vnew = pm.nb & 1u, new0 = pm.nb & 2u, new1 = pm.nb & 4u;
-  *tag = rv; *r0 = 0; *r1 = 0; *newbits = vnew ? 1u : 0u;
-  if (rv == 0u) return;
-  if (!vnew) {
-    if ((mv.x & 0xFFFFu) < a.tv.enter_threshold) { *tag = rv | ROW_FILTERED; return; }  // kv_variable.h:910
-    // RemoveBlacklistUnsafe: fresh zero row (ours already is)
-    if (mv.y & FLAG_BLACK) meta_ptr(a.tv, rv)->flags = FLAG_UNDER;
-  }
-  // AddFrequency(1, today) on the slot rows that already existed (kv_variable.h:409-414); new ones keep freq word 1
-  auto touch = [&](const TableDev& t, unsigned r, bool isnew, unsigned fold) {
-    if (r == 0u || isnew) return;
-    unsigned lo = (fold & 0xFFFFu) + 1u;
-    if (lo > 65535u) lo = 65535u;
-    *freq_ptr(t, r) = (a.day << 16) | lo;
-  };
-  if (OPT == OPT_FTRL) { touch(a.ts1, s1, new1, f1); *r1 = s1; }  // FTRL probes linear before accum (training_ops.cc:701-704)
-  touch(a.ts0, s0, new0, f0);
-  // MarkAsDeltaListElements on every table of the op, for the keys the update reaches (training_ops.cc:7196-7201)
-  if (__builtin_expect(a.tv.track_delta | a.ts0.track_delta | (OPT == OPT_FTRL ? a.ts1.track_delta : 0u), 0)) {
-    mark_delta(a.tv, rv);
-    if (s0) mark_delta(a.ts0, s0);
-    if (OPT == OPT_FTRL && s1) mark_delta(a.ts1, s1);
-  }
-  *r0 = s0;
-  *newbits = (vnew ? 1u : 0u) | (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
-}
-template <int OPT>
-__device__ __forceinline__ void probe_for_apply(const PartArgs& a, long long key, unsigned* tag,
-                                                unsigned* r0, unsigned* r1, unsigned* newbits) {
-  Entry ev, e0, e1;
-  ProbeMid pm;
-  probe_issue<OPT>(a, key, &ev, &e0, &e1);
-  probe_rows<OPT>(a, key, ev, e0, e1, &pm);
-  probe_commit<OPT>(a, pm, tag, r0, r1, newbits);
-}
-
-template <int MODE, int OPT, int V, int LPR, int K>
-__device__ __forceinline__ void part_sum_body(const WsDev& w, const PartArgs& a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int D = a.tv.dim;
-  char* smp = smem_raw;
-  auto take = [&](size_t bytes) { char* q = smp; smp += (bytes + 15) & ~(size_t)15; return q; };
-  long long* hkey = reinterpret_cast<long long*>(take((size_t)(HSS + 1) * 8));
-  unsigned* hval = reinterpret_cast<unsigned*>(take((size_t)(HSS + 1) * 4));  // entries, then cnt<<16 | offset
-  unsigned short* hu = reinterpret_cast<unsigned short*>(take((size_t)(HSS + 1) * 2));  // slot -> unique idx
-  unsigned* eb = reinterpret_cast<unsigned*>(take((size_t)ECAPS * 4));        // gradient locator
-  unsigned short* eslot = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));
-  unsigned short* perm = reinterpret_cast<unsigned short*>(take((size_t)ECAPS * 2));  // rank, then grouped entries
-  unsigned short* ulist = reinterpret_cast<unsigned short*>(take((size_t)UCAPS * 2));
-  unsigned* wtot = reinterpret_cast<unsigned*>(take(64));
-  unsigned* utag = reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4));  // dedup: dense output index
-  unsigned* ur0 = reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4));
-  unsigned* ur1 = (OPT == OPT_FTRL) ? reinterpret_cast<unsigned*>(take((size_t)UCAPS * 4)) : ur0;
-  unsigned char* unew = reinterpret_cast<unsigned char*>(take((size_t)UCAPS));
-  const unsigned hmax = (unsigned)heavy_rows(D);
-  float* hsum = reinterpret_cast<float*>(take((size_t)hmax * D * 4));  // sums of the heavy keys
-  __shared__ unsigned lnu, lsent, lbase, lovf;
-
-  const int tid = threadIdx.x;
-  const unsigned p = xcd_partition(blockIdx.x, w.P);
-  const unsigned NT = w.ntiles;
-  constexpr unsigned GPB = TBS / LPR;
-  const int lane = tid % LPR;
-  const unsigned grp = tid / LPR;
-  KV_STAMPP(0);
-
-  unsigned short* tpre = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
-  unsigned short* tstart = reinterpret_cast<unsigned short*>(take((size_t)NT * 2));
-  const unsigned E = seg_directory<TBS, TBS / 64>(w, p, tpre, tstart, wtot);
-  if (E == 0) return;
-  if (E > 65535u) {  // a key set crafted against the partition hash; reported by the next synchronous call
-    if (tid == 0) atomicExch(&a.tv.counters[1], 2u);
-    return;
-  }
-
-  __shared__ unsigned stkR[24], stkr[24];
-  __shared__ int sp;
-  __shared__ unsigned lcls;
-  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; }
-  __syncthreads();
-  auto split = [&](unsigned R, unsigned round) {  // replace class (R, round) by its two halves
-    __syncthreads();
-    if (tid == 0) {
-      if (sp + 2 <= 24) {
-        stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
-        stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+// ------------------------------------------------------------------------------------------
+// k_order: the sorted position list (+ the lookup's fix-up of rows inserted by this batch)
+// ------------------------------------------------------------------------------------------
+template <bool FIX>
+__device__ __forceinline__ void order_body(const TableDev& t, const WsDev& w, long long n, float* __restrict__ out) {
+  if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: the lists are not valid
+  const int D = t.dim;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned sr = __builtin_nontemporal_load(&w.slot_rank[i]);
+    const unsigned e = sr & SLOT_MASK, rank = sr >> RANK_SHIFT;
+    const unsigned eb = w.ent_base[e];
+    const unsigned j = (eb & BASE_MASK) + rank;
+    if (j < (unsigned)n) w.order[j] = (unsigned)i | (((eb & HEAD_BIT) && rank == 0u) ? HEAD_BIT : 0u);
+    if (FIX && (eb & NEW_BIT)) {
+      // the probing gather ran beside the insert of this key: it may have seen no row, or a row that was
+      // still being initialised
+      const float* row = row_ptr(t, w.ent_b[e]);
+      float* o = out + (size_t)i * D;
+      if ((D & 3) == 0) {
+        for (int q = 0; q < (D >> 2); ++q) reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
       } else {
-        atomicExch(&a.tv.counters[1], 2u);   // keys that no sub-hash separates: reported, not applied
+        for (int q = 0; q < D; ++q) o[q] = row[q];
       }
     }
-    __syncthreads();
-  };
-  while (sp > 0) {
-    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
-    __syncthreads();
-    if (tid == 0) { --sp; lcls = 0; }
-    __syncthreads();
-    // ---- entries of this class ------------------------------------------------------------------
-    unsigned Er = E;
-    if (R > 1) {
-      unsigned c = 0;
-      for (unsigned x = tid; x < E; x += TBS) c += in_round(w.ent_key[seg_entry(tpre, tstart, NT, x)], R, round);
-      if (c) atomicAdd(&lcls, c);
-      __syncthreads();
-      Er = lcls;
-      __syncthreads();
-      if (tid == 0) lcls = 0;
-    }
-    if (Er == 0) { __syncthreads(); continue; }
-    if (Er > (unsigned)ECAPS) {  // block-uniform; nothing of this class has been applied yet
-      split(R, round);
-      continue;
-    }
-    for (int s = tid; s <= HSS; s += TBS) { hkey[s] = EMPTY_KEY; hval[s] = 0; }
-    for (unsigned x = tid; x < hmax * (unsigned)D; x += TBS) hsum[x] = 0.f;
-    if (tid == 0) { lnu = 0; lsent = 0; lovf = 0; }
-    __syncthreads();
-    // every thread takes entries x = tid, tid + TBS, ...: balanced whatever the number of tiles;
-    // EB at a time so their global loads are in flight together
-    constexpr int EB = (ECAPS + TBS - 1) / TBS;
-    for (unsigned x0 = 0; x0 < E; x0 += EB * TBS) {
-      unsigned ge[EB], lb[EB];
-      long long key[EB];
-#pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        const unsigned x = x0 + k * TBS + tid;
-        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
-      }
-#pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        key[k] = 0; lb[k] = 0;
-        if (ge[k] != 0xFFFFFFFFu) { key[k] = w.ent_key[ge[k]]; lb[k] = w.ent_b[ge[k]]; }
-      }
-#pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
-        if (lnu >= (unsigned)UCAPS) { lovf = 1; continue; }
-        const unsigned pos = (R == 1) ? (x0 + k * TBS + tid) : atomicAdd(&lcls, 1u);  // R == 1: deterministic order
-        bool first;
-        const unsigned h = lds_key_slot<HSS>(hkey, &lsent, key[k], true, &first);
-        if (first) {
-          const unsigned u = atomicAdd(&lnu, 1u);
-          if (u < (unsigned)UCAPS) { ulist[u] = (unsigned short)h; hu[h] = (unsigned short)u; }
-        }
-        eb[pos] = lb[k];
-        eslot[pos] = (unsigned short)h;
-        perm[pos] = (unsigned short)atomicAdd(&hval[h], 1u);  // rank among the key's entries
-      }
-    }
-    __syncthreads();
-    if (lovf || lnu > (unsigned)UCAPS) {  // too many distinct keys for the LDS hash: split the class
-      split(R, round);
-      continue;
-    }
-    KV_STAMPP(1);
-    const unsigned nu = lnu;
-    // apply: the first key of every thread has its home entries (hop 1 of the probes) requested
-    // here and used after the grouping and the heavy-key fold below, which hide that round trip
-    Entry pev, pe0, pe1;
-    long long pkey = 0;
-    constexpr bool EARLY = (MODE == MODE_APPLY) && K == 1;  // K = 2 rows have no registers to spare (occupancy)
-    if (EARLY && (unsigned)tid < nu) {
-      const unsigned h = ulist[tid];
-      pkey = (h == HSS) ? EMPTY_KEY : hkey[h];
-      probe_issue<OPT>(a, pkey, &pev, &pe0, &pe1);
-    }
-    // ---- group the entries by key: offsets by a scan over the unique list ----------------------
-    {
-      constexpr int PER = (UCAPS + TBS - 1) / TBS;
-      unsigned c[PER];
-      unsigned sum = 0;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const unsigned u = tid * PER + q;
-        c[q] = u < nu ? hval[ulist[u]] : 0u;
-        sum += c[q];
-      }
-      unsigned tot;
-      unsigned run = block_excl_scan<TBS / 64>(sum, wtot, &tot);
-      unsigned rank[(ECAPS + TBS - 1) / TBS];
-#pragma unroll
-      for (int q = 0; q < (ECAPS + TBS - 1) / TBS; ++q) {
-        const unsigned e = tid + q * TBS;
-        rank[q] = e < Er ? perm[e] : 0u;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const unsigned u = tid * PER + q;
-        if (u < nu) { hval[ulist[u]] = (c[q] << 16) | run; run += c[q]; }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < (ECAPS + TBS - 1) / TBS; ++q) {
-        const unsigned e = tid + q * TBS;
-        if (e < Er) perm[(hval[eslot[e]] & 0xFFFFu) + rank[q]] = (unsigned short)e;
-      }
-    }
-    // ---- one thread per unique key: table probes (apply) / output slots (dedup) ----------------
-    if (MODE == MODE_DEDUP) {
-      if (a.direct_rows > 0) {
-        for (unsigned u = tid; u < nu; u += TBS) {
-          const unsigned h = ulist[u];
-          const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
-          utag[u] = (key >= 0 && key < a.direct_rows) ? (unsigned)key : 0xFFFFFFFFu;  // out of range: dropped
-        }
-      } else {
-        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);  // one atomic per partition block and round
-        __syncthreads();
-        for (unsigned u = tid; u < nu; u += TBS) {
-          utag[u] = lbase + u;
-          const unsigned h = ulist[u];
-          a.out_keys[lbase + u] = (h == HSS) ? EMPTY_KEY : hkey[h];
-        }
-      }
-    }
-    auto finish_probes = [&]() {
-      if (MODE != MODE_APPLY) return;
-      for (unsigned u = tid; u < nu; u += TBS) {
-        unsigned tag, r0, r1, nb;
-        if (EARLY && u == (unsigned)tid) {
-          ProbeMid pm;  // (starting hop 2 before the fold as well measured no further gain)
-          probe_rows<OPT>(a, pkey, pev, pe0, pe1, &pm);
-          probe_commit<OPT>(a, pm, &tag, &r0, &r1, &nb);
-        } else {
-          const unsigned h = ulist[u];
-          probe_for_apply<OPT>(a, (h == HSS) ? EMPTY_KEY : hkey[h], &tag, &r0, &r1, &nb);
-        }
-        utag[u] = tag; ur0[u] = r0; unew[u] = (unsigned char)nb;
-        if (OPT == OPT_FTRL) ur1[u] = r1;
-      }
-    };
-    __syncthreads();
-    KV_STAMPP(2);
-
-    // finish one key whose summed gradient is in gv: optimizer update, or emit (dedup)
-    auto finish = [&](unsigned h, bool live, float (&gv)[K][V]) {
-      const unsigned u = live ? hu[h] : 0u;
-      if (MODE == MODE_APPLY) {
-        const long long key = (h == HSS) ? EMPTY_KEY : hkey[h];
-        const unsigned tag = live ? utag[u] : 0u;
-        const unsigned nb = live ? unew[u] : 0u;
-        bool big = false;
-        const bool doinit = live && (nb & 1u) && (tag & ROW_MASK);
-        if (doinit) big = init_row_coop(a.tv, key, row_ptr(a.tv, tag & ROW_MASK), lane, LPR);
-        const bool any = group_any<LPR>(big);
-        if (doinit && lane == 0) *flags_ptr(a.tv, tag & ROW_MASK) = any ? 0 : FLAG_UNDER;
-        opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, tag, live ? ur0[u] : 0u, (nb & 2u) != 0,
-                                       live ? ur1[u] : 0u, (nb & 4u) != 0, live, gv, a.opt, lane);
-      } else if (live && utag[u] != 0xFFFFFFFFu) {
-        const unsigned dense = utag[u];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) stv<V>(a.out_sum + (size_t)dense * D + e0, gv[k]);
-        }
-      }
-    };
-
-    // ---- (a) keys present in many tiles (> HEAVY entries): their contributions, concatenated,
-    //      are folded by ALL groups (chunks with run detection); partial sums meet in one LDS row
-    //      per heavy key (ds_add_f32), one barrier for all of them.  Afterwards such a key looks
-    //      like a key with a single contribution (LOC_LDS) and phase (b) finishes it.
-    {
-      __shared__ unsigned short hk[HMAXS];      // slot of heavy key j
-      __shared__ unsigned hpre[HMAXS + 1];      // prefix of their entry counts
-      __shared__ unsigned lnh;
-      if (tid == 0) lnh = 0;
-      __syncthreads();
-      for (unsigned u = tid; u < nu; u += TBS) {
-        const unsigned h = ulist[u];
-        if ((hval[h] >> 16) > (unsigned)HEAVY) {
-          const unsigned j = atomicAdd(&lnh, 1u);
-          if (j < hmax) hk[j] = (unsigned short)h;
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned n = min(lnh, hmax);
-        unsigned run = 0;
-        for (unsigned j = 0; j < n; ++j) { hpre[j] = run; run += hval[hk[j]] >> 16; }
-        hpre[n] = run;
-        lnh = n;
-      }
-      __syncthreads();
-      const unsigned nh = lnh;
-      if (nh > 0) {  // block-uniform
-        const unsigned Hn = hpre[nh];
-        const unsigned C = (Hn + GPB - 1) / GPB;
-        const unsigned c0 = min(Hn, grp * C), c1 = min(Hn, (grp + 1) * C);
-        constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-        unsigned j = 0;
-        while (j + 1 < nh && hpre[j + 1] <= c0) ++j;
-        float gv[K][V];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-        auto flush = [&](unsigned jj) {
-          float* rd = hsum + (size_t)jj * D;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const int e0 = (lane + k * LPR) * V;
-            if (e0 < D) {
-#pragma unroll
-              for (int c = 0; c < V; ++c) { atomicAdd(&rd[e0 + c], gv[k][c]); gv[k][c] = 0.f; }
-            }
-          }
-        };
-        for (unsigned vb = c0; vb < c1; vb += RB) {
-          float val[RB][K][V];
-          unsigned kj[RB];
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            kj[r] = 0xFFFFFFFFu;
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-              for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
-            const unsigned vi = vb + r;
-            if (vi < c1) {
-              unsigned jj = j;
-              while (hpre[jj + 1] <= vi) ++jj;
-              kj[r] = jj;
-              const unsigned loc = eb[perm[(hval[hk[jj]] & 0xFFFFu) + (vi - hpre[jj])]];
-              const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
-                                                  : a.grad + (size_t)loc * D;
-#pragma unroll
-              for (int k = 0; k < K; ++k) {
-                const int e0 = (lane + k * LPR) * V;
-                if (e0 < D) ldv_stream<V>(src + e0, val[r][k]);
-              }
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            if (kj[r] == 0xFFFFFFFFu) continue;
-            if (kj[r] != j) { flush(j); j = kj[r]; }
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-              for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
-          }
-        }
-        if (c0 < c1) flush(j);
-        __syncthreads();
-        for (unsigned jj = tid; jj < nh; jj += TBS) {
-          const unsigned h = hk[jj];
-          const unsigned o = hval[h] & 0xFFFFu;
-          eb[perm[o]] = LOC_LDS + jj;
-          hval[h] = (1u << 16) | o;
-        }
-        __syncthreads();
-      }
-    }
-    finish_probes();
-    __syncthreads();
-    KV_STAMPP(3);
-    // ---- (b) one group per key, keys in converged rounds: contributions and state rows are
-    //      loaded together (all addresses known), then the fused update -------------------------
-    {
-      const unsigned upad = (nu + GPB - 1) / GPB * GPB;
-      for (unsigned u = grp; u < upad; u += GPB) {
-        const bool live = u < nu;
-        const unsigned h = live ? ulist[u] : 0u;
-        const unsigned cn = live ? (hval[h] >> 16) : 0u;
-        const unsigned o = hval[h] & 0xFFFFu;
-        float gv[K][V];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int c = 0; c < V; ++c) gv[k][c] = 0.f;
-        // touch this lane's part of the state rows now, so the update's real loads (issued after
-        // the contribution sum) hit cache instead of paying a second HBM round trip
-        float touch = 0.f;
-        if (MODE == MODE_APPLY && live) {
-          const unsigned tg = utag[hu[h]];
-          if (!(tg & ROW_FILTERED) && (tg & ROW_MASK)) {
-            const int e0 = lane * V;
-            if (e0 < D) {
-              const float* xr = row_ptr(a.tv, tg & ROW_MASK);
-              const float* sr = row_ptr(a.ts0, ur0[hu[h]]);
-              touch = xr[e0] + sr[e0];
-              if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
-              if (OPT == OPT_FTRL) touch += row_ptr(a.ts1, ur1[hu[h]])[e0];
-            }
-          }
-        }
-        constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-        for (unsigned jb = 0; jb < cn; jb += RB) {
-          float val[RB][K][V];
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-              for (int c = 0; c < V; ++c) val[r][k][c] = 0.f;
-            if (jb + r < cn) {
-              const unsigned loc = eb[perm[o + jb + r]];
-              if (loc >= LOC_LDS) {
-                const float* src = hsum + (size_t)(loc - LOC_LDS) * D;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                  const int e0 = (lane + k * LPR) * V;
-                  if (e0 < D) ldv<V>(src + e0, val[r][k]);
-                }
-              } else {
-                const float* src = (loc & PART_BIT) ? w.part + (size_t)(loc & ~PART_BIT) * D
-                                                    : a.grad + (size_t)loc * D;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                  const int e0 = (lane + k * LPR) * V;
-                  if (e0 < D) ldv_stream<V>(src + e0, val[r][k]);
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-              for (int c = 0; c < V; ++c) gv[k][c] += val[r][k][c];
-        }
-        asm volatile("" ::"v"(touch));  // keep the touch loads
-#ifdef KV_STAMPS
-        if (tid == 0 && u / GPB < 4) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 11 + (u / GPB)] = wall_clock64();
-#endif
-        finish(h, live, gv);
-      }
-    }
-    if (MODE == MODE_DEDUP) {
-      __syncthreads();
-      // every entry learns its key's dense index: a second pass over the entries with a read-only
-      // LDS hash lookup (an entry-position list in LDS would cost 6.4 KB and the fourth block per CU)
-      for (unsigned x = tid; x < E; x += TBS) {
-        const size_t ge = seg_entry(tpre, tstart, NT, x);
-        const long long key = w.ent_key[ge];
-        if (!in_round(key, R, round)) continue;
-        bool first;
-        w.ent_b[ge] = utag[hu[lds_key_slot<HSS>(hkey, &lsent, key, false, &first)]];
-      }
-    }
-    __syncthreads();
-    KV_STAMPP(4);
-#ifdef KV_STAMPS
-    if (tid == 0) { w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 8] = Er; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 9] = R; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 10] = nu; }
-#endif
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
+}
+template <bool FIX>
+__global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n, float* __restrict__ out) {
+  order_body<FIX>(t, w, n, out);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gather: out[i, :] = rows[ent_b[slot_of_id[i]]]
+// k_apply_sorted / k_apply_span: segmented sum over the sorted position list + fused row update
+// ------------------------------------------------------------------------------------------
+constexpr int TBS = 256;
+// a key with more than long_thresh rows inside one chunk is summed by the whole block (its rows split
+// evenly over the groups); shorter ones by one LPR-lane group each
+__host__ __device__ inline int long_thresh(int D) { return D <= 128 ? 16 : D / 8; }
+__host__ __device__ inline int long_rows(int D) { return CH / (long_thresh(D) + 1) + 1; }
+__host__ __device__ inline size_t apply_smem_bytes(int D, int lpr) {
+  size_t b = (size_t)(CH + 1) * 4 + 16;            // sord
+  b += (size_t)(CH + 2) * 2 + 16;                  // sseg
+  b += (size_t)(CH + 2) + 16;                      // slong
+  b += (size_t)(CH + 1) * 16 + 16;                 // shead
+  b += (size_t)long_rows(D) * 2 + 16;              // llist
+  b += (size_t)long_rows(D) * D * 4 + 16;          // lsum
+  b += (size_t)(TBS / lpr) * D * 4 + 16;           // lpart
+  return b;
+}
+
+// combine two partial results of a key under the fold operation (sum for the optimizers)
+__device__ __forceinline__ float fold2(int op, float acc, float v) {
+  switch (op) {
+    case KV_SCATTER_MUL: return acc * v;
+    case KV_SCATTER_MIN: return fminf(acc, v);
+    case KV_SCATTER_MAX: return fmaxf(acc, v);
+    default: return acc + v;
+  }
+}
+__device__ __forceinline__ float fold_identity(int op) {
+  switch (op) {
+    case KV_SCATTER_MUL: return 1.f;
+    case KV_SCATTER_MIN: return INFINITY;
+    case KV_SCATTER_MAX: return -INFINITY;
+    default: return 0.f;
+  }
+}
+
+// The slot-table rows of one key, resolved by the group leader.  FindOrInsertUnsafe(var, filter_out !=
+// nullptr) kv_variable.h:382-408 and FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear
+// before accum (training_ops.cc:701-704).  `m0` is the record of the hinted slot row (requested early).
+struct RowsOf { unsigned tag, r0, r1, nb; };
+template <int OPT>
+__device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key, unsigned rvw, unsigned hint,
+                                               bool hint_loaded, const RowMeta& m0) {
+  const unsigned rv = rvw & ROW_MASK;
+  const bool vnew = (rvw >> 31) != 0u;   // inserted by this apply: not filtered (kv_variable.h:400-407, succ == false)
+  RowsOf o{rv, 0u, 0u, 0u};
+  if (rv == 0u) return o;
+  // the var record is only needed for the frequency filter: a blacklisted row is all zeros already
+  // (RemoveBlacklistUnsafe hands out a zero row, table_manager.h:359-372) and the group optimizers
+  // rewrite the flags after the update, so with enter_threshold == 0 they never read it
+  const bool need_vmeta = OPT == OPT_ADAGRAD || a.tv.enter_threshold != 0u;
+  if (need_vmeta && !vnew) {
+    const uint2 mv = load_freq_flags(a.tv, rv);
+    if ((mv.x & 0xFFFFu) < a.tv.enter_threshold) { o.tag = rv | ROW_FILTERED; return o; }  // kv_variable.h:910
+    if (mv.y & FLAG_BLACK) meta_ptr(a.tv, rv)->flags = FLAG_UNDER;   // RemoveBlacklistUnsafe: fresh zero row (ours already is)
+  }
+  // slot rows are only created for keys the update will touch (filtered keys returned above)
+  auto slot_row = [&](const TableDev& t, bool use_hint, bool* isnew) -> unsigned {
+    *isnew = false;
+    unsigned r = 0, f = 0;
+    if (use_hint && hint_loaded && m0.key == key && !(m0.flags & FLAG_FREE)) {
+      r = hint; f = m0.freq;
+    } else {
+      r = table_find(t, key);
+      if (__builtin_expect(r == 0u, 0)) {
+        r = table_find_or_insert(t, key, isnew);
+        if (r && *isnew) { RowMeta* m = meta_ptr(t, r); m->freq = 1u; m->flags = 0; }
+      }
+      if (r && !*isnew) f = meta_ptr(t, r)->freq;
+      if (use_hint && r) {   // remember it in the var's index entry
+        Entry* e = table_entry_of(a.tv, key);
+        if (e) e->hint = r;
+      }
+    }
+    // AddFrequency(1, today) on a slot row that already existed (kv_variable.h:409-414); a new one keeps word 1
+    if (r && !*isnew) {
+      unsigned lo = (f & 0xFFFFu) + 1u;
+      if (lo > 65535u) lo = 65535u;
+      *freq_ptr(t, r) = (a.day << 16) | lo;
+    }
+    return r;
+  };
+  bool new0 = false, new1 = false;
+  if (OPT == OPT_FTRL) o.r1 = slot_row(a.ts1, false, &new1);
+  o.r0 = slot_row(a.ts0, a.use_hints != 0, &new0);
+  // MarkAsDeltaListElements on every table of the op, for the keys the update reaches (training_ops.cc:7196-7201)
+  if (__builtin_expect(a.tv.track_delta | a.ts0.track_delta | (OPT == OPT_FTRL ? a.ts1.track_delta : 0u), 0)) {
+    mark_delta(a.tv, rv);
+    if (o.r0) mark_delta(a.ts0, o.r0);
+    if (OPT == OPT_FTRL && o.r1) mark_delta(a.ts1, o.r1);
+  }
+  o.nb = (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
+  return o;
+}
+
+// finish one key whose combined gradient is in gv: optimizer update (MODE_APPLY) or emit (MODE_DEDUP).
+// All LPR lanes of every group of the wave call it (shuffles inside); `live` masks groups without a key.
+template <int MODE, int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bool live, bool hint_loaded,
+                                           const RowMeta& m0, float (&gv)[K][V], int lane) {
+  const int D = a.tv.dim;
+  const long long key = (long long)(((unsigned long long)hd.y << 32) | hd.x);
+  if (MODE == MODE_APPLY) {
+    RowsOf ro{0u, 0u, 0u, 0u};
+    if (live && lane == 0) ro = resolve_rows<OPT>(a, key, hd.z, hd.w, hint_loaded, m0);
+    if (LPR > 1) {
+      ro.tag = __shfl(ro.tag, 0, LPR); ro.r0 = __shfl(ro.r0, 0, LPR);
+      ro.r1 = __shfl(ro.r1, 0, LPR); ro.nb = __shfl(ro.nb, 0, LPR);
+    }
+    opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, ro.tag, ro.r0, (ro.nb & 2u) != 0, ro.r1, (ro.nb & 4u) != 0,
+                                   live, gv, a.opt, lane);
+  } else if (live && hd.z != ROW_MASK) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) stv<V>(a.out_sum + (size_t)hd.z * D + e0, gv[k]);
+    }
+  }
+}
+
+template <int MODE, int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void apply_sorted_body(const WsDev& w, const PartArgs& a) {
+  if (*reinterpret_cast<volatile unsigned*>(&a.tv.counters[1])) return;   // the index pass gave up on this batch
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int D = a.tv.dim;
+  const int NL = long_rows(D);
+  const unsigned LT = (unsigned)long_thresh(D);
+  char* smp = smem_raw;
+  auto take = [&](size_t bytes) { char* q = smp; smp += (bytes + 15) & ~(size_t)15; return q; };
+  unsigned* sord = reinterpret_cast<unsigned*>(take((size_t)(CH + 1) * 4));
+  unsigned short* sseg = reinterpret_cast<unsigned short*>(take((size_t)(CH + 2) * 2));
+  unsigned char* slong = reinterpret_cast<unsigned char*>(take((size_t)(CH + 2)));
+  uint4* shead = reinterpret_cast<uint4*>(take((size_t)(CH + 1) * 16));
+  unsigned short* llist = reinterpret_cast<unsigned short*>(take((size_t)NL * 2));
+  float* lsum = reinterpret_cast<float*>(take((size_t)NL * D * 4));
+  constexpr unsigned GPB = TBS / LPR;
+  float* lpart = reinterpret_cast<float*>(take((size_t)GPB * D * 4));
+  __shared__ unsigned wtot[8];
+  __shared__ unsigned lnl;
+
+  const int tid = threadIdx.x;
+  const int lane = tid % LPR;
+  const unsigned grp = tid / LPR;
+  const long long n = a.n;
+  const unsigned c = blockIdx.x;
+  const long long j0 = (long long)c * CH;
+  if (j0 >= n) return;
+  const unsigned len = (unsigned)min((long long)CH, n - j0);
+  const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
+  KV_STAMPP(0);
+
+  // ---- the chunk's positions and key boundaries ---------------------------------------------------
+  const unsigned o = (unsigned)tid < len ? w.order[j0 + tid] : 0u;
+  const bool hf = (unsigned)tid < len && (o & HEAD_BIT);
+  uint4 hd = make_uint4(0u, 0u, 0u, 0u);
+  if (hf) hd = w.ohead[j0 + tid];
+  if ((unsigned)tid < len) sord[tid] = o;
+  if (tid == 0) { sord[len] = w.order[j0 + len]; lnl = 0; }   // order[n] = HEAD_BIT
+  unsigned nseg;
+  const unsigned sid = block_excl_scan<TBS / 64>(hf ? 1u : 0u, wtot, &nseg) + 1u;   // segments 1..nseg start at a head
+  if (hf) { sseg[sid] = (unsigned short)tid; shead[sid] = hd; }
+  if (tid == 0) { sseg[0] = 0; sseg[nseg + 1] = (unsigned short)len; }
+  __syncthreads();
+  // segment 0 = the positions before the first head: the tail of a key that started in an earlier chunk
+  const bool tail_open = !(sord[len] & HEAD_BIT);   // the last key continues in the next chunk
+  auto seg_lo = [&](unsigned s) -> unsigned { return s == 0u ? 0u : sseg[s]; };
+  auto seg_hi = [&](unsigned s) -> unsigned { return sseg[s + 1]; };
+
+  // ---- long segments: rows split evenly over the groups, partial results meet in LDS in group order ---
+  for (unsigned s = tid; s <= nseg; s += TBS) {
+    const unsigned l = seg_hi(s) - seg_lo(s);
+    unsigned char k = 0;
+    if (l > LT) { const unsigned q = atomicAdd(&lnl, 1u); llist[q] = (unsigned short)s; k = (unsigned char)(q + 1u); }
+    slong[s] = k;
+  }
+  __syncthreads();
+  const unsigned nl = lnl;
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
+    const float* src = a.grad + (size_t)pos * D;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) ldv_stream<V>(src + e0, dst[k]);
+    }
+  };
+  // fold of sorted positions [lo, hi) into gv, RB rows in flight
+  auto fold_range = [&](unsigned lo, unsigned hi, float (&gv)[K][V]) {
+    for (unsigned jb = lo; jb < hi; jb += RB) {
+      float val[RB][K][V];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) val[r][k][cc] = 0.f;
+        if (jb + r < hi) load_row(sord[jb + r] & ~HEAD_BIT, val[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (jb + r >= hi) continue;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc)
+            gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + val[r][k][cc] : fold2(fop, gv[k][cc], val[r][k][cc]);
+      }
+    }
+  };
+  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
+  for (unsigned q = 0; q < nl; ++q) {   // block-uniform
+    const unsigned s = llist[q];
+    const unsigned lo = seg_lo(s), hi = seg_hi(s);
+    const unsigned C = (hi - lo + GPB - 1) / GPB;
+    const unsigned c0 = min(hi, lo + grp * C), c1 = min(hi, c0 + C);
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+    fold_range(c0, c1, gv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) stv<V>(lpart + (size_t)grp * D + e0, gv[k]);
+    }
+    __syncthreads();
+    const unsigned ng = (hi - lo + C - 1) / C;   // groups that had rows
+    for (int e = tid; e < D; e += TBS) {
+      float acc = lpart[e];
+      for (unsigned g = 1; g < ng; ++g) acc = (MODE == MODE_APPLY) ? acc + lpart[(size_t)g * D + e] : fold2(fop, acc, lpart[(size_t)g * D + e]);
+      lsum[(size_t)q * D + e] = acc;
+    }
+    __syncthreads();
+  }
+  KV_STAMPP(1);
+
+  // ---- one group per segment: the (rest of the) fold, then the fused update or the partial store ------
+  const unsigned nsp = (nseg + 1 + GPB - 1) / GPB * GPB;
+  for (unsigned s = grp; s < nsp; s += GPB) {
+    const bool live = s <= nseg && seg_hi(min(s, nseg)) > seg_lo(min(s, nseg));
+    const unsigned ss = live ? s : 0u;
+    const unsigned lo = seg_lo(ss), hi = live ? seg_hi(ss) : lo;
+    const bool is_lead = ss == 0u;
+    const bool is_tail = !is_lead && ss == nseg && tail_open;
+    const uint4 hdr = (live && !is_lead) ? shead[ss] : make_uint4(0u, 0u, 0u, 0u);
+    // requested now, used after the fold: the record of the hinted slot row (leader) and the lines of the
+    // state rows, so the update's own loads find them in cache
+    RowMeta m0{};
+    bool hint_loaded = false;
+    float touch = 0.f;
+    if (MODE == MODE_APPLY && live && !is_lead && !is_tail && (hdr.z & ROW_MASK) != 0u) {
+      const bool hok = a.use_hints && hdr.w != 0u && hdr.w < a.ts0.max_rows;
+      if (lane == 0 && hok) {
+        const uint4 mm = *reinterpret_cast<const uint4*>(meta_ptr(a.ts0, hdr.w));
+        m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
+        m0.freq = mm.z;
+        m0.flags = (unsigned char)(mm.w & 0xFFu);
+        hint_loaded = true;
+      }
+      const int e0 = lane * V;
+      if (e0 < D) {
+        touch = row_ptr(a.tv, hdr.z & ROW_MASK)[e0];
+        if (hok) {
+          const float* sr = row_ptr(a.ts0, hdr.w);
+          touch += sr[e0];
+          if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
+        }
+      }
+    }
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+    if (live) {
+      if (slong[ss]) {
+        const float* src = lsum + (size_t)(slong[ss] - 1u) * D;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) ldv<V>(src + e0, gv[k]);
+        }
+      } else {
+        fold_range(lo, hi, gv);
+      }
+    }
+    asm volatile("" ::"v"(touch));  // keep the touch loads
+    if (live && (is_lead || is_tail)) {
+      float* dst = w.cpart + ((size_t)c * 2 + (is_tail ? 1 : 0)) * D;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) stv<V>(dst + e0, gv[k]);
+      }
+      if (is_tail && lane == 0) w.ctail[c] = hdr;
+    }
+    finish_key<MODE, OPT, V, LPR, K>(a, hdr, live && !is_lead && !is_tail, hint_loaded, m0, gv, lane);
+  }
+  if (tid == 0)
+    w.cmeta[c] = (nseg > 0u ? CM_HAS_HEAD : 0u) | (seg_hi(0) > 0u ? CM_LEAD : 0u) | ((nseg > 0u && tail_open) ? CM_TAIL_OPEN : 0u);
+  KV_STAMPP(2);
+}
+
+// A key that crosses chunk boundaries: chunk c holds its head and the sum of its rows up to the chunk's
+// end (cpart[c][1]); the chunks after it hold leading partial sums (cpart[.][0]) up to and including the
+// first chunk that has a head.  One block per open tail adds them up in chunk order and finishes the key.
+template <int MODE, int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void apply_span_body(const WsDev& w, const PartArgs& a) {
+  if (*reinterpret_cast<volatile unsigned*>(&a.tv.counters[1])) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int D = a.tv.dim;
+  constexpr unsigned GPB = TBS / LPR;
+  float* lpart = reinterpret_cast<float*>(smem_raw);           // [GPB][D]
+  float* ltot = lpart + (size_t)GPB * D;                       // [D]
+  __shared__ unsigned lend;
+  const int tid = threadIdx.x;
+  const int lane = tid % LPR;
+  const unsigned grp = tid / LPR;
+  const unsigned nchunks = (unsigned)((a.n + CH - 1) / CH);
+  const unsigned c = blockIdx.x;
+  if (c >= nchunks || !(w.cmeta[c] & CM_TAIL_OPEN)) return;
+  const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
+  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
+  if (tid == 0) lend = nchunks;
+  __syncthreads();
+  for (unsigned b = c + 1; b < nchunks; b += TBS) {   // block-uniform
+    const unsigned x = b + tid;
+    if (x < nchunks && (w.cmeta[x] & CM_HAS_HEAD)) atomicMin(&lend, x);
+    __syncthreads();
+    if (lend != nchunks) break;
+  }
+  const unsigned last = min(lend, nchunks - 1u);   // chunks c + 1 .. last carry this key's rows in front
+  const unsigned m = last - c;
+  const unsigned C = (m + GPB - 1) / GPB;          // consecutive chunks per group: the sum keeps chunk order
+  float gv[K][V];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+  for (unsigned q = grp * C; q < min(m, (grp + 1) * C); ++q) {
+    const unsigned x = c + 1u + q;
+    if (!(w.cmeta[x] & CM_LEAD)) continue;
+    const float* src = w.cpart + (size_t)x * 2 * D;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) {
+        float v[V];
+        ldv<V>(src + e0, v);
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + v[cc] : fold2(fop, gv[k][cc], v[cc]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e0 = (lane + k * LPR) * V;
+    if (e0 < D) stv<V>(lpart + (size_t)grp * D + e0, gv[k]);
+  }
+  __syncthreads();
+  for (int e = tid; e < D; e += TBS) {
+    float acc = w.cpart[((size_t)c * 2 + 1) * D + e];
+    for (unsigned g = 0; g < GPB && g * C < m; ++g)
+      acc = (MODE == MODE_APPLY) ? acc + lpart[(size_t)g * D + e] : fold2(fop, acc, lpart[(size_t)g * D + e]);
+    ltot[e] = acc;
+  }
+  __syncthreads();
+  if (tid >= 64) return;   // the first wave finishes the key (no block barrier below)
+  const bool live = grp == 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e0 = (lane + k * LPR) * V;
+    if (e0 < D) ldv<V>(ltot + e0, gv[k]);
+  }
+  const uint4 hdr = w.ctail[c];
+  RowMeta m0{};
+  bool hint_loaded = false;
+  if (MODE == MODE_APPLY && live && lane == 0 && a.use_hints && hdr.w != 0u && hdr.w < a.ts0.max_rows) {
+    m0 = *meta_ptr(a.ts0, hdr.w);
+    hint_loaded = true;
+  }
+  finish_key<MODE, OPT, V, LPR, K>(a, hdr, live, hint_loaded, m0, gv, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gather: out[i, :] = rows[ent_b[slot_rank[i] & SLOT_MASK]]
 // ------------------------------------------------------------------------------------------
 // VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
 template <int VQ>
@@ -1356,11 +1180,11 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
                                             long long n) {
   if constexpr (VQ > 0 && VQ <= 64) {
     // One wave takes 64 consecutive output rows per step.  Lane l resolves row l's table row id
-    // (slot_of_id -> ent_b: two dependent loads, 64 rows in flight per wave and no redundancy);
-    // then the wave copies the rows VQ lanes per row, 64 / VQ rows per instruction, CH
+    // (slot_rank -> ent_b: two dependent loads, 64 rows in flight per wave and no redundancy);
+    // then the wave copies the rows VQ lanes per row, 64 / VQ rows per instruction, CW
     // instructions in flight, the row ids passed between lanes with ds_bpermute.
     constexpr int RW = 64 / VQ;            // rows per copy instruction
-    constexpr int CH = VQ < 16 ? VQ : 16;  // copy instructions in flight
+    constexpr int CW = VQ < 16 ? VQ : 16;  // copy instructions in flight
     const int lane = threadIdx.x & 63;
     const int v = lane % VQ, sub = lane / VQ;
     const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
@@ -1370,22 +1194,22 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     const long long stride = nwaves * 64;
     long long r0 = wave * 64;
     unsigned sl1 = 0, sl2 = 0, rr = 0;
-    if (r0 + lane < n) rr = w.ent_b[__builtin_nontemporal_load(&w.slot_of_id[r0 + lane])];
-    if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_of_id[r0 + stride + lane]);
+    if (r0 + lane < n) rr = w.ent_b[__builtin_nontemporal_load(&w.slot_rank[r0 + lane]) & SLOT_MASK];
+    if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_rank[r0 + stride + lane]) & SLOT_MASK;
     for (; r0 < n; r0 += stride) {
       unsigned rr1 = 0;
       if (r0 + stride + lane < n) rr1 = w.ent_b[sl1];
-      if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_of_id[r0 + 2 * stride + lane]);
+      if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_rank[r0 + 2 * stride + lane]) & SLOT_MASK;
 #pragma unroll
-      for (int j0 = 0; j0 < VQ; j0 += CH) {
-        float4 val[CH];
-        unsigned rj[CH];
+      for (int j0 = 0; j0 < VQ; j0 += CW) {
+        float4 val[CW];
+        unsigned rj[CW];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+        for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
+        for (int j = 0; j < CW; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
+        for (int j = 0; j < CW; ++j) {
           const long long ii = r0 + (j0 + j) * RW + sub;
           if (ii < n) {  // the output is not read again by this launch: streaming store, keep L2 for the rows
             float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
@@ -1401,7 +1225,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     constexpr int RPB = TB / VQ;  // rows per block per step (VQ = 128, 256)
     const int v = threadIdx.x % VQ;
     for (long long i = (long long)blockIdx.x * RPB + threadIdx.x / VQ; i < n; i += (long long)gridDim.x * RPB) {
-      const unsigned r = w.ent_b[w.slot_of_id[i]];
+      const unsigned r = w.ent_b[w.slot_rank[i] & SLOT_MASK];
       reinterpret_cast<float4*>(out + (size_t)i * (VQ * 4))[v] = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
     }
   } else {
@@ -1410,52 +1234,9 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += (long long)gridDim.x * TB) {
       const long long i = x / D;
       const int e = (int)(x - i * D);
-      out[x] = row_ptr(t, w.ent_b[w.slot_of_id[i]])[e];
+      out[x] = row_ptr(t, w.ent_b[w.slot_rank[i] & SLOT_MASK])[e];
     }
   }
-}
-
-// ---- kernel entry points: single table (by value) and many tables (descriptor array) ------------
-struct MultiDesc {
-  WsDev w;
-  PartArgs a;            // a.tv is the table of this entry (lookup) / the var table (apply)
-  const void* ids;
-  const int* counts;
-  float* out;            // lookup output rows
-  long long n;
-};
-
-template <int MODE>
-__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
-template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_part_sum(WsDev w, PartArgs a) { part_sum_body<MODE, OPT, V, LPR, K>(w, a); }
-template <int VQ>
-__global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
-  gather_body<VQ>(t, w, out, n);
-}
-
-template <int MODE, typename IdT, int VPL>
-__global__ void __launch_bounds__(TBT) k_tile_multi(const MultiDesc* __restrict__ descs) {
-  const MultiDesc& m = descs[blockIdx.y];
-  if (blockIdx.x >= m.w.ntiles) return;
-  tile_body<MODE, IdT, VPL>(m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.a.grad, m.n, m.a.tv.dim);
-}
-template <int MODE>
-__global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __restrict__ descs) {
-  const MultiDesc& m = descs[blockIdx.y];
-  if (blockIdx.x >= m.w.P || m.n == 0) return;
-  part_keys_body<MODE>(m.w, m.a);
-}
-template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_part_sum_multi(const MultiDesc* __restrict__ descs) {
-  const MultiDesc& m = descs[blockIdx.y];
-  if (blockIdx.x >= m.w.P || m.n == 0) return;
-  part_sum_body<MODE, OPT, V, LPR, K>(m.w, m.a);
-}
-template <int VQ>
-__global__ void __launch_bounds__(TB) k_gather_multi(const MultiDesc* __restrict__ descs) {
-  const MultiDesc& m = descs[blockIdx.y];
-  gather_body<VQ>(m.a.tv, m.w, m.out, m.n);
 }
 
 // KvVariableGatherOrZeros: read-only, no dedup needed (no writes, repeated keys hit cache).
@@ -1483,30 +1264,30 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
 // consecutive ids per step, lane l probes id l (64 independent probes in flight per wave, none of them
 // repeated by neighbouring lanes), then the wave copies the rows VQ lanes per row, CH copy instructions
 // in flight, row ids handed over by shuffle, streaming stores (the output is not read again here).
+// ids_kind: 0 int64, 1 int32, 2 (id, count) int64 pairs.  `wave` of `nwaves` waves share the rows.
 template <int VQ>
-__device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restrict__ ids, bool ids_int32,
-                                         float* __restrict__ out, long long n) {
+__device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restrict__ ids, int ids_kind,
+                                         float* __restrict__ out, long long n, long long wave, long long nwaves) {
   constexpr int RW = 64 / VQ;            // rows per copy instruction
-  constexpr int CH = VQ < 4 ? VQ : 4;    // copy instructions in flight
+  constexpr int CW = VQ < 4 ? VQ : 4;    // copy instructions in flight
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
-  const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-  const long long stride = (long long)gridDim.x * (TB / 64) * 64;
+  const long long stride = nwaves * 64;
   for (long long r0 = wave * 64; r0 < n; r0 += stride) {
     unsigned rr = 0;  // row 0 reads zeros: misses, and lanes past the end
     if (r0 + lane < n)
-      rr = table_find(t, ids_int32 ? (long long)reinterpret_cast<const int*>(ids)[r0 + lane]
-                                   : reinterpret_cast<const long long*>(ids)[r0 + lane]);
+      rr = table_find(t, ids_kind == 1 ? (long long)reinterpret_cast<const int*>(ids)[r0 + lane]
+                                       : reinterpret_cast<const long long*>(ids)[(r0 + lane) << (ids_kind == 2 ? 1 : 0)]);
 #pragma unroll
-    for (int j0 = 0; j0 < VQ; j0 += CH) {
-      float4 val[CH];
-      unsigned rj[CH];
+    for (int j0 = 0; j0 < VQ; j0 += CW) {
+      float4 val[CW];
+      unsigned rj[CW];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+      for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
 #pragma unroll
-      for (int j = 0; j < CH; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
+      for (int j = 0; j < CW; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j]))[v];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
+      for (int j = 0; j < CW; ++j) {
         const long long ii = r0 + (j0 + j) * RW + sub;
         if (ii < n) {
           float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
@@ -1520,7 +1301,105 @@ __device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restri
 template <typename IdT, int VQ>
 __global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT* __restrict__ ids,
                                                           float* __restrict__ out, long long n) {
-  goz_wave<VQ>(t, ids, sizeof(IdT) == 4, out, n);
+  goz_wave<VQ>(t, ids, sizeof(IdT) == 4 ? 1 : 0, out, n, (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6),
+               (long long)gridDim.x * (TB / 64));
+}
+
+// the gather for any dim behind one entry: wave-shaped for dims 4, 8, ..., 256, else 8 lanes per row
+__device__ __forceinline__ void goz_any(const TableDev& t, const void* __restrict__ ids, int ids_kind,
+                                        float* __restrict__ out, long long n, long long blk, long long nblk) {
+  const int D = t.dim;
+  const long long wave = blk * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const long long nwaves = nblk * (blockDim.x / 64);
+  if ((D & 3) == 0) {  // block-uniform
+    switch (D >> 2) {
+      case 1: goz_wave<1>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 2: goz_wave<2>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 4: goz_wave<4>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 8: goz_wave<8>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 16: goz_wave<16>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 32: goz_wave<32>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 64: goz_wave<64>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      default: break;
+    }
+  }
+  const int lane8 = threadIdx.x & 7;
+  const long long gpb = blockDim.x / 8;
+  for (long long i = blk * gpb + (threadIdx.x >> 3); i < n; i += nblk * gpb) {
+    const long long key = ids_kind == 1 ? (long long)reinterpret_cast<const int*>(ids)[i]
+                                        : reinterpret_cast<const long long*>(ids)[i << (ids_kind == 2 ? 1 : 0)];
+    const unsigned r = table_find(t, key);
+    const float* row = row_ptr(t, r);
+    float* o = out + (size_t)i * D;
+    if ((D & 3) == 0) {
+      for (int q = lane8; q < (D >> 2); q += 8)
+        reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
+    } else {
+      for (int e = lane8; e < D; e += 8) o[e] = row[e];
+    }
+  }
+}
+
+// ---- kernel entry points: single table (by value) and many tables (descriptor array) ------------
+struct MultiDesc {
+  WsDev w;
+  PartArgs a;            // a.tv is the table of this entry (lookup) / the var table (apply)
+  const void* ids;
+  const int* counts;
+  float* out;            // lookup output rows
+  long long n;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
+// the training lookup's partition pass with the probing gather beside it: blocks [0, P) own the partitions
+// (latency-bound: dependent probes), the blocks after them copy the output rows (bandwidth-bound)
+__global__ void __launch_bounds__(TBK) k_part_keys_gather(WsDev w, PartArgs a, GatherRole g) {
+  if (blockIdx.x < w.P) part_keys_body<MODE_LOOKUP>(w, a);
+  else goz_any(a.tv, g.ids, g.ids_kind, g.out, g.n, blockIdx.x - w.P, gridDim.x - w.P);
+}
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_sorted(WsDev w, PartArgs a) { apply_sorted_body<MODE, OPT, V, LPR, K>(w, a); }
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_span(WsDev w, PartArgs a) { apply_span_body<MODE, OPT, V, LPR, K>(w, a); }
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
+  gather_body<VQ>(t, w, out, n);
+}
+
+template <bool FIRST, typename IdT>
+__global__ void __launch_bounds__(TBT) k_tile_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.ntiles) return;
+  tile_body<FIRST, IdT>(m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.n, m.a.det);
+}
+template <int MODE>
+__global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  part_keys_body<MODE>(m.w, m.a);
+}
+__global__ void __launch_bounds__(TB) k_order_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (m.n == 0) return;
+  order_body<false>(m.a.tv, m.w, m.n, nullptr);
+}
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_sorted_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if ((long long)blockIdx.x * CH >= m.n) return;
+  apply_sorted_body<MODE, OPT, V, LPR, K>(m.w, m.a);
+}
+template <int MODE, int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_span_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if ((long long)blockIdx.x * CH >= m.n) return;
+  apply_span_body<MODE, OPT, V, LPR, K>(m.w, m.a);
+}
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_gather_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  gather_body<VQ>(m.a.tv, m.w, m.out, m.n);
 }
 
 // BatchKvVariableGatherOrZerosV2 (kernels/kv_variable_ops.cc:431-470): N tables, N id lists, N
@@ -1535,35 +1414,7 @@ struct BatchGatherDesc {
 };
 __global__ void __launch_bounds__(TB) k_batch_gather_or_zeros(const BatchGatherDesc* __restrict__ descs) {
   const BatchGatherDesc& d = descs[blockIdx.y];
-  const TableDev t = d.t;
-  const int D = t.dim;
-  if ((D & 3) == 0) {  // block-uniform: the wave-shaped body for dims 4, 8, ..., 256
-    switch (D >> 2) {
-      case 1: goz_wave<1>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 2: goz_wave<2>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 4: goz_wave<4>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 8: goz_wave<8>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 16: goz_wave<16>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 32: goz_wave<32>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      case 64: goz_wave<64>(t, d.ids, d.ids_int32, d.out, d.n); return;
-      default: break;
-    }
-  }
-  const int lane8 = threadIdx.x & 7;
-  for (long long i = (long long)blockIdx.x * (TB / 8) + (threadIdx.x >> 3); i < d.n;
-       i += (long long)gridDim.x * (TB / 8)) {
-    const long long key = d.ids_int32 ? (long long)reinterpret_cast<const int*>(d.ids)[i]
-                                      : reinterpret_cast<const long long*>(d.ids)[i];
-    const unsigned r = table_find(t, key);
-    const float* row = row_ptr(t, r);
-    float* o = d.out + (size_t)i * D;
-    if ((D & 3) == 0) {
-      for (int q = lane8; q < (D >> 2); q += 8)
-        reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
-    } else {
-      for (int e = lane8; e < D; e += 8) o[e] = row[e];
-    }
-  }
+  goz_any(d.t, d.ids, d.ids_int32 ? 1 : 0, d.out, d.n, blockIdx.x, gridDim.x);
 }
 
 __global__ void k_store_count(const unsigned* ctr, long long* out) { *out = (long long)*ctr; }
@@ -1572,7 +1423,7 @@ __global__ void k_store_count(const unsigned* ctr, long long* out) { *out = (lon
 __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
-    inverse[i] = (int)w.ent_b[w.slot_of_id[i]];
+    inverse[i] = (int)w.ent_b[w.slot_rank[i] & SLOT_MASK];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1696,7 +1547,7 @@ __global__ void __launch_bounds__(TB) k_seg_combine(TableDev t, WsDev w, const u
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const bool ok = j + u < hi;
-          sl[u] = ok ? w.slot_of_id[j + u] : 0xFFFFFFFFu;
+          sl[u] = ok ? (w.slot_rank[j + u] & SLOT_MASK) : 0xFFFFFFFFu;
           wj[u] = ok ? (wts ? wts[j + u] : 1.f) : 0.f;
         }
 #pragma unroll
@@ -1719,7 +1570,7 @@ __global__ void __launch_bounds__(TB) k_seg_combine(TableDev t, WsDev w, const u
         float acc = 0.f;
         wsum = 0.f; w2 = 0.f;
         for (unsigned j = lo; j < hi; ++j) {
-          const unsigned r = w.ent_b[w.slot_of_id[j]];
+          const unsigned r = w.ent_b[w.slot_rank[j] & SLOT_MASK];
           const float wj = wts ? wts[j] : 1.f;
           acc += row_ptr(t, r)[e] * wj;
           wsum += wj; w2 += wj * wj;

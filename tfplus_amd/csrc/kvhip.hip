@@ -2,7 +2,7 @@
 // sparse optimizer kernels, and the C ABI of include/kvhip.h.
 //
 // Layout in HBM (per table):
-//   index    Entry[cap+1]   16 B {int64 key, u32 row, u32 pad}, open addressing, linear
+//   index    Entry[cap+1]   16 B {int64 key, u32 row, u32 slot-row hint}, open addressing, linear
 //                           probing, cap = 2^k >= 2 * rows (load <= 0.5).  Entry[cap] is the
 //                           home of the one key that equals the EMPTY sentinel.
 //   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32 and RowMeta[r] 16 B {int64 key,
@@ -10,15 +10,18 @@
 //            under_threshold, bit2 under_threshold stale, bit3 released by Delete)}.  Row ids are
 //            dense (bump allocated; rows released by Delete are recycled from a device free
 //            list), row 0 is a permanent all-zero row (misses / nothing).
-//   workspace per-batch entry lists (ent_key / ent_a / ent_b, toff, slot_of_id, part): plain
-//            stores only, rewritten by every op — nothing to clean.
+//   workspace per-batch index (ent_key / ent_a / ent_b / ent_base, toff, slot_rank, order, ohead, chunk
+//            partials): plain stores only, rewritten by every op — nothing to clean.
 //
 // Kernel pipeline (kv_kernels.h explains why; DESIGN.md has the byte accounting):
-//   lookup : k_tile<LOOKUP>      LDS dedup per 2048-id tile, entries sorted by hash partition
-//            k_part_keys<LOOKUP> one block owns a partition's keys: find / insert, frequency, flags
-//            k_gather            one wave per 64 output rows, 16 B per lane
-//   apply  : k_tile<APPLY>       same + in-tile fold of repeated ids' gradient rows
-//            k_part_sum<OPT>     per key: sum of the per-tile contributions + fused row update
+//   lookup : k_tile              LDS dedup per 2048-id tile, entries sorted by hash partition
+//            k_part_keys_gather  one block owns a partition's keys: find / insert, frequency, flags, and the
+//                                keys' places in the sorted position list; further blocks of the same launch
+//                                copy the output rows (probing gather)
+//            k_order             sorted position list; rows inserted by this batch re-copied
+//   apply  : [k_tile, k_part_keys<APPLYIDX>, k_order when the batch was not just looked up]
+//            k_apply_sorted<OPT> segmented sum over the sorted positions + fused row update
+//            k_apply_span<OPT>   keys that cross chunk boundaries
 //   many tables in one launch: the *_multi entry points (grid.y = table)
 //
 // Reference semantics restated per function with file:line (relative to the tfplus tree).
@@ -26,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -40,9 +44,11 @@
 
 #include "../../include/kvhip.h"
 
-// k_part_sum dispatch, compiled in two other translation units (kv_part_launch.h)
-extern "C" int kvp_launch_part_sum_a(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab);
-extern "C" int kvp_launch_part_sum_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab);
+// k_apply_sorted / k_apply_span dispatch, compiled in two other translation units (kv_apply_launch.h)
+extern "C" int kvp_launch_apply_a(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab,
+                                  unsigned nchunks, int span);
+extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab,
+                                  unsigned nchunks, int span);
 
 namespace {
 
@@ -55,7 +61,7 @@ namespace {
 __global__ void k_fill_entries(Entry* e, unsigned long long count) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (unsigned long long)gridDim.x * blockDim.x) {
-    Entry v; v.key = EMPTY_KEY; v.row = 0; v.pad = 0;
+    Entry v; v.key = EMPTY_KEY; v.row = 0; v.hint = 0;
     *reinterpret_cast<uint4*>(&e[i]) = *reinterpret_cast<uint4*>(&v);
   }
 }
@@ -76,23 +82,41 @@ __global__ void k_narrow_keys(long long* keys, long long n) {
   }
 }
 
-// re-insert rows [1, next_row) into a fresh index
-__global__ void k_rehash(TableDev t, unsigned nrows) {
+// re-insert rows [1, next_row) into a fresh index; the slot-row hints travel from the old index (told)
+__global__ void k_rehash(TableDev t, TableDev told, unsigned nrows) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     if (*flags_ptr(t, r) & FLAG_FREE) continue;  // released by Delete: no index entry
     const long long key = *key_ptr(t, r);
+    unsigned hint = 0;
+    if (told.entries) { const Entry* oe = table_entry_of(told, key); if (oe) hint = oe->hint; }
     if (key == EMPTY_KEY) {
       Entry* s = &t.entries[t.mask + 1];
-      s->key = 0; s->row = r;
+      s->key = 0; s->row = r; s->hint = hint;
       continue;
     }
     unsigned long long p = mix64((unsigned long long)key) & t.mask;
     for (;;) {
       unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.entries[p].key),
                                          (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-      if (old == (unsigned long long)EMPTY_KEY) { t.entries[p].row = r; break; }
+      if (old == (unsigned long long)EMPTY_KEY) { t.entries[p].row = r; t.entries[p].hint = hint; break; }
       p = (p + 1) & t.mask;
     }
+  }
+}
+// forget every slot-row hint (the attached slot table changed or was cleared)
+__global__ void k_clear_hints(Entry* e, unsigned long long count) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) e[i].hint = 0;
+}
+// kv_attach_slot: every key of the var learns its row in the slot table (one pass over the var's rows)
+__global__ void k_link_hints(TableDev tv, TableDev ts, unsigned nrows) {
+  for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    if (*flags_ptr(tv, r) & FLAG_FREE) continue;
+    const long long key = *key_ptr(tv, r);
+    const unsigned sr = table_find(ts, key);
+    if (!sr) continue;
+    Entry* e = table_entry_of(tv, key);
+    if (e && load_entry(e).row == r) e->hint = sr;
   }
 }
 
@@ -283,12 +307,17 @@ struct Workspace {
   long long* ent_key = nullptr;
   unsigned* ent_a = nullptr;
   unsigned* ent_b = nullptr;
-  unsigned short* toff = nullptr;
-  unsigned* slot_of_id = nullptr;
-  float* part = nullptr;
-  long long part_elems = 0;
+  unsigned* ent_base = nullptr;
+  unsigned* toff = nullptr;
+  unsigned* slot_rank = nullptr;
+  unsigned* order = nullptr;
+  uint4* ohead = nullptr;
+  uint4* ctail = nullptr;
+  unsigned* cmeta = nullptr;
+  float* cpart = nullptr;    // [cap_n / CH][2][dim]
+  long long cpart_elems = 0;
   unsigned* ctr = nullptr;
-  long long* scat_keys = nullptr;  // kv_scatter_update add / sub: de-duplicated ids and summed updates
+  long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
   float* scat_sum = nullptr;
   long long scat_cap = 0;          // rows
   unsigned* seg_off = nullptr;   // kv_lookup_sparse: CSR offsets [seg_cap + 1]
@@ -327,7 +356,21 @@ struct kv_table {
   float* init_table = nullptr;
   long long init_rows = 0;
   bool initialized = false;
+  bool init_placeholder = false;   // init_table is the zero row an import put there, not a real init table
   Workspace ws;
+  // the batch index the workspace holds: `batch_serial` names it (0 = none); an optimizer apply handed the
+  // same token takes the index over instead of rebuilding it
+  uint64_t batch_serial = 0;
+  long long batch_n = 0;
+  bool deterministic = false;      // kv_set_deterministic
+  uint64_t uid = 0;                // unique over the process: names the attached slot table safely
+  uint64_t slot_uid = 0;           // uid of the slot table the index entries' hints refer to (0 = none)
+  uint64_t slot_gen = 0;           // that table's `gen` when the hints were valid
+  uint64_t gen = 0;                // bumped when the table is cleared (import): hints into it die
+  unsigned* err_host = nullptr;    // pinned: the device error flag, copied back after every batch op
+  hipStream_t last_stream = nullptr;  // stream of the table's last op; a different stream first waits for it
+  bool has_last = false;
+  hipEvent_t last_done = nullptr;
   // delta lists (SUPPORT_DELTA_EXPORT / SUPPORT_PREDICTION_DELTA_EXPORT, kv_variable.h:100-111): live keys
   // carry a byte in their RowMeta; keys recorded by Delete have no row and wait here
   bool track_delta = false, track_pred = false;
@@ -386,6 +429,7 @@ TableDev dev_view(const kv_table* t) {
   d.enter_threshold = t->enter_threshold;
   d.seed = t->seed;
   d.track_delta = t->track_delta ? 1u : 0u;
+  d.err_host = t->err_host;   // hipHostMallocMapped: the same address on the device
   return d;
 }
 
@@ -412,14 +456,28 @@ int build_index(kv_table* t, unsigned long long newcap, unsigned nrows, hipStrea
   HIP_TRY(hipMalloc(&ne, (newcap + 1) * sizeof(Entry)));
   k_fill_entries<<<nblocks((long long)newcap + 1, TB, 8192), TB, 0, s>>>(ne, newcap + 1);
   Entry* old = t->entries;
+  TableDev told = dev_view(t);   // the old index: its slot-row hints are carried over
+  if (!old) told.entries = nullptr;
   t->entries = ne;
   t->cap = newcap;
   if (nrows > 1) {
-    k_rehash<<<nblocks(nrows, TB), TB, 0, s>>>(dev_view(t), nrows);
+    k_rehash<<<nblocks(nrows, TB), TB, 0, s>>>(dev_view(t), told, nrows);
   }
   HIP_TRY(hipStreamSynchronize(s));
   if (old) HIP_TRY(hipFree(old));
   return KV_OK;
+}
+
+// the device error flag was found set at a synchronous point: report once, then clear it so the table
+// stays usable (the batch that raised it had no effect beyond rows it may have inserted)
+int flagged_error(kv_table* t, unsigned code, hipStream_t s) {
+  hipMemsetAsync(t->d_counters + 1, 0, sizeof(unsigned), s);
+  hipStreamSynchronize(s);
+  if (t->err_host) *reinterpret_cast<volatile unsigned*>(t->err_host) = 0u;
+  t->batch_serial = 0;
+  return fail(KV_INTERNAL, code == 2 ? "a hash partition received more than 65535 entries in one batch "
+                                       "(key set crafted against the partition hash); that batch was not applied"
+                                     : "row slab overflow detected on device");
 }
 
 // make room for `extra` more keys (worst case: every id of the batch is new).  rows_ub bounds the
@@ -433,10 +491,7 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
     unsigned c[3];
     HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (c[1])
-    return fail(KV_INTERNAL, c[1] == 2 ? "a hash partition received more than 65535 entries in one batch "
-                                         "(key set crafted against the partition hash); that batch was not applied"
-                                       : "row slab overflow detected on device");
+    if (c[1]) return flagged_error(t, c[1], s);
     const long long freed = std::max(0, (int)c[2]);
     t->rows_ub = c[0];
     t->free_known = freed;
@@ -482,38 +537,49 @@ unsigned pick_partitions(long long n) {
   return P;
 }
 
+// (re)allocation that leaves the old buffer in place when the new one cannot be had
+template <typename T>
+int regrow(T** p, size_t count) {
+  T* q = nullptr;
+  HIP_TRY(hipMalloc(&q, count * sizeof(T)));
+  if (*p) hipFree(*p);
+  *p = q;
+  return KV_OK;
+}
+
 int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   Workspace& w = t->ws;
   const unsigned P = pick_partitions(n);
+  int rc;
   if (n > w.cap_n || P > w.capP) {
     HIP_TRY(hipStreamSynchronize(s));
     long long cap = std::max<long long>(n, TILE);
     if (w.cap_n) cap = std::max<long long>(cap, std::min<long long>(w.cap_n * 2, 1ll << 30));
     cap = (cap + TILE - 1) / TILE * TILE;
     const unsigned capP = std::max(pick_partitions(cap), P);
-    hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.toff); hipFree(w.slot_of_id);
-    hipFree(w.part);
-    w.part = nullptr; w.part_elems = 0;
-    const size_t nt = (size_t)(cap / TILE);
-    HIP_TRY(hipMalloc(&w.ent_key, (size_t)cap * sizeof(long long)));
-    HIP_TRY(hipMalloc(&w.ent_a, (size_t)cap * sizeof(unsigned)));
-    HIP_TRY(hipMalloc(&w.ent_b, (size_t)cap * sizeof(unsigned)));
-    HIP_TRY(hipMalloc(&w.toff, nt * (capP + 1) * sizeof(unsigned short)));
-    HIP_TRY(hipMalloc(&w.slot_of_id, (size_t)cap * sizeof(unsigned)));
+    const size_t nt = (size_t)(cap / TILE), nc = (size_t)(cap / CH);
+    // every buffer is replaced only once its successor exists; a failure leaves the old sizes in force
+    w.cap_n = 0; w.capP = 0; w.cpart_elems = 0;
+    t->batch_serial = 0;
+    if ((rc = regrow(&w.ent_key, (size_t)cap)) || (rc = regrow(&w.ent_a, (size_t)cap)) ||
+        (rc = regrow(&w.ent_b, (size_t)cap)) || (rc = regrow(&w.ent_base, (size_t)cap)) ||
+        (rc = regrow(&w.toff, nt * (capP + 1))) || (rc = regrow(&w.slot_rank, (size_t)cap)) ||
+        (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.ohead, (size_t)cap)) ||
+        (rc = regrow(&w.ctail, nc)) || (rc = regrow(&w.cmeta, nc)))
+      return rc;
     if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
 #ifdef KV_STAMPS
-    hipFree(w.dbg);
-    HIP_TRY(hipMalloc(&w.dbg, (size_t)8192 * 16 * sizeof(unsigned long long)));
+    if ((rc = regrow(&w.dbg, (size_t)8192 * 16))) return rc;
 #endif
     w.cap_n = cap;
     w.capP = capP;
   }
-  const long long pe = (w.cap_n / TILE) * PARTCAP * (long long)t->dim;
-  if (need_part && w.part_elems < pe) {
+  const long long pe = (w.cap_n / CH) * 2 * (long long)t->dim;
+  if (need_part && w.cpart_elems < pe) {
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(w.part);
-    w.part_elems = pe;
-    HIP_TRY(hipMalloc(&w.part, (size_t)pe * sizeof(float)));
+    w.cpart_elems = 0;
+    if ((rc = regrow(&w.cpart, (size_t)pe))) return rc;
+    w.cpart_elems = pe;
   }
   return KV_OK;
 }
@@ -521,10 +587,14 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
 WsDev ws_view(kv_table* t, long long n) {
   Workspace& w = t->ws;
   WsDev d;
-  d.ent_key = w.ent_key; d.ent_a = w.ent_a; d.ent_b = w.ent_b;
+  d.ent_key = w.ent_key; d.ent_a = w.ent_a; d.ent_b = w.ent_b; d.ent_base = w.ent_base;
   d.toff = w.toff;
-  d.slot_of_id = w.slot_of_id;
-  d.part = w.part;
+  d.slot_rank = w.slot_rank;
+  d.order = w.order;
+  d.ohead = w.ohead;
+  d.cpart = w.cpart;
+  d.ctail = w.ctail;
+  d.cmeta = w.cmeta;
   d.ctr = w.ctr;
   d.ntiles = (unsigned)((n + TILE - 1) / TILE);
   d.P = pick_partitions(n);
@@ -558,38 +628,26 @@ unsigned today(const kv_table* t) {
   return (unsigned)(std::time(nullptr) / (3600 * 24)) & 0xFFFFu;  // utility.cc:38-40
 }
 
-// tile pass.  vpl: float4 per lane per row for the gradient fold (0 = scalar lanes / no fold)
-template <int MODE>
+// tile pass.  FIRST: scatter / mark flavour (one input position per key instead of the counts).
+// ids_kind: -1 = the table's key dtype, 0 int64, 1 int32, 2 (id, count) int64 pairs (lookups only).
 // md != nullptr: the same launch over `ntab` tables (grid.y), arguments from the descriptor array
 // md, grid.x = gx (the largest table's tile count)
-void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* counts, const float* grad,
-                 long long n, hipStream_t s, int ids_int32 = -1, const MultiDesc* md = nullptr, int ntab = 0,
-                 unsigned gx = 0) {
-  if (ids_int32 < 0) ids_int32 = t->key_dtype == KV_DT_INT32;
-  const int D = t->dim;
+template <bool FIRST>
+void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* counts, long long n, hipStream_t s,
+                 int ids_kind = -1, const MultiDesc* md = nullptr, int ntab = 0, unsigned gx = 0) {
+  if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
   const int grid = (int)wd.ntiles;
-  const size_t sh = tile_smem_bytes(MODE, D);
-  constexpr bool FOLD = (MODE == MODE_APPLY || MODE == MODE_DEDUP);
-  int vpl = 0;
-  if (FOLD && (D & 3) == 0 && D <= 256) vpl = D <= 32 ? 1 : D <= 64 ? 2 : D <= 128 ? 4 : 8;
-#define KV_TILE(IDT, VPL)                                                                          \
-  do {                                                                                             \
-    if (md) k_tile_multi<MODE, IDT, VPL><<<dim3(gx, (unsigned)ntab), TBT, sh, s>>>(md);             \
-    else k_tile<MODE, IDT, VPL><<<grid, TBT, sh, s>>>(wd, (const IDT*)ids, counts, grad, n, D);    \
+  const size_t sh = tile_smem_bytes(FIRST);
+  const int det = t->deterministic ? 1 : 0;
+#define KV_TILE(IDT)                                                                     \
+  do {                                                                                   \
+    if (md) k_tile_multi<FIRST, IDT><<<dim3(gx, (unsigned)ntab), TBT, sh, s>>>(md);       \
+    else k_tile<FIRST, IDT><<<grid, TBT, sh, s>>>(wd, (const IDT*)ids, counts, n, det);  \
   } while (0)
-#define KV_TILE_V(IDT)                                        \
-  do {                                                        \
-    if (!FOLD || vpl == 0) KV_TILE(IDT, 0);                   \
-    else if (vpl == 1) KV_TILE(IDT, (FOLD ? 1 : 0));          \
-    else if (vpl == 2) KV_TILE(IDT, (FOLD ? 2 : 0));          \
-    else if (vpl == 4) KV_TILE(IDT, (FOLD ? 4 : 0));          \
-    else KV_TILE(IDT, (FOLD ? 8 : 0));                        \
-  } while (0)
-  if (ids_int32 == 2) {   // (id, count) pairs: lookups only
-    if constexpr (MODE == MODE_LOOKUP) KV_TILE(IdCount, 0);
-  } else if (ids_int32) KV_TILE_V(int);
-  else KV_TILE_V(long long);
-#undef KV_TILE_V
+  if (ids_kind == 2) {
+    if constexpr (!FIRST) KV_TILE(IdCount);
+  } else if (ids_kind == 1) KV_TILE(int);
+  else KV_TILE(long long);
 #undef KV_TILE
 }
 
@@ -622,42 +680,89 @@ void launch_gather(const TableDev& td, const WsDev& wd, float* op, long long m, 
 #undef KV_GATHER
 }
 
-// partition pass, dispatched on the row geometry: D % 4 == 0 -> float4 lanes, else scalar lanes
-// multi (md != nullptr): wd carries the LARGEST ntiles / P of the batch of tables (LDS sizing, grid.x);
-// only MODE_LOOKUP and MODE_APPLY on float4 rows are instantiated for it
-template <int MODE, int OPT>
-int launch_part(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
-  const int D = pa.tv.dim;
+// partition pass.  multi (md != nullptr): wd carries the LARGEST ntiles / P of the batch of tables (LDS
+// sizing, grid.x); instantiated for MODE_LOOKUP and MODE_APPLYIDX
+template <int MODE>
+void launch_part_keys(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   const int grid = (int)wd.P;
-  if constexpr (MODE != MODE_APPLY && MODE != MODE_DEDUP) {
-    if constexpr (MODE == MODE_LOOKUP) {
-      if (md) {
-        k_part_keys_multi<MODE><<<dim3((unsigned)grid, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
-        return KV_OK;
-      }
+  const size_t sh = (size_t)wd.ntiles * 4 + 32;
+  if constexpr (MODE == MODE_LOOKUP || MODE == MODE_APPLYIDX) {
+    if (md) {
+      k_part_keys_multi<MODE><<<dim3((unsigned)grid, (unsigned)ntab), TBK, sh, s>>>(md);
+      return;
     }
-    k_part_keys<MODE><<<grid, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
-    return KV_OK;
-  } else {
-    // the k_part_sum instantiations live in kv_part_sum_a.hip / kv_part_sum_b.hip (parallel build)
-    int rc;
-    if (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3))
-      rc = kvp_launch_part_sum_a(MODE, OPT, &wd, &pa, (void*)s, md, ntab);
-    else
-      rc = kvp_launch_part_sum_b(MODE, OPT, &wd, &pa, (void*)s, md, ntab);
-    if (rc == KV_UNIMPLEMENTED)
-      return md ? fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D)
-                : fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
-                       "(multiples of 4 up to 1024, any dim up to 256)", D);
-    if (rc) return fail(rc, "partition pass: no kernel for mode %d / optimizer %d", MODE, OPT);
-    return KV_OK;
   }
+  k_part_keys<MODE><<<grid, TBK, sh, s>>>(wd, pa);
+}
+// the training lookup: partitions + the probing gather of the output rows in one launch
+void launch_part_keys_gather(const WsDev& wd, const PartArgs& pa, const GatherRole& g, hipStream_t s) {
+  static const int gcap = [] { const char* e = getenv("KV_GATHER_BLOCKS"); return e ? atoi(e) : 4096; }();
+  const int gb = nblocks(g.n, TBK, gcap);   // a 64-row step per wave: residency, not a loop, hides the hops
+  k_part_keys_gather<<<(int)wd.P + gb, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa, g);
+}
+
+// sorted position list of the batch; out != nullptr: the lookup's fix-up of rows inserted by this batch
+void launch_order(const TableDev& td, const WsDev& wd, long long n, float* out, hipStream_t s,
+                  const MultiDesc* md = nullptr, int ntab = 0) {
+  const int grid = nblocks(n, TB, 4096);
+  if (md) k_order_multi<<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);
+  else if (out) k_order<true><<<grid, TB, 0, s>>>(td, wd, n, out);
+  else k_order<false><<<grid, TB, 0, s>>>(td, wd, n, nullptr);
+}
+
+// segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
+// boundaries (k_apply_span).  pa.n = ids of the batch (multi: nmax = the largest table's batch)
+template <int MODE, int OPT>
+int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long long nmax, hipStream_t s,
+                 const MultiDesc* md = nullptr, int ntab = 0) {
+  const int D = pa.tv.dim;
+  const unsigned nchunks = (unsigned)((nmax + CH - 1) / CH);
+  auto fn = (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3)) ? kvp_launch_apply_a : kvp_launch_apply_b;
+  int rc;
+  {
+    ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, nchunks, 0);
+  }
+  if (rc == KV_OK) {
+    ProfScope ps(prof_t, KV_PROF_APPLY_SPAN, s);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, nchunks, 1);
+  }
+  if (rc == KV_UNIMPLEMENTED)
+    return md ? fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D)
+              : fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels "
+                     "(multiples of 4 up to 1024, any dim up to 256)", D);
+  if (rc) return fail(rc, "apply pass: no kernel for mode %d / optimizer %d", MODE, OPT);
+  return KV_OK;
 }
 
 bool dim_supported(int D) { return (D & 3) == 0 ? D <= 1024 : D <= 256; }
 
 int check_table(kv_handle_t h) {
   if (!h) return fail(KV_INVALID_ARGUMENT, "null table handle");
+  return KV_OK;
+}
+
+// A batch the index pass gave up on (a hash partition with more than 65535 entries, or keys that no
+// sub-hash separates) raises the device flag AND this pinned host word; every later kernel of that op saw
+// the flag and did nothing.  The next call on the table reports it — no synchronisation on the good path.
+int report_deferred_error(kv_table* t, hipStream_t s) {
+  if (!t->err_host || *reinterpret_cast<volatile unsigned*>(t->err_host) == 0u) return KV_OK;
+  const unsigned code = *reinterpret_cast<volatile unsigned*>(t->err_host);
+  hipStreamSynchronize(s);
+  return flagged_error(t, code, s);
+}
+
+// Ops of one table run in the order they were issued, whatever their streams: the per-table workspace
+// and the table itself are shared by every op (the reference's table locks cover execution, not just
+// enqueue, training_ops.cc:96-184).  Same stream as the last op: nothing to do.  Another stream: it first
+// waits for everything the previous stream had been given.
+int hand_over(kv_table* t, hipStream_t s) {
+  if (t->has_last && t->last_stream != s) {
+    HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
+    HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
+  }
+  t->last_stream = s;
+  t->has_last = true;
   return KV_OK;
 }
 
@@ -671,28 +776,45 @@ struct MultiLock {
     for (auto* t : ts) t->mu.lock();
   }
   ~MultiLock() { for (auto it = ts.rbegin(); it != ts.rend(); ++it) (*it)->mu.unlock(); }
+  int enter(hipStream_t s) {
+    int rc;
+    for (auto* t : ts)
+      if ((rc = report_deferred_error(t, s)) || (rc = hand_over(t, s))) return rc;
+    return KV_OK;
+  }
 };
-
-// shared front half of every optimizer op: capacity, workspace, tile pass (dedup + in-tile fold)
-int apply_prologue(kv_table* v, std::initializer_list<kv_table*> slots, const float* grad,
-                   const void* ids, long long n, hipStream_t s, WsDev* wd, unsigned* day) {
-  if (n < 0 || n > (1ll << 21))
-    return fail(n < 0 ? KV_INVALID_ARGUMENT : KV_UNIMPLEMENTED,
-                "indices: %lld ids in one optimizer call (limit 2^21; split the batch)", n);
-  if (n > 0 && (!grad || !ids)) return fail(KV_INVALID_ARGUMENT, "grad / indices pointer is null");
-  if (!dim_supported(v->dim))
-    return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
+// the same for ops on one table (the caller holds t->mu)
+int enter_op(kv_table* t, hipStream_t s) {
   int rc;
-  if ((rc = ensure_capacity(v, n, s))) return rc;
-  for (auto* sl : slots)
-    if ((rc = ensure_capacity(sl, n, s))) return rc;
-  if ((rc = ensure_workspace(v, n, true, s))) return rc;
-  *wd = ws_view(v, n);
-  *day = today(v);
-  ProfScope ps(v, KV_PROF_APPLY_TILE, s);
-  launch_tile<MODE_APPLY>(v, *wd, ids, nullptr, grad, n, s);
-  return KV_OK;
+  if ((rc = report_deferred_error(t, s))) return rc;
+  return hand_over(t, s);
 }
+
+// The index of a batch (kv_kernels.h): tile pass, partition pass, sorted position list.
+//   MODE_LOOKUP   with out != nullptr: the training lookup (rows copied beside the partition pass)
+//   MODE_APPLYIDX the optimizer meets the ids first (FindOrInsertUnsafe on the var table)
+//   MODE_UNIQUE   no table: dense unique indices (pa.out_keys / direct_rows)
+template <int MODE>
+void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
+                int ids_kind, float* out, hipStream_t s) {
+  {
+    ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
+    launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
+  }
+  if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
+  if (MODE == MODE_LOOKUP && out) {
+    ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
+    launch_part_keys_gather(wd, pa, GatherRole{ids, ids_kind, out, n}, s);
+  } else {
+    ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
+    launch_part_keys<MODE>(wd, pa, s);
+  }
+  ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_ORDER : KV_PROF_INDEX, s);
+  launch_order(pa.tv, wd, n, MODE == MODE_LOOKUP ? out : nullptr, s);
+}
+
+uint64_t g_serial = 0;   // batch tokens (under the table's mutex; uniqueness across tables is not needed)
+std::atomic<uint64_t> g_uid{0};
 
 }  // namespace
 
@@ -802,6 +924,13 @@ int kv_create(int key_dtype, int value_dtype, int dim, int enter_threshold, int6
       rc = fail(KV_RESOURCE_EXHAUSTED, "hipMalloc of table header failed");
       break;
     }
+    if (hipHostMalloc(&t->err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipEventCreateWithFlags(&t->last_done, hipEventDisableTiming) != hipSuccess) {
+      rc = fail(KV_RESOURCE_EXHAUSTED, "table header: pinned word / event");
+      break;
+    }
+    *t->err_host = 0;
+    t->uid = ++g_uid;
     unsigned init[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // next_row = 1 (row 0 is the zero row)
     if (hipMemcpy(t->d_counters, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) {
       rc = fail(KV_INTERNAL, "hipMemcpy failed");
@@ -825,8 +954,11 @@ int kv_destroy(kv_handle_t t) {
   hipFree(t->route_hist);
   for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
-  hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.toff); hipFree(w.slot_of_id);
-  hipFree(w.part); hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
+  hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.toff); hipFree(w.slot_rank);
+  hipFree(w.order); hipFree(w.ohead); hipFree(w.ctail); hipFree(w.cmeta); hipFree(w.cpart);
+  hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
+  if (t->err_host) hipHostFree(t->err_host);
+  if (t->last_done) hipEventDestroy(t->last_done);
   delete t;
   return KV_OK;
 }
@@ -851,12 +983,15 @@ int kv_init_table(kv_handle_t t, const float* table, int64_t rows, kv_stream_t s
   if (!table || rows <= 0) return fail(KV_INVALID_ARGUMENT, "random_initializer must be a non-empty [rows, dim] matrix");
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  if (t->initialized && t->init_rows > 1) return KV_OK;  // "re-initialization ignored" kv_variable.h:188-193
+  // "re-initialization ignored" once a table is set (random_init_table_.NumElements() > 0, kv_variable.h:188-193);
+  // the zero row an import leaves in place of a missing init table is not one
+  if (t->initialized && t->init_table && !t->init_placeholder) return KV_OK;
   if (t->init_table) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); hipFree(t->init_table); t->init_table = nullptr; }
   HIP_TRY(hipMalloc(&t->init_table, (size_t)rows * t->dim * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(t->init_table, table, (size_t)rows * t->dim * sizeof(float),
                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
   t->init_rows = rows;
+  t->init_placeholder = false;
   t->initialized = true;
   return KV_OK;
 }
@@ -885,10 +1020,7 @@ static int stats(kv_handle_t t, hipStream_t s, unsigned long long out[2], unsign
   unsigned c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (c[1])
-    return fail(KV_INTERNAL, c[1] == 2 ? "a hash partition received more than 65535 entries in one batch "
-                                         "(key set crafted against the partition hash); that batch was not applied"
-                                       : "row slab overflow detected on device");
+  if (c[1]) return flagged_error(t, c[1], s);
   t->rows_ub = c[0];
   t->free_known = std::max(0, (int)c[2]);
   if (nrows_out) *nrows_out = c[0];
@@ -944,20 +1076,25 @@ int kv_get_meta(kv_handle_t t, const int64_t* ids, int64_t n, uint32_t* fw, uint
 }
 
 static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
-                                 kv_stream_t stream, int pairs);
+                                 kv_stream_t stream, int pairs, kv_batch_token_t* token);
 
 int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
                         kv_stream_t stream) {
-  return gather_or_insert_impl(t, ids, counts, n, out, stream, 0);
+  return gather_or_insert_impl(t, ids, counts, n, out, stream, 0, nullptr);
+}
+int kv_gather_or_insert_tok(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
+                            kv_batch_token_t* token, kv_stream_t stream) {
+  if (token) *token = 0;
+  return gather_or_insert_impl(t, ids, counts, n, out, stream, 0, token);
 }
 int kv_gather_or_insert_pairs(kv_handle_t t, const int64_t* id_count_pairs, int64_t n, float* out,
                               kv_stream_t stream) {
   if (t && t->key_dtype == KV_DT_INT32) return fail(KV_INVALID_ARGUMENT, "id/count pairs carry int64 ids");
-  return gather_or_insert_impl(t, id_count_pairs, nullptr, n, out, stream, 1);
+  return gather_or_insert_impl(t, id_count_pairs, nullptr, n, out, stream, 1, nullptr);
 }
 
 static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
-                                 kv_stream_t stream, int pairs) {
+                                 kv_stream_t stream, int pairs, kv_batch_token_t* token) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (n == 0) return KV_OK;  // kv_variable_ops.cc:530-532
@@ -968,12 +1105,14 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = enter_op(t, s))) return rc;
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
   // pass: the frequency adds saturate identically and rows are inserted by the first chunk)
-  const long long CH = 1ll << 21;
+  const long long CHK = 1ll << 21;
   const size_t idsz = pairs ? 16 : (t->key_dtype == KV_DT_INT32 ? 4 : 8);
-  for (long long off = 0; off < n; off += CH) {
-    const long long m = std::min(CH, (long long)n - off);
+  t->batch_serial = 0;
+  for (long long off = 0; off < n; off += CHK) {
+    const long long m = std::min(CHK, (long long)n - off);
     const void* idp = (const char*)ids + (size_t)off * idsz;
     const int32_t* cp = counts ? counts + off : nullptr;
     float* op = out + (size_t)off * t->dim;
@@ -984,18 +1123,16 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     PartArgs pa{};
     pa.tv = td; pa.ts0 = td; pa.ts1 = td;
     pa.day = today(t);
-    {
-      ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-      launch_tile<MODE_LOOKUP>(t, wd, idp, cp, nullptr, m, s, pairs ? 2 : -1);
-    }
-    {
-      ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-      if ((rc = launch_part<MODE_LOOKUP, 0>(wd, pa, s))) return rc;
-    }
-    ProfScope ps_gather(t, KV_PROF_LOOKUP_GATHER, s);
-    launch_gather(td, wd, op, m, s);
+    pa.det = t->deterministic ? 1 : 0;
+    pa.n = m;
+    index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s);
   }
   HIP_TRY(hipGetLastError());
+  if (n <= CHK) {   // the workspace now holds the index of exactly this batch
+    t->batch_serial = ++g_serial;
+    t->batch_n = n;
+    if (token) *token = t->batch_serial;
+  }
   return KV_OK;
 }
 
@@ -1017,6 +1154,7 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = enter_op(t, s))) return rc;
   const int D = t->dim;
   if (n == 0) {  // every segment is empty
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * D * sizeof(float), s));
@@ -1027,9 +1165,10 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   Workspace& ws = t->ws;
   if (ws.seg_cap < num_segments) {
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(ws.seg_off);
-    ws.seg_cap = std::max<long long>(num_segments, ws.seg_cap * 2);
-    HIP_TRY(hipMalloc(&ws.seg_off, (size_t)(ws.seg_cap + 1) * sizeof(unsigned)));
+    const long long want = std::max<long long>(num_segments, ws.seg_cap * 2);
+    ws.seg_cap = 0;
+    if ((rc = regrow(&ws.seg_off, (size_t)(want + 1)))) return rc;
+    ws.seg_cap = want;
   }
   const TableDev td = dev_view(t);
   const WsDev wd = ws_view(t, n);
@@ -1037,15 +1176,18 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   pa.tv = td; pa.ts0 = td; pa.ts1 = td;
   pa.day = today(t);
   pa.count_once = count_occurrences ? 0 : 1;
+  pa.det = t->deterministic ? 1 : 0;
+  pa.n = n;
+  t->batch_serial = 0;
   {
     ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-    launch_tile<MODE_LOOKUP>(t, wd, ids, nullptr, nullptr, n, s);
+    launch_tile<false>(t, wd, ids, nullptr, n, s);
   }
   {
     ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-    if ((rc = launch_part<MODE_LOOKUP, 0>(wd, pa, s))) return rc;
+    launch_part_keys<MODE_LOOKUP>(wd, pa, s);
   }
-  ProfScope ps_gather(t, KV_PROF_LOOKUP_GATHER, s);
+  ProfScope ps_gather(t, KV_PROF_LOOKUP_ORDER, s);
   if (segment_dtype == KV_DT_INT32)
     k_seg_offsets<int><<<nblocks(n + 1, TB, 2048), TB, 0, s>>>((const int*)segment_ids, n, num_segments, ws.seg_off);
   else
@@ -1191,6 +1333,8 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
   return KV_OK;
 }
 
+static bool claim_slot(kv_table* v, kv_table* sl, hipStream_t s);
+
 // ---- many tables, one launch per pipeline stage (26-feature CTR step: 5 launches, not 130) ------
 // All tables: same device, same dim, same key dtype; each batch <= 2^21 ids.
 static int multi_common(int num_tables, const kv_handle_t* tables, const void* const* ids, const int64_t* ns) {
@@ -1220,8 +1364,10 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  if ((rc = lock.enter(s))) return rc;
   long long nmax = 0;
   for (int i = 0; i < num_tables; ++i) {
+    tables[i]->batch_serial = 0;
     if (ns[i] > 0 && !outs[i]) return fail(KV_INVALID_ARGUMENT, "output pointer is null");
     if ((rc = ensure_capacity(tables[i], ns[i], s))) return rc;
     if ((rc = ensure_workspace(tables[i], std::max<long long>(ns[i], 1), false, s))) return rc;
@@ -1240,6 +1386,8 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
+    d.a.det = tables[i]->deterministic ? 1 : 0;
+    d.a.n = ns[i];
     d.ids = ids[i];
     d.counts = counts ? counts[i] : nullptr;
     d.out = outs[i];
@@ -1252,8 +1400,8 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
-  launch_tile<MODE_LOOKUP>(t0, wmax, nullptr, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
-  if ((rc = launch_part<MODE_LOOKUP, 0>(wmax, hd[0].a, s, md, num_tables))) return rc;
+  launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
   launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -1295,8 +1443,10 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
+  if ((rc = lock.enter(s))) return rc;
   long long nmax = 0;
   for (int i = 0; i < num_tables; ++i) {
+    vars[i]->batch_serial = 0;
     if ((rc = ensure_capacity(vars[i], ns[i], s))) return rc;
     if ((rc = ensure_capacity(slots0[i], ns[i], s))) return rc;
     if (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))) return rc;
@@ -1316,6 +1466,9 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
     d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
     d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
+    d.a.det = vars[i]->deterministic ? 1 : 0;
+    d.a.n = ns[i];
+    d.a.use_hints = claim_slot(vars[i], slots0[i], s) ? 1 : 0;
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
@@ -1325,12 +1478,14 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
-  launch_tile<MODE_APPLY>(vars[0], wmax, nullptr, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+  launch_order(hd[0].a.tv, wmax, nmax, nullptr, s, md, num_tables);
   switch (opt) {
-    case OPT_ADAM_V4: rc = launch_part<MODE_APPLY, OPT_ADAM_V4>(wmax, hd[0].a, s, md, num_tables); break;
-    case OPT_ADAM_V3: rc = launch_part<MODE_APPLY, OPT_ADAM_V3>(wmax, hd[0].a, s, md, num_tables); break;
-    case OPT_ADAGRAD: rc = launch_part<MODE_APPLY, OPT_ADAGRAD>(wmax, hd[0].a, s, md, num_tables); break;
-    default: rc = launch_part<MODE_APPLY, OPT_FTRL>(wmax, hd[0].a, s, md, num_tables); break;
+    case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    case OPT_ADAGRAD: rc = launch_apply<MODE_APPLY, OPT_ADAGRAD>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    default: rc = launch_apply<MODE_APPLY, OPT_FTRL>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
   }
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -1386,9 +1541,50 @@ int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, co
   return multi_apply_common(num_tables, vars, accums, linears, 1, grads, ids, ns, a, OPT_FTRL, stream);
 }
 
-int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const void* ids, int64_t n,
-                        float lr, float b1p, float b2p, float b1, float b2, float eps, float l1,
-                        float l2, float l21, int version, kv_stream_t stream) {
+}  // extern "C"
+
+static bool claim_slot(kv_table* v, kv_table* sl, hipStream_t s);
+
+// shared body of the optimizer ops.  `token` names the batch index a lookup left in the var's workspace
+// (kv_gather_or_insert_tok): the same ids, so the index pass is skipped.  The caller holds the locks.
+template <int OPT>
+static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* grad, const void* ids, int64_t n,
+                        const OptArgs& a, kv_batch_token_t token, hipStream_t s) {
+  if (n < 0 || n > (1ll << 21))
+    return fail(n < 0 ? KV_INVALID_ARGUMENT : KV_UNIMPLEMENTED,
+                "indices: %lld ids in one optimizer call (limit 2^21; split the batch)", (long long)n);
+  if (n > 0 && (!grad || !ids)) return fail(KV_INVALID_ARGUMENT, "grad / indices pointer is null");
+  if (!dim_supported(v->dim))
+    return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
+  int rc;
+  const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
+  if (!reuse && (rc = ensure_capacity(v, n, s))) return rc;
+  if ((rc = ensure_capacity(s0, n, s))) return rc;
+  if (s1 && (rc = ensure_capacity(s1, n, s))) return rc;
+  if ((rc = ensure_workspace(v, n, true, s))) return rc;
+  const WsDev wd = ws_view(v, n);
+  PartArgs pa{};
+  pa.tv = dev_view(v); pa.ts0 = dev_view(s0); pa.ts1 = s1 ? dev_view(s1) : pa.ts0;
+  pa.opt = a; pa.grad = grad; pa.day = today(v);
+  pa.det = v->deterministic ? 1 : 0;
+  pa.n = n;
+  pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
+  if (!reuse) {
+    v->batch_serial = 0;
+    index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
+    v->batch_n = n;
+  }
+  if ((rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s))) return rc;
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+extern "C" {
+
+int kv_apply_group_adam_tok(kv_handle_t v, kv_handle_t mvl, const float* grad, const void* ids, int64_t n,
+                            float lr, float b1p, float b2p, float b1, float b2, float eps, float l1,
+                            float l2, float l21, int version, kv_batch_token_t token, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(v)) || (rc = check_table(mvl))) return rc;
   if (version != 3 && version != 4) return fail(KV_INVALID_ARGUMENT, "GroupAdam version %d: 3 or 4", version);
@@ -1407,8 +1603,7 @@ int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const
   DeviceGuard dg(v->device);
   MultiLock lk({v, mvl});
   hipStream_t s = (hipStream_t)stream;
-  WsDev wd; unsigned day;
-  if ((rc = apply_prologue(v, {mvl}, grad, ids, n, s, &wd, &day))) return rc;
+  if ((rc = lk.enter(s))) return rc;
   OptArgs a{};
   a.lr = lr; a.b1p = b1p; a.b2p = b2p; a.b1 = b1; a.b2 = b2; a.eps = eps;
   if (version == 4) {  // :7111-7120
@@ -1419,21 +1614,17 @@ int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const
     a.alpha = std::sqrt(1.f - b2p) / (1.f - b1p);
   }
   a.l21_norm = a.l21 * std::sqrt((float)v->dim);
-  PartArgs pa{};
-  pa.tv = dev_view(v); pa.ts0 = dev_view(mvl); pa.ts1 = pa.ts0;
-  pa.opt = a; pa.grad = grad; pa.day = day;
-  {
-    ProfScope ps(v, KV_PROF_APPLY_PART, s);
-    rc = version == 4 ? launch_part<MODE_APPLY, OPT_ADAM_V4>(wd, pa, s)
-                      : launch_part<MODE_APPLY, OPT_ADAM_V3>(wd, pa, s);
-  }
-  if (rc) return rc;
-  HIP_TRY(hipGetLastError());
-  return KV_OK;
+  return version == 4 ? apply_common<OPT_ADAM_V4>(v, mvl, nullptr, grad, ids, n, a, token, s)
+                      : apply_common<OPT_ADAM_V3>(v, mvl, nullptr, grad, ids, n, a, token, s);
+}
+int kv_apply_group_adam(kv_handle_t v, kv_handle_t mvl, const float* grad, const void* ids, int64_t n,
+                        float lr, float b1p, float b2p, float b1, float b2, float eps, float l1,
+                        float l2, float l21, int version, kv_stream_t stream) {
+  return kv_apply_group_adam_tok(v, mvl, grad, ids, n, lr, b1p, b2p, b1, b2, eps, l1, l2, l21, version, 0, stream);
 }
 
-int kv_apply_adagrad(kv_handle_t v, kv_handle_t acc, float lr, const float* grad, const void* ids,
-                     int64_t n, int update_slots, kv_stream_t stream) {
+int kv_apply_adagrad_tok(kv_handle_t v, kv_handle_t acc, float lr, const float* grad, const void* ids,
+                         int64_t n, int update_slots, kv_batch_token_t token, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(v)) || (rc = check_table(acc))) return rc;
   if (!v->initialized || !acc->initialized)
@@ -1444,25 +1635,19 @@ int kv_apply_adagrad(kv_handle_t v, kv_handle_t acc, float lr, const float* grad
   DeviceGuard dg(v->device);
   MultiLock lk({v, acc});
   hipStream_t s = (hipStream_t)stream;
-  WsDev wd; unsigned day;
-  if ((rc = apply_prologue(v, {acc}, grad, ids, n, s, &wd, &day))) return rc;
+  if ((rc = lk.enter(s))) return rc;
   OptArgs a{};
   a.lr = lr; a.update_slots = update_slots;
-  PartArgs pa{};
-  pa.tv = dev_view(v); pa.ts0 = dev_view(acc); pa.ts1 = pa.ts0;
-  pa.opt = a; pa.grad = grad; pa.day = day;
-  {
-    ProfScope ps(v, KV_PROF_APPLY_PART, s);
-    rc = launch_part<MODE_APPLY, OPT_ADAGRAD>(wd, pa, s);
-  }
-  if (rc) return rc;
-  HIP_TRY(hipGetLastError());
-  return KV_OK;
+  return apply_common<OPT_ADAGRAD>(v, acc, nullptr, grad, ids, n, a, token, s);
+}
+int kv_apply_adagrad(kv_handle_t v, kv_handle_t acc, float lr, const float* grad, const void* ids,
+                     int64_t n, int update_slots, kv_stream_t stream) {
+  return kv_apply_adagrad_tok(v, acc, lr, grad, ids, n, update_slots, 0, stream);
 }
 
-int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, const float* grad,
-                               const void* ids, int64_t n, float lr, float l1, float l2, float l21,
-                               float l2s, float lr_power, kv_stream_t stream) {
+int kv_apply_sparse_group_ftrl_tok(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, const float* grad,
+                                   const void* ids, int64_t n, float lr, float l1, float l2, float l21,
+                                   float l2s, float lr_power, kv_batch_token_t token, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(v)) || (rc = check_table(acc)) || (rc = check_table(lin))) return rc;
   if (!v->initialized || !acc->initialized || !lin->initialized)
@@ -1481,37 +1666,80 @@ int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, 
   DeviceGuard dg(v->device);
   MultiLock lk({v, acc, lin});
   hipStream_t s = (hipStream_t)stream;
-  WsDev wd; unsigned day;
-  if ((rc = apply_prologue(v, {acc, lin}, grad, ids, n, s, &wd, &day))) return rc;
+  if ((rc = lk.enter(s))) return rc;
   OptArgs a{};
   a.lr = lr; a.l1 = l1; a.l2 = l2; a.l21 = l21; a.l2s = l2s; a.lr_power = lr_power;
   a.l21_norm = l21 * std::sqrt((float)v->dim);  // :728
-  PartArgs pa{};
-  pa.tv = dev_view(v); pa.ts0 = dev_view(acc); pa.ts1 = dev_view(lin);
-  pa.opt = a; pa.grad = grad; pa.day = day;
-  {
-    ProfScope ps(v, KV_PROF_APPLY_PART, s);
-    rc = launch_part<MODE_APPLY, OPT_FTRL>(wd, pa, s);
-  }
-  if (rc) return rc;
+  return apply_common<OPT_FTRL>(v, acc, lin, grad, ids, n, a, token, s);
+}
+int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, const float* grad,
+                               const void* ids, int64_t n, float lr, float l1, float l2, float l21,
+                               float l2s, float lr_power, kv_stream_t stream) {
+  return kv_apply_sparse_group_ftrl_tok(v, acc, lin, grad, ids, n, lr, l1, l2, l21, l2s, lr_power, 0, stream);
+}
+
+// The slot table whose rows the var's index entries remember (Entry::hint): the first slot-0 table an
+// optimizer uses with the var, or the one kv_attach_slot names.  Hints of a table that was cleared since
+// (import) mean nothing any more and are forgotten; another table simply goes without hints.
+static bool claim_slot(kv_table* v, kv_table* sl, hipStream_t s) {
+  if (v->slot_uid == sl->uid && v->slot_gen == sl->gen) return true;
+  if (v->slot_uid != 0 && v->slot_uid != sl->uid) return false;
+  if (v->slot_uid == sl->uid)   // same table, cleared since
+    k_clear_hints<<<nblocks((long long)v->cap + 1, TB, 8192), TB, 0, s>>>(v->entries, v->cap + 1);
+  v->slot_uid = sl->uid;
+  v->slot_gen = sl->gen;
+  return true;
+}
+
+int kv_attach_slot(kv_handle_t v, kv_handle_t sl, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(v)) || (rc = check_table(sl))) return rc;
+  if (v == sl || v->device != sl->device || v->key_dtype != sl->key_dtype)
+    return fail(KV_INVALID_ARGUMENT, "kv_attach_slot: var and slot must be distinct tables on one device with one key dtype");
+  DeviceGuard dg(v->device);
+  MultiLock lk({v, sl});
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = lk.enter(s))) return rc;
+  unsigned nrows = 1;
+  if ((rc = stats(v, s, nullptr, &nrows))) return rc;
+  if (v->slot_uid != 0 && (v->slot_uid != sl->uid || v->slot_gen != sl->gen))
+    k_clear_hints<<<nblocks((long long)v->cap + 1, TB, 8192), TB, 0, s>>>(v->entries, v->cap + 1);
+  v->slot_uid = sl->uid;
+  v->slot_gen = sl->gen;
+  v->batch_serial = 0;
+  if (nrows > 1) k_link_hints<<<nblocks(nrows, TB, 8192), TB, 0, s>>>(dev_view(v), dev_view(sl), nrows);
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
 
-// tf.unique + unsorted_segment_sum on the batch pipeline; the table's mutex is held by the caller
+int kv_set_deterministic(kv_handle_t t, int on) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  std::lock_guard<std::mutex> l(t->mu);
+  t->deterministic = on != 0;
+  t->batch_serial = 0;
+  return KV_OK;
+}
+
+// tf.unique + unsorted_segment_sum on the batch pipeline; the table's mutex is held by the caller.
+// fold_op: how the rows of one id combine (KV_SCATTER_ADD = sum, MUL = product, MIN, MAX)
 static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t n, int64_t* uniq,
-                        float* summed, int32_t* inverse, int64_t* num_unique, hipStream_t s) {
+                        float* summed, int32_t* inverse, int64_t* num_unique, int fold_op, hipStream_t s) {
   int rc;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
   const WsDev wd = ws_view(t, n);
+  t->batch_serial = 0;
   HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
-  launch_tile<MODE_DEDUP>(t, wd, ids, nullptr, grad, n, s);
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.grad = grad;
   pa.out_keys = (long long*)uniq;
   pa.out_sum = summed;
-  if ((rc = launch_part<MODE_DEDUP, 0>(wd, pa, s))) return rc;
+  pa.fold_op = fold_op;
+  pa.det = t->deterministic ? 1 : 0;
+  pa.n = n;
+  index_pass<MODE_UNIQUE>(t, wd, pa, ids, nullptr, n, -1, nullptr, s);
+  if ((rc = launch_apply<MODE_DEDUP, OPT_ADAGRAD>(t, wd, pa, n, s))) return rc;
   if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
   unsigned U = 0;
   HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
@@ -1532,7 +1760,8 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  return dedup_locked(t, ids, grad, n, uniq, summed, inverse, num_unique, (hipStream_t)stream);
+  if ((rc = enter_op(t, (hipStream_t)stream))) return rc;
+  return dedup_locked(t, ids, grad, n, uniq, summed, inverse, num_unique, KV_SCATTER_ADD, (hipStream_t)stream);
 }
 
 int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const float* data, int64_t n,
@@ -1548,17 +1777,22 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = enter_op(t, s))) return rc;
   HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * t->dim * sizeof(float), s));  // segments nobody names
   if (n == 0) return KV_OK;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
   const WsDev wd = ws_view(t, n);
-  launch_tile<MODE_DEDUP>(t, wd, segment_ids, nullptr, data, n, s, 1);
+  t->batch_serial = 0;
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.grad = data;
   pa.out_sum = out;
   pa.direct_rows = num_segments;
-  if ((rc = launch_part<MODE_DEDUP, 0>(wd, pa, s))) return rc;
+  pa.fold_op = KV_SCATTER_ADD;
+  pa.det = t->deterministic ? 1 : 0;
+  pa.n = n;
+  index_pass<MODE_UNIQUE>(t, wd, pa, segment_ids, nullptr, n, 1, nullptr, s);
+  if ((rc = launch_apply<MODE_DEDUP, OPT_ADAGRAD>(t, wd, pa, n, s))) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1578,15 +1812,19 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = enter_op(t, s))) return rc;
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
   const WsDev wd = ws_view(t, n);
+  t->batch_serial = 0;
   HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
-  launch_tile<MODE_LOOKUP>(t, wd, ids, counts, nullptr, n, s);   // ent_a = saturating count per tile
+  launch_tile<false>(t, wd, ids, counts, n, s);   // ent_a = occurrences | saturating count per tile
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = (long long*)uniq;
   pa.out_counts = uniq_counts;
-  if ((rc = launch_part<MODE_UNIQUE, 0>(wd, pa, s))) return rc;
+  pa.det = t->deterministic ? 1 : 0;
+  pa.n = n;
+  launch_part_keys<MODE_UNIQUE>(wd, pa, s);
   if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
   if (num_unique_dev) k_store_count<<<1, 1, 0, s>>>(wd.ctr, (long long*)num_unique_dev);
   HIP_TRY(hipGetLastError());
@@ -1963,9 +2201,10 @@ static int scatter_like(kv_handle_t t, const void* ids, const float* vals, int64
     pa.grad = vals ? vals + (size_t)off * t->dim : nullptr;
     pa.scatter_op = op; pa.is_insert = is_insert;
     pa.mark_what = mark; pa.fvals = fvals ? fvals + off : nullptr;
-    launch_tile<MODE_SCATTER>(t, wd, (const char*)ids + (size_t)off * idsz, nullptr, nullptr, m, s);
-    rc = mark >= 0 ? launch_part<MODE_MARK, 0>(wd, pa, s) : launch_part<MODE_SCATTER, 0>(wd, pa, s);
-    if (rc) return rc;
+    t->batch_serial = 0;
+    launch_tile<true>(t, wd, (const char*)ids + (size_t)off * idsz, nullptr, m, s);
+    if (mark >= 0) launch_part_keys<MODE_MARK>(wd, pa, s);
+    else launch_part_keys<MODE_SCATTER>(wd, pa, s);
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -1976,6 +2215,7 @@ int kv_insert(kv_handle_t t, const void* ids, const float* values, int64_t n, kv
   if ((rc = check_table(t))) return rc;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = enter_op(t, (hipStream_t)stream))) return rc;
   return scatter_like(t, ids, values, n, KV_SCATTER_ASSIGN, 1, -1, nullptr, (hipStream_t)stream);
 }
 
@@ -1987,25 +2227,39 @@ int kv_scatter_update(kv_handle_t t, const void* ids, const float* updates, int6
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
-  if ((op == KV_SCATTER_ADD || op == KV_SCATTER_SUB) && n > 1 && n <= (1ll << 21) && ids && updates &&
-      dim_supported(t->dim)) {
-    // ScatterUpdate applies every occurrence of an id in turn (kv_variable.h:616-734), so repeated
-    // ids add up: sum them first (one row per distinct id), then apply once
+  if ((rc = enter_op(t, s))) return rc;
+  if (op != KV_SCATTER_ASSIGN && n > 1 && ids && updates && dim_supported(t->dim)) {
+    // ScatterUpdate applies every occurrence of an id in turn (kv_variable.h:616-734): the update rows of a
+    // repeated id are combined first (sum for add / sub, product for mul / div, min, max — one row per
+    // distinct id), then applied once.  Chunks of 2^21 ids one after another: occurrences in a later
+    // chunk meet the row the earlier chunk left, as in the reference's sequential order.
+    const int fold = (op == KV_SCATTER_ADD || op == KV_SCATTER_SUB) ? KV_SCATTER_ADD
+                   : (op == KV_SCATTER_MUL || op == KV_SCATTER_DIV) ? KV_SCATTER_MUL : op;
+    const long long CHK = 1ll << 21;
+    const size_t idsz = t->key_dtype == KV_DT_INT32 ? 4 : 8;
     Workspace& w = t->ws;
-    if (w.scat_cap < n) {
+    const long long want = std::min<long long>(n, CHK);
+    if (w.scat_cap < want) {
       HIP_TRY(hipStreamSynchronize(s));
-      hipFree(w.scat_keys); hipFree(w.scat_sum);
-      w.scat_keys = nullptr; w.scat_sum = nullptr;
-      w.scat_cap = std::max<long long>(n, w.scat_cap * 2);
-      HIP_TRY(hipMalloc(&w.scat_keys, (size_t)w.scat_cap * sizeof(long long)));
-      HIP_TRY(hipMalloc(&w.scat_sum, (size_t)w.scat_cap * t->dim * sizeof(float)));
+      const long long cap = std::max<long long>(want, std::min<long long>(w.scat_cap * 2, CHK));
+      w.scat_cap = 0;
+      if ((rc = regrow(&w.scat_keys, (size_t)cap)) || (rc = regrow(&w.scat_sum, (size_t)cap * t->dim))) return rc;
+      w.scat_cap = cap;
     }
-    int64_t U = 0;
-    if ((rc = dedup_locked(t, ids, updates, n, (int64_t*)w.scat_keys, w.scat_sum, nullptr, &U, s))) return rc;
-    if (t->key_dtype == KV_DT_INT32 && U > 0)   // the unique list is int64; the table's ops take its own key type
-      k_narrow_keys<<<1, 1024, 0, s>>>(w.scat_keys, U);
-    return scatter_like(t, w.scat_keys, w.scat_sum, U, op, 0, -1, nullptr, s);
+    for (long long off = 0; off < n; off += CHK) {
+      const long long m = std::min(CHK, (long long)n - off);
+      int64_t U = 0;
+      if ((rc = dedup_locked(t, (const char*)ids + (size_t)off * idsz, updates + (size_t)off * t->dim, m,
+                             (int64_t*)w.scat_keys, w.scat_sum, nullptr, &U, fold, s)))
+        return rc;
+      if (t->key_dtype == KV_DT_INT32 && U > 0)   // the unique list is int64; the table's ops take its own key type
+        k_narrow_keys<<<1, 1024, 0, s>>>(w.scat_keys, U);
+      if ((rc = scatter_like(t, w.scat_keys, w.scat_sum, U, op, 0, -1, nullptr, s))) return rc;
+    }
+    return KV_OK;
   }
+  // assign: one of the occurrences of a repeated id stays (the reference's result depends on its thread
+  // interleaving there); dims outside the fused kernels' range take this path for every operation
   return scatter_like(t, ids, updates, n, op, 0, -1, nullptr, s);
 }
 
@@ -2018,6 +2272,7 @@ static int ensure_init_placeholder(kv_table* t, hipStream_t s) {
     HIP_TRY(hipMalloc(&t->init_table, (size_t)t->dim * sizeof(float)));
     HIP_TRY(hipMemsetAsync(t->init_table, 0, (size_t)t->dim * sizeof(float), s));
     t->init_rows = 1;
+    t->init_placeholder = true;
   }
   return KV_OK;
 }
@@ -2031,6 +2286,7 @@ int kv_import_delta(kv_handle_t t, const int64_t* keys, const float* values, int
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   if (t->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "import with int32 keys");
+  if ((rc = enter_op(t, s))) return rc;
   // Stage 1 (dynamic_restore.hpp:58-77): insert or overwrite, lift the blacklist, re-evaluate under_threshold
   if ((rc = scatter_like(t, keys, values, n, KV_SCATTER_ASSIGN, 3, -1, nullptr, s))) return rc;
   // Stage 2 (:92-112): first_n > 3 marks the blacklist, otherwise (inference load) those keys are removed
@@ -2060,8 +2316,12 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   if (t->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "import with int32 keys");
+  if ((rc = enter_op(t, s))) return rc;
   // clear(): dynamic_restore.hpp:60-62
   HIP_TRY(hipStreamSynchronize(s));
+  t->gen += 1;            // row ids start over: slot-row hints into this table are void
+  t->slot_uid = 0;        // and the fresh index carries none of its own
+  t->batch_serial = 0;
   unsigned init[3] = {1, 0, 0};
   HIP_TRY(hipMemcpy(t->d_counters, init, sizeof init, hipMemcpyHostToDevice));  // stack source: synchronous
   k_fill_entries<<<nblocks((long long)t->cap + 1, TB, 8192), TB, 0, s>>>(t->entries, t->cap + 1);

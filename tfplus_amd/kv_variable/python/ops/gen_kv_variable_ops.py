@@ -29,6 +29,7 @@ class KvHandle(object):
     self.device = device
     self.enter_threshold = enter_threshold
     self.name = name
+    self.batch = None   # (token, ids data_ptr, n, ids version) of the last training lookup
 
   def __del__(self):
     try:
@@ -52,6 +53,20 @@ def _ids(handle, indices):
   if t.dtype != handle.key_dtype:
     t = t.to(handle.key_dtype)
   return t.to(_dev(handle)).contiguous()
+
+
+def _remember_batch(handle, ids, token):
+  """The lookup left the index of `ids` in the table's workspace (kv_gather_or_insert_tok).  An optimizer op
+  that is handed the very same tensor OBJECT, unmodified since, passes the token on.  The tensor is kept
+  alive here: an address comparison alone would mistake a new tensor in recycled memory for the old one."""
+  handle.batch = (token, ids, ids._version) if token else None
+
+
+def _token_for(handle, ids):
+  b = handle.batch
+  if b and b[1] is ids and b[2] == ids._version:
+    return b[0]
+  return 0
 
 
 def _f32(handle, x):
@@ -146,8 +161,10 @@ def kv_variable_gather_or_insert_v2(table_handle, indices, dtype=torch.float32, 
   """REGISTER_OP("KvVariableGatherOrInsertV2") ops/kv_variable_ops.cc:310-320."""
   ids = _ids(table_handle, indices)
   out = _gather_out(table_handle, ids)
-  _lib.check(_lib.lib().kv_gather_or_insert(table_handle.ptr, _p(ids), None, ids.numel(), _p(out),
-                                            _stream(table_handle)))
+  tok = ctypes.c_uint64(0)
+  _lib.check(_lib.lib().kv_gather_or_insert_tok(table_handle.ptr, _p(ids), None, ids.numel(), _p(out),
+                                                ctypes.byref(tok), _stream(table_handle)))
+  _remember_batch(table_handle, ids, tok.value)
   return out
 
 
@@ -167,8 +184,10 @@ def kv_variable_gather_or_insert_with_counts(table_handle, indices, counts, dtyp
         (table_handle.name, tuple(ids.shape), tuple(cnt.shape)))
   cnt = cnt.to(_dev(table_handle)).contiguous()
   out = _gather_out(table_handle, ids)
-  _lib.check(_lib.lib().kv_gather_or_insert(table_handle.ptr, _p(ids), _p(cnt), ids.numel(), _p(out),
-                                            _stream(table_handle)))
+  tok = ctypes.c_uint64(0)
+  _lib.check(_lib.lib().kv_gather_or_insert_tok(table_handle.ptr, _p(ids), _p(cnt), ids.numel(), _p(out),
+                                                ctypes.byref(tok), _stream(table_handle)))
+  _remember_batch(table_handle, ids, tok.value)
   return out
 
 
@@ -200,10 +219,10 @@ def _grad_ids(var, grad, indices):
 def _group_adam(version, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2,
                 epsilon, l1, l2, l21, use_locking):
   g, ids = _grad_ids(var, grad, indices)
-  _lib.check(_lib.lib().kv_apply_group_adam(
+  _lib.check(_lib.lib().kv_apply_group_adam_tok(
       var.ptr, m_v_linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(beta1_power),
       _scalar(beta2_power), _scalar(beat1), _scalar(beta2), _scalar(epsilon), _scalar(l1), _scalar(l2),
-      _scalar(l21), version, _stream(var)))
+      _scalar(l21), version, _token_for(var, ids), _stream(var)))
 
 
 def kv_variable_group_sparse_apply_adam_v4(var, m_v_linear, grad, indices, lr, beta1_power,
@@ -226,8 +245,8 @@ def kv_variable_sparse_apply_adagrad(var, accum, lr, grad, indices, use_locking=
                                      update_slots=True, name=None):
   """REGISTER_OP("KvVariableSparseApplyAdagrad") ops/training_ops.cc:214-226."""
   g, ids = _grad_ids(var, grad, indices)
-  _lib.check(_lib.lib().kv_apply_adagrad(var.ptr, accum.ptr, _scalar(lr), _p(g), _p(ids), ids.numel(),
-                                         int(bool(update_slots)), _stream(var)))
+  _lib.check(_lib.lib().kv_apply_adagrad_tok(var.ptr, accum.ptr, _scalar(lr), _p(g), _p(ids), ids.numel(),
+                                             int(bool(update_slots)), _token_for(var, ids), _stream(var)))
 
 
 def kv_variable_sparse_group_sparse_apply_ftrl_v2(var, accum, linear, grad, indices, lr, l1, l2, l21,
@@ -235,9 +254,9 @@ def kv_variable_sparse_group_sparse_apply_ftrl_v2(var, accum, linear, grad, indi
                                                   name=None):
   """REGISTER_OP("KvVariableSparseGroupSparseApplyFtrlV2") ops/training_ops.cc:135-150."""
   g, ids = _grad_ids(var, grad, indices)
-  _lib.check(_lib.lib().kv_apply_sparse_group_ftrl(
+  _lib.check(_lib.lib().kv_apply_sparse_group_ftrl_tok(
       var.ptr, accum.ptr, linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(l1),
-      _scalar(l2), _scalar(l21), _scalar(l2_shrinkage), _scalar(lr_power), _stream(var)))
+      _scalar(l2), _scalar(l21), _scalar(l2_shrinkage), _scalar(lr_power), _token_for(var, ids), _stream(var)))
 
 
 def kv_dedup_segment_sum(table_handle, indices, grad):
@@ -280,7 +299,12 @@ def read_kv_variable_op_v2(table_handle, Tkeys=torch.int64, Tvalues=torch.float3
 
 def kv_variable_import(table_handle, keys, values, blacklist=None, freq_keys=None, freq_values=None,
                        first_n=6, name=None):
-  """REGISTER_OP("KvVariableImport") ops/kv_variable_ops.cc:392-420 -> ImportValues."""
+  """REGISTER_OP("KvVariableImport") ops/kv_variable_ops.cc:392-420 -> ImportValues.  The lists beyond
+  first_n reach ImportValues as empty tensors (kernels/kv_variable_ops.cc:806-822)."""
+  if first_n <= 3:
+    blacklist = None
+  if first_n <= 4:
+    freq_keys, freq_values = None, None
   dev = _dev(table_handle)
   k = torch.as_tensor(keys, dtype=torch.int64).to(dev).contiguous()
   v = _f32(table_handle, values)
@@ -408,7 +432,16 @@ def kv_reserve(table_handle, capacity):
   _lib.check(_lib.lib().kv_reserve(table_handle.ptr, int(capacity)))
 
 
-PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_gather", "apply_tile", "apply_part")
+PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_order", "apply_index", "apply_sorted", "apply_span")
+
+
+def kv_attach_slot(var, slot):
+  """The var's index entries remember each key's row in `slot` (kvhip.h kv_attach_slot)."""
+  _lib.check(_lib.lib().kv_attach_slot(var.ptr, slot.ptr, _stream(var)))
+
+
+def kv_set_deterministic(table_handle, on=True):
+  _lib.check(_lib.lib().kv_set_deterministic(table_handle.ptr, int(bool(on))))
 
 
 def kv_profile_enable(table_handle, max_launches):
