@@ -4,8 +4,8 @@
 // parallel.  Included inside the anonymous namespace of those files, after kv_device.h and kv_kernels.h.
 //
 // D % 4 == 0 -> float4 lanes, else scalar lanes.  md != nullptr: one launch over `ntab` tables (grid.y),
-// nchunks = the largest table's chunk count; only MODE_APPLY on float4 rows is instantiated for it.
-// span == 0: k_apply_sorted, span == 1: k_apply_span.  Returns KV_OK, or KV_UNIMPLEMENTED for an
+// nchunks = blocks per table; only MODE_APPLY on float4 rows is instantiated for it.
+// span == 0: k_apply, span == 1: k_apply_fin.  Returns KV_OK, or KV_UNIMPLEMENTED for an
 // unsupported dim.
 #pragma once
 
@@ -16,17 +16,17 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
   const int grid = (int)nchunks;
 #define KV_APPLY(V, LPR, K)                                                                        \
   do {                                                                                             \
-    const size_t sh = span ? (size_t)(TBS / LPR + 1) * D * 4 + 32 : apply_smem_bytes(D, LPR);       \
+    const size_t sh = 0;                                                                           \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
       if (md) {                                                                                    \
-        if (span) k_apply_span_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);   \
-        else k_apply_sorted_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);      \
+        if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);   \
+        else k_apply_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);      \
         return KV_OK;                                                                              \
       }                                                                                            \
     }                                                                                              \
     if (md) return KV_UNIMPLEMENTED;                                                               \
-    if (span) k_apply_span<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                     \
-    else k_apply_sorted<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                        \
+    if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                     \
+    else k_apply<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                        \
     return KV_OK;                                                                                  \
   } while (0)
   if ((D & 3) == 0) {

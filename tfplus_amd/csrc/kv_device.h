@@ -19,7 +19,9 @@ constexpr unsigned NEW_BIT = 0x40000000u;       // ent_base: the key's row was i
 constexpr unsigned BASE_MASK = 0x3FFFFFFFu;
 constexpr int RANK_SHIFT = 21;                  // slot_rank: entry index (21 bits, n <= 2^21) | in-tile occurrence rank << 21
 constexpr unsigned SLOT_MASK = (1u << RANK_SHIFT) - 1u;
-constexpr int CH = 256;                         // sorted positions per chunk of the apply kernel
+constexpr int LCOLD = 16;   // a key with at most this many occurrences in the batch is "cold": one lane group sums its
+                            // rows and updates it; a "hot" key's rows are summed in chunks by whole waves
+constexpr int HC = 256;     // rows per hot chunk (more for keys with > 65536 rows, so that a key has at most 256 chunks)
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
 constexpr int TBT = 512;  // threads per block of the tile kernel
@@ -93,25 +95,29 @@ struct WsDev {
                            // in the tile << RANK_SHIFT
   unsigned* order;         // [n + 1] input positions sorted by key (a key's occurrences are contiguous), first
                            // one tagged HEAD_BIT; order[n] = HEAD_BIT
-  uint4* ohead;            // [n] at a key's first sorted position: {key lo, key hi, row, slot-row hint}
-  float* cpart;            // [nchunks][2][dim] leading / trailing partial sums of the apply chunks
-  uint4* ctail;            // [nchunks] ohead record of the chunk's trailing (unfinished) key
-  unsigned* cmeta;         // [nchunks] CM_* flags
-  unsigned* ctr;           // [8] op counters ([0]: unique count of kv_unique / kv_dedup_segment_sum); host-zeroed
+  uint4* coldlist;         // [n][2] KeyRec of the cold keys: {key lo, key hi, row, slot-row hint} {start, count, -, -}
+  uint4* hotlist;          // [n / (LCOLD + 1) + 1][2] the hot keys: ... {start, count, first chunk, rows per chunk}
+  uint2* hotchunk;         // [hot chunks] {hot key index, chunk index inside the key}
+  float* hpart;            // [hot chunks][dim] partial sums of the keys that have more than one chunk
+  unsigned* ctr;           // [8] op counters, zeroed by the tile pass: [0] unique count (kv_unique / kv_dedup_segment_sum),
+                           // [2..3] one 64-bit word: cold keys (22 bits) | hot keys (21) | hot chunks (21)
   unsigned ntiles, P;
   int pshift;              // 64 - log2(P)
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
 };
-constexpr unsigned CM_HAS_HEAD = 1u, CM_LEAD = 2u, CM_TAIL_OPEN = 4u;
 
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
 // block stores s_memtime at phase boundaries into a buffer nothing else reads.
 #ifdef KV_STAMPS
 #define KV_STAMP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
 #define KV_STAMPP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = wall_clock64(); } while (0)
+#define KV_STAMPA(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = wall_clock64(); } while (0)
+#define KV_STAMPV(slot, v) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = (v); } while (0)
 #else
 #define KV_STAMP(slot) do { } while (0)
 #define KV_STAMPP(slot) do { } while (0)
+#define KV_STAMPA(slot) do { } while (0)
+#define KV_STAMPV(slot, v) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------

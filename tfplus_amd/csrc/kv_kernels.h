@@ -18,15 +18,15 @@
 //                 position list: partition p starts at sum over tiles of toff[t][p].positions (no scan
 //                 kernel, no atomics), a key at the block-scan prefix of the occurrence counts, an entry at
 //                 its key's start plus the occurrences of the key's entries before it (ent_base); the key's
-//                 record {key, row, slot-row hint} goes to ohead[start].  The blocks past the partitions of
+//                 record {key, row, slot-row hint, start, count} goes to the cold or the hot key list.  The blocks past the partitions of
 //                 a training lookup copy the output rows meanwhile (probing gather, bandwidth-bound, next
 //                 to the latency-bound partition work).
 //   k_order       order[ent_base[entry] + rank] = position; positions whose key was inserted by this batch
 //                 get their output row re-copied (the probing gather ran beside the inserts).
-//   k_apply_sorted  one block per CH consecutive sorted positions: segmented sum of the gradient rows
-//                 (a key's occurrences are contiguous) fused with the optimizer row update; a key that
-//                 crosses a chunk boundary leaves partial sums that
-//   k_apply_span  adds up in chunk order and finishes.
+//   k_apply       wave-granular segmented sum of the gradient rows (a key's occurrences are contiguous)
+//                 fused with the optimizer row update: hot keys in chunks of HC rows per wave, cold keys
+//                 one per lane group (see there);
+//   k_apply_fin   the hot keys that have more than one chunk: chunk sums added in chunk order, update.
 //
 // Every kernel body is a __device__ function with two entry points: one table (arguments by
 // value) and many tables in one launch (grid.y = table, arguments from a MultiDesc array).
@@ -119,6 +119,7 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
   }
   for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
   if (tid == 0) { lnwork = 0; lsent = 0; }
+  if (tile == 0 && tid < 8) w.ctr[tid] = 0;   // the partition pass counts into them
   __syncthreads();
 
   // ---- phase 1: LDS hash insert of this tile's ids --------------------------------------
@@ -352,8 +353,6 @@ __device__ __forceinline__ unsigned xcd_partition(unsigned b, unsigned P) {
 // occurs in every tile costs nothing extra.  256 threads, ~30 KB LDS, so every block of a
 // 1024-partition launch is resident at once (4 per CU needs < 40 KB).
 constexpr int TBK = 256;
-constexpr int HSK = 1024;          // LDS hash slots
-constexpr int UCAPK = HSK * 3 / 4; // unique keys per round
 
 // per-partition segment directory in LDS: tpre[t] = entries of tiles < t, tstart[t] = first entry of
 // tile t's segment.  Entry x of the partition (0 <= x < E) lives at tile t = last tpre[t] <= x.
@@ -394,8 +393,20 @@ __device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const un
   return (size_t)lo * TILE + tstart[lo] + (x - tpre[lo]);
 }
 
-template <int MODE>
+// chunk geometry of a hot key: rows per chunk (HC, or more so that no key has over 256 chunks)
+__host__ __device__ inline unsigned chunk_rows(unsigned cnt) {
+  return cnt <= 65536u ? (unsigned)HC : ((cnt + 255u) / 256u + 63u) & ~63u;
+}
+
+// HSK_: LDS hash slots (the lookup that runs beside the probing gather takes 512 to leave LDS for the
+// gather blocks; more unique keys than 3/4 of the slots split into sub-hash classes either way)
+template <int MODE, int HSK_ = 1024>
 __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a) {
+  constexpr int HSK = HSK_;
+  // unique keys per class: the check `lnu >= UCAPK` in pass 1 races with up to TBK inserts, so the LDS hash
+  // can receive UCAPK + TBK keys — which must still be fewer than its slots (or the probe loop never ends)
+  constexpr int UCAPK = HSK - TBK;
+  static_assert(UCAPK > 0 && UCAPK + TBK <= HSK, "LDS key hash would overflow");
   constexpr bool ORD = (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE || MODE == MODE_APPLYIDX);
   constexpr bool CNT = (MODE == MODE_LOOKUP || MODE == MODE_UNIQUE);
   __shared__ long long hkey[HSK + 1];
@@ -498,28 +509,66 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     const unsigned nu = lnu;
 
     // ---- the class's keys in the sorted position list: start = partition start + keys of the classes
-    //      before + occurrences of the keys before it in this class (block scan over the unique list)
+    //      before + occurrences of the keys before it in this class (block scan over the unique list);
+    //      the same scan numbers the cold and the hot keys and the hot keys' chunks.  Thread tid owns
+    //      keys tid * PERU .. + PERU - 1 of the unique list from here on.
+    constexpr int PERU = (UCAPK + TBK - 1) / TBK;
+    unsigned kst[PERU], kcnt[PERU], krank[PERU], kchunk[PERU];
     if constexpr (ORD) {
-      constexpr int PERU = (UCAPK + TBK - 1) / TBK;
-      unsigned c[PERU];
-      unsigned sum = 0;
+      unsigned sum = 0, ch = 0, nchs = 0;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
-        c[q] = u < nu ? hocc[ulist[u]] : 0u;
-        sum += c[q];
+        kcnt[q] = u < nu ? hocc[ulist[u]] : 0u;
+        sum += kcnt[q];
+        if (u < nu) {
+          if (kcnt[q] <= (unsigned)LCOLD) ch += 1u;
+          else { ch += 1u << 16; nchs += (kcnt[q] + chunk_rows(kcnt[q]) - 1u) / chunk_rows(kcnt[q]); }
+        }
       }
       const unsigned cur = lpcur;
-      unsigned tot;
+      unsigned tot, chtot, ntot;
       unsigned run = cur + block_excl_scan<TBK / 64>(sum, wtot, &tot);
+      unsigned chrun = block_excl_scan<TBK / 64>(ch, wtot, &chtot);
+      unsigned nrun = block_excl_scan<TBK / 64>(nchs, wtot, &ntot);
+      __shared__ unsigned long long lbase64;
+      if (tid == 0)   // one atomic per block and class: cold keys | hot keys << 22 | hot chunks << 43
+        lbase64 = atomicAdd(reinterpret_cast<unsigned long long*>(&w.ctr[2]),
+                            (unsigned long long)(chtot & 0xFFFFu) | ((unsigned long long)(chtot >> 16) << 22) |
+                                ((unsigned long long)ntot << 43));
+      __syncthreads();
+      const unsigned long long b64 = lbase64;
+      const unsigned cbase = (unsigned)(b64 & 0x3FFFFFu), hbase = (unsigned)((b64 >> 22) & 0x1FFFFFu), kbase = (unsigned)(b64 >> 43);
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
-        if (u < nu) { hocc[ulist[u]] = run; run += c[q]; }
+        kst[q] = run; krank[q] = 0; kchunk[q] = 0;
+        if (u < nu) {
+          hocc[ulist[u]] = run; run += kcnt[q];
+          if (kcnt[q] <= (unsigned)LCOLD) { krank[q] = cbase + (chrun & 0xFFFFu); chrun += 1u; }
+          else {
+            krank[q] = hbase + (chrun >> 16); chrun += 1u << 16;
+            kchunk[q] = kbase + nrun; nrun += (kcnt[q] + chunk_rows(kcnt[q]) - 1u) / chunk_rows(kcnt[q]);
+          }
+        }
       }
       __syncthreads();
       if (tid == 0) lpcur = cur + tot;
     }
+    // the key's record for the apply: cold or hot list, and the hot key's chunk table
+    auto put_rec = [&](int q, long long key, unsigned roww, unsigned hint) {
+      const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), roww, hint);
+      if (kcnt[q] <= (unsigned)LCOLD) {
+        w.coldlist[2 * (size_t)krank[q]] = ra;
+        w.coldlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], 0u, 0u);
+      } else {
+        const unsigned cr = chunk_rows(kcnt[q]);
+        w.hotlist[2 * (size_t)krank[q]] = ra;
+        w.hotlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], kchunk[q], cr);
+        const unsigned nch = (kcnt[q] + cr - 1u) / cr;
+        for (unsigned i = 0; i < nch; ++i) w.hotchunk[kchunk[q] + i] = make_uint2(krank[q], i);
+      }
+    };
 
     // ---- owner work: one thread per unique key ------------------------------------------------
     if constexpr (MODE == MODE_UNIQUE) {
@@ -530,7 +579,10 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);
         __syncthreads();
       }
-      for (unsigned u = tid; u < nu; u += TBK) {
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u >= nu) continue;
         const unsigned s = ulist[u];
         const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
         unsigned dense;
@@ -542,7 +594,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           if (a.out_counts) a.out_counts[dense] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
         }
         hrow[s] = dense;
-        w.ohead[hocc[s]] = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), dense, 0u);
+        put_rec(q, key, dense, 0u);
       }
       __syncthreads();
     }
@@ -550,8 +602,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     // flags with a single load (RowMeta).  A thread that owns several keys (more than 256 distinct
     // keys in the partition: low-skew batches) takes them OB at a time with their probes in flight
     // together, so it pays the two dependent hops once per batch, not once per key.
-    constexpr int OB = 4;
-    for (unsigned u0 = tid; u0 < nu && MODE != MODE_UNIQUE; u0 += OB * TBK) {
+    constexpr int OB = PERU;
+    if (MODE != MODE_UNIQUE) {
       unsigned sl[OB], r[OB], hint[OB];
       long long key[OB];
       unsigned long long pp[OB];
@@ -559,7 +611,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
       bool isnew[OB];
 #pragma unroll
       for (int k = 0; k < OB; ++k) {
-        const unsigned u = u0 + k * TBK;
+        const unsigned u = tid * PERU + k;
         sl[k] = 0xFFFFFFFFu; r[k] = 0; isnew[k] = false; key[k] = 0; pp[k] = 0; hint[k] = 0;
         if (u < nu) {
           sl[k] = ulist[u];
@@ -579,11 +631,9 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           if (isnew[k]) hint[k] = 0;
         }
         hrow[sl[k]] = r[k] | (isnew[k] ? 0x80000000u : 0u);
-        if constexpr (ORD)
-          // bit 31 of the row word: the OPTIMIZER's index pass inserted the key (such a row is neither filtered
-          // by enter_threshold nor counted, FindOrInsertWithFnUnsafe returns false: table_manager.h:192-204)
-          w.ohead[hocc[sl[k]]] = make_uint4((unsigned)key[k], (unsigned)((unsigned long long)key[k] >> 32),
-                                            r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? 0x80000000u : 0u), hint[k]);
+        // bit 31 of the row word: the OPTIMIZER's index pass inserted the key (such a row is neither filtered
+        // by enter_threshold nor counted, FindOrInsertWithFnUnsafe returns false: table_manager.h:192-204)
+        if constexpr (ORD) put_rec(k, key[k], r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? 0x80000000u : 0u), hint[k]);
       }
       uint2 m[OB];
 #pragma unroll
@@ -786,23 +836,19 @@ __global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_apply_sorted / k_apply_span: segmented sum over the sorted position list + fused row update
+// k_apply / k_apply_fin: segmented sum over the sorted position list + fused row update
 // ------------------------------------------------------------------------------------------
+// The partition pass left two lists of key records {key, row, slot-row hint | start, count, ...}: cold keys
+// (<= LCOLD occurrences in the batch: ~98 % of the keys of a Zipf batch, ~25 % of its rows) and hot keys, whose
+// rows are cut into chunks of HC rows.  The unit of work is a WAVE, not a block — no LDS, no barrier, no atomic:
+//   hot chunk   the wave's 64 / LPR lane groups sum the chunk's rows, RB rows in flight per group, and
+//               meet through shuffles; a key with one chunk is updated on the spot, else the chunk's sum
+//               goes to hpart and k_apply_fin adds the key's chunks up in chunk order and updates it
+//   cold batch  one lane group per key: its rows (order[start .. start + count)), its state rows and the
+//               record of the hinted slot row are requested together, then the fused update
+// Waves take items round-robin, hot chunks (streaming, bandwidth-bound) first, cold batches (dependent
+// hops, latency-bound) after them: the two kinds overlap on every CU.
 constexpr int TBS = 256;
-// a key with more than long_thresh rows inside one chunk is summed by the whole block (its rows split
-// evenly over the groups); shorter ones by one LPR-lane group each
-__host__ __device__ inline int long_thresh(int D) { return D <= 128 ? 16 : D / 8; }
-__host__ __device__ inline int long_rows(int D) { return CH / (long_thresh(D) + 1) + 1; }
-__host__ __device__ inline size_t apply_smem_bytes(int D, int lpr) {
-  size_t b = (size_t)(CH + 1) * 4 + 16;            // sord
-  b += (size_t)(CH + 2) * 2 + 16;                  // sseg
-  b += (size_t)(CH + 2) + 16;                      // slong
-  b += (size_t)(CH + 1) * 16 + 16;                 // shead
-  b += (size_t)long_rows(D) * 2 + 16;              // llist
-  b += (size_t)long_rows(D) * D * 4 + 16;          // lsum
-  b += (size_t)(TBS / lpr) * D * 4 + 16;           // lpart
-  return b;
-}
 
 // combine two partial results of a key under the fold operation (sum for the optimizers)
 __device__ __forceinline__ float fold2(int op, float acc, float v) {
@@ -883,6 +929,7 @@ __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key,
 
 // finish one key whose combined gradient is in gv: optimizer update (MODE_APPLY) or emit (MODE_DEDUP).
 // All LPR lanes of every group of the wave call it (shuffles inside); `live` masks groups without a key.
+// hd = {key lo, key hi, row word, slot-row hint}
 template <int MODE, int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bool live, bool hint_loaded,
                                            const RowMeta& m0, float (&gv)[K][V], int lane) {
@@ -906,64 +953,31 @@ __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bo
   }
 }
 
+// the op's counters as the partition pass left them
+struct ApplyCounts { unsigned ncold, nhot, nchunks; };
+__device__ __forceinline__ ApplyCounts apply_counts(const WsDev& w) {
+  const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(&w.ctr[2]);
+  return ApplyCounts{(unsigned)(pk & 0x3FFFFFu), (unsigned)((pk >> 22) & 0x1FFFFFu), (unsigned)(pk >> 43)};
+}
+
 template <int MODE, int OPT, int V, int LPR, int K>
-__device__ __forceinline__ void apply_sorted_body(const WsDev& w, const PartArgs& a) {
-  if (*reinterpret_cast<volatile unsigned*>(&a.tv.counters[1])) return;   // the index pass gave up on this batch
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
+  static_assert(LPR <= 64, "a row is handled by the lanes of one wave");
+  const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
+  const ApplyCounts ac = apply_counts(w);
+  if (errflag) return;   // the index pass gave up on this batch
   const int D = a.tv.dim;
-  const int NL = long_rows(D);
-  const unsigned LT = (unsigned)long_thresh(D);
-  char* smp = smem_raw;
-  auto take = [&](size_t bytes) { char* q = smp; smp += (bytes + 15) & ~(size_t)15; return q; };
-  unsigned* sord = reinterpret_cast<unsigned*>(take((size_t)(CH + 1) * 4));
-  unsigned short* sseg = reinterpret_cast<unsigned short*>(take((size_t)(CH + 2) * 2));
-  unsigned char* slong = reinterpret_cast<unsigned char*>(take((size_t)(CH + 2)));
-  uint4* shead = reinterpret_cast<uint4*>(take((size_t)(CH + 1) * 16));
-  unsigned short* llist = reinterpret_cast<unsigned short*>(take((size_t)NL * 2));
-  float* lsum = reinterpret_cast<float*>(take((size_t)NL * D * 4));
-  constexpr unsigned GPB = TBS / LPR;
-  float* lpart = reinterpret_cast<float*>(take((size_t)GPB * D * 4));
-  __shared__ unsigned wtot[8];
-  __shared__ unsigned lnl;
-
-  const int tid = threadIdx.x;
-  const int lane = tid % LPR;
-  const unsigned grp = tid / LPR;
-  const long long n = a.n;
-  const unsigned c = blockIdx.x;
-  const long long j0 = (long long)c * CH;
-  if (j0 >= n) return;
-  const unsigned len = (unsigned)min((long long)CH, n - j0);
+  constexpr int G = 64 / LPR;                    // lane groups (keys / rows in flight side by side) per wave
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;  // rows in flight per group, hot chunks
+  constexpr int RC = (4 / K) > 0 ? (4 / K) : 1;  // rows in flight per group, cold keys (most have one or two)
+  const int wl = threadIdx.x & 63;
+  const int lane = wl % LPR;
+  const int g = wl / LPR;
   const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
-  KV_STAMPP(0);
-
-  // ---- the chunk's positions and key boundaries ---------------------------------------------------
-  const unsigned o = (unsigned)tid < len ? w.order[j0 + tid] : 0u;
-  const bool hf = (unsigned)tid < len && (o & HEAD_BIT);
-  uint4 hd = make_uint4(0u, 0u, 0u, 0u);
-  if (hf) hd = w.ohead[j0 + tid];
-  if ((unsigned)tid < len) sord[tid] = o;
-  if (tid == 0) { sord[len] = w.order[j0 + len]; lnl = 0; }   // order[n] = HEAD_BIT
-  unsigned nseg;
-  const unsigned sid = block_excl_scan<TBS / 64>(hf ? 1u : 0u, wtot, &nseg) + 1u;   // segments 1..nseg start at a head
-  if (hf) { sseg[sid] = (unsigned short)tid; shead[sid] = hd; }
-  if (tid == 0) { sseg[0] = 0; sseg[nseg + 1] = (unsigned short)len; }
-  __syncthreads();
-  // segment 0 = the positions before the first head: the tail of a key that started in an earlier chunk
-  const bool tail_open = !(sord[len] & HEAD_BIT);   // the last key continues in the next chunk
-  auto seg_lo = [&](unsigned s) -> unsigned { return s == 0u ? 0u : sseg[s]; };
-  auto seg_hi = [&](unsigned s) -> unsigned { return sseg[s + 1]; };
-
-  // ---- long segments: rows split evenly over the groups, partial results meet in LDS in group order ---
-  for (unsigned s = tid; s <= nseg; s += TBS) {
-    const unsigned l = seg_hi(s) - seg_lo(s);
-    unsigned char k = 0;
-    if (l > LT) { const unsigned q = atomicAdd(&lnl, 1u); llist[q] = (unsigned short)s; k = (unsigned char)(q + 1u); }
-    slong[s] = k;
-  }
-  __syncthreads();
-  const unsigned nl = lnl;
-  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
+  const unsigned ncb = (ac.ncold + G - 1) / G;
+  const unsigned total = ac.nchunks + ncb;
+  const unsigned W = gridDim.x * (TBS / 64);
   auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
     const float* src = a.grad + (size_t)pos * D;
 #pragma unroll
@@ -972,203 +986,180 @@ __device__ __forceinline__ void apply_sorted_body(const WsDev& w, const PartArgs
       if (e0 < D) ldv_stream<V>(src + e0, dst[k]);
     }
   };
-  // fold of sorted positions [lo, hi) into gv, RB rows in flight
-  auto fold_range = [&](unsigned lo, unsigned hi, float (&gv)[K][V]) {
-    for (unsigned jb = lo; jb < hi; jb += RB) {
-      float val[RB][K][V];
+  auto acc_row = [&](float (&gv)[K][V], const float (&v)[K][V]) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + v[k][cc] : fold2(fop, gv[k][cc], v[k][cc]);
+  };
+  for (unsigned it = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6); it < total; it += W) {
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+    if (it < ac.nchunks) {
+      // ---- hot chunk: rows [lo, hi) of one key, G * RB of them in flight per step --------------------
+      const uint2 hc = w.hotchunk[it];
+      const uint4 ra = w.hotlist[2 * (size_t)hc.x], rb = w.hotlist[2 * (size_t)hc.x + 1];
+      const unsigned lo = rb.x + hc.y * rb.w, hi = min(rb.x + rb.y, lo + rb.w);
+      for (unsigned r0 = lo; r0 < hi; r0 += G * RB) {
+        float val[RB][K][V];
+        unsigned pos[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const unsigned idx = r0 + g * RB + j;
+          pos[j] = idx < hi ? (w.order[idx] & ~HEAD_BIT) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) val[j][k][cc] = ident;
+          if (pos[j] != 0xFFFFFFFFu) load_row(pos[j], val[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc_row(gv, val[j]);
+      }
+      // the groups' sums meet: a fixed shuffle tree, every lane ends with the chunk's sum
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int cc = 0; cc < V; ++cc) val[r][k][cc] = 0.f;
-        if (jb + r < hi) load_row(sord[jb + r] & ~HEAD_BIT, val[r]);
+          for (int cc = 0; cc < V; ++cc) {
+            const float x = __shfl_xor(gv[k][cc], o);
+            gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
+          }
+      }
+      const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
+      if (nch > 1u) {
+        if (g == 0) {
+          float* dst = w.hpart + (size_t)it * D;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int e0 = (lane + k * LPR) * V;
+            if (e0 < D) stv<V>(dst + e0, gv[k]);
+          }
+        }
+      } else {
+        RowMeta m0{};
+        finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+      }
+    } else {
+      // ---- cold batch: one key per lane group ------------------------------------------------------------
+      const unsigned u = (it - ac.nchunks) * G + g;
+      const bool live = u < ac.ncold;
+      uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = ra;
+      if (live) { ra = w.coldlist[2 * (size_t)u]; rb = w.coldlist[2 * (size_t)u + 1]; }
+      const unsigned start = rb.x, cnt = live ? rb.y : 0u;
+      // requested now, used after the fold: the record of the hinted slot row (leader) and the lines of the
+      // state rows, so that the update's own loads find them in cache
+      RowMeta m0{};
+      bool hint_loaded = false;
+      float touch = 0.f;
+      if (MODE == MODE_APPLY && live && (ra.z & ROW_MASK) != 0u) {
+        const bool hok = a.use_hints && ra.w != 0u && ra.w < a.ts0.max_rows;
+        if (lane == 0 && hok) {
+          const uint4 mm = *reinterpret_cast<const uint4*>(meta_ptr(a.ts0, ra.w));
+          m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
+          m0.freq = mm.z;
+          m0.flags = (unsigned char)(mm.w & 0xFFu);
+          hint_loaded = true;
+        }
+        const int e0 = lane * V;
+        if (e0 < D) {
+          touch = row_ptr(a.tv, ra.z & ROW_MASK)[e0];
+          if (hok) {
+            const float* sr = row_ptr(a.ts0, ra.w);
+            touch += sr[e0];
+            if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
+          }
+        }
+      }
+      for (unsigned j0 = 0; j0 < cnt; j0 += RC) {
+        float val[RC][K][V];
+        unsigned pos[RC];
+#pragma unroll
+        for (int j = 0; j < RC; ++j) pos[j] = j0 + j < cnt ? (w.order[start + j0 + j] & ~HEAD_BIT) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < RC; ++j) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) val[j][k][cc] = ident;
+          if (pos[j] != 0xFFFFFFFFu) load_row(pos[j], val[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RC; ++j) acc_row(gv, val[j]);
+      }
+      asm volatile("" ::"v"(touch));  // keep the touch loads
+      finish_key<MODE, OPT, V, LPR, K>(a, ra, live, hint_loaded, m0, gv, lane);
+    }
+  }
+}
+
+// hot keys with more than one chunk: the chunks' sums (hpart) are added up in chunk order — lane group g
+// takes chunks g, g + G, ..., the groups meet through the same shuffle tree — and the key is finished
+template <int MODE, int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a) {
+  const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
+  const ApplyCounts ac = apply_counts(w);
+  if (errflag) return;
+  const int D = a.tv.dim;
+  constexpr int G = 64 / LPR;
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  const int wl = threadIdx.x & 63;
+  const int lane = wl % LPR;
+  const int g = wl / LPR;
+  const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
+  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
+  const unsigned W = gridDim.x * (TBS / 64);
+  for (unsigned h = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6); h < ac.nhot; h += W) {
+    const uint4 rb = w.hotlist[2 * (size_t)h + 1];
+    const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
+    if (nch < 2u) continue;   // wave-uniform
+    const uint4 ra = w.hotlist[2 * (size_t)h];
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+    for (unsigned c0 = 0; c0 < nch; c0 += G * RB) {
+      float val[RB][K][V];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const unsigned ci = c0 + j * G + g;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) val[j][k][cc] = ident;
+          const int e0 = (lane + k * LPR) * V;
+          if (ci < nch && e0 < D) ldv<V>(w.hpart + (size_t)(rb.z + ci) * D + e0, val[j][k]);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        if (jb + r >= hi) continue;
+      for (int j = 0; j < RB; ++j)
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
           for (int cc = 0; cc < V; ++cc)
-            gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + val[r][k][cc] : fold2(fop, gv[k][cc], val[r][k][cc]);
-      }
+            gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + val[j][k][cc] : fold2(fop, gv[k][cc], val[j][k][cc]);
     }
-  };
-  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
-  for (unsigned q = 0; q < nl; ++q) {   // block-uniform
-    const unsigned s = llist[q];
-    const unsigned lo = seg_lo(s), hi = seg_hi(s);
-    const unsigned C = (hi - lo + GPB - 1) / GPB;
-    const unsigned c0 = min(hi, lo + grp * C), c1 = min(hi, c0 + C);
-    float gv[K][V];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
-      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
-    fold_range(c0, c1, gv);
+      for (int k = 0; k < K; ++k)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int e0 = (lane + k * LPR) * V;
-      if (e0 < D) stv<V>(lpart + (size_t)grp * D + e0, gv[k]);
+        for (int cc = 0; cc < V; ++cc) {
+          const float x = __shfl_xor(gv[k][cc], o);
+          gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
+        }
     }
-    __syncthreads();
-    const unsigned ng = (hi - lo + C - 1) / C;   // groups that had rows
-    for (int e = tid; e < D; e += TBS) {
-      float acc = lpart[e];
-      for (unsigned g = 1; g < ng; ++g) acc = (MODE == MODE_APPLY) ? acc + lpart[(size_t)g * D + e] : fold2(fop, acc, lpart[(size_t)g * D + e]);
-      lsum[(size_t)q * D + e] = acc;
-    }
-    __syncthreads();
-  }
-  KV_STAMPP(1);
-
-  // ---- one group per segment: the (rest of the) fold, then the fused update or the partial store ------
-  const unsigned nsp = (nseg + 1 + GPB - 1) / GPB * GPB;
-  for (unsigned s = grp; s < nsp; s += GPB) {
-    const bool live = s <= nseg && seg_hi(min(s, nseg)) > seg_lo(min(s, nseg));
-    const unsigned ss = live ? s : 0u;
-    const unsigned lo = seg_lo(ss), hi = live ? seg_hi(ss) : lo;
-    const bool is_lead = ss == 0u;
-    const bool is_tail = !is_lead && ss == nseg && tail_open;
-    const uint4 hdr = (live && !is_lead) ? shead[ss] : make_uint4(0u, 0u, 0u, 0u);
-    // requested now, used after the fold: the record of the hinted slot row (leader) and the lines of the
-    // state rows, so the update's own loads find them in cache
     RowMeta m0{};
-    bool hint_loaded = false;
-    float touch = 0.f;
-    if (MODE == MODE_APPLY && live && !is_lead && !is_tail && (hdr.z & ROW_MASK) != 0u) {
-      const bool hok = a.use_hints && hdr.w != 0u && hdr.w < a.ts0.max_rows;
-      if (lane == 0 && hok) {
-        const uint4 mm = *reinterpret_cast<const uint4*>(meta_ptr(a.ts0, hdr.w));
-        m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
-        m0.freq = mm.z;
-        m0.flags = (unsigned char)(mm.w & 0xFFu);
-        hint_loaded = true;
-      }
-      const int e0 = lane * V;
-      if (e0 < D) {
-        touch = row_ptr(a.tv, hdr.z & ROW_MASK)[e0];
-        if (hok) {
-          const float* sr = row_ptr(a.ts0, hdr.w);
-          touch += sr[e0];
-          if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
-        }
-      }
-    }
-    float gv[K][V];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
-    if (live) {
-      if (slong[ss]) {
-        const float* src = lsum + (size_t)(slong[ss] - 1u) * D;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) ldv<V>(src + e0, gv[k]);
-        }
-      } else {
-        fold_range(lo, hi, gv);
-      }
-    }
-    asm volatile("" ::"v"(touch));  // keep the touch loads
-    if (live && (is_lead || is_tail)) {
-      float* dst = w.cpart + ((size_t)c * 2 + (is_tail ? 1 : 0)) * D;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int e0 = (lane + k * LPR) * V;
-        if (e0 < D) stv<V>(dst + e0, gv[k]);
-      }
-      if (is_tail && lane == 0) w.ctail[c] = hdr;
-    }
-    finish_key<MODE, OPT, V, LPR, K>(a, hdr, live && !is_lead && !is_tail, hint_loaded, m0, gv, lane);
+    finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
   }
-  if (tid == 0)
-    w.cmeta[c] = (nseg > 0u ? CM_HAS_HEAD : 0u) | (seg_hi(0) > 0u ? CM_LEAD : 0u) | ((nseg > 0u && tail_open) ? CM_TAIL_OPEN : 0u);
-  KV_STAMPP(2);
-}
-
-// A key that crosses chunk boundaries: chunk c holds its head and the sum of its rows up to the chunk's
-// end (cpart[c][1]); the chunks after it hold leading partial sums (cpart[.][0]) up to and including the
-// first chunk that has a head.  One block per open tail adds them up in chunk order and finishes the key.
-template <int MODE, int OPT, int V, int LPR, int K>
-__device__ __forceinline__ void apply_span_body(const WsDev& w, const PartArgs& a) {
-  if (*reinterpret_cast<volatile unsigned*>(&a.tv.counters[1])) return;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int D = a.tv.dim;
-  constexpr unsigned GPB = TBS / LPR;
-  float* lpart = reinterpret_cast<float*>(smem_raw);           // [GPB][D]
-  float* ltot = lpart + (size_t)GPB * D;                       // [D]
-  __shared__ unsigned lend;
-  const int tid = threadIdx.x;
-  const int lane = tid % LPR;
-  const unsigned grp = tid / LPR;
-  const unsigned nchunks = (unsigned)((a.n + CH - 1) / CH);
-  const unsigned c = blockIdx.x;
-  if (c >= nchunks || !(w.cmeta[c] & CM_TAIL_OPEN)) return;
-  const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
-  const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
-  if (tid == 0) lend = nchunks;
-  __syncthreads();
-  for (unsigned b = c + 1; b < nchunks; b += TBS) {   // block-uniform
-    const unsigned x = b + tid;
-    if (x < nchunks && (w.cmeta[x] & CM_HAS_HEAD)) atomicMin(&lend, x);
-    __syncthreads();
-    if (lend != nchunks) break;
-  }
-  const unsigned last = min(lend, nchunks - 1u);   // chunks c + 1 .. last carry this key's rows in front
-  const unsigned m = last - c;
-  const unsigned C = (m + GPB - 1) / GPB;          // consecutive chunks per group: the sum keeps chunk order
-  float gv[K][V];
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
-  for (unsigned q = grp * C; q < min(m, (grp + 1) * C); ++q) {
-    const unsigned x = c + 1u + q;
-    if (!(w.cmeta[x] & CM_LEAD)) continue;
-    const float* src = w.cpart + (size_t)x * 2 * D;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int e0 = (lane + k * LPR) * V;
-      if (e0 < D) {
-        float v[V];
-        ldv<V>(src + e0, v);
-#pragma unroll
-        for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + v[cc] : fold2(fop, gv[k][cc], v[cc]);
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int e0 = (lane + k * LPR) * V;
-    if (e0 < D) stv<V>(lpart + (size_t)grp * D + e0, gv[k]);
-  }
-  __syncthreads();
-  for (int e = tid; e < D; e += TBS) {
-    float acc = w.cpart[((size_t)c * 2 + 1) * D + e];
-    for (unsigned g = 0; g < GPB && g * C < m; ++g)
-      acc = (MODE == MODE_APPLY) ? acc + lpart[(size_t)g * D + e] : fold2(fop, acc, lpart[(size_t)g * D + e]);
-    ltot[e] = acc;
-  }
-  __syncthreads();
-  if (tid >= 64) return;   // the first wave finishes the key (no block barrier below)
-  const bool live = grp == 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int e0 = (lane + k * LPR) * V;
-    if (e0 < D) ldv<V>(ltot + e0, gv[k]);
-  }
-  const uint4 hdr = w.ctail[c];
-  RowMeta m0{};
-  bool hint_loaded = false;
-  if (MODE == MODE_APPLY && live && lane == 0 && a.use_hints && hdr.w != 0u && hdr.w < a.ts0.max_rows) {
-    m0 = *meta_ptr(a.ts0, hdr.w);
-    hint_loaded = true;
-  }
-  finish_key<MODE, OPT, V, LPR, K>(a, hdr, live, hint_loaded, m0, gv, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1355,13 +1346,13 @@ __global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_k
 // the training lookup's partition pass with the probing gather beside it: blocks [0, P) own the partitions
 // (latency-bound: dependent probes), the blocks after them copy the output rows (bandwidth-bound)
 __global__ void __launch_bounds__(TBK) k_part_keys_gather(WsDev w, PartArgs a, GatherRole g) {
-  if (blockIdx.x < w.P) part_keys_body<MODE_LOOKUP>(w, a);
+  if (blockIdx.x < w.P) part_keys_body<MODE_LOOKUP, 512>(w, a);
   else goz_any(a.tv, g.ids, g.ids_kind, g.out, g.n, blockIdx.x - w.P, gridDim.x - w.P);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_sorted(WsDev w, PartArgs a) { apply_sorted_body<MODE, OPT, V, LPR, K>(w, a); }
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply(WsDev w, PartArgs a) { apply_body<MODE, OPT, V, LPR, K>(w, a); }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_span(WsDev w, PartArgs a) { apply_span_body<MODE, OPT, V, LPR, K>(w, a); }
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_fin(WsDev w, PartArgs a) { apply_fin_body<MODE, OPT, V, LPR, K>(w, a); }
 template <int VQ>
 __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
   gather_body<VQ>(t, w, out, n);
@@ -1385,16 +1376,16 @@ __global__ void __launch_bounds__(TB) k_order_multi(const MultiDesc* __restrict_
   order_body<false>(m.a.tv, m.w, m.n, nullptr);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_sorted_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
-  if ((long long)blockIdx.x * CH >= m.n) return;
-  apply_sorted_body<MODE, OPT, V, LPR, K>(m.w, m.a);
+  if (m.n == 0) return;
+  apply_body<MODE, OPT, V, LPR, K>(m.w, m.a);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_span_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_fin_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
-  if ((long long)blockIdx.x * CH >= m.n) return;
-  apply_span_body<MODE, OPT, V, LPR, K>(m.w, m.a);
+  if (m.n == 0) return;
+  apply_fin_body<MODE, OPT, V, LPR, K>(m.w, m.a);
 }
 template <int VQ>
 __global__ void __launch_bounds__(TB) k_gather_multi(const MultiDesc* __restrict__ descs) {

@@ -10,7 +10,7 @@
 //            under_threshold, bit2 under_threshold stale, bit3 released by Delete)}.  Row ids are
 //            dense (bump allocated; rows released by Delete are recycled from a device free
 //            list), row 0 is a permanent all-zero row (misses / nothing).
-//   workspace per-batch index (ent_key / ent_a / ent_b / ent_base, toff, slot_rank, order, ohead, chunk
+//   workspace per-batch index (ent_key / ent_a / ent_b / ent_base, toff, slot_rank, order, key lists, chunk
 //            partials): plain stores only, rewritten by every op — nothing to clean.
 //
 // Kernel pipeline (kv_kernels.h explains why; DESIGN.md has the byte accounting):
@@ -311,11 +311,11 @@ struct Workspace {
   unsigned* toff = nullptr;
   unsigned* slot_rank = nullptr;
   unsigned* order = nullptr;
-  uint4* ohead = nullptr;
-  uint4* ctail = nullptr;
-  unsigned* cmeta = nullptr;
-  float* cpart = nullptr;    // [cap_n / CH][2][dim]
-  long long cpart_elems = 0;
+  uint4* coldlist = nullptr;   // [cap_n][2]
+  uint4* hotlist = nullptr;    // [hot_cap(cap_n)][2]
+  uint2* hotchunk = nullptr;   // [chunk_cap(cap_n)]
+  float* hpart = nullptr;      // [chunk_cap(cap_n)][dim]
+  long long hpart_elems = 0;
   unsigned* ctr = nullptr;
   long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
   float* scat_sum = nullptr;
@@ -537,6 +537,10 @@ unsigned pick_partitions(long long n) {
   return P;
 }
 
+// upper bounds of a batch of n ids: hot keys (more than LCOLD occurrences each) and their chunks
+size_t hot_cap(long long n) { return (size_t)(n / (LCOLD + 1) + 2); }
+size_t chunk_cap(long long n) { return (size_t)(n / HC + n / (LCOLD + 1) + 4); }
+
 // (re)allocation that leaves the old buffer in place when the new one cannot be had
 template <typename T>
 int regrow(T** p, size_t count) {
@@ -557,29 +561,30 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     if (w.cap_n) cap = std::max<long long>(cap, std::min<long long>(w.cap_n * 2, 1ll << 30));
     cap = (cap + TILE - 1) / TILE * TILE;
     const unsigned capP = std::max(pick_partitions(cap), P);
-    const size_t nt = (size_t)(cap / TILE), nc = (size_t)(cap / CH);
+    const size_t nt = (size_t)(cap / TILE);
     // every buffer is replaced only once its successor exists; a failure leaves the old sizes in force
-    w.cap_n = 0; w.capP = 0; w.cpart_elems = 0;
+    w.cap_n = 0; w.capP = 0; w.hpart_elems = 0;
     t->batch_serial = 0;
     if ((rc = regrow(&w.ent_key, (size_t)cap)) || (rc = regrow(&w.ent_a, (size_t)cap)) ||
         (rc = regrow(&w.ent_b, (size_t)cap)) || (rc = regrow(&w.ent_base, (size_t)cap)) ||
         (rc = regrow(&w.toff, nt * (capP + 1))) || (rc = regrow(&w.slot_rank, (size_t)cap)) ||
-        (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.ohead, (size_t)cap)) ||
-        (rc = regrow(&w.ctail, nc)) || (rc = regrow(&w.cmeta, nc)))
+        (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.coldlist, 2 * (size_t)cap)) ||
+        (rc = regrow(&w.hotlist, 2 * hot_cap(cap))) || (rc = regrow(&w.hotchunk, chunk_cap(cap))))
       return rc;
     if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
 #ifdef KV_STAMPS
-    if ((rc = regrow(&w.dbg, (size_t)8192 * 16))) return rc;
+    if ((rc = regrow(&w.dbg, (size_t)16384 * 16))) return rc;
+    hipMemset(w.dbg, 0, (size_t)16384 * 16 * 8);
 #endif
     w.cap_n = cap;
     w.capP = capP;
   }
-  const long long pe = (w.cap_n / CH) * 2 * (long long)t->dim;
-  if (need_part && w.cpart_elems < pe) {
+  const long long pe = (long long)chunk_cap(w.cap_n) * (long long)t->dim;
+  if (need_part && w.hpart_elems < pe) {
     HIP_TRY(hipStreamSynchronize(s));
-    w.cpart_elems = 0;
-    if ((rc = regrow(&w.cpart, (size_t)pe))) return rc;
-    w.cpart_elems = pe;
+    w.hpart_elems = 0;
+    if ((rc = regrow(&w.hpart, (size_t)pe))) return rc;
+    w.hpart_elems = pe;
   }
   return KV_OK;
 }
@@ -591,10 +596,10 @@ WsDev ws_view(kv_table* t, long long n) {
   d.toff = w.toff;
   d.slot_rank = w.slot_rank;
   d.order = w.order;
-  d.ohead = w.ohead;
-  d.cpart = w.cpart;
-  d.ctail = w.ctail;
-  d.cmeta = w.cmeta;
+  d.coldlist = w.coldlist;
+  d.hotlist = w.hotlist;
+  d.hotchunk = w.hotchunk;
+  d.hpart = w.hpart;
   d.ctr = w.ctr;
   d.ntiles = (unsigned)((n + TILE - 1) / TILE);
   d.P = pick_partitions(n);
@@ -716,16 +721,20 @@ template <int MODE, int OPT>
 int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long long nmax, hipStream_t s,
                  const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = pa.tv.dim;
-  const unsigned nchunks = (unsigned)((nmax + CH - 1) / CH);
+  // waves stride over the items (hot chunks, then cold batches of 64 / LPR keys); 8 blocks of 4 waves per CU
+  // is everything the chip holds at once, fewer for small batches
+  static const int gmax = [] { const char* e = getenv("KV_APPLY_BLOCKS"); return e ? atoi(e) : 2048; }();
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(gmax, (nmax / 2 + chunk_cap(nmax)) / 4 + 1));
+  const unsigned gfin = (unsigned)std::max<long long>(1, std::min<long long>(256, (long long)hot_cap(nmax) / 4 + 1));
   auto fn = (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3)) ? kvp_launch_apply_a : kvp_launch_apply_b;
   int rc;
   {
     ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
-    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, nchunks, 0);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, 0);
   }
   if (rc == KV_OK) {
     ProfScope ps(prof_t, KV_PROF_APPLY_SPAN, s);
-    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, nchunks, 1);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, gfin, 1);
   }
   if (rc == KV_UNIMPLEMENTED)
     return md ? fail(KV_UNIMPLEMENTED, "batched launch: embedding dim %d (multiples of 4 only)", D)
@@ -955,7 +964,7 @@ int kv_destroy(kv_handle_t t) {
   for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.toff); hipFree(w.slot_rank);
-  hipFree(w.order); hipFree(w.ohead); hipFree(w.ctail); hipFree(w.cmeta); hipFree(w.cpart);
+  hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.hotchunk); hipFree(w.hpart);
   hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   if (t->err_host) hipHostFree(t->err_host);
   if (t->last_done) hipEventDestroy(t->last_done);
@@ -1729,7 +1738,6 @@ static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
   const WsDev wd = ws_view(t, n);
   t->batch_serial = 0;
-  HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.grad = grad;
@@ -1816,8 +1824,7 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
   const WsDev wd = ws_view(t, n);
   t->batch_serial = 0;
-  HIP_TRY(hipMemsetAsync(wd.ctr, 0, 8 * sizeof(unsigned), s));
-  launch_tile<false>(t, wd, ids, counts, n, s);   // ent_a = occurrences | saturating count per tile
+  launch_tile<false>(t, wd, ids, counts, n, s);   // ent_a = occurrences | saturating count per tile (and zeroes wd.ctr)
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = (long long*)uniq;
@@ -2064,7 +2071,7 @@ int kv_profile_read(kv_handle_t t, double* ms_sum, int64_t* launches, int n_kind
 int kv_debug_read_stamps(kv_handle_t t, unsigned long long* out, int64_t nblocks_) {
   DeviceGuard dg(t->device);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, t->ws.dbg, (size_t)nblocks_ * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, t->ws.dbg, (size_t)std::min<int64_t>(nblocks_, 16384) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return KV_OK;
 }
 #endif
