@@ -13,20 +13,31 @@ template <int MODE, int OPT>
 int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md, int ntab,
                    unsigned nchunks, int span) {
   const int D = pa.tv.dim;
-  const int grid = (int)nchunks;
+  int grid_ = (int)nchunks;
 #define KV_APPLY(V, LPR, K)                                                                        \
   do {                                                                                             \
-    const size_t sh = 0;                                                                           \
+    const size_t sh = span ? (size_t)(TBF / 64) * D * 4 + 16 : 0;                                   \
+    if (!span) {  /* one resident generation of blocks: a second one would start when the first ends */  \
+      static const int resident = [] {                                                             \
+        int nb = 0, cus = 0, dev = 0;                                                              \
+        hipGetDevice(&dev);                                                                        \
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                   \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply<MODE, OPT, V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
+        if (nb > 6) nb = 6;   /* > 96 SGPRs: the hardware admits 6 blocks of 256 threads per CU */   \
+        return nb * (cus > 0 ? cus : 256);                                                         \
+      }();                                                                                         \
+      if ((int)nchunks > resident) grid_ = resident; else grid_ = (int)nchunks;                     \
+    }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
       if (md) {                                                                                    \
-        if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);   \
-        else k_apply_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), TBS, sh, s>>>(md);      \
+        if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBF, sh, s>>>(md);   \
+        else k_apply_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBS, sh, s>>>(md);      \
         return KV_OK;                                                                              \
       }                                                                                            \
     }                                                                                              \
     if (md) return KV_UNIMPLEMENTED;                                                               \
-    if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                     \
-    else k_apply<MODE, OPT, V, LPR, K><<<grid, TBS, sh, s>>>(wd, pa);                        \
+    if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid_, TBF, sh, s>>>(wd, pa);                     \
+    else k_apply<MODE, OPT, V, LPR, K><<<grid_, TBS, sh, s>>>(wd, pa);                        \
     return KV_OK;                                                                                  \
   } while (0)
   if ((D & 3) == 0) {

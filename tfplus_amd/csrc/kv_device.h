@@ -15,13 +15,12 @@ constexpr unsigned ROW_TOMB = 0xFFFFFFFFu;  // index entry of a deleted key (kep
 constexpr unsigned ROW_FILTERED = 0x80000000u;  // tag bit: var frequency < enter_threshold
 constexpr unsigned ROW_MASK = 0x7FFFFFFFu;
 constexpr unsigned HEAD_BIT = 0x80000000u;      // sorted position list / ent_base: first position of its key
-constexpr unsigned NEW_BIT = 0x40000000u;       // ent_base: the key's row was inserted by this batch (lookup fix-up)
 constexpr unsigned BASE_MASK = 0x3FFFFFFFu;
 constexpr int RANK_SHIFT = 21;                  // slot_rank: entry index (21 bits, n <= 2^21) | in-tile occurrence rank << 21
 constexpr unsigned SLOT_MASK = (1u << RANK_SHIFT) - 1u;
 constexpr int LCOLD = 16;   // a key with at most this many occurrences in the batch is "cold": one lane group sums its
                             // rows and updates it; a "hot" key's rows are summed in chunks by whole waves
-constexpr int HC = 256;     // rows per hot chunk (more for keys with > 65536 rows, so that a key has at most 256 chunks)
+constexpr int HC = 128;     // rows per hot chunk
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
 constexpr int TBT = 512;  // threads per block of the tile kernel
@@ -88,19 +87,26 @@ struct WsDev {
                            // count of the tile (high 16); scatter / mark: one input position of the key
   unsigned* ent_b;         // OUT of the partition pass: var row id of the key (unique: dense index)
   unsigned* ent_base;      // OUT of the partition pass: where the entry's positions start in the sorted position
-                           // list | HEAD_BIT (first entry of its key) | NEW_BIT (row inserted by this batch)
+                           // list | HEAD_BIT (first entry of its key)
+  unsigned* ent_rec;       // OUT of the partition pass, first entry of a key only: the key's record (list index,
+                           // bit 31: hot list) — k_order files the key's first input position there
   unsigned* toff;          // [ntiles][P + 1] partition boundaries inside each tile: entry prefix (low 16) |
                            // position prefix (high 16)
   unsigned* slot_rank;     // [n] entry index of every input position | its rank among the key's occurrences
                            // in the tile << RANK_SHIFT
   unsigned* order;         // [n + 1] input positions sorted by key (a key's occurrences are contiguous), first
                            // one tagged HEAD_BIT; order[n] = HEAD_BIT
-  uint4* coldlist;         // [n][2] KeyRec of the cold keys: {key lo, key hi, row, slot-row hint} {start, count, -, -}
-  uint4* hotlist;          // [n / (LCOLD + 1) + 1][2] the hot keys: ... {start, count, first chunk, rows per chunk}
-  uint2* hotchunk;         // [hot chunks] {hot key index, chunk index inside the key}
+  uint4* coldlist;         // [n][2] KeyRec of the cold keys: {key lo, key hi, row, slot-row hint} {start, count, first position, -}
+  uint4* hotlist;          // [n][2] the hot keys: ... {start, count, first chunk (in the partition), rows per chunk}
+                           // (both indexed by the partition's first sorted position + the key's number in it)
+  uint4* litem;            // [n] the partitions' work items, partition p's at [its first sorted position ...)
+  uint4* pmeta;            // [P] per partition: {items, hot chunks, first sorted position, cold keys}
+  uint4* items;            // [n] the dense work item directory (k_gather<ORDER> / k_order build it): hot chunk
+                           // {hot list index | HEAD_BIT, chunk in the key, chunk number in the batch, -}, cold
+                           // batch {first cold list index, keys, -, -}
   float* hpart;            // [hot chunks][dim] partial sums of the keys that have more than one chunk
   unsigned* ctr;           // [8] op counters, zeroed by the tile pass: [0] unique count (kv_unique / kv_dedup_segment_sum),
-                           // [2..3] one 64-bit word: cold keys (22 bits) | hot keys (21) | hot chunks (21)
+                           // [2] work items, [3] hot chunks
   unsigned ntiles, P;
   int pshift;              // 64 - log2(P)
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
@@ -436,12 +442,20 @@ __device__ __forceinline__ bool group_any(bool p) {
 // rows the group leader probed (probe_for_apply).
 // Restates the per-id body of KvVariableGroupSparseApplyAdamV4Op / V3Op / SparseApplyAdagradOp /
 // SparseGroupSparseApplyFtrlOp (training_ops.cc:7142-7197, 5871-5927, 1455-1486, 684-763).
+// State rows the caller already holds (requested together with the gradient rows, so the update needs no
+// second round trip): x = the var row; s[0..2] = the first slot table's row in blocks of dim floats
+// (GroupAdam m | v | z; Adagrad / FTRL accum in s[0]).  have_x / have_s say which of them are valid.
+template <int V, int K>
+struct PreRows {
+  float x[K][V], s[3][K][V];
+};
 template <int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDev& ts0,
                                                const TableDev& ts1, long long key, unsigned tag,
                                                unsigned r0, bool new0, unsigned r1, bool new1,
                                                bool live, const float (&gv)[K][V], const OptArgs& a,
-                                               int lane) {
+                                               int lane, const PreRows<V, K>* pre = nullptr, bool have_x = false,
+                                               bool have_s = false) {
   const int D = tv.dim;
   const bool skip = !live || (tag & ROW_FILTERED) || (tag & ROW_MASK) == 0u;  // training_ops.cc:7150-7152
   const unsigned rv = tag & ROW_MASK;
@@ -476,10 +490,20 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
       for (int c = 0; c < V; ++c) xo[c] = mo[c] = vo[c] = zo[c] = 0.f;
       const bool valid = act && e0 < D;
       if (valid) {
-        ldv<V>(xrow + e0, xo);
-        ldslot<V>(s0row, ia0, ib0, new0, e0, mo);
-        ldslot<V>(s0row, ia0, ib0, new0, e0 + D, vo);
-        ldslot<V>(s0row, ia0, ib0, new0, e0 + 2 * D, zo);
+        if (pre && have_x) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) xo[c] = pre->x[k][c];
+        } else {
+          ldv<V>(xrow + e0, xo);
+        }
+        if (pre && have_s && !new0) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) { mo[c] = pre->s[0][k][c]; vo[c] = pre->s[1][k][c]; zo[c] = pre->s[2][k][c]; }
+        } else {
+          ldslot<V>(s0row, ia0, ib0, new0, e0, mo);
+          ldslot<V>(s0row, ia0, ib0, new0, e0 + D, vo);
+          ldslot<V>(s0row, ia0, ib0, new0, e0 + 2 * D, zo);
+        }
       }
 #pragma unroll
       for (int c = 0; c < V; ++c) {
@@ -542,8 +566,18 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
       const int e0 = (lane + k * LPR) * V;
       if (act && e0 < D) {
         float xo[V], acc[V];
-        ldv<V>(xrow + e0, xo);
-        ldslot<V>(s0row, ia0, ib0, new0, e0, acc);
+        if (pre && have_x) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) xo[c] = pre->x[k][c];
+        } else {
+          ldv<V>(xrow + e0, xo);
+        }
+        if (pre && have_s && !new0) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) acc[c] = pre->s[0][k][c];
+        } else {
+          ldslot<V>(s0row, ia0, ib0, new0, e0, acc);
+        }
 #pragma unroll
         for (int c = 0; c < V; ++c) {
           const float gg = gv[k][c];
@@ -577,8 +611,18 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
       for (int c = 0; c < V; ++c) x[k][c] = ac[k][c] = zo[c] = 0.f;
       const bool valid = act && e0 < D;
       if (valid) {
-        ldv<V>(xrow + e0, x[k]);
-        ldslot<V>(s0row, ia0, ib0, new0, e0, ac[k]);
+        if (pre && have_x) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) x[k][c] = pre->x[k][c];
+        } else {
+          ldv<V>(xrow + e0, x[k]);
+        }
+        if (pre && have_s && !new0) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) ac[k][c] = pre->s[0][k][c];
+        } else {
+          ldslot<V>(s0row, ia0, ib0, new0, e0, ac[k]);
+        }
         ldslot<V>(s1row, ia1, ib1, new1, e0, zo);
       }
 #pragma unroll

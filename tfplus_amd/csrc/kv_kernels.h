@@ -18,11 +18,9 @@
 //                 position list: partition p starts at sum over tiles of toff[t][p].positions (no scan
 //                 kernel, no atomics), a key at the block-scan prefix of the occurrence counts, an entry at
 //                 its key's start plus the occurrences of the key's entries before it (ent_base); the key's
-//                 record {key, row, slot-row hint, start, count} goes to the cold or the hot key list.  The blocks past the partitions of
-//                 a training lookup copy the output rows meanwhile (probing gather, bandwidth-bound, next
-//                 to the latency-bound partition work).
-//   k_order       order[ent_base[entry] + rank] = position; positions whose key was inserted by this batch
-//                 get their output row re-copied (the probing gather ran beside the inserts).
+//                 record {key, row, slot-row hint, start, count} goes to the cold or the hot key list.
+//   k_gather<ORDER> / k_order   order[ent_base[entry] + rank] = position, and (training lookup) the output
+//                 rows: out[i] = rows[ent_b[entry]], one wave per 64 rows.
 //   k_apply       wave-granular segmented sum of the gradient rows (a key's occurrences are contiguous)
 //                 fused with the optimizer row update: hot keys in chunks of HC rows per wave, cold keys
 //                 one per lane group (see there);
@@ -302,14 +300,6 @@ struct PartArgs {
   long long n;                // ids in the batch
 };
 
-// probing gather of the training lookup, run by the blocks past the partitions of k_part_keys
-struct GatherRole {
-  const void* ids;
-  int ids_kind;               // 0 int64, 1 int32, 2 (id, count) int64 pairs
-  float* out;
-  long long n;
-};
-
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
 __device__ __forceinline__ bool in_round(long long key, unsigned R, unsigned round) {
   return R == 1 || ((mix64((unsigned long long)key) >> 20) & (R - 1)) == round;
@@ -393,14 +383,23 @@ __device__ __forceinline__ size_t seg_entry(const unsigned short* tpre, const un
   return (size_t)lo * TILE + tstart[lo] + (x - tpre[lo]);
 }
 
-// chunk geometry of a hot key: rows per chunk (HC, or more so that no key has over 256 chunks)
-__host__ __device__ inline unsigned chunk_rows(unsigned cnt) {
-  return cnt <= 65536u ? (unsigned)HC : ((cnt + 255u) / 256u + 63u) & ~63u;
+// lanes that share one row in the apply kernels, by dim (kv_apply_launch.h dispatches on the same table);
+// 64 / lanes keys ride side by side in a wave = the cold batch the partition pass forms
+__host__ __device__ inline int apply_lanes(int D) {
+  if ((D & 3) == 0) {
+    const int q = D / 4;
+    return q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 16 ? 8 : q <= 32 ? 16 : 64;
+  }
+  return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
 }
+
+// chunk geometry of a hot key: HC rows per chunk — about what a batch of cold keys costs, so every work item
+// of the apply weighs the same and a round-robin hand-out is balanced
+__host__ __device__ inline unsigned chunk_rows(unsigned cnt) { (void)cnt; return (unsigned)HC; }
 
 // HSK_: LDS hash slots (the lookup that runs beside the probing gather takes 512 to leave LDS for the
 // gather blocks; more unique keys than 3/4 of the slots split into sub-hash classes either way)
-template <int MODE, int HSK_ = 1024>
+template <int MODE, int HSK_ = 1024, int EB_ = 8>
 __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a) {
   constexpr int HSK = HSK_;
   // unique keys per class: the check `lnu >= UCAPK` in pass 1 races with up to TBK inserts, so the LDS hash
@@ -429,6 +428,12 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   KV_STAMPP(0);
   unsigned pbase;
   const unsigned E = seg_directory<TBK, TBK / 64>(w, p, tpre, tstart, wtot, &pbase);
+  // The partition's key records and work items live in ITS stretch of the arrays — index pbase + local number
+  // (a partition has at least as many positions as keys, chunks or items), so nothing is counted through global
+  // atomics; pmeta[p] tells the next kernel how many there are and where.
+  __shared__ unsigned lcold, lhot, lchunk, lnbig;
+  __shared__ unsigned lbig[16][3];   // keys of the class with more than 16 chunks: {hot list index, first chunk, chunks}
+  if (ORD && E == 0) { if (tid == 0) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
   if (E == 0) return;
   const bool wide = E > 65535u;  // needs a key set crafted against the partition hash; guarded, not handled
 
@@ -436,10 +441,10 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
   // class is processed exactly once (block-uniform control flow)
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
-  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; }
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; lcold = 0; lhot = 0; lchunk = 0; }
   __syncthreads();
   if (wide) {  // never silent: every later kernel of this op sees the flag and does nothing; the next call reports it
-    if (tid == 0) raise_error(a.tv, 2u);
+    if (tid == 0) { raise_error(a.tv, 2u); if (ORD) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
     return;
   }
   while (sp > 0) {
@@ -450,13 +455,13 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
       hkey[s] = EMPTY_KEY; hval[s] = 0;
       if constexpr (ORD) { hocc[s] = 0; hrun[s] = 0; }
     }
-    if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; }
+    if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; lnbig = 0; }
     __syncthreads();
     // ---- pass 1: unique keys of the partition + their summed counts ---------------------------
     // entries are taken EB per thread at a time with all their global loads in flight together (a
     // partition that holds a key present in every tile has ~5x the median number of entries); the
     // slot and position of the first EB entries stay in registers for pass 2
-    constexpr int EB = 8;
+    constexpr int EB = EB_;   // entries per thread in flight (the lean variant beside the gather takes 2: registers)
     unsigned cge[EB];
     unsigned short cslot[EB], cocc[EB];
     const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
@@ -531,14 +536,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
       unsigned run = cur + block_excl_scan<TBK / 64>(sum, wtot, &tot);
       unsigned chrun = block_excl_scan<TBK / 64>(ch, wtot, &chtot);
       unsigned nrun = block_excl_scan<TBK / 64>(nchs, wtot, &ntot);
-      __shared__ unsigned long long lbase64;
-      if (tid == 0)   // one atomic per block and class: cold keys | hot keys << 22 | hot chunks << 43
-        lbase64 = atomicAdd(reinterpret_cast<unsigned long long*>(&w.ctr[2]),
-                            (unsigned long long)(chtot & 0xFFFFu) | ((unsigned long long)(chtot >> 16) << 22) |
-                                ((unsigned long long)ntot << 43));
-      __syncthreads();
-      const unsigned long long b64 = lbase64;
-      const unsigned cbase = (unsigned)(b64 & 0x3FFFFFu), hbase = (unsigned)((b64 >> 22) & 0x1FFFFFu), kbase = (unsigned)(b64 >> 43);
+      const unsigned c0 = lcold, h0 = lhot, k0 = lchunk;   // the classes before this one
+      const unsigned cbase = pbase + c0, hbase = pbase + h0, kbase = k0;   // kbase: the partition's own chunk numbers
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
@@ -553,9 +552,9 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         }
       }
       __syncthreads();
-      if (tid == 0) lpcur = cur + tot;
+      if (tid == 0) { lpcur = cur + tot; lcold = c0 + (chtot & 0xFFFFu); lhot = h0 + (chtot >> 16); lchunk = k0 + ntot; }
     }
-    // the key's record for the apply: cold or hot list, and the hot key's chunk table
+    // the key's record for the apply: cold or hot list, and the hot key's chunk items
     auto put_rec = [&](int q, long long key, unsigned roww, unsigned hint) {
       const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), roww, hint);
       if (kcnt[q] <= (unsigned)LCOLD) {
@@ -566,7 +565,15 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         w.hotlist[2 * (size_t)krank[q]] = ra;
         w.hotlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], kchunk[q], cr);
         const unsigned nch = (kcnt[q] + cr - 1u) / cr;
-        for (unsigned i = 0; i < nch; ++i) w.hotchunk[kchunk[q] + i] = make_uint2(krank[q], i);
+        // one work item per chunk: {hot list index | HEAD_BIT, chunk in the key, the partition's chunk number};
+        // a key with many chunks leaves them to the whole block (lbig, below)
+        if (nch <= 16u) {
+          for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+        } else {
+          const unsigned b = atomicAdd(&lnbig, 1u);
+          if (b < 16u) { lbig[b][0] = krank[q]; lbig[b][1] = kchunk[q]; lbig[b][2] = nch; }
+          else for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+        }
       }
     };
 
@@ -672,6 +679,22 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         }
       }
     }
+    if constexpr (ORD) {
+      __syncthreads();
+      const unsigned nbig = min(lnbig, 16u);
+      for (unsigned b = 0; b < nbig; ++b)   // block-uniform
+        for (unsigned i = tid; i < lbig[b][2]; i += TBK)
+          w.litem[pbase + lbig[b][1] + i] = make_uint4(lbig[b][0] | HEAD_BIT, i, lbig[b][1] + i, 0u);
+    }
+    // hval (the frequency sums) has been consumed by its key's owner: it now carries the key's record word
+    // to pass 2 (list index, bit 31 = hot list)
+    if constexpr (ORD) {
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u < nu) hval[ulist[u]] = krank[q] | (kcnt[q] > (unsigned)LCOLD ? 0x80000000u : 0u);
+      }
+    }
     __syncthreads();
     KV_STAMPP(2);
 
@@ -762,7 +785,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         const unsigned off = atomicAdd(&hrun[h], occ);
         const unsigned rv = hrow[h];
         w.ent_b[ge] = rv & ROW_MASK;
-        w.ent_base[ge] = (hocc[h] + off) | (off == 0u ? HEAD_BIT : 0u) | ((rv >> 31) ? NEW_BIT : 0u);
+        w.ent_base[ge] = (hocc[h] + off) | (off == 0u ? HEAD_BIT : 0u);
+        if (off == 0u) w.ent_rec[ge] = hval[h];
       };
       if (a.det) {
         // deterministic mode: a key's entries take their positions in tile order = ascending x; one
@@ -776,7 +800,8 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
             const size_t ge = seg_entry(tpre, tstart, NT, x);
             if (w.ent_key[ge] != key) continue;
             w.ent_b[ge] = rv & ROW_MASK;
-            w.ent_base[ge] = (hocc[s] + off) | (off == 0u ? HEAD_BIT : 0u) | ((rv >> 31) ? NEW_BIT : 0u);
+            w.ent_base[ge] = (hocc[s] + off) | (off == 0u ? HEAD_BIT : 0u);
+            if (off == 0u) w.ent_rec[ge] = hval[s];
             off += w.ent_a[ge] & 0xFFFFu;
           }
         }
@@ -800,40 +825,79 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     if (tid == 0) { w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 8] = lnu; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 9] = R; w.dbg[(size_t)(blockIdx.x + 4096) * 16 + 10] = lnnew; }
 #endif
   }
+  if constexpr (ORD) {
+    // the partition's cold keys in batches of 64 / apply_lanes(dim) (one key per lane group of an apply wave), behind its
+    // chunk items: {first cold list index, keys in the batch}
+    const unsigned nc = lcold, nk = lchunk, gb = 64u / (unsigned)apply_lanes(a.tv.dim);
+    const unsigned nb = (nc + gb - 1u) / gb;
+    for (unsigned b = tid; b < nb; b += TBK) w.litem[pbase + nk + b] = make_uint4(pbase + b * gb, min(gb, nc - b * gb), 0u, 0u);
+    if (tid == 0) w.pmeta[p] = make_uint4(nk + nb, nk, pbase, nc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_order: the sorted position list (+ the lookup's fix-up of rows inserted by this batch)
 // ------------------------------------------------------------------------------------------
-template <bool FIX>
-__device__ __forceinline__ void order_body(const TableDev& t, const WsDev& w, long long n, float* __restrict__ out) {
-  if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: the lists are not valid
-  const int D = t.dim;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const unsigned sr = __builtin_nontemporal_load(&w.slot_rank[i]);
-    const unsigned e = sr & SLOT_MASK, rank = sr >> RANK_SHIFT;
-    const unsigned eb = w.ent_base[e];
-    const unsigned j = (eb & BASE_MASK) + rank;
-    if (j < (unsigned)n) w.order[j] = (unsigned)i | (((eb & HEAD_BIT) && rank == 0u) ? HEAD_BIT : 0u);
-    if (FIX && (eb & NEW_BIT)) {
-      // the probing gather ran beside the insert of this key: it may have seen no row, or a row that was
-      // still being initialised
-      const float* row = row_ptr(t, w.ent_b[e]);
-      float* o = out + (size_t)i * D;
-      if ((D & 3) == 0) {
-        for (int q = 0; q < (D >> 2); ++q) reinterpret_cast<float4*>(o)[q] = reinterpret_cast<const float4*>(row)[q];
-      } else {
-        for (int q = 0; q < D; ++q) o[q] = row[q];
-      }
-    }
+// one input position's place in the sorted list (sr = its slot_rank word): order[ent_base[entry] + rank] = i;
+// the first position of a cold key also goes into the key's record (most cold keys have no other row, and the
+// apply saves a hop)
+__device__ __forceinline__ void order_pos(const WsDev& w, long long n, long long i, unsigned sr) {
+  const unsigned e = sr & SLOT_MASK, rank = sr >> RANK_SHIFT;
+  const unsigned eb = w.ent_base[e];
+  const unsigned j = (eb & BASE_MASK) + rank;
+  const bool head = (eb & HEAD_BIT) && rank == 0u;
+  if (j < (unsigned)n) w.order[j] = (unsigned)i | (head ? HEAD_BIT : 0u);
+  if (head) {
+    const unsigned rec = w.ent_rec[e];
+    if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2] = (unsigned)i;
   }
+}
+// The partitions left their work items in their own stretches (litem, pmeta).  The first ITEM_BLOCKS blocks of
+// the kernel that follows the partition pass make ONE dense directory of them: each scans pmeta (P entries)
+// for itself and copies the items of its share of the partitions, hot chunk items getting their batch-wide
+// chunk number.  Totals go to ctr[2] (items) and ctr[3] (chunks).
+constexpr int ITEM_BLOCKS = 16;
+__device__ __forceinline__ void items_body(const WsDev& w) {
+  __shared__ unsigned sit[MAX_P + 1], sck[MAX_P + 1];
+  __shared__ unsigned wt[8];
+  const unsigned P = w.P;
+  const int tid = threadIdx.x, T = blockDim.x;   // 256 threads
+  const unsigned per = (P + T - 1) / T;
+  const unsigned p0 = min(P, tid * per), p1 = min(P, p0 + per);
+  unsigned si = 0, sc = 0;
+  for (unsigned q = p0; q < p1; ++q) { const uint4 m = w.pmeta[q]; sit[q] = m.x; sck[q] = m.y; si += m.x; sc += m.y; }
+  unsigned ti, tc;
+  unsigned ri = block_excl_scan<TB / 64>(si, wt, &ti);
+  unsigned rc = block_excl_scan<TB / 64>(sc, wt, &tc);
+  for (unsigned q = p0; q < p1; ++q) { const unsigned a_ = sit[q], b_ = sck[q]; sit[q] = ri; sck[q] = rc; ri += a_; rc += b_; }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) { w.ctr[2] = ti; w.ctr[3] = tc; }
+  // this block's share of the items; an item's partition = last q with sit[q] <= its number
+  const unsigned nblk = min((unsigned)ITEM_BLOCKS, gridDim.x);
+  const unsigned ipb = (ti + nblk - 1) / nblk;
+  const unsigned i0 = min(ti, blockIdx.x * ipb), i1 = min(ti, i0 + ipb);
+  for (unsigned i = i0 + tid; i < i1; i += T) {
+    unsigned lo = 0, hi = P;
+    while (hi - lo > 1) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (sit[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint4 m = w.pmeta[lo];
+    uint4 it = w.litem[m.z + (i - sit[lo])];
+    if (it.x & HEAD_BIT) it.z += sck[lo];
+    w.items[i] = it;
+  }
+}
+
+__device__ __forceinline__ void order_body(const TableDev& t, const WsDev& w, long long n) {
+  if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: the lists are not valid
+  if (blockIdx.x < ITEM_BLOCKS) items_body(w);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    order_pos(w, n, i, __builtin_nontemporal_load(&w.slot_rank[i]));
   if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
 }
-template <bool FIX>
-__global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n, float* __restrict__ out) {
-  order_body<FIX>(t, w, n, out);
-}
+__global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n) { order_body(t, w, n); }
 
 // ------------------------------------------------------------------------------------------
 // k_apply / k_apply_fin: segmented sum over the sorted position list + fused row update
@@ -846,8 +910,8 @@ __global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n, 
 //               goes to hpart and k_apply_fin adds the key's chunks up in chunk order and updates it
 //   cold batch  one lane group per key: its rows (order[start .. start + count)), its state rows and the
 //               record of the hinted slot row are requested together, then the fused update
-// Waves take items round-robin, hot chunks (streaming, bandwidth-bound) first, cold batches (dependent
-// hops, latency-bound) after them: the two kinds overlap on every CU.
+// Every wave gets its share of both kinds (hot chunks: streaming, bandwidth-bound; cold batches: dependent
+// hops, latency-bound), so the two overlap on every CU.
 constexpr int TBS = 256;
 
 // combine two partial results of a key under the fold operation (sum for the optimizers)
@@ -871,7 +935,7 @@ __device__ __forceinline__ float fold_identity(int op) {
 // The slot-table rows of one key, resolved by the group leader.  FindOrInsertUnsafe(var, filter_out !=
 // nullptr) kv_variable.h:382-408 and FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear
 // before accum (training_ops.cc:701-704).  `m0` is the record of the hinted slot row (requested early).
-struct RowsOf { unsigned tag, r0, r1, nb; };
+struct RowsOf { unsigned tag, r0, r1, nb; };   // nb: bit 1 / 2 = slot row 0 / 1 inserted now, bit 3 = slot row 0 is the hinted one
 template <int OPT>
 __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key, unsigned rvw, unsigned hint,
                                                bool hint_loaded, const RowMeta& m0) {
@@ -889,11 +953,12 @@ __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key,
     if (mv.y & FLAG_BLACK) meta_ptr(a.tv, rv)->flags = FLAG_UNDER;   // RemoveBlacklistUnsafe: fresh zero row (ours already is)
   }
   // slot rows are only created for keys the update will touch (filtered keys returned above)
+  bool hinted = false;
   auto slot_row = [&](const TableDev& t, bool use_hint, bool* isnew) -> unsigned {
     *isnew = false;
     unsigned r = 0, f = 0;
     if (use_hint && hint_loaded && m0.key == key && !(m0.flags & FLAG_FREE)) {
-      r = hint; f = m0.freq;
+      r = hint; f = m0.freq; hinted = true;
     } else {
       r = table_find(t, key);
       if (__builtin_expect(r == 0u, 0)) {
@@ -923,7 +988,7 @@ __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key,
     if (o.r0) mark_delta(a.ts0, o.r0);
     if (OPT == OPT_FTRL && o.r1) mark_delta(a.ts1, o.r1);
   }
-  o.nb = (new0 ? 2u : 0u) | (new1 ? 4u : 0u);
+  o.nb = (new0 ? 2u : 0u) | (new1 ? 4u : 0u) | (hinted ? 8u : 0u);
   return o;
 }
 
@@ -932,7 +997,8 @@ __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key,
 // hd = {key lo, key hi, row word, slot-row hint}
 template <int MODE, int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bool live, bool hint_loaded,
-                                           const RowMeta& m0, float (&gv)[K][V], int lane) {
+                                           const RowMeta& m0, float (&gv)[K][V], int lane,
+                                           const PreRows<V, K>* pre = nullptr, bool have_x = false, bool have_s = false) {
   const int D = a.tv.dim;
   const long long key = (long long)(((unsigned long long)hd.y << 32) | hd.x);
   if (MODE == MODE_APPLY) {
@@ -942,8 +1008,9 @@ __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bo
       ro.tag = __shfl(ro.tag, 0, LPR); ro.r0 = __shfl(ro.r0, 0, LPR);
       ro.r1 = __shfl(ro.r1, 0, LPR); ro.nb = __shfl(ro.nb, 0, LPR);
     }
+    // the slot rows in `pre` are those of the hinted row: good only if the hint stood up
     opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, ro.tag, ro.r0, (ro.nb & 2u) != 0, ro.r1, (ro.nb & 4u) != 0,
-                                   live, gv, a.opt, lane);
+                                   live, gv, a.opt, lane, pre, have_x, have_s && (ro.nb & 8u) != 0);
   } else if (live && hd.z != ROW_MASK) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -953,31 +1020,21 @@ __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bo
   }
 }
 
-// the op's counters as the partition pass left them
-struct ApplyCounts { unsigned ncold, nhot, nchunks; };
-__device__ __forceinline__ ApplyCounts apply_counts(const WsDev& w) {
-  const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(&w.ctr[2]);
-  return ApplyCounts{(unsigned)(pk & 0x3FFFFFu), (unsigned)((pk >> 22) & 0x1FFFFFu), (unsigned)(pk >> 43)};
-}
-
 template <int MODE, int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
   static_assert(LPR <= 64, "a row is handled by the lanes of one wave");
   const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
-  const ApplyCounts ac = apply_counts(w);
+  const unsigned total = w.ctr[2];   // work items: hot chunks and cold batches, every one about the same weight
   if (errflag) return;   // the index pass gave up on this batch
   const int D = a.tv.dim;
   constexpr int G = 64 / LPR;                    // lane groups (keys / rows in flight side by side) per wave
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;  // rows in flight per group, hot chunks
-  constexpr int RC = (4 / K) > 0 ? (4 / K) : 1;  // rows in flight per group, cold keys (most have one or two)
+  constexpr int RC = (2 / K) > 0 ? (2 / K) : 1;  // further rows of a cold key in flight per group (most keys have none)
   const int wl = threadIdx.x & 63;
   const int lane = wl % LPR;
   const int g = wl / LPR;
   const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
   const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
-  const unsigned ncb = (ac.ncold + G - 1) / G;
-  const unsigned total = ac.nchunks + ncb;
-  const unsigned W = gridDim.x * (TBS / 64);
   auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
     const float* src = a.grad + (size_t)pos * D;
 #pragma unroll
@@ -992,35 +1049,58 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
 #pragma unroll
       for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + v[k][cc] : fold2(fop, gv[k][cc], v[k][cc]);
   };
+  // Round-robin hand-out: the items weigh about the same (HC rows of a hot key ~ one batch of cold keys), and
+  // consecutive items come from one hash partition, so a wave's items are a random sample of the batch.
+  // (Run-time tickets were tried: 18 k returning atomics per launch more than doubled every item's time.)
+  const unsigned W = gridDim.x * (TBS / 64);
+#ifdef KV_STAMPS
+  unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0;
+#endif
   for (unsigned it = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6); it < total; it += W) {
+    const uint4 item = w.items[it];
+    const bool is_hot = (item.x & HEAD_BIT) != 0u;
+#ifdef KV_STAMPS
+    const unsigned long long st_a = wall_clock64();
+#endif
     float gv[K][V];
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
-    if (it < ac.nchunks) {
-      // ---- hot chunk: rows [lo, hi) of one key, G * RB of them in flight per step --------------------
-      const uint2 hc = w.hotchunk[it];
-      const uint4 ra = w.hotlist[2 * (size_t)hc.x], rb = w.hotlist[2 * (size_t)hc.x + 1];
-      const unsigned lo = rb.x + hc.y * rb.w, hi = min(rb.x + rb.y, lo + rb.w);
-      for (unsigned r0 = lo; r0 < hi; r0 += G * RB) {
-        float val[RB][K][V];
-        unsigned pos[RB];
+    if (is_hot) {
+      // ---- hot chunk: rows [lo, hi) of one key, G * RB of them per step ------------------------------------
+      const unsigned hx = item.x & ~HEAD_BIT;
+      const uint4 ra = w.hotlist[2 * (size_t)hx], rb = w.hotlist[2 * (size_t)hx + 1];
+      const unsigned lo = rb.x + item.y * rb.w, hi = min(rb.x + rb.y, lo + rb.w);
+      constexpr int SR = G * RB;              // rows per step: row r of a step goes to group r % G
+      const unsigned nst = (hi - lo + SR - 1) / SR;
+      auto ldpos = [&](unsigned st, unsigned (&pp)[RB]) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-          const unsigned idx = r0 + g * RB + j;
-          pos[j] = idx < hi ? (w.order[idx] & ~HEAD_BIT) : 0xFFFFFFFFu;
+          const unsigned idx = lo + st * SR + j * G + g;
+          pp[j] = idx < hi ? (w.order[idx] & ~HEAD_BIT) : 0xFFFFFFFFu;
         }
+      };
+      auto ldrows = [&](const unsigned (&pp)[RB], float (&dst)[RB][K][V]) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
 #pragma unroll
           for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int cc = 0; cc < V; ++cc) val[j][k][cc] = ident;
-          if (pos[j] != 0xFFFFFFFFu) load_row(pos[j], val[j]);
+            for (int cc = 0; cc < V; ++cc) dst[j][k][cc] = ident;
+          if (pp[j] != 0xFFFFFFFFu) load_row(pp[j], dst[j]);
         }
+      };
+      // one step at a time per wave (registers are what limits the waves per SIMD, and the waves are what
+      // hides the hops: a second row buffer costs more than it gains); positions one step ahead
+      unsigned pa_[RB], pb_[RB];
+      float va[RB][K][V];
+      ldpos(0, pa_);
+      for (unsigned st = 0; st < nst; ++st) {
+        ldrows(pa_, va);
+        ldpos(st + 1, pb_);
 #pragma unroll
-        for (int j = 0; j < RB; ++j) acc_row(gv, val[j]);
+        for (int j = 0; j < RB; ++j) { acc_row(gv, va[j]); pa_[j] = pb_[j]; }
       }
       // the groups' sums meet: a fixed shuffle tree, every lane ends with the chunk's sum
 #pragma unroll
@@ -1036,7 +1116,7 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
       const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
       if (nch > 1u) {
         if (g == 0) {
-          float* dst = w.hpart + (size_t)it * D;
+          float* dst = w.hpart + (size_t)item.z * D;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const int e0 = (lane + k * LPR) * V;
@@ -1049,16 +1129,18 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
       }
     } else {
       // ---- cold batch: one key per lane group ------------------------------------------------------------
-      const unsigned u = (it - ac.nchunks) * G + g;
-      const bool live = u < ac.ncold;
+      // One round trip fetches everything a key with a single row needs (three quarters of the cold keys):
+      // its gradient row (the record carries the first position), the var row, the hinted slot row and that
+      // row's own record.  Further rows of the key, if any, follow RC at a time.
+      const unsigned u = item.x + g;
+      const bool live = (unsigned)g < item.y;
       uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = ra;
       if (live) { ra = w.coldlist[2 * (size_t)u]; rb = w.coldlist[2 * (size_t)u + 1]; }
       const unsigned start = rb.x, cnt = live ? rb.y : 0u;
-      // requested now, used after the fold: the record of the hinted slot row (leader) and the lines of the
-      // state rows, so that the update's own loads find them in cache
       RowMeta m0{};
-      bool hint_loaded = false;
-      float touch = 0.f;
+      bool hint_loaded = false, have_x = false, have_s = false;
+      PreRows<V, K> pre;
+      if (cnt > 0u) load_row(rb.z, gv);     // ident op with one operand: the first row IS the partial result
       if (MODE == MODE_APPLY && live && (ra.z & ROW_MASK) != 0u) {
         const bool hok = a.use_hints && ra.w != 0u && ra.w < a.ts0.max_rows;
         if (lane == 0 && hok) {
@@ -1068,17 +1150,23 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
           m0.flags = (unsigned char)(mm.w & 0xFFu);
           hint_loaded = true;
         }
-        const int e0 = lane * V;
-        if (e0 < D) {
-          touch = row_ptr(a.tv, ra.z & ROW_MASK)[e0];
-          if (hok) {
-            const float* sr = row_ptr(a.ts0, ra.w);
-            touch += sr[e0];
-            if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) touch += sr[e0 + D] + sr[e0 + 2 * D];
+        const float* xr = row_ptr(a.tv, ra.z & ROW_MASK);
+        const float* sr = hok ? row_ptr(a.ts0, ra.w) : nullptr;
+        constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) {
+            ldv<V>(xr + e0, pre.x[k]);
+            if (hok) {
+#pragma unroll
+              for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + e0 + b3 * D, pre.s[b3][k]);
+            }
           }
         }
+        have_x = true; have_s = hok;
       }
-      for (unsigned j0 = 0; j0 < cnt; j0 += RC) {
+      for (unsigned j0 = 1; j0 < cnt; j0 += RC) {
         float val[RC][K][V];
         unsigned pos[RC];
 #pragma unroll
@@ -1094,49 +1182,83 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
 #pragma unroll
         for (int j = 0; j < RC; ++j) acc_row(gv, val[j]);
       }
-      asm volatile("" ::"v"(touch));  // keep the touch loads
-      finish_key<MODE, OPT, V, LPR, K>(a, ra, live, hint_loaded, m0, gv, lane);
+      finish_key<MODE, OPT, V, LPR, K>(a, ra, live, hint_loaded, m0, gv, lane, &pre, have_x, have_s);
     }
+#ifdef KV_STAMPS
+    {
+      const unsigned long long now = wall_clock64();
+      if (is_hot) { st_hot += now - st_a; ++st_nh; } else { st_cold += now - st_a; ++st_nc; }
+    }
+#endif
   }
+#ifdef KV_STAMPS
+  if (wl == 0) {
+    unsigned long long* d = w.dbg + (size_t)(8192 + blockIdx.x * (TBS / 64) + (threadIdx.x >> 6)) * 16;
+    d[0] = st_t0; d[1] = wall_clock64(); d[2] = st_hot; d[3] = st_cold; d[4] = st_nh; d[5] = st_nc; d[6] = total; d[7] = w.ctr[3]; d[8] = 0;
+  }
+#endif
 }
 
-// hot keys with more than one chunk: the chunks' sums (hpart) are added up in chunk order — lane group g
-// takes chunks g, g + G, ..., the groups meet through the same shuffle tree — and the key is finished
+// hot keys with more than one chunk: the chunks' sums (hpart) are added up — the block's waves take
+// consecutive runs of the key's chunks, lane group g of a wave every G-th chunk of the run, the groups meet
+// through the shuffle tree and the waves through LDS in wave order — and the key is finished.  A block reads
+// its share of the item directory at once (a key's first chunk item names the key); keys of up to 64 chunks
+// go one to a wave, bigger ones to the whole block.  The order of the additions depends on nothing but the key.
+constexpr int TBF = 1024;
 template <int MODE, int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a) {
   const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
-  const ApplyCounts ac = apply_counts(w);
+  const unsigned total = w.ctr[2];
   if (errflag) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lsum = reinterpret_cast<float*>(smem_raw);   // [TBF / 64][dim]
+  __shared__ unsigned lkeys[TBF][3];                  // multi-chunk keys among this block's items: {hot index, first chunk, chunks}
+  __shared__ unsigned lnk;
   const int D = a.tv.dim;
   constexpr int G = 64 / LPR;
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-  const int wl = threadIdx.x & 63;
+  constexpr int NW = TBF / 64;
+  const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lane = wl % LPR;
   const int g = wl / LPR;
   const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
   const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
-  const unsigned W = gridDim.x * (TBS / 64);
-  for (unsigned h = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6); h < ac.nhot; h += W) {
-    const uint4 rb = w.hotlist[2 * (size_t)h + 1];
-    const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
-    if (nch < 2u) continue;   // wave-uniform
-    const uint4 ra = w.hotlist[2 * (size_t)h];
-    float gv[K][V];
+  // the block's contiguous share of the item directory, read at once
+  const unsigned per_b = (total + gridDim.x - 1) / gridDim.x;
+  const unsigned b0 = min(total, blockIdx.x * per_b), b1 = min(total, b0 + per_b);
+  if (threadIdx.x == 0) lnk = 0;
+  __syncthreads();
+  for (unsigned i = b0 + threadIdx.x; i < b1; i += TBF) {
+    const uint4 item = w.items[i];
+    if ((item.x & HEAD_BIT) && item.y == 0u) {
+      const uint4 rb = w.hotlist[2 * (size_t)(item.x & ~HEAD_BIT) + 1];
+      const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
+      if (nch > 1u) {
+        const unsigned q = atomicAdd(&lnk, 1u);
+        if (q < (unsigned)TBF) { lkeys[q][0] = item.x & ~HEAD_BIT; lkeys[q][1] = item.z; lkeys[q][2] = nch; }
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned nk = min(lnk, (unsigned)TBF);
+  // sum of chunks [c0, c1) of a key by one wave: lane group g takes every G-th chunk, the groups meet in the
+  // shuffle tree; every lane returns the sum
+  auto wave_sum = [&](unsigned first, unsigned c0, unsigned c1, float (&gv)[K][V]) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
-    for (unsigned c0 = 0; c0 < nch; c0 += G * RB) {
+    for (unsigned cb = c0; cb < c1; cb += G * RB) {
       float val[RB][K][V];
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
-        const unsigned ci = c0 + j * G + g;
+        const unsigned ci = cb + j * G + g;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
 #pragma unroll
           for (int cc = 0; cc < V; ++cc) val[j][k][cc] = ident;
           const int e0 = (lane + k * LPR) * V;
-          if (ci < nch && e0 < D) ldv<V>(w.hpart + (size_t)(rb.z + ci) * D + e0, val[j][k]);
+          if (ci < c1 && e0 < D) ldv<V>(w.hpart + (size_t)(first + ci) * D + e0, val[j][k]);
         }
       }
 #pragma unroll
@@ -1157,8 +1279,52 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
           gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
         }
     }
+  };
+  // keys with up to 64 chunks: one wave each
+  for (unsigned q = wv; q < nk; q += NW) {
+    if (lkeys[q][2] > 64u) continue;
+    float gv[K][V];
+    wave_sum(lkeys[q][1], 0u, lkeys[q][2], gv);
+    const uint4 ra = w.hotlist[2 * (size_t)lkeys[q][0]];
     RowMeta m0{};
     finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+  }
+  // keys with more: the block's waves take consecutive runs of the chunks and meet in LDS in wave order
+  for (unsigned q = 0; q < nk; ++q) {   // block-uniform
+    const unsigned nch = lkeys[q][2];
+    if (nch <= 64u) continue;
+    const unsigned per = (nch + NW - 1) / NW;
+    const unsigned c0 = min(nch, wv * per), c1 = min(nch, c0 + per);
+    float gv[K][V];
+    wave_sum(lkeys[q][1], c0, c1, gv);
+    __syncthreads();   // lsum of the previous key has been read
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) stv<V>(lsum + (size_t)wv * D + e0, gv[k]);
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const unsigned nwv = (nch + per - 1) / per;   // waves that had chunks
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) {
+          ldv<V>(lsum + e0, gv[k]);
+          for (unsigned x = 1; x < nwv; ++x) {
+            float v[V];
+            ldv<V>(lsum + (size_t)x * D + e0, v);
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + v[cc] : fold2(fop, gv[k][cc], v[cc]);
+          }
+        }
+      }
+      const uint4 ra = w.hotlist[2 * (size_t)lkeys[q][0]];
+      RowMeta m0{};
+      finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+    }
   }
 }
 
@@ -1166,9 +1332,15 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
 // k_gather: out[i, :] = rows[ent_b[slot_rank[i] & SLOT_MASK]]
 // ------------------------------------------------------------------------------------------
 // VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
-template <int VQ>
+// ORDER: the same pass files every position in the sorted list (order_pos): the training lookup's last kernel
+template <int VQ, bool ORDER = false>
 __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, float* __restrict__ out,
                                             long long n) {
+  if (ORDER) {
+    if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: nothing is valid
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
+    if (blockIdx.x < ITEM_BLOCKS) items_body(w);
+  }
   if constexpr (VQ > 0 && VQ <= 64) {
     // One wave takes 64 consecutive output rows per step.  Lane l resolves row l's table row id
     // (slot_rank -> ent_b: two dependent loads, 64 rows in flight per wave and no redundancy);
@@ -1185,12 +1357,19 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     const long long stride = nwaves * 64;
     long long r0 = wave * 64;
     unsigned sl1 = 0, sl2 = 0, rr = 0;
-    if (r0 + lane < n) rr = w.ent_b[__builtin_nontemporal_load(&w.slot_rank[r0 + lane]) & SLOT_MASK];
-    if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_rank[r0 + stride + lane]) & SLOT_MASK;
+    if (r0 + lane < n) {
+      const unsigned sr = __builtin_nontemporal_load(&w.slot_rank[r0 + lane]);
+      rr = w.ent_b[sr & SLOT_MASK];
+      if (ORDER) order_pos(w, n, r0 + lane, sr);
+    }
+    if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_rank[r0 + stride + lane]);
     for (; r0 < n; r0 += stride) {
       unsigned rr1 = 0;
-      if (r0 + stride + lane < n) rr1 = w.ent_b[sl1];
-      if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_rank[r0 + 2 * stride + lane]) & SLOT_MASK;
+      if (r0 + stride + lane < n) {
+        rr1 = w.ent_b[sl1 & SLOT_MASK];
+        if (ORDER) order_pos(w, n, r0 + stride + lane, sl1);
+      }
+      if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_rank[r0 + 2 * stride + lane]);
 #pragma unroll
       for (int j0 = 0; j0 < VQ; j0 += CW) {
         float4 val[CW];
@@ -1216,7 +1395,9 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     constexpr int RPB = TB / VQ;  // rows per block per step (VQ = 128, 256)
     const int v = threadIdx.x % VQ;
     for (long long i = (long long)blockIdx.x * RPB + threadIdx.x / VQ; i < n; i += (long long)gridDim.x * RPB) {
-      const unsigned r = w.ent_b[w.slot_rank[i] & SLOT_MASK];
+      const unsigned sr = w.slot_rank[i];
+      const unsigned r = w.ent_b[sr & SLOT_MASK];
+      if (ORDER && v == 0) order_pos(w, n, i, sr);
       reinterpret_cast<float4*>(out + (size_t)i * (VQ * 4))[v] = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
     }
   } else {
@@ -1225,7 +1406,9 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += (long long)gridDim.x * TB) {
       const long long i = x / D;
       const int e = (int)(x - i * D);
-      out[x] = row_ptr(t, w.ent_b[w.slot_rank[i] & SLOT_MASK])[e];
+      const unsigned sr = w.slot_rank[i];
+      if (ORDER && e == 0) order_pos(w, n, i, sr);
+      out[x] = row_ptr(t, w.ent_b[sr & SLOT_MASK])[e];
     }
   }
 }
@@ -1256,19 +1439,37 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros(TableDev t, const IdT* _
 // repeated by neighbouring lanes), then the wave copies the rows VQ lanes per row, CH copy instructions
 // in flight, row ids handed over by shuffle, streaming stores (the output is not read again here).
 // ids_kind: 0 int64, 1 int32, 2 (id, count) int64 pairs.  `wave` of `nwaves` waves share the rows.
-template <int VQ>
+// Software pipeline over the wave's steps: while step i copies its rows, the home index entries of step
+// i + 1 and the ids of step i + 2 are already in flight, so a step costs one round trip, not three — the
+// gather keeps the store bandwidth busy from a few waves per CU (it runs beside the partition pass).
+template <int VQ, int CWMAX = 4>
 __device__ __forceinline__ void goz_wave(const TableDev& t, const void* __restrict__ ids, int ids_kind,
                                          float* __restrict__ out, long long n, long long wave, long long nwaves) {
   constexpr int RW = 64 / VQ;            // rows per copy instruction
-  constexpr int CW = VQ < 4 ? VQ : 4;    // copy instructions in flight
+  constexpr int CW = VQ < CWMAX ? VQ : CWMAX;    // copy instructions in flight (4 with many waves per CU: the probe hop
+                                                 // wants the occupancy; 8 for the few gather waves beside the partition pass)
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
   const long long stride = nwaves * 64;
-  for (long long r0 = wave * 64; r0 < n; r0 += stride) {
-    unsigned rr = 0;  // row 0 reads zeros: misses, and lanes past the end
-    if (r0 + lane < n)
-      rr = table_find(t, ids_kind == 1 ? (long long)reinterpret_cast<const int*>(ids)[r0 + lane]
-                                       : reinterpret_cast<const long long*>(ids)[(r0 + lane) << (ids_kind == 2 ? 1 : 0)]);
+  auto load_key = [&](long long i) -> long long {
+    if (i >= n) return EMPTY_KEY;
+    return ids_kind == 1 ? (long long)reinterpret_cast<const int*>(ids)[i]
+                         : reinterpret_cast<const long long*>(ids)[i << (ids_kind == 2 ? 1 : 0)];
+  };
+  long long r0 = wave * 64;
+  if (r0 >= n) return;
+  long long k1 = load_key(r0 + lane);                  // step i + 1's key (first: step 0's)
+  long long k2 = load_key(r0 + stride + lane);         // step i + 2's
+  unsigned long long p1 = home_of(t, k1, mix64((unsigned long long)k1));
+  Entry e1 = load_entry(&t.entries[p1]);
+  for (; r0 < n; r0 += stride) {
+    // this step's rows: finish the probe started one step ago (row 0 reads zeros: misses, lanes past the end)
+    const unsigned rr = (r0 + lane < n) ? table_find_from(t, k1, p1, e1) : 0u;
+    // next step: its home entries leave now, the ids of the step after it too
+    k1 = k2;
+    p1 = home_of(t, k1, mix64((unsigned long long)k1));
+    if (r0 + stride < n) e1 = load_entry(&t.entries[p1]);
+    k2 = load_key(r0 + 2 * stride + lane);
 #pragma unroll
     for (int j0 = 0; j0 < VQ; j0 += CW) {
       float4 val[CW];
@@ -1297,6 +1498,7 @@ __global__ void __launch_bounds__(TB) k_gather_or_zeros_w(TableDev t, const IdT*
 }
 
 // the gather for any dim behind one entry: wave-shaped for dims 4, 8, ..., 256, else 8 lanes per row
+template <int CWMAX = 4>
 __device__ __forceinline__ void goz_any(const TableDev& t, const void* __restrict__ ids, int ids_kind,
                                         float* __restrict__ out, long long n, long long blk, long long nblk) {
   const int D = t.dim;
@@ -1304,13 +1506,13 @@ __device__ __forceinline__ void goz_any(const TableDev& t, const void* __restric
   const long long nwaves = nblk * (blockDim.x / 64);
   if ((D & 3) == 0) {  // block-uniform
     switch (D >> 2) {
-      case 1: goz_wave<1>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 2: goz_wave<2>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 4: goz_wave<4>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 8: goz_wave<8>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 16: goz_wave<16>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 32: goz_wave<32>(t, ids, ids_kind, out, n, wave, nwaves); return;
-      case 64: goz_wave<64>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 1: goz_wave<1, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 2: goz_wave<2, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 4: goz_wave<4, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 8: goz_wave<8, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 16: goz_wave<16, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 32: goz_wave<32, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
+      case 64: goz_wave<64, CWMAX>(t, ids, ids_kind, out, n, wave, nwaves); return;
       default: break;
     }
   }
@@ -1342,20 +1544,14 @@ struct MultiDesc {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(TBK) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
-// the training lookup's partition pass with the probing gather beside it: blocks [0, P) own the partitions
-// (latency-bound: dependent probes), the blocks after them copy the output rows (bandwidth-bound)
-__global__ void __launch_bounds__(TBK) k_part_keys_gather(WsDev w, PartArgs a, GatherRole g) {
-  if (blockIdx.x < w.P) part_keys_body<MODE_LOOKUP, 512>(w, a);
-  else goz_any(a.tv, g.ids, g.ids_kind, g.out, g.n, blockIdx.x - w.P, gridDim.x - w.P);
-}
+__global__ void __launch_bounds__(TBK, 4) k_part_keys(WsDev w, PartArgs a) { part_keys_body<MODE>(w, a); }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply(WsDev w, PartArgs a) { apply_body<MODE, OPT, V, LPR, K>(w, a); }
+__global__ void __launch_bounds__(TBS, (K == 1 ? 5 : 1)) k_apply(WsDev w, PartArgs a) { apply_body<MODE, OPT, V, LPR, K>(w, a); }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_fin(WsDev w, PartArgs a) { apply_fin_body<MODE, OPT, V, LPR, K>(w, a); }
-template <int VQ>
+__global__ void __launch_bounds__(TBF) k_apply_fin(WsDev w, PartArgs a) { apply_fin_body<MODE, OPT, V, LPR, K>(w, a); }
+template <int VQ, bool ORDER>
 __global__ void __launch_bounds__(TB) k_gather(TableDev t, WsDev w, float* __restrict__ out, long long n) {
-  gather_body<VQ>(t, w, out, n);
+  gather_body<VQ, ORDER>(t, w, out, n);
 }
 
 template <bool FIRST, typename IdT>
@@ -1365,7 +1561,7 @@ __global__ void __launch_bounds__(TBT) k_tile_multi(const MultiDesc* __restrict_
   tile_body<FIRST, IdT>(m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.n, m.a.det);
 }
 template <int MODE>
-__global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBK, 4) k_part_keys_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
   part_keys_body<MODE>(m.w, m.a);
@@ -1373,7 +1569,7 @@ __global__ void __launch_bounds__(TBK) k_part_keys_multi(const MultiDesc* __rest
 __global__ void __launch_bounds__(TB) k_order_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
   if (m.n == 0) return;
-  order_body<false>(m.a.tv, m.w, m.n, nullptr);
+  order_body(m.a.tv, m.w, m.n);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_multi(const MultiDesc* __restrict__ descs) {
@@ -1382,7 +1578,7 @@ __global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_multi(const Mul
   apply_body<MODE, OPT, V, LPR, K>(m.w, m.a);
 }
 template <int MODE, int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply_fin_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBF) k_apply_fin_multi(const MultiDesc* __restrict__ descs) {
   const MultiDesc& m = descs[blockIdx.y];
   if (m.n == 0) return;
   apply_fin_body<MODE, OPT, V, LPR, K>(m.w, m.a);

@@ -308,12 +308,15 @@ struct Workspace {
   unsigned* ent_a = nullptr;
   unsigned* ent_b = nullptr;
   unsigned* ent_base = nullptr;
+  unsigned* ent_rec = nullptr;
   unsigned* toff = nullptr;
   unsigned* slot_rank = nullptr;
   unsigned* order = nullptr;
   uint4* coldlist = nullptr;   // [cap_n][2]
-  uint4* hotlist = nullptr;    // [hot_cap(cap_n)][2]
-  uint2* hotchunk = nullptr;   // [chunk_cap(cap_n)]
+  uint4* hotlist = nullptr;    // [cap_n][2]
+  uint4* litem = nullptr;      // [cap_n]
+  uint4* items = nullptr;      // [cap_n]
+  uint4* pmeta = nullptr;      // [capP]
   float* hpart = nullptr;      // [chunk_cap(cap_n)][dim]
   long long hpart_elems = 0;
   unsigned* ctr = nullptr;
@@ -538,7 +541,6 @@ unsigned pick_partitions(long long n) {
 }
 
 // upper bounds of a batch of n ids: hot keys (more than LCOLD occurrences each) and their chunks
-size_t hot_cap(long long n) { return (size_t)(n / (LCOLD + 1) + 2); }
 size_t chunk_cap(long long n) { return (size_t)(n / HC + n / (LCOLD + 1) + 4); }
 
 // (re)allocation that leaves the old buffer in place when the new one cannot be had
@@ -566,10 +568,11 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     w.cap_n = 0; w.capP = 0; w.hpart_elems = 0;
     t->batch_serial = 0;
     if ((rc = regrow(&w.ent_key, (size_t)cap)) || (rc = regrow(&w.ent_a, (size_t)cap)) ||
-        (rc = regrow(&w.ent_b, (size_t)cap)) || (rc = regrow(&w.ent_base, (size_t)cap)) ||
+        (rc = regrow(&w.ent_b, (size_t)cap)) || (rc = regrow(&w.ent_base, (size_t)cap)) || (rc = regrow(&w.ent_rec, (size_t)cap)) ||
         (rc = regrow(&w.toff, nt * (capP + 1))) || (rc = regrow(&w.slot_rank, (size_t)cap)) ||
         (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.coldlist, 2 * (size_t)cap)) ||
-        (rc = regrow(&w.hotlist, 2 * hot_cap(cap))) || (rc = regrow(&w.hotchunk, chunk_cap(cap))))
+        (rc = regrow(&w.hotlist, 2 * (size_t)cap)) || (rc = regrow(&w.litem, (size_t)cap)) ||
+        (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)))
       return rc;
     if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
 #ifdef KV_STAMPS
@@ -592,13 +595,15 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
 WsDev ws_view(kv_table* t, long long n) {
   Workspace& w = t->ws;
   WsDev d;
-  d.ent_key = w.ent_key; d.ent_a = w.ent_a; d.ent_b = w.ent_b; d.ent_base = w.ent_base;
+  d.ent_key = w.ent_key; d.ent_a = w.ent_a; d.ent_b = w.ent_b; d.ent_base = w.ent_base; d.ent_rec = w.ent_rec;
   d.toff = w.toff;
   d.slot_rank = w.slot_rank;
   d.order = w.order;
   d.coldlist = w.coldlist;
   d.hotlist = w.hotlist;
-  d.hotchunk = w.hotchunk;
+  d.litem = w.litem;
+  d.items = w.items;
+  d.pmeta = w.pmeta;
   d.hpart = w.hpart;
   d.ctr = w.ctr;
   d.ntiles = (unsigned)((n + TILE - 1) / TILE);
@@ -656,9 +661,10 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
 #undef KV_TILE
 }
 
-// out[i] = rows[row of ids[i]] after the lookup index passes; md: many tables in one launch
+// out[i] = rows[row of ids[i]] after the lookup index passes; md: many tables in one launch.
+// order: the same kernel also builds the sorted position list (the training lookup's third and last kernel)
 void launch_gather(const TableDev& td, const WsDev& wd, float* op, long long m, hipStream_t s,
-                   const MultiDesc* md = nullptr, int ntab = 0) {
+                   const MultiDesc* md = nullptr, int ntab = 0, bool order = false) {
   const int D = td.dim;
   const int q = (D % 4 == 0) ? D / 4 : 0;
   const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= TB;
@@ -668,7 +674,8 @@ void launch_gather(const TableDev& td, const WsDev& wd, float* op, long long m, 
 #define KV_GATHER(VQ)                                                                        \
   do {                                                                                       \
     if (md) k_gather_multi<VQ><<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);       \
-    else k_gather<VQ><<<grid, TB, 0, s>>>(td, wd, op, m);                                    \
+    else if (order) k_gather<VQ, true><<<grid, TB, 0, s>>>(td, wd, op, m);                    \
+    else k_gather<VQ, false><<<grid, TB, 0, s>>>(td, wd, op, m);                              \
   } while (0)
   switch (vec ? q : 0) {
     case 1: KV_GATHER(1); break;
@@ -699,20 +706,12 @@ void launch_part_keys(const WsDev& wd, const PartArgs& pa, hipStream_t s, const 
   }
   k_part_keys<MODE><<<grid, TBK, sh, s>>>(wd, pa);
 }
-// the training lookup: partitions + the probing gather of the output rows in one launch
-void launch_part_keys_gather(const WsDev& wd, const PartArgs& pa, const GatherRole& g, hipStream_t s) {
-  static const int gcap = [] { const char* e = getenv("KV_GATHER_BLOCKS"); return e ? atoi(e) : 4096; }();
-  const int gb = nblocks(g.n, TBK, gcap);   // a 64-row step per wave: residency, not a loop, hides the hops
-  k_part_keys_gather<<<(int)wd.P + gb, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa, g);
-}
-
-// sorted position list of the batch; out != nullptr: the lookup's fix-up of rows inserted by this batch
-void launch_order(const TableDev& td, const WsDev& wd, long long n, float* out, hipStream_t s,
+// sorted position list of the batch (the training lookup builds it in its gather kernel instead)
+void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t s,
                   const MultiDesc* md = nullptr, int ntab = 0) {
   const int grid = nblocks(n, TB, 4096);
   if (md) k_order_multi<<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);
-  else if (out) k_order<true><<<grid, TB, 0, s>>>(td, wd, n, out);
-  else k_order<false><<<grid, TB, 0, s>>>(td, wd, n, nullptr);
+  else k_order<<<grid, TB, 0, s>>>(td, wd, n);
 }
 
 // segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
@@ -725,7 +724,7 @@ int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long lon
   // is everything the chip holds at once, fewer for small batches
   static const int gmax = [] { const char* e = getenv("KV_APPLY_BLOCKS"); return e ? atoi(e) : 2048; }();
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(gmax, (nmax / 2 + chunk_cap(nmax)) / 4 + 1));
-  const unsigned gfin = (unsigned)std::max<long long>(1, std::min<long long>(256, (long long)hot_cap(nmax) / 4 + 1));
+  const unsigned gfin = (unsigned)std::max<long long>(1, std::min<long long>(256, nmax / 4096 + 1));   // each block reads its share of the items at once
   auto fn = (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3)) ? kvp_launch_apply_a : kvp_launch_apply_b;
   int rc;
   {
@@ -800,7 +799,7 @@ int enter_op(kv_table* t, hipStream_t s) {
 }
 
 // The index of a batch (kv_kernels.h): tile pass, partition pass, sorted position list.
-//   MODE_LOOKUP   with out != nullptr: the training lookup (rows copied beside the partition pass)
+//   MODE_LOOKUP   with out != nullptr: the training lookup (rows copied by the kernel that builds the list)
 //   MODE_APPLYIDX the optimizer meets the ids first (FindOrInsertUnsafe on the var table)
 //   MODE_UNIQUE   no table: dense unique indices (pa.out_keys / direct_rows)
 template <int MODE>
@@ -810,16 +809,13 @@ void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* id
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
   }
-  if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
-  if (MODE == MODE_LOOKUP && out) {
-    ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-    launch_part_keys_gather(wd, pa, GatherRole{ids, ids_kind, out, n}, s);
-  } else {
+  {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
     launch_part_keys<MODE>(wd, pa, s);
   }
   ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_ORDER : KV_PROF_INDEX, s);
-  launch_order(pa.tv, wd, n, MODE == MODE_LOOKUP ? out : nullptr, s);
+  if (MODE == MODE_LOOKUP && out) launch_gather(pa.tv, wd, out, n, s, nullptr, 0, true);
+  else launch_order(pa.tv, wd, n, s);
 }
 
 uint64_t g_serial = 0;   // batch tokens (under the table's mutex; uniqueness across tables is not needed)
@@ -963,8 +959,8 @@ int kv_destroy(kv_handle_t t) {
   hipFree(t->route_hist);
   for (auto e : t->ev) hipEventDestroy(e);
   Workspace& w = t->ws;
-  hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.toff); hipFree(w.slot_rank);
-  hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.hotchunk); hipFree(w.hpart);
+  hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
+  hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
   hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   if (t->err_host) hipHostFree(t->err_host);
   if (t->last_done) hipEventDestroy(t->last_done);
@@ -1489,7 +1485,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
   launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
-  launch_order(hd[0].a.tv, wmax, nmax, nullptr, s, md, num_tables);
+  launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
   switch (opt) {
     case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
     case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;

@@ -34,24 +34,25 @@ for rep in range(3):
 a = np.zeros((16384, 16), np.uint64)
 L.kv_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
 L.kv_debug_read_stamps(var.ptr, a.ctypes.data, 16384)
-nch = (N + 255) // 256
-t = a[8192:8192 + nch].astype(np.int64)
-print("k_apply_sorted: %d blocks; ticks of 10 ns" % nch)
-def med(x): return "median %6.0f p90 %6.0f max %6.0f" % (np.median(x), np.percentile(x, 90), x.max())
-print("  preamble (order, heads, scan)   ", med(t[:, 1] - t[:, 0]))
-print("  long segments                   ", med(t[:, 2] - t[:, 1]))
-print("  group loop                      ", med(t[:, 11] - t[:, 2]))
-print("  block total                     ", med(t[:, 11] - t[:, 0]), " kernel span %d" % (t[:, 11].max() - t[:, 0].min()))
-nseg, nl = t[:, 12], t[:, 13]
-print("  segments per chunk median %d p10 %d p90 %d ; long segments mean %.2f" % (np.median(nseg), np.percentile(nseg, 10), np.percentile(nseg, 90), nl.mean()))
-for r in range(4):
-  ok = t[:, 4 + 2 * r] > 0
-  if ok.sum() == 0: continue
-  prev = t[ok, 2] if r == 0 else t[ok, 2 + 2 * r]
-  print("  group 0 round %d (%4d blocks): fold+touch %s | resolve+update %s" % (r, ok.sum(), med(t[ok, 3 + 2 * r] - prev), med(t[ok, 4 + 2 * r] - t[ok, 3 + 2 * r])))
-for lo, hi in ((0, 1), (1, 8), (8, 64), (64, 160), (160, 257)):
-  m = (nseg >= lo) & (nseg < hi)
-  if m.any():
-    print("  chunks with %3d..%3d keys: %4d blocks, total %s" % (lo, hi - 1, m.sum(), med((t[:, 11] - t[:, 0])[m])))
-st0 = t[:, 0] - t[:, 0].min()
-print("  block start times: median %d p90 %d max %d" % (np.median(st0), np.percentile(st0, 90), st0.max()))
+t = a[8192:16384].astype(np.int64)
+t = t[t[:, 1] > 0]
+print("k_apply: %d waves ran; items %d, hot chunks %d; ticks of 10 ns" % (len(t), t[0, 6], t[0, 7]))
+def med(x): return "median %6.0f p90 %6.0f max %6.0f" % (np.median(x), np.percentile(x, 90), x.max()) if len(x) else "-"
+t0 = t[:, 0].min()
+print("  wave start  ", med(t[:, 0] - t0))
+print("  wave end    ", med(t[:, 1] - t0), " kernel span %d" % (t[:, 1].max() - t0))
+h = t[:, 4] > 0; c = t[:, 5] > 0
+print("  hot items per wave ", med(t[h, 4]), " time per hot item ", med(t[h, 2] / t[h, 4]))
+print("  cold items per wave", med(t[c, 5]), " time per cold item", med(t[c, 3] / t[c, 5]))
+print("  sum of hot time %.0f us*waves, cold %.0f us*waves" % (t[:, 2].sum() / 100.0, t[:, 3].sum() / 100.0))
+# ---- k_part_keys_gather: the partition blocks (stamps 0..4 at rows 4096 + block)
+pt = a[4096:4096 + 1024].astype(np.int64)
+pt = pt[pt[:, 4] > 0]
+if len(pt):
+  b0 = pt[:, 0].min()
+  print("k_part_keys (partition role of the lookup): %d blocks" % len(pt))
+  for nm, i, j in (("directory + pass 1 (entries -> LDS hash)", 0, 1), ("scan + owner (probe, frequency, records)", 1, 2),
+                   ("lane work (new rows, flags)", 2, 3), ("pass 2 (entries learn row / base)", 3, 4)):
+    print("   %-44s %s" % (nm, med(pt[:, j] - pt[:, i])))
+  print("   block total %s ; start %s ; last end %d" % (med(pt[:, 4] - pt[:, 0]), med(pt[:, 0] - b0), (pt[:, 4] - b0).max()))
+  print("   uniques per block median %d max %d" % (np.median(pt[:, 8]), pt[:, 8].max()))
