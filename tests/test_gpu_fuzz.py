@@ -1,6 +1,11 @@
 """Randomised differential test: a random program of KvVariable ops runs on the GPU table and on the
-oracle side by side; after every op the observable state must agree (key set, frequency words,
-sizes: exactly; rows and optimizer state: 1e-4 relative — fp32 sums of repeated ids reorder)."""
+oracle side by side; after every op the observable state must agree: key set, frequency words, sizes
+exactly; rows and optimizer state to north_star's 1e-6 relative.  The optimizer ops get what the reference's
+ops get — unique ids and TF-core's occurrence-ordered segment sums (variable_scope.py:1096-1106 runs
+tf.unique + unsorted_segment_sum in front of them) — so no summation-order allowance is needed here; the
+fused segment reduction of repeated ids is bounded per element in test_gpu_config_sizes.py,
+test_gpu_parity.py::test_full_size_batch_properties and test_large_batches_match_oracle below."""
+RTOL, ATOL = 1e-6, 1e-7      # ATOL: FTRL rebuilds the row from a linear slot that is a difference of O(1) terms
 import numpy as np
 import pytest
 
@@ -36,7 +41,7 @@ class Pair(object):
     assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_frequency(h) == o.sum_freq(), tag
     q = rng.integers(-keyspace - 5, keyspace + 5, 200)
     np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q),
-                               rtol=1e-4, atol=2e-5, err_msg=tag)   # atol: FTRL's linear slot is a difference of O(10) terms
+                               rtol=RTOL, atol=ATOL, err_msg=tag)
     np.testing.assert_array_equal(ops.kv_variable_get_count_v2(h, q).cpu().numpy(), o.get_count(q), err_msg=tag)
     np.testing.assert_array_equal(ops.kv_variable_get_time_stamp(h, q).cpu().numpy(), o.get_timestamp(q), err_msg=tag)
 
@@ -66,23 +71,23 @@ def test_random_program_matches_oracle(ops, seed):
     tag = "seed %d step %d %s n=%d D=%d" % (seed, step, op, n, D)
     if op == "lookup":
       got = ops.kv_variable_gather_or_insert_v2(var.h, ids).cpu().numpy()
-      np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=1e-4, atol=1e-6, err_msg=tag)
+      np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=RTOL, atol=ATOL, err_msg=tag)
     elif op == "lookup_counts":
       c = rng.integers(1, 40000, n).astype(np.int32)
       got = ops.kv_variable_gather_or_insert_with_counts(var.h, ids, c).cpu().numpy()
-      np.testing.assert_allclose(got, var.o.gather_or_insert(ids, c), rtol=1e-4, atol=1e-6, err_msg=tag)
+      np.testing.assert_allclose(got, var.o.gather_or_insert(ids, c), rtol=RTOL, atol=ATOL, err_msg=tag)
     elif op == "apply":
       g = (rng.uniform(0.5, 1.5, (n, D)) * 1e-2 * rng.choice([-1.0, 1.0], (1, D))).astype(np.float32)
       u, s, _ = ko.dedup_segment_sum(ids, g)
       if opt == "adam":
-        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, g, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
         ko.apply_group_adam(var.o, sl[0].o, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8)
         b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
       elif opt == "adagrad":
-        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, g, ids, use_locking=True)
+        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, s, u, use_locking=True)
         ko.apply_adagrad(var.o, sl[0].o, 0.05, s, u)
       else:
-        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, g, ids, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
+        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
         ko.apply_sparse_group_ftrl(var.o, sl[0].o, sl[1].o, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
     elif op == "scatter":
       uids = np.unique(ids)
@@ -130,7 +135,10 @@ def test_large_batches_match_oracle(ops, n, keyspace, D):
   for step in range(3):
     ids = rng.integers(-keyspace, keyspace, n)
     got = ops.kv_variable_gather_or_insert_v2(var.h, ids).cpu().numpy()
-    np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=1e-4, atol=2e-5)
+    # ids repeat up to ~n / keyspace x 2048 times and the fused reduce sums them in another order than TF-core:
+    # one-signed gradients keep |sum| ~ sum|g|, where (count - 1) 2^-24 relative on the sum moves an Adam step by
+    # far less than 1e-6 of the row; the allowance below is for the sum itself re-entering m and v
+    np.testing.assert_allclose(got, var.o.gather_or_insert(ids), rtol=1e-5, atol=1e-6)
     g = (rng.uniform(0.5, 1.5, (n, D)) * 1e-2 * rng.choice([-1.0, 1.0], (1, D))).astype(np.float32)
     ops.kv_variable_group_sparse_apply_adam_v4(var.h, slot.h, g, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
     u, s, _ = ko.dedup_segment_sum(ids, g)

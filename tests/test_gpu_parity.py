@@ -473,3 +473,36 @@ def test_full_size_batch_properties(ops):
   k, vals = ops.read_kv_variable_op_v2(h)
   assert k.numel() == uniq.numel() and torch.equal(torch.sort(k).values, uniq)
   assert torch.equal(ops.kv_variable_gather_or_zeros_v2(h, k), vals)
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic reduction mode (kv_set_deterministic): the same batch gives bit-identical state
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [8, 32, 64])
+def test_deterministic_mode_is_bit_reproducible(ops, D):
+  rng = np.random.default_rng(77 + D)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  N = 300_000
+  ids = torch.from_numpy(_zipf_ids(rng, N, 40_000)).cuda()
+  grads = [torch.from_numpy(rng.normal(0, 1e-2, (N, D)).astype(np.float32)).cuda() for _ in range(2)]   # two-signed
+  states = []
+  for rep in range(3):
+    hv = ops.kv_variable([D]); hs = ops.kv_variable([3 * D])
+    for h, t in ((hv, table), (hs, np.zeros((4, 3 * D), np.float32))):
+      ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 5); ops.init_kv_variable_v2(h, t)
+      ops.kv_set_deterministic(h, True)
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for g in grads:
+      if rep < 2:
+        out = ops.kv_variable_gather_or_insert_v2(hv, ids)          # batch token path
+        ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, g, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+      else:                                                          # the apply builds the index itself
+        ops.kv_variable_gather_or_insert_v2(hv, ids.clone())
+        ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, g, ids.clone(), 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+      b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+    u = torch.unique(ids)
+    states.append((ops.kv_variable_gather_or_zeros_v2(hv, u), ops.kv_variable_gather_or_zeros_v2(hs, u)))
+  for x, y in zip(states[0], states[1]):
+    assert torch.equal(x, y)                                         # run to run
+  for x, y in zip(states[0], states[2]):
+    assert torch.equal(x, y)                                         # with and without the lookup's index

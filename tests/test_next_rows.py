@@ -128,8 +128,16 @@ def test_import_export_parity(ops):
     assert sorted(gk) == sorted(ok) and sorted(gb) == sorted(ob)
     assert dict(zip(gfk, gfv.view(np.uint32))) == dict(zip(ofk, ofv))
     got, exp = dict(zip(gk, gv)), dict(zip(ok, ovv))
-    for k in ok:
-      np.testing.assert_allclose(got[k], exp[k], rtol=1e-3, atol=1e-8)  # group-lasso scale amplifies ulps (see test_gpu_parity)
+    # x = u (1 - l21n / ||u||) / y: the norm's fp32 reduction order (sequential in the oracle, a shuffle tree on the
+    # GPU) moves ||u|| by an ulp, which the subtraction amplifies by 1 / scale — tolerance per row = 1e-6 / scale,
+    # as in test_gpu_parity.py::test_group_adam_parity_with_regularizers_and_blacklist; nothing else is allowed
+    lr, l1s, l21n = np.float32(0.05), np.float32(1e-4 * 0.05), np.float32(5e-3 * 0.05) * np.sqrt(np.float32(D))
+    z = oz.gather_or_zeros(ok)[:, 2 * D:]
+    nrm = np.sqrt(((np.clip(z, -l1s, l1s) - z).astype(np.float64) ** 2).sum(1))
+    scale = np.abs(1.0 - l21n / np.maximum(nrm, 1e-30))
+    for k, sc in zip(ok, scale):
+      if sc > 1e-4:      # rows closer than that to the blacklist threshold may legitimately flip
+        np.testing.assert_allclose(got[k], exp[k], rtol=1e-6 / sc, atol=1e-9)
   assert len(gb) > 20 and len(gk) > 20                # both populations present
   # import what the GPU exported into a fresh GPU table and into a fresh oracle table
   h2 = ops.kv_variable([D], enter_threshold=2); ops.kv_set_clock_days(h2, DAY)
@@ -187,6 +195,28 @@ def test_scatter_add_sub_repeated_ids_accumulate(ops, op):
   q = np.arange(-20, 20)
   np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q),
                              rtol=2e-6, atol=1e-6)
+  assert ops.kv_variable_frequency(h) == o.sum_freq()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", [3, 4, 5, 6])               # ScatterMul / Div / Min / Max
+def test_scatter_mul_div_min_max_repeated_ids_apply_every_occurrence(ops, op):
+  """Every occurrence of a repeated id counts for every operation (kv_variable.h:616-734 walks the indices);
+  min / max are exact whatever the order, mul / div multiply the same factors in another order."""
+  h, o = _pair(ops, 16)
+  rng = np.random.default_rng(23 + op)
+  ids = rng.integers(-20, 20, 400)                          # ~10 occurrences per id
+  ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+  upd = rng.uniform(0.9, 1.1, (ids.size, 16)).astype(np.float32)
+  [None, None, None, ops.kv_variable_scatter_mul_v2, ops.kv_variable_scatter_div_v2, ops.kv_variable_scatter_min_v2,
+   ops.kv_variable_scatter_max_v2][op](h, ids, upd)
+  o.scatter_update(ids, upd, op)
+  q = np.arange(-20, 20)
+  got, exp = ops.kv_variable_gather_or_zeros_v2(h, q).cpu().numpy(), o.gather_or_zeros(q)
+  if op >= 5:
+    np.testing.assert_array_equal(got, exp)                 # min / max: bit-exact
+  else:
+    np.testing.assert_allclose(got, exp, rtol=2e-6, atol=0)  # ~10 roundings of a product, taken in another order
   assert ops.kv_variable_frequency(h) == o.sum_freq()
 
 
