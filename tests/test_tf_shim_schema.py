@@ -1,0 +1,78 @@
+"""The TF custom-op shim (tfplus_amd/tf_shim/kv_variable_ops_hip.cc) cannot be compiled in this image (no
+TensorFlow headers), so its op SCHEMAS — the drop-in interface: op name, inputs and outputs in order, attr names,
+types and defaults, statefulness — are checked here as text against the reference's own REGISTER_OP blocks
+(tfplus/kv_variable/ops/*.cc), read at test time; nothing of the reference is stored in this repository.
+Skipped where the reference tree is absent (the GPU box)."""
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tfplus_amd", "tf_shim", "kv_variable_ops_hip.cc")
+REF_OPS = "/root/reference/tfplus/kv_variable/ops"
+
+# every op of SURVEY.md §8(b) and the "next" rows the shim also covers
+REQUIRED = ["KvVariable", "KvVariableV2", "KvVariableV3", "KvVariableV4", "InitKvVariableV2", "KvVariableIsInitializedV2",
+            "KvVariableShapeV2", "KvVariableSizeV2", "KvVariableFrequency", "ReadKvVariableOpV2", "DestroyKvVariableOpV2",
+            "KvVariableGatherOrInsertV2", "KvVariableGatherOrInsertWithCounts", "KvVariableGatherOrZerosV2",
+            "KvVariableGroupSparseApplyAdamV4", "KvVariableGroupSparseApplyAdamV3", "KvVariableSparseApplyAdagrad",
+            "KvVariableSparseGroupSparseApplyFtrlV2", "KvVariableInsertV2", "KvVariableScatterUpdateV2",
+            "KvVariableScatterAddV2", "KvVariableScatterSubV2", "KvVariableScatterMulV2", "KvVariableScatterDivV2",
+            "KvVariableScatterMinV2", "KvVariableScatterMaxV2"]
+
+
+def _strip_comments(text):
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return re.sub(r"//[^\n]*", "", text)
+
+
+def _schemas(text):
+  """{op name: [(kind, spec), ...]} with kind in Input / Output / Attr / SetIsStateful, in source order."""
+  text = _strip_comments(text)
+  out = {}
+  for m in re.finditer(r'REGISTER_OP\(\s*"(\w+)"\s*\)', text):
+    i, depth, end = m.end(), 0, None
+    while i < len(text):          # the statement ends at the first ';' outside parentheses / braces
+      c = text[i]
+      if c in "({":
+        depth += 1
+      elif c in ")}":
+        depth -= 1
+      elif c == ";" and depth == 0:
+        end = i
+        break
+      i += 1
+    body = text[m.end():end]
+    items = []
+    for k in re.finditer(r'\.(Input|Output|Attr)\(\s*((?:"[^"]*"\s*)+)\)|\.(SetIsStateful)\(\)', body):
+      if k.group(3):
+        items.append(("SetIsStateful", ""))
+      else:
+        spec = "".join(re.findall(r'"([^"]*)"', k.group(2)))     # adjacent string literals concatenate
+        items.append((k.group(1), re.sub(r"\s+", " ", spec.strip())))
+    out[m.group(1)] = items
+  return out
+
+
+def test_shim_registers_every_hot_path_op():
+  ours = _schemas(open(SHIM).read())
+  missing = [n for n in REQUIRED if n not in ours]
+  assert not missing, missing
+  # every REGISTER_OP of the shim has at least one kernel registered for it
+  text = _strip_comments(open(SHIM).read())
+  built = set(re.findall(r'Name\(\s*"(\w+)"\s*\)', text)) | set(re.findall(r'KV_REGISTER_\w+\(\s*"(\w+)"', text))
+  assert set(ours) <= built, sorted(set(ours) - built)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OPS), reason="reference tree not present")
+def test_shim_schemas_equal_the_reference():
+  ref = {}
+  for f in sorted(glob.glob(os.path.join(REF_OPS, "*.cc"))):
+    ref.update(_schemas(open(f).read()))
+  ours = _schemas(open(SHIM).read())
+  assert len(ours) >= len(REQUIRED)
+  for name, items in ours.items():
+    assert name in ref, "the reference registers no op named %s" % name
+    assert items == ref[name], "%s:\n  shim      %s\n  reference %s" % (name, items, ref[name])

@@ -1,16 +1,24 @@
-// kv_variable_ops_hip.cc — TensorFlow custom-op shim over libkvhip.so (include/kvhip.h).
+// kv_variable_ops_hip.cc — TensorFlow custom-op plug-in over libkvhip.so (include/kvhip.h).
 //
-// NOT built in this repository's image (no TensorFlow headers there; see INTEGRATION.md for the
-// build line).  It re-registers the reference's op names with identical input order, attrs and
-// shape functions (tfplus/kv_variable/ops/kv_variable_ops.cc:37-74,212-222,285-332;
-// ops/training_ops.cc:135-150,214-226,1086-1105,1266-1285) and forwards each Compute() to one C
-// ABI call, so `tfplus.kv_variable.python.*` works unchanged on top of it.  All semantics live
-// behind the C ABI; this file only moves tensors: tensorflow-cpu keeps tensors in host memory, so
-// they are staged through HBM (pinned staging would be the next step; DESIGN.md §4 gives the PCIe
-// bound).  A TF build with a ROCm device would pass tensor.data() straight through instead.
+// Built where TensorFlow 2.13 headers exist (INTEGRATION.md has the build line; this repository's image
+// has none, so tests/test_tf_shim_schema.py checks the op schemas below against the reference's
+// REGISTER_OP text instead of compiling them).  Every op of the hot path is registered with
+// the reference's name, input order, attr names and defaults:
+//   tfplus/kv_variable/ops/kv_variable_ops.cc:37-201 (KvVariable, V2, V3, V4), :203-268 (shape / init / size /
+//   frequency / read / destroy), :285-344 (gathers, insert), :520-574 (scatter family);
+//   tfplus/kv_variable/ops/training_ops.cc:135-150, 214-226, 1086-1105, 1266-1285 (FtrlV2, Adagrad, GroupAdam V3/V4)
+// and forwards Compute() to one C-ABI call.  All semantics live behind the C ABI; this file only moves
+// tensors.  tensorflow-cpu keeps tensors in host memory, so they cross PCIe through a per-resource ring of
+// pinned staging buffers (no allocation per call once warm; DESIGN.md §4 gives the PCIe bound); a TF build
+// with a ROCm device would hand tensor.data() straight to the C ABI instead.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 #include "kvhip.h"
+#include "tensorflow/core/framework/common_shape_fns.h"
 #include "tensorflow/core/framework/op.h"
 #include "tensorflow/core/framework/op_kernel.h"
 #include "tensorflow/core/framework/resource_mgr.h"
@@ -18,34 +26,160 @@
 
 namespace tfplus_hip {
 using namespace tensorflow;  // NOLINT
-
-// The resource the handle points at: owns one kv_handle_t.
-class KvHipResource : public ResourceBase {
- public:
-  explicit KvHipResource(kv_handle_t h, int dim) : h_(h), dim_(dim) {}
-  ~KvHipResource() override { kv_destroy(h_); }
-  string DebugString() const override { return "KvHipResource"; }
-  kv_handle_t h() const { return h_; }
-  int dim() const { return dim_; }
-
- private:
-  kv_handle_t h_;
-  int dim_;
-};
+using shape_inference::InferenceContext;
+using shape_inference::ShapeAndType;
+using shape_inference::ShapeHandle;
 
 static Status FromKv(int rc) {
   if (rc == KV_OK) return OkStatus();
   return Status(static_cast<tsl::error::Code>(rc), kv_last_error());
 }
+static Status FromHip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return OkStatus();
+  return errors::Internal(what, ": ", hipGetErrorString(e));
+}
+#define HIP_OK(ctx, expr) OP_REQUIRES_OK(ctx, FromHip((expr), #expr))
+#define HIP_RET(expr)                                 \
+  do {                                                \
+    Status _s = FromHip((expr), #expr);               \
+    if (!_s.ok()) return _s;                          \
+  } while (0)
 
-// device staging buffer that frees itself
-struct DevBuf {
-  void* p = nullptr;
-  explicit DevBuf(size_t bytes) { if (bytes) hipMalloc(&p, bytes); }
-  ~DevBuf() { if (p) hipFree(p); }
+// Ring of pinned host + device staging buffers.  A slot is reused only after the stream has passed the event
+// recorded behind its last use; buffers grow geometrically and are never freed before the resource dies.
+class StagingRing {
+ public:
+  struct Slot {
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+  };
+  ~StagingRing() {
+    for (Slot& s : slots_) {
+      if (s.done) { hipEventSynchronize(s.done); hipEventDestroy(s.done); }
+      if (s.host) hipHostFree(s.host);
+      if (s.dev) hipFree(s.dev);
+    }
+  }
+  // a slot with room for `bytes` on both sides (waits for the slot's previous user)
+  Status Acquire(size_t bytes, Slot** out) {
+    Slot& s = slots_[cursor_++ % kSlots];
+    if (s.done) HIP_RET(hipEventSynchronize(s.done));
+    if (s.cap < bytes) {
+      size_t cap = s.cap ? s.cap : (1u << 20);
+      while (cap < bytes) cap *= 2;
+      char *h = nullptr, *d = nullptr;
+      HIP_RET(hipHostMalloc(reinterpret_cast<void**>(&h), cap));
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), cap);
+      if (e != hipSuccess) { hipHostFree(h); return FromHip(e, "hipMalloc(staging)"); }
+      if (s.host) hipHostFree(s.host);
+      if (s.dev) hipFree(s.dev);
+      s.host = h; s.dev = d; s.cap = cap;
+    }
+    if (!s.done) HIP_RET(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    *out = &s;
+    return OkStatus();
+  }
+  // host tensor -> device (asynchronous; the slot stays busy until Release)
+  static Status Upload(Slot* s, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return OkStatus();
+    std::memcpy(s->host, src, bytes);
+    HIP_RET(hipMemcpyAsync(s->dev, s->host, bytes, hipMemcpyHostToDevice, st));
+    return OkStatus();
+  }
+  // device -> host tensor (synchronous: the op's output must be complete when Compute returns)
+  static Status Download(Slot* s, void* dst, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return OkStatus();
+    HIP_RET(hipMemcpyAsync(s->host, s->dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_RET(hipStreamSynchronize(st));
+    std::memcpy(dst, s->host, bytes);
+    return OkStatus();
+  }
+  static Status Release(Slot* s, hipStream_t st) { return FromHip(hipEventRecord(s->done, st), "hipEventRecord"); }
+
+ private:
+  static constexpr int kSlots = 6;
+  Slot slots_[kSlots];
+  unsigned cursor_ = 0;
 };
 
-// ---- KvVariable (handle creation) : kernels/kv_variable_ops.cc:31-125 -------------------------
+// The resource the handle points at: owns one kv_handle_t, its stream and its staging ring.
+class KvHipResource : public ResourceBase {
+ public:
+  KvHipResource(kv_handle_t h, int dim, DataType key_dtype) : h_(h), dim_(dim), key_dtype_(key_dtype) {
+    hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+  }
+  ~KvHipResource() override {
+    if (stream_) hipStreamSynchronize(stream_);
+    kv_destroy(h_);
+    if (stream_) hipStreamDestroy(stream_);
+  }
+  string DebugString() const override { return "KvHipResource"; }
+  kv_handle_t h() const { return h_; }
+  int dim() const { return dim_; }
+  DataType key_dtype() const { return key_dtype_; }
+  hipStream_t stream() const { return stream_; }
+  StagingRing* ring() { return &ring_; }
+  std::mutex* mu() { return &mu_; }
+  // the batch a training lookup left behind (kv_gather_or_insert_tok): token + what identified the ids
+  kv_batch_token_t token = 0;
+  const void* token_ids = nullptr;
+  int64_t token_n = 0;
+  uint64_t token_sum = 0;
+
+ private:
+  kv_handle_t h_;
+  int dim_;
+  DataType key_dtype_;
+  hipStream_t stream_ = nullptr;
+  StagingRing ring_;
+  std::mutex mu_;   // one Compute at a time moves data through this resource's ring
+};
+
+// cheap content fingerprint of an ids tensor (the token is only passed on when the optimizer op receives the
+// very ids the lookup saw; TF-core's de-duplicated indices never match and take the general path)
+static uint64_t Fingerprint(const void* p, size_t bytes) {
+  const unsigned char* c = static_cast<const unsigned char*>(p);
+  uint64_t h = 1469598103934665603ull ^ bytes;
+  const size_t step = bytes > 4096 ? bytes / 512 : 1;
+  for (size_t i = 0; i < bytes; i += step) h = (h ^ c[i]) * 1099511628211ull;
+  return h;
+}
+
+static Status KeyTypeMatches(const KvHipResource* r, const Tensor& ids) {
+  const DataType t = ids.dtype();
+  const bool ok = (r->key_dtype() == DT_INT32 && t == DT_INT32) ||
+                  (r->key_dtype() != DT_INT32 && (t == DT_INT64 || t == DT_UINT64));
+  if (!ok) return errors::InvalidArgument("indices dtype ", DataTypeString(t), " does not match the table's key dtype ",
+                                          DataTypeString(r->key_dtype()));
+  return OkStatus();
+}
+
+// handle shape [?, value_shape...] and dtype on the resource output (ops/kv_variable_ops.cc:49-73)
+static Status KvVariableShapeFn(InferenceContext* c) {
+  c->set_output(0, c->Scalar());
+  DataType dtype;
+  TF_RETURN_IF_ERROR(c->GetAttr("value_dtype", &dtype));
+  PartialTensorShape shape;
+  TF_RETURN_IF_ERROR(c->GetAttr("value_shape", &shape));
+  if (shape.dims() == 0) return shape_inference::UnknownShape(c);
+  shape.InsertDim(0, InferenceContext::kUnknownDim);
+  ShapeHandle output_shape;
+  TF_RETURN_IF_ERROR(c->MakeShapeFromPartialTensorShape(shape, &output_shape));
+  c->set_output_handle_shapes_and_types(0, std::vector<ShapeAndType>{{output_shape, dtype}});
+  return OkStatus();
+}
+static Status ScalarOutput(InferenceContext* c) {
+  c->set_output(0, c->Scalar());
+  return OkStatus();
+}
+static Status UnknownOutput(InferenceContext* c) {
+  c->set_output(0, c->UnknownShape());
+  return OkStatus();
+}
+
+// ---- KvVariable / V2 / V3 / V4 : ops/kv_variable_ops.cc:37-201, kernels/kv_variable_ops.cc:31-125 ---------
 REGISTER_OP("KvVariable")
     .Output("table_handle: resource")
     .Attr("container: string = ''")
@@ -57,35 +191,93 @@ REGISTER_OP("KvVariable")
     .Attr("value_shape: shape")
     .Attr("enter_threshold: int = 0")
     .SetIsStateful()
-    .SetShapeFn(shape_inference::ScalarShape);
+    .SetShapeFn(KvVariableShapeFn);
+
+REGISTER_OP("KvVariableV2")
+    .Output("table_handle: resource")
+    .Attr("container: string = ''")
+    .Attr("shared_name: string = ''")
+    .Attr("use_node_name_sharing: bool = false")
+    .Attr("key_dtype: type")
+    .Attr("value_dtype: type")
+    .Attr("key_shape: shape = {}")
+    .Attr("value_shape: shape")
+    .Attr("initial_num_buckets: int = 131072")
+    .Attr("max_load_factor: float = 0.8")
+    .Attr("enter_threshold: int = 5")
+    .Attr("total_iteration: int = 100000")
+    .Attr("worker_num: int = 16")
+    .SetIsStateful()
+    .SetShapeFn(KvVariableShapeFn);
+
+REGISTER_OP("KvVariableV3")
+    .Output("table_handle: resource")
+    .Attr("container: string = ''")
+    .Attr("shared_name: string = ''")
+    .Attr("use_node_name_sharing: bool = false")
+    .Attr("key_dtype: type")
+    .Attr("value_dtype: type")
+    .Attr("key_shape: shape = {}")
+    .Attr("value_shape: shape")
+    .Attr("enter_threshold: int = 0")
+    .Attr("phstore_path: string = ''")
+    .SetIsStateful()
+    .SetShapeFn(KvVariableShapeFn);
+
+REGISTER_OP("KvVariableV4")
+    .Output("table_handle: resource")
+    .Attr("container: string = ''")
+    .Attr("shared_name: string = ''")
+    .Attr("use_node_name_sharing: bool = false")
+    .Attr("key_dtype: type")
+    .Attr("value_dtype: type")
+    .Attr("key_shape: shape = {}")
+    .Attr("value_shape: shape")
+    .Attr("storage_option: string")
+    .Attr("enter_threshold: int = 0")
+    .SetIsStateful()
+    .SetShapeFn(KvVariableShapeFn);
 
 class CreateKvVariableHipOp : public OpKernel {
  public:
   explicit CreateKvVariableHipOp(OpKernelConstruction* c) : OpKernel(c) {
     OP_REQUIRES_OK(c, c->GetAttr("use_node_name_sharing", &use_node_name_sharing_));
     OP_REQUIRES_OK(c, c->GetAttr("key_dtype", &key_dtype_));
+    OP_REQUIRES_OK(c, c->GetAttr("value_dtype", &value_dtype_));
     OP_REQUIRES_OK(c, c->GetAttr("enter_threshold", &enter_threshold_));
     OP_REQUIRES_OK(c, c->GetAttr("value_shape", &value_shape_));
+    OP_REQUIRES(c, key_dtype_ == DT_INT32 || key_dtype_ == DT_INT64 || key_dtype_ == DT_UINT64,
+                errors::InvalidArgument("key_dtype must be int32, int64 or uint64"));   // kernels/kv_variable_ops.cc:149-156
+    OP_REQUIRES(c, value_dtype_ == DT_FLOAT,
+                errors::Unimplemented("value_dtype: only float has optimizer kernels (kernels/training_ops.cc:7232)"));
   }
   void Compute(OpKernelContext* ctx) override {
     mutex_lock l(mu_);
     if (!set_) {
       OP_REQUIRES_OK(ctx, cinfo_.Init(ctx->resource_manager(), def(), use_node_name_sharing_));
       KvHipResource* res = nullptr;
-      const int dim = value_shape_.num_elements();
+      const int dim = static_cast<int>(value_shape_.num_elements());
+      const DataType kd = key_dtype_;
+      const int thr = enter_threshold_;
       OP_REQUIRES_OK(ctx, cinfo_.resource_manager()->LookupOrCreate<KvHipResource>(
-                              cinfo_.container(), cinfo_.name(), &res, [&](KvHipResource** out) {
-                                kv_handle_t h;
-                                TF_RETURN_IF_ERROR(FromKv(kv_create(key_dtype_, KV_DT_FLOAT, dim,
-                                                                    enter_threshold_, 0, 0, &h)));
-                                *out = new KvHipResource(h, dim);
+                              cinfo_.container(), cinfo_.name(), &res, [dim, kd, thr](KvHipResource** out) {
+                                int dev = 0;
+                                TF_RETURN_IF_ERROR(FromHip(hipGetDevice(&dev), "hipGetDevice"));
+                                kv_handle_t h = nullptr;
+                                TF_RETURN_IF_ERROR(FromKv(kv_create(static_cast<int>(kd), KV_DT_FLOAT, dim, thr, 0, dev, &h)));
+                                // the constructor's environment switches (kernels/kv_variable.h:100-111)
+                                const char* d = std::getenv("SUPPORT_DELTA_EXPORT");
+                                const char* p = std::getenv("SUPPORT_PREDICTION_DELTA_EXPORT");
+                                const bool dd = d && std::strcmp(d, "1") == 0, pp = p && std::strcmp(p, "1") == 0;
+                                if (dd || pp) TF_RETURN_IF_ERROR(FromKv(kv_set_delta_tracking(h, dd, pp)));
+                                *out = new KvHipResource(h, dim, kd);
                                 return OkStatus();
                               }));
       core::ScopedUnref unref(res);
       handle_ = MakeResourceHandle<KvHipResource>(ctx, cinfo_.container(), cinfo_.name());
       set_ = true;
     }
-    Tensor* out;
+    Tensor* out = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &out));
     out->scalar<ResourceHandle>()() = handle_;
   }
@@ -93,143 +285,578 @@ class CreateKvVariableHipOp : public OpKernel {
  private:
   mutex mu_;
   bool set_ = false, use_node_name_sharing_ = false;
-  DataType key_dtype_;
+  DataType key_dtype_, value_dtype_;
   int enter_threshold_ = 0;
   TensorShape value_shape_;
   ContainerInfo cinfo_;
   ResourceHandle handle_;
 };
 REGISTER_KERNEL_BUILDER(Name("KvVariable").Device(DEVICE_CPU), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV2").Device(DEVICE_CPU), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV3").Device(DEVICE_CPU), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV4").Device(DEVICE_CPU), CreateKvVariableHipOp);
 
-// ---- InitKvVariableV2 : kernels/kv_variable_ops.cc:188-200 -------------------------------------
+// every kernel below starts the same way
+#define KV_RESOURCE(ctx, index, var)                                          \
+  KvHipResource* var = nullptr;                                               \
+  OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, index), &var)); \
+  core::ScopedUnref unref_##var(var)
+
+// ---- KvVariableShapeV2 : ops :203-210, kernels/kv_variable_ops.cc:159-177 -------------------------------
+REGISTER_OP("KvVariableShapeV2")
+    .Input("table_handle: resource")
+    .Output("output: out_type")
+    .Attr("out_type: {int32, int64} = DT_INT32")
+    .SetShapeFn([](InferenceContext* c) {
+      c->set_output(0, c->Vector(InferenceContext::kUnknownDim));
+      return OkStatus();
+    });
+
+template <typename T>
+class KvShapeHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    int64_t rows = 0;
+    OP_REQUIRES_OK(ctx, FromKv(kv_map_size(r->h(), &rows, r->stream())));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({2}), &out));
+    out->vec<T>()(0) = static_cast<T>(rows);
+    out->vec<T>()(1) = static_cast<T>(r->dim());
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableShapeV2").Device(DEVICE_CPU).TypeConstraint<int32>("out_type"), KvShapeHipOp<int32>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableShapeV2").Device(DEVICE_CPU).TypeConstraint<int64_t>("out_type"), KvShapeHipOp<int64_t>);
+
+// ---- InitKvVariableV2 : ops :212-222, kernels/kv_variable_ops.cc:188-200 ---------------------------------
 REGISTER_OP("InitKvVariableV2")
     .Input("table_handle: resource")
     .Input("random_initializer: T")
     .Attr("T: type")
-    .SetShapeFn(shape_inference::NoOutputs);
+    .SetShapeFn([](InferenceContext* c) {
+      ShapeHandle handle;
+      TF_RETURN_IF_ERROR(c->WithRank(c->input(1), 2, &handle));   // the second input must be 2-D
+      return OkStatus();
+    });
 
 class InitKvVariableHipOp : public OpKernel {
  public:
   using OpKernel::OpKernel;
   void Compute(OpKernelContext* ctx) override {
-    KvHipResource* r;
-    OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &r));
-    core::ScopedUnref unref(r);
+    KV_RESOURCE(ctx, 0, r);
     const Tensor& t = ctx->input(1);
-    DevBuf d(t.TotalBytes());
-    hipMemcpy(d.p, t.data(), t.TotalBytes(), hipMemcpyHostToDevice);
-    OP_REQUIRES_OK(ctx, FromKv(kv_init_table(r->h(), static_cast<const float*>(d.p), t.dim_size(0), nullptr)));
-    hipDeviceSynchronize();
+    OP_REQUIRES(ctx, t.dtype() == DT_FLOAT, errors::InvalidArgument("random_initializer must be float"));
+    OP_REQUIRES(ctx, t.dims() == 2 && t.dim_size(1) == r->dim(),
+                errors::InvalidArgument("random_initializer must be [rows, ", r->dim(), "]"));
+    std::lock_guard<std::mutex> l(*r->mu());
+    StagingRing::Slot* s = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(t.TotalBytes(), &s));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(s, t.data(), t.TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, FromKv(kv_init_table(r->h(), reinterpret_cast<const float*>(s->dev), t.dim_size(0), r->stream())));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(s, r->stream()));
   }
 };
 REGISTER_KERNEL_BUILDER(Name("InitKvVariableV2").Device(DEVICE_CPU), InitKvVariableHipOp);
 
-// ---- KvVariableGatherOrInsertV2 / GatherOrZerosV2 : kernels/kv_variable_ops.cc:348-538 ---------
-#define KV_GATHER_OP(NAME)                                                        \
-  REGISTER_OP(NAME)                                                               \
-      .Input("table_handle: resource")                                            \
-      .Input("indices: Tindices")                                                 \
-      .Output("output: dtype")                                                    \
-      .Attr("dtype: type")                                                        \
-      .Attr("Tindices: {int32, int64, uint64, string}")                           \
-      .SetShapeFn([](shape_inference::InferenceContext* c) {                      \
-        c->set_output(0, c->UnknownShape());                                      \
-        return OkStatus();                                                        \
-      })
-KV_GATHER_OP("KvVariableGatherOrInsertV2");
-KV_GATHER_OP("KvVariableGatherOrZerosV2");
+// ---- IsInitialized / Size / Frequency : ops :224-247, kernels/kv_variable_ops.cc:202-293 ---------------
+REGISTER_OP("KvVariableIsInitializedV2")
+    .Input("table_handle: resource")
+    .Output("is_initialized: bool")
+    .SetShapeFn(ScalarOutput);
 
-template <bool INSERT>
+class KvIsInitializedHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &out));
+    KvHipResource* r = nullptr;
+    if (!LookupResource(ctx, HandleFromInput(ctx, 0), &r).ok()) {   // no resource yet: not initialized (:207-213)
+      out->scalar<bool>()() = false;
+      return;
+    }
+    core::ScopedUnref unref(r);
+    int v = 0;
+    OP_REQUIRES_OK(ctx, FromKv(kv_is_initialized(r->h(), &v)));
+    out->scalar<bool>()() = v != 0;
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableIsInitializedV2").Device(DEVICE_CPU), KvIsInitializedHipOp);
+
+REGISTER_OP("KvVariableSizeV2")
+    .Input("table_handle: resource")
+    .Output("size: T")
+    .Attr("T: {int32, int64} = DT_INT64")
+    .SetShapeFn(ScalarOutput);
+
+REGISTER_OP("KvVariableFrequency")
+    .Input("table_handle: resource")
+    .Output("size: T")
+    .Attr("T: {int32, int64} = DT_INT64")
+    .SetShapeFn(ScalarOutput);
+
+template <typename T, bool FREQ>
+class KvSizeHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    int64_t v = 0;
+    OP_REQUIRES_OK(ctx, FromKv(FREQ ? kv_sum_freq(r->h(), &v, r->stream()) : kv_size(r->h(), &v, r->stream())));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &out));
+    out->scalar<T>()() = static_cast<T>(v);
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int32>("T"), (KvSizeHipOp<int32, false>));
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), (KvSizeHipOp<int64_t, false>));
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int32>("T"), (KvSizeHipOp<int32, true>));
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), (KvSizeHipOp<int64_t, true>));
+
+// ---- ReadKvVariableOpV2 : ops :249-266, kernels/kv_variable_ops.cc:325-346 -> ExportValues(first_n = 2) ---
+REGISTER_OP("ReadKvVariableOpV2")
+    .Input("table_handle: resource")
+    .Output("keys: Tkeys")
+    .Output("values: Tvalues")
+    .Attr("Tkeys: type")
+    .Attr("Tvalues: type")
+    .SetShapeFn([](InferenceContext* c) {
+      ShapeHandle handle;
+      TF_RETURN_IF_ERROR(c->WithRank(c->input(0), 0, &handle));
+      ShapeHandle values = c->UnknownShape();
+      TF_RETURN_IF_ERROR(c->WithRankAtLeast(values, 1, &values));
+      c->set_output(0, c->Vector(c->Dim(values, 0)));
+      c->set_output(1, values);
+      return OkStatus();
+    });
+
+class ReadKvVariableHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    OP_REQUIRES(ctx, r->key_dtype() != DT_INT32, errors::Unimplemented("ReadKvVariableOpV2 with int32 keys"));
+    std::lock_guard<std::mutex> l(*r->mu());
+    int64_t counts[3] = {0, 0, 0};
+    OP_REQUIRES_OK(ctx, FromKv(kv_export_count(r->h(), 2, counts, r->stream())));
+    const int64_t m = counts[0];
+    Tensor *keys = nullptr, *values = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({m}), &keys));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({m, r->dim()}), &values));
+    if (m == 0) return;
+    StagingRing::Slot *sk = nullptr, *sv = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(keys->TotalBytes(), &sk));
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(values->TotalBytes(), &sv));
+    // the table cannot change between the two calls: this resource's mutex is held, and every op that writes
+    // the table goes through a kernel of this file
+    OP_REQUIRES_OK(ctx, FromKv(kv_export_fill(r->h(), 2, reinterpret_cast<int64_t*>(sk->dev), reinterpret_cast<float*>(sv->dev),
+                                              nullptr, nullptr, nullptr, r->stream())));
+    OP_REQUIRES_OK(ctx, StagingRing::Download(sk, keys->data(), keys->TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Download(sv, values->data(), values->TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(sk, r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(sv, r->stream()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("ReadKvVariableOpV2").Device(DEVICE_CPU), ReadKvVariableHipOp);
+
+// ---- DestroyKvVariableOpV2 : ops :268-272, kernels/kv_variable_ops.cc:295-323 ----------------------------
+REGISTER_OP("DestroyKvVariableOpV2")
+    .Input("table_handle: resource")
+    .Attr("ignore_lookup_error: bool = true")
+    .SetIsStateful()
+    .SetShapeFn(shape_inference::NoOutputs);
+
+class DestroyKvVariableHipOp : public OpKernel {
+ public:
+  explicit DestroyKvVariableHipOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("ignore_lookup_error", &ignore_lookup_error_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Status s = DeleteResource(ctx, HandleFromInput(ctx, 0));
+    if (ignore_lookup_error_ && errors::IsNotFound(s)) return;
+    OP_REQUIRES_OK(ctx, s);
+  }
+
+ private:
+  bool ignore_lookup_error_ = true;
+};
+REGISTER_KERNEL_BUILDER(Name("DestroyKvVariableOpV2").Device(DEVICE_CPU), DestroyKvVariableHipOp);
+
+// ---- lookups : ops :285-332, kernels/kv_variable_ops.cc:348-405, 498-538, 564-606 ------------------------
+REGISTER_OP("KvVariableGatherOrZerosV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Output("output: dtype")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+REGISTER_OP("KvVariableGatherOrInsertV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Output("output: dtype")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+REGISTER_OP("KvVariableGatherOrInsertWithCounts")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("counts: int32")
+    .Output("output: dtype")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+// MODE 0 = GatherOrZeros, 1 = GatherOrInsert, 2 = GatherOrInsertWithCounts
+template <int MODE>
 class KvGatherHipOp : public OpKernel {
  public:
   using OpKernel::OpKernel;
   void Compute(OpKernelContext* ctx) override {
-    KvHipResource* r;
-    OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &r));
-    core::ScopedUnref unref(r);
+    KV_RESOURCE(ctx, 0, r);
     const Tensor& ids = ctx->input(1);
+    OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
     TensorShape shape = ids.shape();
-    shape.AddDim(r->dim());
-    Tensor* out;
+    shape.AddDim(r->dim());                               // output shape = indices.shape + [dim] (kernels :516-522)
+    Tensor* out = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, shape, &out));
     const int64_t n = ids.NumElements();
-    if (n == 0) return;
-    DevBuf d_ids(ids.TotalBytes()), d_out(out->TotalBytes());
-    hipMemcpy(d_ids.p, ids.data(), ids.TotalBytes(), hipMemcpyHostToDevice);
-    const int rc = INSERT ? kv_gather_or_insert(r->h(), d_ids.p, nullptr, n, static_cast<float*>(d_out.p), nullptr)
-                          : kv_gather_or_zeros(r->h(), d_ids.p, n, static_cast<float*>(d_out.p), nullptr);
+    if (n == 0) return;                                   // :530-532
+    const Tensor* counts = nullptr;
+    if (MODE == 2) {
+      counts = &ctx->input(2);
+      // kernels/kv_variable.h:268-280
+      OP_REQUIRES(ctx, counts->dtype() == DT_INT32, errors::InvalidArgument("increment count, counts dtype must be int32"));
+      OP_REQUIRES(ctx, counts->shape() == ids.shape(),
+                  errors::InvalidArgument("increment count, indices shape ", ids.shape().DebugString(),
+                                          " does not match with counts shape ", counts->shape().DebugString()));
+    }
+    std::lock_guard<std::mutex> l(*r->mu());
+    StagingRing::Slot *si = nullptr, *so = nullptr, *sc = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si));
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(out->TotalBytes(), &so));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(si, ids.data(), ids.TotalBytes(), r->stream()));
+    if (counts) {
+      OP_REQUIRES_OK(ctx, r->ring()->Acquire(counts->TotalBytes(), &sc));
+      OP_REQUIRES_OK(ctx, StagingRing::Upload(sc, counts->data(), counts->TotalBytes(), r->stream()));
+    }
+    int rc;
+    if (MODE == 0) {
+      rc = kv_gather_or_zeros(r->h(), si->dev, n, reinterpret_cast<float*>(so->dev), r->stream());
+    } else {
+      kv_batch_token_t tok = 0;
+      rc = kv_gather_or_insert_tok(r->h(), si->dev, sc ? reinterpret_cast<const int32_t*>(sc->dev) : nullptr, n,
+                                   reinterpret_cast<float*>(so->dev), &tok, r->stream());
+      r->token = tok; r->token_ids = si->dev; r->token_n = n;
+      r->token_sum = Fingerprint(ids.data(), ids.TotalBytes());
+    }
     OP_REQUIRES_OK(ctx, FromKv(rc));
-    hipMemcpy(out->data(), d_out.p, out->TotalBytes(), hipMemcpyDeviceToHost);
+    OP_REQUIRES_OK(ctx, StagingRing::Download(so, out->data(), out->TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(si, r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(so, r->stream()));
+    if (sc) OP_REQUIRES_OK(ctx, StagingRing::Release(sc, r->stream()));
   }
 };
-REGISTER_KERNEL_BUILDER(Name("KvVariableGatherOrInsertV2").Device(DEVICE_CPU).HostMemory("table_handle"),
-                        KvGatherHipOp<true>);
-REGISTER_KERNEL_BUILDER(Name("KvVariableGatherOrZerosV2").Device(DEVICE_CPU).HostMemory("table_handle"),
-                        KvGatherHipOp<false>);
+// table_handle is HostMemory like in the reference (kernels/kv_variable_ops.cc:540-546); string keys have no kernel
+#define KV_REGISTER_GATHER(NAME, MODE)                                                                                     \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int32>("Tindices")      \
+                              .TypeConstraint<float>("dtype"), KvGatherHipOp<MODE>);                                         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int64_t>("Tindices")    \
+                              .TypeConstraint<float>("dtype"), KvGatherHipOp<MODE>);                                         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<uint64>("Tindices")     \
+                              .TypeConstraint<float>("dtype"), KvGatherHipOp<MODE>)
+KV_REGISTER_GATHER("KvVariableGatherOrZerosV2", 0);
+KV_REGISTER_GATHER("KvVariableGatherOrInsertV2", 1);
+KV_REGISTER_GATHER("KvVariableGatherOrInsertWithCounts", 2);
 
-// ---- KvVariableGroupSparseApplyAdamV4 / V3 : kernels/training_ops.cc:5709-5965,6980-7213 --------
-#define KV_GROUP_ADAM_OP(NAME)                   \
-  REGISTER_OP(NAME)                              \
-      .Input("var: resource")                    \
-      .Input("m_v_linear: resource")             \
-      .Input("grad: T")                          \
-      .Input("indices: Tindices")                \
-      .Input("lr: T")                            \
-      .Input("beta1_power: T")                   \
-      .Input("beta2_power: T")                   \
-      .Input("beat1: T")                         \
-      .Input("beta2: T")                         \
-      .Input("epsilon: T")                       \
-      .Input("l1: T")                            \
-      .Input("l2: T")                            \
-      .Input("l21: T")                           \
-      .Attr("T: numbertype")                     \
-      .Attr("Tindices: {int32, int64, uint64, string}") \
-      .Attr("use_locking: bool = false")         \
-      .SetShapeFn(shape_inference::NoOutputs)
-KV_GROUP_ADAM_OP("KvVariableGroupSparseApplyAdamV4");
-KV_GROUP_ADAM_OP("KvVariableGroupSparseApplyAdamV3");
+// ---- KvVariableInsertV2 and the scatter family : ops :334-344, 520-574, kernels/kv_variable_ops.cc:703-747, 1097-1161
+REGISTER_OP("KvVariableInsertV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("values: dtype")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+
+// OP < 0: InsertOrUpdate; else the kv_scatter_update operation
+template <int OP>
+class KvScatterHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    const Tensor& ids = ctx->input(1);
+    const Tensor& vals = ctx->input(2);
+    OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
+    const int64_t n = ids.NumElements();
+    OP_REQUIRES(ctx, vals.dtype() == DT_FLOAT && vals.NumElements() == n * r->dim(),
+                errors::InvalidArgument("updates must be [indices..., ", r->dim(), "] float"));
+    if (n == 0) return;
+    std::lock_guard<std::mutex> l(*r->mu());
+    StagingRing::Slot *si = nullptr, *sv = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si));
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(vals.TotalBytes(), &sv));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(si, ids.data(), ids.TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(sv, vals.data(), vals.TotalBytes(), r->stream()));
+    const int rc = OP < 0 ? kv_insert(r->h(), si->dev, reinterpret_cast<const float*>(sv->dev), n, r->stream())
+                          : kv_scatter_update(r->h(), si->dev, reinterpret_cast<const float*>(sv->dev), n, OP, r->stream());
+    OP_REQUIRES_OK(ctx, FromKv(rc));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(si, r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(sv, r->stream()));
+    r->token = 0;
+  }
+};
+#define KV_REGISTER_SCATTER(NAME, OP)                                                                               \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int32>("Tindices") \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>);                                   \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int64_t>("Tindices") \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>);                                   \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<uint64>("Tindices") \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>)
+KV_REGISTER_SCATTER("KvVariableInsertV2", -1);
+
+REGISTER_OP("KvVariableScatterAddV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterAddV2", KV_SCATTER_ADD);
+
+REGISTER_OP("KvVariableScatterSubV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterSubV2", KV_SCATTER_SUB);
+
+REGISTER_OP("KvVariableScatterMulV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterMulV2", KV_SCATTER_MUL);
+
+REGISTER_OP("KvVariableScatterDivV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterDivV2", KV_SCATTER_DIV);
+
+REGISTER_OP("KvVariableScatterMinV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterMinV2", KV_SCATTER_MIN);
+
+REGISTER_OP("KvVariableScatterMaxV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterMaxV2", KV_SCATTER_MAX);
+
+REGISTER_OP("KvVariableScatterUpdateV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("updates: dtype")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn([](InferenceContext*) { return OkStatus(); });
+KV_REGISTER_SCATTER("KvVariableScatterUpdateV2", KV_SCATTER_ASSIGN);
+
+// ---- KvVariableGroupSparseApplyAdamV3 / V4 : ops/training_ops.cc:1086-1105, 1266-1285 ---------------------
+REGISTER_OP("KvVariableGroupSparseApplyAdamV3")
+    .Input("var: resource")
+    .Input("m_v_linear: resource")
+    .Input("grad: T")
+    .Input("indices: Tindices")
+    .Input("lr: T")
+    .Input("beta1_power: T")
+    .Input("beta2_power: T")
+    .Input("beat1: T")
+    .Input("beta2: T")
+    .Input("epsilon: T")
+    .Input("l1: T")
+    .Input("l2: T")
+    .Input("l21: T")
+    .Attr("T: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .Attr("use_locking: bool = false")
+    .SetShapeFn(shape_inference::NoOutputs);
+
+REGISTER_OP("KvVariableGroupSparseApplyAdamV4")
+    .Input("var: resource")
+    .Input("m_v_linear: resource")
+    .Input("grad: T")
+    .Input("indices: Tindices")
+    .Input("lr: T")
+    .Input("beta1_power: T")
+    .Input("beta2_power: T")
+    .Input("beat1: T")
+    .Input("beta2: T")
+    .Input("epsilon: T")
+    .Input("l1: T")
+    .Input("l2: T")
+    .Input("l21: T")
+    .Attr("T: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .Attr("use_locking: bool = false")
+    .SetShapeFn(shape_inference::NoOutputs);
+
+// gradient + indices of an optimizer op on the var's ring; the var's stream carries the whole op
+struct GradIds {
+  StagingRing::Slot *sg = nullptr, *si = nullptr;
+  int64_t n = 0;
+  kv_batch_token_t token = 0;
+};
+static Status StageGradIds(OpKernelContext* ctx, KvHipResource* var, const Tensor& grad, const Tensor& ids, GradIds* g) {
+  if (!TensorShapeUtils::IsVector(ids.shape())) return errors::InvalidArgument("indices must be one-dimensional");
+  TF_RETURN_IF_ERROR(KeyTypeMatches(var, ids));
+  if (grad.dims() < 1 || grad.dim_size(0) != ids.dim_size(0))
+    return errors::InvalidArgument("grad must be the same size as indices in the first dimension.");
+  if (grad.NumElements() != ids.dim_size(0) * var->dim())
+    return errors::InvalidArgument("var and grad must match in dimension 1");
+  g->n = ids.dim_size(0);
+  if (g->n == 0) return OkStatus();
+  TF_RETURN_IF_ERROR(var->ring()->Acquire(grad.TotalBytes(), &g->sg));
+  TF_RETURN_IF_ERROR(var->ring()->Acquire(ids.TotalBytes(), &g->si));
+  TF_RETURN_IF_ERROR(StagingRing::Upload(g->sg, grad.data(), grad.TotalBytes(), var->stream()));
+  TF_RETURN_IF_ERROR(StagingRing::Upload(g->si, ids.data(), ids.TotalBytes(), var->stream()));
+  // the batch token of the forward lookup, when these are the very ids it saw (same length and content); TF-core's
+  // _deduplicate_indexed_slices hands over unique ids, which never match: those take the general path
+  if (var->token != 0 && var->token_n == g->n && var->token_sum == Fingerprint(ids.data(), ids.TotalBytes()))
+    g->token = var->token;
+  return OkStatus();
+}
+static Status ReleaseGradIds(KvHipResource* var, GradIds* g) {
+  if (g->sg) TF_RETURN_IF_ERROR(StagingRing::Release(g->sg, var->stream()));
+  if (g->si) TF_RETURN_IF_ERROR(StagingRing::Release(g->si, var->stream()));
+  return OkStatus();
+}
+// the slot resources' own streams must see the work the var's stream was given, and vice versa: the C ABI
+// orders ops of one table across streams itself (kvhip.h), so nothing to do here beyond using var's stream
 
 template <int VERSION>
 class KvGroupAdamHipOp : public OpKernel {
  public:
   using OpKernel::OpKernel;
   void Compute(OpKernelContext* ctx) override {
-    KvHipResource *var, *slot;
-    OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &var));
-    core::ScopedUnref u0(var);
-    OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 1), &slot));
-    core::ScopedUnref u1(slot);
-    const Tensor& grad = ctx->input(2);
-    const Tensor& ids = ctx->input(3);
-    OP_REQUIRES(ctx, TensorShapeUtils::IsVector(ids.shape()),
-                errors::InvalidArgument("indices must be one-dimensional"));
-    for (int i = 4; i <= 12; ++i)
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, slot);
+    for (int i = 4; i <= 12; ++i)   // kernels/training_ops.cc:7034-7068
       OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(i).shape()),
-                  errors::InvalidArgument("input ", i, " is not a scalar"));
-    OP_REQUIRES(ctx, grad.dim_size(0) == ids.dim_size(0),
-                errors::InvalidArgument("grad must be the same size as indices in the first dimension."));
+                  errors::InvalidArgument("input ", i, " is not a scalar: ", ctx->input(i).shape().DebugString()));
     auto f = [&](int i) { return ctx->input(i).scalar<float>()(); };
-    const int64_t n = ids.dim_size(0);
-    DevBuf d_ids(ids.TotalBytes()), d_grad(grad.TotalBytes());
-    hipMemcpy(d_ids.p, ids.data(), ids.TotalBytes(), hipMemcpyHostToDevice);
-    hipMemcpy(d_grad.p, grad.data(), grad.TotalBytes(), hipMemcpyHostToDevice);
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam(var->h(), slot->h(), static_cast<const float*>(d_grad.p),
-                                                   d_ids.p, n, f(4), f(5), f(6), f(7), f(8), f(9), f(10),
-                                                   f(11), f(12), VERSION, nullptr)));
-    hipDeviceSynchronize();
+    std::lock_guard<std::mutex> l(*var->mu());
+    GradIds g;
+    OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(2), ctx->input(3), &g));
+    if (g.n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), reinterpret_cast<const float*>(g.sg->dev), g.si->dev,
+                                                       g.n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), VERSION,
+                                                       g.token, var->stream())));
+    OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
   }
 };
-REGISTER_KERNEL_BUILDER(Name("KvVariableGroupSparseApplyAdamV4").Device(DEVICE_CPU).TypeConstraint<float>("T"),
-                        KvGroupAdamHipOp<4>);
-REGISTER_KERNEL_BUILDER(Name("KvVariableGroupSparseApplyAdamV3").Device(DEVICE_CPU).TypeConstraint<float>("T"),
-                        KvGroupAdamHipOp<3>);
+#define KV_REGISTER_APPLY(NAME, CLASS)                                                                                    \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).TypeConstraint<float>("T").TypeConstraint<int32>("Tindices"), CLASS);   \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).TypeConstraint<float>("T").TypeConstraint<int64_t>("Tindices"), CLASS); \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).TypeConstraint<float>("T").TypeConstraint<uint64>("Tindices"), CLASS)
+KV_REGISTER_APPLY("KvVariableGroupSparseApplyAdamV3", KvGroupAdamHipOp<3>);
+KV_REGISTER_APPLY("KvVariableGroupSparseApplyAdamV4", KvGroupAdamHipOp<4>);
 
-// KvVariableSparseApplyAdagrad, KvVariableSparseGroupSparseApplyFtrlV2, KvVariableSizeV2,
-// KvVariableFrequency, ReadKvVariableOpV2, KvVariableScatter*V2, KvVariableInsertV2 and
-// KvVariableImport/Export and KvVariableFullOrDeltaImport/Export follow the same pattern over
-// kv_apply_adagrad, kv_apply_sparse_group_ftrl, kv_size, kv_sum_freq, kv_export_*, kv_export_delta_*,
-// kv_scatter_update, kv_insert, kv_import, kv_import_delta (INTEGRATION.md lists the one-line mapping
-// for each); the KvVariable op's kernel calls kv_set_delta_tracking once from SUPPORT_DELTA_EXPORT /
-// SUPPORT_PREDICTION_DELTA_EXPORT, as the reference constructor reads them (kv_variable.h:100-111).
+// ---- KvVariableSparseApplyAdagrad : ops/training_ops.cc:214-226, kernels/training_ops.cc:1372-1498 ------
+REGISTER_OP("KvVariableSparseApplyAdagrad")
+    .Input("var: resource")
+    .Input("accum: resource")
+    .Input("lr: T")
+    .Input("grad: T")
+    .Input("indices: Tindices")
+    .Attr("T: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .Attr("use_locking: bool = false")
+    .Attr("update_slots: bool = true")
+    .SetShapeFn(shape_inference::NoOutputs);
+
+class KvAdagradHipOp : public OpKernel {
+ public:
+  explicit KvAdagradHipOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("update_slots", &update_slots_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, acc);
+    OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(2).shape()),
+                errors::InvalidArgument("lr is not a scalar: ", ctx->input(2).shape().DebugString()));
+    std::lock_guard<std::mutex> l(*var->mu());
+    GradIds g;
+    OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(3), ctx->input(4), &g));
+    if (g.n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                    reinterpret_cast<const float*>(g.sg->dev), g.si->dev, g.n,
+                                                    update_slots_ ? 1 : 0, g.token, var->stream())));
+    OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
+  }
+
+ private:
+  bool update_slots_ = true;
+};
+KV_REGISTER_APPLY("KvVariableSparseApplyAdagrad", KvAdagradHipOp);
+
+// ---- KvVariableSparseGroupSparseApplyFtrlV2 : ops/training_ops.cc:135-150, kernels/training_ops.cc:532-801
+REGISTER_OP("KvVariableSparseGroupSparseApplyFtrlV2")
+    .Input("var: resource")
+    .Input("accum: resource")
+    .Input("linear: resource")
+    .Input("grad: T")
+    .Input("indices: Tindices")
+    .Input("lr: T")
+    .Input("l1: T")
+    .Input("l2: T")
+    .Input("l21: T")
+    .Input("l2_shrinkage: T")
+    .Input("lr_power: T")
+    .Attr("T: numbertype")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .Attr("use_locking: bool = false")
+    .SetShapeFn(shape_inference::NoOutputs);
+
+class KvGroupFtrlHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, acc);
+    KV_RESOURCE(ctx, 2, lin);
+    for (int i = 5; i <= 10; ++i)
+      OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(i).shape()),
+                  errors::InvalidArgument("input ", i, " is not a scalar: ", ctx->input(i).shape().DebugString()));
+    auto f = [&](int i) { return ctx->input(i).scalar<float>()(); };
+    std::lock_guard<std::mutex> l(*var->mu());
+    GradIds g;
+    OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(3), ctx->input(4), &g));
+    if (g.n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), reinterpret_cast<const float*>(g.sg->dev),
+                                                              g.si->dev, g.n, f(5), f(6), f(7), f(8), f(9), f(10), g.token,
+                                                              var->stream())));
+    OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
+  }
+};
+KV_REGISTER_APPLY("KvVariableSparseGroupSparseApplyFtrlV2", KvGroupFtrlHipOp);
+
 }  // namespace tfplus_hip
