@@ -183,6 +183,7 @@ def main():
 
   from tfplus_amd import _lib
   from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  from tfplus_amd.kv_variable.python.ops.sharded import owner_of as _owner_of
   L = _lib.lib()
 
   D, N = args.dim, args.batch
@@ -206,7 +207,7 @@ def main():
     r = torch.arange(i + 1, min(i + CH, K) + 1, dtype=torch.int64, device=dev)
     keys = splitmix64(r)
     if world > 1:
-      keys = keys[torch.remainder(keys, world) == rank].contiguous()
+      keys = keys[_owner_of(keys, world) == rank].contiguous()      # hashed ownership: mix64(id) % world
     owned += keys.numel()
     if keys.numel() == 0:
       continue
@@ -256,7 +257,24 @@ def main():
                                          float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
                                          0.0, 4, stream))
 
-  if shard_path:
+  native_shard = shard_path and not one_gpu_debug
+  if native_shard:
+    # the production path: kvhip.h kv_shard_* over a kv_comm (RCCL grouped send / recv on its own stream; a world of
+    # one still goes through RCCL here so that --force-sharded prices the whole mechanism)
+    comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
+    # peer_capacity: the records one rank may send one owner per batch — a deployment constant (both ends of every
+    # send / recv must agree on it without talking).  Sized from the workload: the most distinct ids any pooled
+    # batch holds, shared evenly by the hash, plus a quarter.
+    cap = int(max(p[2] for p in pool) / world * 1.25) + 1024
+    shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
+    hp_t = ctypes.c_float * 9
+    # this step has no dense tower to overlap with: queue it on the communicator's own stream, so the ops fork and
+    # join nothing (with a tower on another stream each op pays one event hop in and one out, hidden behind it)
+    comm_stream = comm.stream()
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(comm_stream)
+    stream = ctypes.c_void_p(comm_stream.cuda_stream)
+  elif shard_path:
     from tfplus_amd.kv_variable.python.ops import sharded
     skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None),
                                     unique_fn=lambda i, c: ops.kv_unique(var, i, c),
@@ -274,8 +292,12 @@ def main():
       _lib.check(L.kv_apply_group_adam_tok(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
                                            float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
                                            0.0, 4, tok.value if not args.no_token else 0, stream))
+    elif native_shard:
+      # ids -> owners (grouped send / recv over xGMI) -> rows back; summed gradients -> owners -> fused apply
+      _lib.check(L.kv_shard_lookup(shard.ptr, comm.ptr, ids.data_ptr(), N, out.data_ptr(), 1, stream))
+      hp = hp_t(1e-3, float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+      _lib.check(L.kv_shard_apply(shard.ptr, comm.ptr, 0, slot.ptr, None, grad.data_ptr(), hp, 1, stream))
     else:
-      # ids -> owners (all_to_all over xGMI) -> rows back; then (ids, grads) -> owners -> fused apply
       skv.lookup(ids)
       skv.apply_gradients(lambda sh, g, served: sh.apply(g, served), grad, ids)
     state["b1p"] = np.float32(state["b1p"] * np.float32(0.9))      # TF-core Adam _finish
@@ -339,8 +361,8 @@ def main():
   Ub = U_mean
   alg = {
       "lookup_tile": N * 8,
-      "lookup_part": Ub * (16 + 4 * D) + N * 4 * D,
-      "lookup_order": 0,
+      "lookup_part": Ub * 16,
+      "lookup_order": Ub * 4 * D + N * 4 * D + N * 4,
       "apply_index": N * 8 + Ub * 16,
       "apply_sorted": N * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,
       "apply_span": 0,
@@ -381,8 +403,8 @@ def main():
       "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d per GPU, %d ids/batch per GPU Zipf(%.1f), "
                              "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
                  "keys": K, "dim": D, "batch": N, "zipf": args.zipf, "global_batch": N * world, "unique_per_batch": Ub,
-                 "parallelism": ("table hash-sharded over %d GPUs (id mod G), all_to_all id/row/grad exchange "
-                                 "over RCCL" % world) if world > 1 else "single GPU"},
+                 "parallelism": ("table sharded over %d GPUs by mix64(id) %% G, fixed-capacity id/row/grad exchange, "
+                                 "grouped ncclSend/ncclRecv over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,

@@ -329,19 +329,77 @@ int kv_lookup_sparse(kv_handle_t h, const void* ids, const void* segment_ids, in
 int kv_unsorted_segment_sum(kv_handle_t h, const int32_t* segment_ids, const float* data, int64_t n,
                             int64_t num_segments, float* out, kv_stream_t stream);
 
-/* ---- multi-GPU routing helper (new design; the reference has no communication
- * layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
- * kernels/utility.h:90-107 ModKeyImpl, kept here) ----------------------------------------------
- * Counting sort of `ids` [n] by owner rank floor_mod(id, world): out_ids [n] holds the ids grouped
- * by owner (rank 0's first), perm[j] = input position of out_ids[j], counts_dev[world] (device,
- * int64) = ids per owner — the send counts of the all-to-all.  n_dev (device, may be NULL): the
- * real length min(n, *n_dev) when it is still on the device.  Optional extras (NULL to skip):
- * pairs_out [n][2] int64 = (id, id_counts[i] or 1) in bucket order — the lookup's exchange payload;
- * pos_out [n] int32 = position of input i in the bucket order (inverse of perm).  `h` supplies
- * device, key dtype and scratch only. */
-int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t* n_dev, int world,
+/* ---- multi-GPU: tables sharded by id over the GPUs of a node (new design; the reference has no
+ * communication layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
+ * kernels/utility.h:90-107 ModKeyImpl) ------------------------------------------------------------------------
+ * Ownership rules of an id: */
+#define KV_OWNER_HASH 0 /* mix64(id) % world: balanced whatever the ids look like (the default) */
+#define KV_OWNER_MOD 1  /* floor_mod(id, world): the reference's rule, for checkpoints partitioned by it */
+
+/* Counting sort of `ids` [n] by owner rank: out_ids [n] holds the ids grouped by owner (rank 0's first),
+ * perm[j] = input position of out_ids[j], counts_dev[world] (device, int64) = ids per owner — the send counts of a
+ * variable-size all-to-all.  n_dev (device, may be NULL): the real length min(n, *n_dev) when it is still on the
+ * device.  Optional extras (NULL to skip): pairs_out [n][2] int64 = (id, id_counts[i] or 1) in bucket order;
+ * pos_out [n] int32 = position of input i in the bucket order (inverse of perm).  `h` supplies device, key dtype
+ * and scratch only. */
+int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t* n_dev, int world, int owner_rule,
                        int64_t* out_ids, int32_t* perm, int64_t* counts_dev, const int32_t* id_counts,
                        int64_t* pairs_out, int32_t* pos_out, kv_stream_t stream);
+
+/* A communicator over the GPUs of one node: RCCL (grouped ncclSend / ncclRecv: xGMI is point to point, one pair per
+ * link) on a stream of its own.  id128 = the 128-byte unique id kv_comm_unique_id produced on one rank, carried to
+ * the others out of band (torch.distributed, MPI, a file).  world == 1 with id128 == NULL needs no RCCL. */
+typedef struct kv_comm* kv_comm_t;
+int kv_comm_unique_id(void* id128);
+int kv_comm_create(int world, int rank, const void* id128, int device, kv_comm_t* out);
+int kv_comm_destroy(kv_comm_t comm);
+/* the communicator's stream: a caller that passes it as `stream` to kv_shard_lookup / kv_shard_apply (its other work
+ * queued there too) pays no event hop into and out of the exchange */
+int kv_comm_stream(kv_comm_t comm, kv_stream_t* stream);
+/* bytes_per_peer bytes to and from every rank (send / recv: [world][bytes_per_peer] device buffers), ordered after
+ * what `stream` has been given and before what it is given next (events; no host synchronisation). */
+int kv_comm_all_to_all(kv_comm_t comm, const void* send, void* recv, int64_t bytes_per_peer, kv_stream_t stream);
+
+/* This rank's side of a table sharded over `world` ranks: `local_table` holds the rows of the ids this rank owns
+ * (optimizer slot tables are sharded the same way: same rule, same rank).  max_ids = largest batch (<= 2^21);
+ * peer_capacity = (id, count) records per peer in the fixed-capacity exchange buffers (0 = twice an even share of
+ * max_ids).  A batch that needs more for one owner is reported by the NEXT call (KV_RESOURCE_EXHAUSTED after the
+ * capacity has been doubled; the surplus ids of that batch read zeros).
+ *
+ * One training step per rank, all on the device, no host synchronisation, no size exchange:
+ *   lookup  kv_shard_lookup_route   ids -> distinct ids + occurrence counts -> the owners' segments of send_pairs
+ *           [exchange of the records]
+ *           kv_shard_lookup_serve   the owner looks the received ids up in its table (GatherOrInsertWithCounts:
+ *                                   frequency words count every occurrence) -> send_rows, record for record
+ *           [exchange of the rows]
+ *           kv_shard_lookup_finish  out[i] = the row that came back for ids[i]
+ *   apply   kv_shard_apply_route    gradients summed per distinct id into the records their ids were sent in
+ *           [exchange of the rows]
+ *           kv_shard_apply_serve    the owner's fused optimizer apply, on the index its lookup left behind
+ * kv_shard_lookup / kv_shard_apply chain the phases with the RCCL exchanges on the shard's own stream, forked from
+ * `stream`: the caller's stream stays free for the dense tower until kv_shard_join (or join != 0). */
+typedef struct kv_shard* kv_shard_t;
+int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule, int64_t max_ids,
+                    int64_t peer_capacity, kv_shard_t* out);
+int kv_shard_destroy(kv_shard_t shard);
+int kv_shard_buffers(kv_shard_t shard, void** send_pairs, void** recv_pairs, void** send_rows, void** recv_rows,
+                     int64_t* pair_bytes_per_peer, int64_t* row_bytes_per_peer);
+int kv_shard_lookup_route(kv_shard_t shard, const void* ids, int64_t n, kv_stream_t stream);
+int kv_shard_lookup_serve(kv_shard_t shard, kv_stream_t stream);
+int kv_shard_lookup_finish(kv_shard_t shard, float* out, kv_stream_t stream);
+int kv_shard_apply_route(kv_shard_t shard, const float* grad, kv_stream_t stream);
+/* optimizer: 0 GroupAdam V4, 1 GroupAdam V3 (hp = lr, beta1_power, beta2_power, beta1, beta2, epsilon, l1, l2, l21),
+ * 2 Adagrad (hp = lr, update_slots), 3 SparseGroupFtrl (hp = lr, l1, l2, l21, l2_shrinkage, lr_power; slot1 = linear) */
+int kv_shard_apply_serve(kv_shard_t shard, int optimizer, kv_handle_t slot0, kv_handle_t slot1, const float* hp,
+                         kv_stream_t stream);
+int kv_shard_lookup(kv_shard_t shard, kv_comm_t comm, const void* ids, int64_t n, float* out, int join,
+                    kv_stream_t stream);
+int kv_shard_apply(kv_shard_t shard, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1,
+                   const float* grad, const float* hp, int join, kv_stream_t stream);
+int kv_shard_join(kv_shard_t shard, kv_stream_t stream);
+/* the exchange between shards of ONE process on one device (segment r of shard p's send buffer -> segment p of
+ * shard r's receive buffer; what: 0 records, 1 rows): several ranks on a single GPU, where RCCL cannot be used */
+int kv_shard_exchange_local(const kv_shard_t* shards, int world, int what, kv_stream_t stream);
 
 /* Row permutation for the exchange (no handle: plain device buffers).  scatter == 0:
  * out[i] = src[index[i]]; scatter == 1: out[index[i]] = src[i]; rows of row_bytes (a multiple of

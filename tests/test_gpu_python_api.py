@@ -227,12 +227,20 @@ def test_bucket_by_owner_matches_floor_mod(api):
   rng = np.random.default_rng(2)
   for world in (1, 2, 3, 8):
     ids = torch.from_numpy(rng.integers(-10**12, 10**12, 5000))
-    out, perm, counts = g.kv_bucket_by_owner(h, ids, world)
+    out, perm, counts = g.kv_bucket_by_owner(h, ids, world, owner_rule=g.KV_OWNER_MOD)
     own = np.mod(ids.numpy(), world)                     # numpy mod is floor-mod like utility.h:90-107
     assert counts.cpu().tolist() == np.bincount(own, minlength=world).tolist()
     o, p = out.cpu().numpy(), perm.cpu().numpy()
     assert sorted(p.tolist()) == list(range(5000)) and np.array_equal(o, ids.numpy()[p])
     assert np.all(np.diff(np.mod(o, world)) >= 0)        # grouped by owner, rank 0 first
+    # the default rule: mix64(id) % world, the same owner sharded.owner_of states in torch
+    from tfplus_amd.kv_variable.python.ops import sharded
+    out, perm, counts = g.kv_bucket_by_owner(h, ids, world)
+    own = sharded.owner_of(ids, world).numpy()
+    assert counts.cpu().tolist() == np.bincount(own, minlength=world).tolist()
+    o = out.cpu().numpy()
+    assert np.all(np.diff(sharded.owner_of(torch.from_numpy(o), world).numpy()) >= 0)
+    assert counts.max().item() < 1.2 * 5000 / world + 50  # hashed owners are balanced
 
 
 @pytest.mark.gpu

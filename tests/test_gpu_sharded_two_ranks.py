@@ -24,7 +24,7 @@ def _a2a_via_host(out, inp, output_split_sizes=None, input_split_sizes=None, gro
   out.copy_(o)
 
 
-def _worker(rank, world, port, q, D):
+def _worker(rank, world, port, q, D, rule):
   sys.path.insert(0, ROOT)
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
@@ -56,7 +56,9 @@ def _worker(rank, world, port, q, D):
       def apply(self, g, ids):
         ops.kv_variable_group_sparse_apply_adam_v4(var, slot, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
 
-    sh = sharded.ShardedKvVariable(Shard(), bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None),
+    rule_id = {"hash": ops.KV_OWNER_HASH, "mod": ops.KV_OWNER_MOD}[rule]
+    sh = sharded.ShardedKvVariable(Shard(), owner_rule=rule,
+                                   bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None, owner_rule=rule_id),
                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
                                    take_fn=ops.kv_take_rows,
@@ -84,8 +86,12 @@ def _worker(rank, world, port, q, D):
       ko.apply_group_adam(ref, rslot, s, u, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8)
       keys, vals = ops.read_kv_variable_op_v2(var)
       keys = keys.cpu().numpy()
-      assert keys.size and np.all(np.mod(keys, world) == rank)          # ownership: floor-mod, negatives included
-      mine_ref = {k: v for k, v in ref.as_dict().items() if k % world == rank}
+      own = lambda k: sharded.owner_of(torch.from_numpy(np.asarray(k, np.int64)), world, rule).numpy()
+      assert keys.size and np.all(own(keys) == rank)                    # ownership: the rule, negatives included
+      if rule == "mod":
+        assert np.all(np.mod(keys, world) == rank)                      # floor-mod: the reference's partition
+      allk = np.array(sorted(ref.as_dict()), np.int64)
+      mine_ref = {int(k): ref.as_dict()[int(k)] for k in allk[own(allk) == rank]}
       assert set(keys.tolist()) == set(mine_ref)
       got = dict(zip(keys.tolist(), vals.cpu().numpy()))
       for k in mine_ref:
@@ -102,8 +108,8 @@ def _worker(rank, world, port, q, D):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,D", [(2, 16), (4, 64)])      # (4, 64): configs[3]'s shape — dim 64, more than two owners
-def test_sharded_world2_on_one_gpu(world, D):
+@pytest.mark.parametrize("world,D,rule", [(2, 16, "hash"), (4, 64, "mod")])      # (4, 64): configs[3]'s shape — dim 64, more than two owners
+def test_sharded_world2_on_one_gpu(world, D, rule):
   if not torch.cuda.is_available():
     pytest.skip("needs a GPU")
   s = socket.socket()
@@ -112,10 +118,146 @@ def test_sharded_world2_on_one_gpu(world, D):
   s.close()
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
-  procs = [ctx.Process(target=_worker, args=(r, world, port, q, D)) for r in range(world)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q, D, rule)) for r in range(world)]
   for p in procs:
     p.start()
   res = [q.get(timeout=300) for _ in procs]
   for p in procs:
     p.join(timeout=60)
   assert all(r[1] == "ok" for r in res), res
+
+
+# ---- the native path: kv_shard_* phases, fixed-capacity segments, no host synchronisation -----------------
+def _native_setup(world, D, rule, table, cap=0, max_ids=1 << 14, det=False):
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  rule_id = {"hash": ops.KV_OWNER_HASH, "mod": ops.KV_OWNER_MOD}[rule]
+  vars_, slots, shards = [], [], []
+  for r in range(world):
+    var = ops.kv_variable([D]); slot = ops.kv_variable([3 * D])
+    for h, t in ((var, table), (slot, np.zeros((4, 3 * D), np.float32))):
+      ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, t)
+    if det:   # the four-kernel stable routing instead of the fused one
+      ops.kv_set_deterministic(var, True); ops.kv_set_deterministic(slot, True)
+    vars_.append(var); slots.append(slot)
+    shards.append(ops.KvShard(var, world, r, rule_id, max_ids=max_ids, peer_capacity=cap))
+  return ops, vars_, slots, shards
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,D,rule,det", [(2, 16, "hash", False), (4, 64, "hash", True), (4, 64, "mod", False),
+                                              (8, 32, "hash", False)])
+def test_native_shard_phases_match_one_unsharded_table(world, D, rule, det):
+  """`world` shards of one table in one process on one device: route -> exchange -> serve -> exchange -> finish and
+  the apply's route -> exchange -> serve, against ONE oracle table fed every rank's ids (kvhip.h kv_shard_*)."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  from tfplus_amd.kv_variable.python.ops import sharded
+  rng = np.random.default_rng(11)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  ops, vars_, slots, shards = _native_setup(world, D, rule, table, det=det)
+  ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)
+  rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  for step in range(4):
+    batches = [rng.integers(-400, 400, 3000 + 517 * r) for r in range(world)]
+    if step == 3:
+      batches[world - 1] = batches[world - 1][:0]                         # a rank with an empty batch
+    sign = rng.choice([-1.0, 1.0], (1, D))
+    grads = [(rng.uniform(0.5, 1.5, (b.size, D)) * 1e-2 * sign).astype(np.float32) for b in batches]
+    for r in range(world):
+      shards[r].lookup_route(torch.from_numpy(batches[r]).cuda())
+    ops.kv_shard_exchange_local(shards, 0)
+    for r in range(world):
+      shards[r].lookup_serve()
+    ops.kv_shard_exchange_local(shards, 1)
+    outs = [shards[r].lookup_finish().cpu().numpy() for r in range(world)]
+    want_all = ref.gather_or_insert(np.concatenate(batches))
+    off = 0
+    for r in range(world):
+      want = want_all[off:off + batches[r].size]
+      off += batches[r].size
+      if step == 0:
+        np.testing.assert_array_equal(outs[r], want)                      # rows are copies
+      else:
+        np.testing.assert_allclose(outs[r], want, rtol=2e-5, atol=2e-6)   # per-rank partial sums: fp32 order
+    for r in range(world):
+      shards[r].apply_route(torch.from_numpy(grads[r]).cuda())
+    ops.kv_shard_exchange_local(shards, 1)
+    hp = (0.1, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+    for r in range(world):
+      shards[r].apply_serve(ops.OPT_GROUP_ADAM_V4, [slots[r]], hp)
+    u, s, _ = ko.dedup_segment_sum(np.concatenate(batches), np.concatenate(grads))
+    ko.apply_group_adam(ref, rslot, s, u, 0.1, float(b1p), float(b2p), 0.9, 0.999, 1e-8)
+    allk = np.array(sorted(ref.as_dict()), np.int64)
+    own = sharded.owner_of(torch.from_numpy(allk), world, rule).numpy()    # the torch statement of the rule
+    total = 0
+    for r in range(world):
+      keys, vals = ops.read_kv_variable_op_v2(vars_[r])
+      keys = keys.cpu().numpy()
+      assert set(keys.tolist()) == set(allk[own == r].tolist())           # every key lives on its owner, only there
+      got = dict(zip(keys.tolist(), vals.cpu().numpy()))
+      for k in keys.tolist():
+        np.testing.assert_allclose(got[k], ref.as_dict()[k], rtol=2e-5, atol=2e-6)
+      total += ops.kv_variable_frequency(vars_[r])
+    assert total == ref.sum_freq()                                        # every occurrence counted exactly once
+
+
+@pytest.mark.gpu
+def test_native_shard_segment_overflow_is_reported_and_capacity_grows():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D, world = 16, 2
+  table = np.ones((4, D), np.float32)
+  ops, vars_, slots, shards = _native_setup(world, D, "mod", table, cap=16, max_ids=4096)
+  ids = torch.arange(0, 400, 2, dtype=torch.int64).cuda()                  # 200 distinct ids, all owned by rank 0
+  for r in range(world):
+    shards[r].lookup_route(ids)
+  ops.kv_shard_exchange_local(shards, 0)
+  for r in range(world):
+    shards[r].lookup_serve()
+  ops.kv_shard_exchange_local(shards, 1)
+  out = shards[0].lookup_finish().cpu().numpy()
+  assert np.count_nonzero(out.any(axis=1)) == 16                           # the surplus read zeros
+  torch.cuda.synchronize()
+  with pytest.raises(Exception, match="peer_capacity"):
+    shards[0].lookup_route(ids)                                           # reported by the next op; capacity doubled
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
+  """kv_shard_lookup / kv_shard_apply as whole ops (forked stream, RCCL grouped send / recv when asked for) on a world
+  of one: same rows, same table as the plain ops on a second table."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D = 32
+  rng = np.random.default_rng(4)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  ops, vars_, slots, shards = _native_setup(1, D, "hash", table, max_ids=1 << 15)
+  var2 = ops.kv_variable([D]); slot2 = ops.kv_variable([3 * D])
+  for h, t in ((var2, table), (slot2, np.zeros((4, 3 * D), np.float32))):
+    ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, t)
+    ops.kv_set_deterministic(h, True)
+  for h in (vars_[0], slots[0]):
+    ops.kv_set_deterministic(h, True)
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id() if with_rccl else None)
+  for step in range(3):
+    ids = torch.from_numpy(rng.integers(0, 5000, 20000)).cuda()
+    g = torch.from_numpy((rng.standard_normal((20000, D)) * 1e-2).astype(np.float32)).cuda()
+    out = shards[0].lookup(comm, ids)
+    want = ops.kv_variable_gather_or_insert_v2(var2, ids)
+    if step == 0:
+      assert torch.equal(out, want)
+    else:
+      torch.testing.assert_close(out, want, rtol=2e-5, atol=2e-6)
+    shards[0].apply(comm, ops.OPT_GROUP_ADAM_V4, [slots[0]], g, (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+    ops.kv_variable_group_sparse_apply_adam_v4(var2, slot2, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    k1, v1 = ops.read_kv_variable_op_v2(vars_[0]); k2, v2 = ops.read_kv_variable_op_v2(var2)
+    o1, o2 = torch.argsort(k1), torch.argsort(k2)
+    assert torch.equal(k1[o1], k2[o2])
+    torch.testing.assert_close(v1[o1], v2[o2], rtol=2e-5, atol=2e-6)     # local pre-sum, then the owner's sum: fp32 order
+  del comm

@@ -34,7 +34,7 @@ class OracleShard(object):
     self.ko.apply_group_adam(self.var, self.slot, s, u, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, rule):
   sys.path.insert(0, ROOT)
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
@@ -43,7 +43,8 @@ def _worker(rank, world, port, q):
     from tfplus_amd.kv_variable.python.ops import sharded
     rng = np.random.default_rng(11)
     table = rng.standard_normal((32, D)).astype(np.float32)
-    sh = sharded.ShardedKvVariable(OracleShard(table))
+    sh = sharded.ShardedKvVariable(OracleShard(table), owner_rule=rule)
+    own_of = lambda k: int(sharded.owner_of(torch.tensor([int(k)]), world, rule))
     ref = OracleShard(table)                                   # the unsharded truth, same on every rank
     for step in range(3):
       batches = [torch.from_numpy(rng.integers(-50, 200, 64 + 13 * r)) for r in range(world)]
@@ -67,9 +68,9 @@ def _worker(rank, world, port, q):
       ref.apply(torch.cat(grads), torch.cat(batches))
       # ownership: this rank's shard holds exactly the keys with floor_mod(key, world) == rank
       keys, vals, *_ = sh.shard.var.export(2)
-      assert all(int(k) % world == rank for k in keys)
+      assert all(own_of(k) == rank for k in keys)
       rk, rv, *_ = ref.var.export(2)
-      own = {int(k): v for k, v in zip(rk, rv) if int(k) % world == rank}
+      own = {int(k): v for k, v in zip(rk, rv) if own_of(k) == rank}
       got = {int(k): v for k, v in zip(keys, vals)}
       assert set(own) == set(got)
       for k in own:
@@ -79,8 +80,17 @@ def _worker(rank, world, port, q):
       assert int(cnt) == ref.var.sum_freq()                    # frequency words add up across shards
     # routing primitives
     ids = torch.tensor([-3, 4, 7, -8, 5])
-    assert sharded.owner_of(ids, 2).tolist() == [1, 0, 1, 0, 1]
-    rt = sharded.route(ids)
+    assert sharded.owner_of(ids, 2, "mod").tolist() == [1, 0, 1, 0, 1]
+    # the hashed rule is the library's mix64(id) % world on the unsigned value (kv_device.h), spelled out in Python
+    def mix(x):
+      x &= (1 << 64) - 1
+      x ^= x >> 33; x = x * 0xff51afd7ed558ccd & ((1 << 64) - 1)
+      x ^= x >> 33; x = x * 0xc4ceb9fe1a85ec53 & ((1 << 64) - 1)
+      return x ^ (x >> 33)
+    probe = torch.tensor([-3, 4, 7, -8, 5, 0, -1, 2**62, -2**63, 2**63 - 1])
+    for w in (2, 3, 7, 8):
+      assert sharded.owner_of(probe, w).tolist() == [mix(int(v)) % w for v in probe.tolist()]
+    rt = sharded.route(ids, rule=rule)
     assert sorted(rt.perm.tolist()) == list(range(5)) and sum(rt.send_counts) == 5
     # occurrence counts survive the dedup-before-exchange: lookup with per-id counts
     extra = sh.lookup(torch.tensor([1000 + rank, 1000 + rank, 1001]), counts=torch.tensor([2, 3, 4], dtype=torch.int32))
@@ -95,14 +105,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_lookup_and_apply_world2():
+@pytest.mark.parametrize("rule", ["hash", "mod"])
+def test_sharded_lookup_and_apply_world2(rule):
   s = socket.socket()
   s.bind(("127.0.0.1", 0))
   port = s.getsockname()[1]
   s.close()
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
-  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, q, rule)) for r in range(2)]
   for p in procs:
     p.start()
   res = [q.get(timeout=240) for _ in procs]

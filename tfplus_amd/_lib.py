@@ -67,7 +67,24 @@ SIGNATURES = {
     "kv_insert": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_scatter_update": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "kv_unique": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _vp]),
-    "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kv_comm_unique_id": (_i32, [_vp]),
+    "kv_comm_create": (_i32, [_i32, _i32, _vp, _i32, _c.POINTER(_vp)]),
+    "kv_comm_destroy": (_i32, [_vp]),
+    "kv_comm_stream": (_i32, [_vp, _c.POINTER(_vp)]),
+    "kv_comm_all_to_all": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "kv_shard_create": (_i32, [_vp, _i32, _i32, _i32, _i64, _i64, _c.POINTER(_vp)]),
+    "kv_shard_destroy": (_i32, [_vp]),
+    "kv_shard_buffers": (_i32, [_vp] + [_c.POINTER(_vp)] * 4 + [_c.POINTER(_i64)] * 2),
+    "kv_shard_lookup_route": (_i32, [_vp, _vp, _i64, _vp]),
+    "kv_shard_lookup_serve": (_i32, [_vp, _vp]),
+    "kv_shard_lookup_finish": (_i32, [_vp, _vp, _vp]),
+    "kv_shard_apply_route": (_i32, [_vp, _vp, _vp]),
+    "kv_shard_apply_serve": (_i32, [_vp, _i32, _vp, _vp, _c.POINTER(_f), _vp]),
+    "kv_shard_lookup": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "kv_shard_apply": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _c.POINTER(_f), _i32, _vp]),
+    "kv_shard_join": (_i32, [_vp, _vp]),
+    "kv_shard_exchange_local": (_i32, [_c.POINTER(_vp), _i32, _i32, _vp]),
     "kv_get_count": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_get_timestamp": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_delete": (_i32, [_vp, _vp, _i64, _c.POINTER(_i64), _vp]),

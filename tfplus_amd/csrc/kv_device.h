@@ -109,6 +109,8 @@ struct WsDev {
                            // [2] work items, [3] hot chunks
   unsigned ntiles, P;
   int pshift;              // 64 - log2(P)
+  unsigned seg_cap;        // (id, count) input in fixed-capacity exchange segments of this many records (0: plain list)
+  const int* row_map;      // k_gather: rows are read at row_map[ent_b] (sharded lookup: the exchange buffer's records); else null
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
 };
 

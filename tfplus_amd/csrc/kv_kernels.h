@@ -127,7 +127,17 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
     const long long i = base + (long long)k * TBT + tid;
     tslot[k] = 0xFFFFFFFFu;
     myrank[k] = 0;
-    if (i < n) {
+    bool there = i < n;
+    if constexpr (PAIRS) {
+      // fixed-capacity exchange segments (k_owner_scatter_fixed): record 0 of a segment is its header {records, -},
+      // records past the header's count are stale bytes of earlier batches; a count of 0 marks a record void too
+      if (there && creg[k] == 0u) there = false;
+      if (there && w.seg_cap) {
+        const long long r = i % w.seg_cap;
+        there = r >= 1 && r <= ids[i - r].id;
+      }
+    }
+    if (there) {
       const long long key = kreg[k];
       unsigned h;
       if (key == EMPTY_KEY) {
@@ -232,7 +242,7 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
       const int lp = k * TBT + tid;
-      if (base + lp < n && sm.lcnt[tslot[k]] > 1u) {
+      if (base + lp < n && tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] > 1u) {
         const unsigned short me = (unsigned short)tslot[k];
         unsigned r = 0;
         for (int q = 0; q < lp; ++q) r += pslot[q] == me;
@@ -245,7 +255,7 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     const long long i = base + (long long)k * TBT + tid;
-    if (i < n) w.slot_rank[i] = (tile * TILE + sm.lpos[tslot[k]]) | (myrank[k] << RANK_SHIFT);
+    if (i < n) w.slot_rank[i] = tslot[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((tile * TILE + sm.lpos[tslot[k]]) | (myrank[k] << RANK_SHIFT));
   }
   // ---- per-occurrence counts: frequency sum per entry (hist is dead: reused as lfreq) -------------
   if (has_counts) {
@@ -290,6 +300,7 @@ struct PartArgs {
   const unsigned* fvals;
   long long* out_keys;        // MODE_UNIQUE
   float* out_sum;             // MODE_DEDUP fold: out_sum[row] = the key's sum
+  const int* out_map;         // ... or out_sum[out_map[row]] when given
   int* out_counts;            // MODE_UNIQUE: occurrences (saturating) of each unique key
   int count_once;             // MODE_LOOKUP: frequency += 1 per unique key instead of per occurrence
   long long direct_rows;      // MODE_UNIQUE, > 0: keys ARE output row indices in [0, direct_rows)
@@ -842,6 +853,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
 // the first position of a cold key also goes into the key's record (most cold keys have no other row, and the
 // apply saves a hop)
 __device__ __forceinline__ void order_pos(const WsDev& w, long long n, long long i, unsigned sr) {
+  if (sr == 0xFFFFFFFFu) return;   // a skipped record (padding of the sharded exchange)
   const unsigned e = sr & SLOT_MASK, rank = sr >> RANK_SHIFT;
   const unsigned eb = w.ent_base[e];
   const unsigned j = (eb & BASE_MASK) + rank;
@@ -1012,10 +1024,11 @@ __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bo
     opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, ro.tag, ro.r0, (ro.nb & 2u) != 0, ro.r1, (ro.nb & 4u) != 0,
                                    live, gv, a.opt, lane, pre, have_x, have_s && (ro.nb & 8u) != 0);
   } else if (live && hd.z != ROW_MASK) {
+    const size_t orow = a.out_map ? (size_t)a.out_map[hd.z] : (size_t)hd.z;   // sharded apply: the unique id's exchange slot
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
-      if (e0 < D) stv<V>(a.out_sum + (size_t)hd.z * D + e0, gv[k]);
+      if (e0 < D) stv<V>(a.out_sum + orow * D + e0, gv[k]);
     }
   }
 }
@@ -1333,6 +1346,14 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
 // ------------------------------------------------------------------------------------------
 // VQ = float4 vectors per row (dim / 4) when > 0 (power of two); VQ = 0 -> generic dim
 // ORDER: the same pass files every position in the sorted list (order_pos): the training lookup's last kernel
+// the row a position reads: its entry's row, through w.row_map when the rows live in an exchange buffer (sharded
+// lookup: entry -> dense unique index -> the record the id was sent in); skipped records read the zero row
+__device__ __forceinline__ unsigned gather_row(const WsDev& w, unsigned sr) {
+  if (sr == 0xFFFFFFFFu) return 0u;
+  const unsigned r = w.ent_b[sr & SLOT_MASK];
+  return w.row_map ? (unsigned)w.row_map[r] : r;
+}
+
 template <int VQ, bool ORDER = false>
 __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, float* __restrict__ out,
                                             long long n) {
@@ -1359,14 +1380,14 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     unsigned sl1 = 0, sl2 = 0, rr = 0;
     if (r0 + lane < n) {
       const unsigned sr = __builtin_nontemporal_load(&w.slot_rank[r0 + lane]);
-      rr = w.ent_b[sr & SLOT_MASK];
+      rr = gather_row(w, sr);
       if (ORDER) order_pos(w, n, r0 + lane, sr);
     }
     if (r0 + stride + lane < n) sl1 = __builtin_nontemporal_load(&w.slot_rank[r0 + stride + lane]);
     for (; r0 < n; r0 += stride) {
       unsigned rr1 = 0;
       if (r0 + stride + lane < n) {
-        rr1 = w.ent_b[sl1 & SLOT_MASK];
+        rr1 = gather_row(w, sl1);
         if (ORDER) order_pos(w, n, r0 + stride + lane, sl1);
       }
       if (r0 + 2 * stride + lane < n) sl2 = __builtin_nontemporal_load(&w.slot_rank[r0 + 2 * stride + lane]);
@@ -1396,7 +1417,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     const int v = threadIdx.x % VQ;
     for (long long i = (long long)blockIdx.x * RPB + threadIdx.x / VQ; i < n; i += (long long)gridDim.x * RPB) {
       const unsigned sr = w.slot_rank[i];
-      const unsigned r = w.ent_b[sr & SLOT_MASK];
+      const unsigned r = gather_row(w, sr);
       if (ORDER && v == 0) order_pos(w, n, i, sr);
       reinterpret_cast<float4*>(out + (size_t)i * (VQ * 4))[v] = reinterpret_cast<const float4*>(row_ptr(t, r))[v];
     }
@@ -1408,7 +1429,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
       const int e = (int)(x - i * D);
       const unsigned sr = w.slot_rank[i];
       if (ORDER && e == 0) order_pos(w, n, i, sr);
-      out[x] = row_ptr(t, w.ent_b[sr & SLOT_MASK])[e];
+      out[x] = row_ptr(t, gather_row(w, sr))[e];
     }
   }
 }
@@ -1620,13 +1641,16 @@ __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
 constexpr int RT = 1024;  // ids per routing tile (256 threads x 4)
 constexpr int MAXW = 64;
 
-__device__ __forceinline__ unsigned owner_rank(long long id, int world) {
+// rule 0 (default): mix64(id) % world — balanced whatever the ids look like; rule 1: floor_mod(id, world), the
+// reference's `ids % num_shards` (python/ops/embedding_ops.py:121-127), for checkpoint compatibility
+__device__ __forceinline__ unsigned owner_rank(long long id, int world, int rule) {
+  if (rule == 0) return (unsigned)(mix64((unsigned long long)id) % (unsigned long long)world);
   long long m = id % world;
   return (unsigned)(m < 0 ? m + world : m);
 }
 
 template <typename IdT>
-__global__ void __launch_bounds__(TB) k_owner_hist(const IdT* __restrict__ ids, long long n, int world,
+__global__ void __launch_bounds__(TB) k_owner_hist(const IdT* __restrict__ ids, long long n, int world, int rule,
                                                    unsigned ntiles, unsigned* __restrict__ hist,
                                                    const long long* __restrict__ n_dev) {
   if (n_dev) n = min(n, *n_dev);   // the list's length is still on the device (kv_unique without a sync)
@@ -1637,7 +1661,7 @@ __global__ void __launch_bounds__(TB) k_owner_hist(const IdT* __restrict__ ids, 
 #pragma unroll
   for (int k = 0; k < RT / TB; ++k) {
     const long long i = base + k * TB + threadIdx.x;
-    if (i < n) atomicAdd(&h[owner_rank(load_id(ids, (size_t)i), world)], 1u);
+    if (i < n) atomicAdd(&h[owner_rank(load_id(ids, (size_t)i), world, rule)], 1u);
   }
   __syncthreads();
   if ((int)threadIdx.x < world) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -1663,7 +1687,7 @@ __global__ void __launch_bounds__(1024) k_owner_scan(unsigned* __restrict__ hist
 }
 
 template <typename IdT>
-__global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ ids, long long n, int world,
+__global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ ids, long long n, int world, int rule,
                                                       unsigned ntiles, const unsigned* __restrict__ base_off,
                                                       long long* __restrict__ out_ids, int* __restrict__ perm,
                                                       const long long* __restrict__ n_dev,
@@ -1679,7 +1703,7 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
     const long long i = base + k * TB + threadIdx.x;
     if (i < n) {
       const long long id = load_id(ids, (size_t)i);
-      const unsigned pos = atomicAdd(&h[owner_rank(id, world)], 1u);
+      const unsigned pos = atomicAdd(&h[owner_rank(id, world, rule)], 1u);
       out_ids[pos] = id;
       perm[pos] = (int)i;
       // optional extras of the sharded lookup: the exchange payload (id, occurrence count) in
@@ -1688,6 +1712,123 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
       if (pos_out) pos_out[i] = (int)pos;
     }
   }
+}
+// The sharded lookup's exchange payload in FIXED-CAPACITY segments (no size collective, no host sync): owner d's
+// segment is seg[d][0 .. C]: record 0 = header {pairs in the segment, 0}, records 1 .. = (id, occurrence count).
+// A record whose count is 0 is skipped by the owner's tile pass, so padding costs nothing but its bytes.  slot_of[u]
+// = where unique id u went (its row comes back at the same place).  More than C ids for one owner: the extra
+// ones are dropped and *overflow is raised (the host doubles C; hashed ownership keeps this from happening).
+__global__ void __launch_bounds__(TB) k_owner_scatter_fixed(const long long* __restrict__ ids, const int* __restrict__ cnts,
+                                                            const unsigned* __restrict__ n_dev32, int world, int rule,
+                                                            unsigned ntiles, const unsigned* __restrict__ base_off,
+                                                            unsigned C, long long* __restrict__ seg, int* __restrict__ slot_of,
+                                                            unsigned* __restrict__ overflow) {
+  const long long n = (long long)*n_dev32;
+  __shared__ unsigned h[MAXW];
+  if ((int)threadIdx.x < world)   // rank inside the owner's bucket = global offset - the bucket's start
+    h[threadIdx.x] = base_off[(size_t)threadIdx.x * ntiles + blockIdx.x] - base_off[(size_t)threadIdx.x * ntiles];
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RT;
+#pragma unroll
+  for (int k = 0; k < RT / TB; ++k) {
+    const long long i = base + k * TB + threadIdx.x;
+    if (i < n) {
+      const long long id = ids[i];
+      const unsigned d = owner_rank(id, world, rule);
+      const unsigned r = atomicAdd(&h[d], 1u);
+      if (r < C) {
+        const size_t slot = (size_t)d * (C + 1) + 1 + r;
+        seg[2 * slot] = id;
+        seg[2 * slot + 1] = cnts ? (long long)cnts[i] : 1ll;
+        slot_of[i] = (int)slot;
+      } else {
+        slot_of[i] = 0;        // record 0 is a header: its "row" is never a real one
+        atomicExch(overflow, 1u);
+      }
+    }
+  }
+}
+// The same in two launches instead of four (hist + scan + scatter in one): a block counts its tile's ids per owner in LDS, takes
+// its place in every owner's segment with one atomic per owner, writes its records.  The order of the records
+// inside a segment then depends on block timing — it decides nothing but the owner's row numbering — so the
+// deterministic mode keeps the four-kernel version above.  gcount: [world] segment fill, zero between batches.
+__global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __restrict__ ids, const int* __restrict__ cnts,
+                                                          const unsigned* __restrict__ n_dev32, int world, int rule, unsigned C,
+                                                          long long* __restrict__ seg, int* __restrict__ slot_of,
+                                                          unsigned* __restrict__ overflow, unsigned* __restrict__ gcount) {
+  const long long n = (long long)*n_dev32;
+  __shared__ unsigned h[MAXW], base[MAXW];
+  if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long b0 = (long long)blockIdx.x * RT;
+  long long id[RT / TB];
+  unsigned d[RT / TB], r[RT / TB];
+  if (b0 < n) {
+#pragma unroll
+    for (int k = 0; k < RT / TB; ++k) {
+      const long long i = b0 + k * TB + threadIdx.x;
+      if (i < n) {
+        id[k] = ids[i];
+        d[k] = owner_rank(id[k], world, rule);
+        r[k] = atomicAdd(&h[d[k]], 1u);
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < world) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&gcount[threadIdx.x], h[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RT / TB; ++k) {
+      const long long i = b0 + k * TB + threadIdx.x;
+      if (i < n) {
+        const unsigned rr = base[d[k]] + r[k];
+        if (rr < C) {
+          const size_t slot = (size_t)d[k] * (C + 1) + 1 + rr;
+          seg[2 * slot] = id[k];
+          seg[2 * slot + 1] = cnts ? (long long)cnts[i] : 1ll;
+          slot_of[i] = (int)slot;
+        } else {
+          slot_of[i] = 0;
+          atomicExch(overflow, 1u);
+        }
+      }
+    }
+  }
+}
+// ... and its headers, from the fill counters, which it zeroes for the next batch.  (A last-block-done epilogue in
+// the kernel above would need a device-scope release fence per block; on gfx950 that writes the XCD's L2 back and
+// cost 60 us behind the partition pass.)
+__global__ void k_seg_headers_take(unsigned* __restrict__ gcount, int world, unsigned C, long long* __restrict__ seg) {
+  const int d = threadIdx.x;
+  if (d < world) {
+    const unsigned c = gcount[d];
+    gcount[d] = 0;
+    seg[2 * (size_t)d * (C + 1)] = c < C ? c : C;
+    seg[2 * (size_t)d * (C + 1) + 1] = 0;
+  }
+}
+// the segments' headers {records in the segment (at most C), 0}
+__global__ void k_seg_headers(const long long* __restrict__ counts, int world, unsigned C, long long* __restrict__ seg) {
+  const int d = threadIdx.x;
+  if (d < world) {
+    seg[2 * (size_t)d * (C + 1)] = counts[d] < (long long)C ? counts[d] : (long long)C;
+    seg[2 * (size_t)d * (C + 1) + 1] = 0;
+  }
+}
+// k_owner_hist / k_owner_scan with the length on the device as a 32-bit word (the unique count of kv_unique)
+__global__ void __launch_bounds__(TB) k_owner_hist_u32(const long long* __restrict__ ids, const unsigned* __restrict__ n_dev32,
+                                                       int world, int rule, unsigned ntiles, unsigned* __restrict__ hist) {
+  const long long n = (long long)*n_dev32;
+  __shared__ unsigned h[MAXW];
+  if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RT;
+#pragma unroll
+  for (int k = 0; k < RT / TB; ++k) {
+    const long long i = base + k * TB + threadIdx.x;
+    if (i < n) atomicAdd(&h[owner_rank(ids[i], world, rule)], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < world) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 // ---------------------------------------------------------------------------------------------
 // embedding_lookup_sparse (python/ops/embedding_ops.py:279-441) fused behind the lookup index:

@@ -27,6 +27,8 @@
 // Reference semantics restated per function with file:line (relative to the tfplus tree).
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -609,6 +611,8 @@ WsDev ws_view(kv_table* t, long long n) {
   d.ntiles = (unsigned)((n + TILE - 1) / TILE);
   d.P = pick_partitions(n);
   d.pshift = 64 - ilog2(d.P);
+  d.seg_cap = 0;
+  d.row_map = nullptr;
   d.dbg = w.dbg;
   return d;
 }
@@ -1081,7 +1085,7 @@ int kv_get_meta(kv_handle_t t, const int64_t* ids, int64_t n, uint32_t* fw, uint
 }
 
 static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
-                                 kv_stream_t stream, int pairs, kv_batch_token_t* token);
+                                 kv_stream_t stream, int pairs, kv_batch_token_t* token, unsigned seg_cap = 0);
 
 int kv_gather_or_insert(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
                         kv_stream_t stream) {
@@ -1099,7 +1103,7 @@ int kv_gather_or_insert_pairs(kv_handle_t t, const int64_t* id_count_pairs, int6
 }
 
 static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, float* out,
-                                 kv_stream_t stream, int pairs, kv_batch_token_t* token) {
+                                 kv_stream_t stream, int pairs, kv_batch_token_t* token, unsigned seg_cap) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (n == 0) return KV_OK;  // kv_variable_ops.cc:530-532
@@ -1124,7 +1128,8 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     if ((rc = ensure_capacity(t, m, s))) return rc;
     if ((rc = ensure_workspace(t, m, false, s))) return rc;
     const TableDev td = dev_view(t);
-    const WsDev wd = ws_view(t, m);
+    WsDev wd = ws_view(t, m);
+    wd.seg_cap = seg_cap;
     PartArgs pa{};
     pa.tv = td; pa.ts0 = td; pa.ts1 = td;
     pa.day = today(t);
@@ -1840,12 +1845,13 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   return KV_OK;
 }
 
-int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t* n_dev, int world, int64_t* out_ids,
+int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t* n_dev, int world, int owner_rule, int64_t* out_ids,
                        int32_t* perm, int64_t* counts_dev, const int32_t* id_counts, int64_t* pairs_out,
                        int32_t* pos_out, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
   if (world < 1 || world > MAXW) return fail(KV_INVALID_ARGUMENT, "world %d: 1..%d ranks", world, MAXW);
+  if (owner_rule != KV_OWNER_HASH && owner_rule != KV_OWNER_MOD) return fail(KV_INVALID_ARGUMENT, "owner_rule %d", owner_rule);
   if (n < 0 || n > (1ll << 31) - 1 || (n > 0 && (!ids || !out_ids || !perm)) || !counts_dev)
     return fail(KV_INVALID_ARGUMENT, "bad arguments");
   DeviceGuard dg(t->device);
@@ -1864,15 +1870,15 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t*
     return KV_OK;
   }
   if (t->key_dtype == KV_DT_INT32) {
-    k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (const long long*)n_dev);
+    k_owner_hist<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, owner_rule, ntiles, t->route_hist, (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
-    k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, ntiles, t->route_hist, (long long*)out_ids, perm,
+    k_owner_scatter<int><<<ntiles, TB, 0, s>>>((const int*)ids, n, world, owner_rule, ntiles, t->route_hist, (long long*)out_ids, perm,
                                                (const long long*)n_dev, id_counts, (long long*)pairs_out, pos_out);
   } else {
-    k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
+    k_owner_hist<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, owner_rule, ntiles, t->route_hist,
                                                   (const long long*)n_dev);
     k_owner_scan<<<1, 1024, 0, s>>>(t->route_hist, ntiles * world, ntiles, world, (long long*)counts_dev);
-    k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, ntiles, t->route_hist,
+    k_owner_scatter<long long><<<ntiles, TB, 0, s>>>((const long long*)ids, n, world, owner_rule, ntiles, t->route_hist,
                                                      (long long*)out_ids, perm, (const long long*)n_dev, id_counts,
                                                      (long long*)pairs_out, pos_out);
   }
@@ -2337,6 +2343,467 @@ int kv_import(kv_handle_t t, const int64_t* keys, const float* values, int64_t n
   if ((rc = ensure_init_placeholder(t, s))) return rc;
   t->initialized = true;
   HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// sharded tables: hashed ownership, fixed-capacity exchange, RCCL over xGMI
+// ------------------------------------------------------------------------------------------
+namespace {
+// RCCL is reached through dlopen: the copy the process already holds (PyTorch bundles one under the same soname)
+// is reused, so there is one RCCL per process; nothing links against it when the table is not sharded
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // PyTorch's wheel carries its RCCL under the soname librccl.so, ROCm's own is librccl.so.1: whichever the process
+    // already holds wins, so that there is one RCCL (one set of xGMI channels) per process
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+      if ((api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!api.lib)
+      for (const char* name : {"librccl.so.1", "librccl.so"})
+        if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!api.lib) return;
+    auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+  });
+  return &api;
+}
+#define NCCL_TRY(expr)                                                                                      \
+  do {                                                                                                      \
+    ncclResult_t _r = (expr);                                                                               \
+    if (_r != ncclSuccess)                                                                                  \
+      return fail(KV_INTERNAL, "%s failed: %s", #expr, rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "?"); \
+  } while (0)
+}  // namespace
+
+struct kv_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0, device = 0;
+  hipStream_t stream = nullptr;      // the collectives' own stream
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};
+
+struct kv_shard {
+  kv_table* table = nullptr;         // this rank's share of the rows
+  kv_table* route = nullptr;         // owns the workspace of the local unique index (no rows of its own)
+  int world = 1, rank = 0, rule = KV_OWNER_HASH;
+  long long max_ids = 0;
+  unsigned C = 0;                    // (id, count) records per peer segment, header not counted
+  long long* uniq = nullptr;         // [max_ids]
+  int* ucnt = nullptr;               // [max_ids]
+  int* slot_of = nullptr;            // [max_ids] unique id -> record in the send buffer
+  long long* send_pairs = nullptr;   // [world][C + 1][2]
+  long long* recv_pairs = nullptr;
+  float* send_rows = nullptr;        // [world][C + 1][dim]
+  float* recv_rows = nullptr;
+  long long* counts = nullptr;       // [world]
+  unsigned* hist = nullptr;          // [world][tiles]
+  unsigned* gcount = nullptr;        // [MAXW + 1] k_owner_route_fixed's counters (zero between launches)
+  unsigned* overflow = nullptr;      // pinned, mapped: a segment was too small for a batch
+  long long n_last = 0;              // ids of the batch whose index `route` holds
+  bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
+  uint64_t route_token = 0;
+  kv_batch_token_t serve_token = 0;
+  hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+};
+
+namespace {
+void shard_free_buffers(kv_shard* sh) {
+  hipFree(sh->send_pairs); hipFree(sh->recv_pairs); hipFree(sh->send_rows); hipFree(sh->recv_rows);
+  sh->send_pairs = sh->recv_pairs = nullptr; sh->send_rows = sh->recv_rows = nullptr;
+}
+int shard_alloc_buffers(kv_shard* sh, unsigned C) {
+  const size_t rec = (size_t)sh->world * (C + 1);
+  if (rec > (1ull << 21)) return fail(KV_INVALID_ARGUMENT, "peer_capacity %u x world %d exceeds 2^21 records per exchange", C, sh->world);
+  shard_free_buffers(sh);
+  HIP_TRY(hipMalloc(&sh->send_pairs, rec * 16));
+  HIP_TRY(hipMalloc(&sh->recv_pairs, rec * 16));
+  HIP_TRY(hipMalloc(&sh->send_rows, rec * sh->table->dim * sizeof(float)));
+  HIP_TRY(hipMalloc(&sh->recv_rows, rec * sh->table->dim * sizeof(float)));
+  HIP_TRY(hipMemset(sh->send_pairs, 0, rec * 16));
+  HIP_TRY(hipMemset(sh->recv_pairs, 0, rec * 16));
+  sh->C = C;
+  return KV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int kv_comm_unique_id(void* id128) {
+  if (!id128) return fail(KV_INVALID_ARGUMENT, "id128 is null");
+  if (!rccl()->ok) return fail(KV_UNIMPLEMENTED, "librccl.so.1 could not be loaded");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+  NCCL_TRY(rccl()->GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+  return KV_OK;
+}
+
+int kv_comm_create(int world, int rank, const void* id128, int device, kv_comm_t* out) {
+  if (!out || world < 1 || world > MAXW || rank < 0 || rank >= world) return fail(KV_INVALID_ARGUMENT, "kv_comm_create: world %d rank %d", world, rank);
+  DeviceGuard dg(device);
+  kv_comm* c = new kv_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  int rc = KV_OK;
+  do {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) {
+      rc = fail(KV_INTERNAL, "kv_comm_create: stream / events");
+      break;
+    }
+    if (world > 1 || id128) {   // a world of one needs no RCCL (the exchange is a device copy) unless asked for
+      if (!id128) { rc = fail(KV_INVALID_ARGUMENT, "kv_comm_create: unique id is null"); break; }
+      if (!rccl()->ok) { rc = fail(KV_UNIMPLEMENTED, "librccl.so.1 could not be loaded"); break; }
+      ncclUniqueId id;
+      std::memcpy(&id, id128, sizeof id);
+      ncclResult_t r = rccl()->CommInitRank(&c->comm, world, id, rank);
+      if (r != ncclSuccess) { rc = fail(KV_INTERNAL, "ncclCommInitRank: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "?"); break; }
+    }
+  } while (0);
+  if (rc) { kv_comm_destroy(c); return rc; }
+  *out = c;
+  return KV_OK;
+}
+
+int kv_comm_stream(kv_comm_t c, kv_stream_t* stream) {
+  if (!c || !stream) return fail(KV_INVALID_ARGUMENT, "kv_comm_stream: null argument");
+  *stream = (kv_stream_t)c->stream;
+  return KV_OK;
+}
+
+int kv_comm_destroy(kv_comm_t c) {
+  if (!c) return KV_OK;
+  DeviceGuard dg(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm && rccl()->ok) rccl()->CommDestroy(c->comm);
+  if (c->ev_in) hipEventDestroy(c->ev_in);
+  if (c->ev_out) hipEventDestroy(c->ev_out);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return KV_OK;
+}
+
+// bytes_per_peer bytes to / from every rank: grouped ncclSend / ncclRecv (xGMI is point to point: one pair per
+// link), on the communicator's own stream, behind everything `stream` was given and in front of what it gets next
+int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_per_peer, kv_stream_t stream) {
+  if (!c || !send || !recv || bytes_per_peer < 0) return fail(KV_INVALID_ARGUMENT, "kv_comm_all_to_all: bad arguments");
+  DeviceGuard dg(c->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->comm) {   // world of one without RCCL
+    HIP_TRY(hipMemcpyAsync(recv, send, (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, s));
+    return KV_OK;
+  }
+  const bool hop = s != c->stream;   // the sharded ops run on the communicator's stream themselves: no hop
+  if (hop) {
+    HIP_TRY(hipEventRecord(c->ev_in, s));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  }
+  // this rank's own segment never meets RCCL: a device copy at HBM speed, queued in front of the group
+  HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer, (const char*)send + (size_t)c->rank * bytes_per_peer,
+                         (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+  if (c->world > 1) NCCL_TRY(rccl()->GroupStart());
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    NCCL_TRY(rccl()->Send((const char*)send + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
+    NCCL_TRY(rccl()->Recv((char*)recv + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
+  }
+  if (c->world > 1) NCCL_TRY(rccl()->GroupEnd());
+  if (hop) {
+    HIP_TRY(hipEventRecord(c->ev_out, c->stream));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_out, 0));
+  }
+  return KV_OK;
+}
+
+int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule, int64_t max_ids, int64_t peer_capacity,
+                    kv_shard_t* out) {
+  int rc;
+  if ((rc = check_table(local_table))) return rc;
+  if (!out || world < 1 || world > MAXW || rank < 0 || rank >= world) return fail(KV_INVALID_ARGUMENT, "kv_shard_create: world %d rank %d", world, rank);
+  if (owner_rule != KV_OWNER_HASH && owner_rule != KV_OWNER_MOD) return fail(KV_INVALID_ARGUMENT, "owner_rule %d", owner_rule);
+  if (max_ids < 1 || max_ids > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "max_ids %lld: 1 .. 2^21 ids per sharded batch", (long long)max_ids);
+  if (local_table->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "sharded tables carry int64 ids");
+  if ((local_table->dim & 3) != 0) return fail(KV_UNIMPLEMENTED, "sharded tables: dim %d (multiples of 4)", local_table->dim);
+  DeviceGuard dg(local_table->device);
+  kv_shard* sh = new kv_shard();
+  sh->table = local_table; sh->world = world; sh->rank = rank; sh->rule = owner_rule; sh->max_ids = max_ids;
+  do {
+    if ((rc = kv_create(KV_DT_INT64, KV_DT_FLOAT, local_table->dim, 0, 0, local_table->device, &sh->route))) break;
+    // default capacity: twice an even share of max_ids distinct ids (hashed ownership spreads them evenly), at least 1024
+    long long C = peer_capacity > 0 ? peer_capacity : std::max<long long>(1024, 2 * ((max_ids + world - 1) / world));
+    C = std::min<long long>(C, max_ids);
+    const unsigned ntr = (unsigned)((max_ids + RT - 1) / RT);
+    if (hipMalloc(&sh->uniq, (size_t)max_ids * 8) != hipSuccess || hipMalloc(&sh->ucnt, (size_t)max_ids * 4) != hipSuccess ||
+        hipMalloc(&sh->slot_of, (size_t)max_ids * 4) != hipSuccess || hipMalloc(&sh->counts, (size_t)world * 8) != hipSuccess ||
+        hipMalloc(&sh->hist, (size_t)ntr * world * 4) != hipSuccess ||
+        hipMalloc(&sh->gcount, (MAXW + 1) * 4) != hipSuccess || hipMemset(sh->gcount, 0, (MAXW + 1) * 4) != hipSuccess ||
+        hipHostMalloc(&sh->overflow, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipEventCreateWithFlags(&sh->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sh->ev_done, hipEventDisableTiming) != hipSuccess) {
+      rc = fail(KV_RESOURCE_EXHAUSTED, "kv_shard_create: allocation failed");
+      break;
+    }
+    *sh->overflow = 0;
+    if ((rc = shard_alloc_buffers(sh, (unsigned)C))) break;
+  } while (0);
+  if (rc) { kv_shard_destroy(sh); return rc; }
+  *out = sh;
+  return KV_OK;
+}
+
+int kv_shard_destroy(kv_shard_t sh) {
+  if (!sh) return KV_OK;
+  DeviceGuard dg(sh->table->device);
+  hipDeviceSynchronize();
+  shard_free_buffers(sh);
+  hipFree(sh->uniq); hipFree(sh->ucnt); hipFree(sh->slot_of); hipFree(sh->counts); hipFree(sh->hist); hipFree(sh->gcount);
+  if (sh->overflow) hipHostFree(sh->overflow);
+  if (sh->ev_fork) hipEventDestroy(sh->ev_fork);
+  if (sh->ev_done) hipEventDestroy(sh->ev_done);
+  if (sh->route) kv_destroy(sh->route);
+  delete sh;
+  return KV_OK;
+}
+
+int kv_shard_buffers(kv_shard_t sh, void** send_pairs, void** recv_pairs, void** send_rows, void** recv_rows,
+                     int64_t* pair_bytes_per_peer, int64_t* row_bytes_per_peer) {
+  if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
+  if (send_pairs) *send_pairs = sh->send_pairs;
+  if (recv_pairs) *recv_pairs = sh->recv_pairs;
+  if (send_rows) *send_rows = sh->send_rows;
+  if (recv_rows) *recv_rows = sh->recv_rows;
+  if (pair_bytes_per_peer) *pair_bytes_per_peer = (int64_t)(sh->C + 1) * 16;
+  if (row_bytes_per_peer) *row_bytes_per_peer = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+  return KV_OK;
+}
+
+// ids -> local unique ids with counts -> the owners' segments of the send buffer.  7 launches, no host sync.
+int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
+  if (!sh || (n > 0 && !ids) || n < 0 || n > sh->max_ids) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup_route: n %lld (max %lld)", (long long)n, sh ? sh->max_ids : 0ll);
+  DeviceGuard dg(sh->table->device);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (*reinterpret_cast<volatile unsigned*>(sh->overflow)) {   // an earlier batch did not fit its segments: grow, report
+    HIP_TRY(hipStreamSynchronize(s));
+    *reinterpret_cast<volatile unsigned*>(sh->overflow) = 0;
+    const unsigned C2 = (unsigned)std::min<long long>(sh->max_ids, 2ll * sh->C);
+    if ((rc = shard_alloc_buffers(sh, C2))) return rc;
+    return fail(KV_RESOURCE_EXHAUSTED, "a sharded batch sent more than peer_capacity ids to one owner (the surplus read zeros); "
+                                       "capacity doubled to %u, re-issue the batch", C2);
+  }
+  kv_table* rt = sh->route;
+  std::lock_guard<std::mutex> l(rt->mu);
+  sh->n_last = n;
+  sh->route_token = 0;
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, s));
+    k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+    return KV_OK;
+  }
+  if ((rc = ensure_workspace(rt, n, true, s))) return rc;
+  const WsDev wd = ws_view(rt, n);
+  PartArgs pa{};
+  pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+  pa.out_keys = sh->uniq;
+  pa.out_counts = sh->ucnt;
+  pa.det = sh->table->deterministic ? 1 : 0;
+  pa.n = n;
+  // tile + partition passes only: kv_shard_lookup_finish's gather files the positions (order, work items) on its way
+  launch_tile<false>(rt, wd, ids, nullptr, n, s, 0);
+  launch_part_keys<MODE_UNIQUE>(wd, pa, s);
+  rt->batch_serial = ++g_serial;
+  rt->batch_n = n;
+  sh->route_token = rt->batch_serial;
+  sh->ordered = false;
+  const unsigned ntr = (unsigned)((n + RT - 1) / RT);
+  if (!pa.det) {
+    k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, wd.ctr, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
+                                           sh->overflow, sh->gcount);
+    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
+  k_owner_hist_u32<<<ntr, TB, 0, s>>>(sh->uniq, wd.ctr, sh->world, sh->rule, ntr, sh->hist);
+  k_owner_scan<<<1, 1024, 0, s>>>(sh->hist, ntr * sh->world, ntr, sh->world, sh->counts);
+  k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+  k_owner_scatter_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, wd.ctr, sh->world, sh->rule, ntr, sh->hist, sh->C, sh->send_pairs,
+                                           sh->slot_of, sh->overflow);
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+// the owner's half: the ids the peers sent (recv_pairs) are looked up in this rank's table — frequency words count
+// every occurrence — and their rows go to send_rows, record for record.  3 launches.
+int kv_shard_lookup_serve(kv_shard_t sh, kv_stream_t stream) {
+  if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
+  const int64_t nrec = (int64_t)sh->world * (sh->C + 1);
+  sh->serve_token = 0;
+  return gather_or_insert_impl(sh->table, sh->recv_pairs, nullptr, nrec, sh->send_rows, stream, 1, &sh->serve_token, sh->C + 1);
+}
+
+// out[i] = the row that came back for ids[i].  1 launch.
+int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
+  if (!sh || (sh->n_last > 0 && !out)) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup_finish: output pointer is null");
+  if (sh->n_last == 0) return KV_OK;
+  DeviceGuard dg(sh->table->device);
+  kv_table* rt = sh->route;
+  std::lock_guard<std::mutex> l(rt->mu);
+  if (rt->batch_serial != sh->route_token || sh->route_token == 0) return fail(KV_FAILED_PRECONDITION, "kv_shard_lookup_finish without kv_shard_lookup_route");
+  // the training lookup's gather (k_gather<ORDER>) over the rows that came back: position -> entry -> dense unique
+  // index -> the record its id was sent in; the same pass files the positions for the gradient sum to come
+  WsDev wd = ws_view(rt, sh->n_last);
+  wd.row_map = sh->slot_of;
+  TableDev rows = dev_view(rt);
+  rows.c0.rows = sh->recv_rows;
+  rows.chunk_bits = 31;
+  launch_gather(rows, wd, out, sh->n_last, (hipStream_t)stream, nullptr, 0, true);
+  sh->ordered = true;
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+// backward: the gradient rows of the batch just looked up are summed per distinct id straight into the records their
+// ids were sent in (the route index is still there: no ids, no sizes, no sync).  2 launches.
+int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
+  if (!sh || (sh->n_last > 0 && !grad)) return fail(KV_INVALID_ARGUMENT, "kv_shard_apply_route: grad pointer is null");
+  if (sh->n_last == 0) return KV_OK;
+  DeviceGuard dg(sh->table->device);
+  kv_table* rt = sh->route;
+  std::lock_guard<std::mutex> l(rt->mu);
+  if (rt->batch_serial != sh->route_token || sh->route_token == 0)
+    return fail(KV_FAILED_PRECONDITION, "kv_shard_apply_route: the batch's lookup must come first (kv_shard_lookup_route)");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
+  const WsDev wd = ws_view(rt, sh->n_last);
+  if (!sh->ordered) {   // a gradient for a batch whose rows were never fetched (kv_shard_lookup_finish skipped)
+    launch_order(dev_view(rt), wd, sh->n_last, s);
+    sh->ordered = true;
+  }
+  PartArgs pa{};
+  pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+  pa.grad = grad;
+  pa.out_sum = sh->send_rows;
+  pa.out_map = sh->slot_of;
+  pa.fold_op = KV_SCATTER_ADD;
+  pa.n = sh->n_last;
+  return launch_apply<MODE_DEDUP, OPT_ADAGRAD>(rt, wd, pa, sh->n_last, s);
+}
+
+// the owner's half: recv_rows holds the peers' summed gradients, record for record as the lookup served them; the
+// fused apply takes the index that lookup left in the table's workspace.  2 launches.
+// optimizer: 0 GroupAdam V4, 1 GroupAdam V3 (hp = lr, beta1_power, beta2_power, beta1, beta2, epsilon, l1, l2, l21),
+// 2 Adagrad (hp = lr, update_slots), 3 SparseGroupFtrl (hp = lr, l1, l2, l21, l2_shrinkage, lr_power; slot1 = linear)
+int kv_shard_apply_serve(kv_shard_t sh, int optimizer, kv_handle_t slot0, kv_handle_t slot1, const float* hp, kv_stream_t stream) {
+  if (!sh || !hp) return fail(KV_INVALID_ARGUMENT, "kv_shard_apply_serve: bad arguments");
+  if (sh->serve_token == 0 || sh->serve_token != sh->table->batch_serial)
+    return fail(KV_FAILED_PRECONDITION, "kv_shard_apply_serve: another op used the table since this batch's lookup "
+                                        "(the sharded apply takes over the lookup's index)");
+  const int64_t nrec = (int64_t)sh->world * (sh->C + 1);
+  switch (optimizer) {
+    case 0: case 1:
+      return kv_apply_group_adam_tok(sh->table, slot0, sh->recv_rows, sh->recv_pairs, nrec, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5],
+                                     hp[6], hp[7], hp[8], optimizer == 0 ? 4 : 3, sh->serve_token, stream);
+    case 2:
+      return kv_apply_adagrad_tok(sh->table, slot0, hp[0], sh->recv_rows, sh->recv_pairs, nrec, hp[1] != 0.f, sh->serve_token, stream);
+    case 3:
+      return kv_apply_sparse_group_ftrl_tok(sh->table, slot0, slot1, sh->recv_rows, sh->recv_pairs, nrec, hp[0], hp[1], hp[2], hp[3],
+                                            hp[4], hp[5], sh->serve_token, stream);
+    default:
+      return fail(KV_INVALID_ARGUMENT, "kv_shard_apply_serve: optimizer %d", optimizer);
+  }
+}
+
+// whole ops: forked from `stream` onto the shard's own stream (the caller's stream is free for the dense tower);
+// join != 0 makes `stream` wait for the result right away, else kv_shard_join does when the caller needs it
+int kv_shard_join(kv_shard_t sh, kv_stream_t stream) {
+  if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
+  DeviceGuard dg(sh->table->device);
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sh->ev_done, 0));
+  return KV_OK;
+}
+static int shard_fork(kv_shard* sh, hipStream_t s, hipStream_t work) {
+  if (s == work) return KV_OK;   // the caller works on the communicator's stream itself: one queue, no hops
+  HIP_TRY(hipEventRecord(sh->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(work, sh->ev_fork, 0));
+  return KV_OK;
+}
+static int shard_done(kv_shard* sh, hipStream_t s, hipStream_t work, int join) {
+  HIP_TRY(hipEventRecord(sh->ev_done, work));
+  if (join && s != work) HIP_TRY(hipStreamWaitEvent(s, sh->ev_done, 0));
+  return KV_OK;
+}
+
+int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, float* out, int join, kv_stream_t stream) {
+  if (!sh || !comm || comm->world != sh->world) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup: shard / communicator mismatch");
+  DeviceGuard dg(sh->table->device);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  hipStream_t w = comm->stream;   // phases and exchanges in one queue: no event hop between a kernel and its exchange
+  if ((rc = shard_fork(sh, s, w))) return rc;
+  const int64_t pb = (int64_t)(sh->C + 1) * 16, rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+  if ((rc = kv_shard_lookup_route(sh, ids, n, w))) return rc;
+  if ((rc = kv_comm_all_to_all(comm, sh->send_pairs, sh->recv_pairs, comm->comm ? pb : pb * sh->world, w))) return rc;
+  if ((rc = kv_shard_lookup_serve(sh, w))) return rc;
+  if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
+  if ((rc = kv_shard_lookup_finish(sh, out, w))) return rc;
+  return shard_done(sh, s, w, join);
+}
+
+int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1, const float* grad,
+                   const float* hp, int join, kv_stream_t stream) {
+  if (!sh || !comm || comm->world != sh->world) return fail(KV_INVALID_ARGUMENT, "kv_shard_apply: shard / communicator mismatch");
+  DeviceGuard dg(sh->table->device);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  hipStream_t w = comm->stream;
+  if ((rc = shard_fork(sh, s, w))) return rc;
+  const int64_t rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+  if ((rc = kv_shard_apply_route(sh, grad, w))) return rc;
+  if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
+  if ((rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w))) return rc;
+  return shard_done(sh, s, w, join);
+}
+
+// The exchange between shards that live in ONE process (all on one device): segment r of shard p's send buffer to
+// segment p of shard r's receive buffer.  what: 0 = the (id, count) records, 1 = the rows.  This is how the
+// phases are exercised with several ranks on a single GPU (RCCL refuses two ranks on one device).
+int kv_shard_exchange_local(const kv_shard_t* shards, int world, int what, kv_stream_t stream) {
+  if (!shards || world < 1) return fail(KV_INVALID_ARGUMENT, "kv_shard_exchange_local: bad arguments");
+  for (int p = 0; p < world; ++p)
+    if (!shards[p] || shards[p]->world != world || shards[p]->C != shards[0]->C || shards[p]->table->dim != shards[0]->table->dim)
+      return fail(KV_INVALID_ARGUMENT, "kv_shard_exchange_local: shards differ in world / capacity / dim");
+  DeviceGuard dg(shards[0]->table->device);
+  const size_t rec = shards[0]->C + 1;
+  const size_t bytes = rec * (what == 0 ? 16 : (size_t)shards[0]->table->dim * sizeof(float));
+  for (int p = 0; p < world; ++p)
+    for (int r = 0; r < world; ++r) {
+      const char* src = what == 0 ? (const char*)shards[p]->send_pairs : (const char*)shards[p]->send_rows;
+      char* dst = what == 0 ? (char*)shards[r]->recv_pairs : (char*)shards[r]->recv_rows;
+      HIP_TRY(hipMemcpyAsync(dst + (size_t)p * bytes, src + (size_t)r * bytes, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
   return KV_OK;
 }
 

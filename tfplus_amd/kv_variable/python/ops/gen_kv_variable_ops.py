@@ -463,7 +463,7 @@ def kv_profile_read(table_handle):
   return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 
-def kv_bucket_by_owner(table_handle, indices, world, n_dev=None, id_counts=None, with_payload=False):
+def kv_bucket_by_owner(table_handle, indices, world, n_dev=None, id_counts=None, with_payload=False, owner_rule=0):
   """Counting sort of the ids by owner rank floor_mod(id, world) on the GPU.
   Returns (ids grouped by owner, perm [n] int32 of input positions, counts [world] int64 on device).
   n_dev (1-element int64 device tensor): the list's real length when it is still on the device.
@@ -479,7 +479,7 @@ def kv_bucket_by_owner(table_handle, indices, world, n_dev=None, id_counts=None,
     pairs = torch.empty((ids.numel(), 2), dtype=torch.int64, device=dev)
     pos = torch.empty(ids.numel(), dtype=torch.int32, device=dev)
     cin = None if id_counts is None else id_counts.to(torch.int32).contiguous()
-  _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), _p(n_dev), int(world), _p(out),
+  _lib.check(_lib.lib().kv_bucket_by_owner(table_handle.ptr, _p(ids), ids.numel(), _p(n_dev), int(world), int(owner_rule), _p(out),
                                            _p(perm), ctypes.c_void_p(counts.data_ptr()), _p(cin), _p(pairs), _p(pos),
                                            _stream(table_handle)))
   return (out, perm, counts, pairs, pos) if with_payload else (out, perm, counts)
@@ -705,3 +705,115 @@ def kv_unique(table_handle, indices, counts=None, sync=True):
   _lib.check(_lib.lib().kv_unique(table_handle.ptr, _p(ids), _p(cnt), n, _p(uniq), _p(ucnt), _p(inv),
                                   ctypes.byref(nu), None, _stream(table_handle)))
   return uniq[:nu.value], ucnt[:nu.value], inv
+
+
+# ---- sharded tables: the native path (kvhip.h kv_comm_* / kv_shard_*) -------------------------------------
+KV_OWNER_HASH, KV_OWNER_MOD = 0, 1
+OPT_GROUP_ADAM_V4, OPT_GROUP_ADAM_V3, OPT_ADAGRAD, OPT_SPARSE_GROUP_FTRL = 0, 1, 2, 3
+
+
+class KvComm(object):
+  """RCCL communicator of the library (grouped ncclSend / ncclRecv on its own stream)."""
+
+  def __init__(self, world, rank, id128=None, device=0):
+    self.ptr = ctypes.c_void_p()
+    buf = None if id128 is None else ctypes.create_string_buffer(bytes(id128), 128)
+    _lib.check(_lib.lib().kv_comm_create(int(world), int(rank), buf, int(device), ctypes.byref(self.ptr)))
+    self.world, self.rank = world, rank
+
+  def stream(self):
+    """The communicator's stream as a torch stream: work queued there reaches the sharded ops without an event hop."""
+    st = ctypes.c_void_p()
+    _lib.check(_lib.lib().kv_comm_stream(self.ptr, ctypes.byref(st)))
+    return torch.cuda.ExternalStream(st.value)
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        _lib.lib().kv_comm_destroy(self.ptr)
+        self.ptr = None
+    except Exception:  # interpreter shutdown
+      pass
+
+
+def kv_comm_unique_id():
+  buf = ctypes.create_string_buffer(128)
+  _lib.check(_lib.lib().kv_comm_unique_id(buf))
+  return buf.raw
+
+
+def kv_comm_from_torch_distributed(device, group=None):
+  """One KvComm per rank of a torch.distributed group: rank 0's unique id travels through the group."""
+  import torch.distributed as dist
+  world, rank = dist.get_world_size(group), dist.get_rank(group)
+  box = [kv_comm_unique_id() if rank == 0 else None]
+  dist.broadcast_object_list(box, src=0, group=group)
+  return KvComm(world, rank, box[0], device)
+
+
+class KvShard(object):
+  """This rank's side of a table sharded over `world` ranks (kvhip.h kv_shard_create)."""
+
+  def __init__(self, table_handle, world, rank, owner_rule=KV_OWNER_HASH, max_ids=1 << 20, peer_capacity=0):
+    self.table = table_handle
+    self.ptr = ctypes.c_void_p()
+    _lib.check(_lib.lib().kv_shard_create(table_handle.ptr, int(world), int(rank), int(owner_rule), int(max_ids),
+                                          int(peer_capacity), ctypes.byref(self.ptr)))
+    self.world, self.rank = world, rank
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        _lib.lib().kv_shard_destroy(self.ptr)
+        self.ptr = None
+    except Exception:  # interpreter shutdown
+      pass
+
+  # whole ops over a KvComm
+  def lookup(self, comm, indices, join=True):
+    ids = _ids(self.table, indices)
+    out = _gather_out(self.table, ids)
+    _lib.check(_lib.lib().kv_shard_lookup(self.ptr, comm.ptr, _p(ids), ids.numel(), _p(out), int(bool(join)), _stream(self.table)))
+    self._keep = (ids, out)     # the shard's stream may still be reading / writing them
+    return out
+
+  def apply(self, comm, optimizer, slots, grad, hp, join=True):
+    g = _f32(self.table, grad)
+    arr = (ctypes.c_float * len(hp))(*[float(np.float32(x)) for x in hp])
+    s0 = slots[0].ptr
+    s1 = slots[1].ptr if len(slots) > 1 else None
+    _lib.check(_lib.lib().kv_shard_apply(self.ptr, comm.ptr, int(optimizer), s0, s1, _p(g), arr, int(bool(join)), _stream(self.table)))
+    self._keep_g = g
+
+  def join(self):
+    _lib.check(_lib.lib().kv_shard_join(self.ptr, _stream(self.table)))
+
+  # the phases, for an exchange the caller provides
+  def lookup_route(self, indices):
+    ids = _ids(self.table, indices)
+    _lib.check(_lib.lib().kv_shard_lookup_route(self.ptr, _p(ids), ids.numel(), _stream(self.table)))
+    self._ids = ids
+
+  def lookup_serve(self):
+    _lib.check(_lib.lib().kv_shard_lookup_serve(self.ptr, _stream(self.table)))
+
+  def lookup_finish(self):
+    out = _gather_out(self.table, self._ids)
+    _lib.check(_lib.lib().kv_shard_lookup_finish(self.ptr, _p(out), _stream(self.table)))
+    return out
+
+  def apply_route(self, grad):
+    g = _f32(self.table, grad)
+    _lib.check(_lib.lib().kv_shard_apply_route(self.ptr, _p(g), _stream(self.table)))
+    self._keep_g = g
+
+  def apply_serve(self, optimizer, slots, hp):
+    arr = (ctypes.c_float * len(hp))(*[float(np.float32(x)) for x in hp])
+    s1 = slots[1].ptr if len(slots) > 1 else None
+    _lib.check(_lib.lib().kv_shard_apply_serve(self.ptr, int(optimizer), slots[0].ptr, s1, arr, _stream(self.table)))
+
+
+def kv_shard_exchange_local(shards, what):
+  """Exchange between shards of one process on one device (what: 0 records, 1 rows)."""
+  arr = (ctypes.c_void_p * len(shards))(*[s.ptr for s in shards])
+  _lib.check(_lib.lib().kv_shard_exchange_local(arr, len(shards), int(what), _stream(shards[0].table)))

@@ -4,8 +4,13 @@ own link; no ring collective and no all-reduce anywhere on this path).
 
 The reference has no communication layer: multi-device there is TF1 PS/worker placement of
 partitioned variables with `ids % num_shards` (python/ops/embedding_ops.py:115-204,
-kernels/utility.h:90-107).  The same floor-mod rule decides ownership here, so a checkpoint
+kernels/utility.h:90-107).  Ownership here is hashed by default (mix64(id) % world: raw Criteo-style ids
+are not uniform mod 8); the reference's floor-mod rule is the "mod" option, under which a checkpoint
 partitioned by the reference maps shard-for-shard onto ranks.
+
+This module is the torch.distributed statement of the exchange (variable-size all_to_all; runs on CPU / gloo in
+the tests).  The production path is native: gen_kv_variable_ops.KvShard / KvComm over kvhip.h's kv_shard_* and
+kv_comm_* — fixed-capacity segments, no size exchange, no host synchronisation, RCCL on a stream of its own.
 
 Per lookup and rank:  local unique-with-counts -> bucket the unique ids by owner -> all_to_all of
 bucket sizes (the one host sync) -> all_to_all of (id, occurrence count) pairs -> owner-side
@@ -33,12 +38,31 @@ class Routing(object):
     self.n_recv = int(sum(recv_counts))
 
 
-def owner_of(ids, world):
-  """floor-mod ownership (negative ids included), the reference's ModKeyImpl (utility.h:90-107)."""
-  return torch.remainder(ids, world)
+def _mix64(x):
+  """the library's mix64 (kv_device.h) on int64 tensors: wrapping multiplies, logical shifts."""
+  def lsr(v, s):
+    return (v >> s) & ((1 << (64 - s)) - 1)
+  def c(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+  x = x ^ lsr(x, 33)
+  x = x * c(0xff51afd7ed558ccd)
+  x = x ^ lsr(x, 33)
+  x = x * c(0xc4ceb9fe1a85ec53)
+  return x ^ lsr(x, 33)
 
 
-def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None, id_counts=None):
+def owner_of(ids, world, rule="hash"):
+  """Owner rank of every id.  "hash" (default): mix64(id) % world as an unsigned value — balanced whatever the ids
+  look like (kvhip.h KV_OWNER_HASH).  "mod": floor-mod (negative ids included), the reference's ModKeyImpl
+  (utility.h:90-107), for checkpoints partitioned by it."""
+  if rule == "mod":
+    return torch.remainder(ids, world)
+  h = _mix64(ids.to(torch.int64))
+  # unsigned h % world from the signed value: h + 2^64 for negative h
+  return torch.remainder(torch.remainder(h, world) + (h < 0).to(torch.int64) * ((1 << 64) % world), world)
+
+
+def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None, id_counts=None, rule="hash"):
   """Buckets a flat id tensor by owner rank and exchanges the bucket sizes.  `bucket_fn(ids, world
   [, n_dev])` -> (bucketed ids, perm, counts) is the GPU counting sort (kv_bucket_by_owner); without
   it the same thing is done with torch ops (CPU tests).  known_counts = (send, recv) python lists
@@ -53,7 +77,7 @@ def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None, id_cou
     if len(res) == 5:                 # (id, count) pairs in bucket order + inverse of perm, from the same kernel
       pairs, pos = res[3], res[4]
   else:
-    own = owner_of(ids, world)
+    own = owner_of(ids, world, rule)
     perm = torch.argsort(own, stable=True)
     send = torch.bincount(own, minlength=world).to(torch.int64)
   if known_counts is not None:
@@ -127,7 +151,8 @@ class ShardedKvVariable(object):
   kv_bucket_by_owner / kv_take_rows).  Without them torch ops do the same (CPU tests)."""
 
   def __init__(self, shard, group=None, bucket_fn=None, unique_fn=None, segsum_fn=None, take_fn=None,
-               index_sum_fn=None, unique_async_fn=None):
+               index_sum_fn=None, unique_async_fn=None, owner_rule="hash"):
+    self.owner_rule = owner_rule   # "hash" (default) or "mod"; a bucket_fn must implement the same rule
     self.shard = shard          # the rank-local table (KvVariable, or any stand-in with the same calls)
     self.group = group
     self.bucket_fn, self.unique_fn, self.segsum_fn = bucket_fn, unique_fn, segsum_fn
@@ -165,12 +190,12 @@ class ShardedKvVariable(object):
     flat = ids.reshape(-1)
     if self.unique_async_fn is not None and self.bucket_fn is not None and flat.numel() > 0:
       uniq, ucnt, inv, nu_dev = self.unique_async_fn(flat, counts)
-      rt, U = route(uniq, self.group, self.bucket_fn, n_dev=nu_dev, id_counts=ucnt)
+      rt, U = route(uniq, self.group, self.bucket_fn, n_dev=nu_dev, id_counts=ucnt, rule=self.owner_rule)
       uniq, ucnt = uniq[:U], ucnt[:U]
     else:
       uniq, ucnt, inv = self._unique(flat, counts)
       U = int(uniq.numel())
-      rt = route(uniq, self.group, self.bucket_fn)
+      rt = route(uniq, self.group, self.bucket_fn, rule=self.owner_rule)
     # one payload for ids and their occurrence counts
     if rt.pairs is not None:
       payload = rt.pairs
@@ -205,7 +230,7 @@ class ShardedKvVariable(object):
       apply_fn(self.shard, g, served)
       return
     uniq, summed = self._segsum(flat, g2)
-    rt = route(uniq, self.group, self.bucket_fn)
+    rt = route(uniq, self.group, self.bucket_fn, rule=self.owner_rule)
     served = exchange(rt, uniq, group=self.group, presorted=rt.bucketed_ids, take_fn=self.take_fn)
     g = exchange(rt, summed, group=self.group, take_fn=self.take_fn)
     apply_fn(self.shard, g, served)
