@@ -192,7 +192,10 @@ int kv_dedup_segment_sum(kv_handle_t h, const void* ids, const float* grad, int6
  * allocates and kv_export_fill writes keys [num_rows], values [num_rows, dim],
  * blacklist [blacklist_nums], freq_keys / freq_values [freq_nums] (any of the last three may be
  * NULL when its count is 0).  first_n: 2 = keys+values; >3 adds blacklist; >4 adds the uint32
- * frequency words.  Row order is unspecified (the reference's is hash-map iteration order). */
+ * frequency words.  Row order is unspecified (the reference's is hash-map iteration order).
+ * The fill must follow its count directly: any other op on the table in between (the buffers would no longer be
+ * known to fit) makes it return KV_FAILED_PRECONDITION; count again.  The same holds for kv_export_delta_count /
+ * _fill and for kv_delete_with_timestamp's dry run / real run. */
 int kv_export_count(kv_handle_t h, int first_n, int64_t* counts, kv_stream_t stream);
 int kv_export_fill(kv_handle_t h, int first_n, int64_t* keys, float* values, int64_t* blacklist,
                    int64_t* freq_keys, uint32_t* freq_values, kv_stream_t stream);

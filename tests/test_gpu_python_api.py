@@ -49,6 +49,39 @@ def _const_weights(api, name, embedding_dim=64, num_shards=1, enter_threshold=0)
   return w, scatter
 
 
+def test_insert_kv_embedding_splits_pairs_over_the_partitions(api):
+  """embedding_ops.py:704-756: ids % num_partition picks the partition, scatter_update stores the pair."""
+  w, _ = _const_weights(api, "insert/kv_embedding", 8, 3)
+  ids = torch.tensor([5, -7, 12, 3, 5 + 3 * 40], dtype=torch.int64)
+  vals = torch.arange(5 * 8, dtype=torch.float32).reshape(5, 8)
+  res = api.eo.insert_kv_embedding(w, ids, vals)
+  assert len(res) == 3
+  got = api.eo.embedding_lookup(w, ids)
+  assert torch.equal(got.cpu(), vals)
+  for p, part in enumerate(list(w)):
+    keys = part._read_variable_op()[0].cpu().tolist()
+    assert sorted(keys) == sorted(int(i) for i in ids.tolist() if i % 3 == p)
+  single, _ = _const_weights(api, "insert_single/kv_embedding", 8, 1)
+  with pytest.raises(ValueError, match="Unknown KvVariable"):
+    api.eo.insert_kv_embedding(single, ids, vals)          # not a partitioned variable's part
+  with pytest.raises(AssertionError):
+    api.eo.insert_kv_embedding(w, ids.to(torch.int32), vals)
+
+
+def test_optimizer_slots_are_bound_to_the_variable_object(api):
+  """A slot found under id(var) must belong to that very variable (ids of collected objects are reused)."""
+  opt = api.tr.AdagradOptimizer(0.1)
+  v1 = api.vs.get_kv_variable("slotbind/a", embedding_dim=4, key_dtype=torch.int64, initializer=api.vs.ones_initializer)
+  s1 = opt._zeros_slot(v1, "accumulator", "Adagrad")
+  assert opt.get_slot(v1, "accumulator") is s1
+  d = opt._slot_dict("accumulator")
+  v2 = api.vs.get_kv_variable("slotbind/b", embedding_dim=4, key_dtype=torch.int64, initializer=api.vs.ones_initializer)
+  d[id(v2)] = d[id(v1)]                                       # what a recycled id would look like
+  assert opt.get_slot(v2, "accumulator") is None
+  s2 = opt._zeros_slot(v2, "accumulator", "Adagrad")
+  assert s2 is not s1 and opt.get_slot(v2, "accumulator") is s2
+
+
 @pytest.mark.parametrize("shards", [2, 10])
 def test_embedding_lookup_sharded_equals_unsharded(api, shards):
   p1, sc1 = _const_weights(api, "no_shards/kv_embedding", 64, 1)

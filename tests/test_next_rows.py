@@ -267,3 +267,32 @@ def test_delta_import_parity(ops, first_n):
   d = ops.kv_variable_full_or_delta_export(h, do_full_export=False)   # nothing tracked: an empty delta
   assert d[5] is False and d[0].numel() == 0 and d[6].numel() == 0
   assert ops.kv_variable_full_or_delta_export(h, True)[5] is True
+
+
+@pytest.mark.gpu
+def test_export_fill_refuses_buffers_sized_before_another_op(ops):
+  """The two-phase calls hand the library buffers sized from an earlier count: a lookup in between (new rows) must
+  make the fill fail instead of writing past them (kvhip.h: kv_export_count / kv_export_fill)."""
+  import ctypes
+  import torch
+  from tfplus_amd import _lib
+  h, _ = _pair(ops, 8)
+  ops.kv_variable_gather_or_insert_v2(h, np.arange(100, dtype=np.int64))
+  L = _lib.lib()
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  cnt = (ctypes.c_int64 * 3)()
+  _lib.check(L.kv_export_count(h.ptr, 2, cnt, st))
+  assert cnt[0] == 100
+  keys = torch.empty(100, dtype=torch.int64, device="cuda"); vals = torch.empty((100, 8), device="cuda")
+  ops.kv_variable_gather_or_insert_v2(h, np.arange(100, 5000, dtype=np.int64))       # 4900 more rows
+  rc = L.kv_export_fill(h.ptr, 2, keys.data_ptr(), vals.data_ptr(), None, None, None, st)
+  assert rc == _lib.KV_FAILED_PRECONDITION
+  assert "count again" in L.kv_last_error().decode()
+  k, v = ops.read_kv_variable_op_v2(h)                                               # count + fill back to back
+  assert k.numel() == 5000
+  # the timed delete: a dry run sizes the key buffer
+  n = ctypes.c_int64()
+  _lib.check(L.kv_delete_with_timestamp(h.ptr, 0, 1, None, ctypes.byref(n), st))
+  ops.kv_variable_gather_or_insert_v2(h, np.arange(5000, 5100, dtype=np.int64))
+  out = torch.empty(max(int(n.value), 1), dtype=torch.int64, device="cuda")
+  assert L.kv_delete_with_timestamp(h.ptr, 0, 0, out.data_ptr(), ctypes.byref(n), st) != 0

@@ -333,6 +333,9 @@ struct Workspace {
 }  // namespace
 
 struct kv_table {
+  // every op that may change which rows exist (or what the delta lists hold) advances op_serial; the two-phase
+  // calls (count, then fill into buffers the caller sized from the counts) refuse to fill once it has moved on
+  uint64_t op_serial = 1, export_serial = 0, delta_serial = 0, expire_serial = 0;
   int device = 0;
   int key_dtype = KV_DT_INT64;
   int dim = 0;
@@ -775,6 +778,7 @@ int hand_over(kv_table* t, hipStream_t s) {
   }
   t->last_stream = s;
   t->has_last = true;
+  ++t->op_serial;
   return KV_OK;
 }
 
@@ -1016,6 +1020,7 @@ int kv_set_clock_days(kv_handle_t t, int day) {
   int rc;
   if ((rc = check_table(t))) return rc;
   t->fixed_day = day;
+  ++t->op_serial;   // what a timed delete would release depends on the day
   return KV_OK;
 }
 int kv_set_seed(kv_handle_t t, uint64_t seed) {
@@ -1932,6 +1937,7 @@ int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, k
 }
 
 static int delete_locked(kv_table* t, const void* ids, int64_t n, int64_t* num_deleted, hipStream_t s) {
+  ++t->op_serial;
   int rc;
   if ((rc = ensure_free_list(t, s))) return rc;
   HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
@@ -1957,6 +1963,12 @@ int kv_delete_with_timestamp(kv_handle_t t, int threshold, int dry_run, int64_t*
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if (!dry_run) {   // out_keys was sized by a dry run: nothing may have touched the table (or its clock) since
+    if (t->expire_serial != t->op_serial)
+      return fail(KV_FAILED_PRECONDITION, "the table was used between the dry run and kv_delete_with_timestamp: the key "
+                                          "buffer sized from the count may be too small; count again");
+    ++t->op_serial;
+  }
   unsigned nrows = 1;
   if ((rc = stats(t, s, nullptr, &nrows))) return rc;
   if (!dry_run && (rc = ensure_free_list(t, s))) return rc;
@@ -1973,6 +1985,7 @@ int kv_delete_with_timestamp(kv_handle_t t, int threshold, int dry_run, int64_t*
     return rc;
   }
   *count = (int64_t)rel;
+  if (dry_run) t->expire_serial = t->op_serial;
   if (!dry_run && (rc = record_deleted(t, out_keys, (int64_t)rel, false, s))) return rc;
   return KV_OK;
 }
@@ -2092,6 +2105,7 @@ int kv_export_count(kv_handle_t t, int first_n, int64_t* counts, kv_stream_t str
   unsigned long long c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_stat, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  t->export_serial = t->op_serial;
   counts[0] = (int64_t)c[0]; counts[1] = (int64_t)c[1]; counts[2] = (int64_t)c[2];
   return KV_OK;
 }
@@ -2103,6 +2117,10 @@ int kv_export_fill(kv_handle_t t, int first_n, int64_t* keys, float* values, int
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if (t->export_serial != t->op_serial)
+    return fail(KV_FAILED_PRECONDITION, "the table was used between kv_export_count and kv_export_fill: the buffers sized "
+                                        "from the counts may be too small; count again");
+  ++t->op_serial;   // a fill ends the export (delta lists handed on): the next fill needs a new count
   unsigned nrows = 1;
   if ((rc = stats(t, s, nullptr, &nrows))) return rc;
   HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
@@ -2146,6 +2164,7 @@ int kv_export_delta_count(kv_handle_t t, int first_n, int64_t* counts, kv_stream
   counts[1] = first_n > 3 ? (int64_t)c[1] : 0;
   counts[2] = first_n > 4 ? (int64_t)(c[2] + absent.size()) : 0;
   counts[3] = (int64_t)absent.size() + (first_n > 3 ? 0 : (int64_t)c[1]);
+  t->delta_serial = t->op_serial;
   return KV_OK;
 }
 
@@ -2158,6 +2177,10 @@ int kv_export_delta_fill(kv_handle_t t, int first_n, int64_t* keys, float* value
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if (t->delta_serial != t->op_serial)
+    return fail(KV_FAILED_PRECONDITION, "the table was used between kv_export_delta_count and kv_export_delta_fill: the "
+                                        "buffers sized from the counts may be too small; count again");
+  ++t->op_serial;
   unsigned nrows = 1;
   if ((rc = stats(t, s, nullptr, &nrows))) return rc;
   std::vector<long long> absent;

@@ -7,6 +7,7 @@ order (:115-204).  Duplicates are NOT merged by embedding_lookup (every occurren
 the frequency); embedding_lookup_sparse merges them with unique[_with_counts] first (:364-372).
 """
 import collections
+import re
 
 import torch
 
@@ -173,3 +174,32 @@ def embedding_lookup_unique(params, ids, partition_strategy="mod", name=None):
   uniq, idx = torch.unique(ids.reshape(-1), return_inverse=True)
   emb = embedding_lookup(params, uniq, partition_strategy, name)
   return emb.index_select(0, idx.to(emb.device)).reshape(tuple(ids.shape) + tuple(emb.shape[1:]))
+
+
+def insert_kv_embedding(params, ids, values, name=None):
+  """Insert id -> value pairs into an existing (partitioned) kv embedding (embedding_ops.py:704-756): the pairs are
+  split over the partitions by `ids % num_partition` and scatter_update'd; returns the per-partition results."""
+  params = _as_list(params)
+  m = re.match(r"(.+)/part_(\d+)(:0)?$", params[0].name)   # variable names carry no ":0" here
+  if not m:
+    raise ValueError("Unknown KvVariable %s" % params[0].name)
+  prefix = m.group(1)
+  for p in params:
+    if not p.name.startswith(prefix):
+      raise ValueError("All KvVariable should be the same, found %s" % p.name)
+  dev = params[0].device
+  ids = torch.as_tensor(ids).to(dev)
+  values = torch.as_tensor(values).to(dev)
+  assert ids.dtype == params[0].key_dtype, "ids' dtype: {} not matched with embedding's {}".format(ids.dtype, params[0].key_dtype)
+  assert values.dtype == params[0].dtype, "values' dtype: {} not matched with embedding's {}".format(values.dtype, params[0].dtype)
+  assert values.shape[-1] == params[0].embedding_dim, \
+      "values' shape: {} not matched with embedding dimension {}".format(tuple(values.shape), params[0].embedding_dim)
+  np_ = len(params)
+  flat = ids.reshape(-1)
+  vals = values.reshape(-1, values.shape[-1])
+  assign = torch.remainder(flat, np_)
+  out = []
+  for p in range(np_):
+    pidx = torch.nonzero(assign == p, as_tuple=False).reshape(-1)       # dynamic_partition keeps order
+    out.append(kv_variable_ops.scatter_update(params[p], flat.index_select(0, pidx), vals.index_select(0, pidx)))
+  return out

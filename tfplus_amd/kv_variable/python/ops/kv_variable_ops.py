@@ -162,9 +162,6 @@ class KvVariable(object):
     """(keys, values) of the exported table — ReadKvVariableOpV2 (kv_variable_ops.py:1004-1009)."""
     return gen_kv_variable_ops.read_kv_variable_op_v2(self._handle)
 
-  value = _read_variable_op
-  read_value = _read_variable_op
-
   def export(self, first_n=6):
     return gen_kv_variable_ops.kv_variable_export(self._handle, first_n=first_n)
 

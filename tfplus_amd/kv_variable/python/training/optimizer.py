@@ -32,20 +32,23 @@ class Optimizer(object):
     return self._slots.setdefault(slot_name, {})
 
   def get_slot(self, var, name):
-    return self._slots.get(name, {}).get(id(var))
+    ent = self._slots.get(name, {}).get(id(var))
+    return ent[1] if ent is not None and ent[0] is var else None
 
   def get_slot_names(self):
     return sorted(self._slots)
 
   def _get_or_make_slot_with_value(self, var, value, slot_name, op_name):
     d = self._slot_dict(slot_name)
-    if id(var) not in d:
+    # keyed by id(var) but the entry holds the variable itself: the id of a collected variable can never be taken
+    # over by a new one, and a stale entry is never mistaken for the new variable's slot
+    if id(var) not in d or d[id(var)][0] is not var:
       dim = var.embedding_dim * int(var.num_concat_opt_vars)
-      d[id(var)] = variable_scope.get_kv_variable(
+      d[id(var)] = (var, variable_scope.get_kv_variable(
           "%s/%s" % (var.name, op_name), embedding_dim=dim,
           initializer=variable_scope.constant_initializer(value), key_dtype=var.key_dtype,
-          value_dtype=var.dtype, trainable=False, device=var.device.index)
-    return d[id(var)]
+          value_dtype=var.dtype, trainable=False, device=var.device.index))
+    return d[id(var)][1]
 
   def _zeros_slot(self, var, slot_name, op_name):
     return self._get_or_make_slot_with_value(var, 0.0, slot_name, op_name)

@@ -1,10 +1,11 @@
 """Condenses a scripts_prof.sh output directory into the per-kernel table kept under profiles/."""
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
-KEYS = {"k_tile<": "lookup_tile  k_tile", "k_part_keys_gather": "lookup_part  k_part_keys_gather",
-        "k_order<": "lookup_order k_order", "k_part_keys<": "apply_index  k_part_keys",
-        "k_apply_sorted<": "apply_sorted k_apply_sorted<APPLY,ADAM_V4>", "k_apply_span<": "apply_span   k_apply_span<APPLY,ADAM_V4>",
-        "k_apply_cold": "apply_cold", "k_apply_hot": "apply_hot", "k_gather_or_zeros": "gather_or_zeros"}
+KEYS = {"k_tile<": "lookup_tile  k_tile", "k_part_keys<0>": "lookup_part  k_part_keys<LOOKUP>",
+        "k_gather<8, true>": "lookup_order k_gather<8,ORDER>", "k_part_keys<6>": "apply_index  k_part_keys<APPLYIDX>",
+        "k_order": "apply_index  k_order",
+        "k_apply<1, 0": "apply_sorted k_apply<APPLY,ADAM_V4>", "k_apply_fin<1, 0": "apply_span   k_apply_fin<APPLY,ADAM_V4>",
+        "k_gather_or_zeros": "gather_or_zeros"}
 def name_of(k):
   for a, b in KEYS.items():
     if a in k: return b
