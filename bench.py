@@ -131,6 +131,8 @@ def main():
                   help="diagnostic: do not bracket kernels with HIP events in the timed region (no roofline)")
   ap.add_argument("--no-token", action="store_true",
                   help="diagnostic: the apply rebuilds the batch index instead of taking over the lookup's")
+  ap.add_argument("--deterministic", action="store_true",
+                  help="diagnostic: the tables' deterministic reduction mode (kv_set_deterministic)")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -219,6 +221,8 @@ def main():
   # steady state of a trained table: every key the optimizer has applied has its slot row remembered in
   # the var's index entry (what GroupAdamOptimizer's first apply per key leaves behind)
   ops.kv_attach_slot(var, slot)
+  if args.deterministic:
+    ops.kv_set_deterministic(var, True); ops.kv_set_deterministic(slot, True)
 
   # ---- synthetic batches, resident in HBM ----
   z = Zipf(K, args.zipf, dev)

@@ -379,8 +379,10 @@ int kv_comm_all_to_all(kv_comm_t comm, const void* send, void* recv, int64_t byt
  *   apply   kv_shard_apply_route    gradients summed per distinct id into the records their ids were sent in
  *           [exchange of the rows]
  *           kv_shard_apply_serve    the owner's fused optimizer apply, on the index its lookup left behind
- * kv_shard_lookup / kv_shard_apply chain the phases with the RCCL exchanges on the shard's own stream, forked from
- * `stream`: the caller's stream stays free for the dense tower until kv_shard_join (or join != 0). */
+ * kv_shard_lookup / kv_shard_apply chain the phases with the RCCL exchanges on the communicator's stream, forked from
+ * `stream` by an event: the caller's stream stays free for the dense tower until kv_shard_join (or join != 0).
+ * With `stream` == kv_comm_stream(comm) nothing is forked or joined (one queue, no event hops).  This rank's own
+ * segment of every exchange is a device copy; the others are one grouped ncclSend / ncclRecv pair per peer. */
 typedef struct kv_shard* kv_shard_t;
 int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule, int64_t max_ids,
                     int64_t peer_capacity, kv_shard_t* out);

@@ -149,9 +149,12 @@ def _train_pair(api, D, opt):
   return np.stack([got[i] for i in range(10)]), g.numpy().astype(np.float64)
 
 
-@pytest.mark.parametrize("D", [64, 1])
-def test_group_adam_optimizer_equals_adam(api, D):
-  res, g = _train_pair(api, D, api.tr.GroupAdamOptimizer(0.5, version=4))
+@pytest.mark.parametrize("D,version", [(64, 4), (1, 4), (64, 3), (16, 2), (16, 1)])
+def test_group_adam_optimizer_equals_adam(api, D, version):
+  # versions 1 and 2 with default kv_options take the fused slot and the V3 op (group_adam.py:141-145, 192-232)
+  opt = api.tr.GroupAdamOptimizer(0.5, version=version)
+  res, g = _train_pair(api, D, opt)
+  assert opt.get_slot_names() == ["m_v_linear"]
   b1, b2, eps = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-8))
   lr_t = 0.5 * np.sqrt(1 - b2) / (1 - b1)
   want = 1.0 - lr_t * ((1 - b1) * g) / (np.sqrt((1 - b2) * g * g) + eps)

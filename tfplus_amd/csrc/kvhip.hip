@@ -15,13 +15,14 @@
 //
 // Kernel pipeline (kv_kernels.h explains why; DESIGN.md has the byte accounting):
 //   lookup : k_tile              LDS dedup per 2048-id tile, entries sorted by hash partition
-//            k_part_keys_gather  one block owns a partition's keys: find / insert, frequency, flags, and the
-//                                keys' places in the sorted position list; further blocks of the same launch
-//                                copy the output rows (probing gather)
-//            k_order             sorted position list; rows inserted by this batch re-copied
-//   apply  : [k_tile, k_part_keys<APPLYIDX>, k_order when the batch was not just looked up]
-//            k_apply_sorted<OPT> segmented sum over the sorted positions + fused row update
-//            k_apply_span<OPT>   keys that cross chunk boundaries
+//            k_part_keys<LOOKUP> one block owns a partition's keys: find / insert, frequency, flags, the keys'
+//                                places in the sorted position list, their records and work items
+//            k_gather<ORDER>     output rows; files every position in the sorted list; item directory
+//   apply  : [k_tile, k_part_keys<APPLYIDX>, k_order unless the batch token names the lookup's index]
+//            k_apply<OPT>        hot chunks (128 rows of one key) and cold batches (one key per lane group):
+//                                segmented sum over the sorted positions + fused row update
+//            k_apply_fin<OPT>    keys that span several chunks
+//   sharded: kv_comm_* (RCCL by dlopen, grouped send / recv), kv_shard_* (route / serve / finish phases)
 //   many tables in one launch: the *_multi entry points (grid.y = table)
 //
 // Reference semantics restated per function with file:line (relative to the tfplus tree).

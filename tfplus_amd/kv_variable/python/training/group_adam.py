@@ -1,8 +1,8 @@
 """GroupAdamOptimizer — tfplus/kv_variable/python/training/group_adam.py:28-272.
 
-Adam with group lasso, on KvVariables only.  Versions 3 and 4 (default) keep one slot table
-`m_v_linear` of dim 3*D (group_adam.py:136-152) and call
-KvVariableGroupSparseApplyAdamV4 / V3 (:199-232).  beta1_power / beta2_power start at beta and are
+Adam with group lasso, on KvVariables only.  One slot table `m_v_linear` of dim 3*D (group_adam.py:136-152);
+version 4 (default) calls KvVariableGroupSparseApplyAdamV4, every other version KvVariableGroupSparseApplyAdamV3
+(:199-232: with default kv_options that is where versions 1 and 2 end up in the reference too).  beta1_power / beta2_power start at beta and are
 multiplied after the apply like TF-core's AdamOptimizer._finish, in float32.
 """
 import numpy as np
@@ -26,9 +26,9 @@ class GroupAdamOptimizer(Optimizer):
       raise ValueError("l2_regularization_strength %f needs to be positive or zero" % l2_regularization_strength)
     if l21_regularization_strength < 0.0:
       raise ValueError("l21_regularization_strength %f needs to be positive or zero" % l21_regularization_strength)
-    if version not in (3, 4):
-      raise ValueError("GroupAdam version %r: the fused m_v_linear versions 3 and 4 are supported "
-                       "(versions <= 2 use separate m / v / linear slot tables)" % (version,))
+    # Versions <= 2 keep separate m / v / linear (/ accum) slot tables only for a KvVariable with non-default
+    # kv_options (group_adam.py:141-170, 233-272); with the default options — the only ones this mirror has, there
+    # is no SSD tier here — every version below 4 takes the fused m_v_linear table and the V3 op (:192-232).
     self._lr, self._beta1, self._beta2, self._epsilon = learning_rate, beta1, beta2, epsilon
     self._l1, self._l2, self._l21 = l1_regularization_strength, l2_regularization_strength, l21_regularization_strength
     self._linear_name = linear_name

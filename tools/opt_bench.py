@@ -36,8 +36,9 @@ for name in ("group_adam", "adagrad", "ftrl"):
   for k in range(20): step(batches[k % 4][1], batches[k % 4][0])
   torch.cuda.synchronize()
   p = ops.kv_profile_read(var); ops.kv_profile_enable(var, 0)
-  tile, part = p["apply_tile"][0] / p["apply_tile"][1], p["apply_part"][0] / p["apply_part"][1]
+  per = {k: p[k][0] / max(p[k][1], 1) for k in p}
+  idx, srt, fin = per["apply_index"] * 3, per["apply_sorted"], per["apply_span"]   # index pass = 3 launches (no token here)
   bytes_ = N * (8 + 4 * D) + U * (16 + state * 4 * D) + U * state * 4 * D
-  print("%-10s apply_tile %6.1f us  apply_part %6.1f us  -> %5.2f TB/s algorithmic (%d B of state per unique key)" % (
-      name, tile * 1e3, part * 1e3, bytes_ / ((tile + part) * 1e-3) / 1e12, 2 * state * 4 * D))
+  print("%-10s index pass %6.1f us  k_apply %6.1f us  k_apply_fin %5.1f us  -> %5.2f TB/s algorithmic (%d B of state per unique key)" % (
+      name, idx * 1e3, srt * 1e3, fin * 1e3, bytes_ / ((idx + srt + fin) * 1e-3) / 1e12, 2 * state * 4 * D))
   del var, slots
