@@ -161,25 +161,6 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29511")
     if one_gpu_debug:
       dist.init_process_group("gloo", rank=rank, world_size=world)
-      from tfplus_amd.kv_variable.python.ops import sharded as _sh
-      _real_a2a, _real_allreduce = dist.all_to_all_single, dist.all_reduce
-
-      def _a2a_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        _real_a2a(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
-        out.copy_(o)
-
-      def _allreduce_host(t, op=dist.ReduceOp.SUM, group=None):
-        c = t.cpu()
-        _real_allreduce(c, op=op, group=group)
-        t.copy_(c)
-
-      class _Dist(object):
-        get_world_size = staticmethod(dist.get_world_size)
-        get_rank = staticmethod(dist.get_rank)
-        all_to_all_single = staticmethod(_a2a_host)
-      _sh.dist = _Dist
-      dist.all_reduce = _allreduce_host
     else:
       dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -237,39 +218,21 @@ def main():
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
-  class LocalShard(object):
-    """The rank's table behind the calls ShardedKvVariable makes (C ABI, no allocation per step
-    beyond the served-rows buffer)."""
-
-    def sparse_read_with_counts(self, served, counts=None):
-      rows = torch.empty((served.numel(), D), dtype=torch.float32, device=dev)
-      if served.numel():
-        cp = None if counts is None else ctypes.c_void_p(counts.data_ptr())
-        _lib.check(L.kv_gather_or_insert(var.ptr, served.data_ptr(), cp, served.numel(), rows.data_ptr(), stream))
-      return rows
-
-    def sparse_read_pairs(self, pairs):
-      rows = torch.empty((pairs.shape[0], D), dtype=torch.float32, device=dev)
-      if pairs.shape[0]:
-        p = pairs.contiguous()
-        _lib.check(L.kv_gather_or_insert_pairs(var.ptr, p.data_ptr(), p.shape[0], rows.data_ptr(), stream))
-      return rows
-
-    def apply(self, g, served):
-      if served.numel():
-        _lib.check(L.kv_apply_group_adam(var.ptr, slot.ptr, g.data_ptr(), served.data_ptr(), served.numel(), 1e-3,
-                                         float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
-                                         0.0, 4, stream))
-
   native_shard = shard_path and not one_gpu_debug
+
+  def peer_capacity():
+    """The records one rank may send one owner per batch — a deployment constant: both ends of every send / recv
+    must agree on it without talking, so it is the SAME number on every rank (max over ranks here).  Sized from
+    the workload: the most distinct ids any pooled batch holds, shared evenly by the hash, plus a quarter."""
+    m = torch.tensor([max(p[2] for p in pool)], dtype=torch.int64, device="cpu" if (one_gpu_debug or world == 1) else dev)
+    if world > 1:
+      dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return int(int(m.item()) / world * 1.25) + 1024
   if native_shard:
     # the production path: kvhip.h kv_shard_* over a kv_comm (RCCL grouped send / recv on its own stream; a world of
     # one still goes through RCCL here so that --force-sharded prices the whole mechanism)
     comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
-    # peer_capacity: the records one rank may send one owner per batch — a deployment constant (both ends of every
-    # send / recv must agree on it without talking).  Sized from the workload: the most distinct ids any pooled
-    # batch holds, shared evenly by the hash, plus a quarter.
-    cap = int(max(p[2] for p in pool) / world * 1.25) + 1024
+    cap = peer_capacity()
     shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
     hp_t = ctypes.c_float * 9
     # this step has no dense tower to overlap with: queue it on the communicator's own stream, so the ops fork and
@@ -279,13 +242,19 @@ def main():
     torch.cuda.set_stream(comm_stream)
     stream = ctypes.c_void_p(comm_stream.cuda_stream)
   elif shard_path:
-    from tfplus_amd.kv_variable.python.ops import sharded
-    skv = sharded.ShardedKvVariable(LocalShard(), bucket_fn=lambda i, w, nd=None, c=None: ops.kv_bucket_by_owner(var, i, w, nd, c, with_payload=nd is not None),
-                                    unique_fn=lambda i, c: ops.kv_unique(var, i, c),
-                                    segsum_fn=lambda i, g: ops.kv_dedup_segment_sum(var, i, g),
-                                    take_fn=ops.kv_take_rows,
-                                    index_sum_fn=lambda g, i, n: ops.kv_unsorted_segment_sum(var, g, i, n),
-                                    unique_async_fn=lambda i, c: ops.kv_unique(var, i, c, sync=False))
+    # debugging mode (KV_BENCH_ONE_GPU=1): the same native phases, every rank on cuda:0, the fixed-size segments
+    # moved between the processes through gloo on the host (RCCL refuses two ranks on one device)
+    cap = peer_capacity()
+    shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
+    hp_t = ctypes.c_float * 9
+    bufs = shard.buffers()
+
+    def xchg(what):
+      send, recv = (bufs["send_pairs"], bufs["recv_pairs"]) if what == 0 else (bufs["send_rows"], bufs["recv_rows"])
+      torch.cuda.synchronize()
+      o = torch.empty(send.numel(), dtype=torch.uint8)
+      dist.all_to_all_single(o, send.cpu())
+      recv.copy_(o)
 
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
@@ -302,8 +271,12 @@ def main():
       hp = hp_t(1e-3, float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
       _lib.check(L.kv_shard_apply(shard.ptr, comm.ptr, 0, slot.ptr, None, grad.data_ptr(), hp, 1, stream))
     else:
-      skv.lookup(ids)
-      skv.apply_gradients(lambda sh, g, served: sh.apply(g, served), grad, ids)
+      _lib.check(L.kv_shard_lookup_route(shard.ptr, ids.data_ptr(), N, stream)); xchg(0)
+      _lib.check(L.kv_shard_lookup_serve(shard.ptr, stream)); xchg(1)
+      _lib.check(L.kv_shard_lookup_finish(shard.ptr, out.data_ptr(), stream))
+      _lib.check(L.kv_shard_apply_route(shard.ptr, grad.data_ptr(), stream)); xchg(1)
+      hp = hp_t(1e-3, float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+      _lib.check(L.kv_shard_apply_serve(shard.ptr, 0, slot.ptr, None, hp, stream))
     state["b1p"] = np.float32(state["b1p"] * np.float32(0.9))      # TF-core Adam _finish
     state["b2p"] = np.float32(state["b2p"] * np.float32(0.999))
 
@@ -334,7 +307,7 @@ def main():
   t1 = time.perf_counter()
   dt = t1 - t0
   if world > 1:
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_debug else dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   timed = ops.kv_profile_read(var)

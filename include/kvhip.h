@@ -366,8 +366,10 @@ int kv_comm_all_to_all(kv_comm_t comm, const void* send, void* recv, int64_t byt
 /* This rank's side of a table sharded over `world` ranks: `local_table` holds the rows of the ids this rank owns
  * (optimizer slot tables are sharded the same way: same rule, same rank).  max_ids = largest batch (<= 2^21);
  * peer_capacity = (id, count) records per peer in the fixed-capacity exchange buffers (0 = twice an even share of
- * max_ids).  A batch that needs more for one owner is reported by the NEXT call (KV_RESOURCE_EXHAUSTED after the
- * capacity has been doubled; the surplus ids of that batch read zeros).
+ * max_ids); it must be the same on every rank, like world, dim and owner_rule (checked by the first exchange:
+ * KV_FAILED_PRECONDITION).  A batch that needs more for one owner: its surplus ids read zeros and their gradients
+ * are dropped; the next kv_shard_lookup / kv_shard_lookup_route returns KV_RESOURCE_EXHAUSTED AFTER queuing all its
+ * own work (a rank that reports stays in step with its peers).  Raise peer_capacity on every rank.
  *
  * One training step per rank, all on the device, no host synchronisation, no size exchange:
  *   lookup  kv_shard_lookup_route   ids -> distinct ids + occurrence counts -> the owners' segments of send_pairs

@@ -205,7 +205,7 @@ def test_native_shard_phases_match_one_unsharded_table(world, D, rule, det):
 
 
 @pytest.mark.gpu
-def test_native_shard_segment_overflow_is_reported_and_capacity_grows():
+def test_native_shard_segment_overflow_is_reported_late_and_once():
   if not torch.cuda.is_available():
     pytest.skip("needs a GPU")
   sys.path.insert(0, ROOT)
@@ -222,8 +222,18 @@ def test_native_shard_segment_overflow_is_reported_and_capacity_grows():
   out = shards[0].lookup_finish().cpu().numpy()
   assert np.count_nonzero(out.any(axis=1)) == 16                           # the surplus read zeros
   torch.cuda.synchronize()
+  # reported by the next call — after that call has queued all its work, so a reporting rank keeps step with its peers
   with pytest.raises(Exception, match="peer_capacity"):
-    shards[0].lookup_route(ids)                                           # reported by the next op; capacity doubled
+    shards[0].lookup_route(ids[:8])
+  with pytest.raises(Exception, match="peer_capacity"):
+    shards[1].lookup_route(ids[:0])                                       # shard 1 routed the same ids: its own report
+  ops.kv_shard_exchange_local(shards, 0)                                  # the reporting calls' records are there
+  for r in range(world):
+    shards[r].lookup_serve()
+  ops.kv_shard_exchange_local(shards, 1)
+  out = shards[0].lookup_finish().cpu().numpy()
+  assert out.shape == (8, D) and np.count_nonzero(out.any(axis=1)) == 8
+  shards[0].lookup_route(ids[:8])                                         # reported once
 
 
 @pytest.mark.gpu

@@ -227,29 +227,38 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
 
   // ---- phase 4: every input position learns its key's entry and its rank in the tile -----------
   if (det) {
-    // rank = occurrences of the key at smaller input positions: the thread scans its key's positions
-    // through the LDS hash slot list (O(count) per position; the deterministic mode pays for it)
-    // positions of one slot are found by a pass over the tile's slots kept in registers of all
-    // threads: publish slot per position in lwork's place (TILE entries of 2 bytes cannot hold a slot
-    // index of 13 bits? they can: LS + 1 = 4097 < 65536)
-    unsigned short* pslot = sm.lwork;   // lwork is dead (entries are written)
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      const int lp = k * TBT + tid;
-      if (base + lp < n) pslot[lp] = (unsigned short)tslot[k];
-    }
+    // rank = occurrences of the key at smaller input positions.  Positions are taken in input order: round k
+    // holds positions k * TBT .. + TBT - 1, one per thread, waves in order.  Inside a wave the lanes that hold
+    // the same entry find each other with one ballot per bit of the entry number (a match-any); across waves
+    // and rounds a running count per entry (in lwork's place: the entries are written, lwork is dead) is read
+    // and advanced wave by wave.
+    unsigned short* run = sm.lwork;
+    for (int e = tid; e <= TILE; e += TBT) run[e] = 0;
     __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
       const int lp = k * TBT + tid;
-      if (base + lp < n && tslot[k] != 0xFFFFFFFFu && sm.lcnt[tslot[k]] > 1u) {
-        const unsigned short me = (unsigned short)tslot[k];
-        unsigned r = 0;
-        for (int q = 0; q < lp; ++q) r += pslot[q] == me;
-        myrank[k] = r;
-      } else {
-        myrank[k] = 0;
+      const bool valid = base + lp < n && tslot[k] != 0xFFFFFFFFu;
+      const unsigned e = valid ? (unsigned)sm.lpos[tslot[k]] : 0u;
+      unsigned long long mask = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 11; ++b) {   // entry numbers are below TILE = 2^11
+        const bool bit = (e >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
       }
+      const unsigned rw = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      const unsigned cnt = (unsigned)__popcll(mask);
+      unsigned before = 0;
+      for (int wv = 0; wv < TBT / 64; ++wv) {   // block-uniform
+        if (wave == wv && valid) {
+          before = run[e];
+          if (rw == 0u) run[e] = (unsigned short)(before + cnt);   // the group's first lane advances the count
+        }
+        __syncthreads();
+      }
+      myrank[k] = valid ? before + rw : 0u;
     }
   }
 #pragma unroll
@@ -800,20 +809,43 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         if (off == 0u) w.ent_rec[ge] = hval[h];
       };
       if (a.det) {
-        // deterministic mode: a key's entries take their positions in tile order = ascending x; one
-        // thread per key walks the partition's entries (O(E) per key: the mode pays for it)
-        for (unsigned u = tid; u < nu; u += TBK) {
-          const unsigned s = ulist[u];
-          const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+        // deterministic mode: a key's entries take their positions in tile order = ascending x.  Entries are
+        // taken in x order, TBK per round; inside a wave an entry adds up the occurrences of the lanes before
+        // it that hold the same key (shuffle loop), across waves and rounds hrun[h] carries the key's total so
+        // far, read and advanced wave by wave.
+        const int lane = tid & 63, wave = tid >> 6;
+        for (unsigned x0 = 0; x0 < E; x0 += TBK) {   // block-uniform
+          const unsigned x = x0 + tid;
+          bool valid = x < E;
+          size_t ge = 0;
+          unsigned h = 0xFFFFFFFFu, occ = 0;
+          if (valid) {
+            ge = seg_entry(tpre, tstart, NT, x);
+            const long long key = w.ent_key[ge];
+            valid = in_round(key, R, round);
+            if (valid) {
+              bool first;
+              h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
+              occ = w.ent_a[ge] & 0xFFFFu;
+            }
+          }
+          unsigned within = 0;
+          for (int j = 0; j < 63; ++j) {   // lanes before this one with the same key
+            const unsigned hj = __shfl(h, j), oj = __shfl(occ, j);
+            if (j < lane && hj == h) within += oj;
+          }
           unsigned off = 0;
-          const unsigned rv = hrow[s];
-          for (unsigned x = 0; x < E; ++x) {
-            const size_t ge = seg_entry(tpre, tstart, NT, x);
-            if (w.ent_key[ge] != key) continue;
-            w.ent_b[ge] = rv & ROW_MASK;
-            w.ent_base[ge] = (hocc[s] + off) | (off == 0u ? HEAD_BIT : 0u);
-            if (off == 0u) w.ent_rec[ge] = hval[s];
-            off += w.ent_a[ge] & 0xFFFFu;
+          for (int wv = 0; wv < TBK / 64; ++wv) {   // block-uniform
+            if (wave == wv && valid) {
+              off = hrun[h] + within;
+              atomicAdd(&hrun[h], occ);   // after every lane of the wave has read (LDS ops of a wave are in order)
+            }
+            __syncthreads();
+          }
+          if (valid) {
+            w.ent_b[ge] = hrow[h] & ROW_MASK;
+            w.ent_base[ge] = (hocc[h] + off) | (off == 0u ? HEAD_BIT : 0u);
+            if (off == 0u) w.ent_rec[ge] = hval[h];
           }
         }
       } else if (cached) {

@@ -2449,6 +2449,7 @@ struct kv_shard {
   unsigned* overflow = nullptr;      // pinned, mapped: a segment was too small for a batch
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
+  const kv_comm* verified = nullptr; // the communicator whose ranks were seen to agree on world / capacity / dim
   uint64_t route_token = 0;
   kv_batch_token_t serve_token = 0;
   hipEvent_t ev_fork = nullptr, ev_done = nullptr;
@@ -2623,20 +2624,24 @@ int kv_shard_buffers(kv_shard_t sh, void** send_pairs, void** recv_pairs, void**
   return KV_OK;
 }
 
-// ids -> local unique ids with counts -> the owners' segments of the send buffer.  7 launches, no host sync.
-int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
+// A batch that sent one owner more than peer_capacity distinct ids raised the pinned flag (the surplus read zeros).
+// It is reported by the first call that ENDS after the flag landed — after that call has queued all its work, so a
+// rank that reports keeps step with its peers (an early return would leave them waiting in the exchange).  The
+// capacity is not changed here: it must change on every rank at once.
+static int shard_late_report(kv_shard* sh) {
+  if (!*reinterpret_cast<volatile unsigned*>(sh->overflow)) return KV_OK;
+  *reinterpret_cast<volatile unsigned*>(sh->overflow) = 0;
+  return fail(KV_RESOURCE_EXHAUSTED, "an earlier sharded batch sent one owner more than peer_capacity (%u) distinct ids: the surplus "
+                                     "ids read zeros and their gradients were dropped (this call itself was queued in full); "
+                                     "create the shards with a larger peer_capacity on every rank", sh->C);
+}
+
+// ids -> local unique ids with counts -> the owners' segments of the send buffer.  4 launches, no host sync.
+static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
   if (!sh || (n > 0 && !ids) || n < 0 || n > sh->max_ids) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup_route: n %lld (max %lld)", (long long)n, sh ? sh->max_ids : 0ll);
   DeviceGuard dg(sh->table->device);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (*reinterpret_cast<volatile unsigned*>(sh->overflow)) {   // an earlier batch did not fit its segments: grow, report
-    HIP_TRY(hipStreamSynchronize(s));
-    *reinterpret_cast<volatile unsigned*>(sh->overflow) = 0;
-    const unsigned C2 = (unsigned)std::min<long long>(sh->max_ids, 2ll * sh->C);
-    if ((rc = shard_alloc_buffers(sh, C2))) return rc;
-    return fail(KV_RESOURCE_EXHAUSTED, "a sharded batch sent more than peer_capacity ids to one owner (the surplus read zeros); "
-                                       "capacity doubled to %u, re-issue the batch", C2);
-  }
   kv_table* rt = sh->route;
   std::lock_guard<std::mutex> l(rt->mu);
   sh->n_last = n;
@@ -2676,6 +2681,12 @@ int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t
                                            sh->slot_of, sh->overflow);
   HIP_TRY(hipGetLastError());
   return KV_OK;
+}
+
+int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
+  int rc;
+  if ((rc = lookup_route_impl(sh, ids, n, stream))) return rc;
+  return shard_late_report(sh);
 }
 
 // the owner's half: the ids the peers sent (recv_pairs) are looked up in this rank's table — frequency words count
@@ -2780,20 +2791,57 @@ static int shard_done(kv_shard* sh, hipStream_t s, hipStream_t work, int join) {
   return KV_OK;
 }
 
+// Once per (shard, communicator): every rank tells every other its {world, rank, capacity, dim, owner rule}.  The
+// exchange has no size negotiation, so ranks that disagree would otherwise hang in RCCL or read each other's padding.
+static int shard_verify(kv_shard* sh, kv_comm* comm) {
+  if (sh->verified == comm) return KV_OK;
+  const int W = sh->world;
+  std::vector<long long> mine((size_t)W * 4), theirs((size_t)W * 4, 0);
+  for (int p = 0; p < W; ++p) {
+    mine[4 * p] = ((long long)W << 32) | (unsigned)sh->rank;
+    mine[4 * p + 1] = sh->C; mine[4 * p + 2] = sh->table->dim; mine[4 * p + 3] = sh->rule;
+  }
+  long long *ds = nullptr, *dr = nullptr;
+  HIP_TRY(hipMalloc(&ds, mine.size() * 8));
+  if (hipMalloc(&dr, mine.size() * 8) != hipSuccess) { hipFree(ds); return fail(KV_RESOURCE_EXHAUSTED, "kv_shard: out of memory"); }
+  int rc = KV_OK;
+  do {
+    if (hipMemcpy(ds, mine.data(), mine.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(KV_INTERNAL, "kv_shard: copy"); break; }
+    if ((rc = kv_comm_all_to_all(comm, ds, dr, comm->comm ? 32 : 32 * W, comm->stream))) break;
+    if (hipStreamSynchronize(comm->stream) != hipSuccess || hipMemcpy(theirs.data(), dr, theirs.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(KV_INTERNAL, "kv_shard: the first exchange failed");
+      break;
+    }
+    for (int p = 0; p < W && !rc; ++p) {
+      if ((theirs[4 * p] >> 32) != W || (int)(theirs[4 * p] & 0xFFFFFFFF) != (comm->comm ? p : sh->rank))
+        rc = fail(KV_FAILED_PRECONDITION, "kv_shard: rank %d of the communicator is not shard %d of a world of %d", p, p, W);
+      else if (theirs[4 * p + 1] != (long long)sh->C || theirs[4 * p + 2] != sh->table->dim || theirs[4 * p + 3] != sh->rule)
+        rc = fail(KV_FAILED_PRECONDITION, "kv_shard: rank %d was created with peer_capacity %lld, dim %lld, owner rule %lld; this "
+                                          "rank with %u, %d, %d — they must be equal on every rank",
+                  p, theirs[4 * p + 1], theirs[4 * p + 2], theirs[4 * p + 3], sh->C, sh->table->dim, sh->rule);
+    }
+  } while (0);
+  hipFree(ds); hipFree(dr);
+  if (!rc) sh->verified = comm;
+  return rc;
+}
+
 int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, float* out, int join, kv_stream_t stream) {
   if (!sh || !comm || comm->world != sh->world) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup: shard / communicator mismatch");
   DeviceGuard dg(sh->table->device);
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if ((rc = shard_verify(sh, comm))) return rc;
   hipStream_t w = comm->stream;   // phases and exchanges in one queue: no event hop between a kernel and its exchange
   if ((rc = shard_fork(sh, s, w))) return rc;
   const int64_t pb = (int64_t)(sh->C + 1) * 16, rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
-  if ((rc = kv_shard_lookup_route(sh, ids, n, w))) return rc;
+  if ((rc = lookup_route_impl(sh, ids, n, w))) return rc;
   if ((rc = kv_comm_all_to_all(comm, sh->send_pairs, sh->recv_pairs, comm->comm ? pb : pb * sh->world, w))) return rc;
   if ((rc = kv_shard_lookup_serve(sh, w))) return rc;
   if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
   if ((rc = kv_shard_lookup_finish(sh, out, w))) return rc;
-  return shard_done(sh, s, w, join);
+  if ((rc = shard_done(sh, s, w, join))) return rc;
+  return shard_late_report(sh);
 }
 
 int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1, const float* grad,

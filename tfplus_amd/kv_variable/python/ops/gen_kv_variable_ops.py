@@ -769,6 +769,23 @@ class KvShard(object):
     except Exception:  # interpreter shutdown
       pass
 
+  def buffers(self):
+    """The exchange buffers as flat uint8 tensors over the library's memory (zero copy): send_pairs, recv_pairs
+    [world x pair_bytes], send_rows, recv_rows [world x row_bytes] — for a caller that moves the segments itself."""
+    ptrs = [ctypes.c_void_p() for _ in range(4)]
+    pb, rb = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(_lib.lib().kv_shard_buffers(self.ptr, *[ctypes.byref(x) for x in ptrs], ctypes.byref(pb), ctypes.byref(rb)))
+
+    class _Raw(object):
+      def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    dev = _dev(self.table)
+    names = ("send_pairs", "recv_pairs", "send_rows", "recv_rows")
+    sizes = (pb.value, pb.value, rb.value, rb.value)
+    out = {n: torch.as_tensor(_Raw(p.value, self.world * sz), device=dev) for n, p, sz in zip(names, ptrs, sizes)}
+    out["pair_bytes_per_peer"], out["row_bytes_per_peer"] = pb.value, rb.value
+    return out
+
   # whole ops over a KvComm
   def lookup(self, comm, indices, join=True):
     ids = _ids(self.table, indices)
@@ -791,8 +808,8 @@ class KvShard(object):
   # the phases, for an exchange the caller provides
   def lookup_route(self, indices):
     ids = _ids(self.table, indices)
+    self._ids = ids    # first: a late report of an earlier batch's overflow (raised below) leaves this batch routed
     _lib.check(_lib.lib().kv_shard_lookup_route(self.ptr, _p(ids), ids.numel(), _stream(self.table)))
-    self._ids = ids
 
   def lookup_serve(self):
     _lib.check(_lib.lib().kv_shard_lookup_serve(self.ptr, _stream(self.table)))
