@@ -217,6 +217,8 @@ def test_uninitialized_is_failed_precondition(ops):
   h = ops.kv_variable([8])
   with pytest.raises(_lib.FailedPreconditionError):
     ops.kv_variable_gather_or_insert_v2(h, np.array([1]))
+  with pytest.raises(_lib.FailedPreconditionError):   # FindOrZeros checks too (kv_variable.h:242)
+    ops.kv_variable_gather_or_zeros_v2(h, np.array([1]))
   s = ops.kv_variable([24])
   with pytest.raises(_lib.FailedPreconditionError):   # training_ops.cc:7001-7008
     ops.kv_variable_group_sparse_apply_adam_v4(h, s, np.zeros((1, 8), np.float32), np.array([1]), 0.1,

@@ -1228,6 +1228,8 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
 int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
+  if (!t->initialized)   // FindOrZeros -> CheckInitializedInternal (kv_variable.h:242)
+    return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
   if (n == 0) return KV_OK;
   if (n < 0 || !ids || !out) return fail(KV_INVALID_ARGUMENT, "indices / output pointer is null");
   DeviceGuard dg(t->device);
@@ -1319,8 +1321,11 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
   int rc;
   if ((rc = check_same_shape(num_tables, tables, "tables"))) return rc;  // Attr("N: int >= 1")
   if (!ids || !ns || !outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
-  for (int i = 0; i < num_tables; ++i)
+  for (int i = 0; i < num_tables; ++i) {
     if (ns[i] < 0 || (ns[i] > 0 && (!ids[i] || !outs[i]))) return fail(KV_INVALID_ARGUMENT, "indices / output pointer is null");
+    if (!tables[i]->initialized)   // FindOrZeros -> CheckInitializedInternal (kv_variable.h:242)
+      return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
+  }
   const int device = tables[0]->device;
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
