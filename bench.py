@@ -256,6 +256,27 @@ def main():
       dist.all_to_all_single(o, send.cpu())
       recv.copy_(o)
 
+  def teardown():
+    """The library's communicator goes first (every rank past its last exchange), then torch's group."""
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))   # the communicator's stream is about to go
+    held = [x for x in ("shard", "comm") if x in live]
+    for x in held:
+      obj = live.pop(x)
+      if x == "comm":
+        _lib.check(L.kv_comm_destroy(obj.ptr)); obj.ptr = None
+      else:
+        _lib.check(L.kv_shard_destroy(obj.ptr)); obj.ptr = None
+    dist.destroy_process_group()
+
+  live = {}
+  if shard_path:
+    live["shard"] = shard
+    if native_shard:
+      live["comm"] = comm
+
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
     if not shard_path:
@@ -327,7 +348,7 @@ def main():
     if rank == 0:
       print(json.dumps({"ms_per_step": ms_per_step, "value": value, "note": "diagnostic run without kernel events"}))
     if shard_path:
-      dist.destroy_process_group()
+      teardown()
     return
 
   # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch time ----
@@ -413,9 +434,9 @@ def main():
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
   if shard_path:
-    dist.destroy_process_group()
+    teardown()
 
 
 if __name__ == "__main__":
