@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20250211 + 2
+SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "4"))   # the dominant kernel is bracketed by events on every 4th step of the timed region
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -320,6 +321,7 @@ def main():
   dom = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if args.warmup > 0 else "apply_sorted"
   ops.kv_profile_enable(var, 0 if args.no_kernel_events else args.steps + 8)
   ops.kv_profile_select(var, [dom])
+  ops.kv_profile_sample(var, SAMPLE_EVERY)     # a pair of event markers costs ~4 us of stream time per launch
   barrier()
   t0 = time.perf_counter()
   for k in range(args.steps):
@@ -333,6 +335,7 @@ def main():
     dt = float(tt.item())
   timed = ops.kv_profile_read(var)
   ops.kv_profile_select(var, None)
+  ops.kv_profile_sample(var, 1)
   prof = timed
   if not args.no_kernel_events:
     ops.kv_profile_enable(var, 8 * args.steps + 8)
@@ -407,8 +410,8 @@ def main():
                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
                    "launches_timed": int(timed[dom][1]),
-                   "measured": "hipEvent pairs on the op's stream around every launch of this kernel inside "
-                               "the timed region"},
+                   "measured": "hipEvent pairs on the op's stream around every %dth launch of this kernel inside "
+                               "the timed region" % SAMPLE_EVERY},
       "kernels_ms": kern,
       "kernels_ms_measured": "%d further steps after the timed region with every kernel bracketed" % args.steps,
       "ops": {"lookup": {"gpu_ms": lookup_ms, "algorithmic_bytes": lookup_bytes,

@@ -426,15 +426,16 @@ int kv_take_rows(int device, const void* src, const int32_t* index, const int32_
  * the bracketing to the kinds whose bit (1 << KV_PROF_*) is set (default: all) — an event pair
  * costs a few microseconds of stream time, so a throughput measurement brackets one kernel. */
 #define KV_PROF_LOOKUP_TILE 0   /* k_tile: tile dedup + partition sort */
-#define KV_PROF_LOOKUP_PART 1   /* k_part_keys_gather: find / insert / frequency + the probing gather of the rows */
-#define KV_PROF_LOOKUP_ORDER 2  /* k_order: sorted position list + fix-up of rows inserted by the batch */
+#define KV_PROF_LOOKUP_PART 1   /* k_part_keys<LOOKUP>: find / insert / frequency, key records, work items */
+#define KV_PROF_LOOKUP_ORDER 2  /* k_gather<ORDER>: output rows + the sorted position list */
 #define KV_PROF_INDEX 3         /* the three index kernels of an apply that was not handed a valid token */
-#define KV_PROF_APPLY_SORTED 4  /* k_apply_sorted: segmented gradient sum + fused row update */
-#define KV_PROF_APPLY_SPAN 5    /* k_apply_span: keys that cross chunk boundaries */
+#define KV_PROF_APPLY_SORTED 4  /* k_apply: segmented gradient sum + fused row update */
+#define KV_PROF_APPLY_SPAN 5    /* k_apply_fin: keys that span several chunks */
 #define KV_PROF_KINDS 6
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
 int kv_profile_select(kv_handle_t h, unsigned kind_mask);
+int kv_profile_sample(kv_handle_t h, int every);
 
 #ifdef __cplusplus
 }

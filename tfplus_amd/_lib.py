@@ -100,6 +100,7 @@ SIGNATURES = {
     "kv_gather_or_insert_pairs": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "kv_profile_enable": (_i32, [_vp, _i32]),
     "kv_profile_select": (_i32, [_vp, _c.c_uint32]),
+    "kv_profile_sample": (_i32, [_vp, _i32]),
     "kv_profile_read": (_i32, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i32]),
 }
 

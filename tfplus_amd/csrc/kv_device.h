@@ -110,6 +110,7 @@ struct WsDev {
   unsigned ntiles, P;
   int pshift;              // 64 - log2(P)
   unsigned seg_cap;        // (id, count) input in fixed-capacity exchange segments of this many records (0: plain list)
+  int* zero_counts;        // k_tile clears this [n] array on its way (the sharded route's sparse unique counts); else null
   const int* row_map;      // k_gather: rows are read at row_map[ent_b] (sharded lookup: the exchange buffer's records); else null
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
 };

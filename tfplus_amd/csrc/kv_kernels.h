@@ -118,6 +118,13 @@ __device__ __forceinline__ void tile_body(const WsDev& w, const IdT* __restrict_
   for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
   if (tid == 0) { lnwork = 0; lsent = 0; }
   if (tile == 0 && tid < 8) w.ctr[tid] = 0;   // the partition pass counts into them
+  if (w.zero_counts) {   // sparse unique numbers (sharded route): a count of 0 = "names no key"
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TBT + tid;
+      if (i < n) w.zero_counts[i] = 0;
+    }
+  }
   __syncthreads();
 
   // ---- phase 1: LDS hash insert of this tile's ids --------------------------------------
@@ -317,6 +324,7 @@ struct PartArgs {
   int use_hints;              // apply: ts0 is tv's attached slot table (Entry::hint names ts0's rows)
   int fold_op;                // MODE_DEDUP fold: KV_SCATTER_ADD (sum) / MUL (product) / MIN / MAX / ASSIGN (last)
   int det;                    // deterministic reduction mode
+  int sparse_unique;          // MODE_UNIQUE: unique numbers = sorted position of the partition + local number (with gaps)
   long long n;                // ids in the batch
 };
 
@@ -601,9 +609,12 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     if constexpr (MODE == MODE_UNIQUE) {
       // tf.unique_with_counts: dense index = block base (ONE global atomic per block) + local rank;
       // direct_rows: the keys are the output rows themselves (tf.unsorted_segment_sum)
+      // ... or, sparse_unique (the sharded route: nobody needs the list to be dense), the partition's first
+      // sorted position + the keys of its earlier classes: no atomic at all (1024 returning atomics on one
+      // address cost this kernel 9 of its 29 us); the gaps keep the count 0 the caller cleared the array to
       __shared__ unsigned lbase;
       if (a.direct_rows == 0) {
-        if (tid == 0) lbase = atomicAdd(&w.ctr[0], nu);
+        if (tid == 0) lbase = a.sparse_unique ? pbase + lcold + lhot - nu : atomicAdd(&w.ctr[0], nu);
         __syncthreads();
       }
 #pragma unroll
@@ -875,6 +886,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
     const unsigned nb = (nc + gb - 1u) / gb;
     for (unsigned b = tid; b < nb; b += TBK) w.litem[pbase + nk + b] = make_uint4(pbase + b * gb, min(gb, nc - b * gb), 0u, 0u);
     if (tid == 0) w.pmeta[p] = make_uint4(nk + nb, nk, pbase, nc);
+
   }
 }
 
@@ -1751,11 +1763,10 @@ __global__ void __launch_bounds__(TB) k_owner_scatter(const IdT* __restrict__ id
 // = where unique id u went (its row comes back at the same place).  More than C ids for one owner: the extra
 // ones are dropped and *overflow is raised (the host doubles C; hashed ownership keeps this from happening).
 __global__ void __launch_bounds__(TB) k_owner_scatter_fixed(const long long* __restrict__ ids, const int* __restrict__ cnts,
-                                                            const unsigned* __restrict__ n_dev32, int world, int rule,
+                                                            long long n, int world, int rule,
                                                             unsigned ntiles, const unsigned* __restrict__ base_off,
                                                             unsigned C, long long* __restrict__ seg, int* __restrict__ slot_of,
                                                             unsigned* __restrict__ overflow) {
-  const long long n = (long long)*n_dev32;
   __shared__ unsigned h[MAXW];
   if ((int)threadIdx.x < world)   // rank inside the owner's bucket = global offset - the bucket's start
     h[threadIdx.x] = base_off[(size_t)threadIdx.x * ntiles + blockIdx.x] - base_off[(size_t)threadIdx.x * ntiles];
@@ -1764,14 +1775,14 @@ __global__ void __launch_bounds__(TB) k_owner_scatter_fixed(const long long* __r
 #pragma unroll
   for (int k = 0; k < RT / TB; ++k) {
     const long long i = base + k * TB + threadIdx.x;
-    if (i < n) {
+    if (i < n && cnts[i] > 0) {   // the list has gaps (sparse unique numbers): a count of 0 names no key
       const long long id = ids[i];
       const unsigned d = owner_rank(id, world, rule);
       const unsigned r = atomicAdd(&h[d], 1u);
       if (r < C) {
         const size_t slot = (size_t)d * (C + 1) + 1 + r;
         seg[2 * slot] = id;
-        seg[2 * slot + 1] = cnts ? (long long)cnts[i] : 1ll;
+        seg[2 * slot + 1] = (long long)cnts[i];
         slot_of[i] = (int)slot;
       } else {
         slot_of[i] = 0;        // record 0 is a header: its "row" is never a real one
@@ -1785,10 +1796,9 @@ __global__ void __launch_bounds__(TB) k_owner_scatter_fixed(const long long* __r
 // inside a segment then depends on block timing — it decides nothing but the owner's row numbering — so the
 // deterministic mode keeps the four-kernel version above.  gcount: [world] segment fill, zero between batches.
 __global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __restrict__ ids, const int* __restrict__ cnts,
-                                                          const unsigned* __restrict__ n_dev32, int world, int rule, unsigned C,
+                                                          long long n, int world, int rule, unsigned C,
                                                           long long* __restrict__ seg, int* __restrict__ slot_of,
                                                           unsigned* __restrict__ overflow, unsigned* __restrict__ gcount) {
-  const long long n = (long long)*n_dev32;
   __shared__ unsigned h[MAXW], base[MAXW];
   if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
   __syncthreads();
@@ -1799,7 +1809,8 @@ __global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __res
 #pragma unroll
     for (int k = 0; k < RT / TB; ++k) {
       const long long i = b0 + k * TB + threadIdx.x;
-      if (i < n) {
+      d[k] = 0xFFFFFFFFu;
+      if (i < n && cnts[i] > 0) {   // gaps of the sparse unique numbering carry a count of 0
         id[k] = ids[i];
         d[k] = owner_rank(id[k], world, rule);
         r[k] = atomicAdd(&h[d[k]], 1u);
@@ -1811,12 +1822,12 @@ __global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __res
 #pragma unroll
     for (int k = 0; k < RT / TB; ++k) {
       const long long i = b0 + k * TB + threadIdx.x;
-      if (i < n) {
+      if (d[k] != 0xFFFFFFFFu) {
         const unsigned rr = base[d[k]] + r[k];
         if (rr < C) {
           const size_t slot = (size_t)d[k] * (C + 1) + 1 + rr;
           seg[2 * slot] = id[k];
-          seg[2 * slot + 1] = cnts ? (long long)cnts[i] : 1ll;
+          seg[2 * slot + 1] = (long long)cnts[i];
           slot_of[i] = (int)slot;
         } else {
           slot_of[i] = 0;
@@ -1846,10 +1857,9 @@ __global__ void k_seg_headers(const long long* __restrict__ counts, int world, u
     seg[2 * (size_t)d * (C + 1) + 1] = 0;
   }
 }
-// k_owner_hist / k_owner_scan with the length on the device as a 32-bit word (the unique count of kv_unique)
-__global__ void __launch_bounds__(TB) k_owner_hist_u32(const long long* __restrict__ ids, const unsigned* __restrict__ n_dev32,
+// k_owner_hist over the sparse unique list of the sharded route (entries with a count of 0 name no key)
+__global__ void __launch_bounds__(TB) k_owner_hist_u32(const long long* __restrict__ ids, const int* __restrict__ cnts, long long n,
                                                        int world, int rule, unsigned ntiles, unsigned* __restrict__ hist) {
-  const long long n = (long long)*n_dev32;
   __shared__ unsigned h[MAXW];
   if (threadIdx.x < MAXW) h[threadIdx.x] = 0;
   __syncthreads();
@@ -1857,7 +1867,7 @@ __global__ void __launch_bounds__(TB) k_owner_hist_u32(const long long* __restri
 #pragma unroll
   for (int k = 0; k < RT / TB; ++k) {
     const long long i = base + k * TB + threadIdx.x;
-    if (i < n) atomicAdd(&h[owner_rank(ids[i], world, rule)], 1u);
+    if (i < n && cnts[i] > 0) atomicAdd(&h[owner_rank(ids[i], world, rule)], 1u);
   }
   __syncthreads();
   if ((int)threadIdx.x < world) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];

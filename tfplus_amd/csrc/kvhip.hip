@@ -394,6 +394,8 @@ struct kv_table {
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_kind;
   size_t ev_used = 0;
+  int prof_every = 1;                // bracket every prof_every-th launch of a kind (kv_profile_sample)
+  unsigned prof_seq[KV_PROF_KINDS] = {};
 };
 
 namespace {
@@ -617,6 +619,7 @@ WsDev ws_view(kv_table* t, long long n) {
   d.pshift = 64 - ilog2(d.P);
   d.seg_cap = 0;
   d.row_map = nullptr;
+  d.zero_counts = nullptr;
   d.dbg = w.dbg;
   return d;
 }
@@ -627,7 +630,8 @@ struct ProfScope {
   hipStream_t s;
   bool on;
   ProfScope(kv_table* t_, int kind, hipStream_t s_) : t(t_), s(s_), on(false) {
-    if (t->prof && ((t->prof_mask >> kind) & 1u) && t->ev_used + 2 <= t->ev.size()) {
+    if (t->prof && ((t->prof_mask >> kind) & 1u) && t->ev_used + 2 <= t->ev.size() &&
+        (t->prof_every <= 1 || (t->prof_seq[kind]++ % (unsigned)t->prof_every) == 0u)) {
       on = true;
       t->ev_kind[t->ev_used / 2] = kind;
       hipEventRecord(t->ev[t->ev_used], s);
@@ -2071,6 +2075,16 @@ int kv_profile_select(kv_handle_t t, unsigned kind_mask) {
   return KV_OK;
 }
 
+int kv_profile_sample(kv_handle_t t, int every) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (every < 1) return fail(KV_INVALID_ARGUMENT, "kv_profile_sample: every %d", every);
+  std::lock_guard<std::mutex> l(t->mu);
+  t->prof_every = every;
+  for (unsigned& q : t->prof_seq) q = 0;
+  return KV_OK;
+}
+
 int kv_profile_read(kv_handle_t t, double* ms_sum, int64_t* launches, int n_kinds) {
   int rc;
   if ((rc = check_table(t))) return rc;
@@ -2662,10 +2676,13 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = sh->uniq;
   pa.out_counts = sh->ucnt;
+  pa.sparse_unique = 1;   // unique numbers with gaps: no counter to serialise on
   pa.det = sh->table->deterministic ? 1 : 0;
   pa.n = n;
   // tile + partition passes only: kv_shard_lookup_finish's gather files the positions (order, work items) on its way
-  launch_tile<false>(rt, wd, ids, nullptr, n, s, 0);
+  WsDev wz = wd;
+  wz.zero_counts = sh->ucnt;   // sparse unique numbers: the tile pass clears the counts, the partition pass sets the real ones
+  launch_tile<false>(rt, wz, ids, nullptr, n, s, 0);
   launch_part_keys<MODE_UNIQUE>(wd, pa, s);
   rt->batch_serial = ++g_serial;
   rt->batch_n = n;
@@ -2673,16 +2690,16 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   sh->ordered = false;
   const unsigned ntr = (unsigned)((n + RT - 1) / RT);
   if (!pa.det) {
-    k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, wd.ctr, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
+    k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
                                            sh->overflow, sh->gcount);
     k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs);
     HIP_TRY(hipGetLastError());
     return KV_OK;
   }
-  k_owner_hist_u32<<<ntr, TB, 0, s>>>(sh->uniq, wd.ctr, sh->world, sh->rule, ntr, sh->hist);
+  k_owner_hist_u32<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, ntr, sh->hist);
   k_owner_scan<<<1, 1024, 0, s>>>(sh->hist, ntr * sh->world, ntr, sh->world, sh->counts);
   k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
-  k_owner_scatter_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, wd.ctr, sh->world, sh->rule, ntr, sh->hist, sh->C, sh->send_pairs,
+  k_owner_scatter_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, ntr, sh->hist, sh->C, sh->send_pairs,
                                            sh->slot_of, sh->overflow);
   HIP_TRY(hipGetLastError());
   return KV_OK;

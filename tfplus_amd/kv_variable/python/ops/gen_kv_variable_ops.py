@@ -454,6 +454,11 @@ def kv_profile_select(table_handle, kinds=None):
   _lib.check(_lib.lib().kv_profile_select(table_handle.ptr, mask))
 
 
+def kv_profile_sample(table_handle, every=1):
+  """Bracket only every `every`-th launch of the selected kinds."""
+  _lib.check(_lib.lib().kv_profile_sample(table_handle.ptr, int(every)))
+
+
 def kv_profile_read(table_handle):
   """{kernel kind: (total ms, launches)} from the HIP events recorded since the last read."""
   n = len(PROF_KINDS)
