@@ -1048,6 +1048,39 @@ __device__ __forceinline__ RowsOf resolve_rows(const PartArgs& a, long long key,
   return o;
 }
 
+// Everything the update of one key needs besides its gradient, requested in ONE round trip: the var row, the
+// hinted slot row and that row's own record (the hint is validated against it in resolve_rows).  Without this the
+// finish walks slot index -> slot record -> rows, three dependent hops.  Called by the LPR lanes of the key's group.
+template <int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void prefetch_state(const PartArgs& a, const uint4& ra, bool live, int lane, int D, RowMeta& m0,
+                                               bool& hint_loaded, PreRows<V, K>& pre, bool& have_x, bool& have_s) {
+  hint_loaded = false; have_x = false; have_s = false;
+  if (!live || (ra.z & ROW_MASK) == 0u) return;
+  const bool hok = a.use_hints && ra.w != 0u && ra.w < a.ts0.max_rows;
+  if (lane == 0 && hok) {
+    const uint4 mm = *reinterpret_cast<const uint4*>(meta_ptr(a.ts0, ra.w));
+    m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
+    m0.freq = mm.z;
+    m0.flags = (unsigned char)(mm.w & 0xFFu);
+    hint_loaded = true;
+  }
+  const float* xr = row_ptr(a.tv, ra.z & ROW_MASK);
+  const float* sr = hok ? row_ptr(a.ts0, ra.w) : nullptr;
+  constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e0 = (lane + k * LPR) * V;
+    if (e0 < D) {
+      ldv<V>(xr + e0, pre.x[k]);
+      if (hok) {
+#pragma unroll
+        for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + e0 + b3 * D, pre.s[b3][k]);
+      }
+    }
+  }
+  have_x = true; have_s = hok;
+}
+
 // finish one key whose combined gradient is in gv: optimizer update (MODE_APPLY) or emit (MODE_DEDUP).
 // All LPR lanes of every group of the wave call it (shuffles inside); `live` masks groups without a key.
 // hd = {key lo, key hi, row word, slot-row hint}
@@ -1124,6 +1157,10 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int cc = 0; cc < V; ++cc) gv[k][cc] = ident;
+    // the state of the key that gets finished here (prefetch_state): one set of registers for both kinds of item
+    RowMeta m0{};
+    bool hint_loaded = false, have_x = false, have_s = false;
+    PreRows<V, K> pre;
     if (is_hot) {
       // ---- hot chunk: rows [lo, hi) of one key, G * RB of them per step ------------------------------------
       const unsigned hx = item.x & ~HEAD_BIT;
@@ -1159,6 +1196,10 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) { acc_row(gv, va[j]); pa_[j] = pb_[j]; }
       }
+      // a key with a single chunk is finished here: its state rows are requested now (the row buffers are free),
+      // one round trip under the shuffle tree instead of three hops behind it
+      const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
+      if (MODE == MODE_APPLY && nch == 1u) prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hint_loaded, pre, have_x, have_s);
       // the groups' sums meet: a fixed shuffle tree, every lane ends with the chunk's sum
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) {
@@ -1170,7 +1211,6 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
             gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
           }
       }
-      const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
       if (nch > 1u) {
         if (g == 0) {
           float* dst = w.hpart + (size_t)item.z * D;
@@ -1181,8 +1221,7 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
           }
         }
       } else {
-        RowMeta m0{};
-        finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+        finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, hint_loaded, m0, gv, lane, &pre, have_x, have_s);
       }
     } else {
       // ---- cold batch: one key per lane group ------------------------------------------------------------
@@ -1194,35 +1233,8 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
       uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = ra;
       if (live) { ra = w.coldlist[2 * (size_t)u]; rb = w.coldlist[2 * (size_t)u + 1]; }
       const unsigned start = rb.x, cnt = live ? rb.y : 0u;
-      RowMeta m0{};
-      bool hint_loaded = false, have_x = false, have_s = false;
-      PreRows<V, K> pre;
       if (cnt > 0u) load_row(rb.z, gv);     // ident op with one operand: the first row IS the partial result
-      if (MODE == MODE_APPLY && live && (ra.z & ROW_MASK) != 0u) {
-        const bool hok = a.use_hints && ra.w != 0u && ra.w < a.ts0.max_rows;
-        if (lane == 0 && hok) {
-          const uint4 mm = *reinterpret_cast<const uint4*>(meta_ptr(a.ts0, ra.w));
-          m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
-          m0.freq = mm.z;
-          m0.flags = (unsigned char)(mm.w & 0xFFu);
-          hint_loaded = true;
-        }
-        const float* xr = row_ptr(a.tv, ra.z & ROW_MASK);
-        const float* sr = hok ? row_ptr(a.ts0, ra.w) : nullptr;
-        constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e0 = (lane + k * LPR) * V;
-          if (e0 < D) {
-            ldv<V>(xr + e0, pre.x[k]);
-            if (hok) {
-#pragma unroll
-              for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + e0 + b3 * D, pre.s[b3][k]);
-            }
-          }
-        }
-        have_x = true; have_s = hok;
-      }
+      if (MODE == MODE_APPLY) prefetch_state<OPT, V, LPR, K>(a, ra, live, lane, D, m0, hint_loaded, pre, have_x, have_s);
       for (unsigned j0 = 1; j0 < cnt; j0 += RC) {
         float val[RC][K][V];
         unsigned pos[RC];
@@ -1341,10 +1353,13 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
   for (unsigned q = wv; q < nk; q += NW) {
     if (lkeys[q][2] > 64u) continue;
     float gv[K][V];
-    wave_sum(lkeys[q][1], 0u, lkeys[q][2], gv);
     const uint4 ra = w.hotlist[2 * (size_t)lkeys[q][0]];
     RowMeta m0{};
-    finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+    bool hl = false, hx = false, hs = false;
+    PreRows<V, K> pre;
+    if (MODE == MODE_APPLY) prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hl, pre, hx, hs);   // with the partials
+    wave_sum(lkeys[q][1], 0u, lkeys[q][2], gv);
+    finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, hl, m0, gv, lane, &pre, hx, hs);
   }
   // keys with more: the block's waves take consecutive runs of the chunks and meet in LDS in wave order
   for (unsigned q = 0; q < nk; ++q) {   // block-uniform
@@ -1353,6 +1368,15 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
     const unsigned per = (nch + NW - 1) / NW;
     const unsigned c0 = min(nch, wv * per), c1 = min(nch, c0 + per);
     float gv[K][V];
+    // wave 0 finishes the key: it asks for the state rows with its share of the partials
+    uint4 ra = make_uint4(0u, 0u, 0u, 0u);
+    RowMeta m0{};
+    bool hl = false, hx = false, hs = false;
+    PreRows<V, K> pre;
+    if (wv == 0) {
+      ra = w.hotlist[2 * (size_t)lkeys[q][0]];
+      if (MODE == MODE_APPLY) prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hl, pre, hx, hs);
+    }
     wave_sum(lkeys[q][1], c0, c1, gv);
     __syncthreads();   // lsum of the previous key has been read
     if (g == 0) {
@@ -1378,9 +1402,7 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
           }
         }
       }
-      const uint4 ra = w.hotlist[2 * (size_t)lkeys[q][0]];
-      RowMeta m0{};
-      finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, false, m0, gv, lane);
+      finish_key<MODE, OPT, V, LPR, K>(a, ra, g == 0, hl, m0, gv, lane, &pre, hx, hs);
     }
   }
 }
