@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
   if (errflag) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* lsum = reinterpret_cast<float*>(smem_raw);   // [TBF / 64][dim]
-  __shared__ unsigned lkeys[TBF][3];                  // multi-chunk keys among this block's items: {hot index, first chunk, chunks}
+  __shared__ unsigned lkeys[TBF][7];                  // multi-chunk keys among this block's items: {hot index, first chunk, chunks, record a}
   __shared__ unsigned lnk;
   const int D = a.tv.dim;
   constexpr int G = 64 / LPR;
@@ -1300,11 +1300,15 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
   for (unsigned i = b0 + threadIdx.x; i < b1; i += TBF) {
     const uint4 item = w.items[i];
     if ((item.x & HEAD_BIT) && item.y == 0u) {
+      const uint4 ra = w.hotlist[2 * (size_t)(item.x & ~HEAD_BIT)];       // both halves of the record in one hop
       const uint4 rb = w.hotlist[2 * (size_t)(item.x & ~HEAD_BIT) + 1];
       const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
       if (nch > 1u) {
         const unsigned q = atomicAdd(&lnk, 1u);
-        if (q < (unsigned)TBF) { lkeys[q][0] = item.x & ~HEAD_BIT; lkeys[q][1] = item.z; lkeys[q][2] = nch; }
+        if (q < (unsigned)TBF) {
+          lkeys[q][0] = item.x & ~HEAD_BIT; lkeys[q][1] = item.z; lkeys[q][2] = nch;
+          lkeys[q][3] = ra.x; lkeys[q][4] = ra.y; lkeys[q][5] = ra.z; lkeys[q][6] = ra.w;
+        }
       }
     }
   }
@@ -1353,7 +1357,7 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
   for (unsigned q = wv; q < nk; q += NW) {
     if (lkeys[q][2] > 64u) continue;
     float gv[K][V];
-    const uint4 ra = w.hotlist[2 * (size_t)lkeys[q][0]];
+    const uint4 ra = make_uint4(lkeys[q][3], lkeys[q][4], lkeys[q][5], lkeys[q][6]);
     RowMeta m0{};
     bool hl = false, hx = false, hs = false;
     PreRows<V, K> pre;
@@ -1374,7 +1378,7 @@ __device__ __forceinline__ void apply_fin_body(const WsDev& w, const PartArgs& a
     bool hl = false, hx = false, hs = false;
     PreRows<V, K> pre;
     if (wv == 0) {
-      ra = w.hotlist[2 * (size_t)lkeys[q][0]];
+      ra = make_uint4(lkeys[q][3], lkeys[q][4], lkeys[q][5], lkeys[q][6]);
       if (MODE == MODE_APPLY) prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hl, pre, hx, hs);
     }
     wave_sum(lkeys[q][1], c0, c1, gv);
