@@ -76,3 +76,20 @@ def test_shim_schemas_equal_the_reference():
   for name, items in ours.items():
     assert name in ref, "the reference registers no op named %s" % name
     assert items == ref[name], "%s:\n  shim      %s\n  reference %s" % (name, items, ref[name])
+
+
+def test_shim_type_checks_against_a_mock_of_the_tf_api():
+  """TensorFlow's headers are not in this image, so the shim cannot be built here.  tests/tf_mock/ declares the slice
+  of TF 2.13's op API the shim uses (OpKernel, OpKernelContext, Tensor, ResourceMgr, shape inference, the
+  registration macros); `g++ -fsyntax-only` against it catches everything but a mismatch between the mock and the
+  real headers (INTEGRATION.md §2 has the real build line)."""
+  import shutil
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include/hip"):
+    pytest.skip("needs g++ and the HIP headers")
+  r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"), "-I",
+                      os.path.join(root, "tests", "tf_mock"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                      os.path.join(root, "tfplus_amd", "tf_shim", "kv_variable_ops_hip.cc")],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-3000:]

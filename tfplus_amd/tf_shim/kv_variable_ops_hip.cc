@@ -409,10 +409,10 @@ class KvSizeHipOp : public OpKernel {
     out->scalar<T>()() = static_cast<T>(v);
   }
 };
-REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int32>("T"), (KvSizeHipOp<int32, false>));
-REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), (KvSizeHipOp<int64_t, false>));
-REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int32>("T"), (KvSizeHipOp<int32, true>));
-REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), (KvSizeHipOp<int64_t, true>));
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int32>("T"), KvSizeHipOp<int32, false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), KvSizeHipOp<int64_t, false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int32>("T"), KvSizeHipOp<int32, true>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_CPU).TypeConstraint<int64_t>("T"), KvSizeHipOp<int64_t, true>);
 
 // ---- ReadKvVariableOpV2 : ops :249-266, kernels/kv_variable_ops.cc:325-346 -> ExportValues(first_n = 2) ---
 REGISTER_OP("ReadKvVariableOpV2")
