@@ -254,6 +254,8 @@ def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
     ops.kv_set_deterministic(h, True)
   for h in (vars_[0], slots[0]):
     ops.kv_set_deterministic(h, True)
+  if with_rccl:   # the self segment through grouped ncclSend / ncclRecv as a peer's would go (read once, at the first exchange)
+    os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
   comm = ops.KvComm(1, 0, ops.kv_comm_unique_id() if with_rccl else None)
   for step in range(3):
     ids = torch.from_numpy(rng.integers(0, 5000, 20000)).cuda()

@@ -2565,15 +2565,19 @@ int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
   }
   // this rank's own segment never meets RCCL: a device copy at HBM speed, queued in front of the group
-  HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer, (const char*)send + (size_t)c->rank * bytes_per_peer,
-                         (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
-  if (c->world > 1) NCCL_TRY(rccl()->GroupStart());
+  // (KV_COMM_SELF_VIA_RCCL=1, a test switch: the self segment goes through ncclSend / ncclRecv like a peer's, which
+  // lets a single GPU exercise the grouped send / recv code)
+  static const bool self_rccl = [] { const char* e = getenv("KV_COMM_SELF_VIA_RCCL"); return e && e[0] == '1'; }();
+  if (!self_rccl)
+    HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer, (const char*)send + (size_t)c->rank * bytes_per_peer,
+                           (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+  if (c->world > 1 || self_rccl) NCCL_TRY(rccl()->GroupStart());
   for (int p = 0; p < c->world; ++p) {
-    if (p == c->rank) continue;
+    if (p == c->rank && !self_rccl) continue;
     NCCL_TRY(rccl()->Send((const char*)send + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
     NCCL_TRY(rccl()->Recv((char*)recv + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
   }
-  if (c->world > 1) NCCL_TRY(rccl()->GroupEnd());
+  if (c->world > 1 || self_rccl) NCCL_TRY(rccl()->GroupEnd());
   if (hop) {
     HIP_TRY(hipEventRecord(c->ev_out, c->stream));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_out, 0));
