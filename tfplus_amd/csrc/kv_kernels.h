@@ -947,11 +947,11 @@ __device__ __forceinline__ void items_body(const WsDev& w) {
 
 __device__ __forceinline__ void order_body(const TableDev& t, const WsDev& w, long long n) {
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: the lists are not valid
-  if (blockIdx.x < ITEM_BLOCKS) items_body(w);
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    order_pos(w, n, i, __builtin_nontemporal_load(&w.slot_rank[i]));
   if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
+  if (blockIdx.x < ITEM_BLOCKS) { items_body(w); return; }   // ITEM_BLOCKS extra blocks in front: the directory only
+  const long long stride = (long long)(gridDim.x - ITEM_BLOCKS) * blockDim.x;
+  for (long long i = (long long)(blockIdx.x - ITEM_BLOCKS) * blockDim.x + threadIdx.x; i < n; i += stride)
+    order_pos(w, n, i, __builtin_nontemporal_load(&w.slot_rank[i]));
 }
 __global__ void __launch_bounds__(TB) k_order(TableDev t, WsDev w, long long n) { order_body(t, w, n); }
 
@@ -1427,10 +1427,15 @@ __device__ __forceinline__ unsigned gather_row(const WsDev& w, unsigned sr) {
 template <int VQ, bool ORDER = false>
 __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, float* __restrict__ out,
                                             long long n) {
+  // ORDER: the launch carries ITEM_BLOCKS extra blocks in front that only build the item directory — a serial
+  // little job that would otherwise sit in front of the first blocks' share of the rows (small batches: the whole
+  // kernel is one generation of blocks, and it ended when those blocks did)
+  unsigned bid = blockIdx.x, nbk = gridDim.x;
   if (ORDER) {
     if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // a partition overflowed: nothing is valid
     if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
-    if (blockIdx.x < ITEM_BLOCKS) items_body(w);
+    if (blockIdx.x < ITEM_BLOCKS) { items_body(w); return; }
+    bid -= ITEM_BLOCKS; nbk -= ITEM_BLOCKS;
   }
   if constexpr (VQ > 0 && VQ <= 64) {
     // One wave takes 64 consecutive output rows per step.  Lane l resolves row l's table row id
@@ -1441,8 +1446,8 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
     constexpr int CW = VQ < 16 ? VQ : 16;  // copy instructions in flight
     const int lane = threadIdx.x & 63;
     const int v = lane % VQ, sub = lane / VQ;
-    const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * (TB / 64);
+    const long long wave = (long long)bid * (TB / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)nbk * (TB / 64);
     // software pipeline over the wave's steps: while step i copies rows, step i+1's row ids and
     // step i+2's slots are already in flight (the three dependent hops overlap across steps)
     const long long stride = nwaves * 64;
@@ -1485,7 +1490,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
   } else if constexpr (VQ > 64) {
     constexpr int RPB = TB / VQ;  // rows per block per step (VQ = 128, 256)
     const int v = threadIdx.x % VQ;
-    for (long long i = (long long)blockIdx.x * RPB + threadIdx.x / VQ; i < n; i += (long long)gridDim.x * RPB) {
+    for (long long i = (long long)bid * RPB + threadIdx.x / VQ; i < n; i += (long long)nbk * RPB) {
       const unsigned sr = w.slot_rank[i];
       const unsigned r = gather_row(w, sr);
       if (ORDER && v == 0) order_pos(w, n, i, sr);
@@ -1494,7 +1499,7 @@ __device__ __forceinline__ void gather_body(const TableDev& t, const WsDev& w, f
   } else {
     const int D = t.dim;
     const long long total = n * D;
-    for (long long x = (long long)blockIdx.x * TB + threadIdx.x; x < total; x += (long long)gridDim.x * TB) {
+    for (long long x = (long long)bid * TB + threadIdx.x; x < total; x += (long long)nbk * TB) {
       const long long i = x / D;
       const int e = (int)(x - i * D);
       const unsigned sr = w.slot_rank[i];

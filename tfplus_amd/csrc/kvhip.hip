@@ -686,7 +686,7 @@ void launch_gather(const TableDev& td, const WsDev& wd, float* op, long long m, 
 #define KV_GATHER(VQ)                                                                        \
   do {                                                                                       \
     if (md) k_gather_multi<VQ><<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);       \
-    else if (order) k_gather<VQ, true><<<grid, TB, 0, s>>>(td, wd, op, m);                    \
+    else if (order) k_gather<VQ, true><<<grid + ITEM_BLOCKS, TB, 0, s>>>(td, wd, op, m);      \
     else k_gather<VQ, false><<<grid, TB, 0, s>>>(td, wd, op, m);                              \
   } while (0)
   switch (vec ? q : 0) {
@@ -721,7 +721,7 @@ void launch_part_keys(const WsDev& wd, const PartArgs& pa, hipStream_t s, const 
 // sorted position list of the batch (the training lookup builds it in its gather kernel instead)
 void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t s,
                   const MultiDesc* md = nullptr, int ntab = 0) {
-  const int grid = nblocks(n, TB, 4096);
+  const int grid = nblocks(n, TB, 4096) + ITEM_BLOCKS;   // ITEM_BLOCKS blocks in front build the item directory only
   if (md) k_order_multi<<<dim3((unsigned)grid, (unsigned)ntab), TB, 0, s>>>(md);
   else k_order<<<grid, TB, 0, s>>>(td, wd, n);
 }
