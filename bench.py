@@ -434,6 +434,14 @@ def main():
                             "note": "sharded path: kernel byte model is reported on the single-GPU line "
                                     "(launch sizes here depend on the exchanged unique ids)"})
     res.pop("ops", None)
+    # xGMI traffic is reported apart from HBM: three fixed-size exchanges per step, every rank sends
+    # every peer one segment of peer_capacity + 1 records — (id, count) pairs, rows back, summed gradient rows
+    seg = cap + 1
+    res["exchange"] = {"exchanges_per_step": 3, "peer_capacity_records": cap,
+                       "wire_bytes_per_rank_per_step": (world - 1) * seg * (16 + 2 * 4 * D),
+                       "payload_bytes_per_rank_per_step_estimate": int((world - 1) / world * Ub * (16 + 2 * 4 * D)),
+                       "transport": "grouped ncclSend / ncclRecv (RCCL) on the communicator's stream; a rank's own "
+                                    "segment is a device copy" if native_shard else "debug: host-staged through gloo"}
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
