@@ -273,3 +273,77 @@ def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
     assert torch.equal(k1[o1], k2[o2])
     torch.testing.assert_close(v1[o1], v2[o2], rtol=2e-5, atol=2e-6)     # local pre-sum, then the owner's sum: fp32 order
   del comm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["adam_v3", "adagrad", "ftrl"])
+def test_native_shard_every_optimizer_matches_the_unsharded_oracle(opt):
+  """kv_shard_apply_serve's other optimizers (GroupAdam V3, Adagrad, SparseGroupFtrl with its two slot tables)
+  through route -> exchange -> serve on 3 shards, against ONE unsharded oracle table."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops, sharded
+  world, D = 3, 16
+  rng = np.random.default_rng(23)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  slot_dims = {"adam_v3": [3 * D], "adagrad": [D], "ftrl": [D, D]}[opt]
+  slot_init = {"adam_v3": [0.0], "adagrad": [0.1], "ftrl": [0.1, 0.0]}[opt]
+  vars_, slots, shards = [], [], []
+  for r in range(world):
+    var = ops.kv_variable([D])
+    ops.kv_set_clock_days(var, DAY); ops.kv_set_seed(var, 3); ops.init_kv_variable_v2(var, table)
+    ss = []
+    for d, v in zip(slot_dims, slot_init):
+      s = ops.kv_variable([d])
+      ops.kv_set_clock_days(s, DAY); ops.kv_set_seed(s, 3); ops.init_kv_variable_v2(s, np.full((4, d), v, np.float32))
+      ss.append(s)
+    vars_.append(var); slots.append(ss)
+    shards.append(ops.KvShard(var, world, r, ops.KV_OWNER_HASH, max_ids=1 << 14))
+  ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)
+  rslots = [ko.OracleKv(d, 0, np.full((4, d), v, np.float32), day=DAY) for d, v in zip(slot_dims, slot_init)]
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  for step in range(3):
+    batches = [rng.integers(-300, 300, 2000 + 311 * r) for r in range(world)]
+    sign = rng.choice([-1.0, 1.0], (1, D))
+    grads = [(rng.uniform(0.5, 1.5, (b.size, D)) * 1e-2 * sign).astype(np.float32) for b in batches]
+    for r in range(world):
+      shards[r].lookup_route(torch.from_numpy(batches[r]).cuda())
+    ops.kv_shard_exchange_local(shards, 0)
+    for r in range(world):
+      shards[r].lookup_serve()
+    ops.kv_shard_exchange_local(shards, 1)
+    for r in range(world):
+      shards[r].lookup_finish()
+    ref.gather_or_insert(np.concatenate(batches))
+    for r in range(world):
+      shards[r].apply_route(torch.from_numpy(grads[r]).cuda())
+    ops.kv_shard_exchange_local(shards, 1)
+    u, s, _ = ko.dedup_segment_sum(np.concatenate(batches), np.concatenate(grads))
+    if opt == "adam_v3":
+      hp, code = (0.1, b1p, b2p, 0.9, 0.999, 1e-8, 1e-4, 1e-3, 1e-3), ops.OPT_GROUP_ADAM_V3
+      ko.apply_group_adam(ref, rslots[0], s, u, 0.1, float(b1p), float(b2p), 0.9, 0.999, 1e-8, 1e-4, 1e-3, 1e-3, version=3)
+      b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+    elif opt == "adagrad":
+      hp, code = (0.05, 1.0), ops.OPT_ADAGRAD
+      ko.apply_adagrad(ref, rslots[0], 0.05, s, u, True)
+    else:
+      hp, code = (0.1, 1e-3, 1e-3, 1e-3, 0.0, -0.5), ops.OPT_SPARSE_GROUP_FTRL
+      ko.apply_sparse_group_ftrl(ref, rslots[0], rslots[1], s, u, 0.1, 1e-3, 1e-3, 1e-3, 0.0, -0.5)
+    for r in range(world):
+      shards[r].apply_serve(code, slots[r], hp)
+    allk = np.array(sorted(ref.as_dict()), np.int64)
+    own = sharded.owner_of(torch.from_numpy(allk), world, "hash").numpy()
+    for r in range(world):
+      keys, vals = ops.read_kv_variable_op_v2(vars_[r])
+      keys = keys.cpu().numpy()
+      assert set(keys.tolist()) <= set(allk[own == r].tolist())          # blacklisted rows are not exported
+      got = dict(zip(keys.tolist(), vals.cpu().numpy()))
+      want = ref.as_dict()
+      for k in keys.tolist():
+        np.testing.assert_allclose(got[k], want[k], rtol=3e-5, atol=3e-6)
+      # the rows a lookup returns (zeros for blacklisted keys) agree for every key of the shard
+      mine = allk[own == r]
+      np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(vars_[r], mine).cpu().numpy(), ref.gather_or_zeros(mine),
+                                 rtol=3e-5, atol=3e-6)
