@@ -213,9 +213,16 @@ def main():
     ids = splitmix64(z.sample(N, gen))
     grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2
     U = int(torch.unique(ids).numel())
-    pool.append((ids, grad, U))
+    # entries of the batch = distinct (2048-id tile, id) pairs; S1 of them occur once in their tile (their gradient
+    # row goes straight to the apply, the others' rows are summed per tile first)
+    tl = torch.arange(N, device=dev, dtype=torch.int64) // 2048
+    _, ec = torch.unique(torch.stack([tl, ids], 1), dim=0, return_counts=True)
+    pool.append((ids, grad, U, int(ec.numel()), int((ec == 1).sum())))
+    del tl, ec
   out = torch.empty((N, D), dtype=torch.float32, device=dev)
   U_mean = float(np.mean([p[2] for p in pool]))
+  E_mean = float(np.mean([p[3] for p in pool]))
+  S1_mean = float(np.mean([p[4] for p in pool]))
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
@@ -360,19 +367,32 @@ def main():
   # the partition pass (its gather blocks copy the rows); the apply reads every gradient row once and
   # reads + writes the optimizer state of every unique key in k_apply_sorted.
   Ub = U_mean
-  alg = {
-      "lookup_tile": N * 8,
-      "lookup_part": Ub * 16,
-      "lookup_order": Ub * 4 * D + N * 4 * D + N * 4,
-      "apply_index": N * 8 + Ub * 16,
-      "apply_sorted": N * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,
-      "apply_span": 0,
-  }
+  fused = prof["apply_tsum"][1] > 0     # the entry-list pipeline ran (kv_fused.h)
+  if fused:
+    alg = {
+        "lookup_tile": N * 8 + Ub * (16 + 4 * D) + N * 4 * D,   # k_ltile: ids, one probe + one row per key, output rows
+        "lookup_part": 0,                                     # k_part2: row records only (not in SURVEY 8d's figure)
+        "lookup_order": 0,
+        "apply_index": N * 8 + Ub * 16,
+        "apply_tsum": (N - S1_mean) * 4 * D,                   # k_tsum: gradient rows of ids repeated inside their tile
+        "apply_sorted": S1_mean * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,   # k_apply: the other gradient rows + state r/w
+        "apply_span": 0,
+    }
+  else:
+    alg = {
+        "lookup_tile": N * 8,
+        "lookup_part": Ub * 16,
+        "lookup_order": Ub * 4 * D + N * 4 * D + N * 4,
+        "apply_index": N * 8 + Ub * 16,
+        "apply_tsum": 0,
+        "apply_sorted": N * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,
+        "apply_span": 0,
+    }
   kern = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items()}
   dom_ms = timed[dom][0] / max(timed[dom][1], 1)      # the dominant kernel, inside the timed region
   achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
   lookup_ms = kern["lookup_tile"] + kern["lookup_part"] + kern["lookup_order"]
-  apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"]
+  apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"] + kern["apply_tsum"]
   lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)
   apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D
 
@@ -404,6 +424,7 @@ def main():
       "config": {"workload": "configs[1]: %dM-key KvVariable x dim%d per GPU, %d ids/batch per GPU Zipf(%.1f), "
                              "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
                  "keys": K, "dim": D, "batch": N, "zipf": args.zipf, "global_batch": N * world, "unique_per_batch": Ub,
+                 "tile_entries_per_batch": E_mean, "tile_entries_single": S1_mean,
                  "parallelism": ("table sharded over %d GPUs by mix64(id) %% G, fixed-capacity id/row/grad exchange, "
                                  "grouped ncclSend/ncclRecv over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

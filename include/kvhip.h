@@ -426,13 +426,14 @@ int kv_take_rows(int device, const void* src, const int32_t* index, const int32_
  * For the optimizer ops the events belong to the `var` table.  kv_profile_select(h, mask) limits
  * the bracketing to the kinds whose bit (1 << KV_PROF_*) is set (default: all) — an event pair
  * costs a few microseconds of stream time, so a throughput measurement brackets one kernel. */
-#define KV_PROF_LOOKUP_TILE 0   /* k_tile: tile dedup + partition sort */
-#define KV_PROF_LOOKUP_PART 1   /* k_part_keys<LOOKUP>: find / insert / frequency, key records, work items */
+#define KV_PROF_LOOKUP_TILE 0   /* k_tile / k_ltile: tile dedup + partition sort (k_ltile: + index probes + output rows) */
+#define KV_PROF_LOOKUP_PART 1   /* k_part_keys<LOOKUP> / k_part2: find / insert / frequency, key records, work items */
 #define KV_PROF_LOOKUP_ORDER 2  /* k_gather<ORDER>: output rows + the sorted position list */
 #define KV_PROF_INDEX 3         /* the three index kernels of an apply that was not handed a valid token */
 #define KV_PROF_APPLY_SORTED 4  /* k_apply: segmented gradient sum + fused row update */
 #define KV_PROF_APPLY_SPAN 5    /* k_apply_fin: keys that span several chunks */
-#define KV_PROF_KINDS 6
+#define KV_PROF_APPLY_TSUM 6    /* k_tsum: tile-local gradient sums of repeated ids (entry-list pipeline) */
+#define KV_PROF_KINDS 7
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
 int kv_profile_select(kv_handle_t h, unsigned kind_mask);

@@ -13,6 +13,7 @@
 namespace {
 #include "kv_device.h"
 #include "kv_kernels.h"
+#include "kv_fused.h"
 #include "kv_apply_launch.h"
 }  // namespace
 

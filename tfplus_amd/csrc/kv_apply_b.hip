@@ -13,6 +13,7 @@
 namespace {
 #include "kv_device.h"
 #include "kv_kernels.h"
+#include "kv_fused.h"
 #include "kv_apply_launch.h"
 }  // namespace
 
@@ -27,4 +28,11 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_apply_b(int mode
   if (mode == MODE_APPLY && opt == OPT_FTRL) return launch_apply_t<MODE_APPLY, OPT_FTRL>(wd, pa, s, md, ntab, nchunks, span);
   if (mode == MODE_DEDUP) return launch_apply_t<MODE_DEDUP, OPT_ADAGRAD>(wd, pa, s, md, ntab, nchunks, span);
   return KV_INTERNAL;
+}
+
+// k_tsum of the entry-list pipeline (kv_fused.h); td_ = TableDev of the var table
+extern "C" __attribute__((visibility("hidden"))) int kvp_launch_tsum(const void* td_, const void* wd_, const float* grad,
+                                                                 long long n, void* stream) {
+  return launch_tsum_t(*static_cast<const TableDev*>(td_), *static_cast<const WsDev*>(wd_), grad, n,
+                       static_cast<hipStream_t>(stream));
 }

@@ -65,3 +65,22 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
 #undef KV_APPLY
   return KV_UNIMPLEMENTED;
 }
+
+// k_tsum (kv_fused.h): the tile sums in front of the entry-list apply; same row geometry as k_apply.
+// grid = ITEM_BLOCKS + ntiles * TSPLIT.  Instantiated once (kv_apply_b.hip).
+inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s) {
+  const int D = td.dim;
+  const unsigned grid = (unsigned)ITEM_BLOCKS + wd.ntiles * (unsigned)TSPLIT;
+#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBS, 0, s>>>(td, wd, grad, n); return KV_OK; } while (0)
+  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
+  const int q = D / 4;
+  if (q <= 1) KV_TSUM(4, 1, 1);
+  if (q <= 2) KV_TSUM(4, 2, 1);
+  if (q <= 4) KV_TSUM(4, 4, 1);
+  if (q <= 8) KV_TSUM(4, 8, 1);
+  if (q <= 16) KV_TSUM(4, 8, 2);
+  if (q <= 32) KV_TSUM(4, 16, 2);
+  if (q <= 64) KV_TSUM(4, 64, 1);
+#undef KV_TSUM
+  return KV_UNIMPLEMENTED;
+}

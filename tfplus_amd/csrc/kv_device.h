@@ -21,6 +21,13 @@ constexpr unsigned SLOT_MASK = (1u << RANK_SHIFT) - 1u;
 constexpr int LCOLD = 16;   // a key with at most this many occurrences in the batch is "cold": one lane group sums its
                             // rows and updates it; a "hot" key's rows are summed in chunks by whole waves
 constexpr int HC = 128;     // rows per hot chunk
+// ---- the entry-list pipeline (kv_fused.h) ----
+constexpr unsigned EP_TAG = 0x40000000u;    // entry list: the source is row (word & ~EP_TAG) of epart, not an input position
+constexpr unsigned NEW_BIT = 0x80000000u;   // ent_b row word: the key was inserted by this batch (row part 0: by another tile, row not seen yet)
+constexpr unsigned HINT_NEW = 0xFFFFFFFFu;  // Entry::hint of a key inserted by the batch in flight (the partition pass resets it)
+constexpr int WIDE = 32;    // an entry with more occurrences in its tile is summed by a whole wave (k_tsum), else by one lane group
+constexpr int HC2 = 512;    // entries per hot chunk of the entry-list apply: a key has at most one entry per tile, so up to
+                            // 1 M ids no key spans chunks and k_apply_fin is not launched
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
 constexpr int TBT = 512;  // threads per block of the tile kernel
@@ -113,6 +120,14 @@ struct WsDev {
   int* zero_counts;        // k_tile clears this [n] array on its way (the sharded route's sparse unique counts); else null
   const int* row_map;      // k_gather: rows are read at row_map[ent_b] (sharded lookup: the exchange buffer's records); else null
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
+  // ---- the entry-list pipeline (kv_fused.h).  It reuses ent_b (row word), ent_base (slot-row hint), ent_rec (the
+  //      entry's source: its input position, or EP_TAG | epart row), order (the entry list) and:
+  unsigned short* torder;  // [n] tile-local input positions sorted by entry (in slot_rank's storage)
+  unsigned* mlist;         // [ntiles][TILE / 2] the tile's entries with more than one occurrence: first position in torder
+                           // (low 16) | occurrences (high 16); up to WIDE occurrences from the front, more from the back
+  unsigned* mcount;        // [ntiles] narrow (low 16) | wide (high 16) entries in mlist
+  float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
+  unsigned hc;             // entries per hot chunk
 };
 
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
@@ -122,11 +137,13 @@ struct WsDev {
 #define KV_STAMPP(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = wall_clock64(); } while (0)
 #define KV_STAMPA(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = wall_clock64(); } while (0)
 #define KV_STAMPV(slot, v) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = (v); } while (0)
+#define KV_STAMPT(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 2048) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define KV_STAMP(slot) do { } while (0)
 #define KV_STAMPP(slot) do { } while (0)
 #define KV_STAMPA(slot) do { } while (0)
 #define KV_STAMPV(slot, v) do { } while (0)
+#define KV_STAMPT(slot) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -151,6 +168,9 @@ __device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
   const Chunk& c = t.chunks[r >> t.chunk_bits];
   return c.rows + (size_t)(r & ((1u << t.chunk_bits) - 1)) * t.dim;
 }
+// the whole slab is chunk 0 (every pre-sized table): rows are c0.rows + r * dim, no chunk-table hop and no branch in
+// front of the load — a loop that asks this once keeps all its row loads in flight together
+__device__ __forceinline__ bool single_chunk(const TableDev& t) { return ((t.max_rows - 1u) >> t.chunk_bits) == 0u; }
 __device__ __forceinline__ RowMeta* meta_ptr(const TableDev& t, unsigned r) {
   if ((r >> t.chunk_bits) == 0) return t.c0.meta + r;
   return t.chunks[r >> t.chunk_bits].meta + (r & ((1u << t.chunk_bits) - 1));

@@ -1,0 +1,930 @@
+// kv_fused.h — the entry-list pipeline of the training step (included after kv_kernels.h).
+//
+// The sorted-position pipeline of kv_kernels.h puts three launches in front of the lookup's output rows (tile pass,
+// partition pass with two dependent random hops per key, gather that files 1 M positions with scattered stores) and
+// walks 1 M random gradient rows plus a second kernel for the keys that span chunks.  Measured on the box
+// (profiles/r03_calibration.txt): random 128-B rows read at 5 TB/s whatever the order, the per-key state update of
+// GroupAdam costs 27-35 us for 109 k keys by itself, so what is left to remove is everything that is not a row.
+// This pipeline keeps the tile and the partition idea but changes who does what:
+//
+//   k_ltile   one block per TILE ids: LDS dedup; ONE index probe per distinct key of the tile, requested as soon as
+//             the keys are known and completed behind the counting sort (a key absent from the table is inserted
+//             here: a 64-bit CAS on the index entry decides between tiles, the loser needs no row — the row of a new
+//             key is a function of (key, seed)); the tile's entries {key, occurrences | count, row word, slot-row
+//             hint, source}; the tile's positions sorted by entry (torder, built in LDS, 2 B per position, coalesced);
+//             and the OUTPUT ROWS of its 2048 positions.  The lookup's result is complete after this one launch.
+//   k_part2   one block per hash partition over the tiles' entries (5 MB, not 1 M positions): exact occurrence
+//             counts, frequency word + day + flags of every key with ONE hop (the row came with the entry), rows of
+//             new keys initialised, key records, the ENTRY LIST — a key's entries contiguous, each naming its source
+//             — and the work items.  Nothing in the lookup's output depends on it, so a lookup may leave it pending:
+//             the optimizer apply of the same batch (batch token) runs it, or the next op on the table does.
+//   k_tsum    per tile: the gradient rows of every entry with more than one occurrence are summed in torder order
+//             into epart (all reads inside the tile's 256 KB of gradient rows; entries of up to WIDE rows by a lane
+//             group, larger ones by a wave).  An entry with one occurrence IS its gradient row.
+//   k_apply   (kv_kernels.h, unchanged but for the tagged source) over the entry list: a key has at most one entry
+//             per tile, so the hottest key of 1 M ids is 489 sources instead of 180 k positions, one chunk, and
+//             k_apply_fin is not launched.
+//
+// Summation order: inside an entry by rank (LDS-atomic arrival; input order in deterministic mode), then the key's
+// entries in list order (arrival in k_part2; tile order in deterministic mode): a fixed tree given those two.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// find-or-insert from a TILE: several tiles may meet the same absent key at once
+// ------------------------------------------------------------------------------------------
+// Index entry states of a key: {EMPTY,0,0} -> {key,0,0} (claimed, row not published yet) -> {key,row,HINT_NEW};
+// a deleted key's {key,ROW_TOMB,-} -> {key,0,-} -> {key,row,HINT_NEW}.  Whoever wins the CAS allocates the row and
+// publishes it; every other tile that meets the key in this launch sees one of the "new" states (or a stale cached
+// line, which the CAS resolves) and reports NEW_BIT with or without the row — k_part2 takes the row from the
+// entries that know it.  The row's contents and its RowMeta are written by k_part2 (the key's single owner there).
+__device__ __forceinline__ unsigned tile_insert(const TableDev& t, long long key) {
+  Entry* slot;
+  unsigned long long stored;
+  unsigned long long p = 0;
+  const bool sentinel = key == EMPTY_KEY;
+  if (sentinel) { slot = &t.entries[t.mask + 1]; stored = 0ull; }
+  else { stored = (unsigned long long)key; p = mix64((unsigned long long)key) & t.mask; slot = &t.entries[p]; }
+  for (;;) {
+    const Entry e = load_entry(slot);
+    if ((unsigned long long)e.key == stored && !(sentinel && e.key == EMPTY_KEY)) {
+      if (e.row == ROW_TOMB) {   // deleted earlier: the entry is still this key's — one tile gives it a row again
+        if (atomicCAS(&slot->row, ROW_TOMB, 0u) == ROW_TOMB) break;
+        return NEW_BIT;
+      }
+      if (e.row == 0u || e.hint == HINT_NEW) return NEW_BIT | e.row;
+      return e.row;              // (a hit that raced with nothing: the caller's probe would have found it)
+    }
+    if (e.key == EMPTY_KEY) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&slot->key),
+                                               (unsigned long long)EMPTY_KEY, stored);
+      if (old == (unsigned long long)EMPTY_KEY) break;   // claimed
+      if (old == stored) return NEW_BIT;                 // another tile is inserting the same key right now
+      if (sentinel) continue;                            // (cannot happen: only the sentinel key lives there)
+    } else if (sentinel) {
+      return NEW_BIT;   // unreachable: entries[cap] holds EMPTY or 0
+    }
+    if (!sentinel) { p = (p + 1) & t.mask; slot = &t.entries[p]; }
+  }
+  // claimed: allocate the row (rows released by Delete first) and publish {row, HINT_NEW} with one 8-byte store
+  unsigned r = 0;
+  bool have = false;
+  if (t.free_rows) {
+    const int f = atomicSub(reinterpret_cast<int*>(&t.counters[2]), 1);
+    if (f > 0) { r = t.free_rows[f - 1]; have = true; }
+    else atomicAdd(reinterpret_cast<int*>(&t.counters[2]), 1);
+  }
+  if (!have) {
+    r = atomicAdd(&t.counters[0], 1u);
+    if (r >= t.max_rows) { raise_error(t, 1u); return NEW_BIT; }
+  }
+  *reinterpret_cast<uint2*>(&slot->row) = make_uint2(r, HINT_NEW);
+  return NEW_BIT | r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ltile
+// ------------------------------------------------------------------------------------------
+struct LtSmem {
+  long long* lkeys;        // [LS + 1] (slot LS: the key that equals EMPTY_KEY); dead once the probes have left:
+  unsigned* lrow;          //   [LS + 1] row word of the slot's key           \.
+  unsigned short* tord;    //   [TILE]   tile-local positions sorted by entry  > live in lkeys' storage
+  unsigned* escan;         //   [TILE + 1] per entry: packed prefix (below)   /
+  unsigned* lcnt;          // [LS + 1] occurrences of the slot's key
+  unsigned short* lpos;    // [LS + 1] entry number of the slot's key
+  unsigned short* lfirst;  // [LS + 1] tile-local position of one occurrence
+  unsigned short* lwork;   // [TILE + 1] occupied slots; deterministic mode: running count per entry
+  unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); then the entries' frequency sums
+  unsigned* wtot;          // [8]
+};
+static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)TILE * 2 + 16 + (size_t)(TILE + 1) * 4, "aliases fit");
+
+__host__ __device__ inline size_t ltile_smem_bytes() {
+  size_t b = (size_t)(LS + 1) * 8 + 16;   // lkeys
+  b += (size_t)(LS + 1) * 4 + 16;         // lcnt
+  b += (size_t)(LS + 1) * 2 + 16;         // lpos
+  b += (size_t)(LS + 1) * 2 + 16;         // lfirst
+  b += (size_t)(TILE + 1) * 2 + 16;       // lwork
+  b += (size_t)(MAX_P + 1) * 4 + 16;      // hist
+  b += 64;                                // wtot
+  return b;
+}
+__device__ __forceinline__ LtSmem carve_ltile(char* base) {
+  LtSmem s;
+  auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
+  char* k0 = take((size_t)(LS + 1) * 8);
+  s.lkeys = reinterpret_cast<long long*>(k0);
+  s.lrow = reinterpret_cast<unsigned*>(k0);
+  s.tord = reinterpret_cast<unsigned short*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
+  s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15) + (size_t)TILE * 2);
+  s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
+  s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.lfirst = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
+  s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
+  s.wtot = reinterpret_cast<unsigned*>(take(64));
+  return s;
+}
+
+// packed per-entry scan word: positions (bits 0..11, sum <= 2048) | narrow multi-occurrence entries (bits 12..22) |
+// wide ones (bits 23..29)
+constexpr unsigned ES_POS = 0xFFFu, ES_NSH = 12, ES_NMASK = 0x7FFu, ES_WSH = 23;
+
+// VQ = float4 per row (power of two <= 64); GATHER: copy the rows of the tile's positions to `out`.
+// insert_ok == 0: a key absent from the table stays absent (row word 0: the zero row) — nothing here needs it yet.
+template <typename IdT, int VQ, bool GATHER>
+__device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, const IdT* __restrict__ ids,
+                                           const int* __restrict__ counts, long long n, int det,
+                                           float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LtSmem sm = carve_ltile(smem_raw);
+  __shared__ unsigned lnwork, lsent;
+
+  const int tid = threadIdx.x;
+  const unsigned tile = blockIdx.x;
+  const long long base = (long long)tile * TILE;
+  const unsigned P = w.P;
+  constexpr bool PAIRS = std::is_same<IdT, IdCount>::value;
+  const bool has_counts = PAIRS || counts != nullptr;
+  KV_STAMP(0);
+
+  long long kreg[IPT];
+  unsigned creg[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const long long i = base + (long long)k * TBT + tid;
+    kreg[k] = 0; creg[k] = 1;
+    if (i < n) {
+      kreg[k] = load_id(ids, (size_t)i);
+      if constexpr (PAIRS) {
+        const long long ci = ids[i].count;
+        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      } else if (counts != nullptr) {
+        const int ci = counts[i];   // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
+        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+      }
+    }
+  }
+  for (int s = tid; s <= LS; s += TBT) { sm.lkeys[s] = EMPTY_KEY; sm.lcnt[s] = 0; }
+  for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
+  if (tid == 0) { lnwork = 0; lsent = 0; }
+  if (tile == 0 && tid < 8) w.ctr[tid] = 0;
+  __syncthreads();
+
+  // ---- phase 1: LDS hash insert of the tile's ids ------------------------------------------------------------
+  unsigned tslot[IPT], myrank[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const long long i = base + (long long)k * TBT + tid;
+    tslot[k] = 0xFFFFFFFFu;
+    myrank[k] = 0;
+    bool there = i < n;
+    if constexpr (PAIRS) {
+      if (there && creg[k] == 0u) there = false;
+      if (there && w.seg_cap) {   // fixed-capacity exchange segments: record 0 is the header, records past its count are stale
+        const long long r = i % w.seg_cap;
+        there = r >= 1 && r <= ids[i - r].id;
+      }
+    }
+    if (there) {
+      const long long key = kreg[k];
+      unsigned h;
+      if (key == EMPTY_KEY) {
+        h = LS;
+        if (atomicCAS(&lsent, 0u, 1u) == 0u) sm.lfirst[LS] = (unsigned short)(k * TBT + tid);
+      } else {
+        h = (unsigned)(mix64((unsigned long long)key) >> 40) & (LS - 1);
+        for (;;) {
+          const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sm.lkeys[h]),
+                                                   (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+          if (old == (unsigned long long)EMPTY_KEY) { sm.lfirst[h] = (unsigned short)(k * TBT + tid); break; }
+          if (old == (unsigned long long)key) break;
+          h = (h + 1) & (LS - 1);
+        }
+      }
+      myrank[k] = atomicAdd(&sm.lcnt[h], 1u);
+      tslot[k] = h;
+    }
+  }
+  __syncthreads();
+  KV_STAMP(1);
+
+  // ---- phase 2: the occupied slots = the tile's distinct keys -----------------------------------------------
+  for (int s = tid; s < LS; s += TBT)
+    if (sm.lkeys[s] != EMPTY_KEY) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)s;
+  if (tid == 0 && lsent) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)LS;
+  __syncthreads();
+  const unsigned nwork = lnwork;
+
+  // ---- the index probes leave now (one per distinct key); they are completed behind the counting sort ---------
+  constexpr int WPT = (TILE + 1 + TBT - 1) / TBT;
+  long long wkey[WPT];
+  unsigned short wslot[WPT];
+  unsigned wcnt[WPT];
+  unsigned long long pp[WPT];
+  Entry en[WPT];
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    const unsigned wi = tid + q * TBT;
+    wkey[q] = 0; wslot[q] = 0; wcnt[q] = 0; pp[q] = 0;
+    en[q].key = EMPTY_KEY; en[q].row = 0; en[q].hint = 0;
+    if (wi < nwork) {
+      const unsigned s = sm.lwork[wi];
+      wslot[q] = (unsigned short)s;
+      wkey[q] = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
+      wcnt[q] = sm.lcnt[s];
+      pp[q] = home_of(t, wkey[q], mix64((unsigned long long)wkey[q]));
+      en[q] = load_entry(&t.entries[pp[q]]);
+    }
+  }
+
+  // ---- phase 3: counting sort of the distinct keys by owning partition ----------------------------------------
+  unsigned wp[WPT], wr[WPT];
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    const unsigned wi = tid + q * TBT;
+    wp[q] = 0; wr[q] = 0;
+    if (wi < nwork) {
+      wp[q] = part_of(wkey[q], w.pshift);
+      wr[q] = atomicAdd(&sm.hist[wp[q]], 1u | (wcnt[q] << 16)) & 0xFFFFu;
+    }
+  }
+  __syncthreads();   // (also: every read of lkeys is done — its storage is lrow / tord / escan from here on)
+  {
+    const unsigned per = (P + TBT - 1) / TBT;
+    const unsigned p0 = tid * per, p1 = min(p0 + per, P);
+    unsigned sum = 0;
+    for (unsigned p = p0; p < p1; ++p) sum += sm.hist[p];
+    unsigned tot;
+    unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
+    for (unsigned p = p0; p < p1; ++p) { const unsigned c = sm.hist[p]; sm.hist[p] = run; run += c; }
+    if (tid == 0) sm.hist[P] = tot;
+  }
+  __syncthreads();
+  // partition-major: toff[p][tile] (k_part2's block p reads rows p and p + 1 as two contiguous runs)
+  for (unsigned p = tid; p <= P; p += TBT) w.toff[(size_t)p * w.ntiles + tile] = sm.hist[p];
+  unsigned wpos[WPT];
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    wpos[q] = 0xFFFFFFFFu;
+    const unsigned wi = tid + q * TBT;
+    if (wi < nwork) {
+      const unsigned pos = (sm.hist[wp[q]] & 0xFFFFu) + wr[q];
+      const size_t e = (size_t)tile * TILE + pos;
+      wpos[q] = pos;
+      sm.lpos[wslot[q]] = (unsigned short)pos;
+      w.ent_key[e] = wkey[q];
+      if (!has_counts) w.ent_a[e] = wcnt[q] | (wcnt[q] << 16);   // <= TILE: the frequency count equals the occurrences
+    }
+  }
+  KV_STAMP(2);
+
+  // ---- the probes come back: row word + slot-row hint of every distinct key; absent keys are inserted ---------
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    if (wpos[q] == 0xFFFFFFFFu) continue;
+    unsigned hint = 0;
+    unsigned r = table_find_from(t, wkey[q], pp[q], en[q], &hint);
+    if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, wkey[q]); hint = 0; }
+    else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
+    const size_t e = (size_t)tile * TILE + wpos[q];
+    sm.lrow[wslot[q]] = r;
+    w.ent_b[e] = r;
+    w.ent_base[e] = hint;
+    // per entry for the scan below: positions | one narrow / one wide multi-occurrence entry
+    sm.escan[wpos[q]] = wcnt[q] | (wcnt[q] > 1u ? (wcnt[q] <= (unsigned)WIDE ? 1u << ES_NSH : 1u << ES_WSH) : 0u);
+  }
+  __syncthreads();
+  KV_STAMP(3);
+
+  // ---- phase 4: where every entry's positions start in the tile (torder), numbers of the multi-occurrence entries --
+  {
+    constexpr unsigned PER = (TILE + 1 + TBT - 1) / TBT;
+    const unsigned e0 = tid * PER, e1 = min(e0 + PER, nwork);
+    unsigned sum = 0;
+    for (unsigned e = e0; e < e1; ++e) sum += sm.escan[e];
+    unsigned tot;
+    unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
+    for (unsigned e = e0; e < e1; ++e) { const unsigned c = sm.escan[e]; sm.escan[e] = run; run += c; }
+    if (tid == 0) w.mcount[tile] = ((tot >> ES_NSH) & ES_NMASK) | ((tot >> ES_WSH) << 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    if (wpos[q] == 0xFFFFFFFFu) continue;
+    const unsigned pre = sm.escan[wpos[q]];
+    const size_t e = (size_t)tile * TILE + wpos[q];
+    unsigned src;
+    if (wcnt[q] > 1u) {
+      const unsigned ms = wcnt[q] <= (unsigned)WIDE ? ((pre >> ES_NSH) & ES_NMASK) : (unsigned)(TILE / 2 - 1) - (pre >> ES_WSH);
+      w.mlist[(size_t)tile * (TILE / 2) + ms] = (pre & ES_POS) | (wcnt[q] << 16);
+      src = EP_TAG | (tile * (unsigned)(TILE / 2) + ms);
+    } else {
+      src = (unsigned)base + sm.lfirst[wslot[q]];
+    }
+    w.ent_rec[e] = src;
+  }
+  if (det) {
+    // rank = occurrences of the key at smaller input positions (see tile_body of kv_kernels.h)
+    unsigned short* run = sm.lwork;
+    for (int e = tid; e <= TILE; e += TBT) run[e] = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const bool valid = tslot[k] != 0xFFFFFFFFu;
+      const unsigned e = valid ? (unsigned)sm.lpos[tslot[k]] : 0u;
+      unsigned long long mask = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 11; ++b) {
+        const bool bit = (e >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+      }
+      const unsigned rw = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      const unsigned cnt = (unsigned)__popcll(mask);
+      unsigned before = 0;
+      for (int wv = 0; wv < TBT / 64; ++wv) {
+        if (wave == wv && valid) {
+          before = run[e];
+          if (rw == 0u) run[e] = (unsigned short)(before + cnt);
+        }
+        __syncthreads();
+      }
+      myrank[k] = valid ? before + rw : 0u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < IPT; ++k)
+    if (tslot[k] != 0xFFFFFFFFu) sm.tord[(sm.escan[sm.lpos[tslot[k]]] & ES_POS) + myrank[k]] = (unsigned short)(k * TBT + tid);
+  // ---- per-occurrence counts: frequency sum per entry (hist is dead: reused) ----------------------------------
+  if (has_counts) {
+    __syncthreads();
+    for (unsigned e = tid; e <= (unsigned)TILE; e += TBT) sm.hist[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k)
+      if (tslot[k] != 0xFFFFFFFFu) atomicAdd(&sm.hist[sm.lpos[tslot[k]]], creg[k]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+      if (wpos[q] == 0xFFFFFFFFu) continue;
+      const unsigned f = sm.hist[wpos[q]];
+      w.ent_a[(size_t)tile * TILE + wpos[q]] = wcnt[q] | ((f > 65535u ? 65535u : f) << 16);
+    }
+  }
+  __syncthreads();
+  {
+    // torder of the tile, two positions per 4-byte store
+    unsigned* dst = reinterpret_cast<unsigned*>(w.torder + (size_t)tile * TILE);
+    const unsigned* srcw = reinterpret_cast<const unsigned*>(sm.tord);
+    for (int j = tid; j < TILE / 2; j += TBT) dst[j] = srcw[j];
+  }
+  KV_STAMP(4);
+
+  // ---- phase 5: the output rows.  Wave wv, round k holds positions k * TBT + wv * 64 + lane in its own registers ---
+  if constexpr (GATHER) {
+    constexpr int RW = 64 / VQ;            // rows per copy instruction
+    constexpr int CW = VQ < 8 ? VQ : 8;    // copy instructions in flight
+    const int lane = tid & 63;
+    const int v = lane % VQ, sub = lane / VQ;
+    // SINGLE: the slab is one chunk — rows are addressed without the chunk-table branch, which would put a wait in
+    // front of every load; with two blocks per CU the CW loads of a step must really be in flight together
+    auto copy_rows = [&](auto single_tag) {
+      constexpr bool SINGLE = decltype(single_tag)::value;
+      const float4* rows0 = reinterpret_cast<const float4*>(t.c0.rows);
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        const long long r0 = base + (long long)k * TBT + (tid & ~63);
+        if (r0 >= n) break;
+        const unsigned rr = tslot[k] != 0xFFFFFFFFu ? sm.lrow[tslot[k]] : 0u;   // skipped records read the zero row
+        const bool anynew = __ballot((rr & NEW_BIT) != 0u) != 0ull;
+#pragma unroll
+        for (int j0 = 0; j0 < VQ; j0 += CW) {
+          float4 val[CW];
+          unsigned rj[CW];
+#pragma unroll
+          for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            if constexpr (SINGLE) val[j] = rows0[(size_t)(rj[j] & ROW_MASK) * VQ + v];
+            else val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j] & ROW_MASK))[v];
+          }
+          if (__builtin_expect(anynew, 0)) {
+            // a key inserted by this batch: its row is the init rule's value (kv_variable.h:889-898), written to the
+            // table by k_part2; here it is computed, not read
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              const long long kj = __shfl(kreg[k], (j0 + j) * RW + sub);
+              if (rj[j] & NEW_BIT) {
+                const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
+                const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
+                const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
+                val[j] = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            const long long ii = r0 + (j0 + j) * RW + sub;
+            if (ii < n) {
+              float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+              __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+              __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+            }
+          }
+        }
+      }
+    };
+    if (single_chunk(t)) copy_rows(std::true_type{}); else copy_rows(std::false_type{});
+  }
+  KV_STAMP(5);
+}
+
+template <typename IdT, int VQ, bool GATHER>
+__global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* __restrict__ ids,
+                                              const int* __restrict__ counts, long long n, int det, float* __restrict__ out) {
+  ltile_body<IdT, VQ, GATHER>(t, w, ids, counts, n, det, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_part2: the partition pass over entries that already carry their rows
+// ------------------------------------------------------------------------------------------
+// seg_directory of kv_kernels.h over the partition-major toff: thread k takes tiles k, k + T, ... (coalesced rows),
+// the exclusive prefix over tiles is taken round by round.  *pbase = ENTRIES of the partitions before p.
+template <int T, int NW>
+__device__ __forceinline__ unsigned seg_directory_t(const WsDev& w, unsigned p, unsigned short* tpre,
+                                                    unsigned short* tstart, unsigned* wtot, unsigned* pbase) {
+  const unsigned NT = w.ntiles;
+  const unsigned* r0 = w.toff + (size_t)p * NT;
+  const unsigned* r1 = r0 + NT;
+  unsigned run0 = 0, pb = 0;
+  for (unsigned tb = 0; tb < NT; tb += T) {   // block-uniform
+    const unsigned t = tb + threadIdx.x;
+    unsigned len = 0, s0 = 0;
+    if (t < NT) {
+      const unsigned a = r0[t], b = r1[t];
+      s0 = a & 0xFFFFu;
+      len = (b & 0xFFFFu) - s0;
+      tstart[t] = (unsigned short)s0;
+    }
+    // one packed scan: entries of the partition (low 16, < 65536 or the caller gives up) | entries before it (high)
+    unsigned tot;
+    const unsigned ex = block_excl_scan<NW>(len, wtot, &tot);
+    unsigned tot2;
+    block_excl_scan<NW>(s0, wtot, &tot2);
+    if (t < NT) tpre[t] = (unsigned short)min(run0 + ex, 65535u);
+    run0 += tot;
+    pb += tot2;
+  }
+  __syncthreads();
+  *pbase = pb;
+  return run0;
+}
+// MODE_LOOKUP: FindOrInsert bookkeeping (frequency += occurrences, day, under-threshold flag, delta marks);
+// MODE_APPLYIDX: FindOrInsertUnsafe (a key the optimizer meets first: frequency word 1, not filtered).
+template <int MODE>
+__device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
+  constexpr int HSK = 1024;
+  constexpr int UCAPK = HSK - TBK;
+  constexpr int EB = 8;
+  __shared__ long long hkey[HSK + 1];
+  __shared__ unsigned hval[HSK + 1];   // summed frequency count; after the owner work: the key's record word
+  __shared__ unsigned hrow[HSK + 1];   // max over the key's entries of the row word (an entry that knows the row wins)
+  __shared__ unsigned hhint[HSK + 1];  // slot-row hint
+  __shared__ unsigned hocc[HSK + 1];   // entries of the key, then its start in the entry list
+  __shared__ unsigned hrun[HSK + 1];   // entries placed so far (pass 2)
+  __shared__ unsigned short lnew[UCAPK + 8];
+  __shared__ unsigned short ulist[UCAPK + 8];
+  __shared__ unsigned lnu, lsent, lnnew, lpcur;
+  __shared__ unsigned wtot[8];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short* tpre = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* tstart = tpre + w.ntiles;
+
+  const int tid = threadIdx.x;
+  const unsigned p = xcd_partition(blockIdx.x, w.P);
+  const unsigned NT = w.ntiles;
+  const int D = a.tv.dim;
+  KV_STAMPP(0);
+  unsigned pbase;
+  const unsigned E = seg_directory_t<TBK, TBK / 64>(w, p, tpre, tstart, wtot, &pbase);
+  __shared__ unsigned lcold, lhot, lchunk, lnbig;
+  __shared__ unsigned lbig[16][3];
+  if (E == 0) { if (tid == 0) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); return; }
+  __shared__ unsigned stkR[24], stkr[24];
+  __shared__ int sp;
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; lcold = 0; lhot = 0; lchunk = 0; }
+  __syncthreads();
+  if (E > 65535u) {
+    if (tid == 0) { raise_error(a.tv, 2u); w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
+    return;
+  }
+  const unsigned hcr = w.hc;
+  while (sp > 0) {
+    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+    __syncthreads();
+    if (tid == 0) --sp;
+    for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; hrun[s] = 0; }
+    if (tid == 0) { lnu = 0; lsent = 0; lnnew = 0; lnbig = 0; }
+    __syncthreads();
+    // ---- pass 1: distinct keys, their counts, rows and hints --------------------------------------------------
+    unsigned cge[EB];
+    unsigned short cslot[EB];
+    const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
+    for (unsigned x0 = 0; x0 < E; x0 += EB * TBK) {
+      unsigned ge[EB];
+      long long key[EB];
+      unsigned ea[EB], rw[EB], hi[EB];
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const unsigned x = x0 + k * TBK + tid;
+        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0;
+        if (ge[k] != 0xFFFFFFFFu) { key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]]; }
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if (x0 == 0) { cge[k] = ge[k]; cslot[k] = 0; }
+        if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
+        if (lnu >= (unsigned)UCAPK) continue;
+        bool first;
+        const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key[k], true, &first);
+        if (first) {
+          const unsigned u = atomicAdd(&lnu, 1u);
+          if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
+        }
+        if (MODE == MODE_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16);
+        atomicAdd(&hocc[h], 1u);
+        atomicMax(&hrow[h], rw[k]);
+        if (hi[k]) atomicMax(&hhint[h], hi[k]);
+        if (x0 == 0) cslot[k] = (unsigned short)h;
+      }
+    }
+    __syncthreads();
+    if (lnu >= (unsigned)UCAPK) {
+      __syncthreads();
+      if (tid == 0) {
+        if (sp + 2 <= 24) {
+          stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+          stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+        } else {
+          raise_error(a.tv, 2u);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    KV_STAMPP(1);
+    const unsigned nu = lnu;
+
+    // ---- the keys' places in the entry list, the cold / hot numbering and the hot keys' chunks ---------------
+    constexpr int PERU = (UCAPK + TBK - 1) / TBK;
+    unsigned kst[PERU], kcnt[PERU], krank[PERU], kchunk[PERU];
+    {
+      unsigned sum = 0, ch = 0, nchs = 0;
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        kcnt[q] = u < nu ? hocc[ulist[u]] : 0u;
+        sum += kcnt[q];
+        if (u < nu) {
+          if (kcnt[q] <= (unsigned)LCOLD) ch += 1u;
+          else { ch += 1u << 16; nchs += (kcnt[q] + hcr - 1u) / hcr; }
+        }
+      }
+      const unsigned cur = lpcur;
+      unsigned tot, chtot, ntot;
+      unsigned run = cur + block_excl_scan<TBK / 64>(sum, wtot, &tot);
+      unsigned chrun = block_excl_scan<TBK / 64>(ch, wtot, &chtot);
+      unsigned nrun = block_excl_scan<TBK / 64>(nchs, wtot, &ntot);
+      const unsigned c0 = lcold, h0 = lhot, k0 = lchunk;
+      const unsigned cbase = pbase + c0, hbase = pbase + h0, kbase = k0;
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        kst[q] = run; krank[q] = 0; kchunk[q] = 0;
+        if (u < nu) {
+          hocc[ulist[u]] = run; run += kcnt[q];
+          if (kcnt[q] <= (unsigned)LCOLD) { krank[q] = cbase + (chrun & 0xFFFFu); chrun += 1u; }
+          else {
+            krank[q] = hbase + (chrun >> 16); chrun += 1u << 16;
+            kchunk[q] = kbase + nrun; nrun += (kcnt[q] + hcr - 1u) / hcr;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { lpcur = cur + tot; lcold = c0 + (chtot & 0xFFFFu); lhot = h0 + (chtot >> 16); lchunk = k0 + ntot; }
+    }
+    auto put_rec = [&](int q, long long key, unsigned roww, unsigned hint) {
+      const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), roww, hint);
+      if (kcnt[q] <= (unsigned)LCOLD) {
+        w.coldlist[2 * (size_t)krank[q]] = ra;
+        w.coldlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], 0u, 0u);
+      } else {
+        w.hotlist[2 * (size_t)krank[q]] = ra;
+        w.hotlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], kchunk[q], hcr);
+        const unsigned nch = (kcnt[q] + hcr - 1u) / hcr;
+        if (nch <= 16u) {
+          for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+        } else {
+          const unsigned b = atomicAdd(&lnbig, 1u);
+          if (b < 16u) { lbig[b][0] = krank[q]; lbig[b][1] = kchunk[q]; lbig[b][2] = nch; }
+          else for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+        }
+      }
+    };
+
+    // ---- owner work: one thread per distinct key; ONE hop (the row's record), none in the optimizer's index pass ----
+    {
+      unsigned sl[PERU], r[PERU];
+      bool isnew[PERU];
+      uint2 m[PERU];
+#pragma unroll
+      for (int k = 0; k < PERU; ++k) {
+        const unsigned u = tid * PERU + k;
+        sl[k] = 0xFFFFFFFFu; r[k] = 0; isnew[k] = false; m[k] = make_uint2(0u, (unsigned)FLAG_DIRTY);
+        if (u < nu) {
+          sl[k] = ulist[u];
+          const unsigned rw = hrow[sl[k]];
+          r[k] = rw & ROW_MASK; isnew[k] = (rw & NEW_BIT) != 0u;
+          if (MODE == MODE_LOOKUP && r[k] != 0u && !isnew[k]) m[k] = load_freq_flags(a.tv, r[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PERU; ++k) {
+        if (sl[k] == 0xFFFFFFFFu) continue;
+        const unsigned s = sl[k];
+        const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+        if (__builtin_expect(isnew[k], 0)) {
+          // the tile that won the key published {row, HINT_NEW}; the hint goes back to "none"
+          Entry* e = table_entry_of(a.tv, key);
+          if (e) {
+            if (r[k] == 0u) { const unsigned er = load_entry(e).row; r[k] = er != ROW_TOMB ? er : 0u; }
+            e->hint = 0u;
+          }
+          hrow[s] = r[k] | NEW_BIT;
+        }
+        put_rec(k, key, r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? NEW_BIT : 0u), isnew[k] ? 0u : hhint[s]);
+        if (r[k] == 0u) continue;   // row slab overflow: the error flag is up
+        RowMeta* mp = meta_ptr(a.tv, r[k]);
+        if (isnew[k]) { mp->key = key; mp->delta_train = 0; mp->delta_pred = 0; }
+        if (MODE == MODE_LOOKUP) {
+          mark_delta(a.tv, r[k]);
+          // find_func / insert_func (kv_variable.h:320-363)
+          const unsigned cnt = a.count_once ? 1u : hval[s];
+          unsigned lo = (m[k].x & 0xFFFFu) + (cnt > 65535u ? 65535u : cnt);
+          if (lo > 65535u) lo = 65535u;
+          mp->freq = (a.day << 16) | lo;
+          if (isnew[k]) mp->flags = (unsigned char)FLAG_DIRTY;
+          if (m[k].y & FLAG_DIRTY) lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | (isnew[k] ? 0x8000u : 0u));
+        } else if (isnew[k]) {
+          // FindOrInsertUnsafe (kv_variable.h:382-416): init rule, frequency word 1; existing rows are not touched
+          mp->freq = 1u; mp->flags = 0;
+          lnew[atomicAdd(&lnnew, 1u)] = (unsigned short)(s | 0x8000u);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const unsigned nbig = min(lnbig, 16u);
+      for (unsigned b = 0; b < nbig; ++b)
+        for (unsigned i = tid; i < lbig[b][2]; i += TBK)
+          w.litem[pbase + lbig[b][1] + i] = make_uint4(lbig[b][0] | HEAD_BIT, i, lbig[b][1] + i, 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < PERU; ++q) {
+      const unsigned u = tid * PERU + q;
+      if (u < nu) hval[ulist[u]] = krank[q] | (kcnt[q] > (unsigned)LCOLD ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    KV_STAMPP(2);
+
+    // ---- rows that need lanes: contents of new rows, under-threshold flag of rows that changed ------------------
+    {
+      const int lane8 = tid & 7;
+      const unsigned nn = lnnew;
+      const unsigned npad = (nn + 7u) & ~7u;
+      for (unsigned j = tid >> 3; j < npad; j += TBK / 8) {
+        const bool live = j < nn;
+        const unsigned sv = live ? lnew[j] : 0u;
+        const unsigned s = sv & 0x7FFFu;
+        const bool isnew = (sv & 0x8000u) != 0;
+        const long long key = (s == HSK) ? EMPTY_KEY : hkey[s];
+        const unsigned r = live ? (hrow[s] & ROW_MASK) : 0u;
+        float* row = row_ptr(a.tv, r);
+        bool big = false;
+        if (live && r != 0) {
+          if (isnew) big = init_row_coop(a.tv, key, row, lane8, 8);
+          else if (MODE == MODE_LOOKUP)
+            for (int e = lane8; e < D; e += 8) big |= fabsf(row[e]) >= CUTOFF;
+        }
+        const unsigned long long mb = __ballot(big);
+        const bool any = ((mb >> ((tid & 63) & ~7)) & 0xFFull) != 0;
+        if (live && r != 0 && lane8 == 0) {
+          unsigned char* fp = flags_ptr(a.tv, r);
+          if (MODE == MODE_LOOKUP) {
+            const unsigned black = isnew ? 0u : (*fp & FLAG_BLACK);
+            *fp = (unsigned char)(black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : FLAG_UNDER));
+          } else {
+            *fp = (unsigned char)(any ? 0u : FLAG_UNDER);
+          }
+        }
+      }
+    }
+    KV_STAMPP(3);
+
+    // ---- pass 2: the entry list — entry x of key h goes to order[start(h) + its number among h's entries] -------
+    {
+      auto place = [&](unsigned ge, unsigned h) {
+        const unsigned idx = atomicAdd(&hrun[h], 1u);
+        const unsigned src = w.ent_rec[ge];
+        w.order[hocc[h] + idx] = src;
+        if (idx == 0u) {
+          const unsigned rec = hval[h];
+          if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2] = src;
+        }
+      };
+      if (a.det) {
+        // deterministic mode: a key's entries in tile order = ascending x (TBK entries per round, wave by wave)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (unsigned x0 = 0; x0 < E; x0 += TBK) {
+          const unsigned x = x0 + tid;
+          bool valid = x < E;
+          size_t ge = 0;
+          unsigned h = 0xFFFFFFFFu;
+          if (valid) {
+            ge = seg_entry(tpre, tstart, NT, x);
+            const long long key = w.ent_key[ge];
+            valid = in_round(key, R, round);
+            if (valid) { bool first; h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first); }
+          }
+          unsigned within = 0;
+          for (int j = 0; j < 63; ++j) {
+            const unsigned hj = __shfl(h, j);
+            if (j < lane && hj == h) within += 1u;
+          }
+          unsigned idx = 0;
+          for (int wv = 0; wv < TBK / 64; ++wv) {
+            if (wave == wv && valid) { idx = hrun[h] + within; atomicAdd(&hrun[h], 1u); }
+            __syncthreads();
+          }
+          if (valid) {
+            const unsigned src = w.ent_rec[ge];
+            w.order[hocc[h] + idx] = src;
+            if (idx == 0u) {
+              const unsigned rec = hval[h];
+              if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2] = src;
+            }
+          }
+        }
+      } else if (cached) {
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+          if (cge[k] != 0xFFFFFFFFu) place(cge[k], cslot[k]);
+      } else {
+        for (unsigned x = tid; x < E; x += TBK) {
+          const size_t ge = seg_entry(tpre, tstart, NT, x);
+          const long long key = w.ent_key[ge];
+          if (!in_round(key, R, round)) continue;
+          bool first;
+          place((unsigned)ge, lds_key_slot<HSK>(hkey, &lsent, key, false, &first));
+        }
+      }
+    }
+    __syncthreads();
+    KV_STAMPP(4);
+  }
+  {
+    const unsigned nc = lcold, nk = lchunk, gb = 64u / (unsigned)apply_lanes(a.tv.dim);
+    const unsigned nb = (nc + gb - 1u) / gb;
+    for (unsigned b = tid; b < nb; b += TBK) w.litem[pbase + nk + b] = make_uint4(pbase + b * gb, min(gb, nc - b * gb), 0u, 0u);
+    if (tid == 0) w.pmeta[p] = make_uint4(nk + nb, nk, pbase, nc);
+  }
+}
+template <int MODE>
+__global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_body<MODE>(w, a); }
+
+// ------------------------------------------------------------------------------------------
+// k_tsum: per tile, the gradient sums of the entries that have more than one occurrence
+// ------------------------------------------------------------------------------------------
+// TSPLIT blocks of 256 threads share a tile: the narrow entries (2 .. WIDE rows) go one to a lane group, the wide
+// ones one to a wave.  ITEM_BLOCKS blocks in front build the dense work-item directory of the partitions (the
+// partition pass is complete when this kernel starts).
+constexpr int TSPLIT = 4;
+template <int V, int LPR, int K>
+__device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, long long n, unsigned b) {
+  constexpr int G = 64 / LPR;
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  const unsigned tile = b / TSPLIT, part = b % TSPLIT;
+  const unsigned mc = w.mcount[tile];
+  const unsigned nn = mc & 0xFFFFu, nw = mc >> 16;
+  const unsigned* ml = w.mlist + (size_t)tile * (TILE / 2);
+  const unsigned short* to = w.torder + (size_t)tile * TILE;
+  const float* g0 = grad + (size_t)tile * TILE * D;
+  float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
+  const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR;
+  auto load_row = [&](unsigned lp, float (&dst)[K][V]) {
+    const float* src = g0 + (size_t)lp * D;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) ldv_stream<V>(src + e0, dst[k]);
+    }
+  };
+  // narrow entries: lane group `gid` of the tile's TSPLIT * 4 * G groups
+  const unsigned gid = part * (TBS / LPR) + threadIdx.x / LPR, ngr = TSPLIT * (TBS / LPR);
+  for (unsigned j = gid; j < nn; j += ngr) {
+    const unsigned m = ml[j];
+    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
+    for (unsigned i0 = 0; i0 < cnt; i0 += RB) {
+      unsigned lp[RB];
+      float val[RB][K][V];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) lp[i] = i0 + i < cnt ? to[st + i0 + i] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) val[i][k][cc] = 0.f;
+        if (lp[i] != 0xFFFFFFFFu) load_row(lp[i], val[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += val[i][k][cc];
+    }
+    float* dst = ep + (size_t)j * D;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e0 = (lane + k * LPR) * V;
+      if (e0 < D) stv<V>(dst + e0, gv[k]);
+    }
+  }
+  // wide entries: one wave each; row i of a step goes to lane group i % G, a fixed shuffle tree joins the groups
+  const unsigned wid = part * (TBS / 64) + (threadIdx.x >> 6), nwv = TSPLIT * (TBS / 64);
+  for (unsigned k2 = wid; k2 < nw; k2 += nwv) {
+    const unsigned ms = (unsigned)(TILE / 2 - 1) - k2;
+    const unsigned m = ml[ms];
+    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
+    constexpr int SR = G * RB;
+    for (unsigned i0 = 0; i0 < cnt; i0 += SR) {
+      unsigned lp[RB];
+      float val[RB][K][V];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) { const unsigned x = i0 + i * G + g; lp[i] = x < cnt ? to[st + x] : 0xFFFFFFFFu; }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) val[i][k][cc] = 0.f;
+        if (lp[i] != 0xFFFFFFFFu) load_row(lp[i], val[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += val[i][k][cc];
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
+    if (g == 0) {
+      float* dst = ep + (size_t)ms * D;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) stv<V>(dst + e0, gv[k]);
+      }
+    }
+  }
+}
+template <int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, long long n) {
+  if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the index pass gave up on this batch
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
+  KV_STAMPT(0);
+  if (blockIdx.x < ITEM_BLOCKS) { items_body(w); KV_STAMPT(1); return; }
+  tsum_body<V, LPR, K>(w, grad, t.dim, n, blockIdx.x - ITEM_BLOCKS);
+  KV_STAMPT(1);
+}

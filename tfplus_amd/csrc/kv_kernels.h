@@ -326,6 +326,7 @@ struct PartArgs {
   int det;                    // deterministic reduction mode
   int sparse_unique;          // MODE_UNIQUE: unique numbers = sorted position of the partition + local number (with gaps)
   long long n;                // ids in the batch
+  const float* epart;         // entry-list pipeline: list words tagged EP_TAG name rows of this array (tile sums), else of grad
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -1126,7 +1127,7 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
   const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
   const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
   auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
-    const float* src = a.grad + (size_t)pos * D;
+    const float* src = (pos & EP_TAG) ? a.epart + (size_t)(pos & ~EP_TAG) * D : a.grad + (size_t)pos * D;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;

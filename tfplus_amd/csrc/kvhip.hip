@@ -53,10 +53,13 @@ extern "C" int kvp_launch_apply_a(int mode, int opt, const void* wd, const void*
 extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab,
                                   unsigned nchunks, int span);
 
+extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream);
+
 namespace {
 
 #include "kv_device.h"
 #include "kv_kernels.h"
+#include "kv_fused.h"
 
 // ------------------------------------------------------------------------------------------
 // maintenance kernels
@@ -323,6 +326,9 @@ struct Workspace {
   float* hpart = nullptr;      // [chunk_cap(cap_n)][dim]
   long long hpart_elems = 0;
   unsigned* ctr = nullptr;
+  unsigned* mcount = nullptr;  // entry-list pipeline: [cap_n / TILE]
+  float* epart = nullptr;      // [cap_n / 2][dim] tile sums
+  long long epart_elems = 0;
   long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
   float* scat_sum = nullptr;
   long long scat_cap = 0;          // rows
@@ -371,6 +377,7 @@ struct kv_table {
   // same token takes the index over instead of rebuilding it
   uint64_t batch_serial = 0;
   long long batch_n = 0;
+  bool fused_index = false;        // the index is an entry list (kv_fused.h), not a sorted position list
   bool deterministic = false;      // kv_set_deterministic
   uint64_t uid = 0;                // unique over the process: names the attached slot table safely
   uint64_t slot_uid = 0;           // uid of the slot table the index entries' hints refer to (0 = none)
@@ -573,14 +580,15 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     const unsigned capP = std::max(pick_partitions(cap), P);
     const size_t nt = (size_t)(cap / TILE);
     // every buffer is replaced only once its successor exists; a failure leaves the old sizes in force
-    w.cap_n = 0; w.capP = 0; w.hpart_elems = 0;
+    w.cap_n = 0; w.capP = 0; w.hpart_elems = 0; w.epart_elems = 0;
     t->batch_serial = 0;
     if ((rc = regrow(&w.ent_key, (size_t)cap)) || (rc = regrow(&w.ent_a, (size_t)cap)) ||
         (rc = regrow(&w.ent_b, (size_t)cap)) || (rc = regrow(&w.ent_base, (size_t)cap)) || (rc = regrow(&w.ent_rec, (size_t)cap)) ||
         (rc = regrow(&w.toff, nt * (capP + 1))) || (rc = regrow(&w.slot_rank, (size_t)cap)) ||
         (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.coldlist, 2 * (size_t)cap)) ||
         (rc = regrow(&w.hotlist, 2 * (size_t)cap)) || (rc = regrow(&w.litem, (size_t)cap)) ||
-        (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)))
+        (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)) ||
+        (rc = regrow(&w.mcount, nt + 1)))
       return rc;
     if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
 #ifdef KV_STAMPS
@@ -596,6 +604,13 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     w.hpart_elems = 0;
     if ((rc = regrow(&w.hpart, (size_t)pe))) return rc;
     w.hpart_elems = pe;
+  }
+  const long long ee = (w.cap_n / 2) * (long long)t->dim;
+  if (need_part && w.epart_elems < ee) {
+    HIP_TRY(hipStreamSynchronize(s));
+    w.epart_elems = 0;
+    if ((rc = regrow(&w.epart, (size_t)ee))) return rc;
+    w.epart_elems = ee;
   }
   return KV_OK;
 }
@@ -621,6 +636,12 @@ WsDev ws_view(kv_table* t, long long n) {
   d.row_map = nullptr;
   d.zero_counts = nullptr;
   d.dbg = w.dbg;
+  // entry-list pipeline: torder and mlist share slot_rank's storage (2 B per position + 4 B per two positions)
+  d.torder = reinterpret_cast<unsigned short*>(w.slot_rank);
+  d.mlist = w.slot_rank + w.cap_n / 2;
+  d.mcount = w.mcount;
+  d.epart = w.epart;
+  d.hc = (unsigned)HC;
   return d;
 }
 
@@ -726,11 +747,52 @@ void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t 
   else k_order<<<grid, TB, 0, s>>>(td, wd, n);
 }
 
+// ---- the entry-list pipeline (kv_fused.h) ----
+// dims it serves: float4 rows with a power-of-two lane count (4, 8, 16, ..., 256)
+bool fused_ok(int D) {
+  static const bool off = [] { const char* e = getenv("KV_NO_FUSED"); return e && atoi(e) != 0; }();   // A/B against the sorted-position pipeline
+  if (off || (D & 3) != 0) return false;
+  const int q = D / 4;
+  return q >= 1 && q <= 64 && (q & (q - 1)) == 0;
+}
+// tile pass: dedup, index probes / inserts, entries, tile-local order and (out != nullptr) the output rows
+void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, const int* counts, long long n, float* out,
+                  hipStream_t s, int ids_kind = -1) {
+  if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
+  const int grid = (int)wd.ntiles;
+  const size_t sh = ltile_smem_bytes();
+  const int det = t->deterministic ? 1 : 0;
+  const int q = td.dim / 4;
+#define KV_LT2(IDT, VQ)                                                                                     \
+  do {                                                                                                      \
+    if (out) k_ltile<IDT, VQ, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out);      \
+    else k_ltile<IDT, 1, false><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr);     \
+  } while (0)
+#define KV_LT(IDT)                                                              \
+  do {                                                                          \
+    switch (q) {                                                                \
+      case 1: KV_LT2(IDT, 1); break;   case 2: KV_LT2(IDT, 2); break;           \
+      case 4: KV_LT2(IDT, 4); break;   case 8: KV_LT2(IDT, 8); break;           \
+      case 16: KV_LT2(IDT, 16); break; case 32: KV_LT2(IDT, 32); break;         \
+      default: KV_LT2(IDT, 64); break;                                          \
+    }                                                                           \
+  } while (0)
+  if (ids_kind == 2) KV_LT(IdCount);
+  else if (ids_kind == 1) KV_LT(int);
+  else KV_LT(long long);
+#undef KV_LT
+#undef KV_LT2
+}
+template <int MODE>
+void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
+  k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
+}
+
 // segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
 // boundaries (k_apply_span).  pa.n = ids of the batch (multi: nmax = the largest table's batch)
 template <int MODE, int OPT>
 int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long long nmax, hipStream_t s,
-                 const MultiDesc* md = nullptr, int ntab = 0) {
+                 const MultiDesc* md = nullptr, int ntab = 0, bool skip_fin = false) {
   const int D = pa.tv.dim;
   // waves stride over the items (hot chunks, then cold batches of 64 / LPR keys); 8 blocks of 4 waves per CU
   // is everything the chip holds at once, fewer for small batches
@@ -743,7 +805,7 @@ int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long lon
     ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
     rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, 0);
   }
-  if (rc == KV_OK) {
+  if (rc == KV_OK && !skip_fin) {
     ProfScope ps(prof_t, KV_PROF_APPLY_SPAN, s);
     rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, gfin, 1);
   }
@@ -818,6 +880,7 @@ int enter_op(kv_table* t, hipStream_t s) {
 template <int MODE>
 void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
                 int ids_kind, float* out, hipStream_t s, bool file_order = true) {
+  t->fused_index = false;
   {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
@@ -833,7 +896,34 @@ void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* id
   else launch_order(pa.tv, wd, n, s);
 }
 
-uint64_t g_serial = 0;   // batch tokens (under the table's mutex; uniqueness across tables is not needed)
+// The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
+template <int MODE>
+void fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
+                      int ids_kind, float* out, hipStream_t s) {
+  wd.hc = (unsigned)HC2;
+  t->fused_index = true;
+  {
+    ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
+    launch_ltile(t, pa.tv, wd, ids, counts, n, out, s, ids_kind);
+  }
+  ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
+  launch_part2<MODE>(wd, pa, s);
+}
+// ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
+// a key can have more entries than a chunk holds, i.e. more tiles than HC2)
+template <int OPT>
+int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s) {
+  wd.hc = (unsigned)HC2;
+  pa.epart = wd.epart;
+  {
+    ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
+    const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s);
+    if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
+  }
+  return launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s, nullptr, 0, wd.ntiles <= wd.hc);
+}
+
+std::atomic<uint64_t> g_serial{0};   // batch tokens
 std::atomic<uint64_t> g_uid{0};
 
 }  // namespace
@@ -976,6 +1066,7 @@ int kv_destroy(kv_handle_t t) {
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
+  hipFree(w.mcount); hipFree(w.epart);
   hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   if (t->err_host) hipHostFree(t->err_host);
   if (t->last_done) hipEventDestroy(t->last_done);
@@ -1147,7 +1238,8 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     pa.day = today(t);
     pa.det = t->deterministic ? 1 : 0;
     pa.n = m;
-    index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
+    if (fused_ok(t->dim) && !pairs) fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s);
+    else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
   if (token && n <= CHK) {   // the workspace now holds the index of exactly this batch, positions filed
@@ -1589,7 +1681,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   if ((rc = ensure_capacity(s0, n, s))) return rc;
   if (s1 && (rc = ensure_capacity(s1, n, s))) return rc;
   if ((rc = ensure_workspace(v, n, true, s))) return rc;
-  const WsDev wd = ws_view(v, n);
+  WsDev wd = ws_view(v, n);
   PartArgs pa{};
   pa.tv = dev_view(v); pa.ts0 = dev_view(s0); pa.ts1 = s1 ? dev_view(s1) : pa.ts0;
   pa.opt = a; pa.grad = grad; pa.day = today(v);
@@ -1598,11 +1690,14 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
   if (!reuse) {
     v->batch_serial = 0;
-    index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    if (fused_ok(v->dim)) fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    else index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
     v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
     v->batch_n = n;
   }
-  if ((rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s))) return rc;
+  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s);
+  else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
