@@ -5,7 +5,7 @@
 //
 // D % 4 == 0 -> float4 lanes, else scalar lanes.  md != nullptr: one launch over `ntab` tables (grid.y),
 // nchunks = blocks per table; only MODE_APPLY on float4 rows is instantiated for it.
-// span == 0: k_apply, span == 1: k_apply_fin.  Returns KV_OK, or KV_UNIMPLEMENTED for an
+// span == 0: k_apply, span == 1: k_apply_fin, span == 2: k_apply2 (entry-list pipeline).  Returns KV_OK, or KV_UNIMPLEMENTED for an
 // unsupported dim.
 #pragma once
 
@@ -16,8 +16,8 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
   int grid_ = (int)nchunks;
 #define KV_APPLY(V, LPR, K)                                                                        \
   do {                                                                                             \
-    const size_t sh = span ? (size_t)(TBF / 64) * D * 4 + 16 : 0;                                   \
-    if (!span) {  /* one resident generation of blocks: a second one would start when the first ends */  \
+    const size_t sh = span == 1 ? (size_t)(TBF / 64) * D * 4 + 16 : 0;                              \
+    if (span != 1) {  /* one resident generation of blocks: a second one would start when the first ends */  \
       static const int resident = [] {                                                             \
         int nb = 0, cus = 0, dev = 0;                                                              \
         hipGetDevice(&dev);                                                                        \
@@ -28,6 +28,19 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
       }();                                                                                         \
       if ((int)nchunks > resident) grid_ = resident; else grid_ = (int)nchunks;                     \
     }                                                                                              \
+    if constexpr (MODE == MODE_APPLY) {                                                            \
+      if (span == 2) {                                                                             \
+        static const int resident2 = [] {                                                          \
+          int nb = 0, cus = 0, dev = 0;                                                            \
+          hipGetDevice(&dev);                                                                      \
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                 \
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply2<OPT, V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
+          if (nb > 6) nb = 6;                                                                      \
+          return nb * (cus > 0 ? cus : 256);                                                       \
+        }();                                                                                       \
+        grid_ = (int)nchunks > resident2 ? resident2 : (int)nchunks;                               \
+      }                                                                                            \
+    }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
       if (md) {                                                                                    \
         if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBF, sh, s>>>(md);   \
@@ -36,6 +49,9 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
       }                                                                                            \
     }                                                                                              \
     if (md) return KV_UNIMPLEMENTED;                                                               \
+    if constexpr (MODE == MODE_APPLY) {   /* span 2: the entry-list apply (kv_fused.h), same grid rule as k_apply */ \
+      if (span == 2) { k_apply2<OPT, V, LPR, K><<<grid_, TBS, 0, s>>>(wd, pa); return KV_OK; }        \
+    }                                                                                              \
     if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid_, TBF, sh, s>>>(wd, pa);                     \
     else k_apply<MODE, OPT, V, LPR, K><<<grid_, TBS, sh, s>>>(wd, pa);                        \
     return KV_OK;                                                                                  \
@@ -70,8 +86,21 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
 // grid = ITEM_BLOCKS + ntiles * TSPLIT.  Instantiated once (kv_apply_b.hip).
 inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s) {
   const int D = td.dim;
-  const unsigned grid = (unsigned)ITEM_BLOCKS + wd.ntiles * (unsigned)TSPLIT;
-#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBS, 0, s>>>(td, wd, grad, n); return KV_OK; } while (0)
+  const unsigned units = wd.ntiles * (unsigned)TSPLIT;
+#define KV_TSUM(V, LPR, K)                                                                            \
+  do {                                                                                                \
+    static const unsigned resident = [] {                                                             \
+      int nb = 0, cus = 0, dev = 0;                                                                   \
+      hipGetDevice(&dev);                                                                             \
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                        \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tsum<V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
+      if (nb > 8) nb = 8;                                                                             \
+      return (unsigned)(nb * (cus > 0 ? cus : 256));                                                  \
+    }();                                                                                              \
+    const unsigned grid = (unsigned)ITEM_BLOCKS + (units < resident - ITEM_BLOCKS ? units : resident - ITEM_BLOCKS); \
+    k_tsum<V, LPR, K><<<grid, TBS, 0, s>>>(td, wd, grad, n);                                          \
+    return KV_OK;                                                                                     \
+  } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const int q = D / 4;
   if (q <= 1) KV_TSUM(4, 1, 1);

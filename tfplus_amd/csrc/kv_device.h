@@ -85,6 +85,8 @@ struct TableDev {
   unsigned long long seed;
   unsigned track_delta;     // NeedDeltaInfo() kv_variable.h:816: touched keys are remembered for DeltaExport
   unsigned* err_host;       // pinned host copy of counters[1] (the host reads it without a synchronisation)
+  unsigned single;          // the slab is chunk 0 alone (every pre-sized table): row addresses need no chunk-table hop —
+                            // a UNIFORM test, so the loads behind it are not fenced by a per-lane branch
 };
 
 // device view of the per-batch workspace (kv_kernels.h explains the pipeline)
@@ -164,15 +166,15 @@ __device__ __forceinline__ unsigned long long pick64(unsigned long long x) {
 }
 
 __device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
-  if ((r >> t.chunk_bits) == 0) return t.c0.rows + (size_t)r * t.dim;
+  if (t.single || (r >> t.chunk_bits) == 0) return t.c0.rows + (size_t)r * t.dim;
   const Chunk& c = t.chunks[r >> t.chunk_bits];
   return c.rows + (size_t)(r & ((1u << t.chunk_bits) - 1)) * t.dim;
 }
 // the whole slab is chunk 0 (every pre-sized table): rows are c0.rows + r * dim, no chunk-table hop and no branch in
 // front of the load — a loop that asks this once keeps all its row loads in flight together
-__device__ __forceinline__ bool single_chunk(const TableDev& t) { return ((t.max_rows - 1u) >> t.chunk_bits) == 0u; }
+__device__ __forceinline__ bool single_chunk(const TableDev& t) { return t.single != 0u; }
 __device__ __forceinline__ RowMeta* meta_ptr(const TableDev& t, unsigned r) {
-  if ((r >> t.chunk_bits) == 0) return t.c0.meta + r;
+  if (t.single || (r >> t.chunk_bits) == 0) return t.c0.meta + r;
   return t.chunks[r >> t.chunk_bits].meta + (r & ((1u << t.chunk_bits) - 1));
 }
 __device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->freq; }
@@ -472,34 +474,16 @@ template <int V, int K>
 struct PreRows {
   float x[K][V], s[3][K][V];
 };
+// The row math and the stores of one key's update, on values the caller already holds: xin = the var row;
+// sin[0..2] = GroupAdam m | v | z, Adagrad accum, FTRL accum | linear.  Element e of a row lives at lane
+// (e / V) % LPR, step (e / V) / LPR.  All LPR lanes of every group of the wave call it (shuffles inside); `act`
+// masks groups without an update.  fvp / f0p / f1p = the flag bytes of the var / first / second slot row.
+// Restates the per-id body of KvVariableGroupSparseApplyAdamV4Op / V3Op / SparseApplyAdagradOp /
+// SparseGroupSparseApplyFtrlOp (training_ops.cc:7142-7197, 5871-5927, 1455-1486, 684-763).
 template <int OPT, int V, int LPR, int K>
-__device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDev& ts0,
-                                               const TableDev& ts1, long long key, unsigned tag,
-                                               unsigned r0, bool new0, unsigned r1, bool new1,
-                                               bool live, const float (&gv)[K][V], const OptArgs& a,
-                                               int lane, const PreRows<V, K>* pre = nullptr, bool have_x = false,
-                                               bool have_s = false) {
-  const int D = tv.dim;
-  const bool skip = !live || (tag & ROW_FILTERED) || (tag & ROW_MASK) == 0u;  // training_ops.cc:7150-7152
-  const unsigned rv = tag & ROW_MASK;
-  const bool act = !skip && r0 != 0 && (OPT != OPT_FTRL || r1 != 0);
-
-  float* xrow = row_ptr(tv, act ? rv : 0u);
-  float* s0row = row_ptr(ts0, act ? r0 : 0u);
-  float* s1row = (OPT == OPT_FTRL) ? row_ptr(ts1, act ? r1 : 0u) : nullptr;
-
-  // new slot rows are initialised in registers with the slot table's init rule
-  const float *ia0 = nullptr, *ib0 = nullptr, *ia1 = nullptr, *ib1 = nullptr;
-  if (act && new0) {
-    unsigned long long h = pick64((unsigned long long)key ^ (ts0.seed * 0x9E3779B97F4A7C15ULL));
-    ia0 = ts0.init_table + (size_t)((unsigned)h % ts0.init_rows) * ts0.dim;
-    ib0 = ts0.init_table + (size_t)((unsigned)(h >> 32) % ts0.init_rows) * ts0.dim;
-  }
-  if (OPT == OPT_FTRL && act && new1) {
-    unsigned long long h = pick64((unsigned long long)key ^ (ts1.seed * 0x9E3779B97F4A7C15ULL));
-    ia1 = ts1.init_table + (size_t)((unsigned)h % ts1.init_rows) * ts1.dim;
-    ib1 = ts1.init_table + (size_t)((unsigned)(h >> 32) % ts1.init_rows) * ts1.dim;
-  }
+__device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row, unsigned char* fvp, unsigned char* f0p,
+                                         unsigned char* f1p, bool act, bool new0, int D, const float (&gv)[K][V],
+                                         const OptArgs& a, int lane, const float (&xin)[K][V], const float (&sin)[3][K][V]) {
   if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) {
     // training_ops.cc:7166-7195 (V4) / :5895-5925 (V3); slot row = [m | v | z]
     float m[K][V], nv[K][V], sq[K][V], z[K][V], uu[K][V];
@@ -508,40 +492,23 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
-      float xo[V], mo[V], vo[V], zo[V];
-#pragma unroll
-      for (int c = 0; c < V; ++c) xo[c] = mo[c] = vo[c] = zo[c] = 0.f;
       const bool valid = act && e0 < D;
-      if (valid) {
-        if (pre && have_x) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) xo[c] = pre->x[k][c];
-        } else {
-          ldv<V>(xrow + e0, xo);
-        }
-        if (pre && have_s && !new0) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) { mo[c] = pre->s[0][k][c]; vo[c] = pre->s[1][k][c]; zo[c] = pre->s[2][k][c]; }
-        } else {
-          ldslot<V>(s0row, ia0, ib0, new0, e0, mo);
-          ldslot<V>(s0row, ia0, ib0, new0, e0 + D, vo);
-          ldslot<V>(s0row, ia0, ib0, new0, e0 + 2 * D, zo);
-        }
-      }
 #pragma unroll
       for (int c = 0; c < V; ++c) {
+        const float xo = valid ? xin[k][c] : 0.f, mo = valid ? sin[0][k][c] : 0.f;
+        const float vo = valid ? sin[1][k][c] : 0.f, zo = valid ? sin[2][k][c] : 0.f;
         const float gg = gv[k][c];
-        const float mn = a.b1 * mo[c] + omb1 * gg;
-        const float vn = a.b2 * vo[c] + omb2 * (gg * gg);
+        const float mn = a.b1 * mo + omb1 * gg;
+        const float vn = a.b2 * vo + omb2 * (gg * gg);
         const float s = sqrtf(vn);
         float d;
         if (OPT == OPT_ADAM_V4) {
-          d = (a.b1 > a.b1p) ? (s - sqrtf(vo[c])) * xo[c] : (s + a.eps) * xo[c];
+          d = (a.b1 > a.b1p) ? (s - sqrtf(vo)) * xo : (s + a.eps) * xo;
         } else {
-          d = (a.b1 > a.b1p) ? (s - sqrtf(vo[c])) / a.lr * xo[c]
-                             : (s - sqrtf(vo[c]) + a.eps) / a.lr * xo[c];
+          d = (a.b1 > a.b1p) ? (s - sqrtf(vo)) / a.lr * xo
+                             : (s - sqrtf(vo) + a.eps) / a.lr * xo;
         }
-        const float zn = zo[c] + (a.alpha * mn - d);
+        const float zn = zo + (a.alpha * mn - d);
         const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
         const float uv = adj - zn;
         m[k][c] = mn; nv[k][c] = vn; sq[k][c] = s; z[k][c] = zn; uu[k][c] = uv;
@@ -578,8 +545,8 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
     const bool anyx = group_any<LPR>(big), anys = group_any<LPR>(sbig);
     if (act && lane == 0) {
       // CoverUpdateUnsafe -> UpdateUnderThreshold, or MarkBlacklistUnsafe (:7187-7195)
-      *flags_ptr(tv, rv) = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
-      *flags_ptr(ts0, r0) = (unsigned char)(anys ? 0u : FLAG_UNDER);
+      *fvp = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
+      *f0p = (unsigned char)(anys ? 0u : FLAG_UNDER);
     }
   } else if (OPT == OPT_ADAGRAD) {
     // training_ops.cc:1470-1482.  No CoverUpdate: flags of existing rows are left alone.
@@ -589,20 +556,9 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
       const int e0 = (lane + k * LPR) * V;
       if (act && e0 < D) {
         float xo[V], acc[V];
-        if (pre && have_x) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) xo[c] = pre->x[k][c];
-        } else {
-          ldv<V>(xrow + e0, xo);
-        }
-        if (pre && have_s && !new0) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) acc[c] = pre->s[0][k][c];
-        } else {
-          ldslot<V>(s0row, ia0, ib0, new0, e0, acc);
-        }
 #pragma unroll
         for (int c = 0; c < V; ++c) {
+          xo[c] = xin[k][c]; acc[c] = sin[0][k][c];
           const float gg = gv[k][c];
           sbig |= fabsf(acc[c]) >= CUTOFF;
           if (a.update_slots) acc[c] = acc[c] + gg * gg;
@@ -616,12 +572,12 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
     const bool anys = group_any<LPR>(sbig);
     if (act && lane == 0) {
       // the reference does not refresh under_threshold here; a later lookup does (FLAG_DIRTY)
-      *flags_ptr(tv, rv) |= (unsigned char)FLAG_DIRTY;
-      if (new0) *flags_ptr(ts0, r0) = (unsigned char)((anys ? 0u : FLAG_UNDER) | (a.update_slots ? FLAG_DIRTY : 0u));
-      else if (a.update_slots) *flags_ptr(ts0, r0) |= (unsigned char)FLAG_DIRTY;
+      *fvp |= (unsigned char)FLAG_DIRTY;
+      if (new0) *f0p = (unsigned char)((anys ? 0u : FLAG_UNDER) | (a.update_slots ? FLAG_DIRTY : 0u));
+      else if (a.update_slots) *f0p |= (unsigned char)FLAG_DIRTY;
     }
   } else {
-    // OPT_FTRL: training_ops.cc:713-751 with has_l2_shrinkage; ts0 = accum, ts1 = linear
+    // OPT_FTRL: training_ops.cc:713-751 with has_l2_shrinkage; slot 0 = accum, slot 1 = linear
     float x[K][V], ac[K][V], z[K][V], uu[K][V];
     float part = 0.f;
     const bool half = a.lr_power == -0.5f;
@@ -629,33 +585,17 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
-      float zo[V];
-#pragma unroll
-      for (int c = 0; c < V; ++c) x[k][c] = ac[k][c] = zo[c] = 0.f;
       const bool valid = act && e0 < D;
-      if (valid) {
-        if (pre && have_x) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) x[k][c] = pre->x[k][c];
-        } else {
-          ldv<V>(xrow + e0, x[k]);
-        }
-        if (pre && have_s && !new0) {
-#pragma unroll
-          for (int c = 0; c < V; ++c) ac[k][c] = pre->s[0][k][c];
-        } else {
-          ldslot<V>(s0row, ia0, ib0, new0, e0, ac[k]);
-        }
-        ldslot<V>(s1row, ia1, ib1, new1, e0, zo);
-      }
 #pragma unroll
       for (int c = 0; c < V; ++c) {
+        x[k][c] = valid ? xin[k][c] : 0.f; ac[k][c] = valid ? sin[0][k][c] : 0.f;
+        const float zo = valid ? sin[1][k][c] : 0.f;
         const float xo = x[k][c], ao = ac[k][c];
         const float gs = gv[k][c] + two_l2s * xo;
         const float na = ao + gs * gs;
         const float pn = half ? sqrtf(na) : powf(na, -a.lr_power);
         const float po = half ? sqrtf(ao) : powf(ao, -a.lr_power);
-        const float zn = zo[c] + (gs - (pn - po) / a.lr * xo);
+        const float zn = zo + (gs - (pn - po) / a.lr * xo);
         const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
         const float uv = adj - zn;
         z[k][c] = zn; uu[k][c] = uv;
@@ -697,9 +637,71 @@ __device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDe
     }
     const bool anyx = group_any<LPR>(big), anya = group_any<LPR>(abig), anyz = group_any<LPR>(zbig);
     if (act && lane == 0) {
-      *flags_ptr(tv, rv) = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
-      *flags_ptr(ts0, r0) = (unsigned char)(anya ? 0u : FLAG_UNDER);
-      *flags_ptr(ts1, r1) = (unsigned char)(anyz ? 0u : FLAG_UNDER);
+      *fvp = (unsigned char)(upd ? (anyx ? 0u : FLAG_UNDER) : (FLAG_BLACK | FLAG_UNDER));
+      *f0p = (unsigned char)(anya ? 0u : FLAG_UNDER);
+      *f1p = (unsigned char)(anyz ? 0u : FLAG_UNDER);
     }
   }
+}
+
+// One unique key's fused optimizer update through the tables: resolves the row pointers, loads (or initialises, for
+// a slot row inserted now) the state rows the caller does not hold yet, then opt_core.
+template <int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void opt_update_row(const TableDev& tv, const TableDev& ts0,
+                                               const TableDev& ts1, long long key, unsigned tag,
+                                               unsigned r0, bool new0, unsigned r1, bool new1,
+                                               bool live, const float (&gv)[K][V], const OptArgs& a,
+                                               int lane, const PreRows<V, K>* pre = nullptr, bool have_x = false,
+                                               bool have_s = false) {
+  const int D = tv.dim;
+  const bool skip = !live || (tag & ROW_FILTERED) || (tag & ROW_MASK) == 0u;  // training_ops.cc:7150-7152
+  const unsigned rv = tag & ROW_MASK;
+  const bool act = !skip && r0 != 0 && (OPT != OPT_FTRL || r1 != 0);
+
+  float* xrow = row_ptr(tv, act ? rv : 0u);
+  float* s0row = row_ptr(ts0, act ? r0 : 0u);
+  float* s1row = (OPT == OPT_FTRL) ? row_ptr(ts1, act ? r1 : 0u) : nullptr;
+
+  // new slot rows are initialised in registers with the slot table's init rule
+  const float *ia0 = nullptr, *ib0 = nullptr, *ia1 = nullptr, *ib1 = nullptr;
+  if (act && new0) {
+    unsigned long long h = pick64((unsigned long long)key ^ (ts0.seed * 0x9E3779B97F4A7C15ULL));
+    ia0 = ts0.init_table + (size_t)((unsigned)h % ts0.init_rows) * ts0.dim;
+    ib0 = ts0.init_table + (size_t)((unsigned)(h >> 32) % ts0.init_rows) * ts0.dim;
+  }
+  if (OPT == OPT_FTRL && act && new1) {
+    unsigned long long h = pick64((unsigned long long)key ^ (ts1.seed * 0x9E3779B97F4A7C15ULL));
+    ia1 = ts1.init_table + (size_t)((unsigned)h % ts1.init_rows) * ts1.dim;
+    ib1 = ts1.init_table + (size_t)((unsigned)(h >> 32) % ts1.init_rows) * ts1.dim;
+  }
+  float xin[K][V], sin[3][K][V];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e0 = (lane + k * LPR) * V;
+#pragma unroll
+    for (int c = 0; c < V; ++c) xin[k][c] = sin[0][k][c] = sin[1][k][c] = sin[2][k][c] = 0.f;
+    if (!(act && e0 < D)) continue;
+    if (pre && have_x) {
+#pragma unroll
+      for (int c = 0; c < V; ++c) xin[k][c] = pre->x[k][c];
+    } else {
+      ldv<V>(xrow + e0, xin[k]);
+    }
+    if (pre && have_s && !new0) {
+      constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
+#pragma unroll
+      for (int b3 = 0; b3 < NS0; ++b3)
+#pragma unroll
+        for (int c = 0; c < V; ++c) sin[b3][k][c] = pre->s[b3][k][c];
+    } else {
+      ldslot<V>(s0row, ia0, ib0, new0, e0, sin[0][k]);
+      if (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) {
+        ldslot<V>(s0row, ia0, ib0, new0, e0 + D, sin[1][k]);
+        ldslot<V>(s0row, ia0, ib0, new0, e0 + 2 * D, sin[2][k]);
+      }
+    }
+    if (OPT == OPT_FTRL) ldslot<V>(s1row, ia1, ib1, new1, e0, sin[1][k]);
+  }
+  opt_core<OPT, V, LPR, K>(xrow, s0row, s1row, flags_ptr(tv, act ? rv : 0u), flags_ptr(ts0, act ? r0 : 0u),
+                           OPT == OPT_FTRL ? flags_ptr(ts1, act ? r1 : 0u) : nullptr, act, new0, D, gv, a, lane, xin, sin);
 }

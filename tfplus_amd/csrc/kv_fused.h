@@ -508,12 +508,12 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
   KV_STAMPP(0);
   unsigned pbase;
   const unsigned E = seg_directory_t<TBK, TBK / 64>(w, p, tpre, tstart, wtot, &pbase);
-  __shared__ unsigned lcold, lhot, lchunk, lnbig;
+  __shared__ unsigned lcold, lhot, lchunk, litm, lnbig;   // litm: cold batches so far (they fill the stretch from its end)
   __shared__ unsigned lbig[16][3];
   if (E == 0) { if (tid == 0) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); return; }
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
-  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; lcold = 0; lhot = 0; lchunk = 0; }
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; lcold = 0; lhot = 0; lchunk = 0; litm = 0; }
   __syncthreads();
   if (E > 65535u) {
     if (tid == 0) { raise_error(a.tv, 2u); w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
@@ -580,59 +580,88 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     KV_STAMPP(1);
     const unsigned nu = lnu;
 
-    // ---- the keys' places in the entry list, the cold / hot numbering and the hot keys' chunks ---------------
+    // ---- the keys' places in the entry list; their numbers: cold keys by class (1, 2, 3..LCOLD entries — a batch of
+    //      the apply then holds keys of ONE class, and the first two sources ride in the record), hot keys and their
+    //      chunks; the round's work items: its chunk items, then its cold batches
     constexpr int PERU = (UCAPK + TBK - 1) / TBK;
     unsigned kst[PERU], kcnt[PERU], krank[PERU], kchunk[PERU];
+    const unsigned gb = 64u / (unsigned)apply_lanes(a.tv.dim);   // keys per cold batch
+    unsigned i0r, k0r;   // cold batches / chunks of the partition's earlier rounds
     {
-      unsigned sum = 0, ch = 0, nchs = 0;
+      unsigned sum = 0, ch = 0, hh = 0;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
         kcnt[q] = u < nu ? hocc[ulist[u]] : 0u;
         sum += kcnt[q];
         if (u < nu) {
-          if (kcnt[q] <= (unsigned)LCOLD) ch += 1u;
-          else { ch += 1u << 16; nchs += (kcnt[q] + hcr - 1u) / hcr; }
+          if (kcnt[q] == 1u) ch += 1u;
+          else if (kcnt[q] == 2u) ch += 1u << 10;
+          else if (kcnt[q] <= (unsigned)LCOLD) ch += 1u << 20;
+          else hh += 1u | (((kcnt[q] + hcr - 1u) / hcr) << 10);
         }
       }
       const unsigned cur = lpcur;
-      unsigned tot, chtot, ntot;
+      unsigned tot, chtot, htot;
       unsigned run = cur + block_excl_scan<TBK / 64>(sum, wtot, &tot);
       unsigned chrun = block_excl_scan<TBK / 64>(ch, wtot, &chtot);
-      unsigned nrun = block_excl_scan<TBK / 64>(nchs, wtot, &ntot);
-      const unsigned c0 = lcold, h0 = lhot, k0 = lchunk;
-      const unsigned cbase = pbase + c0, hbase = pbase + h0, kbase = k0;
+      unsigned hrn = block_excl_scan<TBK / 64>(hh, wtot, &htot);
+      const unsigned t1 = chtot & 1023u, t2 = (chtot >> 10) & 1023u, t3 = chtot >> 20, th = htot & 1023u, tk = htot >> 10;
+      const unsigned c0 = lcold, h0 = lhot, k0 = lchunk, i0 = litm;
+      i0r = i0; k0r = k0;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
         kst[q] = run; krank[q] = 0; kchunk[q] = 0;
         if (u < nu) {
           hocc[ulist[u]] = run; run += kcnt[q];
-          if (kcnt[q] <= (unsigned)LCOLD) { krank[q] = cbase + (chrun & 0xFFFFu); chrun += 1u; }
+          if (kcnt[q] == 1u) { krank[q] = pbase + c0 + (chrun & 1023u); chrun += 1u; }
+          else if (kcnt[q] == 2u) { krank[q] = pbase + c0 + t1 + ((chrun >> 10) & 1023u); chrun += 1u << 10; }
+          else if (kcnt[q] <= (unsigned)LCOLD) { krank[q] = pbase + c0 + t1 + t2 + (chrun >> 20); chrun += 1u << 20; }
           else {
-            krank[q] = hbase + (chrun >> 16); chrun += 1u << 16;
-            kchunk[q] = kbase + nrun; nrun += (kcnt[q] + hcr - 1u) / hcr;
+            krank[q] = pbase + h0 + (hrn & 1023u);
+            kchunk[q] = k0 + (hrn >> 10);
+            hrn += 1u | (((kcnt[q] + hcr - 1u) / hcr) << 10);
           }
         }
       }
-      __syncthreads();
-      if (tid == 0) { lpcur = cur + tot; lcold = c0 + (chtot & 0xFFFFu); lhot = h0 + (chtot >> 16); lchunk = k0 + ntot; }
+      // the round's cold batches, class by class: {first cold list index, keys, class}.  Chunk items fill the
+      // partition's stretch of litem from its front (by chunk number), cold batches from its back: the directory
+      // (items2_body) deals every hot chunk of the batch before any cold batch
+      {
+        const unsigned nb1 = (t1 + gb - 1u) / gb, nb2 = (t2 + gb - 1u) / gb, nb3 = (t3 + gb - 1u) / gb;
+        const unsigned ib = pbase + E - 1u - i0;
+        for (unsigned bq = tid; bq < nb1 + nb2 + nb3; bq += TBK) {
+          unsigned cls, bb, first, cntc;
+          if (bq < nb1) { cls = 1u; bb = bq; first = pbase + c0; cntc = t1; }
+          else if (bq < nb1 + nb2) { cls = 2u; bb = bq - nb1; first = pbase + c0 + t1; cntc = t2; }
+          else { cls = 3u; bb = bq - nb1 - nb2; first = pbase + c0 + t1 + t2; cntc = t3; }
+          w.litem[ib - bq] = make_uint4(first + bb * gb, min(gb, cntc - bb * gb), cls, 0u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          lpcur = cur + tot; lcold = c0 + t1 + t2 + t3; lhot = h0 + th; lchunk = k0 + tk;
+          litm = i0 + nb1 + nb2 + nb3;
+        }
+      }
     }
     auto put_rec = [&](int q, long long key, unsigned roww, unsigned hint) {
       const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), roww, hint);
       if (kcnt[q] <= (unsigned)LCOLD) {
         w.coldlist[2 * (size_t)krank[q]] = ra;
-        w.coldlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], 0u, 0u);
+        // {start in the entry list, entries, first source, second source} — the sources are filed by pass 2
+        reinterpret_cast<uint2*>(&w.coldlist[2 * (size_t)krank[q] + 1])[0] = make_uint2(kst[q], kcnt[q]);
       } else {
         w.hotlist[2 * (size_t)krank[q]] = ra;
         w.hotlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], kchunk[q], hcr);
         const unsigned nch = (kcnt[q] + hcr - 1u) / hcr;
+        const unsigned ib = pbase + kchunk[q];
         if (nch <= 16u) {
-          for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+          for (unsigned i = 0; i < nch; ++i) w.litem[ib + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
         } else {
           const unsigned b = atomicAdd(&lnbig, 1u);
           if (b < 16u) { lbig[b][0] = krank[q]; lbig[b][1] = kchunk[q]; lbig[b][2] = nch; }
-          else for (unsigned i = 0; i < nch; ++i) w.litem[pbase + kchunk[q] + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
+          else for (unsigned i = 0; i < nch; ++i) w.litem[ib + i] = make_uint4(krank[q] | HEAD_BIT, i, kchunk[q] + i, 0u);
         }
       }
     };
@@ -742,9 +771,9 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
         const unsigned idx = atomicAdd(&hrun[h], 1u);
         const unsigned src = w.ent_rec[ge];
         w.order[hocc[h] + idx] = src;
-        if (idx == 0u) {
+        if (idx < 2u) {   // a cold key's first two sources ride in its record
           const unsigned rec = hval[h];
-          if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2] = src;
+          if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2 + idx] = src;
         }
       };
       if (a.det) {
@@ -774,9 +803,9 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
           if (valid) {
             const unsigned src = w.ent_rec[ge];
             w.order[hocc[h] + idx] = src;
-            if (idx == 0u) {
+            if (idx < 2u) {
               const unsigned rec = hval[h];
-              if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2] = src;
+              if (!(rec >> 31)) reinterpret_cast<unsigned*>(&w.coldlist[2 * (size_t)rec + 1])[2 + idx] = src;
             }
           }
         }
@@ -797,27 +826,70 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     __syncthreads();
     KV_STAMPP(4);
   }
-  {
-    const unsigned nc = lcold, nk = lchunk, gb = 64u / (unsigned)apply_lanes(a.tv.dim);
-    const unsigned nb = (nc + gb - 1u) / gb;
-    for (unsigned b = tid; b < nb; b += TBK) w.litem[pbase + nk + b] = make_uint4(pbase + b * gb, min(gb, nc - b * gb), 0u, 0u);
-    if (tid == 0) w.pmeta[p] = make_uint4(nk + nb, nk, pbase, nc);
-  }
+  if (tid == 0) w.pmeta[p] = make_uint4(lchunk + litm, lchunk, pbase, E);
 }
 template <int MODE>
 __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_body<MODE>(w, a); }
 
 // ------------------------------------------------------------------------------------------
+// items2_body: the dense work-item directory, every hot chunk of the batch in front of every cold batch
+// ------------------------------------------------------------------------------------------
+// Waves take items round-robin, so with the hot chunks first every wave gets at most one more of them than any
+// other (a random mix left some waves with four, and the kernel ended when they did).  pmeta[q] = {items, hot
+// chunks, first entry, entries}: the chunk items of partition q are litem[first + j], its cold batches
+// litem[first + entries - 1 - j].
+__device__ __forceinline__ void items2_body(const WsDev& w) {
+  __shared__ unsigned sit[MAX_P + 1], sck[MAX_P + 1];
+  __shared__ unsigned wt[8];
+  const unsigned P = w.P;
+  const int tid = threadIdx.x, T = blockDim.x;   // 256 threads
+  const unsigned per = (P + T - 1) / T;
+  const unsigned p0 = min(P, tid * per), p1 = min(P, p0 + per);
+  unsigned si = 0, sc = 0;
+  for (unsigned q = p0; q < p1; ++q) { const uint4 m = w.pmeta[q]; sit[q] = m.x - m.y; sck[q] = m.y; si += m.x - m.y; sc += m.y; }
+  unsigned ti, tc;
+  unsigned ri = block_excl_scan<TB / 64>(si, wt, &ti);   // ti: cold batches of the batch
+  unsigned rc = block_excl_scan<TB / 64>(sc, wt, &tc);   // tc: hot chunks
+  for (unsigned q = p0; q < p1; ++q) { const unsigned a_ = sit[q], b_ = sck[q]; sit[q] = ri; sck[q] = rc; ri += a_; rc += b_; }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) { w.ctr[2] = ti + tc; w.ctr[3] = tc; }
+  const unsigned total = ti + tc;
+  const unsigned nblk = min((unsigned)ITEM_BLOCKS, gridDim.x);
+  const unsigned ipb = (total + nblk - 1) / nblk;
+  const unsigned i0 = min(total, blockIdx.x * ipb), i1 = min(total, i0 + ipb);
+  for (unsigned i = i0 + tid; i < i1; i += T) {
+    const bool hot = i < tc;
+    const unsigned x = hot ? i : i - tc;
+    const unsigned* pre = hot ? sck : sit;
+    unsigned lo = 0, hi = P;
+    while (hi - lo > 1) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (pre[mid] <= x) lo = mid; else hi = mid;
+    }
+    const uint4 m = w.pmeta[lo];
+    const unsigned j = x - pre[lo];
+    uint4 it = w.litem[hot ? m.z + j : m.z + m.w - 1u - j];
+    if (hot) it.z += sck[lo];   // the chunk's number in the batch (its row of hpart)
+    w.items[i] = it;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_tsum: per tile, the gradient sums of the entries that have more than one occurrence
 // ------------------------------------------------------------------------------------------
-// TSPLIT blocks of 256 threads share a tile: the narrow entries (2 .. WIDE rows) go one to a lane group, the wide
-// ones one to a wave.  ITEM_BLOCKS blocks in front build the dense work-item directory of the partitions (the
-// partition pass is complete when this kernel starts).
+// TSPLIT blocks of 256 threads share a tile.  Narrow entries (2 .. WIDE rows) go one to a lane group.  A wide entry
+// is summed by a whole BLOCK: row x of the entry goes to wave x / 64 % 4, lane group x % G, the waves' sums meet in
+// LDS in wave order (the hottest key of a Zipf(1.2) batch owns 370 rows of every tile: six dependent steps for one
+// wave, two for a block).  The positions of the next step are requested with the rows of this one.
+// ITEM_BLOCKS blocks in front build the dense work-item directory of the partitions (the partition pass is
+// complete when this kernel starts).
 constexpr int TSPLIT = 4;
 template <int V, int LPR, int K>
 __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, long long n, unsigned b) {
   constexpr int G = 64 / LPR;
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  constexpr int NWV = TBS / 64;
+  __shared__ float lsum[NWV][K * V * LPR];
   const unsigned tile = b / TSPLIT, part = b % TSPLIT;
   const unsigned mc = w.mcount[tile];
   const unsigned nn = mc & 0xFFFFu, nw = mc >> 16;
@@ -825,16 +897,79 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
   const unsigned short* to = w.torder + (size_t)tile * TILE;
   const float* g0 = grad + (size_t)tile * TILE * D;
   float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
-  const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR;
+  const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR, wv = threadIdx.x >> 6;
+  int eoff[K];   // a lane past the row's end reads element 0 instead of branching around the load
+#pragma unroll
+  for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; eoff[k] = e0 < D ? e0 : 0; }
   auto load_row = [&](unsigned lp, float (&dst)[K][V]) {
     const float* src = g0 + (size_t)lp * D;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int e0 = (lane + k * LPR) * V;
-      if (e0 < D) ldv_stream<V>(src + e0, dst[k]);
-    }
+    for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
   };
-  // narrow entries: lane group `gid` of the tile's TSPLIT * 4 * G groups
+  // ---- wide entries first (the long poles): entry k2 of the tile's wide list by block k2 % TSPLIT -----------------
+  for (unsigned k2 = part; k2 < nw; k2 += TSPLIT) {   // block-uniform
+    const unsigned ms = (unsigned)(TILE / 2 - 1) - k2;
+    const unsigned m = ml[ms];
+    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
+    constexpr int SR = NWV * G * RB;   // rows per step of the block
+    unsigned lp[RB], lq[RB];
+    auto ldpos = [&](unsigned i0, unsigned (&pp)[RB]) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) { const unsigned x = i0 + (i * NWV + wv) * G + g; pp[i] = to[st + (x < cnt ? x : 0u)]; }
+    };
+    ldpos(0, lp);
+    for (unsigned i0 = 0; i0 < cnt; i0 += SR) {
+      float val[RB][K][V];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) load_row(lp[i], val[i]);
+      ldpos(i0 + SR, lq);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const bool ok = i0 + (i * NWV + wv) * G + g < cnt;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? val[i][k][cc] : 0.f;
+        lp[i] = lq[i];
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
+    __syncthreads();   // lsum of the previous entry has been read
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) lsum[wv][(k * LPR + lane) * V + cc] = gv[k][cc];
+    }
+    __syncthreads();
+    if (wv == 0 && g == 0) {
+      float* dst = ep + (size_t)ms * D;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float o4[V];
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) {
+          float acc = lsum[0][(k * LPR + lane) * V + cc];
+#pragma unroll
+          for (int x = 1; x < NWV; ++x) acc += lsum[x][(k * LPR + lane) * V + cc];
+          o4[cc] = acc;
+        }
+        const int e0 = (lane + k * LPR) * V;
+        if (e0 < D) stv<V>(dst + e0, o4);
+      }
+    }
+  }
+  // ---- narrow entries: lane group `gid` of the tile's TSPLIT * NWV * G groups, two entries in flight per group ------
   const unsigned gid = part * (TBS / LPR) + threadIdx.x / LPR, ngr = TSPLIT * (TBS / LPR);
   for (unsigned j = gid; j < nn; j += ngr) {
     const unsigned m = ml[j];
@@ -847,22 +982,20 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
     for (unsigned i0 = 0; i0 < cnt; i0 += RB) {
       unsigned lp[RB];
       float val[RB][K][V];
+      // every load unconditional (a slot past the entry's end re-reads its first row and is masked): a branch
+      // around a load serialises the loads before it
 #pragma unroll
-      for (int i = 0; i < RB; ++i) lp[i] = i0 + i < cnt ? to[st + i0 + i] : 0xFFFFFFFFu;
+      for (int i = 0; i < RB; ++i) lp[i] = to[st + (i0 + i < cnt ? i0 + i : 0u)];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) load_row(lp[i], val[i]);
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
+        const bool ok = i0 + i < cnt;
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int cc = 0; cc < V; ++cc) val[i][k][cc] = 0.f;
-        if (lp[i] != 0xFFFFFFFFu) load_row(lp[i], val[i]);
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? val[i][k][cc] : 0.f;
       }
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int cc = 0; cc < V; ++cc) gv[k][cc] += val[i][k][cc];
     }
     float* dst = ep + (size_t)j * D;
 #pragma unroll
@@ -871,60 +1004,268 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
       if (e0 < D) stv<V>(dst + e0, gv[k]);
     }
   }
-  // wide entries: one wave each; row i of a step goes to lane group i % G, a fixed shuffle tree joins the groups
-  const unsigned wid = part * (TBS / 64) + (threadIdx.x >> 6), nwv = TSPLIT * (TBS / 64);
-  for (unsigned k2 = wid; k2 < nw; k2 += nwv) {
-    const unsigned ms = (unsigned)(TILE / 2 - 1) - k2;
-    const unsigned m = ml[ms];
-    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
-    float gv[K][V];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
-    constexpr int SR = G * RB;
-    for (unsigned i0 = 0; i0 < cnt; i0 += SR) {
-      unsigned lp[RB];
-      float val[RB][K][V];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) { const unsigned x = i0 + i * G + g; lp[i] = x < cnt ? to[st + x] : 0xFFFFFFFFu; }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int cc = 0; cc < V; ++cc) val[i][k][cc] = 0.f;
-        if (lp[i] != 0xFFFFFFFFu) load_row(lp[i], val[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int cc = 0; cc < V; ++cc) gv[k][cc] += val[i][k][cc];
-    }
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
-    if (g == 0) {
-      float* dst = ep + (size_t)ms * D;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int e0 = (lane + k * LPR) * V;
-        if (e0 < D) stv<V>(dst + e0, gv[k]);
-      }
-    }
-  }
 }
 template <int V, int LPR, int K>
 __global__ void __launch_bounds__(TBS) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, long long n) {
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the index pass gave up on this batch
   if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
   KV_STAMPT(0);
-  if (blockIdx.x < ITEM_BLOCKS) { items_body(w); KV_STAMPT(1); return; }
-  tsum_body<V, LPR, K>(w, grad, t.dim, n, blockIdx.x - ITEM_BLOCKS);
+  if (blockIdx.x < ITEM_BLOCKS) { items2_body(w); KV_STAMPT(1); return; }
+  // one resident generation of blocks strides over the (tile, part) units
+  for (unsigned b = blockIdx.x - ITEM_BLOCKS; b < w.ntiles * (unsigned)TSPLIT; b += gridDim.x - ITEM_BLOCKS)
+    tsum_body<V, LPR, K>(w, grad, t.dim, n, b);
   KV_STAMPT(1);
 }
+
+// ------------------------------------------------------------------------------------------
+// k_apply2: the fused optimizer update over the entry list
+// ------------------------------------------------------------------------------------------
+// Same work items as k_apply (kv_kernels.h) — a hot chunk per wave, a cold batch of 64 / LPR keys per wave, dealt
+// round-robin — but built for a launch in which every dependent hop costs 3-5 us:
+//   * the NEXT item's descriptor and records are requested before the current item is worked on (two-deep software
+//     pipeline), so an item pays one exposed hop: its rows;
+//   * a cold batch holds keys of one class: one source (75 % of the keys), two, or 3 .. LCOLD; the first two sources
+//     come inside the record, so only the last class walks the entry list;
+//   * every load of a batch is unconditional (a lane group without a key reads row 0) — a branch around a load makes
+//     the compiler wait for the loads before it;
+//   * a hot key's state rows are requested with its first gradient rows, not behind its last.
+template <int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
+  const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
+  const unsigned total = w.ctr[2];
+  if (errflag) return;
+  const int D = a.tv.dim;
+  constexpr int G = 64 / LPR;
+  constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
+  constexpr int RC = (2 / K) > 0 ? (2 / K) : 1;
+  const int wl = threadIdx.x & 63;
+  const int lane = wl % LPR;
+  const int g = wl / LPR;
+  // the two bases in registers (a select between a.epart and a.grad themselves becomes a per-lane LOAD of the
+  // pointer out of the argument block, with a wait behind it, in front of every row); a lane past the row's end
+  // reads element 0 instead of branching around the load
+  const float* const gbase = a.grad;
+  const float* const ebase = a.epart;
+  int eoff[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; eoff[k] = e0 < D ? e0 : 0; }
+  auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
+    const float* base = (pos & EP_TAG) ? ebase : gbase;
+    const float* src = base + (size_t)(pos & ~EP_TAG) * D;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
+  };
+  // ---- the lean update.  When the var and its hinted slot table are single-chunk tables without delta tracking
+  //      (every pre-sized training table), a key whose slot-row hint stands up is updated with nothing but the
+  //      base pointers below, all in registers; any other key of the batch takes the general finish_key ----------
+  const bool fast = (OPT != OPT_FTRL) && a.tv.single != 0u && a.ts0.single != 0u && a.use_hints != 0 &&
+                    (a.tv.track_delta | a.ts0.track_delta) == 0u;
+  float* const vrows = a.tv.c0.rows;
+  RowMeta* const vmeta = a.tv.c0.meta;
+  float* const srows = a.ts0.c0.rows;
+  RowMeta* const smeta = a.ts0.c0.meta;
+  const int SD = a.ts0.dim;
+  const unsigned smax = a.ts0.max_rows, thr = a.tv.enter_threshold;
+  const bool need_vmeta = OPT == OPT_ADAGRAD || thr != 0u;
+  constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
+  // the state of one key, every load unconditional (no key: row 0 of both tables)
+  auto prefetch_fast = [&](const uint4& rq, bool live, RowMeta& m0, uint2& vm, PreRows<V, K>& pre) {
+    const unsigned row = live ? (rq.z & ROW_MASK) : 0u;
+    const unsigned hint = (live && rq.w < smax) ? rq.w : 0u;
+    const uint4 mm = *reinterpret_cast<const uint4*>(smeta + hint);
+    m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
+    m0.freq = mm.z;
+    m0.flags = (unsigned char)(mm.w & 0xFFu);
+    vm = make_uint2(0u, 0u);
+    if (need_vmeta) vm = *reinterpret_cast<const uint2*>(&vmeta[row].freq);   // uniform
+    const float* xr = vrows + (size_t)row * D;
+    const float* sr = srows + (size_t)hint * SD;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ldv<V>(xr + eoff[k], pre.x[k]);
+#pragma unroll
+      for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eoff[k], pre.s[b3][k]);
+    }
+  };
+  const unsigned W = gridDim.x * (TBS / 64);
+  const unsigned it0 = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6);
+  // an item's records: hot chunk -> the key's two record words (every lane the same); cold batch -> the lane group's
+  // key (a group past the batch's last key reads the batch's first record and is masked later)
+  auto load_item = [&](unsigned it) -> uint4 { return w.items[it < total ? it : 0u]; };
+  auto load_rec = [&](const uint4& item, uint4& ra, uint4& rb) {
+    const bool hot = (item.x & HEAD_BIT) != 0u;
+    const uint4* list = hot ? w.hotlist : w.coldlist;
+    const unsigned u = hot ? (item.x & ~HEAD_BIT) : item.x + ((unsigned)g < item.y ? (unsigned)g : 0u);
+    ra = list[2 * (size_t)u];
+    rb = list[2 * (size_t)u + 1];
+  };
+  if (it0 >= total) return;
+  uint4 item = load_item(it0), ra, rb;
+  uint4 item_n = load_item(it0 + W);
+  load_rec(item, ra, rb);
+#ifdef KV_STAMPS
+  unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0, st_wait = 0;
+#endif
+  for (unsigned it = it0; it < total; it += W) {
+    // the pipeline: records of the next item, descriptor of the one after it
+    uint4 ra_n, rb_n;
+    load_rec(item_n, ra_n, rb_n);
+    const uint4 item_nn = load_item(it + 2 * W);
+#ifdef KV_STAMPS
+    const unsigned long long st_a = wall_clock64();
+#endif
+    const bool is_hot = (item.x & HEAD_BIT) != 0u;
+    float gv[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
+    RowMeta m0{};
+    uint2 vm = make_uint2(0u, 0u);
+    bool hint_loaded = false, have_x = false, have_s = false;
+    PreRows<V, K> pre;
+    bool fin_live = false;
+    if (is_hot) {
+      // ---- hot chunk: entries [lo, hi) of one key, G * RB of them per step ------------------------------------
+      const unsigned lo = rb.x + item.y * rb.w, hi = min(rb.x + rb.y, lo + rb.w);
+      constexpr int SR = G * RB;
+      const unsigned nst = (hi - lo + SR - 1) / SR;
+      const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
+      auto ldpos = [&](unsigned st, unsigned (&pp)[RB]) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const unsigned idx = lo + st * SR + j * G + g;
+          pp[j] = w.order[idx < hi ? idx : lo] & ~HEAD_BIT;   // unconditional: a slot past the end re-reads the first source, masked below
+        }
+      };
+      unsigned pa_[RB], pb_[RB];
+      float va[RB][K][V];
+      ldpos(0, pa_);
+      // a key with a single chunk is finished here: its state rows leave with the first gradient rows
+      if (nch == 1u) {
+        if (fast) prefetch_fast(ra, g == 0, m0, vm, pre);
+        else prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hint_loaded, pre, have_x, have_s);
+      }
+      for (unsigned st = 0; st < nst; ++st) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) load_row(pa_[j], va[j]);
+        ldpos(st + 1, pb_);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const bool ok = lo + st * SR + j * G + g < hi;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? va[j][k][cc] : 0.f;
+          pa_[j] = pb_[j];
+        }
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
+      }
+      fin_live = g == 0;
+      if (nch > 1u) {   // the key's chunks meet in k_apply_fin
+        if (g == 0) {
+          float* dst = w.hpart + (size_t)item.z * D;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int e0 = (lane + k * LPR) * V;
+            if (e0 < D) stv<V>(dst + e0, gv[k]);
+          }
+        }
+        fin_live = false;
+      }
+    } else {
+      // ---- cold batch: one key per lane group, all of one class (item.z: 1, 2 or 3 = up to LCOLD sources) -------
+      const bool live = (unsigned)g < item.y;
+      const unsigned start = rb.x, cnt = live ? rb.y : 0u;
+      const unsigned cls = item.z;
+      float g2[K][V];
+      load_row(rb.z, gv);                       // (a group without a key reads the first key's row: masked by `live`)
+      if (cls >= 2u) load_row(rb.w, g2);        // uniform over the wave
+      if (fast) {
+        prefetch_fast(ra, live, m0, vm, pre);
+      } else {
+        // the state: row 0 of each table for a group without a key (no branch around the loads)
+        uint4 rq = ra;
+        if (!live) { rq.z = 0u; rq.w = 0u; }
+        prefetch_state<OPT, V, LPR, K>(a, rq, true, lane, D, m0, hint_loaded, pre, have_x, have_s);
+      }
+      if (cls >= 2u) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) gv[k][cc] += g2[k][cc];
+      }
+      if (cls >= 3u) {
+        for (unsigned j0 = 2; j0 < cnt; j0 += RC) {
+          float val[RC][K][V];
+          unsigned pos[RC];
+#pragma unroll
+          for (int j = 0; j < RC; ++j) pos[j] = w.order[start + (j0 + j < cnt ? j0 + j : 0u)] & ~HEAD_BIT;
+#pragma unroll
+          for (int j = 0; j < RC; ++j) load_row(pos[j], val[j]);
+#pragma unroll
+          for (int j = 0; j < RC; ++j) {
+            const bool ok = j0 + j < cnt;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? val[j][k][cc] : 0.f;
+          }
+        }
+      }
+      fin_live = live;
+    }
+#ifdef KV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_b = wall_clock64();
+    if (!is_hot) st_wait += st_b - st_a;
+#endif
+    // ONE copy of the update for both kinds of item (two would double the kernel's registers)
+    bool general = fin_live;
+    if (fast) {
+      const long long key = (long long)(((unsigned long long)ra.y << 32) | ra.x);
+      const unsigned row = ra.z & ROW_MASK;
+      const unsigned hint = ra.w < smax ? ra.w : 0u;
+      // the hint stands up: the slot row carries this key and is not released (what resolve_rows checks)
+      const bool ok = fin_live && row != 0u && hint != 0u && m0.key == key && !(m0.flags & FLAG_FREE);
+      bool act = ok;
+      if (need_vmeta && ok && !(ra.z >> 31)) {   // frequency filter / un-blacklisting (resolve_rows; kv_variable.h:910)
+        if ((vm.x & 0xFFFFu) < thr) act = false;
+        else if ((vm.y & FLAG_BLACK) && lane == 0) vmeta[row].flags = FLAG_UNDER;
+      }
+      if (act && lane == 0) {   // AddFrequency(1, today) on the slot row (kv_variable.h:409-414)
+        unsigned lo = (m0.freq & 0xFFFFu) + 1u;
+        if (lo > 65535u) lo = 65535u;
+        smeta[hint].freq = (a.day << 16) | lo;
+      }
+      const unsigned rr = act ? row : 0u, hh = act ? hint : 0u;
+      opt_core<OPT, V, LPR, K>(vrows + (size_t)rr * D, srows + (size_t)hh * SD, nullptr, &vmeta[rr].flags, &smeta[hh].flags,
+                               nullptr, act, false, D, gv, a.opt, lane, pre.x, pre.s);
+      general = fin_live && !ok;
+      hint_loaded = hint != 0u; have_x = true; have_s = hint != 0u;
+    }
+    if (!fast || __ballot(general) != 0ull)
+      finish_key<MODE_APPLY, OPT, V, LPR, K>(a, ra, general, hint_loaded && general, m0, gv, lane, &pre, have_x && general, have_s && general);
+#ifdef KV_STAMPS
+    {
+      const unsigned long long now = wall_clock64();
+      if (is_hot) { st_hot += now - st_a; ++st_nh; } else { st_cold += now - st_a; ++st_nc; }
+    }
+#endif
+    item = item_n; ra = ra_n; rb = rb_n; item_n = item_nn;
+  }
+#ifdef KV_STAMPS
+  if (wl == 0) {
+    unsigned long long* d = w.dbg + (size_t)(8192 + blockIdx.x * (TBS / 64) + (threadIdx.x >> 6)) * 16;
+    d[0] = st_t0; d[1] = wall_clock64(); d[2] = st_hot; d[3] = st_cold; d[4] = st_nh; d[5] = st_nc; d[6] = total; d[7] = w.ctr[3]; d[8] = st_wait;
+  }
+#endif
+}
+template <int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply2(WsDev w, PartArgs a) { apply2_body<OPT, V, LPR, K>(w, a); }

@@ -1126,8 +1126,13 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
   const int g = wl / LPR;
   const int fop = (MODE == MODE_APPLY) ? KV_SCATTER_ADD : a.fold_op;
   const float ident = (MODE == MODE_APPLY) ? 0.f : fold_identity(fop);
+  // (both bases in registers: a select between a.epart and a.grad themselves compiles to a per-lane load of the
+  // pointer from the argument block in front of every row)
+  const float* const gbase = a.grad;
+  const float* const ebase = a.epart;
   auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
-    const float* src = (pos & EP_TAG) ? a.epart + (size_t)(pos & ~EP_TAG) * D : a.grad + (size_t)pos * D;
+    const float* base = (pos & EP_TAG) ? ebase : gbase;
+    const float* src = base + (size_t)(pos & ~EP_TAG) * D;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;

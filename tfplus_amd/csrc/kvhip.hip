@@ -448,6 +448,7 @@ TableDev dev_view(const kv_table* t) {
   d.seed = t->seed;
   d.track_delta = t->track_delta ? 1u : 0u;
   d.err_host = t->err_host;   // hipHostMallocMapped: the same address on the device
+  d.single = t->chunks.size() <= 1 ? 1u : 0u;
   return d;
 }
 
@@ -792,7 +793,7 @@ void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
 // boundaries (k_apply_span).  pa.n = ids of the batch (multi: nmax = the largest table's batch)
 template <int MODE, int OPT>
 int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long long nmax, hipStream_t s,
-                 const MultiDesc* md = nullptr, int ntab = 0, bool skip_fin = false) {
+                 const MultiDesc* md = nullptr, int ntab = 0, bool skip_fin = false, bool entry_list = false) {
   const int D = pa.tv.dim;
   // waves stride over the items (hot chunks, then cold batches of 64 / LPR keys); 8 blocks of 4 waves per CU
   // is everything the chip holds at once, fewer for small batches
@@ -803,7 +804,7 @@ int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long lon
   int rc;
   {
     ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
-    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, 0);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, entry_list ? 2 : 0);
   }
   if (rc == KV_OK && !skip_fin) {
     ProfScope ps(prof_t, KV_PROF_APPLY_SPAN, s);
@@ -920,7 +921,8 @@ int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s
     const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s);
     if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
   }
-  return launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s, nullptr, 0, wd.ntiles <= wd.hc);
+  static const bool old_apply = [] { const char* e = getenv("KV_OLD_APPLY"); return e && atoi(e) != 0; }();   // A/B: k_apply over the entry list
+  return launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s, nullptr, 0, wd.ntiles <= wd.hc, !old_apply);
 }
 
 std::atomic<uint64_t> g_serial{0};   // batch tokens

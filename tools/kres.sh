@@ -4,9 +4,17 @@
 set -e
 cd "$(dirname "$0")/../tfplus_amd/csrc"
 out=/tmp/kres_$$; mkdir -p $out
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics --offload-device-only -c -o $out/u.co "$1"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -w --offload-device-only -c -o $out/u.co "$1"
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --input=$out/u.co --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$out/u.elf --unbundle
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $out/u.elf | grep -E "^\s+\.name:|\.vgpr_count|\.sgpr_count|vgpr_spill_count|group_segment_fixed|private_segment_fixed" | paste - - - - - - \
-  | sed 's/ \+/ /g; s/\.group_segment_fixed_size/lds/; s/\.private_segment_fixed_size/scratch/; s/\.sgpr_count/sgpr/; s/\.vgpr_count/vgpr/; s/\.vgpr_spill_count/spill/' \
-  | grep -E "${2:-.}" | while read -r l; do n=$(echo "$l" | sed 's/.*\.name: \([^ \t]*\).*/\1/'); echo "$(echo "$n" | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | cut -c1-110)  $(echo "$l" | sed 's/\.name: [^ \t]*//')"; done
+  | python3 -c '
+import re, subprocess, sys
+pat = sys.argv[1] if len(sys.argv) > 1 else "."
+for l in sys.stdin:
+  f = dict(re.findall(r"\.(\w+):\s+(\S+)", l))
+  name = subprocess.run(["c++filt", f["name"]], capture_output=True, text=True).stdout.strip()
+  name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+  if re.search(pat, name):
+    print("%-64s vgpr %3s sgpr %3s lds %6s scratch %s spill %s" % (name[:64], f["vgpr_count"], f["sgpr_count"], f["group_segment_fixed_size"], f["private_segment_fixed_size"], f["vgpr_spill_count"]))
+' "${2:-.}"
 rm -rf $out

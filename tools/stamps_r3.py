@@ -67,3 +67,5 @@ if len(t):
   h = t[:, 4] > 0; c = t[:, 5] > 0
   print("  hot items per wave ", med(t[h, 4]), " time per hot item ", med(t[h, 2] / t[h, 4]))
   print("  cold items per wave", med(t[c, 5]), " time per cold item", med(t[c, 3] / t[c, 5]))
+  if t[:, 8].max() > 0:
+    print("  cold item: start -> rows arrived", med(t[c, 8] / t[c, 5]), " (rest = the update)")
