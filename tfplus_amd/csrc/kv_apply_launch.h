@@ -83,24 +83,11 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
 }
 
 // k_tsum (kv_fused.h): the tile sums in front of the entry-list apply; same row geometry as k_apply.
-// grid = ITEM_BLOCKS + ntiles * TSPLIT.  Instantiated once (kv_apply_b.hip).
+// grid = ITEM_BLOCKS + ntiles blocks of TBC threads.  Instantiated once (kv_apply_b.hip).
 inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s) {
   const int D = td.dim;
-  const unsigned units = wd.ntiles * (unsigned)TSPLIT;
-#define KV_TSUM(V, LPR, K)                                                                            \
-  do {                                                                                                \
-    static const unsigned resident = [] {                                                             \
-      int nb = 0, cus = 0, dev = 0;                                                                   \
-      hipGetDevice(&dev);                                                                             \
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                        \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tsum<V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
-      if (nb > 8) nb = 8;                                                                             \
-      return (unsigned)(nb * (cus > 0 ? cus : 256));                                                  \
-    }();                                                                                              \
-    const unsigned grid = (unsigned)ITEM_BLOCKS + (units < resident - ITEM_BLOCKS ? units : resident - ITEM_BLOCKS); \
-    k_tsum<V, LPR, K><<<grid, TBS, 0, s>>>(td, wd, grad, n);                                          \
-    return KV_OK;                                                                                     \
-  } while (0)
+  const unsigned grid = (unsigned)ITEM_BLOCKS + wd.ntiles;
+#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, n); return KV_OK; } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const int q = D / 4;
   if (q <= 1) KV_TSUM(4, 1, 1);

@@ -25,7 +25,6 @@ constexpr int HC = 128;     // rows per hot chunk
 constexpr unsigned EP_TAG = 0x40000000u;    // entry list: the source is row (word & ~EP_TAG) of epart, not an input position
 constexpr unsigned NEW_BIT = 0x80000000u;   // ent_b row word: the key was inserted by this batch (row part 0: by another tile, row not seen yet)
 constexpr unsigned HINT_NEW = 0xFFFFFFFFu;  // Entry::hint of a key inserted by the batch in flight (the partition pass resets it)
-constexpr int WIDE = 32;    // an entry with more occurrences in its tile is summed by a whole wave (k_tsum), else by one lane group
 constexpr int HC2 = 512;    // entries per hot chunk of the entry-list apply: a key has at most one entry per tile, so up to
                             // 1 M ids no key spans chunks and k_apply_fin is not launched
 
@@ -124,10 +123,10 @@ struct WsDev {
   unsigned long long* dbg; // diagnostic build only (-DKV_STAMPS): per-block phase stamps
   // ---- the entry-list pipeline (kv_fused.h).  It reuses ent_b (row word), ent_base (slot-row hint), ent_rec (the
   //      entry's source: its input position, or EP_TAG | epart row), order (the entry list) and:
-  unsigned short* torder;  // [n] tile-local input positions sorted by entry (in slot_rank's storage)
-  unsigned* mlist;         // [ntiles][TILE / 2] the tile's entries with more than one occurrence: first position in torder
-                           // (low 16) | occurrences (high 16); up to WIDE occurrences from the front, more from the back
-  unsigned* mcount;        // [ntiles] narrow (low 16) | wide (high 16) entries in mlist
+  unsigned* mrow;          // [n] per tile, the rows of its entries with more than one occurrence, entry by entry and in
+                           // rank order: tile-local position (bits 0..10) | the entry's epart row in the tile (bits 11..20)
+                           // | bit 31: first row of its entry  (in slot_rank's storage)
+  unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
   unsigned hc;             // entries per hot chunk
 };

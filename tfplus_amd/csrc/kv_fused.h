@@ -86,9 +86,9 @@ __device__ __forceinline__ unsigned tile_insert(const TableDev& t, long long key
 // ------------------------------------------------------------------------------------------
 struct LtSmem {
   long long* lkeys;        // [LS + 1] (slot LS: the key that equals EMPTY_KEY); dead once the probes have left:
-  unsigned* lrow;          //   [LS + 1] row word of the slot's key           \.
-  unsigned short* tord;    //   [TILE]   tile-local positions sorted by entry  > live in lkeys' storage
+  unsigned* lrow;          //   [LS + 1] row word of the slot's key           \  live in lkeys' storage
   unsigned* escan;         //   [TILE + 1] per entry: packed prefix (below)   /
+  unsigned* mr;            // [TILE] the tile's mrow image; in lfirst's storage once the sources are written
   unsigned* lcnt;          // [LS + 1] occurrences of the slot's key
   unsigned short* lpos;    // [LS + 1] entry number of the slot's key
   unsigned short* lfirst;  // [LS + 1] tile-local position of one occurrence
@@ -96,7 +96,7 @@ struct LtSmem {
   unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); then the entries' frequency sums
   unsigned* wtot;          // [8]
 };
-static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)TILE * 2 + 16 + (size_t)(TILE + 1) * 4, "aliases fit");
+static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)(TILE + 1) * 4 && (size_t)(LS + 1) * 2 >= (size_t)TILE * 4, "aliases fit");
 
 __host__ __device__ inline size_t ltile_smem_bytes() {
   size_t b = (size_t)(LS + 1) * 8 + 16;   // lkeys
@@ -114,20 +114,20 @@ __device__ __forceinline__ LtSmem carve_ltile(char* base) {
   char* k0 = take((size_t)(LS + 1) * 8);
   s.lkeys = reinterpret_cast<long long*>(k0);
   s.lrow = reinterpret_cast<unsigned*>(k0);
-  s.tord = reinterpret_cast<unsigned short*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
-  s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15) + (size_t)TILE * 2);
+  s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
   s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
   s.lfirst = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.mr = reinterpret_cast<unsigned*>(s.lfirst);
   s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
   s.wtot = reinterpret_cast<unsigned*>(take(64));
   return s;
 }
 
-// packed per-entry scan word: positions (bits 0..11, sum <= 2048) | narrow multi-occurrence entries (bits 12..22) |
-// wide ones (bits 23..29)
-constexpr unsigned ES_POS = 0xFFFu, ES_NSH = 12, ES_NMASK = 0x7FFu, ES_WSH = 23;
+// packed per-entry scan word, over the entries with more than one occurrence: their rows (bits 0..11, sum <= 2048) |
+// their number (bits 12..22)
+constexpr unsigned ES_POS = 0xFFFu, ES_NSH = 12;
 
 // VQ = float4 per row (power of two <= 64); GATHER: copy the rows of the tile's positions to `out`.
 // insert_ok == 0: a key absent from the table stays absent (row word 0: the zero row) — nothing here needs it yet.
@@ -276,6 +276,31 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       if (!has_counts) w.ent_a[e] = wcnt[q] | (wcnt[q] << 16);   // <= TILE: the frequency count equals the occurrences
     }
   }
+  if (det) {
+    // deterministic mode: the order of a partition's entries inside the tile was the arrival order of LDS atomics;
+    // it becomes the order of their keys (k_tsum's additions follow the entries' places in the tile's row list)
+    __syncthreads();   // the tile's ent_key is written
+    unsigned npos[WPT];
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+      npos[q] = 0xFFFFFFFFu;
+      if (wpos[q] == 0xFFFFFFFFu) continue;
+      const unsigned p0 = sm.hist[wp[q]] & 0xFFFFu, p1 = sm.hist[wp[q] + 1u] & 0xFFFFu;
+      unsigned less = 0;
+      for (unsigned j = p0; j < p1; ++j) less += w.ent_key[(size_t)tile * TILE + j] < wkey[q] ? 1u : 0u;
+      npos[q] = p0 + less;
+    }
+    __syncthreads();   // ... and read by everyone
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+      if (npos[q] == 0xFFFFFFFFu) continue;
+      const size_t e = (size_t)tile * TILE + npos[q];
+      wpos[q] = npos[q];
+      sm.lpos[wslot[q]] = (unsigned short)npos[q];
+      w.ent_key[e] = wkey[q];
+      if (!has_counts) w.ent_a[e] = wcnt[q] | (wcnt[q] << 16);
+    }
+  }
   KV_STAMP(2);
 
   // ---- the probes come back: row word + slot-row hint of every distinct key; absent keys are inserted ---------
@@ -290,13 +315,13 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     sm.lrow[wslot[q]] = r;
     w.ent_b[e] = r;
     w.ent_base[e] = hint;
-    // per entry for the scan below: positions | one narrow / one wide multi-occurrence entry
-    sm.escan[wpos[q]] = wcnt[q] | (wcnt[q] > 1u ? (wcnt[q] <= (unsigned)WIDE ? 1u << ES_NSH : 1u << ES_WSH) : 0u);
+    // per entry for the scan below: its rows | 1, if it has more than one
+    sm.escan[wpos[q]] = wcnt[q] > 1u ? (wcnt[q] | (1u << ES_NSH)) : 0u;
   }
   __syncthreads();
   KV_STAMP(3);
 
-  // ---- phase 4: where every entry's positions start in the tile (torder), numbers of the multi-occurrence entries --
+  // ---- phase 4: the multi-occurrence entries: where their rows start in the tile's mrow image, their numbers ----------
   {
     constexpr unsigned PER = (TILE + 1 + TBT - 1) / TBT;
     const unsigned e0 = tid * PER, e1 = min(e0 + PER, nwork);
@@ -305,7 +330,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     unsigned tot;
     unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
     for (unsigned e = e0; e < e1; ++e) { const unsigned c = sm.escan[e]; sm.escan[e] = run; run += c; }
-    if (tid == 0) w.mcount[tile] = ((tot >> ES_NSH) & ES_NMASK) | ((tot >> ES_WSH) << 16);
+    if (tid == 0) w.mcount[tile] = (tot & ES_POS) | ((tot >> ES_NSH) << 16);
   }
   __syncthreads();
 #pragma unroll
@@ -315,9 +340,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     const size_t e = (size_t)tile * TILE + wpos[q];
     unsigned src;
     if (wcnt[q] > 1u) {
-      const unsigned ms = wcnt[q] <= (unsigned)WIDE ? ((pre >> ES_NSH) & ES_NMASK) : (unsigned)(TILE / 2 - 1) - (pre >> ES_WSH);
-      w.mlist[(size_t)tile * (TILE / 2) + ms] = (pre & ES_POS) | (wcnt[q] << 16);
-      src = EP_TAG | (tile * (unsigned)(TILE / 2) + ms);
+      src = EP_TAG | (tile * (unsigned)(TILE / 2) + (pre >> ES_NSH));   // its sum: row (pre >> ES_NSH) of the tile's epart rows
     } else {
       src = (unsigned)base + sm.lfirst[wslot[q]];
     }
@@ -353,9 +376,13 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       myrank[k] = valid ? before + rw : 0u;
     }
   }
+  if (!det) __syncthreads();   // every source is written: lfirst's storage becomes the mrow image
 #pragma unroll
-  for (int k = 0; k < IPT; ++k)
-    if (tslot[k] != 0xFFFFFFFFu) sm.tord[(sm.escan[sm.lpos[tslot[k]]] & ES_POS) + myrank[k]] = (unsigned short)(k * TBT + tid);
+  for (int k = 0; k < IPT; ++k) {
+    if (tslot[k] == 0xFFFFFFFFu || sm.lcnt[tslot[k]] <= 1u) continue;
+    const unsigned pre = sm.escan[sm.lpos[tslot[k]]];
+    sm.mr[(pre & ES_POS) + myrank[k]] = (unsigned)(k * TBT + tid) | ((pre >> ES_NSH) << 11) | (myrank[k] == 0u ? 0x80000000u : 0u);
+  }
   // ---- per-occurrence counts: frequency sum per entry (hist is dead: reused) ----------------------------------
   if (has_counts) {
     __syncthreads();
@@ -374,10 +401,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   __syncthreads();
   {
-    // torder of the tile, two positions per 4-byte store
-    unsigned* dst = reinterpret_cast<unsigned*>(w.torder + (size_t)tile * TILE);
-    const unsigned* srcw = reinterpret_cast<const unsigned*>(sm.tord);
-    for (int j = tid; j < TILE / 2; j += TBT) dst[j] = srcw[j];
+    unsigned* dst = w.mrow + (size_t)tile * TILE;
+    for (int j = tid; j < TILE; j += TBT) dst[j] = sm.mr[j];
   }
   KV_STAMP(4);
 
@@ -838,18 +863,19 @@ __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_b
 // other (a random mix left some waves with four, and the kernel ended when they did).  pmeta[q] = {items, hot
 // chunks, first entry, entries}: the chunk items of partition q are litem[first + j], its cold batches
 // litem[first + entries - 1 - j].
+template <int NW>
 __device__ __forceinline__ void items2_body(const WsDev& w) {
   __shared__ unsigned sit[MAX_P + 1], sck[MAX_P + 1];
   __shared__ unsigned wt[8];
   const unsigned P = w.P;
-  const int tid = threadIdx.x, T = blockDim.x;   // 256 threads
+  const int tid = threadIdx.x, T = NW * 64;
   const unsigned per = (P + T - 1) / T;
   const unsigned p0 = min(P, tid * per), p1 = min(P, p0 + per);
   unsigned si = 0, sc = 0;
   for (unsigned q = p0; q < p1; ++q) { const uint4 m = w.pmeta[q]; sit[q] = m.x - m.y; sck[q] = m.y; si += m.x - m.y; sc += m.y; }
   unsigned ti, tc;
-  unsigned ri = block_excl_scan<TB / 64>(si, wt, &ti);   // ti: cold batches of the batch
-  unsigned rc = block_excl_scan<TB / 64>(sc, wt, &tc);   // tc: hot chunks
+  unsigned ri = block_excl_scan<NW>(si, wt, &ti);   // ti: cold batches of the batch
+  unsigned rc = block_excl_scan<NW>(sc, wt, &tc);   // tc: hot chunks
   for (unsigned q = p0; q < p1; ++q) { const unsigned a_ = sit[q], b_ = sck[q]; sit[q] = ri; sck[q] = rc; ri += a_; rc += b_; }
   __syncthreads();
   if (blockIdx.x == 0 && tid == 0) { w.ctr[2] = ti + tc; w.ctr[3] = tc; }
@@ -877,143 +903,240 @@ __device__ __forceinline__ void items2_body(const WsDev& w) {
 // ------------------------------------------------------------------------------------------
 // k_tsum: per tile, the gradient sums of the entries that have more than one occurrence
 // ------------------------------------------------------------------------------------------
-// TSPLIT blocks of 256 threads share a tile.  Narrow entries (2 .. WIDE rows) go one to a lane group.  A wide entry
-// is summed by a whole BLOCK: row x of the entry goes to wave x / 64 % 4, lane group x % G, the waves' sums meet in
-// LDS in wave order (the hottest key of a Zipf(1.2) batch owns 370 rows of every tile: six dependent steps for one
-// wave, two for a block).  The positions of the next step are requested with the rows of this one.
-// ITEM_BLOCKS blocks in front build the dense work-item directory of the partitions (the partition pass is
-// complete when this kernel starts).
-constexpr int TSPLIT = 4;
+// One block of TBC threads per tile.  The tile kernel left the rows of those entries in entry order (mrow: position,
+// epart row of the entry, head flag), so the sums are a SEGMENTED REDUCTION over one list: wave w takes a contiguous
+// share of the rows, RS = G * RB rows per step (lane group g the RB consecutive rows g * RB ..), every wave the same
+// number whatever the skew — the hottest key's 370 rows of a tile are six waves' work, not one wave's.
+//   inside a group  rows are added in order; a run between two heads inside the group is complete: stored
+//   across groups   a segmented scan over the groups' open runs (shuffles), the wave's open run carried from step to
+//                   step in registers
+//   across waves    a wave's first run (it began in an earlier wave) and its last (it may go on) meet in LDS, wave
+//                   by wave in order
+// The order of the additions depends on nothing but the list.  The positions of the next step are requested with
+// the rows of this one.  ITEM_BLOCKS blocks in front build the dense work-item directory (items2_body).
+constexpr int TBC = 512;
 template <int V, int LPR, int K>
-__device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, long long n, unsigned b) {
+__device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, unsigned tile) {
   constexpr int G = 64 / LPR;
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
-  constexpr int NWV = TBS / 64;
-  __shared__ float lsum[NWV][K * V * LPR];
-  const unsigned tile = b / TSPLIT, part = b % TSPLIT;
+  constexpr int RS = G * RB;            // rows per wave and step
+  constexpr int NWC = TBC / 64;
+  constexpr int RF = K * V * LPR;       // floats of a row image in LDS
+  __shared__ float lfs[2][NWC][RF];     // [0]: a wave's rows before its first head; [1]: its last run
+  __shared__ unsigned lmeta[NWC][2];    // {1 = the wave saw a head, epart row of its last run}
   const unsigned mc = w.mcount[tile];
-  const unsigned nn = mc & 0xFFFFu, nw = mc >> 16;
-  const unsigned* ml = w.mlist + (size_t)tile * (TILE / 2);
-  const unsigned short* to = w.torder + (size_t)tile * TILE;
+  const unsigned nm = mc & 0xFFFFu;
+  if (nm == 0u) return;   // block-uniform
+  const unsigned* mrow = w.mrow + (size_t)tile * TILE;
   const float* g0 = grad + (size_t)tile * TILE * D;
   float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
   const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR, wv = threadIdx.x >> 6;
   int eoff[K];   // a lane past the row's end reads element 0 instead of branching around the load
+  bool evalid[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; eoff[k] = e0 < D ? e0 : 0; }
-  auto load_row = [&](unsigned lp, float (&dst)[K][V]) {
-    const float* src = g0 + (size_t)lp * D;
+  for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; evalid[k] = e0 < D; eoff[k] = evalid[k] ? e0 : 0; }
+  auto store_row = [&](unsigned slot, const float (&v)[K][V]) {
+    float* dst = ep + (size_t)slot * D;
 #pragma unroll
-    for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
+    for (int k = 0; k < K; ++k)
+      if (evalid[k]) stv<V>(dst + eoff[k], v[k]);
   };
-  // ---- wide entries first (the long poles): entry k2 of the tile's wide list by block k2 % TSPLIT -----------------
-  for (unsigned k2 = part; k2 < nw; k2 += TSPLIT) {   // block-uniform
-    const unsigned ms = (unsigned)(TILE / 2 - 1) - k2;
-    const unsigned m = ml[ms];
-    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
-    float gv[K][V];
+  // the wave's share: whole steps, the same number for every wave
+  const unsigned steps = (nm + (unsigned)(NWC * RS) - 1u) / (unsigned)(NWC * RS);
+  const unsigned r0 = (unsigned)wv * steps * RS, r1 = min(nm, r0 + steps * RS);
+  float carry[K][V];          // the wave's open run so far
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int cc = 0; cc < V; ++cc) carry[k][cc] = 0.f;
+  bool seen = false;          // a head was met in this wave: `carry` began here
+  unsigned last_slot = 0;     // epart row of the last row taken so far
+  unsigned mw[RB], mn[RB];
+  auto ldm = [&](unsigned rbase, unsigned (&m)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) { const unsigned r = rbase + g * RB + i; m[i] = mrow[r < r1 ? r : (r0 < nm ? r0 : 0u)]; }
+  };
+  if (r0 < r1) ldm(r0, mw);
+  for (unsigned rb = r0; rb < r1; rb += RS) {   // wave-uniform
+    float val[RB][K][V];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const float* src = g0 + (size_t)(mw[i] & 0x7FFu) * D;
+#pragma unroll
+      for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], val[i][k]);
+    }
+    ldm(rb + RS, mn);
+    // ---- inside the group: runs in row order ----
+    float acc[K][V], pfx[K][V];
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
-    constexpr int SR = NWV * G * RB;   // rows per step of the block
-    unsigned lp[RB], lq[RB];
-    auto ldpos = [&](unsigned i0, unsigned (&pp)[RB]) {
+      for (int cc = 0; cc < V; ++cc) { acc[k][cc] = 0.f; pfx[k][cc] = 0.f; }
+    bool has_head = false;
+    unsigned cur_slot = 0, first_slot = 0;   // first_slot: epart row of the group's first row
 #pragma unroll
-      for (int i = 0; i < RB; ++i) { const unsigned x = i0 + (i * NWV + wv) * G + g; pp[i] = to[st + (x < cnt ? x : 0u)]; }
-    };
-    ldpos(0, lp);
-    for (unsigned i0 = 0; i0 < cnt; i0 += SR) {
-      float val[RB][K][V];
+    for (int i = 0; i < RB; ++i) {
+      const bool ok = rb + g * RB + i < r1;
+      const bool head = ok && (mw[i] >> 31) != 0u;
+      const unsigned slot = (mw[i] >> 11) & 0x3FFu;
+      if (i == 0) first_slot = slot;
+      if (head) {
+        if (!has_head) {
 #pragma unroll
-      for (int i = 0; i < RB; ++i) load_row(lp[i], val[i]);
-      ldpos(i0 + SR, lq);
+          for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const bool ok = i0 + (i * NWV + wv) * G + g < cnt;
+            for (int cc = 0; cc < V; ++cc) pfx[k][cc] = acc[k][cc];
+          has_head = true;
+        } else {
+          store_row(cur_slot, acc);   // a run that begins and ends inside the group
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? val[i][k][cc] : 0.f;
-        lp[i] = lq[i];
+          for (int cc = 0; cc < V; ++cc) acc[k][cc] = 0.f;
       }
-    }
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1)
+      if (ok) cur_slot = slot;
 #pragma unroll
       for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
-    __syncthreads();   // lsum of the previous entry has been read
-    if (g == 0) {
+        for (int cc = 0; cc < V; ++cc) acc[k][cc] += ok ? val[i][k][cc] : 0.f;
+    }
+    // the group's contribution to the run that is open at its end: its suffix, or all of it when it has no head
+    // (then pfx is not set: the whole group is acc)
+    // ---- across the groups: inclusive segmented scan of (acc, has_head) ----
+    float sc[K][V];
+    bool sf = has_head;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) sc[k][cc] = acc[k][cc];
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      const bool of = __shfl_up((int)sf, o) != 0;
+      const bool take = wl >= o && !sf;
 #pragma unroll
       for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int cc = 0; cc < V; ++cc) lsum[wv][(k * LPR + lane) * V + cc] = gv[k][cc];
-    }
-    __syncthreads();
-    if (wv == 0 && g == 0) {
-      float* dst = ep + (size_t)ms * D;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        float o4[V];
 #pragma unroll
         for (int cc = 0; cc < V; ++cc) {
-          float acc = lsum[0][(k * LPR + lane) * V + cc];
-#pragma unroll
-          for (int x = 1; x < NWV; ++x) acc += lsum[x][(k * LPR + lane) * V + cc];
-          o4[cc] = acc;
+          const float x = __shfl_up(sc[k][cc], o);
+          if (take) sc[k][cc] += x;
         }
-        const int e0 = (lane + k * LPR) * V;
-        if (e0 < D) stv<V>(dst + e0, o4);
-      }
+      if (wl >= o) sf = sf || of;
     }
-  }
-  // ---- narrow entries: lane group `gid` of the tile's TSPLIT * NWV * G groups, two entries in flight per group ------
-  const unsigned gid = part * (TBS / LPR) + threadIdx.x / LPR, ngr = TSPLIT * (TBS / LPR);
-  for (unsigned j = gid; j < nn; j += ngr) {
-    const unsigned m = ml[j];
-    const unsigned st = m & 0xFFFFu, cnt = m >> 16;
-    float gv[K][V];
+    // what arrives at the group's first row: the scan of the groups before it, plus the wave's carry if none of
+    // them had a head
+    bool pf = false;            // a head in an earlier group of this step
+    float arr[K][V];
+    {
+      const bool pf_ = __shfl_up((int)sf, LPR) != 0;
+      pf = g > 0 && pf_;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+      for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
-    for (unsigned i0 = 0; i0 < cnt; i0 += RB) {
-      unsigned lp[RB];
-      float val[RB][K][V];
-      // every load unconditional (a slot past the entry's end re-reads its first row and is masked): a branch
-      // around a load serialises the loads before it
+        for (int cc = 0; cc < V; ++cc) {
+          const float x = __shfl_up(sc[k][cc], LPR);
+          arr[k][cc] = (g > 0 ? x : 0.f) + (pf ? 0.f : carry[k][cc]);
+        }
+    }
+    const unsigned prev_slot_ = __shfl_up(cur_slot, LPR);
+    const unsigned arr_slot = g > 0 ? prev_slot_ : last_slot;   // epart row of the run that arrives
+    const bool arr_here = pf || seen;                           // it began in this wave
+    if (has_head) {
+      // the arriving run ends at this group's first head: arriving sum + the group's rows before that head
+      float tot[K][V];
 #pragma unroll
-      for (int i = 0; i < RB; ++i) lp[i] = to[st + (i0 + i < cnt ? i0 + i : 0u)];
+      for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int i = 0; i < RB; ++i) load_row(lp[i], val[i]);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const bool ok = i0 + i < cnt;
+        for (int cc = 0; cc < V; ++cc) tot[k][cc] = arr[k][cc] + pfx[k][cc];
+      const bool has_pfx = (mw[0] >> 31) == 0u;   // the group's first row continues the arriving run
+      const unsigned slot = has_pfx ? first_slot : arr_slot;
+      if (arr_here) {
+        if (has_pfx || g > 0 || rb > r0 || true) store_row(slot, tot);
+      } else {
+        // the wave's first run: it began in an earlier wave (or this is the tile's very first row: nothing arrives)
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? val[i][k][cc] : 0.f;
+          for (int cc = 0; cc < V; ++cc) lfs[0][wv][(k * LPR + lane) * V + cc] = tot[k][cc];
       }
     }
-    float* dst = ep + (size_t)j * D;
+    // ---- the wave's carry for the next step: the scan at the last group ----
+    {
+      const int lastl = (G - 1) * LPR + lane;
+      const bool any = __shfl((int)sf, lastl) != 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int e0 = (lane + k * LPR) * V;
-      if (e0 < D) stv<V>(dst + e0, gv[k]);
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) {
+          const float x = __shfl(sc[k][cc], lastl);
+          carry[k][cc] = any ? x : carry[k][cc] + x;
+        }
+      seen = seen || any;
+      // epart row of the last row taken: the last group that had a row in range
+      const unsigned ls = __shfl(cur_slot, lastl);
+      const unsigned nrows = min((unsigned)RS, r1 - rb);
+      const int lg = (int)((nrows - 1u) / RB);
+      last_slot = __shfl(cur_slot, lg * LPR + lane);
+      (void)ls;
     }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) mw[i] = mn[i];
+  }
+  // ---- the wave's ends meet in LDS ----
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) {
+        if (!seen) lfs[0][wv][(k * LPR + lane) * V + cc] = carry[k][cc];   // no head at all: everything continues the arriving run
+        lfs[1][wv][(k * LPR + lane) * V + cc] = carry[k][cc];
+      }
+    if (lane == 0) { lmeta[wv][0] = (r0 < r1 ? 2u : 0u) | (seen ? 1u : 0u); lmeta[wv][1] = last_slot; }
+  }
+  __syncthreads();
+  if (wv == 0 && g == 0) {
+    float run[K][V];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int cc = 0; cc < V; ++cc) run[k][cc] = 0.f;
+    unsigned rslot = 0;
+    bool active = false;
+    for (int x = 0; x < NWC; ++x) {
+      const unsigned mt = lmeta[x][0];
+      if (!(mt & 2u)) break;            // waves past the list's end
+      if (mt & 1u) {
+        // wave x met a head: the run that arrived ends there
+        if (active) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) run[k][cc] += lfs[0][x][(k * LPR + lane) * V + cc];
+          store_row(rslot, run);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) run[k][cc] = lfs[1][x][(k * LPR + lane) * V + cc];
+        rslot = lmeta[x][1];
+        active = true;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int cc = 0; cc < V; ++cc) run[k][cc] += lfs[0][x][(k * LPR + lane) * V + cc];
+      }
+    }
+    if (active) store_row(rslot, run);
   }
 }
 template <int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, long long n) {
+__global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, long long n) {
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the index pass gave up on this batch
   if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
   KV_STAMPT(0);
-  if (blockIdx.x < ITEM_BLOCKS) { items2_body(w); KV_STAMPT(1); return; }
-  // one resident generation of blocks strides over the (tile, part) units
-  for (unsigned b = blockIdx.x - ITEM_BLOCKS; b < w.ntiles * (unsigned)TSPLIT; b += gridDim.x - ITEM_BLOCKS)
-    tsum_body<V, LPR, K>(w, grad, t.dim, n, b);
+  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(w); KV_STAMPT(1); return; }
+  tsum_body<V, LPR, K>(w, grad, t.dim, blockIdx.x - ITEM_BLOCKS);
   KV_STAMPT(1);
 }
 

@@ -637,9 +637,8 @@ WsDev ws_view(kv_table* t, long long n) {
   d.row_map = nullptr;
   d.zero_counts = nullptr;
   d.dbg = w.dbg;
-  // entry-list pipeline: torder and mlist share slot_rank's storage (2 B per position + 4 B per two positions)
-  d.torder = reinterpret_cast<unsigned short*>(w.slot_rank);
-  d.mlist = w.slot_rank + w.cap_n / 2;
+  // entry-list pipeline: mrow lives in slot_rank's storage
+  d.mrow = w.slot_rank;
   d.mcount = w.mcount;
   d.epart = w.epart;
   d.hc = (unsigned)HC;
