@@ -34,11 +34,11 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
           int nb = 0, cus = 0, dev = 0;                                                            \
           hipGetDevice(&dev);                                                                      \
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                 \
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply2<OPT, V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
-          if (nb > 6) nb = 6;                                                                      \
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply2<OPT, V, LPR, K>, TBA, 0) != hipSuccess || nb < 1) nb = 1; \
+          if (nb > 2) nb = 2;                                                                      \
           return nb * (cus > 0 ? cus : 256);                                                       \
         }();                                                                                       \
-        grid_ = (int)nchunks > resident2 ? resident2 : (int)nchunks;                               \
+        grid_ = (int)(nchunks / 4 + 1) > resident2 ? resident2 : (int)(nchunks / 4 + 1);   /* 16 waves per block */ \
       }                                                                                            \
     }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
@@ -50,7 +50,7 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
     }                                                                                              \
     if (md) return KV_UNIMPLEMENTED;                                                               \
     if constexpr (MODE == MODE_APPLY) {   /* span 2: the entry-list apply (kv_fused.h), same grid rule as k_apply */ \
-      if (span == 2) { k_apply2<OPT, V, LPR, K><<<grid_, TBS, 0, s>>>(wd, pa); return KV_OK; }        \
+      if (span == 2) { k_apply2<OPT, V, LPR, K><<<grid_, TBA, 0, s>>>(wd, pa); return KV_OK; }        \
     }                                                                                              \
     if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid_, TBF, sh, s>>>(wd, pa);                     \
     else k_apply<MODE, OPT, V, LPR, K><<<grid_, TBS, sh, s>>>(wd, pa);                        \

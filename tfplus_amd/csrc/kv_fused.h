@@ -1152,6 +1152,7 @@ __global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* 
 //   * every load of a batch is unconditional (a lane group without a key reads row 0) — a branch around a load makes
 //     the compiler wait for the loads before it;
 //   * a hot key's state rows are requested with its first gradient rows, not behind its last.
+constexpr int TBA = 1024;   // 16 waves share a block's items
 template <int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
   const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);
@@ -1210,11 +1211,24 @@ __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
       for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eoff[k], pre.s[b3][k]);
     }
   };
-  const unsigned W = gridDim.x * (TBS / 64);
-  const unsigned it0 = blockIdx.x * (TBS / 64) + (threadIdx.x >> 6);
+  // Block b owns items b, b + NB, b + 2 NB, ... (the directory lists every hot chunk before any cold batch, so
+  // each block's list starts with its hot chunks); its waves take them through a ticket in LDS: a wave that drew a
+  // long item simply takes fewer.  One item is held ahead (descriptor and records), no more: what a wave holds
+  // nobody else can take.
+  __shared__ unsigned lnext;
+  if (threadIdx.x == 0) lnext = 0;
+  __syncthreads();
+  const unsigned NB = gridDim.x;
+  const unsigned nmine = total > blockIdx.x ? (total - blockIdx.x + NB - 1u) / NB : 0u;
+  auto pull = [&]() -> unsigned {
+    unsigned j = 0;
+    if (wl == 0) j = atomicAdd(&lnext, 1u);
+    j = (unsigned)__shfl((int)j, 0);
+    return j < nmine ? blockIdx.x + j * NB : 0xFFFFFFFFu;
+  };
   // an item's records: hot chunk -> the key's two record words (every lane the same); cold batch -> the lane group's
   // key (a group past the batch's last key reads the batch's first record and is masked later)
-  auto load_item = [&](unsigned it) -> uint4 { return w.items[it < total ? it : 0u]; };
+  auto load_item = [&](unsigned it) -> uint4 { return w.items[it != 0xFFFFFFFFu ? it : 0u]; };
   auto load_rec = [&](const uint4& item, uint4& ra, uint4& rb) {
     const bool hot = (item.x & HEAD_BIT) != 0u;
     const uint4* list = hot ? w.hotlist : w.coldlist;
@@ -1222,18 +1236,18 @@ __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
     ra = list[2 * (size_t)u];
     rb = list[2 * (size_t)u + 1];
   };
-  if (it0 >= total) return;
-  uint4 item = load_item(it0), ra, rb;
-  uint4 item_n = load_item(it0 + W);
+  unsigned cur = pull();
+  if (cur == 0xFFFFFFFFu) return;
+  uint4 item = load_item(cur), ra, rb;
   load_rec(item, ra, rb);
 #ifdef KV_STAMPS
   unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0, st_wait = 0;
 #endif
-  for (unsigned it = it0; it < total; it += W) {
-    // the pipeline: records of the next item, descriptor of the one after it
+  while (cur != 0xFFFFFFFFu) {
+    // the next item: its descriptor leaves now, its records once this item's rows are on their way
+    const unsigned nxt = pull();
+    const uint4 item_n = load_item(nxt);
     uint4 ra_n, rb_n;
-    load_rec(item_n, ra_n, rb_n);
-    const uint4 item_nn = load_item(it + 2 * W);
 #ifdef KV_STAMPS
     const unsigned long long st_a = wall_clock64();
 #endif
@@ -1344,8 +1358,9 @@ __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
       }
       fin_live = live;
     }
+    load_rec(item_n, ra_n, rb_n);
 #ifdef KV_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     const unsigned long long st_b = wall_clock64();
     if (!is_hot) st_wait += st_b - st_a;
 #endif
@@ -1381,14 +1396,14 @@ __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
       if (is_hot) { st_hot += now - st_a; ++st_nh; } else { st_cold += now - st_a; ++st_nc; }
     }
 #endif
-    item = item_n; ra = ra_n; rb = rb_n; item_n = item_nn;
+    item = item_n; ra = ra_n; rb = rb_n; cur = nxt;
   }
 #ifdef KV_STAMPS
   if (wl == 0) {
-    unsigned long long* d = w.dbg + (size_t)(8192 + blockIdx.x * (TBS / 64) + (threadIdx.x >> 6)) * 16;
+    unsigned long long* d = w.dbg + (size_t)(8192 + blockIdx.x * (TBA / 64) + (threadIdx.x >> 6)) * 16;
     d[0] = st_t0; d[1] = wall_clock64(); d[2] = st_hot; d[3] = st_cold; d[4] = st_nh; d[5] = st_nc; d[6] = total; d[7] = w.ctr[3]; d[8] = st_wait;
   }
 #endif
 }
 template <int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBS, (K == 1 ? 4 : 1)) k_apply2(WsDev w, PartArgs a) { apply2_body<OPT, V, LPR, K>(w, a); }
+__global__ void __launch_bounds__(TBA, (K == 1 ? 4 : 1)) k_apply2(WsDev w, PartArgs a) { apply2_body<OPT, V, LPR, K>(w, a); }
