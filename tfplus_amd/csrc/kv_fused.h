@@ -84,26 +84,28 @@ __device__ __forceinline__ unsigned tile_insert(const TableDev& t, long long key
 // ------------------------------------------------------------------------------------------
 // k_ltile
 // ------------------------------------------------------------------------------------------
+// The position whose LDS insert created a key's slot is the key's WINNER: it probes the table for the key (the
+// request leaves right behind the hash insert and is collected behind the counting sort), takes the key's place in
+// the partition sort and writes its entry.  No list of occupied slots is built.
 struct LtSmem {
-  long long* lkeys;        // [LS + 1] (slot LS: the key that equals EMPTY_KEY); dead once the probes have left:
+  long long* lkeys;        // [LS + 1] (slot LS: the key that equals EMPTY_KEY); dead once the hash insert is done:
   unsigned* lrow;          //   [LS + 1] row word of the slot's key           \  live in lkeys' storage
   unsigned* escan;         //   [TILE + 1] per entry: packed prefix (below)   /
-  unsigned* mr;            // [TILE] the tile's mrow image; in lfirst's storage once the sources are written
   unsigned* lcnt;          // [LS + 1] occurrences of the slot's key
   unsigned short* lpos;    // [LS + 1] entry number of the slot's key
-  unsigned short* lfirst;  // [LS + 1] tile-local position of one occurrence
-  unsigned short* lwork;   // [TILE + 1] occupied slots; deterministic mode: running count per entry
+  unsigned* mr;            // [TILE] the tile's mrow image
+  unsigned short* lrun;    // [TILE + 1] deterministic mode: running count per entry
   unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); then the entries' frequency sums
   unsigned* wtot;          // [8]
 };
-static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)(TILE + 1) * 4 && (size_t)(LS + 1) * 2 >= (size_t)TILE * 4, "aliases fit");
+static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)(TILE + 1) * 4, "aliases fit");
 
 __host__ __device__ inline size_t ltile_smem_bytes() {
   size_t b = (size_t)(LS + 1) * 8 + 16;   // lkeys
   b += (size_t)(LS + 1) * 4 + 16;         // lcnt
   b += (size_t)(LS + 1) * 2 + 16;         // lpos
-  b += (size_t)(LS + 1) * 2 + 16;         // lfirst
-  b += (size_t)(TILE + 1) * 2 + 16;       // lwork
+  b += (size_t)TILE * 4 + 16;             // mr
+  b += (size_t)(TILE + 1) * 2 + 16;       // lrun
   b += (size_t)(MAX_P + 1) * 4 + 16;      // hist
   b += 64;                                // wtot
   return b;
@@ -117,9 +119,8 @@ __device__ __forceinline__ LtSmem carve_ltile(char* base) {
   s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
   s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
-  s.lfirst = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
-  s.mr = reinterpret_cast<unsigned*>(s.lfirst);
-  s.lwork = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
+  s.mr = reinterpret_cast<unsigned*>(take((size_t)TILE * 4));
+  s.lrun = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
   s.wtot = reinterpret_cast<unsigned*>(take(64));
   return s;
@@ -130,14 +131,13 @@ __device__ __forceinline__ LtSmem carve_ltile(char* base) {
 constexpr unsigned ES_POS = 0xFFFu, ES_NSH = 12;
 
 // VQ = float4 per row (power of two <= 64); GATHER: copy the rows of the tile's positions to `out`.
-// insert_ok == 0: a key absent from the table stays absent (row word 0: the zero row) — nothing here needs it yet.
 template <typename IdT, int VQ, bool GATHER>
 __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, const IdT* __restrict__ ids,
                                            const int* __restrict__ counts, long long n, int det,
                                            float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LtSmem sm = carve_ltile(smem_raw);
-  __shared__ unsigned lnwork, lsent;
+  __shared__ unsigned lsent;
 
   const int tid = threadIdx.x;
   const unsigned tile = blockIdx.x;
@@ -147,56 +147,71 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   const bool has_counts = PAIRS || counts != nullptr;
   KV_STAMP(0);
 
+  // the tile's ids: every load unconditional (a position past the end re-reads the last id) so that they are all
+  // in flight together
   long long kreg[IPT];
   unsigned creg[IPT];
+  unsigned there = 0;   // bit k: position k * TBT + tid holds an id
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     const long long i = base + (long long)k * TBT + tid;
-    kreg[k] = 0; creg[k] = 1;
-    if (i < n) {
-      kreg[k] = load_id(ids, (size_t)i);
-      if constexpr (PAIRS) {
-        const long long ci = ids[i].count;
-        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
-      } else if (counts != nullptr) {
-        const int ci = counts[i];   // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
-        creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
-      }
+    if (i < n) there |= 1u << k;
+    kreg[k] = load_id(ids, (size_t)(i < n ? i : n - 1));
+    creg[k] = 1;
+  }
+  if constexpr (PAIRS) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TBT + tid;
+      const long long ci = ids[i < n ? i : n - 1].count;
+      creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
+    }
+  } else if (counts != nullptr) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TBT + tid;
+      const int ci = counts[i < n ? i : n - 1];   // SaturateMaxFrequency(int32) -> uint16 (utility.h:57-59)
+      creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
     }
   }
   for (int s = tid; s <= LS; s += TBT) { sm.lkeys[s] = EMPTY_KEY; sm.lcnt[s] = 0; }
   for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
-  if (tid == 0) { lnwork = 0; lsent = 0; }
+  if (tid == 0) lsent = 0;
   if (tile == 0 && tid < 8) w.ctr[tid] = 0;
+  if constexpr (PAIRS) {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TBT + tid;
+      if (!((there >> k) & 1u)) continue;
+      bool ok = creg[k] != 0u;
+      if (ok && w.seg_cap) {   // fixed-capacity exchange segments: record 0 is the header, records past its count are stale
+        const long long r = i % w.seg_cap;
+        ok = r >= 1 && r <= ids[i - r].id;
+      }
+      if (!ok) there &= ~(1u << k);
+    }
+  }
   __syncthreads();
 
-  // ---- phase 1: LDS hash insert of the tile's ids ------------------------------------------------------------
+  // ---- phase 1: LDS hash insert of the tile's ids; `win` bit k: this position created its key's slot ------------
   unsigned tslot[IPT], myrank[IPT];
+  unsigned win = 0;
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
-    const long long i = base + (long long)k * TBT + tid;
     tslot[k] = 0xFFFFFFFFu;
     myrank[k] = 0;
-    bool there = i < n;
-    if constexpr (PAIRS) {
-      if (there && creg[k] == 0u) there = false;
-      if (there && w.seg_cap) {   // fixed-capacity exchange segments: record 0 is the header, records past its count are stale
-        const long long r = i % w.seg_cap;
-        there = r >= 1 && r <= ids[i - r].id;
-      }
-    }
-    if (there) {
+    if ((there >> k) & 1u) {
       const long long key = kreg[k];
       unsigned h;
       if (key == EMPTY_KEY) {
         h = LS;
-        if (atomicCAS(&lsent, 0u, 1u) == 0u) sm.lfirst[LS] = (unsigned short)(k * TBT + tid);
+        if (atomicCAS(&lsent, 0u, 1u) == 0u) win |= 1u << k;
       } else {
         h = (unsigned)(mix64((unsigned long long)key) >> 40) & (LS - 1);
         for (;;) {
           const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&sm.lkeys[h]),
                                                    (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-          if (old == (unsigned long long)EMPTY_KEY) { sm.lfirst[h] = (unsigned short)(k * TBT + tid); break; }
+          if (old == (unsigned long long)EMPTY_KEY) { win |= 1u << k; break; }
           if (old == (unsigned long long)key) break;
           h = (h + 1) & (LS - 1);
         }
@@ -205,50 +220,29 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       tslot[k] = h;
     }
   }
-  __syncthreads();
+  // ---- the winners' probes leave (one per distinct key; a position that is no winner asks for entry 0) -----------
+  unsigned long long pp[IPT];
+  Entry en[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    pp[k] = ((win >> k) & 1u) ? home_of(t, kreg[k], mix64((unsigned long long)kreg[k])) : 0ull;
+    en[k] = load_entry(&t.entries[pp[k]]);
+  }
+  __syncthreads();   // lcnt is final; lkeys is dead: its storage is lrow / escan from here on
   KV_STAMP(1);
 
-  // ---- phase 2: the occupied slots = the tile's distinct keys -----------------------------------------------
-  for (int s = tid; s < LS; s += TBT)
-    if (sm.lkeys[s] != EMPTY_KEY) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)s;
-  if (tid == 0 && lsent) sm.lwork[atomicAdd(&lnwork, 1u)] = (unsigned short)LS;
+  // ---- phase 2: the distinct keys counting-sorted by owning partition ----------------------------------------------
+  unsigned wcnt[IPT], wp[IPT], wr[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    wcnt[k] = 0; wp[k] = 0; wr[k] = 0;
+    if ((win >> k) & 1u) {
+      wcnt[k] = sm.lcnt[tslot[k]];
+      wp[k] = part_of(kreg[k], w.pshift);
+      wr[k] = atomicAdd(&sm.hist[wp[k]], 1u | (wcnt[k] << 16)) & 0xFFFFu;
+    }
+  }
   __syncthreads();
-  const unsigned nwork = lnwork;
-
-  // ---- the index probes leave now (one per distinct key); they are completed behind the counting sort ---------
-  constexpr int WPT = (TILE + 1 + TBT - 1) / TBT;
-  long long wkey[WPT];
-  unsigned short wslot[WPT];
-  unsigned wcnt[WPT];
-  unsigned long long pp[WPT];
-  Entry en[WPT];
-#pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    const unsigned wi = tid + q * TBT;
-    wkey[q] = 0; wslot[q] = 0; wcnt[q] = 0; pp[q] = 0;
-    en[q].key = EMPTY_KEY; en[q].row = 0; en[q].hint = 0;
-    if (wi < nwork) {
-      const unsigned s = sm.lwork[wi];
-      wslot[q] = (unsigned short)s;
-      wkey[q] = (s == LS) ? EMPTY_KEY : sm.lkeys[s];
-      wcnt[q] = sm.lcnt[s];
-      pp[q] = home_of(t, wkey[q], mix64((unsigned long long)wkey[q]));
-      en[q] = load_entry(&t.entries[pp[q]]);
-    }
-  }
-
-  // ---- phase 3: counting sort of the distinct keys by owning partition ----------------------------------------
-  unsigned wp[WPT], wr[WPT];
-#pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    const unsigned wi = tid + q * TBT;
-    wp[q] = 0; wr[q] = 0;
-    if (wi < nwork) {
-      wp[q] = part_of(wkey[q], w.pshift);
-      wr[q] = atomicAdd(&sm.hist[wp[q]], 1u | (wcnt[q] << 16)) & 0xFFFFu;
-    }
-  }
-  __syncthreads();   // (also: every read of lkeys is done — its storage is lrow / tord / escan from here on)
   {
     const unsigned per = (P + TBT - 1) / TBT;
     const unsigned p0 = tid * per, p1 = min(p0 + per, P);
@@ -260,71 +254,55 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     if (tid == 0) sm.hist[P] = tot;
   }
   __syncthreads();
+  const unsigned nent = sm.hist[P] & 0xFFFFu;   // entries of the tile
   // partition-major: toff[p][tile] (k_part2's block p reads rows p and p + 1 as two contiguous runs)
   for (unsigned p = tid; p <= P; p += TBT) w.toff[(size_t)p * w.ntiles + tile] = sm.hist[p];
-  unsigned wpos[WPT];
+  unsigned wpos[IPT];
 #pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    wpos[q] = 0xFFFFFFFFu;
-    const unsigned wi = tid + q * TBT;
-    if (wi < nwork) {
-      const unsigned pos = (sm.hist[wp[q]] & 0xFFFFu) + wr[q];
-      const size_t e = (size_t)tile * TILE + pos;
-      wpos[q] = pos;
-      sm.lpos[wslot[q]] = (unsigned short)pos;
-      w.ent_key[e] = wkey[q];
-      if (!has_counts) w.ent_a[e] = wcnt[q] | (wcnt[q] << 16);   // <= TILE: the frequency count equals the occurrences
+  for (int k = 0; k < IPT; ++k) {
+    wpos[k] = 0xFFFFFFFFu;
+    if ((win >> k) & 1u) {
+      wpos[k] = (sm.hist[wp[k]] & 0xFFFFu) + wr[k];
+      w.ent_key[(size_t)tile * TILE + wpos[k]] = kreg[k];
     }
   }
   if (det) {
     // deterministic mode: the order of a partition's entries inside the tile was the arrival order of LDS atomics;
     // it becomes the order of their keys (k_tsum's additions follow the entries' places in the tile's row list)
     __syncthreads();   // the tile's ent_key is written
-    unsigned npos[WPT];
+    unsigned npos[IPT];
 #pragma unroll
-    for (int q = 0; q < WPT; ++q) {
-      npos[q] = 0xFFFFFFFFu;
-      if (wpos[q] == 0xFFFFFFFFu) continue;
-      const unsigned p0 = sm.hist[wp[q]] & 0xFFFFu, p1 = sm.hist[wp[q] + 1u] & 0xFFFFu;
+    for (int k = 0; k < IPT; ++k) {
+      npos[k] = 0xFFFFFFFFu;
+      if (wpos[k] == 0xFFFFFFFFu) continue;
+      const unsigned p0 = sm.hist[wp[k]] & 0xFFFFu, p1 = sm.hist[wp[k] + 1u] & 0xFFFFu;
       unsigned less = 0;
-      for (unsigned j = p0; j < p1; ++j) less += w.ent_key[(size_t)tile * TILE + j] < wkey[q] ? 1u : 0u;
-      npos[q] = p0 + less;
+      for (unsigned j = p0; j < p1; ++j) less += w.ent_key[(size_t)tile * TILE + j] < kreg[k] ? 1u : 0u;
+      npos[k] = p0 + less;
     }
     __syncthreads();   // ... and read by everyone
 #pragma unroll
-    for (int q = 0; q < WPT; ++q) {
-      if (npos[q] == 0xFFFFFFFFu) continue;
-      const size_t e = (size_t)tile * TILE + npos[q];
-      wpos[q] = npos[q];
-      sm.lpos[wslot[q]] = (unsigned short)npos[q];
-      w.ent_key[e] = wkey[q];
-      if (!has_counts) w.ent_a[e] = wcnt[q] | (wcnt[q] << 16);
+    for (int k = 0; k < IPT; ++k) {
+      if (npos[k] == 0xFFFFFFFFu) continue;
+      wpos[k] = npos[k];
+      w.ent_key[(size_t)tile * TILE + wpos[k]] = kreg[k];
     }
   }
-  KV_STAMP(2);
-
-  // ---- the probes come back: row word + slot-row hint of every distinct key; absent keys are inserted ---------
 #pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    if (wpos[q] == 0xFFFFFFFFu) continue;
-    unsigned hint = 0;
-    unsigned r = table_find_from(t, wkey[q], pp[q], en[q], &hint);
-    if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, wkey[q]); hint = 0; }
-    else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
-    const size_t e = (size_t)tile * TILE + wpos[q];
-    sm.lrow[wslot[q]] = r;
-    w.ent_b[e] = r;
-    w.ent_base[e] = hint;
+  for (int k = 0; k < IPT; ++k) {
+    if (wpos[k] == 0xFFFFFFFFu) continue;
+    sm.lpos[tslot[k]] = (unsigned short)wpos[k];
+    if (!has_counts) w.ent_a[(size_t)tile * TILE + wpos[k]] = wcnt[k] | (wcnt[k] << 16);   // <= TILE: the frequency count equals the occurrences
     // per entry for the scan below: its rows | 1, if it has more than one
-    sm.escan[wpos[q]] = wcnt[q] > 1u ? (wcnt[q] | (1u << ES_NSH)) : 0u;
+    sm.escan[wpos[k]] = wcnt[k] > 1u ? (wcnt[k] | (1u << ES_NSH)) : 0u;
   }
   __syncthreads();
-  KV_STAMP(3);
+  KV_STAMP(2);
 
-  // ---- phase 4: the multi-occurrence entries: where their rows start in the tile's mrow image, their numbers ----------
+  // ---- phase 3: the multi-occurrence entries: where their rows start in the tile's mrow image, their numbers --------
   {
     constexpr unsigned PER = (TILE + 1 + TBT - 1) / TBT;
-    const unsigned e0 = tid * PER, e1 = min(e0 + PER, nwork);
+    const unsigned e0 = tid * PER, e1 = min(e0 + PER, nent);
     unsigned sum = 0;
     for (unsigned e = e0; e < e1; ++e) sum += sm.escan[e];
     unsigned tot;
@@ -332,23 +310,32 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     for (unsigned e = e0; e < e1; ++e) { const unsigned c = sm.escan[e]; sm.escan[e] = run; run += c; }
     if (tid == 0) w.mcount[tile] = (tot & ES_POS) | ((tot >> ES_NSH) << 16);
   }
-  __syncthreads();
+  // ---- the probes come back: row word + slot-row hint of every distinct key; absent keys are inserted ---------------
 #pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    if (wpos[q] == 0xFFFFFFFFu) continue;
-    const unsigned pre = sm.escan[wpos[q]];
-    const size_t e = (size_t)tile * TILE + wpos[q];
-    unsigned src;
-    if (wcnt[q] > 1u) {
-      src = EP_TAG | (tile * (unsigned)(TILE / 2) + (pre >> ES_NSH));   // its sum: row (pre >> ES_NSH) of the tile's epart rows
-    } else {
-      src = (unsigned)base + sm.lfirst[wslot[q]];
-    }
-    w.ent_rec[e] = src;
+  for (int k = 0; k < IPT; ++k) {
+    if (wpos[k] == 0xFFFFFFFFu) continue;
+    unsigned hint = 0;
+    unsigned r = table_find_from(t, kreg[k], pp[k], en[k], &hint);
+    if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, kreg[k]); hint = 0; }
+    else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
+    const size_t e = (size_t)tile * TILE + wpos[k];
+    sm.lrow[tslot[k]] = r;
+    w.ent_b[e] = r;
+    w.ent_base[e] = hint;
+  }
+  __syncthreads();
+  KV_STAMP(3);
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    if (wpos[k] == 0xFFFFFFFFu) continue;
+    const unsigned pre = sm.escan[wpos[k]];
+    // the entry's source: its sum — row (pre >> ES_NSH) of the tile's epart rows — or, alone, its one position
+    w.ent_rec[(size_t)tile * TILE + wpos[k]] = wcnt[k] > 1u ? (EP_TAG | (tile * (unsigned)(TILE / 2) + (pre >> ES_NSH)))
+                                                            : (unsigned)base + (unsigned)(k * TBT + tid);
   }
   if (det) {
     // rank = occurrences of the key at smaller input positions (see tile_body of kv_kernels.h)
-    unsigned short* run = sm.lwork;
+    unsigned short* run = sm.lrun;
     for (int e = tid; e <= TILE; e += TBT) run[e] = 0;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -376,7 +363,6 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       myrank[k] = valid ? before + rw : 0u;
     }
   }
-  if (!det) __syncthreads();   // every source is written: lfirst's storage becomes the mrow image
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     if (tslot[k] == 0xFFFFFFFFu || sm.lcnt[tslot[k]] <= 1u) continue;
@@ -393,10 +379,10 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       if (tslot[k] != 0xFFFFFFFFu) atomicAdd(&sm.hist[sm.lpos[tslot[k]]], creg[k]);
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < WPT; ++q) {
-      if (wpos[q] == 0xFFFFFFFFu) continue;
-      const unsigned f = sm.hist[wpos[q]];
-      w.ent_a[(size_t)tile * TILE + wpos[q]] = wcnt[q] | ((f > 65535u ? 65535u : f) << 16);
+    for (int k = 0; k < IPT; ++k) {
+      if (wpos[k] == 0xFFFFFFFFu) continue;
+      const unsigned f = sm.hist[wpos[k]];
+      w.ent_a[(size_t)tile * TILE + wpos[k]] = wcnt[k] | ((f > 65535u ? 65535u : f) << 16);
     }
   }
   __syncthreads();
@@ -406,7 +392,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   KV_STAMP(4);
 
-  // ---- phase 5: the output rows.  Wave wv, round k holds positions k * TBT + wv * 64 + lane in its own registers ---
+  // ---- phase 4: the output rows.  Wave wv, round k holds positions k * TBT + wv * 64 + lane in its own registers ---
   if constexpr (GATHER) {
     constexpr int RW = 64 / VQ;            // rows per copy instruction
     constexpr int CW = VQ < 8 ? VQ : 8;    // copy instructions in flight
