@@ -134,6 +134,10 @@ def main():
                   help="diagnostic: the apply rebuilds the batch index instead of taking over the lookup's")
   ap.add_argument("--deterministic", action="store_true",
                   help="diagnostic: the tables' deterministic reduction mode (kv_set_deterministic)")
+  ap.add_argument("--overlap", action="store_true",
+                  help="diagnostic: overlap mode (kv_set_overlap) without graph capture: the forks and joins are event hops")
+  ap.add_argument("--graph", action="store_true",
+                  help="the timed steps replay HIP graphs captured in overlap mode (one graph per pooled batch)")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -177,8 +181,8 @@ def main():
   K_local = args.keys if world == 1 else int(args.keys * 1.05) + 1024
   gen = torch.Generator(device=dev).manual_seed(SEED + rank)
   table = (torch.randn(10000, D, device=dev, generator=torch.Generator(device=dev).manual_seed(SEED)) * 0.05)
-  var = ops.kv_variable([D], capacity_hint=K_local + 4 * N, device=local)
-  slot = ops.kv_variable([3 * D], capacity_hint=K_local + 4 * N, device=local)
+  var = ops.kv_variable([D], capacity_hint=K_local + 24 * N, device=local)
+  slot = ops.kv_variable([3 * D], capacity_hint=K_local + 24 * N, device=local)
   ops.init_kv_variable_v2(var, table)
   ops.init_kv_variable_v2(slot, torch.zeros(16, 3 * D, device=dev))
   stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -285,9 +289,13 @@ def main():
     if native_shard:
       live["comm"] = comm
 
+  if args.overlap and not shard_path:
+    ops.kv_set_overlap(var, True)
+
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
     if not shard_path:
+      stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # (the capture stream inside a graph capture)
       # the lookup names the batch; the apply of the same ids takes its index over (kvhip.h: batch token)
       tok = ctypes.c_uint64(0)
       _lib.check(L.kv_gather_or_insert_tok(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), ctypes.byref(tok), stream))
@@ -326,13 +334,35 @@ def main():
   torch.cuda.synchronize()
   warm = ops.kv_profile_read(var)
   dom = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if args.warmup > 0 else "apply_sorted"
-  ops.kv_profile_enable(var, 0 if args.no_kernel_events else args.steps + 8)
+  graphs = None
+  if args.graph and not shard_path:
+    # one graph per pooled batch, captured in overlap mode: the lookup's rows beside its tile pass, the partition pass
+    # beside the apply's tile sums — graph edges instead of event hops, no launch gaps.  (The Adam powers b1p / b2p
+    # are arguments by value: a replay uses the ones of its capture.)
+    ops.kv_profile_enable(var, 0)
+    torch.cuda.synchronize()
+    for h in (var, slot):
+      ops.kv_prepare_capture(h, (len(pool) + 2) * N)
+    graphs = []
+    for p in range(len(pool)):
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        step(p)
+      graphs.append(g)
+    for g in graphs:           # untimed: every graph once
+      g.replay()
+    torch.cuda.synchronize()
+  ops.kv_profile_enable(var, 0 if (args.no_kernel_events or graphs) else args.steps + 8)
   ops.kv_profile_select(var, [dom])
   ops.kv_profile_sample(var, SAMPLE_EVERY)     # a pair of event markers costs ~4 us of stream time per launch
   barrier()
   t0 = time.perf_counter()
-  for k in range(args.steps):
-    step(args.warmup + k)
+  if graphs:
+    for k in range(args.steps):
+      graphs[(args.warmup + k) % len(graphs)].replay()
+  else:
+    for k in range(args.steps):
+      step(args.warmup + k)
   torch.cuda.synchronize()
   t1 = time.perf_counter()
   dt = t1 - t0
@@ -354,7 +384,7 @@ def main():
 
   ms_per_step = dt / args.steps * 1e3
   value = N * world / (dt / args.steps)
-  if args.no_kernel_events:
+  if args.no_kernel_events or graphs:
     if rank == 0:
       print(json.dumps({"ms_per_step": ms_per_step, "value": value, "note": "diagnostic run without kernel events"}))
     if shard_path:

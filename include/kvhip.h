@@ -177,6 +177,21 @@ int kv_attach_slot(kv_handle_t var, kv_handle_t slot, kv_stream_t stream);
  * key's tiles in tile order — so the same batch gives bit-identical optimizer state on every run. */
 int kv_set_deterministic(kv_handle_t h, int on);
 
+/* Overlap mode (off by default), for steps that are captured in a HIP graph.  The training lookup then forks a side
+ * stream of the table: the output rows are copied there (k_copy) beside the tile pass, and the partition pass follows
+ * them there, so that it runs beside whatever the caller does between the lookup and the optimizer apply (the dense
+ * tower; in a bare benchmark: the apply's tile sums).  The lookup returns with `out` complete on the caller's
+ * stream; the next op on the table (any op, on any stream) first joins the side stream.  Under stream capture the
+ * forks and joins are graph edges and cost nothing; outside a capture each is an event hop of several microseconds,
+ * which is why this is not the default.  A capture that holds a lookup must also hold the table's next op (the
+ * optimizer apply), or the side stream is left unjoined.  Results are the same as without it. */
+int kv_set_overlap(kv_handle_t h, int on);
+/* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that
+ * follows can then take `max_new_ids` more ids without consulting the device — what a stream capture needs, where a
+ * synchronisation is not allowed.  KV_RESOURCE_EXHAUSTED when the table would have to grow for that many ids (it
+ * grows here, outside the capture, if it can). */
+int kv_prepare_capture(kv_handle_t h, int64_t max_new_ids, kv_stream_t stream);
+
 /* The TF-core step on its own (for callers that want the [U, dim] IndexedSlices):
  * uniq_ids [n], summed [n, dim] are filled for the first *num_unique entries; inverse [n]
  * (may be NULL) maps each input position to its unique row.  Unique order is unspecified

@@ -84,10 +84,12 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
 
 // k_tsum (kv_fused.h): the tile sums in front of the entry-list apply; same row geometry as k_apply.
 // grid = ITEM_BLOCKS + ntiles blocks of TBC threads.  Instantiated once (kv_apply_b.hip).
+// n < 0: the sums alone; grad == nullptr: the directory alone (overlap mode, kvhip.hip fused_apply).
 inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s) {
   const int D = td.dim;
-  const unsigned grid = (unsigned)ITEM_BLOCKS + wd.ntiles;
-#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, n); return KV_OK; } while (0)
+  const int what = n < 0 ? 1 : (grad == nullptr ? 2 : 0);
+  const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? (unsigned)ITEM_BLOCKS : (unsigned)ITEM_BLOCKS + wd.ntiles;
+#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, what); return KV_OK; } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const int q = D / 4;
   if (q <= 1) KV_TSUM(4, 1, 1);

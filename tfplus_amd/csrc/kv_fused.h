@@ -1116,13 +1116,15 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
     if (active) store_row(rslot, run);
   }
 }
+// what: 0 = the directory blocks in front of the tiles' blocks; 1 = the tiles only; 2 = the directory only (overlap
+// mode: the sums run beside the partition pass, the directory behind it)
 template <int V, int LPR, int K>
-__global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, long long n) {
+__global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, int what) {
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the index pass gave up on this batch
-  if (blockIdx.x == 0 && threadIdx.x == 0) w.order[n] = HEAD_BIT;
   KV_STAMPT(0);
-  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(w); KV_STAMPT(1); return; }
-  tsum_body<V, LPR, K>(w, grad, t.dim, blockIdx.x - ITEM_BLOCKS);
+  const unsigned nib = what == 1 ? 0u : (unsigned)ITEM_BLOCKS;
+  if (blockIdx.x < nib) { items2_body<TBC / 64>(w); KV_STAMPT(1); return; }
+  tsum_body<V, LPR, K>(w, grad, t.dim, blockIdx.x - nib);
   KV_STAMPT(1);
 }
 
@@ -1393,3 +1395,68 @@ __device__ __forceinline__ void apply2_body(const WsDev& w, const PartArgs& a) {
 }
 template <int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TBA, (K == 1 ? 4 : 1)) k_apply2(WsDev w, PartArgs a) { apply2_body<OPT, V, LPR, K>(w, a); }
+
+// ------------------------------------------------------------------------------------------
+// k_copy: the training lookup's output rows by themselves (overlap mode)
+// ------------------------------------------------------------------------------------------
+// goz_wave (kv_kernels.h) with the training lookup's answer for a key the table does not hold yet: the init rule's
+// value (kv_variable.h:889-898) instead of zeros.  It runs BESIDE k_ltile<GATHER = false> of the same batch, which
+// inserts those keys: whatever state of a new key's index entry a probe meets — empty, claimed, published with
+// HINT_NEW — the answer is the init value, and the row of a key that was there before the batch is not written by
+// anything the lookup runs.  One wave per 64 ids and step, lane l probes id l, the rows go VQ lanes per row.
+template <typename IdT, int VQ>
+__global__ void __launch_bounds__(TB) k_copy(TableDev t, const IdT* __restrict__ ids, float* __restrict__ out, long long n) {
+  constexpr int RW = 64 / VQ;
+  constexpr int CW = VQ < 8 ? VQ : 8;
+  const int lane = threadIdx.x & 63;
+  const int v = lane % VQ, sub = lane / VQ;
+  const long long wave = (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (TB / 64) * 64;
+  const bool single = single_chunk(t);
+  const float4* rows0 = reinterpret_cast<const float4*>(t.c0.rows);
+  for (long long r0 = wave * 64; r0 < n; r0 += stride) {
+    const long long i = r0 + lane;
+    const long long key = (long long)ids[i < n ? i : n - 1];
+    const unsigned long long p = home_of(t, key, mix64((unsigned long long)key));
+    const Entry e = load_entry(&t.entries[p]);
+    unsigned hint = 0;
+    unsigned rr = table_find_from(t, key, p, e, &hint);
+    if (rr == 0u || hint == HINT_NEW) rr = NEW_BIT;
+    const bool anynew = __ballot((rr & NEW_BIT) != 0u) != 0ull;
+#pragma unroll
+    for (int j0 = 0; j0 < VQ; j0 += CW) {
+      float4 val[CW];
+      unsigned rj[CW];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+      if (single) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) val[j] = rows0[(size_t)(rj[j] & ROW_MASK) * VQ + v];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j] & ROW_MASK))[v];
+      }
+      if (__builtin_expect(anynew, 0)) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          const long long kj = __shfl(key, (j0 + j) * RW + sub);
+          if (rj[j] & NEW_BIT) {
+            const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
+            const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
+            const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
+            val[j] = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const long long ii = r0 + (j0 + j) * RW + sub;
+        if (ii < n) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+          __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+        }
+      }
+    }
+  }
+}

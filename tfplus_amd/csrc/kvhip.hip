@@ -378,6 +378,11 @@ struct kv_table {
   uint64_t batch_serial = 0;
   long long batch_n = 0;
   bool fused_index = false;        // the index is an entry list (kv_fused.h), not a sorted position list
+  // overlap mode (kv_set_overlap): a side stream of the table's own; side_pending: it still runs the lookup's
+  // partition pass — the table's next op joins it (ev_part) first
+  bool overlap = false, side_pending = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_tile = nullptr, ev_copy = nullptr, ev_part = nullptr;
   bool deterministic = false;      // kv_set_deterministic
   uint64_t uid = 0;                // unique over the process: names the attached slot table safely
   uint64_t slot_uid = 0;           // uid of the slot table the index entries' hints refer to (0 = none)
@@ -783,6 +788,24 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
 #undef KV_LT
 #undef KV_LT2
 }
+// the training lookup's rows alone (overlap mode): one 64-id step per wave
+void launch_copy(kv_table* t, const TableDev& td, const void* ids, long long n, float* out, hipStream_t s) {
+  const int q = td.dim / 4;
+  const int grid = nblocks(n, TB, 8192);
+#define KV_CP2(IDT, VQ) k_copy<IDT, VQ><<<grid, TB, 0, s>>>(td, (const IDT*)ids, out, n)
+#define KV_CP(IDT)                                                              \
+  do {                                                                          \
+    switch (q) {                                                                \
+      case 1: KV_CP2(IDT, 1); break;   case 2: KV_CP2(IDT, 2); break;           \
+      case 4: KV_CP2(IDT, 4); break;   case 8: KV_CP2(IDT, 8); break;           \
+      case 16: KV_CP2(IDT, 16); break; case 32: KV_CP2(IDT, 32); break;         \
+      default: KV_CP2(IDT, 64); break;                                          \
+    }                                                                           \
+  } while (0)
+  if (t->key_dtype == KV_DT_INT32) KV_CP(int); else KV_CP(long long);
+#undef KV_CP
+#undef KV_CP2
+}
 template <int MODE>
 void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
   k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
@@ -838,7 +861,11 @@ int report_deferred_error(kv_table* t, hipStream_t s) {
 // and the table itself are shared by every op (the reference's table locks cover execution, not just
 // enqueue, training_ops.cc:96-184).  Same stream as the last op: nothing to do.  Another stream: it first
 // waits for everything the previous stream had been given.
-int hand_over(kv_table* t, hipStream_t s) {
+int hand_over(kv_table* t, hipStream_t s, bool join_side = true) {
+  if (t->side_pending && join_side) {   // the lookup's partition pass on the table's side stream (overlap mode)
+    HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
+    t->side_pending = false;
+  }
   if (t->has_last && t->last_stream != s) {
     HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
     HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
@@ -859,10 +886,11 @@ struct MultiLock {
     for (auto* t : ts) t->mu.lock();
   }
   ~MultiLock() { for (auto it = ts.rbegin(); it != ts.rend(); ++it) (*it)->mu.unlock(); }
-  int enter(hipStream_t s) {
+  // later: this table's side stream (overlap mode) is joined by the caller, behind the work that does not need it
+  int enter(hipStream_t s, kv_table* later = nullptr) {
     int rc;
     for (auto* t : ts)
-      if ((rc = report_deferred_error(t, s)) || (rc = hand_over(t, s))) return rc;
+      if ((rc = report_deferred_error(t, s)) || (rc = hand_over(t, s, t != later))) return rc;
     return KV_OK;
   }
 };
@@ -898,24 +926,56 @@ void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* id
 
 // The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
 template <int MODE>
-void fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
-                      int ids_kind, float* out, hipStream_t s) {
+int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
+                     int ids_kind, float* out, hipStream_t s) {
   wd.hc = (unsigned)HC2;
   t->fused_index = true;
+  if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
+    // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
+    // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
+    HIP_TRY(hipEventRecord(t->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(t->side, t->ev_fork, 0));
+    {
+      ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
+      launch_ltile(t, pa.tv, wd, ids, counts, n, nullptr, s, ids_kind);
+    }
+    HIP_TRY(hipEventRecord(t->ev_tile, s));
+    launch_copy(t, pa.tv, ids, n, out, t->side);
+    HIP_TRY(hipEventRecord(t->ev_copy, t->side));
+    HIP_TRY(hipStreamWaitEvent(t->side, t->ev_tile, 0));
+    launch_part2<MODE_LOOKUP>(wd, pa, t->side);
+    HIP_TRY(hipEventRecord(t->ev_part, t->side));
+    t->side_pending = true;
+    HIP_TRY(hipStreamWaitEvent(s, t->ev_copy, 0));
+    return KV_OK;
+  }
   {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_ltile(t, pa.tv, wd, ids, counts, n, out, s, ids_kind);
   }
   ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
   launch_part2<MODE>(wd, pa, s);
+  return KV_OK;
 }
 // ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
 // a key can have more entries than a chunk holds, i.e. more tiles than HC2)
 template <int OPT>
-int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s) {
+int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false) {
   wd.hc = (unsigned)HC2;
   pa.epart = wd.epart;
-  {
+  if (join_side) {
+    // overlap mode: the tile sums need the tile pass only; the item directory needs the partition pass, so here it
+    // is its own little launch behind the join
+    {
+      ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
+      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s);
+      if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
+    }
+    HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
+    v->side_pending = false;
+    const int rc = kvp_launch_tsum(&pa.tv, &wd, nullptr, n, (void*)s);
+    if (rc) return fail(rc, "item directory");
+  } else {
     ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
     const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s);
     if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
@@ -1068,6 +1128,11 @@ int kv_destroy(kv_handle_t t) {
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
   hipFree(w.mcount); hipFree(w.epart);
+  if (t->side) {
+    hipStreamSynchronize(t->side);
+    hipStreamDestroy(t->side);
+    for (hipEvent_t e : {t->ev_fork, t->ev_tile, t->ev_copy, t->ev_part}) if (e) hipEventDestroy(e);
+  }
   hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   if (t->err_host) hipHostFree(t->err_host);
   if (t->last_done) hipEventDestroy(t->last_done);
@@ -1239,7 +1304,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     pa.day = today(t);
     pa.det = t->deterministic ? 1 : 0;
     pa.n = m;
-    if (fused_ok(t->dim) && !pairs) fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s);
+    if (fused_ok(t->dim) && !pairs) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -1678,6 +1743,11 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
   const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
+  const bool keep_side = reuse && v->side_pending && v->fused_index;   // overlap mode: joined behind the tile sums
+  if (v->side_pending && !keep_side) {
+    HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
+    v->side_pending = false;
+  }
   if (!reuse && (rc = ensure_capacity(v, n, s))) return rc;
   if ((rc = ensure_capacity(s0, n, s))) return rc;
   if (s1 && (rc = ensure_capacity(s1, n, s))) return rc;
@@ -1691,12 +1761,12 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
   if (!reuse) {
     v->batch_serial = 0;
-    if (fused_ok(v->dim)) fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    if (fused_ok(v->dim)) { if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s))) return rc; }
     else index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
     v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
     v->batch_n = n;
   }
-  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s);
+  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -1726,7 +1796,7 @@ int kv_apply_group_adam_tok(kv_handle_t v, kv_handle_t mvl, const float* grad, c
   DeviceGuard dg(v->device);
   MultiLock lk({v, mvl});
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = lk.enter(s))) return rc;
+  if ((rc = lk.enter(s, token != 0 && token == v->batch_serial ? v : nullptr))) return rc;
   OptArgs a{};
   a.lr = lr; a.b1p = b1p; a.b2p = b2p; a.b1 = b1; a.b2 = b2; a.eps = eps;
   if (version == 4) {  // :7111-7120
@@ -1758,7 +1828,7 @@ int kv_apply_adagrad_tok(kv_handle_t v, kv_handle_t acc, float lr, const float* 
   DeviceGuard dg(v->device);
   MultiLock lk({v, acc});
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = lk.enter(s))) return rc;
+  if ((rc = lk.enter(s, token != 0 && token == v->batch_serial ? v : nullptr))) return rc;
   OptArgs a{};
   a.lr = lr; a.update_slots = update_slots;
   return apply_common<OPT_ADAGRAD>(v, acc, nullptr, grad, ids, n, a, token, s);
@@ -1789,7 +1859,7 @@ int kv_apply_sparse_group_ftrl_tok(kv_handle_t v, kv_handle_t acc, kv_handle_t l
   DeviceGuard dg(v->device);
   MultiLock lk({v, acc, lin});
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = lk.enter(s))) return rc;
+  if ((rc = lk.enter(s, token != 0 && token == v->batch_serial ? v : nullptr))) return rc;
   OptArgs a{};
   a.lr = lr; a.l1 = l1; a.l2 = l2; a.l21 = l21; a.l2s = l2s; a.lr_power = lr_power;
   a.l21_norm = l21 * std::sqrt((float)v->dim);  // :728
@@ -1841,6 +1911,44 @@ int kv_set_deterministic(kv_handle_t t, int on) {
   std::lock_guard<std::mutex> l(t->mu);
   t->deterministic = on != 0;
   t->batch_serial = 0;
+  return KV_OK;
+}
+
+int kv_set_overlap(kv_handle_t t, int on) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  if (on && !t->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&t->ev_fork, &t->ev_tile, &t->ev_copy, &t->ev_part}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  t->overlap = on != 0;
+  return KV_OK;
+}
+
+int kv_prepare_capture(kv_handle_t t, int64_t max_new_ids, kv_stream_t stream) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (max_new_ids < 0) return fail(KV_INVALID_ARGUMENT, "max_new_ids < 0");
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = enter_op(t, s))) return rc;
+  unsigned c[3];
+  HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (c[1]) return flagged_error(t, c[1], s);
+  const long long freed = std::max(0, (int)c[2]);
+  t->rows_ub = c[0];
+  t->free_known = freed;
+  t->idx_ub = t->idx_base + (c[0] - t->bump_base) +
+              (unsigned long long)std::max<long long>(0, (long long)t->pushes_since - (freed - t->free_base));
+  // make room now (this may grow the table), then give the room back: the captured calls take it piece by piece
+  const unsigned long long r0 = t->rows_ub, i0 = t->idx_ub;
+  if ((rc = ensure_capacity(t, max_new_ids, s))) return rc;
+  t->rows_ub = r0; t->idx_ub = i0;
+  HIP_TRY(hipStreamSynchronize(s));
   return KV_OK;
 }
 

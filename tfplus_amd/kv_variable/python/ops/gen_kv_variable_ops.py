@@ -444,6 +444,16 @@ def kv_set_deterministic(table_handle, on=True):
   _lib.check(_lib.lib().kv_set_deterministic(table_handle.ptr, int(bool(on))))
 
 
+def kv_set_overlap(table_handle, on=True):
+  """Overlap mode for steps captured in a HIP graph (kvhip.h kv_set_overlap)."""
+  _lib.check(_lib.lib().kv_set_overlap(table_handle.ptr, int(bool(on))))
+
+
+def kv_prepare_capture(table_handle, max_new_ids):
+  """Refreshes the host's row-count bounds so that captured calls taking up to max_new_ids ids need no sync."""
+  _lib.check(_lib.lib().kv_prepare_capture(table_handle.ptr, int(max_new_ids), _stream(table_handle)))
+
+
 def kv_profile_enable(table_handle, max_launches):
   _lib.check(_lib.lib().kv_profile_enable(table_handle.ptr, int(max_launches)))
 
