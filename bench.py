@@ -295,13 +295,13 @@ def main():
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
     if not shard_path:
-      stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # (the capture stream inside a graph capture)
+      st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # (the capture stream inside a graph capture)
       # the lookup names the batch; the apply of the same ids takes its index over (kvhip.h: batch token)
       tok = ctypes.c_uint64(0)
-      _lib.check(L.kv_gather_or_insert_tok(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), ctypes.byref(tok), stream))
+      _lib.check(L.kv_gather_or_insert_tok(var.ptr, ids.data_ptr(), None, N, out.data_ptr(), ctypes.byref(tok), st))
       _lib.check(L.kv_apply_group_adam_tok(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
                                            float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
-                                           0.0, 4, tok.value if not args.no_token else 0, stream))
+                                           0.0, 4, tok.value if not args.no_token else 0, st))
     elif native_shard:
       # ids -> owners (grouped send / recv over xGMI) -> rows back; summed gradients -> owners -> fused apply
       _lib.check(L.kv_shard_lookup(shard.ptr, comm.ptr, ids.data_ptr(), N, out.data_ptr(), 1, stream))

@@ -268,14 +268,25 @@ def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
     want = ops.kv_variable_gather_or_insert_v2(var2, ids)
     if step == 0:
       assert torch.equal(out, want)
-    else:
-      torch.testing.assert_close(out, want, rtol=2e-5, atol=2e-6)
+    else:   # two states that already differ by the order of their sums; the per-step bound below is the real check
+      torch.testing.assert_close(out, want, rtol=1e-3, atol=1e-4)
+    # the two paths sum a repeated id's gradients (two-signed here) in different fp32 orders — local pre-sum then the
+    # owner's sum, against tile sums then the key's entries: each is held to the float64 update of ITS OWN state before
+    # the step, within the per-element reorder bound (tests/_reorder.py), not to a blanket rtol
+    from _reorder import adam_hp, adam_reorder_check
+    u = torch.unique(ids)
+    pre = []
+    for hv, hs in ((vars_[0], slots[0]), (var2, slot2)):
+      st = ops.kv_variable_gather_or_zeros_v2(hs, u).cpu().numpy()
+      pre.append((ops.kv_variable_gather_or_zeros_v2(hv, u).cpu().numpy(), st[:, :D], st[:, D:2 * D], st[:, 2 * D:]))
     shards[0].apply(comm, ops.OPT_GROUP_ADAM_V4, [slots[0]], g, (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
     ops.kv_variable_group_sparse_apply_adam_v4(var2, slot2, g, ids, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    hp = adam_hp(0.1, 0.9, 0.999)
+    for (x0, m0, v0, z0), hv, name in zip(pre, (vars_[0], var2), ("sharded", "unsharded")):
+      x1 = ops.kv_variable_gather_or_zeros_v2(hv, u).cpu().numpy()
+      adam_reorder_check(x0, m0, v0, z0, ids.cpu().numpy(), g.cpu().numpy(), x1, hp, what="%s step %d" % (name, step))
     k1, v1 = ops.read_kv_variable_op_v2(vars_[0]); k2, v2 = ops.read_kv_variable_op_v2(var2)
-    o1, o2 = torch.argsort(k1), torch.argsort(k2)
-    assert torch.equal(k1[o1], k2[o2])
-    torch.testing.assert_close(v1[o1], v2[o2], rtol=2e-5, atol=2e-6)     # local pre-sum, then the owner's sum: fp32 order
+    assert torch.equal(torch.sort(k1).values, torch.sort(k2).values)
   del comm
 
 

@@ -42,6 +42,10 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
       }                                                                                            \
     }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
+      if (md && span == 2) {                                                                       \
+        k_apply2_multi<OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBA, 0, s>>>(md);  \
+        return KV_OK;                                                                              \
+      }                                                                                            \
       if (md) {                                                                                    \
         if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBF, sh, s>>>(md);   \
         else k_apply_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBS, sh, s>>>(md);      \
@@ -85,11 +89,18 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
 // k_tsum (kv_fused.h): the tile sums in front of the entry-list apply; same row geometry as k_apply.
 // grid = ITEM_BLOCKS + ntiles blocks of TBC threads.  Instantiated once (kv_apply_b.hip).
 // n < 0: the sums alone; grad == nullptr: the directory alone (overlap mode, kvhip.hip fused_apply).
-inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s) {
+// md != nullptr: `ntab` tables in one launch (wd = the largest ntiles of the batch).
+inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s,
+                         const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = td.dim;
   const int what = n < 0 ? 1 : (grad == nullptr ? 2 : 0);
   const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? (unsigned)ITEM_BLOCKS : (unsigned)ITEM_BLOCKS + wd.ntiles;
-#define KV_TSUM(V, LPR, K) do { k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, what); return KV_OK; } while (0)
+#define KV_TSUM(V, LPR, K)                                                                              \
+  do {                                                                                                  \
+    if (md) k_tsum_multi<V, LPR, K><<<dim3((unsigned)ITEM_BLOCKS + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md); \
+    else k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, what);                                    \
+    return KV_OK;                                                                                       \
+  } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const int q = D / 4;
   if (q <= 1) KV_TSUM(4, 1, 1);

@@ -1460,3 +1460,34 @@ __global__ void __launch_bounds__(TB) k_copy(TableDev t, const IdT* __restrict__
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// the same kernels over many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array)
+// ------------------------------------------------------------------------------------------
+template <typename IdT, int VQ, bool GATHER>
+__global__ void __launch_bounds__(TBT) k_ltile_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.ntiles) return;
+  ltile_body<IdT, VQ, GATHER>(m.a.tv, m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.n, m.a.det, m.out);
+}
+template <int MODE>
+__global__ void __launch_bounds__(TBK, 4) k_part2_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  part2_body<MODE>(m.w, m.a);
+}
+template <int V, int LPR, int K>
+__global__ void __launch_bounds__(TBC) k_tsum_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (m.n == 0) return;
+  if (*reinterpret_cast<volatile unsigned*>(&m.a.tv.counters[1])) return;
+  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(m.w); return; }
+  if (blockIdx.x - ITEM_BLOCKS >= m.w.ntiles) return;
+  tsum_body<V, LPR, K>(m.w, m.a.grad, m.a.tv.dim, blockIdx.x - ITEM_BLOCKS);
+}
+template <int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBA, (K == 1 ? 4 : 1)) k_apply2_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (m.n == 0) return;
+  apply2_body<OPT, V, LPR, K>(m.w, m.a);
+}

@@ -53,7 +53,8 @@ extern "C" int kvp_launch_apply_a(int mode, int opt, const void* wd, const void*
 extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab,
                                   unsigned nchunks, int span);
 
-extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream);
+extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream, const void* md,
+                               int ntab);
 
 namespace {
 
@@ -761,8 +762,9 @@ bool fused_ok(int D) {
   return q >= 1 && q <= 64 && (q & (q - 1)) == 0;
 }
 // tile pass: dedup, index probes / inserts, entries, tile-local order and (out != nullptr) the output rows
+// md != nullptr: `ntab` tables in one launch (grid.y), arguments from the descriptor array; multi_rows: with rows
 void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, const int* counts, long long n, float* out,
-                  hipStream_t s, int ids_kind = -1) {
+                  hipStream_t s, int ids_kind = -1, const MultiDesc* md = nullptr, int ntab = 0, bool multi_rows = false) {
   if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
   const int grid = (int)wd.ntiles;
   const size_t sh = ltile_smem_bytes();
@@ -770,7 +772,9 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   const int q = td.dim / 4;
 #define KV_LT2(IDT, VQ)                                                                                     \
   do {                                                                                                      \
-    if (out) k_ltile<IDT, VQ, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out);      \
+    if (md && multi_rows) k_ltile_multi<IDT, VQ, true><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md); \
+    else if (md) k_ltile_multi<IDT, 1, false><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md);     \
+    else if (out) k_ltile<IDT, VQ, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out); \
     else k_ltile<IDT, 1, false><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr);     \
   } while (0)
 #define KV_LT(IDT)                                                              \
@@ -807,8 +811,9 @@ void launch_copy(kv_table* t, const TableDev& td, const void* ids, long long n, 
 #undef KV_CP2
 }
 template <int MODE>
-void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s) {
-  k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
+void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
+  if (md) k_part2_multi<MODE><<<dim3(wd.P, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
+  else k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
 }
 
 // segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
@@ -968,16 +973,16 @@ int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s
     // is its own little launch behind the join
     {
       ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
-      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s);
+      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s, nullptr, 0);
       if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
     }
     HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
     v->side_pending = false;
-    const int rc = kvp_launch_tsum(&pa.tv, &wd, nullptr, n, (void*)s);
+    const int rc = kvp_launch_tsum(&pa.tv, &wd, nullptr, n, (void*)s, nullptr, 0);
     if (rc) return fail(rc, "item directory");
   } else {
     ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
-    const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s);
+    const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s, nullptr, 0);
     if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
   }
   static const bool old_apply = [] { const char* e = getenv("KV_OLD_APPLY"); return e && atoi(e) != 0; }();   // A/B: k_apply over the entry list
@@ -1569,6 +1574,7 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
     MultiDesc& d = hd[i];
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
+    if (fused_ok(tables[i]->dim)) d.w.hc = (unsigned)HC2;
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
     d.a.det = tables[i]->deterministic ? 1 : 0;
@@ -1585,9 +1591,16 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
-  launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
-  launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
-  launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
+  if (fused_ok(t0->dim)) {
+    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = true;
+    launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
+    launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
+  } else {
+    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = false;
+    launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+    launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
+    launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
+  }
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1650,6 +1663,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
     d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
+    if (fused_ok(D)) { d.w.hc = (unsigned)HC2; d.a.epart = d.w.epart; }
     d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
     d.a.det = vars[i]->deterministic ? 1 : 0;
     d.a.n = ns[i];
@@ -1663,14 +1677,26 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
-  launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
-  launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
-  launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
+  const bool fz = fused_ok(D);
+  bool skip_fin = false;
+  if (fz) {
+    for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = true;
+    wmax.hc = (unsigned)HC2;
+    skip_fin = wmax.ntiles <= wmax.hc;
+    launch_ltile(vars[0], hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, false);
+    launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+    if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, nmax, (void*)s, md, num_tables))) return fail(rc, "tile sums: no kernel for dim %d", D);
+  } else {
+    for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = false;
+    launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+    launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+    launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
+  }
   switch (opt) {
-    case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
-    case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
-    case OPT_ADAGRAD: rc = launch_apply<MODE_APPLY, OPT_ADAGRAD>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
-    default: rc = launch_apply<MODE_APPLY, OPT_FTRL>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
+    case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
+    case OPT_ADAGRAD: rc = launch_apply<MODE_APPLY, OPT_ADAGRAD>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
+    default: rc = launch_apply<MODE_APPLY, OPT_FTRL>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
   }
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
