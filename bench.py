@@ -195,7 +195,7 @@ def main():
     r = torch.arange(i + 1, min(i + CH, K) + 1, dtype=torch.int64, device=dev)
     keys = splitmix64(r)
     if world > 1:
-      keys = keys[_owner_of(keys, world) == rank].contiguous()      # hashed ownership: mix64(id) % world
+      keys = keys[_owner_of(keys, world) == rank].contiguous()      # hashed ownership: (mix64(id) >> 32) % world
     owned += keys.numel()
     if keys.numel() == 0:
       continue
@@ -455,7 +455,7 @@ def main():
                              "lookup + sparse GroupAdam apply" % (args.keys // 1_000_000, D, N, args.zipf),
                  "keys": K, "dim": D, "batch": N, "zipf": args.zipf, "global_batch": N * world, "unique_per_batch": Ub,
                  "tile_entries_per_batch": E_mean, "tile_entries_single": S1_mean,
-                 "parallelism": ("table sharded over %d GPUs by mix64(id) %% G, fixed-capacity id/row/grad exchange, "
+                 "parallelism": ("table sharded over %d GPUs by (mix64(id) >> 32) %% G, fixed-capacity id/row/grad exchange, "
                                  "grouped ncclSend/ncclRecv over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

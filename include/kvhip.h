@@ -352,7 +352,7 @@ int kv_unsorted_segment_sum(kv_handle_t h, const int32_t* segment_ids, const flo
  * communication layer — its only sharding rule is `ids % num_shards`, python/ops/embedding_ops.py:121-127 and
  * kernels/utility.h:90-107 ModKeyImpl) ------------------------------------------------------------------------
  * Ownership rules of an id: */
-#define KV_OWNER_HASH 0 /* mix64(id) % world: balanced whatever the ids look like (the default) */
+#define KV_OWNER_HASH 0 /* (mix64(id) >> 32) % world: balanced whatever the ids look like (the default); the high half: the index homes keys by the low bits */
 #define KV_OWNER_MOD 1  /* floor_mod(id, world): the reference's rule, for checkpoints partitioned by it */
 
 /* Counting sort of `ids` [n] by owner rank: out_ids [n] holds the ids grouped by owner (rank 0's first),

@@ -269,7 +269,7 @@ def test_bucket_by_owner_matches_floor_mod(api):
     o, p = out.cpu().numpy(), perm.cpu().numpy()
     assert sorted(p.tolist()) == list(range(5000)) and np.array_equal(o, ids.numpy()[p])
     assert np.all(np.diff(np.mod(o, world)) >= 0)        # grouped by owner, rank 0 first
-    # the default rule: mix64(id) % world, the same owner sharded.owner_of states in torch
+    # the default rule: (mix64(id) >> 32) % world, the same owner sharded.owner_of states in torch
     from tfplus_amd.kv_variable.python.ops import sharded
     out, perm, counts = g.kv_bucket_by_owner(h, ids, world)
     own = sharded.owner_of(ids, world).numpy()

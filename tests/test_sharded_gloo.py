@@ -81,7 +81,7 @@ def _worker(rank, world, port, q, rule):
     # routing primitives
     ids = torch.tensor([-3, 4, 7, -8, 5])
     assert sharded.owner_of(ids, 2, "mod").tolist() == [1, 0, 1, 0, 1]
-    # the hashed rule is the library's mix64(id) % world on the unsigned value (kv_device.h), spelled out in Python
+    # the hashed rule is the high half of the library's mix64(id) (kv_device.h) modulo the world, spelled out in Python
     def mix(x):
       x &= (1 << 64) - 1
       x ^= x >> 33; x = x * 0xff51afd7ed558ccd & ((1 << 64) - 1)
@@ -89,7 +89,7 @@ def _worker(rank, world, port, q, rule):
       return x ^ (x >> 33)
     probe = torch.tensor([-3, 4, 7, -8, 5, 0, -1, 2**62, -2**63, 2**63 - 1])
     for w in (2, 3, 7, 8):
-      assert sharded.owner_of(probe, w).tolist() == [mix(int(v)) % w for v in probe.tolist()]
+      assert sharded.owner_of(probe, w).tolist() == [(mix(int(v)) >> 32) % w for v in probe.tolist()]
     rt = sharded.route(ids, rule=rule)
     assert sorted(rt.perm.tolist()) == list(range(5)) and sum(rt.send_counts) == 5
     # occurrence counts survive the dedup-before-exchange: lookup with per-id counts

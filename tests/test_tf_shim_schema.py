@@ -13,14 +13,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tfplus_amd", "tf_shim", "kv_variable_ops_hip.cc")
 REF_OPS = "/root/reference/tfplus/kv_variable/ops"
 
-# every op of SURVEY.md §8(b) and the "next" rows the shim also covers
+# every op of SURVEY.md §8(b), the "next" rows, and what the reference's Python layer needs to build a graph with a
+# Saver (KvVariableSaveable) and its hygiene calls
 REQUIRED = ["KvVariable", "KvVariableV2", "KvVariableV3", "KvVariableV4", "InitKvVariableV2", "KvVariableIsInitializedV2",
             "KvVariableShapeV2", "KvVariableSizeV2", "KvVariableFrequency", "ReadKvVariableOpV2", "DestroyKvVariableOpV2",
             "KvVariableGatherOrInsertV2", "KvVariableGatherOrInsertWithCounts", "KvVariableGatherOrZerosV2",
             "KvVariableGroupSparseApplyAdamV4", "KvVariableGroupSparseApplyAdamV3", "KvVariableSparseApplyAdagrad",
             "KvVariableSparseGroupSparseApplyFtrlV2", "KvVariableInsertV2", "KvVariableScatterUpdateV2",
             "KvVariableScatterAddV2", "KvVariableScatterSubV2", "KvVariableScatterMulV2", "KvVariableScatterDivV2",
-            "KvVariableScatterMinV2", "KvVariableScatterMaxV2"]
+            "KvVariableScatterMinV2", "KvVariableScatterMaxV2",
+            "KvVariableExport", "KvVariableImport", "KvVariableFullOrDeltaImport", "KvVariableFullOrDeltaImportV2",
+            "KvVariableFullOrDeltaExport", "KvVariableSizeV3", "KvVariableGetCountV2", "KvVariableGetTimeStamp",
+            "KvVariableDelete", "KvVariableDeleteWithTimestamp", "BatchKvVariableGatherOrZerosV2",
+            "KvVariableIncreaseCountV2"]
+
+# ops the reference's Python layer also names but that are outside the hot path and its neighbours:
+# multi-hash variables, snapshots / remote tables / the dynamic restore and save_v3 checkpoint plumbing, and the
+# separate-slot GroupAdam variants that only non-default kv_options reach
+EXCLUDED = {"append_kv_variable_for_multi_hash", "kv_variable_export_for_multi_hash", "kv_variable_apply_snapshot",
+            "kv_variable_apply_snapshot_v2", "kv_variable_dynamic_restore", "kv_variable_load_remote_table", "save_v3",
+            "kv_variable_group_sparse_apply_adam_v2", "kv_variable_group_sparse_apply_adam_new_v2"}
+REF_PY = "/root/reference/tfplus/kv_variable/python"
+
+
+def _snake(name):
+  """TF's op-name -> python wrapper name rule (KvVariableV4 -> kv_variable_v4)."""
+  out = re.sub(r"(?<=[a-z0-9])(?=[A-Z])|(?<=[A-Z])(?=[A-Z][a-z])", "_", name).lower()
+  return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PY), reason="reference tree not present")
+def test_required_covers_what_the_reference_python_layer_calls():
+  files = [os.path.join(REF_PY, "ops", f) for f in ("kv_variable_ops.py", "embedding_ops.py", "variable_scope.py")] + \
+          [os.path.join(REF_PY, "training", f) for f in ("group_adam.py", "adagrad.py", "sparse_group_ftrl.py", "adam.py",
+                                                         "gradient_descent.py")]
+  called = set()
+  for f in files:
+    if os.path.exists(f):
+      called |= set(re.findall(r"gen_kv_variable_ops\.([a-z_0-9]+)", open(f).read()))
+  have = {_snake(n) for n in REQUIRED}
+  missing = sorted(called - have - EXCLUDED)
+  assert not missing, missing
 
 
 def _strip_comments(text):

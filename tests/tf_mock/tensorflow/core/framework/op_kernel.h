@@ -24,6 +24,7 @@ using int64 = long long;
 using int32 = int;
 using uint32 = unsigned;
 typedef unsigned long long uint64;
+typedef unsigned short uint16;
 class mutex {
  public:
   void lock();

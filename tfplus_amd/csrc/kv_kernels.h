@@ -1722,10 +1722,12 @@ __global__ void k_dedup_inverse(WsDev w, long long n, int* inverse) {
 constexpr int RT = 1024;  // ids per routing tile (256 threads x 4)
 constexpr int MAXW = 64;
 
-// rule 0 (default): mix64(id) % world — balanced whatever the ids look like; rule 1: floor_mod(id, world), the
+// rule 0 (default): (mix64(id) >> 32) % world — balanced whatever the ids look like; rule 1: floor_mod(id, world), the
 // reference's `ids % num_shards` (python/ops/embedding_ops.py:121-127), for checkpoint compatibility
 __device__ __forceinline__ unsigned owner_rank(long long id, int world, int rule) {
-  if (rule == 0) return (unsigned)(mix64((unsigned long long)id) % (unsigned long long)world);
+  // (the HIGH half of the hash: the index's home slot is mix64(key) & mask — with the low bits every key of a rank
+  // would share its low home-slot bits and the probe chains of a rank's table would cluster)
+  if (rule == 0) return (unsigned)((mix64((unsigned long long)id) >> 32) % (unsigned long long)world);
   long long m = id % world;
   return (unsigned)(m < 0 ? m + world : m);
 }

@@ -881,6 +881,16 @@ int hand_over(kv_table* t, hipStream_t s, bool join_side = true) {
   return KV_OK;
 }
 
+// ops that read a table without the full hand_over (no workspace, no row-set change): they still join the table's
+// side stream (overlap mode: the last lookup's partition pass may be initialising rows there)
+int join_side(kv_table* t, hipStream_t s) {
+  if (t->side_pending) {
+    HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
+    t->side_pending = false;
+  }
+  return KV_OK;
+}
+
 // locks tables in address order like MaybeLockVariableInputMutexesInOrder (training_ops.cc:96-184)
 struct MultiLock {
   std::vector<kv_table*> ts;
@@ -1200,6 +1210,7 @@ int kv_set_seed(kv_handle_t t, uint64_t seed) {
 }
 
 static int stats(kv_handle_t t, hipStream_t s, unsigned long long out[2], unsigned* nrows_out) {
+  { const int jr = join_side(t, s); if (jr) return jr; }
   unsigned c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1253,6 +1264,7 @@ int kv_get_meta(kv_handle_t t, const int64_t* ids, int64_t n, uint32_t* fw, uint
   if (n <= 0) return KV_OK;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = join_side(t, (hipStream_t)stream))) return rc;
   k_get_meta<long long><<<nblocks(n, TB), TB, 0, (hipStream_t)stream>>>(dev_view(t), (const long long*)ids, n, fw, fl);
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -1404,6 +1416,7 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = join_side(t, s))) return rc;
   const TableDev td = dev_view(t);
   const int q = t->dim / 4;
   const bool wave_shaped = (t->dim & 3) == 0 && q >= 1 && q <= 64 && (q & (q - 1)) == 0;
@@ -1499,6 +1512,8 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  for (int i = 0; i < num_tables; ++i)
+    if ((rc = join_side(tables[i], s))) return rc;
   BatchStage& st = g_stage[device][0];
   StageSlot* sl = nullptr;
   if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(BatchGatherDesc), &sl))) return rc;
@@ -2179,8 +2194,9 @@ int kv_delete(kv_handle_t t, const void* ids, int64_t n, int64_t* num_deleted, k
 }
 
 static int delete_locked(kv_table* t, const void* ids, int64_t n, int64_t* num_deleted, hipStream_t s) {
-  ++t->op_serial;
   int rc;
+  if ((rc = enter_op(t, s))) return rc;
+  t->batch_serial = 0;   // rows are released: an index of a batch that held them is void (its token goes stale)
   if ((rc = ensure_free_list(t, s))) return rc;
   HIP_TRY(hipMemsetAsync(t->d_stat, 0, 4 * sizeof(unsigned long long), s));
   const TableDev td = dev_view(t);
@@ -2210,6 +2226,7 @@ int kv_delete_with_timestamp(kv_handle_t t, int threshold, int dry_run, int64_t*
       return fail(KV_FAILED_PRECONDITION, "the table was used between the dry run and kv_delete_with_timestamp: the key "
                                           "buffer sized from the count may be too small; count again");
     ++t->op_serial;
+    t->batch_serial = 0;   // rows are released: an index of a batch that held them is void
   }
   unsigned nrows = 1;
   if ((rc = stats(t, s, nullptr, &nrows))) return rc;
@@ -2242,6 +2259,7 @@ static int count_or_ts(kv_handle_t t, const void* ids, int64_t n, int what, uint
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = join_side(t, s))) return rc;
   if (t->key_dtype == KV_DT_INT32)
     k_get_count_ts<int><<<nblocks(n, TB, 4096), TB, 0, s>>>(dev_view(t), (const int*)ids, n, what, today(t), out);
   else
@@ -2803,13 +2821,21 @@ int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_
   if (!self_rccl)
     HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer, (const char*)send + (size_t)c->rank * bytes_per_peer,
                            (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
-  if (c->world > 1 || self_rccl) NCCL_TRY(rccl()->GroupStart());
-  for (int p = 0; p < c->world; ++p) {
+  const bool grouped = c->world > 1 || self_rccl;
+  if (grouped) NCCL_TRY(rccl()->GroupStart());
+  ncclResult_t bad = ncclSuccess;   // a failed Send / Recv must not leave the group open on this communicator
+  for (int p = 0; p < c->world && bad == ncclSuccess; ++p) {
     if (p == c->rank && !self_rccl) continue;
-    NCCL_TRY(rccl()->Send((const char*)send + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
-    NCCL_TRY(rccl()->Recv((char*)recv + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream));
+    bad = rccl()->Send((const char*)send + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream);
+    if (bad == ncclSuccess)
+      bad = rccl()->Recv((char*)recv + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream);
   }
-  if (c->world > 1 || self_rccl) NCCL_TRY(rccl()->GroupEnd());
+  if (grouped) {
+    const ncclResult_t e = rccl()->GroupEnd();
+    if (bad == ncclSuccess) bad = e;
+  }
+  if (bad != ncclSuccess)
+    return fail(KV_INTERNAL, "grouped send / recv failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(bad) : "?");
   if (hop) {
     HIP_TRY(hipEventRecord(c->ev_out, c->stream));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_out, 0));

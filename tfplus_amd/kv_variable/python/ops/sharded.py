@@ -4,7 +4,7 @@ own link; no ring collective and no all-reduce anywhere on this path).
 
 The reference has no communication layer: multi-device there is TF1 PS/worker placement of
 partitioned variables with `ids % num_shards` (python/ops/embedding_ops.py:115-204,
-kernels/utility.h:90-107).  Ownership here is hashed by default (mix64(id) % world: raw Criteo-style ids
+kernels/utility.h:90-107).  Ownership here is hashed by default ((mix64(id) >> 32) % world: raw Criteo-style ids
 are not uniform mod 8); the reference's floor-mod rule is the "mod" option, under which a checkpoint
 partitioned by the reference maps shard-for-shard onto ranks.
 
@@ -52,14 +52,14 @@ def _mix64(x):
 
 
 def owner_of(ids, world, rule="hash"):
-  """Owner rank of every id.  "hash" (default): mix64(id) % world as an unsigned value — balanced whatever the ids
+  """Owner rank of every id.  "hash" (default): (mix64(id) >> 32) % world — balanced whatever the ids
   look like (kvhip.h KV_OWNER_HASH).  "mod": floor-mod (negative ids included), the reference's ModKeyImpl
   (utility.h:90-107), for checkpoints partitioned by it."""
   if rule == "mod":
     return torch.remainder(ids, world)
   h = _mix64(ids.to(torch.int64))
-  # unsigned h % world from the signed value: h + 2^64 for negative h
-  return torch.remainder(torch.remainder(h, world) + (h < 0).to(torch.int64) * ((1 << 64) % world), world)
+  # the high half of the hash (the table index takes its home slot from the low bits), as an unsigned 32-bit value
+  return torch.remainder((h >> 32) & 0xFFFFFFFF, world)
 
 
 def route(ids, group=None, bucket_fn=None, known_counts=None, n_dev=None, id_counts=None, rule="hash"):

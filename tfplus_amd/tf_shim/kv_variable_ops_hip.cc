@@ -127,6 +127,9 @@ class KvHipResource : public ResourceBase {
   const void* token_ids = nullptr;
   int64_t token_n = 0;
   uint64_t token_sum = 0;
+  // the init table as the graph gave it (KvVariableExport returns it: dynamic_save.hpp:110-118)
+  std::vector<float> init_host;
+  int64_t init_rows = 0;
 
  private:
   kv_handle_t h_;
@@ -137,13 +140,22 @@ class KvHipResource : public ResourceBase {
   std::mutex mu_;   // one Compute at a time moves data through this resource's ring
 };
 
-// cheap content fingerprint of an ids tensor (the token is only passed on when the optimizer op receives the
-// very ids the lookup saw; TF-core's de-duplicated indices never match and take the general path)
+// content fingerprint of an ids tensor: EVERY byte takes part (the token is only passed on when the optimizer op
+// receives the very ids the lookup saw — kvhip.h promises a right result only then; a sampled hash would let two
+// batches that differ in an unsampled id share an index).  The ids are on the host here and about to be copied
+// anyway; one multiply-xor per 8 bytes is nothing next to the PCIe transfer.  TF-core's de-duplicated indices
+// never match and take the general path.
 static uint64_t Fingerprint(const void* p, size_t bytes) {
   const unsigned char* c = static_cast<const unsigned char*>(p);
   uint64_t h = 1469598103934665603ull ^ bytes;
-  const size_t step = bytes > 4096 ? bytes / 512 : 1;
-  for (size_t i = 0; i < bytes; i += step) h = (h ^ c[i]) * 1099511628211ull;
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, c + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  for (; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ull;
   return h;
 }
 
@@ -355,6 +367,11 @@ class InitKvVariableHipOp : public OpKernel {
     OP_REQUIRES_OK(ctx, StagingRing::Upload(s, t.data(), t.TotalBytes(), r->stream()));
     OP_REQUIRES_OK(ctx, FromKv(kv_init_table(r->h(), reinterpret_cast<const float*>(s->dev), t.dim_size(0), r->stream())));
     OP_REQUIRES_OK(ctx, StagingRing::Release(s, r->stream()));
+    if (r->init_rows == 0) {   // first call wins, like the table's own copy (kv_variable.h:188-193)
+      const float* src = static_cast<const float*>(t.data());
+      r->init_host.assign(src, src + t.NumElements());
+      r->init_rows = t.dim_size(0);
+    }
   }
 };
 REGISTER_KERNEL_BUILDER(Name("InitKvVariableV2").Device(DEVICE_CPU), InitKvVariableHipOp);
@@ -858,5 +875,455 @@ class KvGroupFtrlHipOp : public OpKernel {
   }
 };
 KV_REGISTER_APPLY("KvVariableSparseGroupSparseApplyFtrlV2", KvGroupFtrlHipOp);
+
+// =====================================================================================================================
+// The ops the reference's Python layer needs to build a graph with a Saver (KvVariableSaveable,
+// python/ops/kv_variable_ops.py:1225-1227,1487,1629,1737; example/dcn/train.py:548) and its table hygiene calls.
+// Every kernel forwards to the C ABI call that already exists for it.
+// =====================================================================================================================
+
+// ---- KvVariableSizeV3 : ops :235-238, kernels/kv_variable_ops.cc:260-272 -> CountStorageSize
+//      (table_manager.h:473-478): one entry per storage tier; there is one tier: every key of the map -------------
+REGISTER_OP("KvVariableSizeV3")
+    .Input("table_handle: resource")
+    .Output("sizes: T")
+    .Attr("T: {int32, int64} = DT_INT64");
+
+class KvSizeV3HipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    int64_t v = 0;
+    OP_REQUIRES_OK(ctx, FromKv(kv_map_size(r->h(), &v, r->stream())));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({1}), &out));
+    out->flat<int64_t>()(0) = v;   // the reference fills an int64 tensor whatever T says (kv_variable.h:576-583)
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV3").Device(DEVICE_CPU), KvSizeV3HipOp);
+
+// ---- KvVariableGetCountV2 / KvVariableGetTimeStamp : ops :349-358, 687-697 -> kv_variable.h:503-561 ----------------
+REGISTER_OP("KvVariableGetCountV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Output("output: dtype")
+    .Attr("dtype: {int32} = DT_INT32")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+REGISTER_OP("KvVariableGetTimeStamp")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Output("output: dtype")
+    .Attr("dtype: {uint32} = DT_UINT32")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+template <bool STAMP>
+class KvCountHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    const Tensor& ids = ctx->input(1);
+    OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, ids.shape(), &out));
+    const int64_t n = ids.NumElements();
+    if (n == 0) return;
+    std::lock_guard<std::mutex> l(*r->mu());
+    StagingRing::Slot *si = nullptr, *so = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si));
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(out->TotalBytes(), &so));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(si, ids.data(), ids.TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, FromKv(STAMP ? kv_get_timestamp(r->h(), si->dev, n, reinterpret_cast<uint32_t*>(so->dev), r->stream())
+                                     : kv_get_count(r->h(), si->dev, n, reinterpret_cast<int32_t*>(so->dev), r->stream())));
+    OP_REQUIRES_OK(ctx, StagingRing::Download(so, out->data(), out->TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(si, r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(so, r->stream()));
+  }
+};
+#define KV_REGISTER_IDS_OP(NAME, ...)                                                                                      \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int32>("Tindices"), __VA_ARGS__);   \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<int64_t>("Tindices"), __VA_ARGS__); \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).HostMemory("table_handle").TypeConstraint<uint64>("Tindices"), __VA_ARGS__)
+KV_REGISTER_IDS_OP("KvVariableGetCountV2", KvCountHipOp<false>);
+KV_REGISTER_IDS_OP("KvVariableGetTimeStamp", KvCountHipOp<true>);
+
+// ---- KvVariableIncreaseCountV2 : ops :342-347; the reference's kernel does nothing (kernels/kv_variable_ops.cc:749-764)
+REGISTER_OP("KvVariableIncreaseCountV2")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Input("counts: int32")
+    .Attr("Tindices: {int32, int64, uint64, string}");
+
+class KvIncreaseCountHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);   // the handle must name a table; nothing else happens, as in the reference
+    (void)r;
+  }
+};
+KV_REGISTER_IDS_OP("KvVariableIncreaseCountV2", KvIncreaseCountHipOp);
+
+// ---- KvVariableDelete / KvVariableDeleteWithTimestamp : ops :681-685, 698-706 -> kv_variable.h:737-789 -------------
+REGISTER_OP("KvVariableDelete")
+    .Input("table_handle: resource")
+    .Input("indices: Tindices")
+    .Attr("Tindices: {int32, int64, uint64, string}");
+
+class KvDeleteHipOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    const Tensor& ids = ctx->input(1);
+    OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
+    const int64_t n = ids.NumElements();
+    if (n == 0) return;
+    std::lock_guard<std::mutex> l(*r->mu());
+    r->token = 0;   // rows go away: no index of an earlier batch may be taken over
+    StagingRing::Slot* si = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si));
+    OP_REQUIRES_OK(ctx, StagingRing::Upload(si, ids.data(), ids.TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, FromKv(kv_delete(r->h(), si->dev, n, nullptr, r->stream())));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(si, r->stream()));
+  }
+};
+KV_REGISTER_IDS_OP("KvVariableDelete", KvDeleteHipOp);
+
+REGISTER_OP("KvVariableDeleteWithTimestamp")
+    .Input("table_handle: resource")
+    .Output("delete_keys: Tkeys")
+    .Attr("Tkeys: type")
+    .Attr("threshold: int=7");
+
+class KvDeleteWithTimestampHipOp : public OpKernel {
+ public:
+  explicit KvDeleteWithTimestampHipOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("threshold", &threshold_)); }
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    OP_REQUIRES(ctx, r->key_dtype() != DT_INT32, errors::Unimplemented("KvVariableDeleteWithTimestamp with int32 keys"));
+    std::lock_guard<std::mutex> l(*r->mu());
+    r->token = 0;
+    int64_t count = 0;   // dry run: how many keys are old enough — sizes the output (kv_variable.h:757-789)
+    OP_REQUIRES_OK(ctx, FromKv(kv_delete_with_timestamp(r->h(), threshold_, 1, nullptr, &count, r->stream())));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({count}), &out));
+    if (count == 0) return;
+    StagingRing::Slot* sk = nullptr;
+    OP_REQUIRES_OK(ctx, r->ring()->Acquire(out->TotalBytes(), &sk));
+    OP_REQUIRES_OK(ctx, FromKv(kv_delete_with_timestamp(r->h(), threshold_, 0, reinterpret_cast<int64_t*>(sk->dev), &count, r->stream())));
+    OP_REQUIRES_OK(ctx, StagingRing::Download(sk, out->data(), out->TotalBytes(), r->stream()));
+    OP_REQUIRES_OK(ctx, StagingRing::Release(sk, r->stream()));
+  }
+
+ private:
+  int threshold_ = 7;
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableDeleteWithTimestamp").Device(DEVICE_CPU), KvDeleteWithTimestampHipOp);
+
+// ---- BatchKvVariableGatherOrZerosV2 : ops :297-308, kernels/kv_variable_ops.cc:431-470 (the reference loops over the
+//      tables; kv_batch_gather_or_zeros covers them with one launch).  Inputs: N handles, then N index tensors. --------
+REGISTER_OP("BatchKvVariableGatherOrZerosV2")
+    .Input("table_handles: N * resource")
+    .Input("indices: N * Tindices")
+    .Output("output: N * dtype")
+    .Attr("N: int >= 1")
+    .Attr("dtype: type")
+    .Attr("Tindices: {int32, int64, uint64, string}")
+    .SetShapeFn(UnknownOutput);
+
+class KvBatchGatherHipOp : public OpKernel {
+ public:
+  explicit KvBatchGatherHipOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("N", &n_)); }
+  void Compute(OpKernelContext* ctx) override {
+    std::vector<KvHipResource*> rs((size_t)n_, nullptr);
+    std::vector<core::ScopedUnref> unref;
+    unref.reserve((size_t)n_);
+    for (int i = 0; i < n_; ++i) {
+      OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, i), &rs[(size_t)i]));
+      unref.emplace_back(rs[(size_t)i]);
+    }
+    // every table's ids and rows travel through the FIRST table's stream (one launch serves them all); each
+    // resource's ring stages its own tensors
+    hipStream_t st = rs[0]->stream();
+    std::vector<kv_handle_t> hs((size_t)n_);
+    std::vector<const void*> idp((size_t)n_);
+    std::vector<int64_t> ns((size_t)n_);
+    std::vector<float*> outp((size_t)n_);
+    std::vector<StagingRing::Slot*> si((size_t)n_, nullptr), so((size_t)n_, nullptr);
+    std::vector<Tensor*> outs((size_t)n_, nullptr);
+    for (int i = 0; i < n_; ++i) {
+      KvHipResource* r = rs[(size_t)i];
+      const Tensor& ids = ctx->input(n_ + i);
+      OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
+      TensorShape shape = ids.shape();
+      shape.AddDim(r->dim());
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, shape, &outs[(size_t)i]));
+      hs[(size_t)i] = r->h();
+      ns[(size_t)i] = ids.NumElements();
+      if (ns[(size_t)i] == 0) continue;
+      std::lock_guard<std::mutex> l(*r->mu());
+      OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si[(size_t)i]));
+      OP_REQUIRES_OK(ctx, r->ring()->Acquire(outs[(size_t)i]->TotalBytes(), &so[(size_t)i]));
+      OP_REQUIRES_OK(ctx, StagingRing::Upload(si[(size_t)i], ids.data(), ids.TotalBytes(), st));
+      idp[(size_t)i] = si[(size_t)i]->dev;
+      outp[(size_t)i] = reinterpret_cast<float*>(so[(size_t)i]->dev);
+    }
+    OP_REQUIRES_OK(ctx, FromKv(kv_batch_gather_or_zeros(n_, hs.data(), idp.data(), ns.data(), outp.data(), st)));
+    for (int i = 0; i < n_; ++i) {
+      if (ns[(size_t)i] == 0) continue;
+      OP_REQUIRES_OK(ctx, StagingRing::Download(so[(size_t)i], outs[(size_t)i]->data(), outs[(size_t)i]->TotalBytes(), st));
+      OP_REQUIRES_OK(ctx, StagingRing::Release(si[(size_t)i], st));
+      OP_REQUIRES_OK(ctx, StagingRing::Release(so[(size_t)i], st));
+    }
+  }
+
+ private:
+  int n_ = 1;
+};
+KV_REGISTER_IDS_OP("BatchKvVariableGatherOrZerosV2", KvBatchGatherHipOp);
+
+// ---- KvVariableExport / KvVariableFullOrDeltaExport : ops :421-447, 633-665, kernels/kv_variable_ops.cc:990-1017,
+//      1064-1095 -> ExportValues / DeltaExport (dynamic_save.hpp:47-195, 198-451).  Outputs: keys, values, init_table,
+//      blacklist, freq_keys, freq_values (uint16 counts for Export, uint32 words for FullOrDelta), and for the latter
+//      need_full_import, delete_keys.  enable_cutoff re-thresholds the rows before the export; not offered here. ------
+REGISTER_OP("KvVariableExport")
+    .Input("table_handle: resource")
+    .Output("keys: Tkeys")
+    .Output("values: Tvalues")
+    .Output("init_table: Tvalues")
+    .Output("blacklist: Tkeys")
+    .Output("freq_keys: Tkeys")
+    .Output("freq_values: uint16")
+    .Attr("Tkeys: type")
+    .Attr("Tvalues: type")
+    .Attr("enable_cutoff: bool = false")
+    .Attr("cutoff_value: float = 0.0")
+    .Attr("first_n: int=3");
+
+REGISTER_OP("KvVariableFullOrDeltaExport")
+    .Input("table_handle: resource")
+    .Input("do_full_export: bool")
+    .Output("keys: Tkeys")
+    .Output("values: Tvalues")
+    .Output("init_table: Tvalues")
+    .Output("blacklist: Tkeys")
+    .Output("freq_keys: Tkeys")
+    .Output("freq_values: uint32")
+    .Output("need_full_import: bool")
+    .Output("delete_keys: Tkeys")
+    .Attr("Tkeys: type")
+    .Attr("Tvalues: type")
+    .Attr("enable_cutoff: bool = false")
+    .Attr("cutoff_value: float = 0.0")
+    .Attr("first_n: int=3");
+
+template <bool FULL_OR_DELTA>
+class KvExportHipOp : public OpKernel {
+ public:
+  explicit KvExportHipOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("first_n", &first_n_));
+    OP_REQUIRES_OK(c, c->GetAttr("enable_cutoff", &enable_cutoff_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    OP_REQUIRES(ctx, r->key_dtype() != DT_INT32, errors::Unimplemented("export with int32 keys"));
+    OP_REQUIRES(ctx, !enable_cutoff_, errors::Unimplemented("export with enable_cutoff = true"));
+    bool full = true;
+    if (FULL_OR_DELTA) full = ctx->input(1).flat<bool>()(0);
+    std::lock_guard<std::mutex> l(*r->mu());
+    int64_t counts[4] = {0, 0, 0, 0};
+    if (full) OP_REQUIRES_OK(ctx, FromKv(kv_export_count(r->h(), first_n_, counts, r->stream())));
+    else OP_REQUIRES_OK(ctx, FromKv(kv_export_delta_count(r->h(), first_n_, counts, r->stream())));
+    Tensor *keys = nullptr, *values = nullptr, *init = nullptr, *black = nullptr, *fk = nullptr, *fv = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({counts[0]}), &keys));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({counts[0], r->dim()}), &values));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(2, TensorShape({r->init_rows, r->dim()}), &init));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(3, TensorShape({counts[1]}), &black));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(4, TensorShape({counts[2]}), &fk));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(5, TensorShape({counts[2]}), &fv));
+    Tensor *need = nullptr, *del = nullptr;
+    if (FULL_OR_DELTA) {
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(6, TensorShape({}), &need));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(7, TensorShape({counts[3]}), &del));
+      need->scalar<bool>()() = full;
+    }
+    if (r->init_rows) std::memcpy(init->data(), r->init_host.data(), r->init_host.size() * sizeof(float));
+    StagingRing::Slot *sk = nullptr, *sv = nullptr, *sb = nullptr, *sfk = nullptr, *sfv = nullptr, *sd = nullptr;
+    auto want = [&](int64_t m, size_t elem, StagingRing::Slot** sl) -> Status {
+      return m > 0 ? r->ring()->Acquire((size_t)m * elem, sl) : OkStatus();
+    };
+    OP_REQUIRES_OK(ctx, want(counts[0], 8, &sk));
+    OP_REQUIRES_OK(ctx, want(counts[0] * r->dim(), 4, &sv));
+    OP_REQUIRES_OK(ctx, want(counts[1], 8, &sb));
+    OP_REQUIRES_OK(ctx, want(counts[2], 8, &sfk));
+    OP_REQUIRES_OK(ctx, want(counts[2], 4, &sfv));     // the library hands out the 32-bit frequency words
+    OP_REQUIRES_OK(ctx, want(counts[3], 8, &sd));
+    auto dp = [](StagingRing::Slot* sl) -> void* { return sl ? sl->dev : nullptr; };
+    // the table cannot change between count and fill: this resource's mutex is held and every op that writes the
+    // table goes through a kernel of this file
+    if (full)
+      OP_REQUIRES_OK(ctx, FromKv(kv_export_fill(r->h(), first_n_, static_cast<int64_t*>(dp(sk)), static_cast<float*>(dp(sv)),
+                                                static_cast<int64_t*>(dp(sb)), static_cast<int64_t*>(dp(sfk)),
+                                                static_cast<uint32_t*>(dp(sfv)), r->stream())));
+    else
+      OP_REQUIRES_OK(ctx, FromKv(kv_export_delta_fill(r->h(), first_n_, static_cast<int64_t*>(dp(sk)), static_cast<float*>(dp(sv)),
+                                                      static_cast<int64_t*>(dp(sb)), static_cast<int64_t*>(dp(sfk)),
+                                                      static_cast<uint32_t*>(dp(sfv)), static_cast<int64_t*>(dp(sd)), r->stream())));
+    if (sk) OP_REQUIRES_OK(ctx, StagingRing::Download(sk, keys->data(), keys->TotalBytes(), r->stream()));
+    if (sv) OP_REQUIRES_OK(ctx, StagingRing::Download(sv, values->data(), values->TotalBytes(), r->stream()));
+    if (sb) OP_REQUIRES_OK(ctx, StagingRing::Download(sb, black->data(), black->TotalBytes(), r->stream()));
+    if (sfk) OP_REQUIRES_OK(ctx, StagingRing::Download(sfk, fk->data(), fk->TotalBytes(), r->stream()));
+    if (sfv) {
+      if (FULL_OR_DELTA) {
+        OP_REQUIRES_OK(ctx, StagingRing::Download(sfv, fv->data(), fv->TotalBytes(), r->stream()));
+      } else {
+        // KvVariableExport's freq_values are uint16 counts: the low half of the word (dynamic_save.hpp:160-166)
+        std::vector<uint32_t> w32((size_t)counts[2]);
+        OP_REQUIRES_OK(ctx, StagingRing::Download(sfv, w32.data(), w32.size() * 4, r->stream()));
+        uint16* dst = fv->flat<uint16>().data();
+        for (size_t i = 0; i < w32.size(); ++i) dst[i] = static_cast<uint16>(w32[i] & 0xFFFFu);
+      }
+    }
+    if (sd) OP_REQUIRES_OK(ctx, StagingRing::Download(sd, del->data(), del->TotalBytes(), r->stream()));
+    for (StagingRing::Slot* sl : {sk, sv, sb, sfk, sfv, sd})
+      if (sl) OP_REQUIRES_OK(ctx, StagingRing::Release(sl, r->stream()));
+  }
+
+ private:
+  int first_n_ = 3;
+  bool enable_cutoff_ = false;
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableExport").Device(DEVICE_CPU), KvExportHipOp<false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaExport").Device(DEVICE_CPU), KvExportHipOp<true>);
+
+// ---- KvVariableImport / KvVariableFullOrDeltaImport[V2] : ops :361-378, 576-631, kernels/kv_variable_ops.cc:779-988
+//      -> ImportValues / DeltaImport (dynamic_restore.hpp:29-195).  Inputs: keys, values, init_table, blacklist,
+//      freq_keys, freq_values (uint16 | uint32) [, need_full_import, delete_keys [, is_loading_finished]] -----------
+REGISTER_OP("KvVariableImport")
+    .Input("table_handle: resource")
+    .Input("keys: Tin")
+    .Input("values: Tout")
+    .Input("init_table: Tout")
+    .Input("blacklist: Tin")
+    .Input("freq_keys: Tin")
+    .Input("freq_values: uint16")
+    .Attr("Tin: type")
+    .Attr("Tout: type")
+    .Attr("first_n: int=6");
+
+REGISTER_OP("KvVariableFullOrDeltaImport")
+    .Input("table_handle: resource")
+    .Input("keys: Tin")
+    .Input("values: Tout")
+    .Input("init_table: Tout")
+    .Input("blacklist: Tin")
+    .Input("freq_keys: Tin")
+    .Input("freq_values: uint32")
+    .Input("need_full_import: bool")
+    .Input("delete_keys: Tin")
+    .Attr("Tin: type")
+    .Attr("Tout: type")
+    .Attr("first_n: int=6");
+
+REGISTER_OP("KvVariableFullOrDeltaImportV2")
+    .Input("table_handle: resource")
+    .Input("keys: Tin")
+    .Input("values: Tout")
+    .Input("init_table: Tout")
+    .Input("blacklist: Tin")
+    .Input("freq_keys: Tin")
+    .Input("freq_values: uint32")
+    .Input("need_full_import: bool")
+    .Input("delete_keys: Tin")
+    .Input("is_loading_finished: bool")
+    .Attr("Tin: type")
+    .Attr("Tout: type")
+    .Attr("first_n: int=6");
+
+// KIND 0 = Import (uint16 counts, always full), 1 = FullOrDeltaImport, 2 = ...V2 (is_loading_finished is the
+// reference's hint to its own loader threads; nothing to do with it here)
+template <int KIND>
+class KvImportHipOp : public OpKernel {
+ public:
+  explicit KvImportHipOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("first_n", &first_n_)); }
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    OP_REQUIRES(ctx, r->key_dtype() != DT_INT32, errors::Unimplemented("import with int32 keys"));
+    const Tensor& keys = ctx->input(1);
+    const Tensor& values = ctx->input(2);
+    const Tensor& init = ctx->input(3);
+    OP_REQUIRES(ctx, values.dims() == 2 && values.dim_size(0) == keys.NumElements() && values.dim_size(1) == r->dim(),
+                errors::InvalidArgument("values must be [", keys.NumElements(), ", ", r->dim(), "]: ", values.shape().DebugString()));
+    const bool full = KIND == 0 ? true : ctx->input(7).flat<bool>()(0);
+    const Tensor* black = first_n_ > 3 ? &ctx->input(4) : nullptr;          // kernels/kv_variable_ops.cc:808-814
+    const Tensor* fk = first_n_ > 4 ? &ctx->input(5) : nullptr;             // :817-824
+    const Tensor* fv = first_n_ > 4 ? &ctx->input(6) : nullptr;
+    const Tensor* del = KIND >= 1 ? &ctx->input(8) : nullptr;
+    if (fk) OP_REQUIRES(ctx, fk->NumElements() == fv->NumElements(), errors::InvalidArgument("freq_keys and freq_values differ in length"));
+    std::lock_guard<std::mutex> l(*r->mu());
+    r->token = 0;
+    // the init table travels with the checkpoint: a table that has none yet takes this one (dynamic_restore.hpp:160-175)
+    if (init.NumElements() > 0 && init.dims() == 2 && init.dim_size(1) == r->dim()) {
+      StagingRing::Slot* st = nullptr;
+      OP_REQUIRES_OK(ctx, r->ring()->Acquire(init.TotalBytes(), &st));
+      OP_REQUIRES_OK(ctx, StagingRing::Upload(st, init.data(), init.TotalBytes(), r->stream()));
+      OP_REQUIRES_OK(ctx, FromKv(kv_init_table(r->h(), reinterpret_cast<const float*>(st->dev), init.dim_size(0), r->stream())));
+      OP_REQUIRES_OK(ctx, StagingRing::Release(st, r->stream()));
+      if (r->init_rows == 0) {
+        const float* src = static_cast<const float*>(init.data());
+        r->init_host.assign(src, src + init.NumElements());
+        r->init_rows = init.dim_size(0);
+      }
+    }
+    StagingRing::Slot *sk = nullptr, *sv = nullptr, *sb = nullptr, *sfk = nullptr, *sfv = nullptr, *sd = nullptr;
+    auto up = [&](const Tensor* t, StagingRing::Slot** sl) -> Status {
+      if (!t || t->NumElements() == 0) return OkStatus();
+      TF_RETURN_IF_ERROR(r->ring()->Acquire(t->TotalBytes(), sl));
+      return StagingRing::Upload(*sl, t->data(), t->TotalBytes(), r->stream());
+    };
+    OP_REQUIRES_OK(ctx, up(&keys, &sk));
+    OP_REQUIRES_OK(ctx, up(&values, &sv));
+    OP_REQUIRES_OK(ctx, up(black, &sb));
+    OP_REQUIRES_OK(ctx, up(fk, &sfk));
+    if (fv && fv->NumElements() > 0) {
+      if (KIND == 0) {   // uint16 counts -> the 32-bit words the library stores (day 0)
+        std::vector<uint32_t> w32((size_t)fv->NumElements());
+        const uint16* src = fv->flat<uint16>().data();
+        for (size_t i = 0; i < w32.size(); ++i) w32[i] = src[i];
+        OP_REQUIRES_OK(ctx, r->ring()->Acquire(w32.size() * 4, &sfv));
+        OP_REQUIRES_OK(ctx, StagingRing::Upload(sfv, w32.data(), w32.size() * 4, r->stream()));
+      } else {
+        OP_REQUIRES_OK(ctx, up(fv, &sfv));
+      }
+    }
+    if (!full) OP_REQUIRES_OK(ctx, up(del, &sd));
+    auto dp = [](StagingRing::Slot* sl) -> const void* { return sl ? sl->dev : nullptr; };
+    auto cnt = [](const Tensor* t) -> int64_t { return t ? t->NumElements() : 0; };
+    int rc;
+    if (full)
+      rc = kv_import(r->h(), static_cast<const int64_t*>(dp(sk)), static_cast<const float*>(dp(sv)), keys.NumElements(),
+                     static_cast<const int64_t*>(dp(sb)), cnt(black), static_cast<const int64_t*>(dp(sfk)),
+                     static_cast<const uint32_t*>(dp(sfv)), cnt(fk), r->stream());
+    else
+      rc = kv_import_delta(r->h(), static_cast<const int64_t*>(dp(sk)), static_cast<const float*>(dp(sv)), keys.NumElements(),
+                           static_cast<const int64_t*>(dp(sb)), cnt(black), static_cast<const int64_t*>(dp(sfk)),
+                           static_cast<const uint32_t*>(dp(sfv)), cnt(fk), static_cast<const int64_t*>(dp(sd)), cnt(del),
+                           first_n_, r->stream());
+    OP_REQUIRES_OK(ctx, FromKv(rc));
+    for (StagingRing::Slot* sl : {sk, sv, sb, sfk, sfv, sd})
+      if (sl) OP_REQUIRES_OK(ctx, StagingRing::Release(sl, r->stream()));
+  }
+
+ private:
+  int first_n_ = 6;
+};
+REGISTER_KERNEL_BUILDER(Name("KvVariableImport").Device(DEVICE_CPU), KvImportHipOp<0>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImport").Device(DEVICE_CPU), KvImportHipOp<1>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImportV2").Device(DEVICE_CPU), KvImportHipOp<2>);
 
 }  // namespace tfplus_hip
