@@ -34,6 +34,9 @@ def test_bench_single_gpu_line():
   assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
   cb = d["cpu_baseline"]
   assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+  # what the drop-in runs, next to the headline: op boundary, no token, staged through pinned host memory; other skews
+  assert d["op_boundary"]["ms"] > 0 and d["no_token"]["ms_per_step"] > 0 and d["staged"]["ms_per_step"] > 0
+  assert [x["zipf"] for x in d["skew_sweep"]] == [0.3, 0.8, 1.2] and "repeated_id_tolerance" in d
 
 
 @pytest.mark.gpu
@@ -48,3 +51,20 @@ def test_bench_two_ranks_control_flow():
   assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
   d = _line(r.stdout)
   assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 400000 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` without a launcher: the parent starts the ranks as child processes before it touches
+  the GPU and relays rank 0's line (how the driver may call it)."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  env = dict(os.environ, KV_BENCH_ONE_GPU="1")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--keys", "1000000",
+                      "--batch", "200000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+  d = _line(r.stdout)
+  assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 400000 and d["value"] > 0
+  assert d["exchange"]["wire_bytes_per_rank_per_step"] > 0

@@ -347,7 +347,13 @@ __device__ __forceinline__ unsigned part_of(long long key, int pshift) {
 
 // exclusive scan of one value per thread across the block (NW = waves per block);
 // wtot: LDS scratch [NW + 1]; returns the exclusive prefix, *total = block sum.
-template <int NW>
+// A barrier that orders LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL loads (its fence
+// drains vmcnt), which exposes the latency of loads requested ahead of time (index probes, id loads) at the first
+// barrier behind them.  Where every hand-over between the waves goes through LDS, this one lets them stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDSONLY: barriers that leave global loads in flight (lds_barrier)
+template <int NW, bool LDSONLY = false>
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* wtot, unsigned* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned incl = v;
@@ -356,9 +362,9 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* wtot, 
     const unsigned x = __shfl_up(incl, o);
     if (lane >= o) incl += x;
   }
-  __syncthreads();  // wtot may still be read from a previous scan
+  if (LDSONLY) lds_barrier(); else __syncthreads();  // wtot may still be read from a previous scan
   if (lane == 63) wtot[wv] = incl;
-  __syncthreads();
+  if (LDSONLY) lds_barrier(); else __syncthreads();
   unsigned base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < NW; ++i) {

@@ -84,6 +84,8 @@ __device__ __forceinline__ unsigned tile_insert(const TableDev& t, long long key
 // ------------------------------------------------------------------------------------------
 // k_ltile
 // ------------------------------------------------------------------------------------------
+// (Barriers: lds_barrier, kv_device.h — the probes and the id loads stay in flight across them; the deterministic
+// mode's re-read of ent_key through global memory keeps the full barrier.)
 // The position whose LDS insert created a key's slot is the key's WINNER: it probes the table for the key (the
 // request leaves right behind the hash insert and is collected behind the counting sort), takes the key's place in
 // the partition sort and writes its entry.  No list of occupied slots is built.
@@ -177,6 +179,9 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   for (int s = tid; s <= LS; s += TBT) { sm.lkeys[s] = EMPTY_KEY; sm.lcnt[s] = 0; }
   for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
   if (tid == 0) lsent = 0;
+  if (tile == 0 && tid == 0 && t.err_host)   // the distinct keys the previous index pass counted: a hint for the host (partitions)
+    __hip_atomic_store(t.err_host + 1, w.ctr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  lds_barrier();
   if (tile == 0 && tid < 8) w.ctr[tid] = 0;
   if constexpr (PAIRS) {
 #pragma unroll
@@ -191,7 +196,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       if (!ok) there &= ~(1u << k);
     }
   }
-  __syncthreads();
+  lds_barrier();
+  KV_STAMP(7);
 
   // ---- phase 1: LDS hash insert of the tile's ids; `win` bit k: this position created its key's slot ------------
   unsigned tslot[IPT], myrank[IPT];
@@ -220,6 +226,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       tslot[k] = h;
     }
   }
+  KV_STAMP(8);
   // ---- the winners' probes leave (one per distinct key; a position that is no winner asks for entry 0) -----------
   unsigned long long pp[IPT];
   Entry en[IPT];
@@ -228,7 +235,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     pp[k] = ((win >> k) & 1u) ? home_of(t, kreg[k], mix64((unsigned long long)kreg[k])) : 0ull;
     en[k] = load_entry(&t.entries[pp[k]]);
   }
-  __syncthreads();   // lcnt is final; lkeys is dead: its storage is lrow / escan from here on
+  KV_STAMP(9);
+  lds_barrier();   // lcnt is final; lkeys is dead: its storage is lrow / escan from here on
   KV_STAMP(1);
 
   // ---- phase 2: the distinct keys counting-sorted by owning partition ----------------------------------------------
@@ -242,18 +250,18 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       wr[k] = atomicAdd(&sm.hist[wp[k]], 1u | (wcnt[k] << 16)) & 0xFFFFu;
     }
   }
-  __syncthreads();
+  lds_barrier();
   {
     const unsigned per = (P + TBT - 1) / TBT;
     const unsigned p0 = tid * per, p1 = min(p0 + per, P);
     unsigned sum = 0;
     for (unsigned p = p0; p < p1; ++p) sum += sm.hist[p];
     unsigned tot;
-    unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
+    unsigned run = block_excl_scan<TBT / 64, true>(sum, sm.wtot, &tot);
     for (unsigned p = p0; p < p1; ++p) { const unsigned c = sm.hist[p]; sm.hist[p] = run; run += c; }
     if (tid == 0) sm.hist[P] = tot;
   }
-  __syncthreads();
+  lds_barrier();
   const unsigned nent = sm.hist[P] & 0xFFFFu;   // entries of the tile
   // partition-major: toff[p][tile] (k_part2's block p reads rows p and p + 1 as two contiguous runs)
   for (unsigned p = tid; p <= P; p += TBT) w.toff[(size_t)p * w.ntiles + tile] = sm.hist[p];
@@ -296,7 +304,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     // per entry for the scan below: its rows | 1, if it has more than one
     sm.escan[wpos[k]] = wcnt[k] > 1u ? (wcnt[k] | (1u << ES_NSH)) : 0u;
   }
-  __syncthreads();
+  lds_barrier();
   KV_STAMP(2);
 
   // ---- phase 3: the multi-occurrence entries: where their rows start in the tile's mrow image, their numbers --------
@@ -306,7 +314,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     unsigned sum = 0;
     for (unsigned e = e0; e < e1; ++e) sum += sm.escan[e];
     unsigned tot;
-    unsigned run = block_excl_scan<TBT / 64>(sum, sm.wtot, &tot);
+    unsigned run = block_excl_scan<TBT / 64, true>(sum, sm.wtot, &tot);
     for (unsigned e = e0; e < e1; ++e) { const unsigned c = sm.escan[e]; sm.escan[e] = run; run += c; }
     if (tid == 0) w.mcount[tile] = (tot & ES_POS) | ((tot >> ES_NSH) << 16);
   }
@@ -323,7 +331,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     w.ent_b[e] = r;
     w.ent_base[e] = hint;
   }
-  __syncthreads();
+  lds_barrier();
   KV_STAMP(3);
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
@@ -337,7 +345,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     // rank = occurrences of the key at smaller input positions (see tile_body of kv_kernels.h)
     unsigned short* run = sm.lrun;
     for (int e = tid; e <= TILE; e += TBT) run[e] = 0;
-    __syncthreads();
+    lds_barrier();
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
@@ -358,7 +366,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
           before = run[e];
           if (rw == 0u) run[e] = (unsigned short)(before + cnt);
         }
-        __syncthreads();
+        lds_barrier();
       }
       myrank[k] = valid ? before + rw : 0u;
     }
@@ -371,13 +379,13 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   // ---- per-occurrence counts: frequency sum per entry (hist is dead: reused) ----------------------------------
   if (has_counts) {
-    __syncthreads();
+    lds_barrier();
     for (unsigned e = tid; e <= (unsigned)TILE; e += TBT) sm.hist[e] = 0;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < IPT; ++k)
       if (tslot[k] != 0xFFFFFFFFu) atomicAdd(&sm.hist[sm.lpos[tslot[k]]], creg[k]);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
       if (wpos[k] == 0xFFFFFFFFu) continue;
@@ -385,7 +393,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       w.ent_a[(size_t)tile * TILE + wpos[k]] = wcnt[k] | ((f > 65535u ? 65535u : f) << 16);
     }
   }
-  __syncthreads();
+  lds_barrier();
   {
     unsigned* dst = w.mrow + (size_t)tile * TILE;
     for (int j = tid; j < TILE; j += TBT) dst[j] = sm.mr[j];
@@ -837,7 +845,10 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     __syncthreads();
     KV_STAMPP(4);
   }
-  if (tid == 0) w.pmeta[p] = make_uint4(lchunk + litm, lchunk, pbase, E);
+  if (tid == 0) {
+    w.pmeta[p] = make_uint4(lchunk + litm, lchunk, pbase, E);
+    atomicAdd(&w.ctr[5], lcold + lhot);   // distinct keys of the batch (no value returned: nothing waits for it)
+  }
 }
 template <int MODE>
 __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_body<MODE>(w, a); }

@@ -379,6 +379,8 @@ struct kv_table {
   uint64_t batch_serial = 0;
   long long batch_n = 0;
   bool fused_index = false;        // the index is an entry list (kv_fused.h), not a sorted position list
+  long long batch_n_prev = 0;      // ids of the previous entry-list index pass (the distinct-count hint belongs to that size)
+  unsigned index_P = 0;            // partitions of the entry-list index the workspace holds
   // overlap mode (kv_set_overlap): a side stream of the table's own; side_pending: it still runs the lookup's
   // partition pass — the table's next op joins it (ev_part) first
   bool overlap = false, side_pending = false;
@@ -552,7 +554,15 @@ int ensure_capacity(kv_table* t, long long extra, hipStream_t s) {
 // get 1024 blocks = one resident wave of blocks.  Above 1 M ids: ~1024 ids per partition (2 M ids ->
 // 2048 blocks in two waves; with 1024 the hot partitions overflow the LDS entry lists and split:
 // measured 331 us vs 2 x 70)
-unsigned pick_partitions(long long n) {
+// `many_distinct`: the table's recent batches held mostly distinct ids (err_host[1], below): twice the partitions,
+// so that a partition's distinct keys still fit the partition block's LDS hash in one round (1 M nearly distinct ids
+// over 1024 partitions are ~960 keys each against 768 slots: every block split its keys and read its entries three
+// times)
+unsigned pick_partitions(long long n, bool many_distinct = false) {
+  if (many_distinct && n >= (1ll << 18)) {
+    const unsigned P0 = pick_partitions(n, false);
+    return P0 < (unsigned)MAX_P ? P0 * 2u : P0;
+  }
   static const long long forced = [] { const char* e = getenv("KV_FORCE_P"); return e ? atoll(e) : 0ll; }();
   if (forced > 0) return (unsigned)forced;  // diagnostic A/B only (tools/)
   unsigned long long want = std::min<unsigned long long>(1024, (unsigned long long)((n + 31) / 32));
@@ -577,14 +587,14 @@ int regrow(T** p, size_t count) {
 
 int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   Workspace& w = t->ws;
-  const unsigned P = pick_partitions(n);
+  const unsigned P = pick_partitions(n, true);
   int rc;
   if (n > w.cap_n || P > w.capP) {
     HIP_TRY(hipStreamSynchronize(s));
     long long cap = std::max<long long>(n, TILE);
     if (w.cap_n) cap = std::max<long long>(cap, std::min<long long>(w.cap_n * 2, 1ll << 30));
     cap = (cap + TILE - 1) / TILE * TILE;
-    const unsigned capP = std::max(pick_partitions(cap), P);
+    const unsigned capP = std::max(pick_partitions(cap, true), P);
     const size_t nt = (size_t)(cap / TILE);
     // every buffer is replaced only once its successor exists; a failure leaves the old sizes in force
     w.cap_n = 0; w.capP = 0; w.hpart_elems = 0; w.epart_elems = 0;
@@ -945,6 +955,17 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
                      int ids_kind, float* out, hipStream_t s) {
   wd.hc = (unsigned)HC2;
   t->fused_index = true;
+  {
+    // the distinct ids of the batch before the last one (the tile pass hands the partition pass's count to the host
+    // through a pinned word, no synchronisation): mostly distinct ids -> twice the partitions
+    const unsigned u_prev = t->err_host ? reinterpret_cast<volatile unsigned*>(t->err_host)[1] : 0u;
+    // (not in deterministic mode: the partitioning decides the order of a tile's entries, hence of the additions —
+    // there it depends on the batch alone)
+    const bool many = !t->deterministic && (long long)u_prev * 2 > n && t->batch_n_prev == n;
+    t->batch_n_prev = n;
+    if (many) { wd.P = pick_partitions(n, true); wd.pshift = 64 - ilog2(wd.P); }
+    t->index_P = wd.P;
+  }
   if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
     // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
     // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
@@ -1110,12 +1131,12 @@ int kv_create(int key_dtype, int value_dtype, int dim, int enter_threshold, int6
       rc = fail(KV_RESOURCE_EXHAUSTED, "hipMalloc of table header failed");
       break;
     }
-    if (hipHostMalloc(&t->err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc(&t->err_host, 4 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
         hipEventCreateWithFlags(&t->last_done, hipEventDisableTiming) != hipSuccess) {
       rc = fail(KV_RESOURCE_EXHAUSTED, "table header: pinned word / event");
       break;
     }
-    *t->err_host = 0;
+    t->err_host[0] = t->err_host[1] = t->err_host[2] = t->err_host[3] = 0;
     t->uid = ++g_uid;
     unsigned init[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // next_row = 1 (row 0 is the zero row)
     if (hipMemcpy(t->d_counters, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1807,6 +1828,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
     v->batch_n = n;
   }
+  if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
   if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;

@@ -46,6 +46,9 @@ if len(tt):
                    ("entry scan, torder, mlist", 3, 4), ("output rows", 4, 5)):
     print("   %-48s %s" % (nm, med(tt[:, j] - tt[:, i])))
   print("   block total %s ; start %s ; last end %d" % (med(tt[:, 5] - tt[:, 0]), med(tt[:, 0] - b0), (tt[:, 5] - b0).max()))
+  if tt[:, 9].max() > 0:
+    for nm, i, j in (("  ids requested + LDS cleared + barrier", 0, 7), ("  hash insert", 7, 8), ("  probes requested", 8, 9), ("  barrier", 9, 1)):
+      print("   %-48s %s" % (nm, med(tt[:, j] - tt[:, i])))
 pt = a[4096:4096 + 1024].astype(np.int64); pt = pt[pt[:, 4] > 0]
 if len(pt):
   b0 = pt[:, 0].min()
