@@ -411,46 +411,69 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     auto copy_rows = [&](auto single_tag) {
       constexpr bool SINGLE = decltype(single_tag)::value;
       const float4* rows0 = reinterpret_cast<const float4*>(t.c0.rows);
+      constexpr int SPK = VQ / CW;          // pieces (CW copy instructions) per round k
+      constexpr int NP = IPT * SPK;
+      unsigned rr[IPT];
 #pragma unroll
-      for (int k = 0; k < IPT; ++k) {
+      for (int k = 0; k < IPT; ++k) rr[k] = tslot[k] != 0xFFFFFFFFu ? sm.lrow[tslot[k]] : 0u;   // skipped records read the zero row
+      auto issue = [&](int pc, float4 (&val)[CW]) {
+        const int k = pc / SPK, j0 = (pc % SPK) * CW;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          const unsigned rj = __shfl(rr[k], (j0 + j) * RW + sub) & ROW_MASK;
+          if constexpr (SINGLE) val[j] = rows0[(size_t)rj * VQ + v];
+          else val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj))[v];
+        }
+      };
+      auto flush = [&](int pc, float4 (&val)[CW]) {
+        const int k = pc / SPK, j0 = (pc % SPK) * CW;
         const long long r0 = base + (long long)k * TBT + (tid & ~63);
-        if (r0 >= n) break;
-        const unsigned rr = tslot[k] != 0xFFFFFFFFu ? sm.lrow[tslot[k]] : 0u;   // skipped records read the zero row
-        const bool anynew = __ballot((rr & NEW_BIT) != 0u) != 0ull;
-#pragma unroll
-        for (int j0 = 0; j0 < VQ; j0 += CW) {
-          float4 val[CW];
-          unsigned rj[CW];
-#pragma unroll
-          for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+        if (__builtin_expect(__ballot((rr[k] & NEW_BIT) != 0u) != 0ull, 0)) {
+          // a key inserted by this batch: its row is the init rule's value (kv_variable.h:889-898), written to the
+          // table by k_part2; here it is computed, not read
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
-            if constexpr (SINGLE) val[j] = rows0[(size_t)(rj[j] & ROW_MASK) * VQ + v];
-            else val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j] & ROW_MASK))[v];
-          }
-          if (__builtin_expect(anynew, 0)) {
-            // a key inserted by this batch: its row is the init rule's value (kv_variable.h:889-898), written to the
-            // table by k_part2; here it is computed, not read
-#pragma unroll
-            for (int j = 0; j < CW; ++j) {
-              const long long kj = __shfl(kreg[k], (j0 + j) * RW + sub);
-              if (rj[j] & NEW_BIT) {
-                const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
-                const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
-                const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
-                val[j] = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
-              }
+            const unsigned rj = __shfl(rr[k], (j0 + j) * RW + sub);
+            const long long kj = __shfl(kreg[k], (j0 + j) * RW + sub);
+            if (rj & NEW_BIT) {
+              const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
+              const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
+              const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
+              val[j] = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
             }
           }
+        }
 #pragma unroll
-          for (int j = 0; j < CW; ++j) {
-            const long long ii = r0 + (j0 + j) * RW + sub;
-            if (ii < n) {
-              float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
-              __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
-              __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
-            }
+        for (int j = 0; j < CW; ++j) {
+          const long long ii = r0 + (j0 + j) * RW + sub;
+          if (ii < n) {
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+            __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+            __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
           }
+        }
+      };
+      // two pieces in flight (NP is even: IPT = 4) where the registers allow two blocks per CU with them; the compiler
+      // barriers pin that schedule in the unrolled loop
+      float4 va[CW];
+      if constexpr (VQ <= 16) {
+        float4 vb[CW];
+        issue(0, va);
+#pragma unroll
+        for (int pc = 0; pc < NP; pc += 2) {
+          issue(pc + 1, vb);
+          asm volatile("" ::: "memory");
+          flush(pc, va);
+          if (pc + 2 < NP) issue(pc + 2, va);
+          asm volatile("" ::: "memory");
+          flush(pc + 1, vb);
+        }
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+          issue(pc, va);
+          flush(pc, va);
+          asm volatile("" ::: "memory");
         }
       }
     };
