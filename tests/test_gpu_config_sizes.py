@@ -70,13 +70,13 @@ def _adam_bound(gsum, gabs, cnt, alpha, omb1, omb2, eps32):
   return 1e-6 + slope * dg
 
 
-def _lookup_apply_check(ops, var, slot, K, D, table, seed, sample_max):
+def _lookup_apply_check(ops, var, slot, K, D, table, seed, sample_max, zipf=1.2):
   """one training step of the configs[1] / configs[3] shape + every check; returns (unique ids, sampled)."""
   import bench
   dev = torch.device("cuda", 0)
   N = 1_000_000
   gen = torch.Generator(device=dev).manual_seed(SEED + 2)
-  ids = bench.splitmix64(bench.Zipf(K, 1.2, dev).sample(N, gen))
+  ids = bench.splitmix64(bench.Zipf(K, zipf, dev).sample(N, gen))
   grad = torch.randn(N, D, device=dev, generator=gen) * 1e-2            # two-signed: sums of repeated ids cancel
   # ---- lookup: size-independent properties -------------------------------------------------------------
   f0 = ops.kv_variable_frequency(var)
@@ -146,6 +146,19 @@ def test_config1_50M_keys_1M_zipf_ids(ops):
   var, slot = _build(ops, K, D, table, seed=11)
   u, s = _lookup_apply_check(ops, var, slot, K, D, table, 11, sample_max=10 ** 9)   # every touched key
   assert 90_000 < u < 130_000 and s == u
+
+
+@pytest.mark.gpu
+def test_low_skew_1M_ids_zipf03(ops):
+  """the same step where nearly every id of the batch is distinct (Zipf 0.3: ~0.99 M keys per 1 M ids): the tile and
+  partition passes see no repeats to fold, the partition pass runs with twice the partitions after the first batch"""
+  _need_hbm(40)
+  rng = np.random.Generator(np.random.PCG64(SEED + 3))
+  D, K = 32, 20_000_000
+  table = (rng.standard_normal((10000, D)) * 0.05).astype(np.float32)
+  var, slot = _build(ops, K, D, table, seed=12)
+  u, s = _lookup_apply_check(ops, var, slot, K, D, table, 12, sample_max=100_000, zipf=0.3)
+  assert u > 950_000 and s == 100_000
 
 
 @pytest.mark.gpu
@@ -302,3 +315,39 @@ def test_config4_one_rank_share_32_tables(ops):
 def test_config4_all_256_tables(ops):
   keys = _run_config4(ops, 256, 4096, 4e7, steps=2)
   assert keys > 256 * 50
+
+
+@pytest.mark.gpu
+def test_apply_four_million_ids_in_one_call(ops):
+  """one optimizer call takes more than 2^21 ids (the reference's op shards any N, training_ops.cc:7205-7208): 4 M ids
+  over 300 k keys, the lookup's token and the apply's own index pass, against the oracle's sum-then-apply."""
+  rng = np.random.default_rng(SEED + 9)
+  D, N = 8, 4_000_000
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  ids = (rng.zipf(1.3, N) % 300_000).astype(np.int64)
+  sign = rng.choice([-1.0, 1.0], (1, D))
+  grad = (rng.uniform(0.5, 1.5, (N, D)) * 1e-2 * sign).astype(np.float32)   # one-signed: no cancelling sums
+  ov = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=5)
+  os_ = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY, picker=1, seed=5)
+  want_rows = ov.gather_or_insert(ids)
+  u, sm, _ = ko.dedup_segment_sum(ids, grad)
+  ko.apply_group_adam(ov, os_, sm, u, 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8)
+  exp = ov.gather_or_zeros(u)
+  ids_t, grad_t = torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda()
+  for with_token in (True, False):
+    hv = ops.kv_variable([D]); hs = ops.kv_variable([3 * D])
+    for h, t in ((hv, table), (hs, np.zeros((4, 3 * D), np.float32))):
+      ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 5); ops.init_kv_variable_v2(h, t)
+    out = ops.kv_variable_gather_or_insert_v2(hv, ids_t)
+    np.testing.assert_array_equal(out.cpu().numpy(), want_rows)
+    assert ops.kv_variable_frequency(hv) == ov.sum_freq()
+    ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, grad_t, ids_t if with_token else ids_t.clone(), 1e-2, 0.9, 0.999, 0.9,
+                                               0.999, 1e-8, 0, 0, 0)
+    got = ops.kv_variable_gather_or_zeros_v2(hv, u).cpu().numpy()
+    # sums of up to ~1e5 one-signed addends in another order: a few 1e-6 of the sum, pushed through Adam
+    np.testing.assert_allclose(got, exp, rtol=2e-4, atol=2e-6)
+    order = np.argsort(u)                                # u comes in the oracle's first-occurrence order
+    once = np.empty(u.size, bool)
+    once[order] = np.unique(ids, return_counts=True)[1] == 1
+    assert once.sum() > 1000
+    np.testing.assert_allclose(got[once], exp[once], rtol=1e-6, atol=1e-9)

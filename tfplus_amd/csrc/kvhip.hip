@@ -765,6 +765,9 @@ void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t 
 }
 
 // ---- the entry-list pipeline (kv_fused.h) ----
+// ids per index pass: positions and epart rows are 30-bit fields of the entry list's words, a partition block takes
+// up to 65535 entries; 2^23 ids (4096 tiles) stay well inside both
+constexpr long long FUSED_MAX_N = 1ll << 23;
 // dims it serves: float4 rows with a power-of-two lane count (4, 8, 16, ..., 256)
 bool fused_ok(int D) {
   static const bool off = [] { const char* e = getenv("KV_NO_FUSED"); return e && atoi(e) != 0; }();   // A/B against the sorted-position pipeline
@@ -1353,7 +1356,8 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
   if ((rc = enter_op(t, s))) return rc;
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
   // pass: the frequency adds saturate identically and rows are inserted by the first chunk)
-  const long long CHK = 1ll << 21;
+  // the entry-list pipeline indexes a batch of up to FUSED_MAX_N ids in one pass; the sorted-position one 2^21
+  const long long CHK = (fused_ok(t->dim) && !pairs) ? FUSED_MAX_N : (1ll << 21);
   const size_t idsz = pairs ? 16 : (t->key_dtype == KV_DT_INT32 ? 4 : 8);
   t->batch_serial = 0;
   for (long long off = 0; off < n; off += CHK) {
@@ -1831,9 +1835,10 @@ static bool claim_slot(kv_table* v, kv_table* sl, hipStream_t s);
 template <int OPT>
 static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* grad, const void* ids, int64_t n,
                         const OptArgs& a, kv_batch_token_t token, hipStream_t s) {
-  if (n < 0 || n > (1ll << 21))
+  const long long nmax = fused_ok(v->dim) ? FUSED_MAX_N : (1ll << 21);
+  if (n < 0 || n > nmax)
     return fail(n < 0 ? KV_INVALID_ARGUMENT : KV_UNIMPLEMENTED,
-                "indices: %lld ids in one optimizer call (limit 2^21; split the batch)", (long long)n);
+                "indices: %lld ids in one optimizer call (limit %lld for this embedding dim; split the batch)", (long long)n, nmax);
   if (n > 0 && (!grad || !ids)) return fail(KV_INVALID_ARGUMENT, "grad / indices pointer is null");
   if (!dim_supported(v->dim))
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
