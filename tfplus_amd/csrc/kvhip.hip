@@ -385,6 +385,12 @@ struct kv_table {
   // partition pass — the table's next op joins it (ev_part) first
   bool overlap = false, side_pending = false;
   bool side_has_items = false;     // the side stream also built the work-item directory (the apply launches the sums alone)
+  // A training lookup that hands out a batch token returns when its rows are written; its partition pass (frequency
+  // words, rows of new keys, the batch's key records and entry list) is PENDING: the optimizer apply of that batch
+  // runs it in front of its own kernels, any other op on the table runs it first thing (settle).  Same stream order
+  // as before, the rows just do not wait for it.
+  bool part_pending = false;
+  unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_tile = nullptr, ev_copy = nullptr, ev_part = nullptr;
   bool deterministic = false;      // kv_set_deterministic
@@ -887,10 +893,21 @@ int report_deferred_error(kv_table* t, hipStream_t s) {
 // and the table itself are shared by every op (the reference's table locks cover execution, not just
 // enqueue, training_ops.cc:96-184).  Same stream as the last op: nothing to do.  Another stream: it first
 // waits for everything the previous stream had been given.
+// launches a lookup's pending partition pass (see kv_table::part_pending) on stream s
+int flush_part(kv_table* t, hipStream_t s);
 int hand_over(kv_table* t, hipStream_t s, bool join_side = true) {
   if (t->side_pending && join_side) {   // the lookup's partition pass on the table's side stream (overlap mode)
     HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
     t->side_pending = false;
+  }
+  if (t->part_pending && join_side) {   // (an apply that takes the batch over runs it itself, behind the stream hand-over below)
+    int rc;
+    if (t->has_last && t->last_stream != s) {
+      HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
+      HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
+      t->last_stream = s;
+    }
+    if ((rc = flush_part(t, s))) return rc;
   }
   if (t->has_last && t->last_stream != s) {
     HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
@@ -908,6 +925,14 @@ int join_side(kv_table* t, hipStream_t s) {
   if (t->side_pending) {
     HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
     t->side_pending = false;
+  }
+  if (t->part_pending) {
+    if (t->has_last && t->last_stream != s) {
+      HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
+      HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
+      t->last_stream = s;
+    }
+    return flush_part(t, s);
   }
   return KV_OK;
 }
@@ -960,10 +985,22 @@ void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* id
   else launch_order(pa.tv, wd, n, s);
 }
 
+int flush_part(kv_table* t, hipStream_t s) {
+  if (!t->part_pending) return KV_OK;
+  t->part_pending = false;
+  WsDev wd; PartArgs pa;
+  std::memcpy(&wd, t->pend_wd, sizeof wd);
+  std::memcpy(&pa, t->pend_pa, sizeof pa);
+  ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
+  launch_part2<MODE_LOOKUP>(wd, pa, s);
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
 // The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
 template <int MODE>
 int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
-                     int ids_kind, float* out, hipStream_t s, bool side_part = false) {
+                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false) {
   wd.hc = (unsigned)HC2;
   t->fused_index = true;
   {
@@ -1019,6 +1056,12 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     return KV_OK;
   }
   t->side_has_items = false;
+  if (MODE == MODE_LOOKUP && defer_part) {   // the rows are out: the partition pass waits for the table's next op
+    std::memcpy(t->pend_wd, &wd, sizeof wd);
+    std::memcpy(t->pend_pa, &pa, sizeof pa);
+    t->part_pending = true;
+    return KV_OK;
+  }
   ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
   launch_part2<MODE>(wd, pa, s);
   return KV_OK;
@@ -1380,7 +1423,9 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     // dependency between two streams costs more than the whole pass; off unless asked for.
     static const bool side_on = [] { const char* e = getenv("KV_SIDE_PART"); return e && atoi(e) != 0; }();
     const bool side_part = side_on && token != nullptr && n <= CHK;
-    if (fused_ok(t->dim) && !pairs) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s, side_part))) return rc; }
+    static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();   // A/B
+    const bool defer_part = token != nullptr && n <= CHK && !side_part && !no_defer;   // a token is asked for: an apply of this batch follows
+    if (fused_ok(t->dim) && !pairs) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s, side_part, defer_part))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -1844,6 +1889,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
   const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
+  if (v->part_pending && (rc = flush_part(v, s))) return rc;   // the batch's own partition pass (or a stale one: same thing)
   const bool keep_side = reuse && v->side_pending && v->fused_index;   // overlap mode: joined behind the tile sums
   if (v->side_pending && !keep_side) {
     HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
