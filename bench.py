@@ -620,7 +620,7 @@ def main():
                                   "tests/_reorder.py (typically a few 1e-6 relative), bit-reproducible in deterministic mode")
   if not shard_path and not args.no_extras:
     res.update(extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state))
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
     print(json.dumps(res), flush=True)

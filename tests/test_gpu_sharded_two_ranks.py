@@ -291,6 +291,36 @@ def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
 
 
 @pytest.mark.gpu
+def test_native_shard_a_failing_rank_still_queues_its_exchanges():
+  """A phase that fails on THIS rank (a batch longer than max_ids) returns its error only after the exchanges were
+  queued — void headers, zero rows — so peers are not left waiting in a grouped recv; the table is untouched and the
+  next batch runs as if nothing had happened."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D = 16
+  table = np.ones((4, D), np.float32)
+  ops, vars_, slots, shards = _native_setup(1, D, "hash", table, max_ids=1024)
+  os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
+  good = torch.arange(100, dtype=torch.int64).cuda()
+  out = shards[0].lookup(comm, good)
+  assert torch.equal(out, torch.ones(100, D, device="cuda"))
+  with pytest.raises(Exception, match="queued all the same"):
+    shards[0].lookup(comm, torch.arange(5000, dtype=torch.int64).cuda())
+  # the failed batch left an empty route: its apply exchanges void records and changes nothing
+  shards[0].apply(comm, ops.OPT_GROUP_ADAM_V4, [slots[0]], torch.ones(5000, D, device="cuda"), (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+  torch.cuda.synchronize()
+  assert ops.kv_variable_size_v2(vars_[0]) == 100                    # nothing of the failed batch reached the table
+  assert torch.equal(ops.kv_variable_gather_or_zeros_v2(vars_[0], good), torch.ones(100, D, device="cuda"))
+  out = shards[0].lookup(comm, good)
+  shards[0].apply(comm, ops.OPT_GROUP_ADAM_V4, [slots[0]], torch.full((100, D), 0.5, device="cuda"), (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+  torch.cuda.synchronize()
+  assert torch.equal(out, torch.ones(100, D, device="cuda")) and ops.kv_variable_size_v2(vars_[0]) == 100
+  del comm
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("opt", ["adam_v3", "adagrad", "ftrl"])
 def test_native_shard_every_optimizer_matches_the_unsharded_oracle(opt):
   """kv_shard_apply_serve's other optimizers (GroupAdam V3, Adagrad, SparseGroupFtrl with its two slot tables)

@@ -1400,7 +1400,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
   // pass: the frequency adds saturate identically and rows are inserted by the first chunk)
   // the entry-list pipeline indexes a batch of up to FUSED_MAX_N ids in one pass; the sorted-position one 2^21
-  const long long CHK = (fused_ok(t->dim) && !pairs) ? FUSED_MAX_N : (1ll << 21);
+  const long long CHK = fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21);
   const size_t idsz = pairs ? 16 : (t->key_dtype == KV_DT_INT32 ? 4 : 8);
   t->batch_serial = 0;
   for (long long off = 0; off < n; off += CHK) {
@@ -1425,7 +1425,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     const bool side_part = side_on && token != nullptr && n <= CHK;
     static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();   // A/B
     const bool defer_part = token != nullptr && n <= CHK && !side_part && !no_defer;   // a token is asked for: an apply of this batch follows
-    if (fused_ok(t->dim) && !pairs) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, -1, op, s, side_part, defer_part))) return rc; }
+    if (fused_ok(t->dim)) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, side_part, defer_part))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -2820,6 +2820,7 @@ struct kv_shard {
   unsigned* hist = nullptr;          // [world][tiles]
   unsigned* gcount = nullptr;        // [MAXW + 1] k_owner_route_fixed's counters (zero between launches)
   unsigned* overflow = nullptr;      // pinned, mapped: a segment was too small for a batch
+  unsigned long long overflows = 0;  // batches reported so far
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
   const kv_comm* verified = nullptr; // the communicator whose ranks were seen to agree on world / capacity / dim
@@ -3013,9 +3014,14 @@ int kv_shard_buffers(kv_shard_t sh, void** send_pairs, void** recv_pairs, void**
 // It is reported by the first call that ENDS after the flag landed — after that call has queued all its work, so a
 // rank that reports keeps step with its peers (an early return would leave them waiting in the exchange).  The
 // capacity is not changed here: it must change on every rank at once.
-static int shard_late_report(kv_shard* sh) {
-  if (!*reinterpret_cast<volatile unsigned*>(sh->overflow)) return KV_OK;
-  *reinterpret_cast<volatile unsigned*>(sh->overflow) = 0;
+// (`seen` is the flag as the call found it when it STARTED: a batch's own overflow is reported by the next call, never
+// by itself — which call reports does not depend on how fast the kernels ran.)
+static unsigned shard_take_flag(kv_shard* sh) {
+  return __atomic_exchange_n(sh->overflow, 0u, __ATOMIC_RELAXED);
+}
+static int shard_late_report(kv_shard* sh, unsigned seen) {
+  if (!seen) return KV_OK;
+  ++sh->overflows;
   return fail(KV_RESOURCE_EXHAUSTED, "an earlier sharded batch sent one owner more than peer_capacity (%u) distinct ids: the surplus "
                                      "ids read zeros and their gradients were dropped (this call itself was queued in full); "
                                      "create the shards with a larger peer_capacity on every rank", sh->C);
@@ -3029,6 +3035,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   int rc;
   kv_table* rt = sh->route;
   std::lock_guard<std::mutex> l(rt->mu);
+  if ((rc = hand_over(rt, s))) return rc;   // the phases of one shard keep their order whatever streams they are given
   sh->n_last = n;
   sh->route_token = 0;
   if (n == 0) {
@@ -3073,8 +3080,9 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
 
 int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
   int rc;
+  const unsigned seen = sh ? shard_take_flag(sh) : 0u;
   if ((rc = lookup_route_impl(sh, ids, n, stream))) return rc;
-  return shard_late_report(sh);
+  return shard_late_report(sh, seen);
 }
 
 // the owner's half: the ids the peers sent (recv_pairs) are looked up in this rank's table — frequency words count
@@ -3094,6 +3102,7 @@ int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
   kv_table* rt = sh->route;
   std::lock_guard<std::mutex> l(rt->mu);
   if (rt->batch_serial != sh->route_token || sh->route_token == 0) return fail(KV_FAILED_PRECONDITION, "kv_shard_lookup_finish without kv_shard_lookup_route");
+  { int rc; if ((rc = hand_over(rt, (hipStream_t)stream))) return rc; }
   // the training lookup's gather (k_gather<ORDER>) over the rows that came back: position -> entry -> dense unique
   // index -> the record its id was sent in; the same pass files the positions for the gradient sum to come
   WsDev wd = ws_view(rt, sh->n_last);
@@ -3119,6 +3128,7 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
     return fail(KV_FAILED_PRECONDITION, "kv_shard_apply_route: the batch's lookup must come first (kv_shard_lookup_route)");
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if ((rc = hand_over(rt, s))) return rc;
   if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
   const WsDev wd = ws_view(rt, sh->n_last);
   if (!sh->ordered) {   // a gradient for a batch whose rows were never fetched (kv_shard_lookup_finish skipped)
@@ -3220,16 +3230,29 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = shard_verify(sh, comm))) return rc;
+  const unsigned seen = shard_take_flag(sh);
   hipStream_t w = comm->stream;   // phases and exchanges in one queue: no event hop between a kernel and its exchange
   if ((rc = shard_fork(sh, s, w))) return rc;
   const int64_t pb = (int64_t)(sh->C + 1) * 16, rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
-  if ((rc = lookup_route_impl(sh, ids, n, w))) return rc;
+  // A failure of THIS rank's phase (out of memory, a bad argument) must not leave the peers waiting in a grouped recv:
+  // the exchanges are queued all the same — void headers for a failed route, zero rows for a failed serve — and the
+  // first error is returned once everything is queued.  Only a failed exchange itself returns at once.
+  int first = KV_OK;
+  std::string first_msg;
+  auto note = [&](int r) { if (r && !first) { first = r; first_msg = kv_last_error(); } return r; };
+  if (note(lookup_route_impl(sh, ids, n, w))) {
+    sh->n_last = 0; sh->route_token = 0;
+    HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
+    k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+  }
   if ((rc = kv_comm_all_to_all(comm, sh->send_pairs, sh->recv_pairs, comm->comm ? pb : pb * sh->world, w))) return rc;
-  if ((rc = kv_shard_lookup_serve(sh, w))) return rc;
+  if (note(kv_shard_lookup_serve(sh, w)))
+    HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
   if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
-  if ((rc = kv_shard_lookup_finish(sh, out, w))) return rc;
+  if (!first) note(kv_shard_lookup_finish(sh, out, w));
   if ((rc = shard_done(sh, s, w, join))) return rc;
-  return shard_late_report(sh);
+  if (first) return fail(first, "%s (this rank's exchanges were queued all the same)", first_msg.c_str());
+  return shard_late_report(sh, seen);
 }
 
 int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1, const float* grad,
@@ -3241,10 +3264,19 @@ int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slo
   hipStream_t w = comm->stream;
   if ((rc = shard_fork(sh, s, w))) return rc;
   const int64_t rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
-  if ((rc = kv_shard_apply_route(sh, grad, w))) return rc;
+  // as in kv_shard_lookup: a rank whose route phase failed still takes part in the exchange (zero gradient rows)
+  int first = KV_OK;
+  std::string first_msg;
+  if ((first = kv_shard_apply_route(sh, grad, w))) {
+    first_msg = kv_last_error();
+    HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
+  }
   if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
-  if ((rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w))) return rc;
-  return shard_done(sh, s, w, join);
+  rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w);
+  if (rc && !first) { first = rc; first_msg = kv_last_error(); }
+  if ((rc = shard_done(sh, s, w, join))) return rc;
+  if (first) return fail(first, "%s (this rank's exchange was queued all the same)", first_msg.c_str());
+  return KV_OK;
 }
 
 // The exchange between shards that live in ONE process (all on one device): segment r of shard p's send buffer to
