@@ -420,6 +420,17 @@ int kv_shard_lookup(kv_shard_t shard, kv_comm_t comm, const void* ids, int64_t n
 int kv_shard_apply(kv_shard_t shard, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1,
                    const float* grad, const float* hp, int join, kv_stream_t stream);
 int kv_shard_join(kv_shard_t shard, kv_stream_t stream);
+/* Several sharded tables in one step (the embedding tables of one model; the reference looks its tables up one op
+ * each, python/ops/embedding_ops.py:150-204 per variable): all route phases, ONE grouped exchange carrying every
+ * table's segments, all serve phases, ONE exchange back, all finish phases — two exchanges per lookup and one per
+ * apply whatever ntab is.  Results equal the per-table ops'.  ids[k] / n[k] / outs[k] / grads[k] / slot0[k] belong to
+ * shards[k]; slot1 may be NULL unless optimizer == 3.  A deferred join (join == 0) is completed by
+ * kv_shard_join(shards[0], stream). */
+int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, const void* const* ids, const int64_t* n,
+                          float* const* outs, int join, kv_stream_t stream);
+int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int optimizer, const kv_handle_t* slot0,
+                         const kv_handle_t* slot1, const float* const* grads, const float* hp, int join,
+                         kv_stream_t stream);
 /* the exchange between shards of ONE process on one device (segment r of shard p's send buffer -> segment p of
  * shard r's receive buffer; what: 0 records, 1 rows): several ranks on a single GPU, where RCCL cannot be used */
 int kv_shard_exchange_local(const kv_shard_t* shards, int world, int what, kv_stream_t stream);

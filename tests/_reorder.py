@@ -17,6 +17,19 @@ def adam_step(x, m, v, z, g, hp):
   return -zn / (s + hp["eps"])
 
 
+def adam_eval_err(x, m, v, z, g, hp):
+  """What fp32 evaluation of adam_step can be off by: x_new = -z_new / (s + eps) and z_new is a sum of terms that
+  cancel (z, alpha m_new, d), each rounded to fp32 — a few ulps of the LARGEST of them, divided by s + eps, which
+  for a small row can be far more than an ulp of x_new itself."""
+  mn = hp["b1"] * m + (1 - hp["b1"]) * g
+  vn = hp["b2"] * v + (1 - hp["b2"]) * g * g
+  s = np.sqrt(vn)
+  d = (s - np.sqrt(v)) * x if hp["b1"] > hp["b1p"] else (s + hp["eps"]) * x
+  # ... and m_new itself is a sum of two terms of opposite sign when the gradient turns against the momentum
+  mterms = hp["alpha"] * (np.abs(hp["b1"] * m) + np.abs((1 - hp["b1"]) * g))
+  return 2.0 ** -22 * (np.abs(z) + mterms + np.abs(d)) / (s + hp["eps"])
+
+
 def adam_hp(lr, b1p, b2p, b1=0.9, b2=0.999, eps=1e-8):
   b1p, b2p = float(np.float32(b1p)), float(np.float32(b2p))
   return {"alpha": lr * np.sqrt(1.0 - b2p) / (1.0 - b1p), "b1": float(np.float32(b1)), "b2": float(np.float32(b2)),
@@ -38,10 +51,10 @@ def adam_reorder_check(x0, m0, v0, z0, ids, grads, x1, hp, what=""):
   inside = np.abs(gsum) <= dg
   dev = np.where(inside, np.maximum(dev, np.abs(adam_step(x0, m0, v0, z0, np.zeros_like(gsum), hp) - f0)), dev)
   # the fp32 evaluation of the update itself: a few ulps of |x| and of the step
-  bound = 2.0 * dev + 2.0 ** -19 * (np.abs(x0) + np.abs(f0 - x0)) + 1e-6 * np.abs(f0) + 1e-9
+  bound = 2.0 * dev + 2.0 ** -19 * (np.abs(x0) + np.abs(f0 - x0)) + 1e-6 * np.abs(f0) + 1e-9 + adam_eval_err(x0, m0, v0, z0, gsum, hp)
   bad = np.argwhere(np.abs(x1.astype(np.float64) - f0) > bound)
   if bad.size:
     i, e = bad[0]
-    raise AssertionError("%s key %d elem %d cnt %d: got %.9g exp %.9g bound %.3g dg %.3g gsum %.9g x0 %.9g" % (
-        what, u[i], e, cnt[i], x1[i, e], f0[i, e], bound[i, e], dg[i, e], gsum[i, e], x0[i, e]))
+    raise AssertionError("%s key %d elem %d cnt %d: got %.9g exp %.9g bound %.3g dg %.3g gsum %.9g x0 %.9g m0 %.9g v0 %.9g z0 %.9g" % (
+        what, u[i], e, cnt[i], x1[i, e], f0[i, e], bound[i, e], dg[i, e], gsum[i, e], x0[i, e], m0[i, e], v0[i, e], z0[i, e]))
   return u

@@ -1,0 +1,151 @@
+"""Sharded lookup + apply of SEVERAL tables (kvhip.h kv_multi_shard_lookup / kv_multi_shard_apply): the tables of one model
+share two grouped exchanges per lookup and one per apply.  (a) the whole ops on a world of one through RCCL's grouped
+send / recv, bit-identical to the per-table sharded ops; (b) world 8 x 40 tables in ONE process on one device, phase by
+phase with the in-process exchange, against one unsharded oracle table per embedding table."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DAY = 19000
+HP = (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+
+
+def _table(ops, D, init, det):
+  h = ops.kv_variable([D])
+  ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, init)
+  if det:
+    ops.kv_set_deterministic(h, True)
+  return h
+
+
+@pytest.mark.gpu
+def test_multi_shard_ops_equal_the_per_table_sharded_ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
+  rng = np.random.default_rng(8)
+  dims = [16, 32, 8, 64, 32]
+  T = len(dims)
+  sets = []
+  for which in range(2):   # 0: driven by the multi ops, 1: by the per-table ops
+    vs, ss, shs = [], [], []
+    for k, D in enumerate(dims):
+      init = np.random.default_rng(100 + k).standard_normal((32, D)).astype(np.float32)
+      v = _table(ops, D, init, True); s = _table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), True)
+      vs.append(v); ss.append(s); shs.append(ops.KvShard(v, 1, 0, ops.KV_OWNER_HASH, max_ids=1 << 14))
+    sets.append((vs, ss, shs))
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
+  for step in range(3):
+    ids = [torch.from_numpy(rng.integers(0, 3000, 5000 + 777 * k)).cuda() for k in range(T)]
+    if step == 2:
+      ids[1] = ids[1][:0]                                                  # a table nobody looks up this step
+    grads = [torch.from_numpy((rng.standard_normal((i.numel(), D)) * 1e-2).astype(np.float32)).cuda() for i, D in zip(ids, dims)]
+    outs = ops.kv_multi_shard_lookup(sets[0][2], comm, ids, join=(step != 1))
+    if step == 1:
+      sets[0][2][0].join()
+    want = [sets[1][2][k].lookup(comm, ids[k]) for k in range(T)]
+    for k in range(T):
+      assert torch.equal(outs[k], want[k]), (step, k)
+    ops.kv_multi_shard_apply(sets[0][2], comm, ops.OPT_GROUP_ADAM_V4, [[s] for s in sets[0][1]], grads, HP)
+    for k in range(T):
+      sets[1][2][k].apply(comm, ops.OPT_GROUP_ADAM_V4, [sets[1][1][k]], grads[k], HP)
+  torch.cuda.synchronize()
+  for k in range(T):
+    for a, b in ((sets[0][0][k], sets[1][0][k]), (sets[0][1][k], sets[1][1][k])):
+      ka, va = ops.read_kv_variable_op_v2(a); kb, vb = ops.read_kv_variable_op_v2(b)
+      oa, ob = torch.argsort(ka), torch.argsort(kb)
+      assert torch.equal(ka[oa], kb[ob]) and torch.equal(va[oa], vb[ob]), k   # deterministic mode: bit for bit
+  # a shard listed twice, a communicator of another world: refused before anything is queued
+  with pytest.raises(Exception, match="listed twice"):
+    ops.kv_multi_shard_lookup([sets[0][2][0], sets[0][2][0]], comm, [ids[0], ids[0]])
+  del comm
+
+
+@pytest.mark.gpu
+def test_world_of_eight_forty_tables_in_one_process_match_unsharded_oracles():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops, sharded
+  from _reorder import adam_hp, adam_reorder_check
+  world, T, D = 8, 40, 8
+  rng = np.random.default_rng(21)
+  inits = [np.random.default_rng(500 + k).standard_normal((16, D)).astype(np.float32) for k in range(T)]
+  vars_ = [[_table(ops, D, inits[k], False) for r in range(world)] for k in range(T)]
+  slots = [[_table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), False) for r in range(world)] for k in range(T)]
+  shards = [[ops.KvShard(vars_[k][r], world, r, ops.KV_OWNER_HASH, max_ids=2048) for r in range(world)] for k in range(T)]
+  refs = [ko.OracleKv(D, 0, inits[k], day=DAY, picker=1, seed=3) for k in range(T)]
+  rslots = [ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY) for k in range(T)]
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  hp = adam_hp(0.1, float(b1p), float(b2p))
+  for step in range(2):
+    batches = [[rng.integers(0, 300 + 40 * k, 200 + 13 * r + k) for r in range(world)] for k in range(T)]
+    grads = [[(rng.standard_normal((b.size, D)) * 1e-2).astype(np.float32) for b in batches[k]] for k in range(T)]
+    # every table's route phase, then every table's exchange (a multi-table step queues them in this order), ...
+    for k in range(T):
+      for r in range(world):
+        shards[k][r].lookup_route(torch.from_numpy(batches[k][r]).cuda())
+    for k in range(T):
+      ops.kv_shard_exchange_local(shards[k], 0)
+    for k in range(T):
+      for r in range(world):
+        shards[k][r].lookup_serve()
+    for k in range(T):
+      ops.kv_shard_exchange_local(shards[k], 1)
+    for k in range(T):
+      allb = np.concatenate(batches[k])
+      want_all = refs[k].gather_or_insert(allb)
+      # the rows as the owners hold them now (the state itself is held to the oracle by the reorder bound below)
+      u = np.unique(allb)
+      own = sharded.owner_of(torch.from_numpy(u), world, "hash").numpy()
+      held = np.zeros((u.size, D), np.float32)
+      for r in range(world):
+        held[own == r] = ops.kv_variable_gather_or_zeros_v2(vars_[k][r], torch.from_numpy(u[own == r]).cuda()).cpu().numpy()
+      off = 0
+      for r in range(world):
+        got = shards[k][r].lookup_finish().cpu().numpy()
+        want = want_all[off:off + batches[k][r].size]
+        off += batches[k][r].size
+        if step == 0:
+          np.testing.assert_array_equal(got, want)                          # rows are copies of the init rule's rows
+        np.testing.assert_array_equal(got, held[np.searchsorted(u, batches[k][r])])   # ... and of the owner's rows
+    for k in range(T):
+      for r in range(world):
+        shards[k][r].apply_route(torch.from_numpy(grads[k][r]).cuda())
+    for k in range(T):
+      ops.kv_shard_exchange_local(shards[k], 1)
+    for k in range(T):
+      allb, allg = np.concatenate(batches[k]), np.concatenate(grads[k])
+      u = np.unique(allb)
+      own = sharded.owner_of(torch.from_numpy(u), world, "hash").numpy()
+      # each owner's state before the step (its own fp32 state), for the per-element reorder bound
+      pre = {}
+      for r in range(world):
+        ur = torch.from_numpy(u[own == r]).cuda()
+        st = ops.kv_variable_gather_or_zeros_v2(slots[k][r], ur).cpu().numpy()
+        pre[r] = (ops.kv_variable_gather_or_zeros_v2(vars_[k][r], ur).cpu().numpy(), st[:, :D], st[:, D:2 * D], st[:, 2 * D:])
+      for r in range(world):
+        shards[k][r].apply_serve(ops.OPT_GROUP_ADAM_V4, [slots[k][r]], (0.1, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0))
+      us, s, _ = ko.dedup_segment_sum(allb, allg)
+      ko.apply_group_adam(refs[k], rslots[k], s, us, 0.1, float(b1p), float(b2p), 0.9, 0.999, 1e-8)
+      total = 0
+      for r in range(world):
+        keys, _ = ops.read_kv_variable_op_v2(vars_[k][r])
+        keys = keys.cpu().numpy()
+        mine = np.array(sorted(refs[k].as_dict()), np.int64)
+        mine = mine[sharded.owner_of(torch.from_numpy(mine), world, "hash").numpy() == r]
+        assert set(keys.tolist()) == set(mine.tolist()), (k, r)             # every key on its owner, only there
+        total += keys.size
+        ur = u[own == r]
+        sel = np.isin(allb, ur)
+        x1 = ops.kv_variable_gather_or_zeros_v2(vars_[k][r], torch.from_numpy(ur).cuda()).cpu().numpy()
+        x0, m0, v0, z0 = pre[r]
+        adam_reorder_check(x0, m0, v0, z0, allb[sel], allg[sel], x1, hp, what="table %d rank %d step %d" % (k, r, step))
+      assert total == len(refs[k].as_dict())

@@ -2905,13 +2905,13 @@ int kv_comm_destroy(kv_comm_t c) {
 }
 
 // bytes_per_peer bytes to / from every rank: grouped ncclSend / ncclRecv (xGMI is point to point: one pair per
-// link), on the communicator's own stream, behind everything `stream` was given and in front of what it gets next
-int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_per_peer, kv_stream_t stream) {
-  if (!c || !send || !recv || bytes_per_peer < 0) return fail(KV_INVALID_ARGUMENT, "kv_comm_all_to_all: bad arguments");
-  DeviceGuard dg(c->device);
-  hipStream_t s = (hipStream_t)stream;
+// link), on the communicator's own stream, behind everything `stream` was given and in front of what it gets next.
+// nseg buffers (the tables of a multi-table step) go out in ONE group: RCCL runs a group's sends and receives as one
+// launch, so 40 tables cost one exchange, not 40.
+static int comm_exchange(kv_comm* c, int nseg, const void* const* sends, void* const* recvs, const int64_t* bytes_per_peer, hipStream_t s) {
   if (!c->comm) {   // world of one without RCCL
-    HIP_TRY(hipMemcpyAsync(recv, send, (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < nseg; ++k)
+      HIP_TRY(hipMemcpyAsync(recvs[k], sends[k], (size_t)bytes_per_peer[k], hipMemcpyDeviceToDevice, s));
     return KV_OK;
   }
   const bool hop = s != c->stream;   // the sharded ops run on the communicator's stream themselves: no hop
@@ -2924,16 +2924,19 @@ int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_
   // lets a single GPU exercise the grouped send / recv code)
   static const bool self_rccl = [] { const char* e = getenv("KV_COMM_SELF_VIA_RCCL"); return e && e[0] == '1'; }();
   if (!self_rccl)
-    HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer, (const char*)send + (size_t)c->rank * bytes_per_peer,
-                           (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+    for (int k = 0; k < nseg; ++k)
+      HIP_TRY(hipMemcpyAsync((char*)recvs[k] + (size_t)c->rank * bytes_per_peer[k], (const char*)sends[k] + (size_t)c->rank * bytes_per_peer[k],
+                             (size_t)bytes_per_peer[k], hipMemcpyDeviceToDevice, c->stream));
   const bool grouped = c->world > 1 || self_rccl;
   if (grouped) NCCL_TRY(rccl()->GroupStart());
   ncclResult_t bad = ncclSuccess;   // a failed Send / Recv must not leave the group open on this communicator
   for (int p = 0; p < c->world && bad == ncclSuccess; ++p) {
     if (p == c->rank && !self_rccl) continue;
-    bad = rccl()->Send((const char*)send + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream);
-    if (bad == ncclSuccess)
-      bad = rccl()->Recv((char*)recv + (size_t)p * bytes_per_peer, (size_t)bytes_per_peer, ncclChar, p, c->comm, c->stream);
+    for (int k = 0; k < nseg && bad == ncclSuccess; ++k) {   // peer-major: both ends of a pair post the tables in the same order
+      const size_t b = (size_t)bytes_per_peer[k];
+      bad = rccl()->Send((const char*)sends[k] + (size_t)p * b, b, ncclChar, p, c->comm, c->stream);
+      if (bad == ncclSuccess) bad = rccl()->Recv((char*)recvs[k] + (size_t)p * b, b, ncclChar, p, c->comm, c->stream);
+    }
   }
   if (grouped) {
     const ncclResult_t e = rccl()->GroupEnd();
@@ -2946,6 +2949,11 @@ int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_
     HIP_TRY(hipStreamWaitEvent(s, c->ev_out, 0));
   }
   return KV_OK;
+}
+int kv_comm_all_to_all(kv_comm_t c, const void* send, void* recv, int64_t bytes_per_peer, kv_stream_t stream) {
+  if (!c || !send || !recv || bytes_per_peer < 0) return fail(KV_INVALID_ARGUMENT, "kv_comm_all_to_all: bad arguments");
+  DeviceGuard dg(c->device);
+  return comm_exchange(c, 1, &send, &recv, &bytes_per_peer, (hipStream_t)stream);
 }
 
 int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule, int64_t max_ids, int64_t peer_capacity,
@@ -3036,6 +3044,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   kv_table* rt = sh->route;
   std::lock_guard<std::mutex> l(rt->mu);
   if ((rc = hand_over(rt, s))) return rc;   // the phases of one shard keep their order whatever streams they are given
+  rt->deterministic = sh->table->deterministic;   // the route index (tile pass, position order) follows the table's mode
   sh->n_last = n;
   sh->route_token = 0;
   if (n == 0) {
@@ -3141,6 +3150,7 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
   pa.out_sum = sh->send_rows;
   pa.out_map = sh->slot_of;
   pa.fold_op = KV_SCATTER_ADD;
+  pa.det = rt->deterministic ? 1 : 0;
   pa.n = sh->n_last;
   return launch_apply<MODE_DEDUP, OPT_ADAGRAD>(rt, wd, pa, sh->n_last, s);
 }
@@ -3275,6 +3285,95 @@ int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slo
   rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w);
   if (rc && !first) { first = rc; first_msg = kv_last_error(); }
   if ((rc = shard_done(sh, s, w, join))) return rc;
+  if (first) return fail(first, "%s (this rank's exchange was queued all the same)", first_msg.c_str());
+  return KV_OK;
+}
+
+// Several sharded tables in one step (the 40 embedding tables of a DCN): every table's route phase, then ONE grouped
+// exchange carrying all their segments, every table's serve phase, ONE exchange back, every table's finish — two
+// exchanges per lookup and one per apply whatever the number of tables.  Same results as the per-table ops.
+static int multi_shard_check(const kv_shard_t* shards, int ntab, kv_comm_t comm, const char* what) {
+  if (!shards || ntab < 1 || ntab > 4096 || !comm) return fail(KV_INVALID_ARGUMENT, "%s: bad arguments", what);
+  for (int k = 0; k < ntab; ++k) {
+    if (!shards[k] || shards[k]->world != comm->world || shards[k]->table->device != shards[0]->table->device)
+      return fail(KV_INVALID_ARGUMENT, "%s: shard %d / communicator mismatch", what, k);
+    for (int j = 0; j < k; ++j)
+      if (shards[j] == shards[k]) return fail(KV_INVALID_ARGUMENT, "%s: shard %d is listed twice", what, k);
+  }
+  return KV_OK;
+}
+int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, const void* const* ids, const int64_t* n,
+                          float* const* outs, int join, kv_stream_t stream) {
+  int rc;
+  if ((rc = multi_shard_check(shards, ntab, comm, "kv_multi_shard_lookup"))) return rc;
+  if (!ids || !n || !outs) return fail(KV_INVALID_ARGUMENT, "kv_multi_shard_lookup: null argument list");
+  DeviceGuard dg(shards[0]->table->device);
+  hipStream_t s = (hipStream_t)stream, w = comm->stream;
+  for (int k = 0; k < ntab; ++k)
+    if ((rc = shard_verify(shards[k], comm))) return rc;
+  std::vector<unsigned> seen(ntab);
+  for (int k = 0; k < ntab; ++k) seen[k] = shard_take_flag(shards[k]);
+  if ((rc = shard_fork(shards[0], s, w))) return rc;
+  int first = KV_OK;
+  std::string first_msg;
+  auto note = [&](int r) { if (r && !first) { first = r; first_msg = kv_last_error(); } return r; };
+  std::vector<const void*> sp(ntab), sr(ntab);
+  std::vector<void*> rp(ntab), rr(ntab);
+  std::vector<int64_t> pb(ntab), rb(ntab);
+  std::vector<char> routed(ntab, 1);
+  for (int k = 0; k < ntab; ++k) {
+    kv_shard* sh = shards[k];
+    const int64_t mul = comm->comm ? 1 : sh->world;
+    pb[k] = (int64_t)(sh->C + 1) * 16 * mul;
+    rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * mul;
+    sp[k] = sh->send_pairs; rp[k] = sh->recv_pairs; sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
+    if (note(lookup_route_impl(sh, ids[k], n[k], w))) {   // as in kv_shard_lookup: void headers, the peers are not left waiting
+      routed[k] = 0;
+      sh->n_last = 0; sh->route_token = 0;
+      HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
+      k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+    }
+  }
+  if ((rc = comm_exchange(comm, ntab, sp.data(), rp.data(), pb.data(), w))) return rc;
+  for (int k = 0; k < ntab; ++k)
+    if (note(kv_shard_lookup_serve(shards[k], w)))
+      HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (comm->comm ? shards[k]->world : 1), w));
+  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w))) return rc;
+  for (int k = 0; k < ntab; ++k)
+    if (routed[k]) note(kv_shard_lookup_finish(shards[k], outs[k], w));
+  if ((rc = shard_done(shards[0], s, w, join))) return rc;
+  if (first) return fail(first, "%s (this rank's exchanges were queued all the same)", first_msg.c_str());
+  for (int k = 0; k < ntab; ++k)
+    if ((rc = shard_late_report(shards[k], seen[k]))) return rc;
+  return KV_OK;
+}
+
+// slot0 / slot1: one handle per table (slot1 only for SparseGroupFtrl, else nullptr); hp as in kv_shard_apply_serve
+int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int optimizer, const kv_handle_t* slot0,
+                         const kv_handle_t* slot1, const float* const* grads, const float* hp, int join, kv_stream_t stream) {
+  int rc;
+  if ((rc = multi_shard_check(shards, ntab, comm, "kv_multi_shard_apply"))) return rc;
+  if (!slot0 || !grads || !hp) return fail(KV_INVALID_ARGUMENT, "kv_multi_shard_apply: null argument list");
+  DeviceGuard dg(shards[0]->table->device);
+  hipStream_t s = (hipStream_t)stream, w = comm->stream;
+  if ((rc = shard_fork(shards[0], s, w))) return rc;
+  int first = KV_OK;
+  std::string first_msg;
+  auto note = [&](int r) { if (r && !first) { first = r; first_msg = kv_last_error(); } return r; };
+  std::vector<const void*> sr(ntab);
+  std::vector<void*> rr(ntab);
+  std::vector<int64_t> rb(ntab);
+  for (int k = 0; k < ntab; ++k) {
+    kv_shard* sh = shards[k];
+    rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * (comm->comm ? 1 : sh->world);
+    sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
+    if (note(kv_shard_apply_route(sh, grads[k], w)))
+      HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb[k] * (comm->comm ? sh->world : 1), w));
+  }
+  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w))) return rc;
+  for (int k = 0; k < ntab; ++k)
+    note(kv_shard_apply_serve(shards[k], optimizer, slot0[k], slot1 ? slot1[k] : nullptr, hp, w));
+  if ((rc = shard_done(shards[0], s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchange was queued all the same)", first_msg.c_str());
   return KV_OK;
 }

@@ -845,6 +845,38 @@ class KvShard(object):
     _lib.check(_lib.lib().kv_shard_apply_serve(self.ptr, int(optimizer), slots[0].ptr, s1, arr, _stream(self.table)))
 
 
+def kv_multi_shard_lookup(shards, comm, indices_list, join=True):
+  """Sharded lookup of several tables in one step: two grouped exchanges whatever len(shards) is (kvhip.h
+  kv_multi_shard_lookup).  Returns one [n_k, dim_k] tensor per table."""
+  T = len(shards)
+  ids = [_ids(sh.table, x) for sh, x in zip(shards, indices_list)]
+  outs = [_gather_out(sh.table, i) for sh, i in zip(shards, ids)]
+  arr = (ctypes.c_void_p * T)(*[sh.ptr for sh in shards])
+  ip = (ctypes.c_void_p * T)(*[_p(i) for i in ids])
+  nn = (ctypes.c_int64 * T)(*[i.numel() for i in ids])
+  op = (ctypes.c_void_p * T)(*[_p(o) for o in outs])
+  _lib.check(_lib.lib().kv_multi_shard_lookup(arr, T, comm.ptr, ip, nn, op, int(bool(join)), _stream(shards[0].table)))
+  for sh, i, o in zip(shards, ids, outs):
+    sh._keep = (i, o)
+  return outs
+
+
+def kv_multi_shard_apply(shards, comm, optimizer, slots_list, grads, hp, join=True):
+  """The sharded optimizer apply of several tables: one grouped exchange (kvhip.h kv_multi_shard_apply).
+  slots_list[k] = the slot table(s) of shards[k]."""
+  T = len(shards)
+  gs = [_f32(sh.table, g) for sh, g in zip(shards, grads)]
+  arr = (ctypes.c_void_p * T)(*[sh.ptr for sh in shards])
+  s0 = (ctypes.c_void_p * T)(*[sl[0].ptr for sl in slots_list])
+  two = all(len(sl) > 1 for sl in slots_list)
+  s1 = (ctypes.c_void_p * T)(*[sl[1].ptr for sl in slots_list]) if two else None
+  gp = (ctypes.c_void_p * T)(*[_p(g) for g in gs])
+  hpa = (ctypes.c_float * len(hp))(*[float(np.float32(x)) for x in hp])
+  _lib.check(_lib.lib().kv_multi_shard_apply(arr, T, comm.ptr, int(optimizer), s0, s1, gp, hpa, int(bool(join)), _stream(shards[0].table)))
+  for sh, g in zip(shards, gs):
+    sh._keep_g = g
+
+
 def kv_shard_exchange_local(shards, what):
   """Exchange between shards of one process on one device (what: 0 records, 1 rows)."""
   arr = (ctypes.c_void_p * len(shards))(*[s.ptr for s in shards])
