@@ -11,22 +11,26 @@
 //             the keys are known and completed behind the counting sort (a key absent from the table is inserted
 //             here: a 64-bit CAS on the index entry decides between tiles, the loser needs no row — the row of a new
 //             key is a function of (key, seed)); the tile's entries {key, occurrences | count, row word, slot-row
-//             hint, source}; the tile's positions sorted by entry (torder, built in LDS, 2 B per position, coalesced);
-//             and the OUTPUT ROWS of its 2048 positions.  The lookup's result is complete after this one launch.
+//             hint, source}; the rows of the entries that occur more than once, in entry order (mrow: position,
+//             epart row, head flag — built in LDS, coalesced); and the OUTPUT ROWS of its 2048 positions.  The
+//             lookup's result is complete after this one launch.
 //   k_part2   one block per hash partition over the tiles' entries (5 MB, not 1 M positions): exact occurrence
 //             counts, frequency word + day + flags of every key with ONE hop (the row came with the entry), rows of
-//             new keys initialised, key records, the ENTRY LIST — a key's entries contiguous, each naming its source
-//             — and the work items.  Nothing in the lookup's output depends on it, so a lookup may leave it pending:
-//             the optimizer apply of the same batch (batch token) runs it, or the next op on the table does.
-//   k_tsum    per tile: the gradient rows of every entry with more than one occurrence are summed in torder order
-//             into epart (all reads inside the tile's 256 KB of gradient rows; entries of up to WIDE rows by a lane
-//             group, larger ones by a wave).  An entry with one occurrence IS its gradient row.
-//   k_apply   (kv_kernels.h, unchanged but for the tagged source) over the entry list: a key has at most one entry
-//             per tile, so the hottest key of 1 M ids is 489 sources instead of 180 k positions, one chunk, and
-//             k_apply_fin is not launched.
+//             new keys initialised, key records sorted into classes (1 source, 2 sources, 3 .. LCOLD, hot), the ENTRY
+//             LIST — a key's entries contiguous, each naming its source — and the work items.  Nothing in the
+//             lookup's output depends on it, so a lookup that hands out a batch token leaves it pending: the
+//             optimizer apply of the same batch runs it first, or whatever op the table sees next does.
+//   k_tsum    per tile: the gradient rows of every entry with more than one occurrence are summed into epart by a
+//             segmented reduction over mrow (all reads inside the tile's 256 KB of gradient rows, every wave the
+//             same number of rows whatever the skew).  An entry with one occurrence IS its gradient row.  Its
+//             first ITEM_BLOCKS blocks turn the partitions' work items into the dense directory.
+//   k_apply2  over the entry list: a key has at most one entry per tile, so the hottest key of 1 M ids is 489
+//             sources instead of 180 k positions — one chunk, no k_apply_fin.  1024-thread blocks take items from
+//             an LDS ticket, the next item's records are requested while the current one is worked on, a cold
+//             batch holds keys of one class so that its loads are unconditional.
 //
 // Summation order: inside an entry by rank (LDS-atomic arrival; input order in deterministic mode), then the key's
-// entries in list order (arrival in k_part2; tile order in deterministic mode): a fixed tree given those two.
+// entries in list order (arrival in k_part2; (tile, key) order in deterministic mode): a fixed tree given those two.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
