@@ -182,9 +182,11 @@ int kv_set_deterministic(kv_handle_t h, int on);
  * them there, so that it runs beside whatever the caller does between the lookup and the optimizer apply (the dense
  * tower; in a bare benchmark: the apply's tile sums).  The lookup returns with `out` complete on the caller's
  * stream; the next op on the table (any op, on any stream) first joins the side stream.  Under stream capture the
- * forks and joins are graph edges and cost nothing; outside a capture each is an event hop of several microseconds,
- * which is why this is not the default.  A capture that holds a lookup must also hold the table's next op (the
- * optimizer apply), or the side stream is left unjoined.  Results are the same as without it. */
+ * forks and joins are graph edges; outside a capture each is an event hop of several microseconds.  Measured at
+ * configs[1]: the step is SLOWER with it both eagerly and as a replayed graph (0.183 ms against
+ * 0.155 ms) — parallel graph branches are scheduled like streams on this stack — so it stays off by default and is
+ * kept for callers whose dense tower is long enough to hide the join.  A capture that holds a lookup must also hold
+ * the table's next op (the optimizer apply), or the side stream is left unjoined.  Results are the same as without it. */
 int kv_set_overlap(kv_handle_t h, int on);
 /* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that
  * follows can then take `max_new_ids` more ids without consulting the device — what a stream capture needs, where a

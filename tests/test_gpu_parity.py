@@ -288,6 +288,32 @@ def test_group_adam_parity_unique_ids(ops, D, ver):
     _assert_same_table(ops, hs, os_, keys, rtol=RTOL, atol=1e-12)
 
 
+def test_delete_between_lookup_and_apply_makes_the_token_stale(ops):
+  """lookup(ids) -> delete(some of them) -> apply(the SAME ids tensor): the Python layer hands the optimizer op the
+  lookup's batch token (same tensor object); the delete must have invalidated it, so the apply re-creates the deleted
+  keys like the reference's FindOrInsertUnsafe would (and does not write into freed rows)."""
+  D = 32
+  rng = np.random.default_rng(77)
+  hv, ov = _pair(ops, D, seed=1, rng=rng)
+  hs, os_ = _const(ops, 3 * D, 0.0)
+  for t in range(3):
+    ids_np = rng.choice(4000, 1200, replace=False).astype(np.int64)
+    ids = torch.from_numpy(ids_np).cuda()                                  # ONE tensor object for lookup and apply
+    np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_insert_v2(hv, ids)), ov.gather_or_insert(ids_np))
+    gone = ids_np[rng.choice(ids_np.size, 300, replace=False)]
+    if t == 2:
+      assert ops.kv_variable_delete_with_timestamp(hv, threshold=0).numel() == len(ov.delete_with_timestamp(0))
+    else:
+      assert ops.kv_variable_delete(hv, gone) == 300
+      ov.delete(gone)
+    grad = torch.from_numpy(rng.normal(0, 1e-2, (ids_np.size, D)).astype(np.float32)).cuda()
+    b1p, b2p = _beta_pows(t)
+    ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, grad, ids, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+    ko.apply_group_adam(ov, os_, _np(grad), ids_np, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, version=4)
+    _assert_same_table(ops, hv, ov, ids_np, rtol=RTOL, atol=1e-9)
+    _assert_same_table(ops, hs, os_, ids_np, rtol=RTOL, atol=1e-12)
+
+
 def test_group_adam_parity_with_regularizers_and_blacklist(ops):
   rng = np.random.default_rng(31)
   D = 32

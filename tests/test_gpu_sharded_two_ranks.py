@@ -237,6 +237,39 @@ def test_native_shard_segment_overflow_is_reported_late_and_once():
 
 
 @pytest.mark.gpu
+def test_native_shard_full_capacity_cannot_overflow():
+  """peer_capacity = max_ids: the worst case — every distinct id of a full batch owned by ONE rank — fits; nothing is
+  dropped, nothing is reported (the lossless setting; it costs world x the wire bytes)."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D, world = 16, 2
+  table = np.ones((4, D), np.float32)
+  ops, vars_, slots, shards = _native_setup(world, D, "mod", table, cap=4096, max_ids=4096)
+  ids = torch.arange(0, 8192, 2, dtype=torch.int64).cuda()                 # 4096 distinct ids, all owned by rank 0
+  for step in range(2):
+    for r in range(world):
+      shards[r].lookup_route(ids)
+    ops.kv_shard_exchange_local(shards, 0)
+    for r in range(world):
+      shards[r].lookup_serve()
+    ops.kv_shard_exchange_local(shards, 1)
+    for r in range(world):
+      out = shards[r].lookup_finish()
+      assert torch.equal(out, torch.ones(4096, D, device="cuda")) if step == 0 else bool(out.any(dim=1).all())
+    for r in range(world):
+      shards[r].apply_route(torch.full((4096, D), 0.25, device="cuda"))
+    ops.kv_shard_exchange_local(shards, 1)
+    for r in range(world):
+      shards[r].apply_serve(ops.OPT_GROUP_ADAM_V4, [slots[r]], (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+    torch.cuda.synchronize()
+  assert ops.kv_variable_size_v2(vars_[0]) == 4096 and ops.kv_variable_size_v2(vars_[1]) == 0
+  # both ranks sent + 0.25 per id and element: every row of every one of the 4096 keys moved down
+  k, v = ops.read_kv_variable_op_v2(vars_[0])
+  assert k.numel() == 4096 and bool((v < 1.0).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("with_rccl", [False, True])
 def test_native_shard_world_of_one_equals_the_unsharded_ops(with_rccl):
   """kv_shard_lookup / kv_shard_apply as whole ops (forked stream, RCCL grouped send / recv when asked for) on a world
