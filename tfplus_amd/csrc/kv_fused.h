@@ -152,6 +152,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   constexpr bool PAIRS = std::is_same<IdT, IdCount>::value;
   const bool has_counts = PAIRS || counts != nullptr;
   KV_STAMP(0);
+  KV_STAMP_HW(10);
 
   // the tile's ids: every load unconditional (a position past the end re-reads the last id) so that they are all
   // in flight together

@@ -288,10 +288,8 @@ class KvVariable(object):
     return prefix + suffix[:len(suffix) - 2]
 
   def increase_counting(self, indices, counts, name=None):
-    """KvVariableIncreaseCountV2 is declared (ops/kv_variable_ops.cc:342-347) but has no kernel in the
-    reference; training mode fails the same way here, prediction mode is the reference's no-op."""
-    if IS_TRAINING:
-      raise _lib.UnimplementedError("KvVariableIncreaseCountV2: no kernel is registered for this op in the reference")
+    """KvVariableIncreaseCountV2 (kv_variable_ops.py:1115-1127): the reference registers a kernel whose Compute is
+    empty ("reserved OP", kernels/kv_variable_ops.cc:749-757) — a no-op in training and in prediction mode."""
     return None
 
   # -- table hygiene (kv_variable_ops.py:1129-1131, 1499-1518) -------------------------------------

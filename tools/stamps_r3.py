@@ -49,6 +49,24 @@ if len(tt):
   if tt[:, 9].max() > 0:
     for nm, i, j in (("  ids requested + LDS cleared + barrier", 0, 7), ("  hash insert", 7, 8), ("  probes requested", 8, 9), ("  barrier", 9, 1)):
       print("   %-48s %s" % (nm, med(tt[:, j] - tt[:, i])))
+  if tt[:, 10].max() > 0:   # where the blocks ran
+    hw = tt[:, 10]
+    xcc = (hw >> 32) & 0xF; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    where = xcc * 1000 + se * 100 + sh * 16 + cu
+    ids_, inv, cnt = np.unique(where, return_inverse=True, return_counts=True)
+    tot = tt[:, 5] - tt[:, 0]
+    print("   distinct CUs used %d; blocks per CU: %s" % (len(ids_), dict(zip(*np.unique(cnt, return_counts=True)))))
+    for c in sorted(set(cnt)):
+      sel = cnt[inv] == c
+      print("   blocks on a CU holding %d: total %s ; rows phase %s" % (c, med(tot[sel]), med((tt[:, 5] - tt[:, 4])[sel])))
+    for x in range(8):
+      sel = xcc == x
+      if sel.any():
+        print("   XCC %d: %3d blocks, total %s ; end %s" % (x, sel.sum(), med(tot[sel]), med((tt[:, 5] - b0)[sel])))
+    slow = np.argsort(-(tt[:, 5] - b0))[:12]
+    print("   last blocks to end (tile, xcc, se, cu, start, phases..., end):")
+    for i in slow:
+      print("     ", i, int(xcc[i]), int(se[i]), int(cu[i]), int(tt[i, 0] - b0), [int(tt[i, j + 1] - tt[i, j]) for j in range(5)], int(tt[i, 5] - b0))
 pt = a[4096:4096 + 1024].astype(np.int64); pt = pt[pt[:, 4] > 0]
 if len(pt):
   b0 = pt[:, 0].min()
