@@ -195,8 +195,16 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
       adam(ids, grad, N, lookup(ids, True))
     ms_step = timed(full, steps=8, warm=3)
     ms_look = timed(lambda k: lookup(bs[k % 2][0], True), steps=8, warm=2)
+    # when the lookup's output rows are complete (a token lookup defers its partition pass): the tile kernel alone
+    ops.kv_profile_enable(var, 64)
+    for k in range(4):
+      full(k)
+    torch.cuda.synchronize()
+    pr = ops.kv_profile_read(var)
+    ops.kv_profile_enable(var, 0)
+    rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0]) / max(pr["lookup_tile"][1], 1)
     sweep.append({"zipf": sk, "unique_per_batch": float(np.mean([b[2] for b in bs])), "ms_per_step": ms_step,
-                  "lookup_ms": ms_look, "apply_ms": ms_step - ms_look})
+                  "lookup_ms": ms_look, "lookup_rows_ready_ms": rows_ms, "apply_ms": ms_step - ms_look})
     del bs
   res["skew_sweep"] = sweep
   return res

@@ -4,7 +4,7 @@ with every sparse feature in a GPU KvVariable, fp32, synthetic Criteo-shaped dat
 26 categorical features (hash buckets and embedding dims of train.py:45-101: eighteen tables of
 dim 64, eight of dim 128), 13 continuous ones, a 2-layer cross network and a 1024-512-256 MLP.
 The sparse side goes through the batched ops — one kv_multi_gather_or_insert and one
-kv_multi_apply_group_adam per embedding dim — so a step issues 2 x (3 + 2) sparse launches
+kv_multi_apply_group_adam per embedding dim — so a step issues 2 x (2 + 2) sparse launches
 instead of 26 x 5; the dense tower is plain torch (it is not part of the rebuilt hot path).
 
   python examples/dcn_train.py --steps 200 --batch_size 2048
@@ -45,17 +45,21 @@ class SparseFeatures(object):
   def lookup(self, cat_ids):
     """cat_ids [B, 26] int64 -> list of 26 leaf tensors [B, dim] that collect their gradients."""
     outs = [None] * 26
-    for dim, members in self.groups.items():
-      rows = ops.kv_multi_gather_or_insert([m[1] for m in members], [cat_ids[:, m[0]].contiguous() for m in members])
+    self._cols = (cat_ids, {})   # the id columns as handed to the lookup: the apply passes the SAME tensors, so the
+    for dim, members in self.groups.items():   # batched optimizer op takes over the lookup's index (batch tokens)
+      cols = [cat_ids[:, m[0]].contiguous() for m in members]
+      self._cols[1][dim] = cols
+      rows = ops.kv_multi_gather_or_insert([m[1] for m in members], cols)
       for m, r in zip(members, rows):
         outs[m[0]] = r.requires_grad_(True)
     return outs
 
   def apply(self, cat_ids, leaves):
+    kept = getattr(self, "_cols", (None, {}))
     for dim, members in self.groups.items():
+      cols = kept[1][dim] if kept[0] is cat_ids else [cat_ids[:, m[0]].contiguous() for m in members]
       ops.kv_multi_group_sparse_apply_adam([m[1] for m in members], [m[2] for m in members],
-                                           [leaves[m[0]].grad for m in members],
-                                           [cat_ids[:, m[0]].contiguous() for m in members], self.lr, self.b1p, self.b2p,
+                                           [leaves[m[0]].grad for m in members], cols, self.lr, self.b1p, self.b2p,
                                            0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, version=4)
     self.b1p, self.b2p = np.float32(self.b1p * np.float32(0.9)), np.float32(self.b2p * np.float32(0.999))
 

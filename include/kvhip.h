@@ -326,6 +326,26 @@ int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, co
                                      const void* const* ids, const int64_t* ns, float lr, float l1,
                                      float l2, float l21, float l2_shrinkage, float lr_power,
                                      kv_stream_t stream);
+/* The batch token (see kv_gather_or_insert_tok) for the batched ops: tokens[i] names the index the batched lookup left
+ * in tables[i]'s workspace; the batched optimizer ops given the same ids and those tokens skip their index pass when
+ * EVERY token is still valid (else all tables are indexed again — stale tokens are always safe).  tokens == NULL:
+ * the plain ops. */
+int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                                  const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                                  kv_batch_token_t* tokens, kv_stream_t stream);
+int kv_multi_apply_group_adam_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                                  const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                                  float beta1_power, float beta2_power, float beta1, float beta2, float epsilon, float l1,
+                                  float l2, float l21, int version, const kv_batch_token_t* tokens, kv_stream_t stream);
+int kv_multi_apply_adagrad_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                               const float* const* grads, const void* const* ids, const int64_t* ns,
+                               int update_slots, const kv_batch_token_t* tokens, kv_stream_t stream);
+int kv_multi_apply_sparse_group_ftrl_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                         const kv_handle_t* linears, const float* const* grads,
+                                         const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
+                                         float l21, float l2_shrinkage, float lr_power,
+                                         const kv_batch_token_t* tokens, kv_stream_t stream);
+
 
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the
  * reference runs unique_with_counts -> GatherOrInsert[WithCounts] -> gather(idx) -> (x weights) ->

@@ -83,6 +83,78 @@ def test_multi_ops_equal_single_ops(ops, D, sizes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "ftrl"])
+def test_multi_ops_take_over_the_batched_lookups_index(ops, opt):
+  """The batched lookup hands every table a batch token; the batched optimizer op given the very same id tensors skips
+  its index pass (kv_multi_*_tok).  Same results as the single-table ops (which take the single lookup's token), bit for
+  bit in deterministic mode; a stale token (an op in between, another tensor) falls back to indexing again."""
+  D, sizes = 32, [3000, 2048, 1, 0, 9000, 40]
+  T = len(sizes)
+  rng = np.random.default_rng(5)
+  nslot = {"adam": 1, "adagrad": 1, "ftrl": 2}[opt]
+
+  def make():
+    out = []
+    for j in range(T):
+      hs = []
+      for si in range(1 + nslot):
+        dim = 3 * D if (opt == "adam" and si == 1) else D
+        h = ops.kv_variable([dim])
+        ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 21 + j)
+        tab = np.random.default_rng(90 + j).standard_normal((32, D)).astype(np.float32) if si == 0 \
+            else np.full((4, dim), 0.1 if (opt != "adam" and si == 1) else 0.0, np.float32)
+        ops.init_kv_variable_v2(h, tab)
+        ops.kv_set_deterministic(h, True)
+        hs.append(h)
+      out.append(hs)
+    return out
+
+  def apply(multi, tabs, grads, ids):
+    if opt == "adam":
+      if multi:
+        ops.kv_multi_group_sparse_apply_adam([a[0] for a in tabs], [a[1] for a in tabs], grads, ids, 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+      else:
+        for b, g, i in zip(tabs, grads, ids):
+          ops.kv_variable_group_sparse_apply_adam_v4(b[0], b[1], g, i, 1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+    elif opt == "adagrad":
+      if multi:
+        ops.kv_multi_sparse_apply_adagrad([a[0] for a in tabs], [a[1] for a in tabs], 0.05, grads, ids)
+      else:
+        for b, g, i in zip(tabs, grads, ids):
+          ops.kv_variable_sparse_apply_adagrad(b[0], b[1], 0.05, g, i, use_locking=True)
+    else:
+      if multi:
+        ops.kv_multi_sparse_group_sparse_apply_ftrl([a[0] for a in tabs], [a[1] for a in tabs], [a[2] for a in tabs], grads, ids,
+                                                    0.05, 1e-3, 1e-3, 1e-4, 0.0, -0.5)
+      else:
+        for b, g, i in zip(tabs, grads, ids):
+          ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(b[0], b[1], b[2], g, i, 0.05, 1e-3, 1e-3, 1e-4, 0.0, -0.5)
+
+  A, B = make(), make()
+  for step in range(4):
+    ids = [torch.from_numpy(rng.integers(-400, 400, n)).cuda() for n in sizes]          # the SAME tensor objects go to both ops
+    grads = [torch.from_numpy((rng.standard_normal((n, D)) * 1e-2).astype(np.float32)).cuda() for n in sizes]
+    outs = ops.kv_multi_gather_or_insert([a[0] for a in A], ids)
+    assert all(a[0].batch is not None for a, n in zip(A, sizes) if n > 0)               # tokens were handed out
+    for j in range(T):
+      assert torch.equal(outs[j], ops.kv_variable_gather_or_insert_v2(B[j][0], ids[j])), (step, j)
+    if step == 2:     # an op in between makes one token stale: every table is indexed again, same result
+      assert ops.kv_variable_size_v2(A[0][0]) == ops.kv_variable_size_v2(B[0][0])
+      ops.kv_variable_delete(A[4][0], ids[4][:5]); ops.kv_variable_delete(B[4][0], ids[4][:5])
+    if step == 3:     # other tensor objects with the same contents: no token is passed at all
+      apply(True, A, grads, [i.clone() for i in ids])
+    else:
+      apply(True, A, grads, ids)
+    apply(False, B, grads, ids)
+  for a, b in zip(A, B):
+    for ha, hb in zip(a, b):
+      ka, va, fa, sa = _dump(ops, ha)
+      kb, vb, fb, sb = _dump(ops, hb)
+      assert torch.equal(ka, kb) and fa == fb and sa == sb
+      assert torch.equal(va, vb)
+
+
+@pytest.mark.gpu
 def test_multi_ops_argument_checks(ops):
   from tfplus_amd import _lib
   (v8, s8, _), = _tables(ops, 1, 8, seed=5)

@@ -39,6 +39,9 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
           return nb * (cus > 0 ? cus : 256);                                                       \
         }();                                                                                       \
         grid_ = (int)(nchunks / 4 + 1) > resident2 ? resident2 : (int)(nchunks / 4 + 1);   /* 16 waves per block */ \
+        /* many tables in one launch: ALL their blocks are one resident generation (26 tables x 74 blocks were four, \
+           and a generation of blocks that find no item left still costs its start-up) */       \
+        if (md && ntab > 0 && grid_ * ntab > resident2) grid_ = resident2 / ntab > 1 ? resident2 / ntab : 1;  \
       }                                                                                            \
     }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \

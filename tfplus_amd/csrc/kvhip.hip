@@ -1666,7 +1666,14 @@ static int multi_common(int num_tables, const kv_handle_t* tables, const void* c
 int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const void* const* ids,
                               const int32_t* const* counts, const int64_t* ns, float* const* outs,
                               kv_stream_t stream) {
+  return kv_multi_gather_or_insert_tok(num_tables, tables, ids, counts, ns, outs, nullptr, stream);
+}
+
+int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                                  const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                                  kv_batch_token_t* tokens, kv_stream_t stream) {
   int rc;
+  if (tokens && num_tables > 0) std::memset(tokens, 0, (size_t)num_tables * sizeof(kv_batch_token_t));
   if ((rc = multi_common(num_tables, tables, ids, ns))) return rc;
   if (!outs) return fail(KV_INVALID_ARGUMENT, "null argument array");
   const int device = tables[0]->device;
@@ -1714,6 +1721,14 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
     for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = true;
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
     launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
+    if (tokens)   // every table's workspace now holds the index of exactly its batch (kv_multi_apply_*_tok takes it over)
+      for (int i = 0; i < num_tables; ++i) {
+        if (ns[i] <= 0) continue;
+        tables[i]->batch_serial = ++g_serial;
+        tables[i]->batch_n = ns[i];
+        tables[i]->index_P = hd[i].w.P;
+        tokens[i] = tables[i]->batch_serial;
+      }
   } else {
     for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = false;
     launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
@@ -1729,7 +1744,7 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
 static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots0,
                               const kv_handle_t* slots1, int slot_mult, const float* const* grads,
                               const void* const* ids, const int64_t* ns, const OptArgs& a, int opt,
-                              kv_stream_t stream) {
+                              kv_stream_t stream, const kv_batch_token_t* tokens = nullptr) {
   int rc;
   if ((rc = multi_common(num_tables, vars, ids, ns))) return rc;
   if ((rc = check_same_shape(num_tables, slots0, "slot tables"))) return rc;
@@ -1762,9 +1777,16 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   MultiLock lock(all);
   if ((rc = lock.enter(s))) return rc;
   long long nmax = 0;
+  // the batch tokens of a kv_multi_gather_or_insert_tok over the same ids: the index pass is skipped when EVERY table
+  // still holds the index of its batch (one stale token and all tables are indexed again: one launch either way)
+  bool reuse = tokens != nullptr && fused_ok(D);
+  for (int i = 0; i < num_tables && reuse; ++i)
+    if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
+                       !vars[i]->part_pending && !vars[i]->side_pending))
+      reuse = false;
   for (int i = 0; i < num_tables; ++i) {
-    vars[i]->batch_serial = 0;
-    if ((rc = ensure_capacity(vars[i], ns[i], s))) return rc;
+    if (!reuse) vars[i]->batch_serial = 0;
+    if (!reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
     if ((rc = ensure_capacity(slots0[i], ns[i], s))) return rc;
     if (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))) return rc;
     if ((rc = ensure_workspace(vars[i], std::max<long long>(ns[i], 1), true, s))) return rc;
@@ -1790,6 +1812,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
+    if (reuse && ns[i] > 0 && vars[i]->index_P) { d.w.P = vars[i]->index_P; d.w.pshift = 64 - ilog2(d.w.P); }   // the lookup's partitioning
     wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
     wmax.P = std::max(wmax.P, d.w.P);
   }
@@ -1802,8 +1825,12 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = true;
     wmax.hc = (unsigned)HC2;
     skip_fin = wmax.ntiles <= wmax.hc;
-    launch_ltile(vars[0], hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, false);
-    launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+    if (!reuse) {
+      launch_ltile(vars[0], hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, false);
+      launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+      for (int i = 0; i < num_tables; ++i)
+        if (ns[i] > 0) { vars[i]->batch_serial = ++g_serial; vars[i]->batch_n = ns[i]; vars[i]->index_P = hd[i].w.P; }
+    }
     if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, nmax, (void*)s, md, num_tables))) return fail(rc, "tile sums: no kernel for dim %d", D);
   } else {
     for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = false;
@@ -1826,6 +1853,14 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
                               const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
                               float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
                               int version, kv_stream_t stream) {
+  return kv_multi_apply_group_adam_tok(num_tables, vars, slots, grads, ids, ns, lr, b1p, b2p, b1, b2, eps, l1, l2, l21, version,
+                                       nullptr, stream);
+}
+
+int kv_multi_apply_group_adam_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                                  const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                                  float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
+                                  int version, const kv_batch_token_t* tokens, kv_stream_t stream) {
   if (version != 3 && version != 4) return fail(KV_INVALID_ARGUMENT, "GroupAdam version %d: 3 or 4", version);
   if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
   if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
@@ -1843,21 +1878,36 @@ int kv_multi_apply_group_adam(int num_tables, const kv_handle_t* vars, const kv_
   }
   a.l21_norm = a.l21 * std::sqrt((float)vars[0]->dim);
   return multi_apply_common(num_tables, vars, slots, nullptr, 3, grads, ids, ns, a,
-                            version == 4 ? OPT_ADAM_V4 : OPT_ADAM_V3, stream);
+                            version == 4 ? OPT_ADAM_V4 : OPT_ADAM_V3, stream, tokens);
 }
 
 int kv_multi_apply_adagrad(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
                            const float* const* grads, const void* const* ids, const int64_t* ns,
                            int update_slots, kv_stream_t stream) {
+  return kv_multi_apply_adagrad_tok(num_tables, vars, accums, lr, grads, ids, ns, update_slots, nullptr, stream);
+}
+
+int kv_multi_apply_adagrad_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                               const float* const* grads, const void* const* ids, const int64_t* ns,
+                               int update_slots, const kv_batch_token_t* tokens, kv_stream_t stream) {
   OptArgs a{};
   a.lr = lr; a.update_slots = update_slots;
-  return multi_apply_common(num_tables, vars, accums, nullptr, 1, grads, ids, ns, a, OPT_ADAGRAD, stream);
+  return multi_apply_common(num_tables, vars, accums, nullptr, 1, grads, ids, ns, a, OPT_ADAGRAD, stream, tokens);
 }
 
 int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
                                      const kv_handle_t* linears, const float* const* grads,
                                      const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
                                      float l21, float l2s, float lr_power, kv_stream_t stream) {
+  return kv_multi_apply_sparse_group_ftrl_tok(num_tables, vars, accums, linears, grads, ids, ns, lr, l1, l2, l21, l2s, lr_power,
+                                              nullptr, stream);
+}
+
+int kv_multi_apply_sparse_group_ftrl_tok(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                         const kv_handle_t* linears, const float* const* grads,
+                                         const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
+                                         float l21, float l2s, float lr_power, const kv_batch_token_t* tokens,
+                                         kv_stream_t stream) {
   if (!(lr > 0.f)) return fail(KV_INVALID_ARGUMENT, "lr is not a positive scalar: %g", lr);
   if (!(l1 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l1 regularization strength is not a non-negative scalar: %g", l1);
   if (!(l2 >= 0.f)) return fail(KV_INVALID_ARGUMENT, "l2 regularization strength is not a non-negative scalar: %g", l2);
@@ -1868,7 +1918,7 @@ int kv_multi_apply_sparse_group_ftrl(int num_tables, const kv_handle_t* vars, co
   OptArgs a{};
   a.lr = lr; a.l1 = l1; a.l2 = l2; a.l21 = l21; a.l2s = l2s; a.lr_power = lr_power;
   a.l21_norm = l21 * std::sqrt((float)vars[0]->dim);  // training_ops.cc:728
-  return multi_apply_common(num_tables, vars, accums, linears, 1, grads, ids, ns, a, OPT_FTRL, stream);
+  return multi_apply_common(num_tables, vars, accums, linears, 1, grads, ids, ns, a, OPT_FTRL, stream, tokens);
 }
 
 }  // extern "C"

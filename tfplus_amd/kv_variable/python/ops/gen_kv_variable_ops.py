@@ -569,9 +569,19 @@ def kv_multi_gather_or_insert(table_handles, indices, counts=None):
   outs = [torch.empty(tuple(i.shape) + (h.dim,), dtype=torch.float32, device=i.device) for h, i in zip(table_handles, ids)]
   hp = (ctypes.c_void_p * n)(*[h.ptr for h in table_handles])
   ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
-  _lib.check(_lib.lib().kv_multi_gather_or_insert(n, hp, _ptr_array(ids), None if cnt is None else _ptr_array(cnt), ns,
-                                                  _ptr_array(outs), _stream(table_handles[0])))
+  toks = (ctypes.c_uint64 * n)()
+  _lib.check(_lib.lib().kv_multi_gather_or_insert_tok(n, hp, _ptr_array(ids), None if cnt is None else _ptr_array(cnt), ns,
+                                                      _ptr_array(outs), toks, _stream(table_handles[0])))
+  for h, i, t in zip(table_handles, ids, toks):   # the batched optimizer ops handed these very tensors skip their index pass
+    _remember_batch(h, i, int(t))
   return outs
+
+
+def _multi_tokens(var_handles, indices):
+  """ids as the C ABI wants them (flat) and the batch tokens of a batched lookup over the very same tensor objects."""
+  base = [_ids(h, i) for h, i in zip(var_handles, indices)]
+  toks = (ctypes.c_uint64 * len(base))(*[_token_for(h, b) for h, b in zip(var_handles, base)])
+  return [b.reshape(-1) for b in base], toks
 
 
 def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, indices, lr, beta1_power, beta2_power,
@@ -580,7 +590,7 @@ def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, ind
   n = len(var_handles)
   if n < 1 or not (n == len(m_v_linear_handles) == len(grads) == len(indices)):
     raise _lib.InvalidArgumentError("vars, slots, grads and indices must be equally long, N >= 1")
-  ids = [_ids(h, i).reshape(-1) for h, i in zip(var_handles, indices)]
+  ids, toks = _multi_tokens(var_handles, indices)
   gr = [_f32(h, g).reshape(-1, h.dim) for h, g in zip(var_handles, grads)]
   for g, i in zip(gr, ids):
     if g.shape[0] != i.numel():
@@ -589,18 +599,18 @@ def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, ind
   sp = (ctypes.c_void_p * n)(*[h.ptr for h in m_v_linear_handles])
   ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
   sc = [ctypes.c_float(_scalar(x)) for x in (lr, beta1_power, beta2_power, beat1, beta2, epsilon, l1, l2, l21)]
-  _lib.check(_lib.lib().kv_multi_apply_group_adam(n, vp, sp, _ptr_array(gr), _ptr_array(ids), ns, *sc, int(version),
-                                                  _stream(var_handles[0])))
+  _lib.check(_lib.lib().kv_multi_apply_group_adam_tok(n, vp, sp, _ptr_array(gr), _ptr_array(ids), ns, *sc, int(version),
+                                                      toks, _stream(var_handles[0])))
 
 
 def _multi_prep(var_handles, grads, indices):
-  ids = [_ids(h, i).reshape(-1) for h, i in zip(var_handles, indices)]
+  ids, toks = _multi_tokens(var_handles, indices)
   gr = [_f32(h, g).reshape(-1, h.dim) for h, g in zip(var_handles, grads)]
   for g, i in zip(gr, ids):
     if g.shape[0] != i.numel():
       raise _lib.InvalidArgumentError("grad must be the same size as indices in the first dimension.")
   n = len(var_handles)
-  return ids, gr, (ctypes.c_int64 * n)(*[i.numel() for i in ids])
+  return ids, gr, (ctypes.c_int64 * n)(*[i.numel() for i in ids]), toks
 
 
 def kv_multi_sparse_apply_adagrad(var_handles, accum_handles, lr, grads, indices, update_slots=True):
@@ -608,10 +618,10 @@ def kv_multi_sparse_apply_adagrad(var_handles, accum_handles, lr, grads, indices
   n = len(var_handles)
   if n < 1 or not (n == len(accum_handles) == len(grads) == len(indices)):
     raise _lib.InvalidArgumentError("vars, accums, grads and indices must be equally long, N >= 1")
-  ids, gr, ns = _multi_prep(var_handles, grads, indices)
+  ids, gr, ns, toks = _multi_prep(var_handles, grads, indices)
   vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
-  _lib.check(_lib.lib().kv_multi_apply_adagrad(n, vp, ap, ctypes.c_float(_scalar(lr)), _ptr_array(gr), _ptr_array(ids), ns,
-                                               int(bool(update_slots)), _stream(var_handles[0])))
+  _lib.check(_lib.lib().kv_multi_apply_adagrad_tok(n, vp, ap, ctypes.c_float(_scalar(lr)), _ptr_array(gr), _ptr_array(ids), ns,
+                                                   int(bool(update_slots)), toks, _stream(var_handles[0])))
 
 
 def kv_multi_sparse_group_sparse_apply_ftrl(var_handles, accum_handles, linear_handles, grads, indices, lr, l1, l2, l21,
@@ -620,12 +630,12 @@ def kv_multi_sparse_group_sparse_apply_ftrl(var_handles, accum_handles, linear_h
   n = len(var_handles)
   if n < 1 or not (n == len(accum_handles) == len(linear_handles) == len(grads) == len(indices)):
     raise _lib.InvalidArgumentError("vars, accums, linears, grads and indices must be equally long, N >= 1")
-  ids, gr, ns = _multi_prep(var_handles, grads, indices)
+  ids, gr, ns, toks = _multi_prep(var_handles, grads, indices)
   vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
   lp = (ctypes.c_void_p * n)(*[h.ptr for h in linear_handles])
   sc = [ctypes.c_float(_scalar(x)) for x in (lr, l1, l2, l21, l2_shrinkage, lr_power)]
-  _lib.check(_lib.lib().kv_multi_apply_sparse_group_ftrl(n, vp, ap, lp, _ptr_array(gr), _ptr_array(ids), ns, *sc,
-                                                         _stream(var_handles[0])))
+  _lib.check(_lib.lib().kv_multi_apply_sparse_group_ftrl_tok(n, vp, ap, lp, _ptr_array(gr), _ptr_array(ids), ns, *sc,
+                                                             toks, _stream(var_handles[0])))
 
 
 _COMBINERS = {"sum": _lib.KV_COMBINER_SUM, "mean": _lib.KV_COMBINER_MEAN, "sqrtn": _lib.KV_COMBINER_SQRTN}

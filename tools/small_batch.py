@@ -31,10 +31,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "multi":
   ip = (ctypes.c_void_p * T_)(*[i.data_ptr() for i in ids]); gp = (ctypes.c_void_p * T_)(*[g_.data_ptr() for g_ in grads])
   op = (ctypes.c_void_p * T_)(*[o.data_ptr() for o in outs]); nsz = (ctypes.c_int64 * T_)(*([N] * T_))
   f = ctypes.c_float
+  toks = (ctypes.c_uint64 * T_)()
+  use_tok = not (len(sys.argv) > 4 and sys.argv[4] == "notoken")   # batch tokens: the apply takes over the lookup's index
   def step():
-    _lib.check(L.kv_multi_gather_or_insert(T_, vp, ip, None, nsz, op, sts[0]))
-    _lib.check(L.kv_multi_apply_group_adam(T_, vp, sp, gp, ip, nsz, f(1e-3), f(0.9), f(0.999), f(0.9), f(0.999), f(1e-8),
-                                           f(0), f(0), f(0), 4, sts[0]))
+    _lib.check(L.kv_multi_gather_or_insert_tok(T_, vp, ip, None, nsz, op, toks if use_tok else None, sts[0]))
+    _lib.check(L.kv_multi_apply_group_adam_tok(T_, vp, sp, gp, ip, nsz, f(1e-3), f(0.9), f(0.999), f(0.9), f(0.999), f(1e-8),
+                                               f(0), f(0), f(0), 4, toks if use_tok else None, sts[0]))
 for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 50
