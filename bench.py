@@ -186,18 +186,19 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
   for sk in (0.3, 0.8, 1.2):
     z = Zipf(K, sk, dev)
     bs = []
-    for _ in range(2):
+    NB = 6   # as many distinct batches as the headline's pool nearly: two alternating ones would stay warm in the 256 MB MALL
+    for _ in range(NB):
       ids = splitmix64(z.sample(N, gen))
       bs.append((ids, torch.randn(N, D, device=dev, generator=gen) * 1e-2, int(torch.unique(ids).numel())))
 
     def full(k):
-      ids, grad, _ = bs[k % 2]
+      ids, grad, _ = bs[k % NB]
       adam(ids, grad, N, lookup(ids, True))
-    ms_step = timed(full, steps=8, warm=3)
-    ms_look = timed(lambda k: lookup(bs[k % 2][0], True), steps=8, warm=2)
+    ms_step = timed(full, steps=12, warm=3)
+    ms_look = timed(lambda k: lookup(bs[k % NB][0], True), steps=12, warm=2)
     # when the lookup's output rows are complete (a token lookup defers its partition pass): the tile kernel alone
     ops.kv_profile_enable(var, 64)
-    for k in range(4):
+    for k in range(NB):
       full(k)
     torch.cuda.synchronize()
     pr = ops.kv_profile_read(var)
@@ -235,6 +236,8 @@ def main():
                   help="diagnostic: overlap mode (kv_set_overlap) without graph capture: the forks and joins are event hops")
   ap.add_argument("--graph", action="store_true",
                   help="the timed steps replay HIP graphs captured in overlap mode (one graph per pooled batch)")
+  ap.add_argument("--lossless", action="store_true",
+                  help="sharded path: kv_shard_set_lossless (capacity agreed before every exchange; a host round trip per lookup)")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -355,6 +358,8 @@ def main():
     comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
     cap = peer_capacity()
     shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
+    if args.lossless:   # ranks agree on the capacity before every exchange: one all-reduce + one host round trip per lookup
+      shard.set_lossless(True)
     hp_t = ctypes.c_float * 9
     # this step has no dense tower to overlap with: queue it on the communicator's own stream, so the ops fork and
     # join nothing (with a tower on another stream each op pays one event hop in and one out, hidden behind it)
@@ -608,7 +613,7 @@ def main():
     # xGMI traffic is reported apart from HBM: three fixed-size exchanges per step, every rank sends
     # every peer one segment of peer_capacity + 1 records — (id, count) pairs, rows back, summed gradient rows
     seg = cap + 1
-    res["exchange"] = {"exchanges_per_step": 3, "peer_capacity_records": cap,
+    res["exchange"] = {"exchanges_per_step": 3, "peer_capacity_records": cap, "lossless": bool(args.lossless),
                        "wire_bytes_per_rank_per_step": (world - 1) * seg * (16 + 2 * 4 * D),
                        "payload_bytes_per_rank_per_step_estimate": int((world - 1) / world * Ub * (16 + 2 * 4 * D)),
                        "transport": "grouped ncclSend / ncclRecv (RCCL) on the communicator's stream; a rank's own "

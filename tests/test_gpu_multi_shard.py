@@ -68,6 +68,46 @@ def test_multi_shard_ops_equal_the_per_table_sharded_ops():
 
 
 @pytest.mark.gpu
+def test_multi_shard_lossless_tables_grow_together():
+  """Lossless tables in a multi-table step: ONE agreement (an all-reduce per table in one group, one synchronisation)
+  raises the capacity of exactly the tables that need it; rows and state equal the unsharded ops."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
+  rng = np.random.default_rng(12)
+  D, T = 16, 3
+  vs, ss, shs, v2, s2 = [], [], [], [], []
+  for k in range(T):
+    init = np.random.default_rng(300 + k).standard_normal((32, D)).astype(np.float32)
+    v = _table(ops, D, init, False); s = _table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), False)
+    vs.append(v); ss.append(s)
+    sh = ops.KvShard(v, 1, 0, ops.KV_OWNER_HASH, max_ids=1 << 14, peer_capacity=4096 if k == 1 else 16)
+    sh.set_lossless(k != 1)                                                # table 1: default mode, roomy capacity
+    shs.append(sh)
+    v2.append(_table(ops, D, init, False)); s2.append(_table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), False))
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
+  for step in range(2):
+    ids = [torch.from_numpy(rng.choice(50000, 2500 + 500 * k, replace=False)).cuda() for k in range(T)]
+    grads = [torch.from_numpy((rng.uniform(0.5, 1.5, (i.numel(), D)) * 1e-2).astype(np.float32)).cuda() for i in ids]
+    outs = ops.kv_multi_shard_lookup(shs, comm, ids)
+    for k in range(T):
+      assert torch.equal(outs[k], ops.kv_variable_gather_or_insert_v2(v2[k], ids[k])), (step, k)
+    assert shs[0].peer_capacity >= 2500 and shs[2].peer_capacity >= 3500 and shs[1].peer_capacity == 4096
+    ops.kv_multi_shard_apply(shs, comm, ops.OPT_GROUP_ADAM_V4, [[s] for s in ss], grads, HP)
+    for k in range(T):
+      ops.kv_variable_group_sparse_apply_adam_v4(v2[k], s2[k], grads[k], ids[k], *HP)
+  torch.cuda.synchronize()
+  for k in range(T):
+    ka, va = ops.read_kv_variable_op_v2(vs[k]); kb, vb = ops.read_kv_variable_op_v2(v2[k])
+    oa, ob = torch.argsort(ka), torch.argsort(kb)
+    assert torch.equal(ka[oa], kb[ob])
+    torch.testing.assert_close(va[oa], vb[ob], rtol=1e-6, atol=1e-7)      # distinct ids: nothing to reorder
+  del comm
+
+
+@pytest.mark.gpu
 def test_world_of_eight_forty_tables_in_one_process_match_unsharded_oracles():
   if not torch.cuda.is_available():
     pytest.skip("needs a GPU")

@@ -237,6 +237,99 @@ def test_native_shard_segment_overflow_is_reported_late_and_once():
 
 
 @pytest.mark.gpu
+def test_native_shard_lossless_mode_grows_the_capacity_on_every_shard():
+  """kv_shard_set_lossless: after the routes the shards agree on the largest segment any of them wanted; it exceeds
+  peer_capacity (16) here, so every shard raises its capacity to the same value and routes again — no id reads zeros,
+  no gradient is dropped, nothing is reported late, and the state equals ONE unsharded oracle table."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  D, world = 16, 2
+  rng = np.random.default_rng(3)
+  table = rng.standard_normal((32, D)).astype(np.float32)
+  ops, vars_, slots, shards = _native_setup(world, D, "mod", table, cap=16, max_ids=4096)
+  for sh in shards:
+    sh.set_lossless(True)
+  ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)
+  rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
+  caps = []
+  for step in range(3):
+    # rank 0's batch: 200 .. 600 distinct even ids (all owned by rank 0); rank 1's: a few odd ones
+    batches = [np.arange(0, 400 * (step + 1), 2, dtype=np.int64), rng.integers(0, 50, 40) * 2 + 1]
+    grads = [(rng.uniform(0.5, 1.5, (b.size, D)) * 1e-2).astype(np.float32) for b in batches]
+    for r in range(world):
+      shards[r].lookup_route(torch.from_numpy(batches[r]).cuda())
+    if ops.kv_shard_agree_local(shards):                                   # raised on every shard: route again
+      for r in range(world):
+        shards[r].lookup_route(torch.from_numpy(batches[r]).cuda())
+      assert not ops.kv_shard_agree_local(shards)
+    caps.append(shards[0].peer_capacity)
+    assert shards[1].peer_capacity == caps[-1] >= batches[0].size
+    ops.kv_shard_exchange_local(shards, 0)
+    for r in range(world):
+      shards[r].lookup_serve()
+    ops.kv_shard_exchange_local(shards, 1)
+    want = ref.gather_or_insert(np.concatenate(batches))
+    off = 0
+    for r in range(world):
+      got = shards[r].lookup_finish().cpu().numpy()
+      np.testing.assert_allclose(got, want[off:off + batches[r].size], rtol=2e-5, atol=2e-6)   # every row is there
+      assert np.count_nonzero(got.any(axis=1)) == batches[r].size
+      off += batches[r].size
+    for r in range(world):
+      shards[r].apply_route(torch.from_numpy(grads[r]).cuda())
+    ops.kv_shard_exchange_local(shards, 1)
+    for r in range(world):
+      shards[r].apply_serve(ops.OPT_GROUP_ADAM_V4, [slots[r]], (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+    u, s_, _ = ko.dedup_segment_sum(np.concatenate(batches), np.concatenate(grads))
+    ko.apply_group_adam(ref, rslot, s_, u, 0.1, 0.9, 0.999, 0.9, 0.999, 1e-8)
+  assert caps[0] > 16 and caps[2] > caps[0]                                # grew twice (200 ids, then 600)
+  torch.cuda.synchronize()
+  keys, vals = ops.read_kv_variable_op_v2(vars_[0])
+  refd = ref.as_dict()
+  even = sorted(k for k in refd if k % 2 == 0)
+  assert sorted(keys.cpu().tolist()) == even
+  o = torch.argsort(keys)
+  np.testing.assert_allclose(vals[o].cpu().numpy(), np.stack([refd[k] for k in even]), rtol=2e-5, atol=2e-6)
+  shards[0].lookup_route(torch.arange(4, dtype=torch.int64).cuda())        # no late report: nothing was dropped
+
+
+@pytest.mark.gpu
+def test_native_shard_lossless_whole_op_through_rccl():
+  """The whole op on a world of one through RCCL (ncclAllReduce of the needed capacity, grouped send / recv): a batch
+  of 5000 distinct ids against peer_capacity 16 comes back complete and equals the unsharded ops."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D = 16
+  rng = np.random.default_rng(9)
+  table = rng.standard_normal((32, D)).astype(np.float32)
+  ops, vars_, slots, shards = _native_setup(1, D, "hash", table, cap=16, max_ids=1 << 14)
+  var2 = ops.kv_variable([D]); slot2 = ops.kv_variable([3 * D])
+  for h, t in ((var2, table), (slot2, np.zeros((4, 3 * D), np.float32))):
+    ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, t)
+  shards[0].set_lossless(True)
+  os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
+  hp = (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
+  for step, n in enumerate((5000, 12000, 300)):
+    ids = torch.from_numpy(rng.choice(100000, n, replace=False)).cuda()
+    g = torch.from_numpy((rng.uniform(0.5, 1.5, (n, D)) * 1e-2).astype(np.float32)).cuda()
+    out = shards[0].lookup(comm, ids)
+    assert torch.equal(out, ops.kv_variable_gather_or_insert_v2(var2, ids))     # distinct ids: rows are copies
+    assert shards[0].peer_capacity >= min(n, 12000 if step else 5000)
+    shards[0].apply(comm, ops.OPT_GROUP_ADAM_V4, [slots[0]], g, hp)
+    ops.kv_variable_group_sparse_apply_adam_v4(var2, slot2, g, ids, *hp)
+  torch.cuda.synchronize()
+  k1, v1 = ops.read_kv_variable_op_v2(vars_[0]); k2, v2 = ops.read_kv_variable_op_v2(var2)
+  o1, o2 = torch.argsort(k1), torch.argsort(k2)
+  assert torch.equal(k1[o1], k2[o2])
+  torch.testing.assert_close(v1[o1], v2[o2], rtol=1e-6, atol=1e-7)              # unique ids: the op boundary's tolerance
+  del comm
+
+
+@pytest.mark.gpu
 def test_native_shard_full_capacity_cannot_overflow():
   """peer_capacity = max_ids: the worst case — every distinct id of a full batch owned by ONE rank — fits; nothing is
   dropped, nothing is reported (the lossless setting; it costs world x the wire bytes)."""

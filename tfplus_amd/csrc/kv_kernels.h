@@ -1879,21 +1879,31 @@ __global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __res
 // ... and its headers, from the fill counters, which it zeroes for the next batch.  (A last-block-done epilogue in
 // the kernel above would need a device-scope release fence per block; on gfx950 that writes the XCD's L2 back and
 // cost 60 us behind the partition pass.)
-__global__ void k_seg_headers_take(unsigned* __restrict__ gcount, int world, unsigned C, long long* __restrict__ seg) {
+// need[0] (may be null) = the largest segment this batch WANTED, capped or not: what peer_capacity would have had to be
+// (one block: thread 0 clears it, every owner's thread raises it)
+__global__ void k_seg_headers_take(unsigned* __restrict__ gcount, int world, unsigned C, long long* __restrict__ seg,
+                                   unsigned* __restrict__ need) {
   const int d = threadIdx.x;
+  if (need && d == 0) *need = 0u;
+  __syncthreads();
   if (d < world) {
     const unsigned c = gcount[d];
     gcount[d] = 0;
     seg[2 * (size_t)d * (C + 1)] = c < C ? c : C;
     seg[2 * (size_t)d * (C + 1) + 1] = 0;
+    if (need) atomicMax(need, c);
   }
 }
 // the segments' headers {records in the segment (at most C), 0}
-__global__ void k_seg_headers(const long long* __restrict__ counts, int world, unsigned C, long long* __restrict__ seg) {
+__global__ void k_seg_headers(const long long* __restrict__ counts, int world, unsigned C, long long* __restrict__ seg,
+                              unsigned* __restrict__ need) {
   const int d = threadIdx.x;
+  if (need && d == 0) *need = 0u;
+  __syncthreads();
   if (d < world) {
     seg[2 * (size_t)d * (C + 1)] = counts[d] < (long long)C ? counts[d] : (long long)C;
     seg[2 * (size_t)d * (C + 1) + 1] = 0;
+    if (need) atomicMax(need, (unsigned)(counts[d] < 0x7FFFFFFFll ? counts[d] : 0x7FFFFFFFll));
   }
 }
 // k_owner_hist over the sparse unique list of the sharded route (entries with a count of 0 name no key)

@@ -2810,6 +2810,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;   // lossless mode only
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -2833,6 +2834,7 @@ RcclApi* rccl() {
     api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
     api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv;
   });
@@ -2871,6 +2873,10 @@ struct kv_shard {
   unsigned* gcount = nullptr;        // [MAXW + 1] k_owner_route_fixed's counters (zero between launches)
   unsigned* overflow = nullptr;      // pinned, mapped: a segment was too small for a batch
   unsigned long long overflows = 0;  // batches reported so far
+  unsigned* need = nullptr;          // device [2]: the largest segment the last routed batch wanted; the same over all ranks
+  unsigned* need_host = nullptr;     // pinned copy of need[1]
+  bool lossless = false;             // kv_shard_set_lossless: ranks agree on the capacity before every exchange
+  unsigned long long grows = 0;      // times the capacity was raised
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
   const kv_comm* verified = nullptr; // the communicator whose ranks were seen to agree on world / capacity / dim
@@ -3029,6 +3035,8 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
         hipMalloc(&sh->hist, (size_t)ntr * world * 4) != hipSuccess ||
         hipMalloc(&sh->gcount, (MAXW + 1) * 4) != hipSuccess || hipMemset(sh->gcount, 0, (MAXW + 1) * 4) != hipSuccess ||
         hipHostMalloc(&sh->overflow, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipMalloc(&sh->need, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(sh->need, 0, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc(&sh->need_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&sh->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sh->ev_done, hipEventDisableTiming) != hipSuccess) {
       rc = fail(KV_RESOURCE_EXHAUSTED, "kv_shard_create: allocation failed");
@@ -3049,6 +3057,8 @@ int kv_shard_destroy(kv_shard_t sh) {
   shard_free_buffers(sh);
   hipFree(sh->uniq); hipFree(sh->ucnt); hipFree(sh->slot_of); hipFree(sh->counts); hipFree(sh->hist); hipFree(sh->gcount);
   if (sh->overflow) hipHostFree(sh->overflow);
+  if (sh->need) hipFree(sh->need);
+  if (sh->need_host) hipHostFree(sh->need_host);
   if (sh->ev_fork) hipEventDestroy(sh->ev_fork);
   if (sh->ev_done) hipEventDestroy(sh->ev_done);
   if (sh->route) kv_destroy(sh->route);
@@ -3099,7 +3109,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   sh->route_token = 0;
   if (n == 0) {
     HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, s));
-    k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+    k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
     return KV_OK;
   }
   if ((rc = ensure_workspace(rt, n, true, s))) return rc;
@@ -3124,13 +3134,13 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   if (!pa.det) {
     k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
                                            sh->overflow, sh->gcount);
-    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs);
+    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need);
     HIP_TRY(hipGetLastError());
     return KV_OK;
   }
   k_owner_hist_u32<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, ntr, sh->hist);
   k_owner_scan<<<1, 1024, 0, s>>>(sh->hist, ntr * sh->world, ntr, sh->world, sh->counts);
-  k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+  k_seg_headers<<<1, MAXW, 0, s>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
   k_owner_scatter_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, ntr, sh->hist, sh->C, sh->send_pairs,
                                            sh->slot_of, sh->overflow);
   HIP_TRY(hipGetLastError());
@@ -3284,6 +3294,78 @@ static int shard_verify(kv_shard* sh, kv_comm* comm) {
   return rc;
 }
 
+// Lossless mode (kv_shard_set_lossless): before anything is exchanged every rank learns the largest segment ANY rank's
+// route wanted (one 4-byte all-reduce per table, one stream synchronisation for all tables) and, when that exceeds the
+// capacity, every rank raises its capacity to the same new value — they all computed it from the same number — and
+// routes the batch again.  grown[k] != 0: shards[k] must be routed again.  The price is the host round trip per lookup
+// that the default mode avoids; nothing is ever dropped.
+static int shard_agree_many(const kv_shard_t* shards, int ntab, kv_comm* comm, hipStream_t w, char* grown) {
+  bool any = false;
+  for (int k = 0; k < ntab; ++k) { grown[k] = 0; any = any || shards[k]->lossless; }
+  if (!any) return KV_OK;
+  if (comm->comm) {
+    if (!rccl()->AllReduce) return fail(KV_UNIMPLEMENTED, "lossless sharding needs ncclAllReduce");
+    NCCL_TRY(rccl()->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int k = 0; k < ntab && bad == ncclSuccess; ++k)
+      if (shards[k]->lossless)
+        bad = rccl()->AllReduce(shards[k]->need, shards[k]->need + 1, 1, ncclUint32, ncclMax, comm->comm, w);
+    const ncclResult_t e = rccl()->GroupEnd();
+    if (bad == ncclSuccess) bad = e;
+    if (bad != ncclSuccess) return fail(KV_INTERNAL, "ncclAllReduce failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(bad) : "?");
+  }
+  for (int k = 0; k < ntab; ++k)
+    if (shards[k]->lossless)
+      HIP_TRY(hipMemcpyAsync(shards[k]->need_host, shards[k]->need + (comm->comm ? 1 : 0), sizeof(unsigned), hipMemcpyDeviceToHost, w));
+  HIP_TRY(hipStreamSynchronize(w));
+  for (int k = 0; k < ntab; ++k) {
+    kv_shard* sh = shards[k];
+    if (!sh->lossless) continue;
+    const unsigned need = *sh->need_host;
+    if (need <= sh->C) continue;
+    const long long newC = std::min<long long>(sh->max_ids, (long long)need + need / 4 + 64);
+    int rc;
+    if ((rc = shard_alloc_buffers(sh, (unsigned)newC))) return rc;
+    *reinterpret_cast<volatile unsigned*>(sh->overflow) = 0;   // raised by the attempt that is now repeated
+    ++sh->grows;
+    grown[k] = 1;
+  }
+  return KV_OK;
+}
+
+int kv_shard_set_lossless(kv_shard_t sh, int on) {
+  if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
+  sh->lossless = on != 0;
+  return KV_OK;
+}
+
+// the same agreement between shards that live in ONE process (see kv_shard_exchange_local): call it after every
+// shard's kv_shard_lookup_route; *rerouted != 0 means the capacity was raised on all of them and the routes must run again
+int kv_shard_agree_local(const kv_shard_t* shards, int world, int* rerouted, kv_stream_t stream) {
+  if (!shards || world < 1 || !rerouted) return fail(KV_INVALID_ARGUMENT, "kv_shard_agree_local: bad arguments");
+  *rerouted = 0;
+  for (int p = 0; p < world; ++p)
+    if (!shards[p] || shards[p]->world != world || shards[p]->C != shards[0]->C)
+      return fail(KV_INVALID_ARGUMENT, "kv_shard_agree_local: shards differ in world / capacity");
+  DeviceGuard dg(shards[0]->table->device);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned need = 0;
+  for (int p = 0; p < world; ++p)
+    HIP_TRY(hipMemcpyAsync(shards[p]->need_host, shards[p]->need, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int p = 0; p < world; ++p) need = std::max(need, *shards[p]->need_host);
+  if (need <= shards[0]->C) return KV_OK;
+  const long long newC = std::min<long long>(shards[0]->max_ids, (long long)need + need / 4 + 64);
+  for (int p = 0; p < world; ++p) {
+    int rc;
+    if ((rc = shard_alloc_buffers(shards[p], (unsigned)newC))) return rc;
+    *reinterpret_cast<volatile unsigned*>(shards[p]->overflow) = 0;
+    ++shards[p]->grows;
+  }
+  *rerouted = 1;
+  return KV_OK;
+}
+
 int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, float* out, int join, kv_stream_t stream) {
   if (!sh || !comm || comm->world != sh->world) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup: shard / communicator mismatch");
   DeviceGuard dg(sh->table->device);
@@ -3293,7 +3375,7 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   const unsigned seen = shard_take_flag(sh);
   hipStream_t w = comm->stream;   // phases and exchanges in one queue: no event hop between a kernel and its exchange
   if ((rc = shard_fork(sh, s, w))) return rc;
-  const int64_t pb = (int64_t)(sh->C + 1) * 16, rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+  int64_t pb = (int64_t)(sh->C + 1) * 16, rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
   // A failure of THIS rank's phase (out of memory, a bad argument) must not leave the peers waiting in a grouped recv:
   // the exchanges are queued all the same — void headers for a failed route, zero rows for a failed serve — and the
   // first error is returned once everything is queued.  Only a failed exchange itself returns at once.
@@ -3303,7 +3385,19 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   if (note(lookup_route_impl(sh, ids, n, w))) {
     sh->n_last = 0; sh->route_token = 0;
     HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
-    k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+    k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
+  }
+  if (sh->lossless) {   // every rank takes part in the agreement, whatever its own route did
+    char grown = 0;
+    if ((rc = shard_agree_many(&sh, 1, comm, w, &grown))) return rc;
+    if (grown) {
+      pb = (int64_t)(sh->C + 1) * 16; rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+      if (!first && note(lookup_route_impl(sh, ids, n, w))) { sh->n_last = 0; sh->route_token = 0; }
+      if (first) {   // this rank's batch was refused: its segments are void in the new buffers too
+        HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
+        k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
+      }
+    }
   }
   if ((rc = kv_comm_all_to_all(comm, sh->send_pairs, sh->recv_pairs, comm->comm ? pb : pb * sh->world, w))) return rc;
   if (note(kv_shard_lookup_serve(sh, w)))
@@ -3371,18 +3465,35 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   std::vector<void*> rp(ntab), rr(ntab);
   std::vector<int64_t> pb(ntab), rb(ntab);
   std::vector<char> routed(ntab, 1);
-  for (int k = 0; k < ntab; ++k) {
+  auto buffers = [&](int k) {
     kv_shard* sh = shards[k];
     const int64_t mul = comm->comm ? 1 : sh->world;
     pb[k] = (int64_t)(sh->C + 1) * 16 * mul;
     rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * mul;
     sp[k] = sh->send_pairs; rp[k] = sh->recv_pairs; sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
-    if (note(lookup_route_impl(sh, ids[k], n[k], w))) {   // as in kv_shard_lookup: void headers, the peers are not left waiting
-      routed[k] = 0;
+  };
+  auto route = [&](int k) -> int {
+    kv_shard* sh = shards[k];
+    if (routed[k] && note(lookup_route_impl(sh, ids[k], n[k], w))) routed[k] = 0;
+    if (!routed[k]) {   // as in kv_shard_lookup: void headers, the peers are not left waiting
       sh->n_last = 0; sh->route_token = 0;
       HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
-      k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs);
+      k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
     }
+    return KV_OK;
+  };
+  for (int k = 0; k < ntab; ++k) {
+    buffers(k);
+    if ((rc = route(k))) return rc;
+  }
+  {   // lossless tables: one agreement for all of them (see shard_agree_many), then the grown ones are routed again
+    std::vector<char> grown(ntab, 0);
+    if ((rc = shard_agree_many(shards, ntab, comm, w, grown.data()))) return rc;
+    for (int k = 0; k < ntab; ++k)
+      if (grown[k]) {
+        buffers(k);
+        if ((rc = route(k))) return rc;
+      }
   }
   if ((rc = comm_exchange(comm, ntab, sp.data(), rp.data(), pb.data(), w))) return rc;
   for (int k = 0; k < ntab; ++k)

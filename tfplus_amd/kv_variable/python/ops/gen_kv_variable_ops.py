@@ -811,6 +811,14 @@ class KvShard(object):
     out["pair_bytes_per_peer"], out["row_bytes_per_peer"] = pb.value, rb.value
     return out
 
+  def set_lossless(self, on=True):
+    """Ranks agree on the capacity before every exchange (one host round trip per lookup); nothing is ever dropped."""
+    _lib.check(_lib.lib().kv_shard_set_lossless(self.ptr, int(bool(on))))
+
+  @property
+  def peer_capacity(self):
+    return self.buffers()["pair_bytes_per_peer"] // 16 - 1
+
   # whole ops over a KvComm
   def lookup(self, comm, indices, join=True):
     ids = _ids(self.table, indices)
@@ -885,6 +893,14 @@ def kv_multi_shard_apply(shards, comm, optimizer, slots_list, grads, hp, join=Tr
   _lib.check(_lib.lib().kv_multi_shard_apply(arr, T, comm.ptr, int(optimizer), s0, s1, gp, hpa, int(bool(join)), _stream(shards[0].table)))
   for sh, g in zip(shards, gs):
     sh._keep_g = g
+
+
+def kv_shard_agree_local(shards):
+  """Lossless mode between shards of one process: True when the capacity was raised (route every shard again)."""
+  arr = (ctypes.c_void_p * len(shards))(*[s.ptr for s in shards])
+  again = ctypes.c_int32(0)
+  _lib.check(_lib.lib().kv_shard_agree_local(arr, len(shards), ctypes.byref(again), _stream(shards[0].table)))
+  return bool(again.value)
 
 
 def kv_shard_exchange_local(shards, what):
