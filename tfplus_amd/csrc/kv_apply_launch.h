@@ -97,7 +97,7 @@ inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad,
                          const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = td.dim;
   const int what = n < 0 ? 1 : (grad == nullptr ? 2 : 0);
-  const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? (unsigned)ITEM_BLOCKS : (unsigned)ITEM_BLOCKS + wd.ntiles;
+  const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? wd.nib : wd.nib + wd.ntiles;
 #define KV_TSUM(V, LPR, K)                                                                              \
   do {                                                                                                  \
     if (md) k_tsum_multi<V, LPR, K><<<dim3((unsigned)ITEM_BLOCKS + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md); \

@@ -129,6 +129,7 @@ struct WsDev {
   unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
   unsigned hc;             // entries per hot chunk
+  unsigned nib;            // k_tsum: directory blocks in front of the tile blocks (a single table's launch; 16 .. 128 by batch size)
 };
 
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each

@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_b
 // chunks, first entry, entries}: the chunk items of partition q are litem[first + j], its cold batches
 // litem[first + entries - 1 - j].
 template <int NW>
-__device__ __forceinline__ void items2_body(const WsDev& w) {
+__device__ __forceinline__ void items2_body(const WsDev& w, unsigned nib) {
   __shared__ unsigned sit[MAX_P + 1], sck[MAX_P + 1];
   __shared__ unsigned wt[8];
   const unsigned P = w.P;
@@ -905,7 +905,7 @@ __device__ __forceinline__ void items2_body(const WsDev& w) {
   __syncthreads();
   if (blockIdx.x == 0 && tid == 0) { w.ctr[2] = ti + tc; w.ctr[3] = tc; }
   const unsigned total = ti + tc;
-  const unsigned nblk = min((unsigned)ITEM_BLOCKS, gridDim.x);
+  const unsigned nblk = min(nib, gridDim.x);
   const unsigned ipb = (total + nblk - 1) / nblk;
   const unsigned i0 = min(total, blockIdx.x * ipb), i1 = min(total, i0 + ipb);
   for (unsigned i = i0 + tid; i < i1; i += T) {
@@ -1161,8 +1161,8 @@ template <int V, int LPR, int K>
 __global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* __restrict__ grad, int what) {
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the index pass gave up on this batch
   KV_STAMPT(0);
-  const unsigned nib = what == 1 ? 0u : (unsigned)ITEM_BLOCKS;
-  if (blockIdx.x < nib) { items2_body<TBC / 64>(w); KV_STAMPT(1); return; }
+  const unsigned nib = what == 1 ? 0u : w.nib;
+  if (blockIdx.x < nib) { items2_body<TBC / 64>(w, nib); KV_STAMPT(1); return; }
   tsum_body<V, LPR, K>(w, grad, t.dim, blockIdx.x - nib);
   KV_STAMPT(1);
 }
@@ -1520,7 +1520,7 @@ __global__ void __launch_bounds__(TBC) k_tsum_multi(const MultiDesc* __restrict_
   const MultiDesc& m = descs[blockIdx.y];
   if (m.n == 0) return;
   if (*reinterpret_cast<volatile unsigned*>(&m.a.tv.counters[1])) return;
-  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(m.w); return; }
+  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(m.w, (unsigned)ITEM_BLOCKS); return; }
   if (blockIdx.x - ITEM_BLOCKS >= m.w.ntiles) return;
   tsum_body<V, LPR, K>(m.w, m.a.grad, m.a.tv.dim, blockIdx.x - ITEM_BLOCKS);
 }

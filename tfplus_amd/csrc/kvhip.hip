@@ -665,6 +665,8 @@ WsDev ws_view(kv_table* t, long long n) {
   d.mcount = w.mcount;
   d.epart = w.epart;
   d.hc = (unsigned)HC;
+  // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
+  d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
   return d;
 }
 
