@@ -140,6 +140,7 @@ struct WsDev {
 // where the block runs: HW_ID (wave / simd / cu / sh / se) and XCC_ID
 #define KV_STAMP_HW(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)blockIdx.x * 16 + (slot)] = \
     ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); } while (0)
+#define KV_STAMPPV(slot, v) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 4096) * 16 + (slot)] = (v); } while (0)
 #define KV_STAMPA(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = wall_clock64(); } while (0)
 #define KV_STAMPV(slot, v) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 8192) * 16 + (slot)] = (v); } while (0)
 #define KV_STAMPT(slot) do { if (threadIdx.x == 0) w.dbg[(size_t)(blockIdx.x + 2048) * 16 + (slot)] = wall_clock64(); } while (0)
@@ -147,6 +148,7 @@ struct WsDev {
 #define KV_STAMP(slot) do { } while (0)
 #define KV_STAMPP(slot) do { } while (0)
 #define KV_STAMP_HW(slot) do { } while (0)
+#define KV_STAMPPV(slot, v) do { } while (0)
 #define KV_STAMPA(slot) do { } while (0)
 #define KV_STAMPV(slot, v) do { } while (0)
 #define KV_STAMPT(slot) do { } while (0)

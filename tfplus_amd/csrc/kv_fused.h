@@ -626,6 +626,7 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     }
     KV_STAMPP(1);
     const unsigned nu = lnu;
+    KV_STAMPPV(6, E); KV_STAMPPV(7, nu); KV_STAMPPV(8, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492));
 
     // ---- the keys' places in the entry list; their numbers: cold keys by class (1, 2, 3..LCOLD entries — a batch of
     //      the apply then holds keys of ONE class, and the first two sources ride in the record), hot keys and their

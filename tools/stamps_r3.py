@@ -75,6 +75,24 @@ if len(pt):
                    ("lane work (new rows, flags)", 2, 3), ("pass 2 (entry list)", 3, 4)):
     print("   %-48s %s" % (nm, med(pt[:, j] - pt[:, i])))
   print("   block total %s ; start %s ; last end %d" % (med(pt[:, 4] - pt[:, 0]), med(pt[:, 0] - b0), (pt[:, 4] - b0).max()))
+  if pt[:, 6].max() > 0:   # entries, distinct keys and place of every partition block
+    tot = pt[:, 4] - pt[:, 0]
+    E_, nu_ = pt[:, 6], pt[:, 7]
+    print("   entries per partition %s ; distinct keys %s" % (med(E_), med(nu_)))
+    print("   corr(total, entries) %.2f  corr(total, keys) %.2f" % (np.corrcoef(tot, E_)[0, 1], np.corrcoef(tot, nu_)[0, 1]))
+    for lo, hi in ((0, 400), (400, 700), (700, 1200), (1200, 1 << 30)):
+      sel = (E_ >= lo) & (E_ < hi)
+      if sel.any():
+        print("   partitions with %4d <= entries < %-6d: %4d blocks, total %s" % (lo, min(hi, 99999), sel.sum(), med(tot[sel])))
+    xcc = (pt[:, 8] >> 32) & 0xF
+    for x in range(8):
+      sel = xcc == x
+      if sel.any():
+        print("   XCC %d: %4d blocks, total %s" % (x, sel.sum(), med(tot[sel])))
+    slow = np.argsort(-(pt[:, 4] - b0))[:10]
+    print("   last blocks to end (partition block, xcc, entries, keys, phases..., end):")
+    for i in slow:
+      print("     ", i, int(xcc[i]), int(E_[i]), int(nu_[i]), [int(pt[i, j + 1] - pt[i, j]) for j in range(4)], int(pt[i, 4] - b0))
 ts = a[2048:2048 + 16 + 4 * ((N + 2047) // 2048)].astype(np.int64); ts = ts[ts[:, 1] > 0]
 if len(ts):
   b0 = ts[:, 0].min()
