@@ -1011,9 +1011,16 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     const unsigned u_prev = t->err_host ? reinterpret_cast<volatile unsigned*>(t->err_host)[1] : 0u;
     // (not in deterministic mode: the partitioning decides the order of a tile's entries, hence of the additions —
     // there it depends on the batch alone)
-    const bool many = !t->deterministic && (long long)u_prev * 2 > n && t->batch_n_prev == n;
+    const bool hinted = !t->deterministic && t->batch_n_prev == n && u_prev > 0u;
+    const bool many = hinted && (long long)u_prev * 2 > n;
+    // ... few distinct ids (a skewed batch: 109 k of 1 M at Zipf 1.2): half the partitions — 213 keys per block instead
+    // of 107 still sit well inside the LDS hash, the tile pass sorts into fewer bins and the partition pass runs two
+    // blocks per CU less: -2.5 us per step, measured; at Zipf 0.8 and below it would split partitions (0.45 ms against
+    // 0.41), hence the bound
+    const bool few = hinted && !many && (long long)u_prev * 8 <= n && n >= (1ll << 18);
     t->batch_n_prev = n;
     if (many) { wd.P = pick_partitions(n, true); wd.pshift = 64 - ilog2(wd.P); }
+    else if (few) { wd.P = std::max(64u, pick_partitions(n, false) / 2u); wd.pshift = 64 - ilog2(wd.P); }
     t->index_P = wd.P;
   }
   if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
