@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20250211 + 2
-SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "4"))   # the dominant kernel is bracketed by events on every 4th step of the timed region
+SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "8"))   # the dominant kernel is bracketed by events on every 8th step of the timed region (a pair of markers costs ~4 us of stream time)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
