@@ -634,7 +634,6 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     constexpr int PERU = (UCAPK + TBK - 1) / TBK;
     unsigned kst[PERU], kcnt[PERU], krank[PERU], kchunk[PERU];
     const unsigned gb = 64u / (unsigned)apply_lanes(a.tv.dim);   // keys per cold batch
-    unsigned i0r, k0r;   // cold batches / chunks of the partition's earlier rounds
     {
       unsigned sum = 0, ch = 0, hh = 0;
 #pragma unroll
@@ -656,7 +655,7 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
       unsigned hrn = block_excl_scan<TBK / 64>(hh, wtot, &htot);
       const unsigned t1 = chtot & 1023u, t2 = (chtot >> 10) & 1023u, t3 = chtot >> 20, th = htot & 1023u, tk = htot >> 10;
       const unsigned c0 = lcold, h0 = lhot, k0 = lchunk, i0 = litm;
-      i0r = i0; k0r = k0;
+
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
         const unsigned u = tid * PERU + q;
