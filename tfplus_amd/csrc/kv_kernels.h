@@ -1881,10 +1881,12 @@ __global__ void __launch_bounds__(TB) k_owner_route_fixed(const long long* __res
 // cost 60 us behind the partition pass.)
 // need[0] (may be null) = the largest segment this batch WANTED, capped or not: what peer_capacity would have had to be
 // (one block: thread 0 clears it, every owner's thread raises it)
+// uhint (pinned host word, may be null) = the batch's distinct ids: the next route picks its partition count by it
 __global__ void k_seg_headers_take(unsigned* __restrict__ gcount, int world, unsigned C, long long* __restrict__ seg,
-                                   unsigned* __restrict__ need) {
+                                   unsigned* __restrict__ need, unsigned* __restrict__ uhint) {
+  __shared__ unsigned tot;
   const int d = threadIdx.x;
-  if (need && d == 0) *need = 0u;
+  if (d == 0) { if (need) *need = 0u; tot = 0u; }
   __syncthreads();
   if (d < world) {
     const unsigned c = gcount[d];
@@ -1892,7 +1894,10 @@ __global__ void k_seg_headers_take(unsigned* __restrict__ gcount, int world, uns
     seg[2 * (size_t)d * (C + 1)] = c < C ? c : C;
     seg[2 * (size_t)d * (C + 1) + 1] = 0;
     if (need) atomicMax(need, c);
+    atomicAdd(&tot, c);
   }
+  __syncthreads();
+  if (d == 0 && uhint) __hip_atomic_store(uhint, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the segments' headers {records in the segment (at most C), 0}
 __global__ void k_seg_headers(const long long* __restrict__ counts, int world, unsigned C, long long* __restrict__ seg,

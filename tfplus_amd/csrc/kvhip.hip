@@ -579,6 +579,20 @@ unsigned pick_partitions(long long n, bool many_distinct = false) {
   return P;
 }
 
+// the entry-list pipeline's partition count when nothing is known about the batch: about 384 ids per partition block
+// (k_part2 works on a tile's distinct keys, not on positions: fewer, fatter partitions than the sorted-position
+// pipeline wants), 64 .. 1024; never more than pick_partitions(n), so the workspace of either rule holds it
+long long forced_P() {   // KV_FORCE_P: diagnostic A/B only (tools/)
+  static const long long forced = [] { const char* e = getenv("KV_FORCE_P"); return e ? atoll(e) : 0ll; }();
+  return forced;
+}
+unsigned fused_default_P(long long n) {
+  if (forced_P() > 0) return (unsigned)forced_P();
+  unsigned P = 64;
+  while ((long long)P * 384 < n && P < 1024u) P <<= 1;
+  return std::min(P, pick_partitions(n, false));
+}
+
 // upper bounds of a batch of n ids: hot keys (more than LCOLD occurrences each) and their chunks
 size_t chunk_cap(long long n) { return (size_t)(n / HC + n / (LCOLD + 1) + 4); }
 
@@ -614,7 +628,10 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
         (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)) ||
         (rc = regrow(&w.mcount, nt + 1)))
       return rc;
-    if (!w.ctr) HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
+    if (!w.ctr) {   // zeroed: the first tile pass publishes ctr[5] (the previous pass's distinct keys) as a hint
+      HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
+      HIP_TRY(hipMemset(w.ctr, 0, 8 * sizeof(unsigned)));
+    }
 #ifdef KV_STAMPS
     if ((rc = regrow(&w.dbg, (size_t)16384 * 16))) return rc;
     hipMemset(w.dbg, 0, (size_t)16384 * 16 * 8);
@@ -1011,16 +1028,23 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     const unsigned u_prev = t->err_host ? reinterpret_cast<volatile unsigned*>(t->err_host)[1] : 0u;
     // (not in deterministic mode: the partitioning decides the order of a tile's entries, hence of the additions —
     // there it depends on the batch alone)
-    const bool hinted = !t->deterministic && t->batch_n_prev == n && u_prev > 0u;
-    const bool many = hinted && (long long)u_prev * 2 > n;
-    // ... few distinct ids (a skewed batch: 109 k of 1 M at Zipf 1.2): half the partitions — 213 keys per block instead
-    // of 107 still sit well inside the LDS hash, the tile pass sorts into fewer bins and the partition pass runs two
-    // blocks per CU less: -2.5 us per step, measured; at Zipf 0.8 and below it would split partitions (0.45 ms against
-    // 0.41), hence the bound
-    const bool few = hinted && !many && (long long)u_prev * 8 <= n && n >= (1ll << 18);
+    const bool hinted = !t->deterministic && t->batch_n_prev == n && u_prev > 0u && forced_P() <= 0;
     t->batch_n_prev = n;
-    if (many) { wd.P = pick_partitions(n, true); wd.pshift = 64 - ilog2(wd.P); }
-    else if (few) { wd.P = std::max(64u, pick_partitions(n, false) / 2u); wd.pshift = 64 - ilog2(wd.P); }
+    if (hinted) {
+      // about 384 distinct keys per partition block (the LDS hash of k_part2 holds 768 before a partition splits),
+      // at most 2048 entries: 109 k keys of 1 M ids (Zipf 1.2) -> 512 partitions, 773 k (Zipf 0.8) -> 2048.
+      // Measured at 1 M ids: 512 against 1024 partitions is -2.5 us per step at Zipf 1.2 and +40 us at Zipf 0.8.
+      // (a hint is only a hint: never more distinct keys than ids, never more partitions than the workspace was sized for)
+      const unsigned long long u = std::min<unsigned long long>(u_prev, (unsigned long long)n);
+      const unsigned long long want = std::max<unsigned long long>((u + 383ull) / 384ull, (unsigned long long)((n + 2047) / 2048));
+      const unsigned pmax = std::min<unsigned>((unsigned)MAX_P, std::max(64u, t->ws.capP));
+      unsigned P = 64;
+      while (P < want && P < pmax) P <<= 1;
+      wd.P = P;
+    } else {
+      wd.P = fused_default_P(n);
+    }
+    wd.pshift = 64 - ilog2(wd.P);
     t->index_P = wd.P;
   }
   if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
@@ -1709,7 +1733,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
     MultiDesc& d = hd[i];
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
-    if (fused_ok(tables[i]->dim)) d.w.hc = (unsigned)HC2;
+    if (fused_ok(tables[i]->dim)) { d.w.hc = (unsigned)HC2; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
     d.a.det = tables[i]->deterministic ? 1 : 0;
@@ -1813,7 +1837,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
     d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
-    if (fused_ok(D)) { d.w.hc = (unsigned)HC2; d.a.epart = d.w.epart; }
+    if (fused_ok(D)) { d.w.hc = (unsigned)HC2; d.a.epart = d.w.epart; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
     d.a.det = vars[i]->deterministic ? 1 : 0;
     d.a.n = ns[i];
@@ -3043,7 +3067,7 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
         hipMalloc(&sh->slot_of, (size_t)max_ids * 4) != hipSuccess || hipMalloc(&sh->counts, (size_t)world * 8) != hipSuccess ||
         hipMalloc(&sh->hist, (size_t)ntr * world * 4) != hipSuccess ||
         hipMalloc(&sh->gcount, (MAXW + 1) * 4) != hipSuccess || hipMemset(sh->gcount, 0, (MAXW + 1) * 4) != hipSuccess ||
-        hipHostMalloc(&sh->overflow, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(&sh->overflow, 2 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
         hipMalloc(&sh->need, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(sh->need, 0, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&sh->need_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&sh->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -3051,7 +3075,7 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
       rc = fail(KV_RESOURCE_EXHAUSTED, "kv_shard_create: allocation failed");
       break;
     }
-    *sh->overflow = 0;
+    sh->overflow[0] = 0; sh->overflow[1] = 0;   // [1]: the last routed batch's distinct ids (k_seg_headers_take)
     if ((rc = shard_alloc_buffers(sh, (unsigned)C))) break;
   } while (0);
   if (rc) { kv_shard_destroy(sh); return rc; }
@@ -3122,7 +3146,16 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
     return KV_OK;
   }
   if ((rc = ensure_workspace(rt, n, true, s))) return rc;
-  const WsDev wd = ws_view(rt, n);
+  WsDev wd = ws_view(rt, n);
+  {
+    // a skewed batch (the previous one of this length held at most n / 8 distinct ids; pinned word, no
+    // synchronisation): half the partitions, as in the unsharded index pass (fused_index_pass)
+    const unsigned u_prev = reinterpret_cast<volatile unsigned*>(sh->overflow)[1];
+    const bool few = !rt->deterministic && rt->batch_n_prev == n && u_prev > 0u && (long long)u_prev * 8 <= n && n >= (1ll << 18);
+    rt->batch_n_prev = n;
+    if (few) { wd.P = std::max(64u, wd.P / 2u); wd.pshift = 64 - ilog2(wd.P); }
+    rt->index_P = wd.P;
+  }
   PartArgs pa{};
   pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = sh->uniq;
@@ -3143,7 +3176,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   if (!pa.det) {
     k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
                                            sh->overflow, sh->gcount);
-    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need);
+    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need, sh->overflow + 1);
     HIP_TRY(hipGetLastError());
     return KV_OK;
   }
@@ -3184,6 +3217,7 @@ int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
   // the training lookup's gather (k_gather<ORDER>) over the rows that came back: position -> entry -> dense unique
   // index -> the record its id was sent in; the same pass files the positions for the gradient sum to come
   WsDev wd = ws_view(rt, sh->n_last);
+  if (rt->index_P) { wd.P = rt->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the route's partitioning
   wd.row_map = sh->slot_of;
   TableDev rows = dev_view(rt);
   rows.c0.rows = sh->recv_rows;
@@ -3208,7 +3242,8 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
   int rc;
   if ((rc = hand_over(rt, s))) return rc;
   if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
-  const WsDev wd = ws_view(rt, sh->n_last);
+  WsDev wd = ws_view(rt, sh->n_last);
+  if (rt->index_P) { wd.P = rt->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the route's partitioning
   if (!sh->ordered) {   // a gradient for a batch whose rows were never fetched (kv_shard_lookup_finish skipped)
     launch_order(dev_view(rt), wd, sh->n_last, s);
     sh->ordered = true;
