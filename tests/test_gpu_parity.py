@@ -178,6 +178,39 @@ def test_lookup_parity_random_init(ops, D):
   _assert_same_table(ops, h, o, ids)
 
 
+def test_partition_hint_survives_changing_batch_sizes(ops):
+  """The entry-list pipeline sizes its partition pass by the distinct keys of the table's PREVIOUS batch of the same
+  length (a pinned word, no synchronisation).  The hint may be stale or come from a batch of another length: mostly
+  distinct ids, then tiny batches, then heavy repeats, then distinct ids again — rows and table state equal the oracle
+  every time (a wrong partition count must cost time, never results or memory)."""
+  D = 32
+  rng = np.random.default_rng(55)
+  h, o = _pair(ops, D, seed=5, rng=rng, cap=1 << 20)
+  hs, os_ = _const(ops, 3 * D, 0.0)
+  plans = [("distinct", 300000), ("small", 2048), ("small", 2048), ("small", 2048), ("repeats", 300000),
+           ("repeats", 300000), ("distinct", 300000), ("distinct", 300000), ("small", 5000), ("repeats", 300000)]
+  for step, (kind, n) in enumerate(plans):
+    if kind == "distinct":
+      ids = rng.choice(2_000_000, n, replace=False).astype(np.int64)
+    elif kind == "repeats":
+      ids = rng.integers(0, 300, n).astype(np.int64)
+    else:
+      ids = rng.integers(0, 100000, n).astype(np.int64)
+    got = _np(ops.kv_variable_gather_or_insert_v2(h, ids))
+    if step <= 2:     # no optimizer step yet: rows are copies of the init rule's rows
+      np.testing.assert_array_equal(got, o.gather_or_insert(ids), err_msg="step %d %s" % (step, kind))
+    else:             # the applies below sum repeated ids in another fp32 order than the oracle's pre-summed input
+      np.testing.assert_allclose(got, o.gather_or_insert(ids), rtol=2e-5, atol=1e-6, err_msg="step %d %s" % (step, kind))
+    if step % 3 == 2:
+      grad = rng.uniform(0.5, 1.5, (n, D)).astype(np.float32) * 1e-3
+      b1p, b2p = _beta_pows(step // 3)
+      _apply_both(ops, "adam4", (h, hs), (o, os_), grad, ids, lr=1e-2, b1p=b1p, b2p=b2p, l1=0.0, l2=0.0, l21=0.0)
+    sample = ids[:: max(1, n // 2000)]
+    got = _np(ops.kv_variable_gather_or_zeros_v2(h, sample))
+    np.testing.assert_allclose(got, o.gather_or_zeros(sample), rtol=2e-5, atol=1e-6, err_msg="state, step %d" % step)
+    assert ops.kv_variable_size_v2(h) == o.size() and ops.kv_variable_frequency(h) == o.sum_freq()
+
+
 def test_lookup_with_counts_and_saturation(ops):
   rng = np.random.default_rng(7)
   h, o = _pair(ops, 16, thr=3, seed=5, rng=rng)
