@@ -327,6 +327,7 @@ struct PartArgs {
   int sparse_unique;          // MODE_UNIQUE: unique numbers = sorted position of the partition + local number (with gaps)
   long long n;                // ids in the batch
   const float* epart;         // entry-list pipeline: list words tagged EP_TAG name rows of this array (tile sums), else of grad
+  unsigned day_lk;            // k_papply (kv_papply.h), PA_LOOKUP: the day stamp of the lookup whose bookkeeping it completes
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)

@@ -1,0 +1,578 @@
+// kv_papply.h — the partition pass and the optimizer apply of a batch in ONE launch (included after kv_fused.h).
+//
+// k_part2 + k_apply2 (kv_fused.h) hand the batch from one to the other through global memory: key records, the entry
+// list, work items, a dense item directory — and through two dependent chains (directory -> entries -> RowMeta;
+// item -> record -> rows) during which HBM idles, 28 + 46 us at configs[1] for 112 MB of state traffic.  Here the
+// block that owns a hash partition keeps what it learned in LDS and goes on to update its keys itself:
+//
+//   directory of the partition's segment in every tile -> its entries {key, counts, row word, hint, source}, all loads
+//   in flight -> LDS hash of the distinct keys (summed frequency count, row, hint, entries) -> block scans: every
+//   key's stretch of the partition's SOURCE LIST (in LDS), keys ordered hot / 1 / 2 / 3.. sources -> the entries'
+//   sources filed -> the waves take items from an LDS ticket: a hot key (more than LCOLD sources) per wave, or a batch
+//   of 64 / LPR cold keys, one per lane group: sources (gradient rows, or tile sums of k_tsum), the var row and its
+//   record, the hinted slot row and its record in ONE round trip -> the lookup's bookkeeping for the key (frequency
+//   word, day, under-threshold flag, a new key's record and row: what k_part2<LOOKUP> does) and the fused row update
+//   (opt_core), both by the key's single owner.
+//
+// No key record, entry list, work item or directory is written; the var record is read once for both purposes; a key
+// never spans blocks, so there are no chunks and no k_apply_fin whatever the batch size.  k_tsum (tiles only) runs in
+// front: its sums are sources here.
+//
+// mode: PA_LOOKUP   the batch's training lookup left its partition pass pending: FindOrInsert bookkeeping, then apply
+//       PA_APPLYIDX the optimizer meets the ids first (FindOrInsertUnsafe: a new key gets frequency word 1, unfiltered)
+//       PA_NONE     the entries of a batch whose bookkeeping is done (a second optimizer on the same token)
+#pragma once
+
+enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2 };
+#ifndef KV_PA_WAVES
+#define KV_PA_WAVES 2      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
+#endif
+#ifndef KV_PA_HOTRB
+#define KV_PA_HOTRB 8      // a hot key's sources in flight per lane group and step
+#endif
+constexpr int PA_LSRC = 1536;   // sources of a partition held in LDS; a larger partition files them in w.order
+
+template <int OPT, int V, int LPR, int K>
+__device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, const int mode_) {
+#ifdef KV_PA_X_MODE
+  constexpr int mode = KV_PA_X_MODE;
+#else
+  const int mode = mode_;
+#endif
+  constexpr int HSK = 1024;
+  constexpr int UCAPK = HSK - TBK;
+  constexpr int EB = 8;
+  constexpr int G = 64 / LPR;
+  constexpr int RB = (KV_PA_HOTRB / K) > 0 ? (KV_PA_HOTRB / K) : 1;
+  constexpr int NW = TBK / 64;
+  __shared__ long long hkey[HSK + 1];
+  __shared__ unsigned hval[HSK + 1];    // summed frequency count of the key's entries
+  __shared__ unsigned hrow[HSK + 1];    // max over the key's entries of the row word (an entry that knows the row wins)
+  __shared__ unsigned hhint[HSK + 1];   // slot-row hint
+  __shared__ unsigned hocc[HSK + 1];    // entries of the key; then the cursor into the source list (ends at the stretch's end)
+  __shared__ unsigned short hcn[HSK + 1];   // entries of the key (final)
+  __shared__ unsigned short ulist[UCAPK + 8];
+  __shared__ unsigned short kord[UCAPK + 8];   // key slots: hot keys, then 1 / 2 / 3.. sources
+  __shared__ unsigned lsrc[PA_LSRC];
+  __shared__ unsigned lnu, lsent, lnext, lkeys;
+  __shared__ unsigned wtot[8];
+  __shared__ unsigned stkR[24], stkr[24];
+  __shared__ int sp;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned short* tpre = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* tstart = tpre + w.ntiles;
+
+  const int tid = threadIdx.x;
+  const unsigned p = xcd_partition(blockIdx.x, w.P);
+  const unsigned NT = w.ntiles;
+  const int D = a.tv.dim;
+  const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);   // the tile pass gave up: bookkeeping only
+  KV_STAMPP(0);
+  unsigned pbase;
+  const unsigned E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
+  if (E == 0) return;
+  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lkeys = 0; }
+  __syncthreads();
+  if (E > 65535u) {
+    if (tid == 0) raise_error(a.tv, 2u);
+    return;
+  }
+  const bool in_lds = E <= (unsigned)PA_LSRC;
+  unsigned* const gsrc = w.order + pbase;   // (the partitions' stretches of w.order are disjoint)
+  auto src_at = [&](unsigned i) -> unsigned {
+    // a stretch filed in global memory was written by other waves of this block: read past the CU's vector cache
+    return in_lds ? lsrc[i] : __hip_atomic_load(gsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  while (sp > 0) {
+    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+    __syncthreads();
+    if (tid == 0) --sp;
+    for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; }
+    if (tid == 0) { lnu = 0; lsent = 0; lnext = 0; }
+    __syncthreads();
+    // ---- pass 1: distinct keys, their counts, rows and hints (the entries' sources ride along) -------------------
+    unsigned csrc[EB];
+    unsigned short cslot[EB];
+    bool cin[EB];
+    const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
+    for (unsigned x0 = 0; x0 < E; x0 += EB * TBK) {
+      unsigned ge[EB];
+      long long key[EB];
+      unsigned ea[EB], rw[EB], hi[EB], sr[EB];
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const unsigned x = x0 + k * TBK + tid;
+        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
+        if (ge[k] != 0xFFFFFFFFu) {
+          key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]];
+          if (cached) sr[k] = w.ent_rec[ge[k]];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if (x0 == 0) { csrc[k] = sr[k]; cslot[k] = 0; cin[k] = false; }
+        if (ge[k] == 0xFFFFFFFFu || !in_round(key[k], R, round)) continue;
+        if (lnu >= (unsigned)UCAPK) continue;
+        bool first;
+        const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key[k], true, &first);
+        if (first) {
+          const unsigned u = atomicAdd(&lnu, 1u);
+          if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
+        }
+        if (mode == PA_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16);
+        atomicAdd(&hocc[h], 1u);
+        atomicMax(&hrow[h], rw[k]);
+        if (hi[k]) atomicMax(&hhint[h], hi[k]);
+        if (x0 == 0) { cslot[k] = (unsigned short)h; cin[k] = true; }
+      }
+    }
+    __syncthreads();
+    if (lnu >= (unsigned)UCAPK) {   // more distinct keys than the hash holds: two sub-hash classes, each on its own
+      __syncthreads();
+      if (tid == 0) {
+        if (sp + 2 <= 24) {
+          stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+          stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+        } else {
+          raise_error(a.tv, 2u);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    KV_STAMPP(1);
+    const unsigned nu = lnu;
+    if (tid == 0) lkeys += nu;
+
+    // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
+    constexpr int PERU = (UCAPK + TBK - 1) / TBK;
+    unsigned nhot, ncold;
+    {
+      unsigned kcnt[PERU];
+      unsigned sum = 0, ch = 0, hh = 0;
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        kcnt[q] = u < nu ? hocc[ulist[u]] : 0u;
+        sum += kcnt[q];
+        if (u < nu) {
+          if (kcnt[q] == 1u) ch += 1u;
+          else if (kcnt[q] == 2u) ch += 1u << 10;
+          else if (kcnt[q] <= (unsigned)LCOLD) ch += 1u << 20;
+          else hh += 1u;
+        }
+      }
+      unsigned tot, chtot, htot;
+      unsigned run = block_excl_scan<NW>(sum, wtot, &tot);
+      unsigned chrun = block_excl_scan<NW>(ch, wtot, &chtot);
+      unsigned hrn = block_excl_scan<NW>(hh, wtot, &htot);
+      const unsigned t1 = chtot & 1023u, t2 = (chtot >> 10) & 1023u;
+      nhot = htot; ncold = nu - htot;
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u < nu) {
+          const unsigned s = ulist[u];
+          unsigned rank;
+          if (kcnt[q] == 1u) { rank = nhot + (chrun & 1023u); chrun += 1u; }
+          else if (kcnt[q] == 2u) { rank = nhot + t1 + ((chrun >> 10) & 1023u); chrun += 1u << 10; }
+          else if (kcnt[q] <= (unsigned)LCOLD) { rank = nhot + t1 + t2 + (chrun >> 20); chrun += 1u << 20; }
+          else { rank = hrn; hrn += 1u; }
+          kord[rank] = (unsigned short)s;
+          hocc[s] = run; run += kcnt[q];
+          hcn[s] = (unsigned short)kcnt[q];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- pass 2: the source list — entry x of key h goes to its key's stretch ---------------------------------------
+    {
+      auto file = [&](unsigned pos, unsigned src) { if (in_lds) lsrc[pos] = src; else gsrc[pos] = src; };
+      if (a.det) {
+        // deterministic mode: a key's entries in tile order = ascending x (TBK entries per round, wave by wave)
+        const int wave = tid >> 6, wl = tid & 63;
+        for (unsigned x0 = 0; x0 < E; x0 += TBK) {
+          const unsigned x = x0 + tid;
+          bool valid = x < E;
+          size_t ge = 0;
+          unsigned h = 0xFFFFFFFFu;
+          if (valid) {
+            ge = seg_entry(tpre, tstart, NT, x);
+            const long long key = w.ent_key[ge];
+            valid = in_round(key, R, round);
+            if (valid) { bool first; h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first); }
+          }
+          unsigned within = 0;
+          for (int j = 0; j < 63; ++j) {
+            const unsigned hj = __shfl(h, j);
+            if (j < wl && hj == h) within += 1u;
+          }
+          unsigned pos = 0;
+          for (int wv = 0; wv < NW; ++wv) {
+            if (wave == wv && valid) { pos = hocc[h] + within; atomicAdd(&hocc[h], 1u); }
+            __syncthreads();
+          }
+          if (valid) file(pos, w.ent_rec[ge]);
+        }
+      } else if (cached) {
+#pragma unroll
+        for (int k = 0; k < EB; ++k)
+          if (cin[k]) file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
+      } else {
+        for (unsigned x = tid; x < E; x += TBK) {
+          const size_t ge = seg_entry(tpre, tstart, NT, x);
+          const long long key = w.ent_key[ge];
+          if (!in_round(key, R, round)) continue;
+          bool first;
+          const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
+          file(atomicAdd(&hocc[h], 1u), w.ent_rec[ge]);
+        }
+      }
+    }
+    if (!in_lds) __threadfence_block();
+    __syncthreads();
+    KV_STAMPP(2);
+
+    // ---- what the apply phase needs per wave --------------------------------------------------------------------
+    // (the lane's own numbers through an opaque move: what derives from them is computed HERE, per round, instead of
+    //  being hoisted in front of the whole kernel and kept — spilled — across the partition phases)
+    unsigned tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int wl = (int)(tid2 & 63u), lane = wl % LPR, g = wl / LPR;
+    const float* const gbase = a.grad;
+    const float* const ebase = a.epart;
+    int eoff[K];
+    bool evalid[K];
+  #pragma unroll
+    for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; evalid[k] = e0 < D; eoff[k] = evalid[k] ? e0 : 0; }
+    auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
+      const float* base = (pos & EP_TAG) ? ebase : gbase;
+      const float* src = base + (size_t)(pos & ~EP_TAG) * D;
+  #pragma unroll
+      for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
+    };
+    const bool fast = (OPT != OPT_FTRL) && a.tv.single != 0u && a.ts0.single != 0u && a.use_hints != 0 &&
+                      (a.tv.track_delta | a.ts0.track_delta) == 0u;
+    float* const vrows = a.tv.c0.rows;
+    RowMeta* const vmeta = a.tv.c0.meta;
+    float* const srows = a.ts0.c0.rows;
+    RowMeta* const smeta = a.ts0.c0.meta;
+    const int SD = a.ts0.dim;
+    const unsigned smax = a.ts0.max_rows, thr = a.tv.enter_threshold;
+    const bool need_vmeta = OPT == OPT_ADAGRAD || thr != 0u;
+    constexpr int NS0 = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? 3 : 1;
+
+    // ---- the apply: items = the round's hot keys (one per wave), then batches of G cold keys (one per lane group) -------
+    const unsigned nbatch = (ncold + (unsigned)G - 1u) / (unsigned)G;
+    const unsigned nitems = nhot + nbatch;
+    KV_STAMPPV(6, E); KV_STAMPPV(7, nu); KV_STAMPPV(8, nhot);
+#ifdef KV_PA_X_NOAPPLY
+    continue;
+#endif
+#ifdef KV_STAMPS
+    unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0;
+#endif
+    for (;;) {
+#ifdef KV_STAMPS
+      const unsigned long long st_a = wall_clock64();
+#endif
+      unsigned it = 0;
+      if (wl == 0) it = atomicAdd(&lnext, 1u);
+      it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);   // wave-uniform (a scalar): the branches on it are scalar branches
+      if (it >= nitems) break;
+#ifdef KV_PA_X_NOHOT
+      const bool is_hot = false;
+#else
+      const bool is_hot = it < nhot;
+#endif
+      // the key of this lane group (hot: every group the same key, group 0 finishes it)
+      const unsigned kr = is_hot ? it : nhot + (it - nhot) * (unsigned)G + (unsigned)g;
+      const bool have = is_hot || kr < nu;
+      const unsigned s = kord[have ? kr : nhot + (it - nhot) * (unsigned)G];
+      const long long key = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
+      const unsigned cnt = have ? (unsigned)hcn[s] : 0u;
+      const unsigned st = hocc[s] - (unsigned)hcn[s];
+      const unsigned rww = hrow[s];
+      unsigned row = rww & ROW_MASK;
+      const bool isnew = have && mode != PA_NONE && (rww & NEW_BIT) != 0u;
+      const unsigned hint = isnew ? 0u : hhint[s];
+      const unsigned fsum = hval[s];
+      const bool live = is_hot ? g == 0 : have;
+      if (__builtin_expect(__ballot(isnew) != 0ull, 0)) {
+        // the tile that won the key published {row, HINT_NEW}; the hint goes back to "none"
+        unsigned r2 = row;
+        if (isnew && lane == 0 && live) {
+          Entry* e = table_entry_of(a.tv, key);
+          if (e) {
+            if (r2 == 0u) { const unsigned er = load_entry(e).row; r2 = er != ROW_TOMB ? er : 0u; }
+            e->hint = 0u;
+          }
+        }
+        if (LPR > 1) r2 = __shfl(r2, 0, LPR);
+        if (isnew) row = r2;
+      }
+
+      // ---- everything the key needs, in one round trip ---------------------------------------------------------------
+      float gv[K][V];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cc = 0; cc < V; ++cc) gv[k][cc] = 0.f;
+      RowMeta m0{};
+      uint2 vm = make_uint2(0u, 0u);
+      bool hint_loaded = false, have_x = false, have_s = false;
+      PreRows<V, K> pre;
+      const bool st_live = live && row != 0u;
+      auto prefetch = [&]() {
+        if (fast) {
+          const unsigned rr = st_live ? row : 0u;
+          const unsigned hh = (st_live && hint < smax) ? hint : 0u;
+          const uint4 mm = *reinterpret_cast<const uint4*>(smeta + hh);
+          m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
+          m0.freq = mm.z;
+          m0.flags = (unsigned char)(mm.w & 0xFFu);
+          vm = *reinterpret_cast<const uint2*>(&vmeta[rr].freq);
+          const float* xr = vrows + (size_t)rr * D;
+          const float* sr = srows + (size_t)hh * SD;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            ldv<V>(xr + eoff[k], pre.x[k]);
+#pragma unroll
+            for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eoff[k], pre.s[b3][k]);
+          }
+          hint_loaded = hh != 0u; have_x = true; have_s = hh != 0u;
+        } else {
+          if (st_live && !isnew) vm = load_freq_flags(a.tv, row);
+          uint4 rq = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), st_live ? row : 0u, st_live ? hint : 0u);
+          prefetch_state<OPT, V, LPR, K>(a, rq, st_live, lane, D, m0, hint_loaded, pre, have_x, have_s);
+          if (!have_x) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int cc = 0; cc < V; ++cc) pre.x[k][cc] = 0.f;
+          }
+        }
+      };
+      if (is_hot) {
+        // ---- hot key: its sources, G * RB per step, summed by the whole wave ------------------------------------------
+        const unsigned lo = st, hi = st + cnt;
+        constexpr int SR = G * RB;
+        const unsigned nst = (cnt + SR - 1) / SR;
+        auto ldpos = [&](unsigned stp, unsigned (&pp)[RB]) {
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            const unsigned idx = lo + stp * SR + j * G + g;
+            pp[j] = src_at(idx < hi ? idx : lo);   // a slot past the end re-reads the first source, masked below
+          }
+        };
+        unsigned pa_[RB], pb_[RB];
+        float va[RB][K][V];
+        ldpos(0, pa_);
+        prefetch();
+        for (unsigned stp = 0; stp < nst; ++stp) {
+#pragma unroll
+          for (int j = 0; j < RB; ++j) load_row(pa_[j], va[j]);
+          ldpos(stp + 1, pb_);
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            const bool ok = lo + stp * SR + j * G + g < hi;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int cc = 0; cc < V; ++cc) gv[k][cc] += ok ? va[j][k][cc] : 0.f;
+            pa_[j] = pb_[j];
+          }
+        }
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) gv[k][cc] += __shfl_xor(gv[k][cc], o);
+        }
+      } else {
+        // ---- cold batch: one key per lane group; sources in list order ---------------------------------------------
+        float g2[K][V];
+        const unsigned p0 = src_at(st < E ? st : 0u);
+        const bool two = __ballot(live && cnt >= 2u) != 0ull;
+        const unsigned p1 = src_at((cnt >= 2u ? st + 1u : st) < E ? (cnt >= 2u ? st + 1u : st) : 0u);
+        load_row(p0, gv);
+        if (two) load_row(p1, g2);   // uniform over the wave
+        prefetch();
+        if (two) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) gv[k][cc] += (cnt >= 2u) ? g2[k][cc] : 0.f;
+        }
+#ifndef KV_PA_RC
+#define KV_PA_RC 4
+#endif
+        constexpr int RC = (KV_PA_RC / K) > 0 ? (KV_PA_RC / K) : 1;
+        for (unsigned j0 = 2; __ballot(live && j0 < cnt) != 0ull; j0 += RC) {
+          float val[RC][K][V];
+          unsigned pj[RC];
+#pragma unroll
+          for (int j = 0; j < RC; ++j) pj[j] = src_at(j0 + j < cnt ? st + j0 + j : (st < E ? st : 0u));
+#pragma unroll
+          for (int j = 0; j < RC; ++j) load_row(pj[j], val[j]);
+#pragma unroll
+          for (int j = 0; j < RC; ++j) {
+            const bool okj = j0 + j < cnt;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+              for (int cc = 0; cc < V; ++cc) gv[k][cc] += okj ? val[j][k][cc] : 0.f;
+          }
+        }
+      }
+
+      // ---- the lookup's bookkeeping for the key (k_part2's owner work), on what the round trip brought ----------------
+      // kv_variable.h:320-363 (find_func / insert_func) for PA_LOOKUP, :382-416 (FindOrInsertUnsafe) for PA_APPLYIDX
+      bool vnew = false;   // the apply below treats the key as inserted by itself: never filtered (kv_variable.h:400-407)
+      if (mode != PA_NONE) {
+        const bool nk = st_live && isnew;
+        if (__builtin_expect(__ballot(nk) != 0ull, 0)) {
+          if (nk) {   // the init rule's value (kv_variable.h:889-898): the row the update starts from, and what the table holds if it does not act
+            const unsigned long long h = pick64((unsigned long long)key ^ (a.tv.seed * 0x9E3779B97F4A7C15ULL));
+            const float* ia = a.tv.init_table + (size_t)((unsigned)h % a.tv.init_rows) * D;
+            const float* ib = a.tv.init_table + (size_t)((unsigned)(h >> 32) % a.tv.init_rows) * D;
+            float* xrow = row_ptr(a.tv, row);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              float va_[V], vb_[V];
+              ldv<V>(ia + eoff[k], va_);
+              ldv<V>(ib + eoff[k], vb_);
+#pragma unroll
+              for (int cc = 0; cc < V; ++cc) pre.x[k][cc] = (va_[cc] + vb_[cc]) * 0.5f;
+              if (evalid[k]) stv<V>(xrow + eoff[k], pre.x[k]);
+            }
+            have_x = true;
+          }
+        }
+        const unsigned oflags = nk ? (unsigned)FLAG_DIRTY : (vm.y & 0xFFu);
+        const bool recompute = st_live && (mode == PA_LOOKUP ? (oflags & FLAG_DIRTY) != 0u : nk);
+        bool big = false;
+        if (__ballot(recompute) != 0ull) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) big |= recompute && evalid[k] && fabsf(pre.x[k][cc]) >= CUTOFF;
+        }
+        const bool any = group_any<LPR>(big);
+        if (mode == PA_LOOKUP) {
+          if (st_live) {
+            const unsigned c = a.count_once ? 1u : fsum;
+            unsigned lo16 = ((nk ? 0u : vm.x) & 0xFFFFu) + (c > 65535u ? 65535u : c);
+            if (lo16 > 65535u) lo16 = 65535u;
+            const unsigned nf = (a.day_lk << 16) | lo16;
+            unsigned nfl = oflags;
+            if (oflags & FLAG_DIRTY) {
+              const unsigned black = nk ? 0u : (oflags & FLAG_BLACK);
+              nfl = black ? (FLAG_BLACK | FLAG_UNDER) : (any ? 0u : (unsigned)FLAG_UNDER);
+            }
+            if (lane == 0) {
+              RowMeta* mp = meta_ptr(a.tv, row);
+              if (nk) {
+                RowMeta nm; nm.key = key; nm.freq = nf; nm.flags = (unsigned char)nfl;
+                nm.delta_train = a.tv.track_delta ? 1 : 0; nm.delta_pred = 0; nm.pad = 0;
+                *mp = nm;
+              } else {
+                mp->freq = nf;
+                if (nfl != oflags) mp->flags = (unsigned char)nfl;
+                if (a.tv.track_delta) mp->delta_train = 1;
+              }
+            }
+            vm.x = nf; vm.y = (vm.y & ~0xFFu) | nfl;
+          }
+        } else if (nk) {
+          const unsigned nfl = any ? 0u : (unsigned)FLAG_UNDER;
+          if (lane == 0) {
+            RowMeta nm; nm.key = key; nm.freq = 1u; nm.flags = (unsigned char)nfl;
+            nm.delta_train = 0; nm.delta_pred = 0; nm.pad = 0;
+            *meta_ptr(a.tv, row) = nm;
+          }
+          vm.x = 1u; vm.y = nfl;
+          vnew = true;
+        }
+      }
+
+      // ---- the update (k_apply2's tail: one copy for both kinds of item) ------------------------------------------------
+      const bool fin_live = live && errflag == 0u;
+      const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), row | (vnew ? NEW_BIT : 0u), hint);
+      bool general = fin_live;
+      if (fast) {
+        const unsigned hh = hint < smax ? hint : 0u;
+        // the hint stands up: the slot row carries this key and is not released (what resolve_rows checks)
+        const bool ok = fin_live && row != 0u && hh != 0u && m0.key == key && !(m0.flags & FLAG_FREE);
+        bool act = ok;
+        if (need_vmeta && ok && !vnew) {   // frequency filter / un-blacklisting (resolve_rows; kv_variable.h:910)
+          if ((vm.x & 0xFFFFu) < thr) act = false;
+          else if ((vm.y & FLAG_BLACK) && lane == 0) vmeta[row].flags = FLAG_UNDER;
+        }
+        if (act && lane == 0) {   // AddFrequency(1, today) on the slot row (kv_variable.h:409-414)
+          unsigned lo16 = (m0.freq & 0xFFFFu) + 1u;
+          if (lo16 > 65535u) lo16 = 65535u;
+          smeta[hh].freq = (a.day << 16) | lo16;
+        }
+        const unsigned rr = act ? row : 0u, h2 = act ? hh : 0u;
+        opt_core<OPT, V, LPR, K>(vrows + (size_t)rr * D, srows + (size_t)h2 * SD, nullptr, &vmeta[rr].flags, &smeta[h2].flags,
+                                 nullptr, act, false, D, gv, a.opt, lane, pre.x, pre.s);
+        general = fin_live && !ok;
+      }
+#ifndef KV_PA_X_NOGENERAL
+      if (!fast || __ballot(general) != 0ull)
+        finish_key<MODE_APPLY, OPT, V, LPR, K>(a, ra, general, hint_loaded && general, m0, gv, lane, &pre, have_x && general,
+                                               have_s && general);
+#endif
+#ifdef KV_STAMPS
+      {
+        const unsigned long long now = wall_clock64();
+        if (is_hot) { st_hot += now - st_a; ++st_nh; } else { st_cold += now - st_a; ++st_nc; }
+      }
+#endif
+    }
+#ifdef KV_STAMPS
+    if (wl == 0) {
+      unsigned long long* d = w.dbg + (size_t)(8192 + blockIdx.x * NW + (tid >> 6)) * 16;
+      d[0] = st_t0; d[1] = wall_clock64(); d[2] = st_hot; d[3] = st_cold; d[4] = st_nh; d[5] = st_nc;
+    }
+#endif
+    __syncthreads();
+    KV_STAMPP(3);
+  }
+  if (tid == 0 && mode != PA_NONE) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
+}
+
+template <int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBK, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) { papply_body<OPT, V, LPR, K>(w, a, mode); }
+
+// dispatch on the row geometry (the dims fused_ok() admits: float4 rows, a power-of-two lane count); one block per
+// partition.  Returns KV_OK, or KV_UNIMPLEMENTED for a dim the entry-list pipeline does not serve.
+template <int OPT>
+int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s) {
+  const int D = pa.tv.dim;
+  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
+  const size_t sh = (size_t)wd.ntiles * 4 + 32;
+#define KV_PA(V, LPR, K)                                                     \
+  do {                                                                       \
+    k_papply<OPT, V, LPR, K><<<(int)wd.P, TBK, sh, s>>>(wd, pa, mode);       \
+    return KV_OK;                                                            \
+  } while (0)
+  const int q = D / 4;
+  if (q <= 1) KV_PA(4, 1, 1);
+  if (q <= 2) KV_PA(4, 2, 1);
+  if (q <= 4) KV_PA(4, 4, 1);
+  if (q <= 8) KV_PA(4, 8, 1);
+  if (q <= 16) KV_PA(4, 8, 2);
+  if (q <= 32) KV_PA(4, 16, 2);
+  if (q <= 64) KV_PA(4, 64, 1);
+#undef KV_PA
+  return KV_UNIMPLEMENTED;
+}

@@ -1,0 +1,27 @@
+// kv_papply_b.hip — instantiates k_papply (kv_papply.h: partition pass + optimizer apply in one launch) for Adagrad / SparseGroupFtrl.
+// A translation unit of its own so that `make -j` builds the instantiations side by side; arguments travel as void
+// pointers because WsDev / PartArgs live in each file's anonymous namespace (same headers, same layout).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+#include "../../include/kvhip.h"
+
+namespace {
+#include "kv_device.h"
+#include "kv_kernels.h"
+#include "kv_fused.h"
+#include "kv_papply.h"
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_b(int opt, const void* wd_, const void* pa_, int mode,
+                                                                      void* stream) {
+  const WsDev& wd = *static_cast<const WsDev*>(wd_);
+  const PartArgs& pa = *static_cast<const PartArgs*>(pa_);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (opt == OPT_ADAGRAD) return launch_papply_t<OPT_ADAGRAD>(wd, pa, mode, s);
+  if (opt == OPT_FTRL) return launch_papply_t<OPT_FTRL>(wd, pa, mode, s);
+  return KV_INTERNAL;
+}

@@ -55,12 +55,16 @@ extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void*
 
 extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream, const void* md,
                                int ntab);
+// k_papply dispatch (kv_papply.h), two more translation units: a = GroupAdam V4 / V3, b = Adagrad / SparseGroupFtrl
+extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream);
+extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream);
 
 namespace {
 
 #include "kv_device.h"
 #include "kv_kernels.h"
 #include "kv_fused.h"
+#include "kv_papply.h"
 
 // ------------------------------------------------------------------------------------------
 // maintenance kernels
@@ -379,6 +383,9 @@ struct kv_table {
   uint64_t batch_serial = 0;
   long long batch_n = 0;
   bool fused_index = false;        // the index is an entry list (kv_fused.h), not a sorted position list
+  bool index_records = true;       // ... whose partition pass has run: key records, entry list and work items exist (k_apply2's
+                                   // input).  false: the tiles' entries alone (a deferred partition pass, or an index that
+                                   // k_papply consumed straight from the entries) — an apply of that batch goes through k_papply
   long long batch_n_prev = 0;      // ids of the previous entry-list index pass (the distinct-count hint belongs to that size)
   unsigned index_P = 0;            // partitions of the entry-list index the workspace holds
   // overlap mode (kv_set_overlap): a side stream of the table's own; side_pending: it still runs the lookup's
@@ -989,6 +996,7 @@ template <int MODE>
 void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
                 int ids_kind, float* out, hipStream_t s, bool file_order = true) {
   t->fused_index = false;
+  t->index_records = true;
   {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
@@ -1012,6 +1020,7 @@ int flush_part(kv_table* t, hipStream_t s) {
   std::memcpy(&pa, t->pend_pa, sizeof pa);
   ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
   launch_part2<MODE_LOOKUP>(wd, pa, s);
+  t->index_records = true;
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1019,9 +1028,11 @@ int flush_part(kv_table* t, hipStream_t s) {
 // The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
 template <int MODE>
 int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
-                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false) {
+                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false,
+                     bool tile_only = false) {
   wd.hc = (unsigned)HC2;
   t->fused_index = true;
+  t->index_records = true;
   {
     // the distinct ids of the batch before the last one (the tile pass hands the partition pass's count to the host
     // through a pinned word, no synchronisation): mostly distinct ids -> twice the partitions
@@ -1089,10 +1100,15 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     return KV_OK;
   }
   t->side_has_items = false;
+  if (tile_only) {   // the caller goes on with k_papply, which works on the tiles' entries
+    t->index_records = false;
+    return KV_OK;
+  }
   if (MODE == MODE_LOOKUP && defer_part) {   // the rows are out: the partition pass waits for the table's next op
     std::memcpy(t->pend_wd, &wd, sizeof wd);
     std::memcpy(t->pend_pa, &pa, sizeof pa);
     t->part_pending = true;
+    t->index_records = false;
     return KV_OK;
   }
   ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
@@ -1101,10 +1117,28 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
 }
 // ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
 // a key can have more entries than a chunk holds, i.e. more tiles than HC2)
+// KV_NO_PAPPLY=1: A/B against k_part2 + k_apply2
+bool papply_enabled() {
+  static const bool off = [] { const char* e = getenv("KV_NO_PAPPLY"); return e && atoi(e) != 0; }();
+  return !off;
+}
+// pa_mode >= 0: the tile sums, then partition pass + apply in one launch (k_papply, kv_papply.h) over the tiles' entries
 template <int OPT>
-int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false) {
+int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false, int pa_mode = -1) {
   wd.hc = (unsigned)HC2;
   pa.epart = wd.epart;
+  if (pa_mode >= 0) {
+    {
+      ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
+      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s, nullptr, 0);
+      if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
+    }
+    ProfScope ps(v, KV_PROF_APPLY_SORTED, s);
+    const int rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_papply_a(OPT, &wd, &pa, pa_mode, (void*)s)
+                                                              : kvp_launch_papply_b(OPT, &wd, &pa, pa_mode, (void*)s);
+    if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", pa.tv.dim);
+    return KV_OK;
+  }
   if (join_side) {
     // overlap mode: the tile sums need the tile pass only; the item directory needs the partition pass, so here it
     // is its own little launch behind the join
@@ -1751,7 +1785,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
   if (fused_ok(t0->dim)) {
-    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = true;
+    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; }
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
     launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     if (tokens)   // every table's workspace now holds the index of exactly its batch (kv_multi_apply_*_tok takes it over)
@@ -1763,7 +1797,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
         tokens[i] = tables[i]->batch_serial;
       }
   } else {
-    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = false;
+    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = false; tables[i]->index_records = true; }
     launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
     launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
@@ -1815,7 +1849,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   bool reuse = tokens != nullptr && fused_ok(D);
   for (int i = 0; i < num_tables && reuse; ++i)
     if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
-                       !vars[i]->part_pending && !vars[i]->side_pending))
+                       vars[i]->index_records && !vars[i]->part_pending && !vars[i]->side_pending))
       reuse = false;
   for (int i = 0; i < num_tables; ++i) {
     if (!reuse) vars[i]->batch_serial = 0;
@@ -1855,7 +1889,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   const bool fz = fused_ok(D);
   bool skip_fin = false;
   if (fz) {
-    for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = true;
+    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = true; }
     wmax.hc = (unsigned)HC2;
     skip_fin = wmax.ntiles <= wmax.hc;
     if (!reuse) {
@@ -1866,7 +1900,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     }
     if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, nmax, (void*)s, md, num_tables))) return fail(rc, "tile sums: no kernel for dim %d", D);
   } else {
-    for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = false;
+    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = false; vars[i]->index_records = true; }
     launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
     launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
     launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
@@ -1972,7 +2006,20 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
   const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
-  if (v->part_pending && (rc = flush_part(v, s))) return rc;   // the batch's own partition pass (or a stale one: same thing)
+  // The batch's own partition pass is still pending and the entry-list kernels serve this dim: k_papply completes the
+  // lookup's bookkeeping and applies the update in one launch (PA_LOOKUP).  Anything else pending is flushed first.
+  const bool pa_route = papply_enabled() && fused_ok(v->dim);
+  int pa_mode = -1;
+  PartArgs pend{};
+  if (v->part_pending) {
+    if (reuse && pa_route && v->fused_index && !v->side_pending) {
+      std::memcpy(&pend, v->pend_pa, sizeof pend);
+      v->part_pending = false;
+      pa_mode = PA_LOOKUP;
+    } else if ((rc = flush_part(v, s))) {
+      return rc;
+    }
+  }
   const bool keep_side = reuse && v->side_pending && v->fused_index;   // overlap mode: joined behind the tile sums
   if (v->side_pending && !keep_side) {
     HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
@@ -1989,15 +2036,25 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   pa.det = v->deterministic ? 1 : 0;
   pa.n = n;
   pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
+  pa.day_lk = pa.day;
+  if (pa_mode == PA_LOOKUP) { pa.day_lk = pend.day; pa.count_once = pend.count_once; }
   if (!reuse) {
     v->batch_serial = 0;
-    if (fused_ok(v->dim)) { if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s))) return rc; }
-    else index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    if (fused_ok(v->dim)) {
+      if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s, false, false, pa_route))) return rc;
+      if (pa_route) pa_mode = PA_APPLYIDX;
+    } else {
+      index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    }
     v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
     v->batch_n = n;
+  } else if (pa_mode < 0 && v->fused_index && !v->index_records && !keep_side) {
+    // a batch whose entries k_papply consumed before (a second optimizer on the same token): its bookkeeping is done
+    if (!pa_route) return fail(KV_FAILED_PRECONDITION, "the batch index holds no key records (KV_NO_PAPPLY set between two applies)");
+    pa_mode = PA_NONE;
   }
   if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
-  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side);
+  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side, pa_mode);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());

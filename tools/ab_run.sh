@@ -1,0 +1,18 @@
+B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+run() { tag=$1; shift; "$@" > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err; python3 - <<PY
+import json
+try:
+  d=json.loads(open('gpurun_out/ab_$tag.json').read().strip().splitlines()[-1]); k=d['kernels_ms']
+  print('%-14s step %.4f  ltile %.1f part %.1f tsum %.1f apply %.1f' % ('$tag', d['ms_per_step'], k['lookup_tile']*1e3, k['lookup_part']*1e3, k['apply_tsum']*1e3, k['apply_sorted']*1e3))
+except Exception as e: print('$tag', 'failed', e)
+PY
+}
+run base python bench.py $B
+run w4 python tools/ab_bench.py build/ab/w4.so $B
+run w3 python tools/ab_bench.py build/ab/w3.so $B
+run w4rb4 python tools/ab_bench.py build/ab/w4rb4.so $B
+KV_FORCE_P=1024 run base_p1024 python bench.py $B
+KV_FORCE_P=1024 run w4_p1024 python tools/ab_bench.py build/ab/w4.so $B
+KV_FORCE_P=1024 run w3_p1024 python tools/ab_bench.py build/ab/w3.so $B
+KV_FORCE_P=1024 run w4rb4_p1024 python tools/ab_bench.py build/ab/w4rb4.so $B
+KV_FORCE_P=256 run base_p256 python bench.py $B
