@@ -25,7 +25,7 @@
 
 enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2 };
 #ifndef KV_PA_WAVES
-#define KV_PA_WAVES 2      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
+#define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
 #endif
 #ifndef KV_PA_HOTRB
 #define KV_PA_HOTRB 8      // a hot key's sources in flight per lane group and step
@@ -71,23 +71,28 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   unsigned pbase;
   const unsigned E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
   if (E == 0) return;
-  if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lkeys = 0; }
+  if (tid == 0) { sp = 0; lkeys = 0; }
   __syncthreads();
   if (E > 65535u) {
     if (tid == 0) raise_error(a.tv, 2u);
     return;
   }
+#ifdef KV_PA_X_LDSONLY
+  constexpr bool in_lds = true;
+#else
   const bool in_lds = E <= (unsigned)PA_LSRC;
+#endif
   unsigned* const gsrc = w.order + pbase;   // (the partitions' stretches of w.order are disjoint)
   auto src_at = [&](unsigned i) -> unsigned {
     // a stretch filed in global memory was written by other waves of this block: read past the CU's vector cache
     return in_lds ? lsrc[i] : __hip_atomic_load(gsrc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  while (sp > 0) {
-    const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+  // One round = the keys of one sub-hash class (R == 1: all of them).  Returns true when the class holds more distinct
+  // keys than the LDS hash: the caller splits it.  A lambda, expanded twice: the common single round is straight-line
+  // code (what the partition phases hold in registers is dead when the apply begins), the split rounds loop below.
+  auto do_round = [&](const unsigned R, const unsigned round) -> bool {
     __syncthreads();
-    if (tid == 0) --sp;
     for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; }
     if (tid == 0) { lnu = 0; lsent = 0; lnext = 0; }
     __syncthreads();
@@ -132,19 +137,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       }
     }
     __syncthreads();
-    if (lnu >= (unsigned)UCAPK) {   // more distinct keys than the hash holds: two sub-hash classes, each on its own
-      __syncthreads();
-      if (tid == 0) {
-        if (sp + 2 <= 24) {
-          stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
-          stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
-        } else {
-          raise_error(a.tv, 2u);
-        }
-      }
-      __syncthreads();
-      continue;
-    }
+    if (lnu >= (unsigned)UCAPK) return true;   // more distinct keys than the hash holds
     KV_STAMPP(1);
     const unsigned nu = lnu;
     if (tid == 0) lkeys += nu;
@@ -273,7 +266,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     const unsigned nitems = nhot + nbatch;
     KV_STAMPPV(6, E); KV_STAMPPV(7, nu); KV_STAMPPV(8, nhot);
 #ifdef KV_PA_X_NOAPPLY
-    continue;
+    return false;
 #endif
 #ifdef KV_STAMPS
     unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0;
@@ -546,6 +539,29 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 #endif
     __syncthreads();
     KV_STAMPP(3);
+    return false;
+  };
+  if (do_round(1u, 0u)) {
+    // two sub-hash classes, each on its own; a class that still overflows splits again
+    __syncthreads();
+    if (tid == 0) { stkR[0] = 2; stkr[0] = 0; stkR[1] = 2; stkr[1] = 1; sp = 2; }
+    __syncthreads();
+    while (sp > 0) {
+      const unsigned R = stkR[sp - 1], round = stkr[sp - 1];
+      __syncthreads();
+      if (tid == 0) --sp;
+      const bool ovf = do_round(R, round);   // (block-uniform)
+      __syncthreads();
+      if (ovf && tid == 0) {
+        if (sp + 2 <= 24) {
+          stkR[sp] = 2 * R; stkr[sp] = round; ++sp;
+          stkR[sp] = 2 * R; stkr[sp] = round + R; ++sp;
+        } else {
+          raise_error(a.tv, 2u);
+        }
+      }
+      __syncthreads();
+    }
   }
   if (tid == 0 && mode != PA_NONE) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
 }
@@ -569,7 +585,13 @@ int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s
   if (q <= 1) KV_PA(4, 1, 1);
   if (q <= 2) KV_PA(4, 2, 1);
   if (q <= 4) KV_PA(4, 4, 1);
+#ifdef KV_PA_D32_L4K2
+  if (q <= 8) KV_PA(4, 4, 2);
+#elif defined(KV_PA_D32_L2K4)
+  if (q <= 8) KV_PA(4, 2, 4);
+#else
   if (q <= 8) KV_PA(4, 8, 1);
+#endif
   if (q <= 16) KV_PA(4, 8, 2);
   if (q <= 32) KV_PA(4, 16, 2);
   if (q <= 64) KV_PA(4, 64, 1);

@@ -797,6 +797,11 @@ void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t 
 }
 
 // ---- the entry-list pipeline (kv_fused.h) ----
+// KV_NO_PAPPLY=1: A/B against k_part2 + k_apply2
+bool papply_enabled() {
+  static const bool off = [] { const char* e = getenv("KV_NO_PAPPLY"); return e && atoi(e) != 0; }();
+  return !off;
+}
 // ids per index pass: positions and epart rows are 30-bit fields of the entry list's words, a partition block takes
 // up to 65535 entries; 2^23 ids (4096 tiles) stay well inside both
 constexpr long long FUSED_MAX_N = 1ll << 23;
@@ -1045,9 +1050,13 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
       // about 384 distinct keys per partition block (the LDS hash of k_part2 holds 768 before a partition splits),
       // at most 2048 entries: 109 k keys of 1 M ids (Zipf 1.2) -> 512 partitions, 773 k (Zipf 0.8) -> 2048.
       // Measured at 1 M ids: 512 against 1024 partitions is -2.5 us per step at Zipf 1.2 and +40 us at Zipf 0.8.
+      // With k_papply (kv_papply.h) the partition block also applies its keys' updates, four blocks of four waves per
+      // CU: about 128 keys per block keep all 1024 slots of the chip busy (109 k keys -> 1024 partitions: 64.7 us
+      // against 79.9 us with 512, profiles/r04_*).
       // (a hint is only a hint: never more distinct keys than ids, never more partitions than the workspace was sized for)
       const unsigned long long u = std::min<unsigned long long>(u_prev, (unsigned long long)n);
-      const unsigned long long want = std::max<unsigned long long>((u + 383ull) / 384ull, (unsigned long long)((n + 2047) / 2048));
+      const unsigned long long per = papply_enabled() ? 128ull : 384ull;
+      const unsigned long long want = std::max<unsigned long long>((u + per - 1ull) / per, (unsigned long long)((n + 2047) / 2048));
       const unsigned pmax = std::min<unsigned>((unsigned)MAX_P, std::max(64u, t->ws.capP));
       unsigned P = 64;
       while (P < want && P < pmax) P <<= 1;
@@ -1117,11 +1126,6 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
 }
 // ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
 // a key can have more entries than a chunk holds, i.e. more tiles than HC2)
-// KV_NO_PAPPLY=1: A/B against k_part2 + k_apply2
-bool papply_enabled() {
-  static const bool off = [] { const char* e = getenv("KV_NO_PAPPLY"); return e && atoi(e) != 0; }();
-  return !off;
-}
 // pa_mode >= 0: the tile sums, then partition pass + apply in one launch (k_papply, kv_papply.h) over the tiles' entries
 template <int OPT>
 int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false, int pa_mode = -1) {

@@ -8,11 +8,7 @@ except Exception as e: print('$tag', 'failed', e)
 PY
 }
 run base python bench.py $B
-run w4 python tools/ab_bench.py build/ab/w4.so $B
-run w3 python tools/ab_bench.py build/ab/w3.so $B
-run w4rb4 python tools/ab_bench.py build/ab/w4rb4.so $B
-KV_FORCE_P=1024 run base_p1024 python bench.py $B
-KV_FORCE_P=1024 run w4_p1024 python tools/ab_bench.py build/ab/w4.so $B
-KV_FORCE_P=1024 run w3_p1024 python tools/ab_bench.py build/ab/w3.so $B
-KV_FORCE_P=1024 run w4rb4_p1024 python tools/ab_bench.py build/ab/w4rb4.so $B
-KV_FORCE_P=256 run base_p256 python bench.py $B
+for v in "$@"; do
+  run $v python tools/ab_bench.py build/ab/$v.so $B
+  KV_FORCE_P=1024 run ${v}_p1024 python tools/ab_bench.py build/ab/$v.so $B
+done

@@ -40,6 +40,7 @@ L.kv_debug_read_stamps(var.ptr, a.ctypes.data, 16384)
 def med(x): return "median %6.0f p90 %6.0f max %6.0f" % (np.median(x), np.percentile(x, 90), x.max()) if len(x) else "-"
 print("ticks of 10 ns; K = %d, Zipf %.1f" % (K, S))
 pt = a[4096:4096 + 2048].astype(np.int64); pt = pt[pt[:, 3] > 0]
+pt = pt[pt[:, 0] > pt[:, 0].max() - 30000]   # the last launch only (earlier batches ran other partition counts)
 if len(pt):
   b0 = pt[:, 0].min()
   print("k_papply: %d blocks" % len(pt))
@@ -53,6 +54,7 @@ if len(pt):
   slow = np.argsort(-(pt[:, 3] - b0))[:8]
   for i in slow: print("     slow block: E %d keys %d hot %d phases %s end %d" % (E_[i], nu_[i], nh_[i], [int(pt[i, j + 1] - pt[i, j]) for j in range(3)], pt[i, 3] - b0))
 wv = a[8192:8192 + 8192].astype(np.int64); wv = wv[wv[:, 1] > 0]
+wv = wv[wv[:, 0] > wv[:, 0].max() - 30000]
 if len(wv):
   print("   per wave (%d): apply span %s" % (len(wv), med(wv[:, 1] - wv[:, 0])))
   print("   hot items per wave %s ; time per hot item %s" % (med(wv[:, 4]), med(wv[:, 2][wv[:, 4] > 0] / wv[:, 4][wv[:, 4] > 0])))
