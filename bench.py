@@ -203,7 +203,7 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
     torch.cuda.synchronize()
     pr = ops.kv_profile_read(var)
     ops.kv_profile_enable(var, 0)
-    rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0]) / max(pr["lookup_tile"][1], 1)
+    rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0] + pr["lookup_rows"][0]) / max(pr["lookup_tile"][1] + pr["lookup_rows"][1], 1)
     sweep.append({"zipf": sk, "unique_per_batch": float(np.mean([b[2] for b in bs])), "ms_per_step": ms_step,
                   "lookup_ms": ms_look, "lookup_rows_ready_ms": rows_ms, "apply_ms": ms_step - ms_look})
     del bs
@@ -517,24 +517,29 @@ def main():
   # the partition pass (its gather blocks copy the rows); the apply reads every gradient row once and
   # reads + writes the optimizer state of every unique key in k_apply_sorted.
   Ub = U_mean
-  fused = prof["apply_tsum"][1] > 0     # the entry-list pipeline ran (kv_fused.h)
+  fused = prof["apply_tsum"][1] > 0 or prof["apply_tile"][1] > 0     # the entry-list pipeline ran (kv_fused.h)
+  deferred_tile = prof["lookup_rows"][1] > 0                          # ... with the lookup's rows by per-position probe (k_lrows)
   if fused:
     alg = {
         "lookup_tile": N * 8 + Ub * (16 + 4 * D) + N * 4 * D,   # k_ltile: ids, one probe + one row per key, output rows
+        "lookup_rows": N * 8 + Ub * (16 + 4 * D) + N * 4 * D,   # k_lrows: the whole lookup of SURVEY 8d (ids, probe + row per key, output rows)
         "lookup_part": 0,                                     # k_part2: row records only (not in SURVEY 8d's figure)
         "lookup_order": 0,
         "apply_index": N * 8 + Ub * 16,
         "apply_tsum": (N - S1_mean) * 4 * D,                   # k_tsum: gradient rows of ids repeated inside their tile
-        "apply_sorted": S1_mean * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,   # k_apply: the other gradient rows + state r/w
+        "apply_tile": N * 8 + (N - S1_mean) * 4 * D,           # k_ltsum: the ids again (tile pass) + those gradient rows
+        "apply_sorted": S1_mean * 4 * D + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,   # k_papply / k_apply2: the other gradient rows + state r/w
         "apply_span": 0,
     }
   else:
     alg = {
         "lookup_tile": N * 8,
+        "lookup_rows": 0,
         "lookup_part": Ub * 16,
         "lookup_order": Ub * 4 * D + N * 4 * D + N * 4,
         "apply_index": N * 8 + Ub * 16,
         "apply_tsum": 0,
+        "apply_tile": 0,
         "apply_sorted": N * 4 * D + Ub * (4 * 4 * D) + Ub * 4 * 4 * D,
         "apply_span": 0,
     }
@@ -543,8 +548,8 @@ def main():
   achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
   # entry-list pipeline: a lookup that hands out a batch token returns when its rows are written (k_ltile); its
   # partition pass (k_part2: frequency words, key records) is deferred to the head of the apply of that batch
-  lookup_ms = kern["lookup_tile"] + kern["lookup_order"] + (0.0 if fused and not args.no_token else kern["lookup_part"])
-  apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"] + kern["apply_tsum"] + \
+  lookup_ms = kern["lookup_tile"] + kern["lookup_order"] + kern["lookup_rows"] + (0.0 if fused and not args.no_token else kern["lookup_part"])
+  apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"] + kern["apply_tsum"] + kern["apply_tile"] + \
       (kern["lookup_part"] if fused and not args.no_token else 0.0)
   lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)
   apply_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D

@@ -492,7 +492,9 @@ int kv_take_rows(int device, const void* src, const int32_t* index, const int32_
 #define KV_PROF_APPLY_SORTED 4  /* k_apply: segmented gradient sum + fused row update */
 #define KV_PROF_APPLY_SPAN 5    /* k_apply_fin: keys that span several chunks */
 #define KV_PROF_APPLY_TSUM 6    /* k_tsum: tile-local gradient sums of repeated ids (entry-list pipeline) */
-#define KV_PROF_KINDS 7
+#define KV_PROF_LOOKUP_ROWS 7   /* k_lrows: the training lookup's rows by per-position probe (its tile pass is deferred) */
+#define KV_PROF_APPLY_TILE 8    /* k_ltsum: the batch's tile pass + the tile sums in front of the optimizer apply */
+#define KV_PROF_KINDS 9
 int kv_profile_enable(kv_handle_t h, int max_launches);
 int kv_profile_read(kv_handle_t h, double* ms_sum, int64_t* launches, int n_kinds);
 int kv_profile_select(kv_handle_t h, unsigned kind_mask);

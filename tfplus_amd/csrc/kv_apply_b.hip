@@ -36,3 +36,13 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_tsum(const void*
   return launch_tsum_t(*static_cast<const TableDev*>(td_), *static_cast<const WsDev*>(wd_), grad, n,
                        static_cast<hipStream_t>(stream), static_cast<const MultiDesc*>(md), ntab);
 }
+
+// k_ltsum of the entry-list pipeline (kv_fused.h): tile pass + tile sums; ids_kind 0 int64, 1 int32
+extern "C" __attribute__((visibility("hidden"))) int kvp_launch_ltsum(const void* td_, const void* wd_, const void* ids, int ids_kind,
+                                                                  long long n, int det, const float* grad, void* stream) {
+  const TableDev& td = *static_cast<const TableDev*>(td_);
+  const WsDev& wd = *static_cast<const WsDev*>(wd_);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ids_kind == 1) return launch_ltsum_t<int>(td, wd, static_cast<const int*>(ids), n, det, grad, s);
+  return launch_ltsum_t<long long>(td, wd, static_cast<const long long*>(ids), n, det, grad, s);
+}

@@ -116,3 +116,27 @@ inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad,
 #undef KV_TSUM
   return KV_UNIMPLEMENTED;
 }
+
+// k_ltsum (kv_fused.h): the tile pass of a batch and its tile sums in one launch; one block per tile.
+template <typename IdT>
+inline int launch_ltsum_t(const TableDev& td, const WsDev& wd, const IdT* ids, long long n, int det, const float* grad,
+                          hipStream_t s) {
+  const int D = td.dim;
+  const size_t sh = ltile_smem_bytes();
+#define KV_LTSUM(V, LPR, K)                                                                              \
+  do {                                                                                                   \
+    k_ltsum<IdT, V, LPR, K><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);          \
+    return KV_OK;                                                                                        \
+  } while (0)
+  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
+  const int q = D / 4;
+  if (q <= 1) KV_LTSUM(4, 1, 1);
+  if (q <= 2) KV_LTSUM(4, 2, 1);
+  if (q <= 4) KV_LTSUM(4, 4, 1);
+  if (q <= 8) KV_LTSUM(4, 8, 1);
+  if (q <= 16) KV_LTSUM(4, 8, 2);
+  if (q <= 32) KV_LTSUM(4, 16, 2);
+  if (q <= 64) KV_LTSUM(4, 64, 1);
+#undef KV_LTSUM
+  return KV_UNIMPLEMENTED;
+}

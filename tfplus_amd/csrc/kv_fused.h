@@ -940,7 +940,8 @@ __device__ __forceinline__ void items2_body(const WsDev& w, unsigned nib) {
 // The order of the additions depends on nothing but the list.  The positions of the next step are requested with
 // the rows of this one.  ITEM_BLOCKS blocks in front build the dense work-item directory (items2_body).
 constexpr int TBC = 512;
-template <int V, int LPR, int K>
+// FROM_LDS: the caller is the tile pass itself (k_ltsum): the tile's mrow image is read from its LDS (LtSmem::mr)
+template <int V, int LPR, int K, bool FROM_LDS = false>
 __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, unsigned tile) {
   constexpr int G = 64 / LPR;
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
@@ -952,7 +953,9 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
   const unsigned mc = w.mcount[tile];
   const unsigned nm = mc & 0xFFFFu;
   if (nm == 0u) return;   // block-uniform
-  const unsigned* mrow = w.mrow + (size_t)tile * TILE;
+  extern __shared__ __attribute__((aligned(16))) char tsum_smem_raw[];
+  const unsigned* const mrow_l = carve_ltile(tsum_smem_raw).mr;        // (two pointers: a select between LDS and global
+  const unsigned* const mrow_g = w.mrow + (size_t)tile * TILE;         //  memory would make every read a flat load)
   const float* g0 = grad + (size_t)tile * TILE * D;
   float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
   const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR, wv = threadIdx.x >> 6;
@@ -979,7 +982,10 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
   unsigned mw[RB], mn[RB];
   auto ldm = [&](unsigned rbase, unsigned (&m)[RB]) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i) { const unsigned r = rbase + g * RB + i; m[i] = mrow[r < r1 ? r : (r0 < nm ? r0 : 0u)]; }
+    for (int i = 0; i < RB; ++i) {
+      const unsigned r = rbase + g * RB + i, rc = r < r1 ? r : (r0 < nm ? r0 : 0u);
+      if constexpr (FROM_LDS) m[i] = mrow_l[rc]; else m[i] = mrow_g[rc];
+    }
   };
   if (r0 < r1) ldm(r0, mw);
   for (unsigned rb = r0; rb < r1; rb += RS) {   // wave-uniform
@@ -1498,6 +1504,103 @@ __global__ void __launch_bounds__(TB) k_copy(TableDev t, const IdT* __restrict__
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lrows: the training lookup's output rows by per-position probe; the tile pass is deferred
+// ------------------------------------------------------------------------------------------
+// What a training lookup RETURNS needs no de-duplication: out[i] = the row of ids[i], and for a key the table does not
+// hold yet the init rule's value, a function of (key, seed) (kv_variable.h:889-898).  goz_wave (kv_kernels.h) with that
+// answer for absent keys: a wave takes 64 ids per step, lane l probes id l, the rows go VQ lanes per row with streaming
+// stores; rows of absent keys (or of keys whose index entry is being published: HINT_NEW) are filled in a second
+// pass over the step, so the common path is the inference gather's.  The ids are copied to `ids_copy` on the way: the
+// tile pass that inserts the new keys, counts frequencies and builds the batch index (k_ltile<GATHER = false>, or
+// k_ltsum in front of the optimizer apply) runs later, when the caller's ids may be gone.
+template <typename IdT, int VQ, int CWMAX = 4>
+__device__ __forceinline__ void lrows_wave(const TableDev& t, const IdT* __restrict__ ids, IdT* __restrict__ ids_copy,
+                                           float* __restrict__ out, long long n, long long wave, long long nwaves) {
+  constexpr int RW = 64 / VQ;
+  constexpr int CW = VQ < CWMAX ? VQ : CWMAX;
+  const int lane = threadIdx.x & 63;
+  const int v = lane % VQ, sub = lane / VQ;
+  const long long stride = nwaves * 64;
+  long long r0 = wave * 64;
+  if (r0 >= n) return;
+  auto load_raw = [&](long long i) -> IdT { return i < n ? ids[i] : (IdT)0; };
+  IdT raw1 = load_raw(r0 + lane), raw2 = load_raw(r0 + stride + lane);
+  long long k1 = (long long)raw1;
+  unsigned long long p1 = home_of(t, k1, mix64((unsigned long long)k1));
+  Entry e1 = load_entry(&t.entries[p1]);
+  for (; r0 < n; r0 += stride) {
+    const bool valid = r0 + lane < n;
+    unsigned hint = 0;
+    unsigned rr = valid ? table_find_from(t, k1, p1, e1, &hint) : 0u;
+    const bool isnew = valid && (rr == 0u || hint == HINT_NEW);
+    if (isnew) rr = NEW_BIT;
+    if (ids_copy != nullptr && valid) ids_copy[r0 + lane] = raw1;
+    const long long kcur = k1;
+    // next step: its home entries leave now, the ids of the step after it too
+    raw1 = raw2;
+    k1 = (long long)raw1;
+    p1 = home_of(t, k1, mix64((unsigned long long)k1));
+    if (r0 + stride < n) e1 = load_entry(&t.entries[p1]);
+    raw2 = load_raw(r0 + 2 * stride + lane);
+#pragma unroll
+    for (int j0 = 0; j0 < VQ; j0 += CW) {
+      float4 val[CW];
+      unsigned rj[CW];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) rj[j] = __shfl(rr, (j0 + j) * RW + sub);
+#pragma unroll
+      for (int j = 0; j < CW; ++j) val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj[j] & ROW_MASK))[v];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const long long ii = r0 + (j0 + j) * RW + sub;
+        if (ii < n && !(rj[j] >> 31)) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+          __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+        }
+      }
+    }
+    if (__builtin_expect(__ballot(isnew) != 0ull, 0)) {
+      for (int j = 0; j < VQ; ++j) {
+        const unsigned rjn = __shfl(rr, j * RW + sub);
+        const long long kj = __shfl(kcur, j * RW + sub);
+        const long long ii = r0 + j * RW + sub;
+        if ((rjn >> 31) && ii < n) {
+          const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
+          const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
+          const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          __builtin_nontemporal_store((a.x + b.x) * 0.5f, &dst->x); __builtin_nontemporal_store((a.y + b.y) * 0.5f, &dst->y);
+          __builtin_nontemporal_store((a.z + b.z) * 0.5f, &dst->z); __builtin_nontemporal_store((a.w + b.w) * 0.5f, &dst->w);
+        }
+      }
+    }
+  }
+}
+template <typename IdT, int VQ>
+__global__ void __launch_bounds__(TB) k_lrows(TableDev t, const IdT* __restrict__ ids, IdT* __restrict__ ids_copy,
+                                              float* __restrict__ out, long long n) {
+  lrows_wave<IdT, VQ>(t, ids, ids_copy, out, n, (long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6),
+                      (long long)gridDim.x * (TB / 64));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ltsum: the tile pass and the tile sums of an optimizer apply in one launch
+// ------------------------------------------------------------------------------------------
+// The apply has the gradient rows at hand when it runs the batch's tile pass (the lookup deferred it, or the optimizer
+// meets the ids first): the block that de-duplicated a tile goes on to sum the rows of its repeated ids (tsum_body, fed
+// from the mrow image still in LDS).  The dedup chain of one block — LDS phases, one probe round trip — overlaps with
+// the row reads of the others; k_ltile<GATHER = false> + k_tsum one after the other were 23.5 + 24 us at configs[1].
+template <typename IdT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBT) k_ltsum(TableDev t, WsDev w, const IdT* __restrict__ ids, const int* __restrict__ counts,
+                                              long long n, int det, const float* __restrict__ grad) {
+  ltile_body<IdT, 1, false>(t, w, ids, counts, n, det, nullptr);
+  __syncthreads();   // the tile's mrow image and mcount are written (and every phase of the tile pass is behind us)
+  if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the tile pass gave up on this batch
+  tsum_body<V, LPR, K, true>(w, grad, t.dim, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -56,6 +56,9 @@ extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void*
 extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream, const void* md,
                                int ntab);
 // k_papply dispatch (kv_papply.h), two more translation units: a = GroupAdam V4 / V3, b = Adagrad / SparseGroupFtrl
+// k_ltsum dispatch (kv_fused.h: tile pass + tile sums), instantiated next to k_tsum; ids_kind 0 int64, 1 int32
+extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids, int ids_kind, long long n, int det,
+                                const float* grad, void* stream);
 extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream);
 extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream);
 
@@ -332,6 +335,7 @@ struct Workspace {
   long long hpart_elems = 0;
   unsigned* ctr = nullptr;
   unsigned* mcount = nullptr;  // entry-list pipeline: [cap_n / TILE]
+  long long* ids_copy = nullptr;   // [cap_n] the ids of a lookup whose tile pass is deferred (k_lrows copies them)
   float* epart = nullptr;      // [cap_n / 2][dim] tile sums
   long long epart_elems = 0;
   long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
@@ -397,6 +401,7 @@ struct kv_table {
   // runs it in front of its own kernels, any other op on the table runs it first thing (settle).  Same stream order
   // as before, the rows just do not wait for it.
   bool part_pending = false;
+  bool tile_pending = false;       // ... and so is its tile pass (k_lrows wrote the rows): the ids wait in ws.ids_copy
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_tile = nullptr, ev_copy = nullptr, ev_part = nullptr;
@@ -633,7 +638,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
         (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.coldlist, 2 * (size_t)cap)) ||
         (rc = regrow(&w.hotlist, 2 * (size_t)cap)) || (rc = regrow(&w.litem, (size_t)cap)) ||
         (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)) ||
-        (rc = regrow(&w.mcount, nt + 1)))
+        (rc = regrow(&w.mcount, nt + 1)) || (rc = regrow(&w.ids_copy, (size_t)cap)))
       return rc;
     if (!w.ctr) {   // zeroed: the first tile pass publishes ctr[5] (the previous pass's distinct keys) as a hint
       HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
@@ -868,6 +873,24 @@ void launch_copy(kv_table* t, const TableDev& td, const void* ids, long long n, 
 #undef KV_CP
 #undef KV_CP2
 }
+// the training lookup's rows by per-position probe (+ a copy of the ids for the deferred tile pass)
+void launch_lrows(kv_table* t, const TableDev& td, const void* ids, void* ids_copy, long long n, float* out, hipStream_t s) {
+  const int q = td.dim / 4;
+  const int grid = nblocks(n, TB, 8192);
+#define KV_LR2(IDT, VQ) k_lrows<IDT, VQ><<<grid, TB, 0, s>>>(td, (const IDT*)ids, (IDT*)ids_copy, out, n)
+#define KV_LR(IDT)                                                              \
+  do {                                                                          \
+    switch (q) {                                                                \
+      case 1: KV_LR2(IDT, 1); break;   case 2: KV_LR2(IDT, 2); break;           \
+      case 4: KV_LR2(IDT, 4); break;   case 8: KV_LR2(IDT, 8); break;           \
+      case 16: KV_LR2(IDT, 16); break; case 32: KV_LR2(IDT, 32); break;         \
+      default: KV_LR2(IDT, 64); break;                                          \
+    }                                                                           \
+  } while (0)
+  if (t->key_dtype == KV_DT_INT32) KV_LR(int); else KV_LR(long long);
+#undef KV_LR
+#undef KV_LR2
+}
 template <int MODE>
 void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   if (md) k_part2_multi<MODE><<<dim3(wd.P, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
@@ -1023,6 +1046,11 @@ int flush_part(kv_table* t, hipStream_t s) {
   WsDev wd; PartArgs pa;
   std::memcpy(&wd, t->pend_wd, sizeof wd);
   std::memcpy(&pa, t->pend_pa, sizeof pa);
+  if (t->tile_pending) {   // the lookup wrote its rows by per-position probe: the tile pass over its copy of the ids
+    t->tile_pending = false;
+    ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
+    launch_ltile(t, pa.tv, wd, t->ws.ids_copy, nullptr, pa.n, nullptr, s, -1);
+  }
   ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
   launch_part2<MODE_LOOKUP>(wd, pa, s);
   t->index_records = true;
@@ -1030,14 +1058,8 @@ int flush_part(kv_table* t, hipStream_t s) {
   return KV_OK;
 }
 
-// The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
-template <int MODE>
-int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
-                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false,
-                     bool tile_only = false) {
-  wd.hc = (unsigned)HC2;
-  t->fused_index = true;
-  t->index_records = true;
+// partitions of an entry-list index pass over n ids (wd.P, wd.pshift; remembered in t->index_P)
+void choose_partitions(kv_table* t, WsDev& wd, long long n) {
   {
     // the distinct ids of the batch before the last one (the tile pass hands the partition pass's count to the host
     // through a pinned word, no synchronisation): mostly distinct ids -> twice the partitions
@@ -1067,6 +1089,17 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     wd.pshift = 64 - ilog2(wd.P);
     t->index_P = wd.P;
   }
+}
+
+// The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
+template <int MODE>
+int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
+                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false,
+                     bool tile_only = false, bool defer_tile = false) {
+  wd.hc = (unsigned)HC2;
+  t->fused_index = true;
+  t->index_records = true;
+  choose_partitions(t, wd, n);
   if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
     // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
     // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
@@ -1085,6 +1118,28 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     t->side_pending = true;
     t->side_has_items = false;
     HIP_TRY(hipStreamWaitEvent(s, t->ev_copy, 0));
+    return KV_OK;
+  }
+  if (MODE == MODE_LOOKUP && out && defer_tile && defer_part && !counts && ids_kind < 0) {
+    // The rows by per-position probe (k_lrows: the inference gather with the init rule's value for absent keys) and
+    // nothing else: the tile pass — inserts, entries — and the partition pass wait for the table's next op.  The
+    // optimizer apply of this batch runs the tile pass together with its tile sums (k_ltsum) and the partition pass
+    // together with the update (k_papply); any other op settles both first (flush_part).
+    static const bool x_goz = [] { const char* e = getenv("KV_X_LROWS_GOZ"); return e && atoi(e) != 0; }();   // diagnostic: the inference gather in k_lrows' place (every key present)
+    if (x_goz && t->key_dtype != KV_DT_INT32 && pa.tv.dim == 32) {
+      HIP_TRY(hipMemcpyAsync(t->ws.ids_copy, ids, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+      ProfScope ps(t, KV_PROF_LOOKUP_ROWS, s);
+      k_gather_or_zeros_w<long long, 8><<<nblocks(n, TB, 8192), TB, 0, s>>>(pa.tv, (const long long*)ids, out, n);
+    } else {
+      ProfScope ps(t, KV_PROF_LOOKUP_ROWS, s);
+      launch_lrows(t, pa.tv, ids, t->ws.ids_copy, n, out, s);
+    }
+    t->side_has_items = false;
+    std::memcpy(t->pend_wd, &wd, sizeof wd);
+    std::memcpy(t->pend_pa, &pa, sizeof pa);
+    t->part_pending = true;
+    t->tile_pending = true;
+    t->index_records = false;
     return KV_OK;
   }
   {
@@ -1128,11 +1183,17 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
 // a key can have more entries than a chunk holds, i.e. more tiles than HC2)
 // pa_mode >= 0: the tile sums, then partition pass + apply in one launch (k_papply, kv_papply.h) over the tiles' entries
 template <int OPT>
-int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false, int pa_mode = -1) {
+int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false, int pa_mode = -1,
+                const void* tile_ids = nullptr) {
   wd.hc = (unsigned)HC2;
   pa.epart = wd.epart;
   if (pa_mode >= 0) {
-    {
+    if (tile_ids) {   // the batch's tile pass has not run yet: it runs here, with the tile sums (k_ltsum)
+      ProfScope ps(v, KV_PROF_APPLY_TILE, s);
+      const int rc = kvp_launch_ltsum(&pa.tv, &wd, tile_ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, v->deterministic ? 1 : 0,
+                                      pa.grad, (void*)s);
+      if (rc) return fail(rc, "tile pass + tile sums: no kernel for dim %d", pa.tv.dim);
+    } else {
       ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
       const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s, nullptr, 0);
       if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
@@ -1309,7 +1370,7 @@ int kv_destroy(kv_handle_t t) {
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
-  hipFree(w.mcount); hipFree(w.epart);
+  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy);
   if (t->side) {
     hipStreamSynchronize(t->side);
     hipStreamDestroy(t->side);
@@ -1322,11 +1383,24 @@ int kv_destroy(kv_handle_t t) {
   return KV_OK;
 }
 
+// A lookup's deferred passes hold a snapshot of the table's arrays (pend_pa): whatever moves or frees those arrays, or
+// changes what the passes would compute (seed, deterministic order), first lets them run — on the stream of the
+// table's last op — and waits for them.
+static int settle_pending(kv_table* t) {
+  if (!t->part_pending && !t->side_pending) return KV_OK;
+  hipStream_t s = t->has_last ? t->last_stream : nullptr;
+  int rc;
+  if ((rc = join_side(t, s))) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return KV_OK;
+}
+
 int kv_reserve(kv_handle_t t, int64_t capacity) {
   int rc;
   if ((rc = check_table(t))) return rc;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = settle_pending(t))) return rc;
   unsigned long long save = t->rows_ub, save_idx = t->idx_ub;
   long long extra = capacity + 1 - (long long)t->rows_ub;
   if (extra <= 0) return KV_OK;
@@ -1345,6 +1419,7 @@ int kv_init_table(kv_handle_t t, const float* table, int64_t rows, kv_stream_t s
   // "re-initialization ignored" once a table is set (random_init_table_.NumElements() > 0, kv_variable.h:188-193);
   // the zero row an import leaves in place of a missing init table is not one
   if (t->initialized && t->init_table && !t->init_placeholder) return KV_OK;
+  if ((rc = settle_pending(t))) return rc;   // (a pending pass reads the placeholder the next line frees)
   if (t->init_table) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); hipFree(t->init_table); t->init_table = nullptr; }
   HIP_TRY(hipMalloc(&t->init_table, (size_t)rows * t->dim * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(t->init_table, table, (size_t)rows * t->dim * sizeof(float),
@@ -1372,6 +1447,9 @@ int kv_set_clock_days(kv_handle_t t, int day) {
 int kv_set_seed(kv_handle_t t, uint64_t seed) {
   int rc;
   if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
+  std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = settle_pending(t))) return rc;   // rows a pending pass initialises follow the seed the lookup answered with
   t->seed = seed;
   return KV_OK;
 }
@@ -1496,7 +1574,13 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     const bool side_part = side_on && token != nullptr && n <= CHK;
     static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();   // A/B
     const bool defer_part = token != nullptr && n <= CHK && !side_part && !no_defer;   // a token is asked for: an apply of this batch follows
-    if (fused_ok(t->dim)) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, side_part, defer_part))) return rc; }
+    // KV_DEFER_TILE=1 (A/B): the rows by per-position probe (k_lrows), the tile pass with the apply's tile sums (k_ltsum).
+    // Measured at configs[1] inside the training loop: k_lrows 49 us (the inference gather in its place: 45 us; 28 us
+    // only when the same few batches repeat and stay in the infinity cache) + k_ltsum 43 us against k_ltile 55 us +
+    // k_tsum 24 us: the de-duplicated probes and rows of k_ltile win.  Off unless asked for.
+    static const bool defer_tile_on = [] { const char* e = getenv("KV_DEFER_TILE"); return e && atoi(e) != 0; }();
+    const bool defer_tile = defer_part && papply_enabled() && defer_tile_on && !t->overlap && !cp && !pairs && seg_cap == 0;
+    if (fused_ok(t->dim)) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, side_part, defer_part, false, defer_tile))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -2015,11 +2099,13 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   const bool pa_route = papply_enabled() && fused_ok(v->dim);
   int pa_mode = -1;
   PartArgs pend{};
+  const void* tile_ids = nullptr;   // != nullptr: the batch's tile pass runs in front of the apply (k_ltsum)
   if (v->part_pending) {
     if (reuse && pa_route && v->fused_index && !v->side_pending) {
       std::memcpy(&pend, v->pend_pa, sizeof pend);
       v->part_pending = false;
       pa_mode = PA_LOOKUP;
+      if (v->tile_pending) { v->tile_pending = false; tile_ids = v->ws.ids_copy; }
     } else if ((rc = flush_part(v, s))) {
       return rc;
     }
@@ -2044,9 +2130,16 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   if (pa_mode == PA_LOOKUP) { pa.day_lk = pend.day; pa.count_once = pend.count_once; }
   if (!reuse) {
     v->batch_serial = 0;
-    if (fused_ok(v->dim)) {
-      if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s, false, false, pa_route))) return rc;
-      if (pa_route) pa_mode = PA_APPLYIDX;
+    if (pa_route) {   // tile pass + tile sums in one launch, then partition pass + update in one launch
+      wd.hc = (unsigned)HC2;
+      v->fused_index = true;
+      v->index_records = false;
+      v->side_has_items = false;
+      choose_partitions(v, wd, n);
+      tile_ids = ids;
+      pa_mode = PA_APPLYIDX;
+    } else if (fused_ok(v->dim)) {
+      if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s))) return rc;
     } else {
       index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
     }
@@ -2058,7 +2151,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     pa_mode = PA_NONE;
   }
   if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
-  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side, pa_mode);
+  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side, pa_mode, tile_ids);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -2200,7 +2293,9 @@ int kv_attach_slot(kv_handle_t v, kv_handle_t sl, kv_stream_t stream) {
 int kv_set_deterministic(kv_handle_t t, int on) {
   int rc;
   if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = settle_pending(t))) return rc;
   t->deterministic = on != 0;
   t->batch_serial = 0;
   return KV_OK;
@@ -2653,7 +2748,9 @@ int kv_export_fill(kv_handle_t t, int first_n, int64_t* keys, float* values, int
 int kv_set_delta_tracking(kv_handle_t t, int support_delta_export, int support_prediction_delta_export) {
   int rc;
   if ((rc = check_table(t))) return rc;
+  DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  if ((rc = settle_pending(t))) return rc;
   t->track_delta = support_delta_export != 0;
   t->track_pred = support_prediction_delta_export != 0;
   return KV_OK;

@@ -432,7 +432,8 @@ def kv_reserve(table_handle, capacity):
   _lib.check(_lib.lib().kv_reserve(table_handle.ptr, int(capacity)))
 
 
-PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_order", "apply_index", "apply_sorted", "apply_span", "apply_tsum")
+PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_order", "apply_index", "apply_sorted", "apply_span", "apply_tsum",
+              "lookup_rows", "apply_tile")   # include/kvhip.h KV_PROF_*
 
 
 def kv_attach_slot(var, slot):
