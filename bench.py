@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20250211 + 2
-SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "8"))   # the dominant kernel is bracketed by events on every 8th step of the timed region (a pair of markers costs ~4 us of stream time)
+SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "0"))   # 0: the dominant kernel is bracketed by events on every 8th step of the timed region (a pair of markers costs ~4 us of stream time), every 2nd when the run has 24 steps or fewer (so that at least 8 launches are timed)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -73,7 +73,8 @@ class Zipf(object):
 def cpu_baseline(args, D):
   """The oracle (a port of the reference's CPU algorithm: 1031-segment unordered_map, per-row heap buffers, rw spin
   locks, Shard-style contiguous blocks) on this host's cores, BASELINE.md section 3's protocol on a bounded sample:
-  a table with --cpu-keys keys (10 M by default; 50 M take too long to build for a default run), warm-up steps, then
+  a table with --cpu-keys keys (configs[1]'s 50 M by default, built with every host thread inside --cpu-build-budget
+  seconds: a host too slow for that times the baseline on the keys it got in, and says how many), warm-up steps, then
   --cpu-steps timed steps of the same 1 M-id Zipf batch shape; median and p95.  The lookup and the optimizer apply
   are sharded over the cores like the reference's ops; TF-core's Unique / UnsortedSegmentSum run on ONE thread, as
   they do in TF-core."""
@@ -87,9 +88,16 @@ def cpu_baseline(args, D):
   z = Zipf(K, args.zipf, torch.device("cpu"))
   g = torch.Generator().manual_seed(SEED)
   t0 = time.perf_counter()
+  built = 0
   for i in range(0, K, 1 << 20):
     var.gather_or_insert(splitmix64(torch.arange(i + 1, min(i + (1 << 20), K) + 1, dtype=torch.int64)).numpy())
+    built = min(i + (1 << 20), K)
+    if time.perf_counter() - t0 > args.cpu_build_budget and built < K:
+      break
   build_s = time.perf_counter() - t0
+  if built < K:      # the Zipf ranks are drawn over the keys that exist
+    K = built
+    z = Zipf(K, args.zipf, torch.device("cpu"))
   N = args.batch
 
   def one_step():
@@ -108,7 +116,8 @@ def cpu_baseline(args, D):
   t1 = one_step()                                       # the same step on ONE thread (SURVEY.md section 8d asks for both)
   return {"value": N / t, "unit": "ids/s", "cores": cores, "kind": "port", "value_1_thread": N / t1,
           "median_s_per_step": t, "p95_s_per_step": p95,
-          "sample": "oracle/kv_oracle.cc, %d threads (dedup on 1 like TF-core's Unique), %d-key table (not 50M), 2 warm-up + "
+          "keys": K, "keys_asked": args.cpu_keys,
+          "sample": "oracle/kv_oracle.cc, %d threads (dedup on 1 like TF-core's Unique), %d-key table, 2 warm-up + "
                     "%d timed steps of %d Zipf(%.1f) ids: lookup + tf.unique/segment_sum + GroupAdamV4; median %.3f s / "
                     "p95 %.3f s per step; table build %.1f s" % (cores, K, args.cpu_steps, N, args.zipf, t, p95, build_s)}
 
@@ -221,7 +230,10 @@ def main():
   ap.add_argument("--dim", type=int, default=32)
   ap.add_argument("--zipf", type=float, default=1.2)
   ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
-  ap.add_argument("--cpu-keys", type=int, default=10_000_000)
+  ap.add_argument("--cpu-keys", type=int, default=50_000_000,
+                  help="keys of the CPU baseline's table (BASELINE.md section 3: configs[1] = 50 M)")
+  ap.add_argument("--cpu-build-budget", type=float, default=240.0,
+                  help="seconds the CPU table build may take; when it runs out the baseline is timed on the keys inserted so far (and says so)")
   ap.add_argument("--cpu-steps", type=int, default=10)
   ap.add_argument("--no-extras", action="store_true",
                   help="skip the measurements taken after the timed region (skew sweep, op boundary, no token, staged)")
@@ -287,8 +299,9 @@ def main():
   L = _lib.lib()
 
   D, N = args.dim, args.batch
-  # weak scaling: every rank owns ~args.keys keys of a table of args.keys * world keys, sharded by
-  # floor_mod(key, world) (the reference's partition rule), and feeds its own batch of N ids
+  # weak scaling: every rank owns ~args.keys keys of a table of args.keys * world keys, sharded by the hashed owner
+  # rule (mix64(id) >> 32) % world (KV_OWNER_HASH; the reference's floor_mod rule is the library's other option),
+  # and feeds its own batch of N ids
   K = args.keys * world
   K_local = args.keys if world == 1 else int(args.keys * 1.05) + 1024
   gen = torch.Generator(device=dev).manual_seed(SEED + rank)
@@ -474,7 +487,8 @@ def main():
     torch.cuda.synchronize()
   ops.kv_profile_enable(var, 0 if (args.no_kernel_events or graphs) else args.steps + 8)
   ops.kv_profile_select(var, [dom])
-  ops.kv_profile_sample(var, SAMPLE_EVERY)     # a pair of event markers costs ~4 us of stream time per launch
+  sample_every = SAMPLE_EVERY if SAMPLE_EVERY > 0 else (2 if args.steps <= 24 else 8)
+  ops.kv_profile_sample(var, sample_every)     # a pair of event markers costs ~4 us of stream time per launch
   barrier()
   t0 = time.perf_counter()
   if graphs:
@@ -501,6 +515,25 @@ def main():
     torch.cuda.synchronize()
     prof = ops.kv_profile_read(var)
   ops.kv_profile_enable(var, 0)
+  # the COMPLETE lookup — output rows and the op's own bookkeeping (frequency words, day stamps, rows of new keys): a
+  # token lookup defers that half to the head of the apply, where k_papply does it in the same pass as the update; a
+  # lookup that is followed by another lookup runs it itself.  Timed here as a lookup-only loop (every lookup settles
+  # the one before it), events on the op's stream, outside the timed region.
+  lookup_complete_ms = None
+  if not shard_path:
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    def look(k):
+      tok = ctypes.c_uint64(0)
+      _lib.check(L.kv_gather_or_insert_tok(var.ptr, pool[k % len(pool)][0].data_ptr(), None, N, out.data_ptr(), ctypes.byref(tok), st))
+    for k in range(3):
+      look(k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(12):
+      look(3 + k)
+    e1.record()
+    torch.cuda.synchronize()
+    lookup_complete_ms = e0.elapsed_time(e1) / 12
 
   ms_per_step = dt / args.steps * 1e3
   value = N * world / (dt / args.steps)
@@ -557,14 +590,19 @@ def main():
   # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
   # figure is the one collected by scripts_prof.sh (rocprofv3 --pmc passes of this same command) and
   # committed under profiles/; null when that file is absent or was taken on another workload.
-  traffic, traffic_src = None, None
+  traffic, traffic_src, traffic_raw = None, None, None
+  tj = None
   try:
-    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_traffic.json")))
+    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_traffic.json")))
     if tj.get("workload") == [K, N, D, args.zipf] and dom in tj["kernels"]:
       traffic = tj["kernels"][dom]["hbm_bytes"]
-      traffic_src = "profiles/r03_traffic.json: " + tj["source"]
+      traffic_raw = tj["kernels"][dom]["fetch_size_kib_raw"] * 1024 + tj["kernels"][dom]["write_bytes"]
+      traffic_src = ("profiles/r04_traffic.json, a COMMITTED profile of this command taken on the builder's box (PMC counters "
+                     "cannot be read from inside this process; not measured in this run): " + tj["source"])
+    else:
+      tj = None
   except (OSError, ValueError, KeyError):
-    pass
+    tj = None
 
   res = {
       "metric": "lookups+GroupAdam-applies/sec and HBM GB/s, 1M int64 ids x dim32",
@@ -586,18 +624,27 @@ def main():
                  "parallelism": ("table sharded over %d GPUs by (mix64(id) >> 32) %% G, fixed-capacity id/row/grad exchange, "
                                  "grouped ncclSend/ncclRecv over RCCL" % world) if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_fetch_uncorrected": traffic_raw,
+                   "traffic_source": traffic_src,
                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": dom_ms,
                    "launches_timed": int(timed[dom][1]),
                    "measured": "hipEvent pairs on the op's stream around every %dth launch of this kernel inside "
-                               "the timed region" % SAMPLE_EVERY},
+                               "the timed region" % sample_every},
       "kernels_ms": kern,
+      "kernels": {k: {"ms": kern[k], "algorithmic_bytes": alg[k], "GBps": alg[k] / (kern[k] * 1e-3) / 1e9,
+                      "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "ceiling_frac": alg[k] / (kern[k] * 1e-3) / 1e9 / 5000.0,
+                      "traffic": (tj["kernels"][k]["hbm_bytes"] if tj and k in tj["kernels"] else None)}
+                  for k in kern if kern[k] > 0 and alg.get(k, 0) > 0},
       "kernels_ms_measured": "%d further steps after the timed region with every kernel bracketed" % args.steps,
-      "ops": {"lookup": {"gpu_ms": lookup_ms, "what": "kernels until the output rows are complete" +
-                         ("; the partition pass of the batch (lookup_part) runs at the head of its apply" if fused and not args.no_token else ""),
+      "ops": {"lookup": {"gpu_ms": lookup_ms, "rows_ready_ms": lookup_ms, "complete_ms": lookup_complete_ms,
+                         "what": "rows_ready_ms (= gpu_ms): kernels until the output rows are complete" +
+                         ("; the batch's bookkeeping runs inside its apply (k_papply)" if fused and not args.no_token else "") +
+                         "; complete_ms: a lookup-only loop, every lookup running its own bookkeeping pass",
                          "algorithmic_bytes": lookup_bytes,
                          "GBps": lookup_bytes / (lookup_ms * 1e-3) / 1e9,
                          "frac_of_peak": lookup_bytes / (lookup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "complete_frac_of_peak": (lookup_bytes / (lookup_complete_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lookup_complete_ms else None,
                          "lookups_per_s": N / (lookup_ms * 1e-3)},
               "group_adam_apply": {"gpu_ms": apply_ms, "algorithmic_bytes": apply_bytes,
                                    "GBps": apply_bytes / (apply_ms * 1e-3) / 1e9,

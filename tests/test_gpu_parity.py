@@ -347,6 +347,75 @@ def test_delete_between_lookup_and_apply_makes_the_token_stale(ops):
     _assert_same_table(ops, hs, os_, ids_np, rtol=RTOL, atol=1e-12)
 
 
+def test_reserve_between_token_lookup_and_apply(ops):
+  """a token lookup returns with its partition pass pending (new keys sit in the index with no row contents
+  yet).  kv_reserve in between grows the slab and rebuilds the index: the pending pass must have run first.  Then the
+  apply with the same tensor object (the token is stale after the growth: the general path) against the oracle."""
+  D = 32
+  rng = np.random.default_rng(404)
+  hv, ov = _pair(ops, D, seed=2, rng=rng)
+  hs, os_ = _const(ops, 3 * D, 0.0)
+  for t in range(3):
+    ids_np = (rng.choice(50000, 6000, replace=True) + 100000 * t).astype(np.int64)      # new keys every step, with repeats
+    ids = torch.from_numpy(ids_np).cuda()
+    np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_insert_v2(hv, ids)), ov.gather_or_insert(ids_np))
+    ops.kv_reserve(hv, 200000 * (t + 1))                # larger than the table: slab chunks + index rebuild
+    u, gs, _ = ko.dedup_segment_sum(ids_np, rng.normal(0, 1e-2, (ids_np.size, D)).astype(np.float32))
+    b1p, b2p = _beta_pows(t)
+    ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, gs, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+    ko.apply_group_adam(ov, os_, gs, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, version=4)
+    _assert_same_table(ops, hv, ov, ids_np, rtol=RTOL, atol=1e-9)
+    _assert_same_table(ops, hs, os_, ids_np, rtol=RTOL, atol=1e-12)
+
+
+def test_seed_change_after_a_token_lookup_keeps_the_rows_it_returned(ops):
+  """The rows a lookup returned for new keys are the rows the table holds afterwards, whatever happens to the seed
+  before the deferred pass writes them (kv_set_seed settles pending work first)."""
+  D = 16
+  rng = np.random.default_rng(9)
+  hv, ov = _pair(ops, D, seed=3, rng=rng)
+  ids_np = rng.choice(10 ** 6, 3000, replace=True).astype(np.int64)
+  ids = torch.from_numpy(ids_np).cuda()
+  got = _np(ops.kv_variable_gather_or_insert_v2(hv, ids))
+  np.testing.assert_array_equal(got, ov.gather_or_insert(ids_np))
+  ops.kv_set_seed(hv, 12345)
+  np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_zeros_v2(hv, ids)), got)
+  _assert_same_table(ops, hv, ov, ids_np)
+
+
+def test_two_optimizer_steps_on_one_lookup_token(ops):
+  """lookup(ids) -> apply(ids, token) -> apply(ids, token) again (a second optimizer step on the same batch index): the
+  first apply consumed the lookup's pending bookkeeping (k_papply, PA_LOOKUP), the second must find the batch indexed
+  and bookkept (PA_NONE) — frequencies count the lookup once."""
+  D = 32
+  rng = np.random.default_rng(1234)
+  hv, ov = _pair(ops, D, seed=5, rng=rng)
+  hs, os_ = _const(ops, 3 * D, 0.0)
+  from tfplus_amd import _lib
+  import ctypes
+  L = _lib.lib()
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  for t in range(2):
+    ids_np = rng.integers(0, 8000, 20000).astype(np.int64) + 8000 * t      # a few repeats per id (the summation order hardly matters), new keys in step 1
+    ids = torch.from_numpy(ids_np).cuda()
+    out = torch.empty((ids_np.size, D), device="cuda")
+    tok = ctypes.c_uint64(0)
+    _lib.check(L.kv_gather_or_insert_tok(hv.ptr, ids.data_ptr(), None, ids_np.size, out.data_ptr(), ctypes.byref(tok), st))
+    np.testing.assert_array_equal(_np(out), ov.gather_or_insert(ids_np))
+    u = np.unique(ids_np)
+    for rep in range(2):
+      # one gradient row per id, repeated for every occurrence (the sum then hardly depends on its order)
+      g_np = rng.normal(0, 1e-2, (u.size, D)).astype(np.float32)[np.searchsorted(u, ids_np)]
+      grad = torch.from_numpy(g_np).cuda()
+      b1p, b2p = _beta_pows(2 * t + rep)
+      _lib.check(L.kv_apply_group_adam_tok(hv.ptr, hs.ptr, grad.data_ptr(), ids.data_ptr(), ids_np.size, 1e-2, float(b1p), float(b2p),
+                                           0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, 4, tok.value, st))
+      uu, gs, _ = ko.dedup_segment_sum(ids_np, g_np)
+      ko.apply_group_adam(ov, os_, gs, uu, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, version=4)
+    _assert_same_table(ops, hv, ov, ids_np, rtol=2e-5, atol=1e-7)      # repeated ids: summation order (tests/_reorder.py has the bound)
+    _assert_same_table(ops, hs, os_, ids_np, rtol=2e-5, atol=1e-7)
+
+
 def test_group_adam_parity_with_regularizers_and_blacklist(ops):
   rng = np.random.default_rng(31)
   D = 32

@@ -99,6 +99,116 @@ def test_shim_registers_every_hot_path_op():
   assert set(ours) <= built, sorted(set(ours) - built)
 
 
+def _expand_macros(text):
+  """Kernel registrations as the preprocessor would leave them: the shim's own registration macros expanded (they are
+  simple token pastes), so that every registration reads Name("Op").Device(DEVICE_X)...; one string per registration."""
+  text = _strip_comments(text)
+  # object-like / function-like macros of the shim, as (name, params, body)
+  macros = {}
+  for m in re.finditer(r'#define\s+(KV_\w+)(\(([^)]*)\))?((?:[^\n\\]|\\\n|\\.)*)', text):
+    params = [a.strip() for a in m.group(3).split(",")] if m.group(3) else None
+    macros[m.group(1)] = (params, m.group(4).replace("\\\n", " "))
+  body = re.sub(r'#define\s+KV_\w+(?:[^\n\\]|\\\n|\\.)*', "", text)
+
+  def split_args(a):
+    out, depth, cur = [], 0, ""
+    for ch in a:
+      if ch in "(<": depth += 1
+      if ch in ")>": depth -= 1
+      if ch == "," and depth == 0:
+        out.append(cur.strip()); cur = ""
+      else:
+        cur += ch
+    out.append(cur.strip())
+    return out
+
+  def expand(t, depth=0):
+    if depth > 6:
+      return t
+    changed = True
+    while changed:
+      changed = False
+      for name, (params, mbody) in macros.items():
+        if params is None:
+          if re.search(r'\b%s\b' % name, t):
+            t = re.sub(r'\b%s\b' % name, mbody, t); changed = True
+          continue
+        m = re.search(r'\b%s\(' % name, t)
+        if not m:
+          continue
+        i, d = m.end(), 1
+        while d:
+          d += {"(": 1, ")": -1}.get(t[i], 0); i += 1
+        args = split_args(t[m.end():i - 1])
+        b = mbody
+        if params and params[-1] == "...":
+          fixed = params[:-1]
+          va = ", ".join(args[len(fixed):])
+          for p_, a_ in zip(fixed, args):
+            b = re.sub(r'\b%s\b' % p_, a_, b)
+          b = b.replace("__VA_ARGS__", va)
+        else:
+          for p_, a_ in zip(params, args):
+            b = re.sub(r'\b%s\b' % p_, a_, b)
+        t = t[:m.start()] + b + t[i:]
+        changed = True
+    return t
+  flat = expand(body)
+  regs = []
+  for m in re.finditer(r'REGISTER_KERNEL_BUILDER\(\s*Name\(\s*"(\w+)"\s*\)', flat):
+    i, d = m.start() + len("REGISTER_KERNEL_BUILDER("), 1
+    while d:
+      d += {"(": 1, ")": -1}.get(flat[i], 0); i += 1
+    regs.append((m.group(1), re.sub(r"\s+", "", flat[m.start():i])))
+  return regs
+
+
+def test_shim_registers_device_gpu_kernels():
+  """the measured path must be reachable from a TF graph — the lookups and the optimizer ops take
+  device-resident indices / grad / output on DEVICE_GPU (TensorFlow-ROCm's device), the resource handle and the scalar
+  hyper-parameters in host memory; every other op has a DEVICE_GPU registration too (a resource is visible to kernels
+  of its own device only)."""
+  text = open(SHIM).read()
+  regs = _expand_macros(text)
+  by_dev = {"DEVICE_CPU": {}, "DEVICE_GPU": {}}
+  for name, r in regs:
+    for dev in by_dev:
+      if ".Device(%s)" % dev in r:
+        by_dev[dev].setdefault(name, []).append(r)
+  ours = _schemas(text)
+  for dev in by_dev:
+    assert set(ours) <= set(by_dev[dev]), (dev, sorted(set(ours) - set(by_dev[dev])))
+  gpu = by_dev["DEVICE_GPU"]
+  for op in ("KvVariableGatherOrZerosV2", "KvVariableGatherOrInsertV2", "KvVariableGatherOrInsertWithCounts"):
+    assert len(gpu[op]) == 3, op                                   # int32 / int64 / uint64 indices
+    for r in gpu[op]:
+      assert 'HostMemory("table_handle")' in r and "KvGatherGpuOp" in r, r
+      assert 'HostMemory("indices")' not in r and 'HostMemory("output")' not in r, r    # device-resident
+  scalars = {"KvVariableGroupSparseApplyAdamV4": ("var", "m_v_linear", "lr", "beta1_power", "beta2_power", "beat1", "beta2", "epsilon", "l1", "l2", "l21"),
+             "KvVariableGroupSparseApplyAdamV3": ("var", "m_v_linear", "lr", "beta1_power", "beta2_power", "beat1", "beta2", "epsilon", "l1", "l2", "l21"),
+             "KvVariableSparseApplyAdagrad": ("var", "accum", "lr"),
+             "KvVariableSparseGroupSparseApplyFtrlV2": ("var", "accum", "linear", "lr", "l1", "l2", "l21", "l2_shrinkage", "lr_power")}
+  for op, host in scalars.items():
+    assert len(gpu[op]) == 3, op
+    for r in gpu[op]:
+      assert "GpuOp" in r, r
+      for h in host:
+        assert 'HostMemory("%s")' % h in r, (op, h)
+      assert 'HostMemory("grad")' not in r and 'HostMemory("indices")' not in r, r
+    # ... and the host-memory names are inputs of the op
+    names = [spec.split(":")[0].strip() for kind, spec in ours[op] if kind == "Input"]
+    assert set(host) <= set(names), (op, set(host) - set(names))
+  # every HostMemory argument of every registration names an input or output of its op
+  for dev in by_dev:
+    for op, rs in by_dev[dev].items():
+      names = {spec.split(":")[0].strip() for kind, spec in ours[op] if kind in ("Input", "Output")}
+      for r in rs:
+        for h in re.findall(r'HostMemory\("(\w+)"\)', r):
+          assert h in names, "%s: HostMemory(%s) is not an argument of the op (%s)" % (op, h, sorted(names))
+  for op in ("KvVariable", "KvVariableV2", "KvVariableV3", "KvVariableV4", "InitKvVariableV2"):
+    assert any('HostMemory("table_handle")' in r for r in gpu[op]), op
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_OPS), reason="reference tree not present")
 def test_shim_schemas_equal_the_reference():
   ref = {}

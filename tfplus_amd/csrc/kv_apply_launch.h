@@ -101,7 +101,7 @@ inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad,
 #define KV_TSUM(V, LPR, K)                                                                              \
   do {                                                                                                  \
     if (md) k_tsum_multi<V, LPR, K><<<dim3((unsigned)ITEM_BLOCKS + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md); \
-    else k_tsum<V, LPR, K><<<grid, TBC, 0, s>>>(td, wd, grad, what);                                    \
+    else k_tsum<V, LPR, K><<<grid, TBC, (size_t)TILE * 4, s>>>(td, wd, grad, what);                                    \
     return KV_OK;                                                                                       \
   } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;

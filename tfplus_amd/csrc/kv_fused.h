@@ -940,9 +940,11 @@ __device__ __forceinline__ void items2_body(const WsDev& w, unsigned nib) {
 // The order of the additions depends on nothing but the list.  The positions of the next step are requested with
 // the rows of this one.  ITEM_BLOCKS blocks in front build the dense work-item directory (items2_body).
 constexpr int TBC = 512;
-// FROM_LDS: the caller is the tile pass itself (k_ltsum): the tile's mrow image is read from its LDS (LtSmem::mr)
+// FROM_LDS: the tile's mrow image is read from LDS at mrow_l — the tile pass's own image (k_ltsum: LtSmem::mr), or the
+// copy k_tsum stages while the count is still on its way (one round trip in front of the rows instead of two); mc_l = mcount[tile]
 template <int V, int LPR, int K, bool FROM_LDS = false>
-__device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, unsigned tile) {
+__device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restrict__ grad, int D, unsigned tile,
+                                          const unsigned* mrow_l = nullptr, unsigned mc_l = 0u) {
   constexpr int G = 64 / LPR;
   constexpr int RB = (8 / K) > 0 ? (8 / K) : 1;
   constexpr int RS = G * RB;            // rows per wave and step
@@ -950,12 +952,11 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
   constexpr int RF = K * V * LPR;       // floats of a row image in LDS
   __shared__ float lfs[2][NWC][RF];     // [0]: a wave's rows before its first head; [1]: its last run
   __shared__ unsigned lmeta[NWC][2];    // {1 = the wave saw a head, epart row of its last run}
-  const unsigned mc = w.mcount[tile];
+  const unsigned mc = FROM_LDS ? mc_l : w.mcount[tile];
   const unsigned nm = mc & 0xFFFFu;
   if (nm == 0u) return;   // block-uniform
-  extern __shared__ __attribute__((aligned(16))) char tsum_smem_raw[];
-  const unsigned* const mrow_l = carve_ltile(tsum_smem_raw).mr;        // (two pointers: a select between LDS and global
-  const unsigned* const mrow_g = w.mrow + (size_t)tile * TILE;         //  memory would make every read a flat load)
+  const unsigned* const mrow_g = w.mrow + (size_t)tile * TILE;   // (two pointers: a select between LDS and global memory
+                                                                 //  would make every read a flat load)
   const float* g0 = grad + (size_t)tile * TILE * D;
   float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
   const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR, wv = threadIdx.x >> 6;
@@ -1169,7 +1170,15 @@ __global__ void __launch_bounds__(TBC) k_tsum(TableDev t, WsDev w, const float* 
   KV_STAMPT(0);
   const unsigned nib = what == 1 ? 0u : w.nib;
   if (blockIdx.x < nib) { items2_body<TBC / 64>(w, nib); KV_STAMPT(1); return; }
-  tsum_body<V, LPR, K>(w, grad, t.dim, blockIdx.x - nib);
+  // the tile's mrow image (TILE words = 16 bytes per thread) is requested together with its count
+  static_assert(TILE * 4 == TBC * 16, "one uint4 of mrow per thread");
+  extern __shared__ __attribute__((aligned(16))) char ts_smem_raw[];
+  const unsigned tile = blockIdx.x - nib;
+  const uint4 img = reinterpret_cast<const uint4*>(w.mrow + (size_t)tile * TILE)[threadIdx.x];
+  const unsigned mc = w.mcount[tile];
+  reinterpret_cast<uint4*>(ts_smem_raw)[threadIdx.x] = img;
+  __syncthreads();
+  tsum_body<V, LPR, K, true>(w, grad, t.dim, tile, reinterpret_cast<const unsigned*>(ts_smem_raw), mc);
   KV_STAMPT(1);
 }
 
@@ -1600,7 +1609,8 @@ __global__ void __launch_bounds__(TBT) k_ltsum(TableDev t, WsDev w, const IdT* _
   ltile_body<IdT, 1, false>(t, w, ids, counts, n, det, nullptr);
   __syncthreads();   // the tile's mrow image and mcount are written (and every phase of the tile pass is behind us)
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the tile pass gave up on this batch
-  tsum_body<V, LPR, K, true>(w, grad, t.dim, blockIdx.x);
+  extern __shared__ __attribute__((aligned(16))) char lt_smem_raw[];
+  tsum_body<V, LPR, K, true>(w, grad, t.dim, blockIdx.x, carve_ltile(lt_smem_raw).mr, w.mcount[blockIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------

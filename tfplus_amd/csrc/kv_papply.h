@@ -70,6 +70,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   KV_STAMPP(0);
   unsigned pbase;
   const unsigned E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
+  KV_STAMPP(5);
   if (E == 0) return;
   if (tid == 0) { sp = 0; lkeys = 0; }
   __syncthreads();

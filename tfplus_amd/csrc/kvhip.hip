@@ -949,7 +949,9 @@ int report_deferred_error(kv_table* t, hipStream_t s) {
 // waits for everything the previous stream had been given.
 // launches a lookup's pending partition pass (see kv_table::part_pending) on stream s
 int flush_part(kv_table* t, hipStream_t s);
-int hand_over(kv_table* t, hipStream_t s, bool join_side = true) {
+// mutates == false: a read-only op (the inference gathers): ordered like any other op of the table — behind the table's
+// last op whatever its stream, and the next op behind it — but it does not move op_serial (a two-phase export may go on)
+int hand_over(kv_table* t, hipStream_t s, bool join_side = true, bool mutates = true) {
   if (t->side_pending && join_side) {   // the lookup's partition pass on the table's side stream (overlap mode)
     HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
     t->side_pending = false;
@@ -969,7 +971,7 @@ int hand_over(kv_table* t, hipStream_t s, bool join_side = true) {
   }
   t->last_stream = s;
   t->has_last = true;
-  ++t->op_serial;
+  if (mutates) ++t->op_serial;
   return KV_OK;
 }
 
@@ -1675,7 +1677,7 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = join_side(t, s))) return rc;
+  if ((rc = hand_over(t, s, true, false))) return rc;   // a read: behind the table's last op on whatever stream, no serial bump
   const TableDev td = dev_view(t);
   const int q = t->dim / 4;
   const bool wave_shaped = (t->dim & 3) == 0 && q >= 1 && q <= 64 && (q & (q - 1)) == 0;
@@ -1771,8 +1773,10 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
-  for (int i = 0; i < num_tables; ++i)
-    if ((rc = join_side(tables[i], s))) return rc;
+  // every table is read on the op's stream: behind whatever its own last op queued on another stream (an optimizer
+  // apply that has not finished), and its next op behind this read
+  for (kv_table* tb : lock.ts)
+    if ((rc = report_deferred_error(tb, s)) || (rc = hand_over(tb, s, true, false))) return rc;
   BatchStage& st = g_stage[device][0];
   StageSlot* sl = nullptr;
   if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(BatchGatherDesc), &sl))) return rc;

@@ -9,13 +9,16 @@
 //   tfplus/kv_variable/ops/training_ops.cc:135-150, 214-226, 1086-1105, 1266-1285 (FtrlV2, Adagrad, GroupAdam V3/V4)
 // and forwards Compute() to one C-ABI call.  All semantics live behind the C ABI; this file only moves
 // tensors.  tensorflow-cpu keeps tensors in host memory, so they cross PCIe through a per-resource ring of
-// pinned staging buffers (no allocation per call once warm; DESIGN.md §4 gives the PCIe bound); a TF build
-// with a ROCm device would hand tensor.data() straight to the C ABI instead.
+// pinned staging buffers (no allocation per call once warm; DESIGN.md §4 gives the PCIe bound): the DEVICE_CPU
+// kernels.  The DEVICE_GPU kernels at the end of the file (a TensorFlow-ROCm build) hand tensor.data() straight to the
+// C ABI on TF's stream: no staging, the measured path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "kvhip.h"
 #include "tensorflow/core/framework/common_shape_fns.h"
@@ -1049,7 +1052,16 @@ class KvBatchGatherHipOp : public OpKernel {
     }
     // every table's ids and rows travel through the FIRST table's stream (one launch serves them all); each
     // resource's ring stages its own tensors
+    // (the library orders the read behind every table's own last op whatever its stream: kv_batch_gather_or_zeros
+    //  hands each table over to `st`).  Every resource's mutex is held, in address order, until the rows are back:
+    // a concurrent op on one of the resources cannot wrap its staging ring onto a slot this op still uses.
     hipStream_t st = rs[0]->stream();
+    std::vector<std::mutex*> mus;
+    for (KvHipResource* r : rs) mus.push_back(r->mu());
+    std::sort(mus.begin(), mus.end());
+    mus.erase(std::unique(mus.begin(), mus.end()), mus.end());
+    for (std::mutex* m : mus) m->lock();
+    struct UnlockAll { std::vector<std::mutex*>* v; ~UnlockAll() { for (auto it = v->rbegin(); it != v->rend(); ++it) (*it)->unlock(); } } unlock_all{&mus};
     std::vector<kv_handle_t> hs((size_t)n_);
     std::vector<const void*> idp((size_t)n_);
     std::vector<int64_t> ns((size_t)n_);
@@ -1066,7 +1078,6 @@ class KvBatchGatherHipOp : public OpKernel {
       hs[(size_t)i] = r->h();
       ns[(size_t)i] = ids.NumElements();
       if (ns[(size_t)i] == 0) continue;
-      std::lock_guard<std::mutex> l(*r->mu());
       OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si[(size_t)i]));
       OP_REQUIRES_OK(ctx, r->ring()->Acquire(outs[(size_t)i]->TotalBytes(), &so[(size_t)i]));
       OP_REQUIRES_OK(ctx, StagingRing::Upload(si[(size_t)i], ids.data(), ids.TotalBytes(), st));
@@ -1085,7 +1096,11 @@ class KvBatchGatherHipOp : public OpKernel {
  private:
   int n_ = 1;
 };
-KV_REGISTER_IDS_OP("BatchKvVariableGatherOrZerosV2", KvBatchGatherHipOp);
+// (this op's resource input is the list "table_handles": no HostMemory("table_handle") — the reference registers the
+//  kernel without one, kernels/kv_variable_ops.cc:475-480; on DEVICE_CPU every input is host memory anyway)
+REGISTER_KERNEL_BUILDER(Name("BatchKvVariableGatherOrZerosV2").Device(DEVICE_CPU).TypeConstraint<int32>("Tindices"), KvBatchGatherHipOp);
+REGISTER_KERNEL_BUILDER(Name("BatchKvVariableGatherOrZerosV2").Device(DEVICE_CPU).TypeConstraint<int64_t>("Tindices"), KvBatchGatherHipOp);
+REGISTER_KERNEL_BUILDER(Name("BatchKvVariableGatherOrZerosV2").Device(DEVICE_CPU).TypeConstraint<uint64>("Tindices"), KvBatchGatherHipOp);
 
 // ---- KvVariableExport / KvVariableFullOrDeltaExport : ops :421-447, 633-665, kernels/kv_variable_ops.cc:990-1017,
 //      1064-1095 -> ExportValues / DeltaExport (dynamic_save.hpp:47-195, 198-451).  Outputs: keys, values, init_table,
@@ -1142,17 +1157,19 @@ class KvExportHipOp : public OpKernel {
     Tensor *keys = nullptr, *values = nullptr, *init = nullptr, *black = nullptr, *fk = nullptr, *fv = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({counts[0]}), &keys));
     OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({counts[0], r->dim()}), &values));
-    OP_REQUIRES_OK(ctx, ctx->allocate_output(2, TensorShape({r->init_rows, r->dim()}), &init));
+    // the init table travels only when first_n > 3 (FIRST_N_EXPORT_BLACK_LIST), else an empty [0, dim] one (dynamic_save.hpp:104-115)
+    const int64_t init_out_rows = first_n_ > 3 ? r->init_rows : 0;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(2, TensorShape({init_out_rows, r->dim()}), &init));
     OP_REQUIRES_OK(ctx, ctx->allocate_output(3, TensorShape({counts[1]}), &black));
     OP_REQUIRES_OK(ctx, ctx->allocate_output(4, TensorShape({counts[2]}), &fk));
     OP_REQUIRES_OK(ctx, ctx->allocate_output(5, TensorShape({counts[2]}), &fv));
     Tensor *need = nullptr, *del = nullptr;
     if (FULL_OR_DELTA) {
-      OP_REQUIRES_OK(ctx, ctx->allocate_output(6, TensorShape({}), &need));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(6, TensorShape({1}), &need));   // shape {1}, dynamic_save.hpp:35-38
       OP_REQUIRES_OK(ctx, ctx->allocate_output(7, TensorShape({counts[3]}), &del));
-      need->scalar<bool>()() = full;
+      need->flat<bool>()(0) = full;
     }
-    if (r->init_rows) std::memcpy(init->data(), r->init_host.data(), r->init_host.size() * sizeof(float));
+    if (init_out_rows) std::memcpy(init->data(), r->init_host.data(), r->init_host.size() * sizeof(float));
     StagingRing::Slot *sk = nullptr, *sv = nullptr, *sb = nullptr, *sfk = nullptr, *sfv = nullptr, *sd = nullptr;
     auto want = [&](int64_t m, size_t elem, StagingRing::Slot** sl) -> Status {
       return m > 0 ? r->ring()->Acquire((size_t)m * elem, sl) : OkStatus();
@@ -1325,5 +1342,248 @@ class KvImportHipOp : public OpKernel {
 REGISTER_KERNEL_BUILDER(Name("KvVariableImport").Device(DEVICE_CPU), KvImportHipOp<0>);
 REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImport").Device(DEVICE_CPU), KvImportHipOp<1>);
 REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImportV2").Device(DEVICE_CPU), KvImportHipOp<2>);
+
+// =====================================================================================================================
+// DEVICE_GPU kernels — TensorFlow-ROCm's device (DEVICE_GPU is the name of the ROCm device in a TF build with
+// TENSORFLOW_USE_ROCM; nothing here is a CUDA path).  A graph whose KvVariable is placed on the GPU runs the hot path
+// with NO staging: `indices`, `grad` and `output` are device tensors, their pointers go straight to the C ABI on TF's
+// own compute stream (GetGpuStream), and what bench.py measures is what the graph gets.  As in the reference, the
+// resource handle is host memory (kernels/kv_variable_ops.cc:540-546); so are the scalar hyper-parameters (`lr`,
+// `beta1_power`, ...), which the C ABI takes by value.
+//
+// The batch token.  A training lookup leaves the batch's index behind (kv_gather_or_insert_tok); the optimizer op
+// takes it over when it is handed THE TENSOR the lookup saw: same device buffer, same length.  In a TF1 graph that is
+// the case exactly when the optimizer receives the raw IndexedSlices of the lookup's gradient (_GatherGrad returns
+// `indices = reshape(ids)`: the same buffer) — INTEGRATION.md §2a has the one-line processor patch that makes it so;
+// TF-core's _deduplicate_indexed_slices produces a new tensor and takes the general path.  The ids buffer is an input
+// of the gradient op, so it is alive (its address is not reused) until the optimizer op has run; the token is
+// dropped by every other op on the table.
+//
+// Every other op of this file is registered for DEVICE_GPU with all its tensor arguments in host memory, so that a
+// GPU-placed variable finds a kernel for each of them (a resource is only visible to kernels of its own device); those
+// run the kernel bodies above unchanged — they are savers, counters and maintenance, not the hot path.
+// =====================================================================================================================
+}  // namespace tfplus_hip
+#include "tensorflow/core/util/gpu_kernel_helper.h"   // GetGpuStream: gpuStream_t is hipStream_t under TENSORFLOW_USE_ROCM
+namespace tfplus_hip {
+
+static hipStream_t TfStream(OpKernelContext* ctx) { return GetGpuStream(ctx); }
+
+template <int MODE>
+class KvGatherGpuOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    const Tensor& ids = ctx->input(1);
+    OP_REQUIRES_OK(ctx, KeyTypeMatches(r, ids));
+    TensorShape shape = ids.shape();
+    shape.AddDim(r->dim());
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, shape, &out));   // device memory
+    const int64_t n = ids.NumElements();
+    if (n == 0) return;
+    const Tensor* counts = nullptr;
+    if (MODE == 2) {
+      counts = &ctx->input(2);
+      OP_REQUIRES(ctx, counts->dtype() == DT_INT32, errors::InvalidArgument("increment count, counts dtype must be int32"));
+      OP_REQUIRES(ctx, counts->shape() == ids.shape(),
+                  errors::InvalidArgument("increment count, indices shape ", ids.shape().DebugString(),
+                                          " does not match with counts shape ", counts->shape().DebugString()));
+    }
+    std::lock_guard<std::mutex> l(*r->mu());
+    hipStream_t st = TfStream(ctx);
+    if (MODE == 0) {
+      OP_REQUIRES_OK(ctx, FromKv(kv_gather_or_zeros(r->h(), ids.data(), n, static_cast<float*>(out->data()), st)));
+      return;
+    }
+    kv_batch_token_t tok = 0;
+    OP_REQUIRES_OK(ctx, FromKv(kv_gather_or_insert_tok(r->h(), ids.data(), counts ? static_cast<const int32_t*>(counts->data()) : nullptr,
+                                                       n, static_cast<float*>(out->data()), &tok, st)));
+    r->token = tok; r->token_ids = ids.data(); r->token_n = n; r->token_sum = 0;
+  }
+};
+#define KV_REGISTER_GATHER_GPU(NAME, MODE)                                                                                \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU).HostMemory("table_handle").TypeConstraint<int32>("Tindices")      \
+                              .TypeConstraint<float>("dtype"), KvGatherGpuOp<MODE>);                                         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU).HostMemory("table_handle").TypeConstraint<int64_t>("Tindices")    \
+                              .TypeConstraint<float>("dtype"), KvGatherGpuOp<MODE>);                                         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU).HostMemory("table_handle").TypeConstraint<uint64>("Tindices")     \
+                              .TypeConstraint<float>("dtype"), KvGatherGpuOp<MODE>)
+KV_REGISTER_GATHER_GPU("KvVariableGatherOrZerosV2", 0);
+KV_REGISTER_GATHER_GPU("KvVariableGatherOrInsertV2", 1);
+KV_REGISTER_GATHER_GPU("KvVariableGatherOrInsertWithCounts", 2);
+
+// gradient + indices of an optimizer op, device-resident: shape checks, and the lookup's token when these are its ids
+static Status DeviceGradIds(KvHipResource* var, const Tensor& grad, const Tensor& ids, int64_t* n, kv_batch_token_t* token) {
+  if (!TensorShapeUtils::IsVector(ids.shape())) return errors::InvalidArgument("indices must be one-dimensional");
+  TF_RETURN_IF_ERROR(KeyTypeMatches(var, ids));
+  if (grad.dims() < 1 || grad.dim_size(0) != ids.dim_size(0))
+    return errors::InvalidArgument("grad must be the same size as indices in the first dimension.");
+  if (grad.NumElements() != ids.dim_size(0) * var->dim())
+    return errors::InvalidArgument("var and grad must match in dimension 1");
+  *n = ids.dim_size(0);
+  *token = (var->token != 0 && var->token_n == *n && var->token_ids == ids.data()) ? var->token : 0;
+  var->token = 0;   // one apply per lookup: a second optimizer op on the same ids rebuilds the index
+  return OkStatus();
+}
+
+template <int VERSION>
+class KvGroupAdamGpuOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, slot);
+    for (int i = 4; i <= 12; ++i)   // kernels/training_ops.cc:7034-7068
+      OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(i).shape()),
+                  errors::InvalidArgument("input ", i, " is not a scalar: ", ctx->input(i).shape().DebugString()));
+    auto f = [&](int i) { return ctx->input(i).scalar<float>()(); };   // host memory (registration below)
+    std::lock_guard<std::mutex> l(*var->mu());
+    int64_t n = 0;
+    kv_batch_token_t token = 0;
+    OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(2), ctx->input(3), &n, &token));
+    if (n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), static_cast<const float*>(ctx->input(2).data()),
+                                                       ctx->input(3).data(), n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11),
+                                                       f(12), VERSION, token, TfStream(ctx))));
+  }
+};
+#define KV_GPU_ADAM_HOST .HostMemory("var").HostMemory("m_v_linear").HostMemory("lr").HostMemory("beta1_power")           \
+      .HostMemory("beta2_power").HostMemory("beat1").HostMemory("beta2").HostMemory("epsilon").HostMemory("l1")          \
+      .HostMemory("l2").HostMemory("l21")
+#define KV_REGISTER_APPLY_GPU(NAME, HOSTMEM, CLASS)                                                                         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<float>("T").TypeConstraint<int32>("Tindices"), CLASS);   \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<float>("T").TypeConstraint<int64_t>("Tindices"), CLASS); \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<float>("T").TypeConstraint<uint64>("Tindices"), CLASS)
+KV_REGISTER_APPLY_GPU("KvVariableGroupSparseApplyAdamV3", KV_GPU_ADAM_HOST, KvGroupAdamGpuOp<3>);
+KV_REGISTER_APPLY_GPU("KvVariableGroupSparseApplyAdamV4", KV_GPU_ADAM_HOST, KvGroupAdamGpuOp<4>);
+
+class KvAdagradGpuOp : public OpKernel {
+ public:
+  explicit KvAdagradGpuOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("update_slots", &update_slots_)); }
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, acc);
+    OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(2).shape()),
+                errors::InvalidArgument("lr is not a scalar: ", ctx->input(2).shape().DebugString()));
+    std::lock_guard<std::mutex> l(*var->mu());
+    int64_t n = 0;
+    kv_batch_token_t token = 0;
+    OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(3), ctx->input(4), &n, &token));
+    if (n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                    static_cast<const float*>(ctx->input(3).data()), ctx->input(4).data(), n,
+                                                    update_slots_ ? 1 : 0, token, TfStream(ctx))));
+  }
+
+ private:
+  bool update_slots_ = true;
+};
+#define KV_GPU_ADAGRAD_HOST .HostMemory("var").HostMemory("accum").HostMemory("lr")
+KV_REGISTER_APPLY_GPU("KvVariableSparseApplyAdagrad", KV_GPU_ADAGRAD_HOST, KvAdagradGpuOp);
+
+class KvGroupFtrlGpuOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, var);
+    KV_RESOURCE(ctx, 1, acc);
+    KV_RESOURCE(ctx, 2, lin);
+    for (int i = 5; i <= 10; ++i)
+      OP_REQUIRES(ctx, TensorShapeUtils::IsScalar(ctx->input(i).shape()),
+                  errors::InvalidArgument("input ", i, " is not a scalar: ", ctx->input(i).shape().DebugString()));
+    auto f = [&](int i) { return ctx->input(i).scalar<float>()(); };
+    std::lock_guard<std::mutex> l(*var->mu());
+    int64_t n = 0;
+    kv_batch_token_t token = 0;
+    OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(3), ctx->input(4), &n, &token));
+    if (n == 0) return;
+    OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), static_cast<const float*>(ctx->input(3).data()),
+                                                              ctx->input(4).data(), n, f(5), f(6), f(7), f(8), f(9), f(10), token,
+                                                              TfStream(ctx))));
+  }
+};
+#define KV_GPU_FTRL_HOST .HostMemory("var").HostMemory("accum").HostMemory("linear").HostMemory("lr").HostMemory("l1")    \
+      .HostMemory("l2").HostMemory("l21").HostMemory("l2_shrinkage").HostMemory("lr_power")
+KV_REGISTER_APPLY_GPU("KvVariableSparseGroupSparseApplyFtrlV2", KV_GPU_FTRL_HOST, KvGroupFtrlGpuOp);
+
+// ---- create / init on the GPU device: the resource lives in the GPU device's resource manager ------------------------
+REGISTER_KERNEL_BUILDER(Name("KvVariable").Device(DEVICE_GPU).HostMemory("table_handle"), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV2").Device(DEVICE_GPU).HostMemory("table_handle"), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV3").Device(DEVICE_GPU).HostMemory("table_handle"), CreateKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableV4").Device(DEVICE_GPU).HostMemory("table_handle"), CreateKvVariableHipOp);
+
+class InitKvVariableGpuOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    KV_RESOURCE(ctx, 0, r);
+    const Tensor& t = ctx->input(1);   // device memory: the initializer ran on the GPU
+    OP_REQUIRES(ctx, t.dtype() == DT_FLOAT, errors::InvalidArgument("random_initializer must be float"));
+    OP_REQUIRES(ctx, t.dims() == 2 && t.dim_size(1) == r->dim(),
+                errors::InvalidArgument("random_initializer must be [rows, ", r->dim(), "]"));
+    std::lock_guard<std::mutex> l(*r->mu());
+    hipStream_t st = TfStream(ctx);
+    OP_REQUIRES_OK(ctx, FromKv(kv_init_table(r->h(), static_cast<const float*>(t.data()), t.dim_size(0), st)));
+    if (r->init_rows == 0) {   // the host copy KvVariableExport hands out (once per variable: the one synchronisation here)
+      r->init_host.resize(static_cast<size_t>(t.NumElements()));
+      HIP_OK(ctx, hipMemcpyAsync(r->init_host.data(), t.data(), t.TotalBytes(), hipMemcpyDeviceToHost, st));
+      HIP_OK(ctx, hipStreamSynchronize(st));
+      r->init_rows = t.dim_size(0);
+    }
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("InitKvVariableV2").Device(DEVICE_GPU).HostMemory("table_handle"), InitKvVariableGpuOp);
+
+// ---- everything else: the kernels above, every tensor argument in host memory ----------------------------------------
+#define KV_GPU_IDX3(NAME, HOSTMEM, ...)                                                                                \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<int32>("Tindices"), __VA_ARGS__);         \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<int64_t>("Tindices"), __VA_ARGS__);       \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) HOSTMEM.TypeConstraint<uint64>("Tindices"), __VA_ARGS__)
+#define KV_H1(a) .HostMemory(a)
+#define KV_H2(a, b) .HostMemory(a).HostMemory(b)
+#define KV_H3(a, b, c) .HostMemory(a).HostMemory(b).HostMemory(c)
+REGISTER_KERNEL_BUILDER(Name("KvVariableShapeV2").Device(DEVICE_GPU) KV_H2("table_handle", "output").TypeConstraint<int32>("out_type"), KvShapeHipOp<int32>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableShapeV2").Device(DEVICE_GPU) KV_H2("table_handle", "output").TypeConstraint<int64_t>("out_type"), KvShapeHipOp<int64_t>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableIsInitializedV2").Device(DEVICE_GPU) KV_H2("table_handle", "is_initialized"), KvIsInitializedHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_GPU) KV_H2("table_handle", "size").TypeConstraint<int32>("T"), KvSizeHipOp<int32, false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV2").Device(DEVICE_GPU) KV_H2("table_handle", "size").TypeConstraint<int64_t>("T"), KvSizeHipOp<int64_t, false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_GPU) KV_H2("table_handle", "size").TypeConstraint<int32>("T"), KvSizeHipOp<int32, true>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFrequency").Device(DEVICE_GPU) KV_H2("table_handle", "size").TypeConstraint<int64_t>("T"), KvSizeHipOp<int64_t, true>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableSizeV3").Device(DEVICE_GPU) KV_H2("table_handle", "sizes"), KvSizeV3HipOp);
+REGISTER_KERNEL_BUILDER(Name("ReadKvVariableOpV2").Device(DEVICE_GPU) KV_H3("table_handle", "keys", "values"), ReadKvVariableHipOp);
+REGISTER_KERNEL_BUILDER(Name("DestroyKvVariableOpV2").Device(DEVICE_GPU) KV_H1("table_handle"), DestroyKvVariableHipOp);
+#define KV_REGISTER_SCATTER_GPU(NAME, VALS, OP)                                                                           \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) KV_H3("table_handle", "indices", VALS).TypeConstraint<int32>("Tindices")    \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>);                                       \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) KV_H3("table_handle", "indices", VALS).TypeConstraint<int64_t>("Tindices")  \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>);                                       \
+  REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_GPU) KV_H3("table_handle", "indices", VALS).TypeConstraint<uint64>("Tindices")   \
+                              .TypeConstraint<float>("dtype"), KvScatterHipOp<OP>)
+KV_REGISTER_SCATTER_GPU("KvVariableInsertV2", "values", -1);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterAddV2", "updates", KV_SCATTER_ADD);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterSubV2", "updates", KV_SCATTER_SUB);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterMulV2", "updates", KV_SCATTER_MUL);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterDivV2", "updates", KV_SCATTER_DIV);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterMinV2", "updates", KV_SCATTER_MIN);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterMaxV2", "updates", KV_SCATTER_MAX);
+KV_REGISTER_SCATTER_GPU("KvVariableScatterUpdateV2", "updates", KV_SCATTER_ASSIGN);
+KV_GPU_IDX3("KvVariableGetCountV2", KV_H3("table_handle", "indices", "output"), KvCountHipOp<false>);
+KV_GPU_IDX3("KvVariableGetTimeStamp", KV_H3("table_handle", "indices", "output"), KvCountHipOp<true>);
+KV_GPU_IDX3("KvVariableIncreaseCountV2", KV_H3("table_handle", "indices", "counts"), KvIncreaseCountHipOp);
+KV_GPU_IDX3("KvVariableDelete", KV_H2("table_handle", "indices"), KvDeleteHipOp);
+REGISTER_KERNEL_BUILDER(Name("KvVariableDeleteWithTimestamp").Device(DEVICE_GPU) KV_H2("table_handle", "delete_keys"), KvDeleteWithTimestampHipOp);
+KV_GPU_IDX3("BatchKvVariableGatherOrZerosV2", KV_H3("table_handles", "indices", "output"), KvBatchGatherHipOp);
+#define KV_H_EXPORT .HostMemory("table_handle").HostMemory("keys").HostMemory("values").HostMemory("init_table")         \
+      .HostMemory("blacklist").HostMemory("freq_keys").HostMemory("freq_values")
+REGISTER_KERNEL_BUILDER(Name("KvVariableExport").Device(DEVICE_GPU) KV_H_EXPORT, KvExportHipOp<false>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaExport").Device(DEVICE_GPU) KV_H_EXPORT.HostMemory("do_full_export")
+                            .HostMemory("need_full_import").HostMemory("delete_keys"), KvExportHipOp<true>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableImport").Device(DEVICE_GPU) KV_H_EXPORT, KvImportHipOp<0>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImport").Device(DEVICE_GPU) KV_H_EXPORT.HostMemory("need_full_import")
+                            .HostMemory("delete_keys"), KvImportHipOp<1>);
+REGISTER_KERNEL_BUILDER(Name("KvVariableFullOrDeltaImportV2").Device(DEVICE_GPU) KV_H_EXPORT.HostMemory("need_full_import")
+                            .HostMemory("delete_keys").HostMemory("is_loading_finished"), KvImportHipOp<2>);
 
 }  // namespace tfplus_hip

@@ -44,7 +44,7 @@ pt = pt[pt[:, 0] > pt[:, 0].max() - 30000]   # the last launch only (earlier bat
 if len(pt):
   b0 = pt[:, 0].min()
   print("k_papply: %d blocks" % len(pt))
-  for nm, i, j in (("directory + pass 1 (entries -> LDS hash)", 0, 1), ("scans + source list", 1, 2), ("apply phase", 2, 3)):
+  for nm, i, j in (("directory", 0, 5), ("pass 1 (entries -> LDS hash)", 5, 1), ("scans + source list", 1, 2), ("apply phase", 2, 3)):
     print("   %-48s %s" % (nm, med(pt[:, j] - pt[:, i])))
   print("   block total %s ; start %s ; last end %d" % (med(pt[:, 3] - pt[:, 0]), med(pt[:, 0] - b0), (pt[:, 3] - b0).max()))
   E_, nu_, nh_ = pt[:, 6], pt[:, 7], pt[:, 8]
@@ -59,3 +59,8 @@ if len(wv):
   print("   per wave (%d): apply span %s" % (len(wv), med(wv[:, 1] - wv[:, 0])))
   print("   hot items per wave %s ; time per hot item %s" % (med(wv[:, 4]), med(wv[:, 2][wv[:, 4] > 0] / wv[:, 4][wv[:, 4] > 0])))
   print("   cold batches per wave %s ; time per batch %s" % (med(wv[:, 5]), med(wv[:, 3][wv[:, 5] > 0] / wv[:, 5][wv[:, 5] > 0])))
+
+tt = a[2048:2048 + 1024].astype(np.int64); tt = tt[tt[:, 1] > 0]
+if len(tt):
+  tt = tt[tt[:, 0] > tt[:, 0].max() - 30000]
+  print("k_tsum: %d blocks, block time %s, last end %d" % (len(tt), med(tt[:, 1] - tt[:, 0]), (tt[:, 1] - tt[:, 0].min()).max()))
