@@ -125,7 +125,8 @@ inline int launch_ltsum_t(const TableDev& td, const WsDev& wd, const IdT* ids, l
   const size_t sh = ltile_smem_bytes();
 #define KV_LTSUM(V, LPR, K)                                                                              \
   do {                                                                                                   \
-    k_ltsum<IdT, V, LPR, K><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);          \
+    if (wd.bcap != 0u) k_ltsum<IdT, V, LPR, K, true><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);   \
+    else k_ltsum<IdT, V, LPR, K><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);     \
     return KV_OK;                                                                                        \
   } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;

@@ -36,6 +36,8 @@ constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every 
                                  // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int MAX_P = 2048;      // partitions (power of two); 1024 up to 1 M ids, 2048 for 2 M
+constexpr int BCNT_STRIDE = 16;     // words between two bucket cursors (bucket mode, WsDev::bcnt)
+constexpr int NXCD = 8;             // a partition's bucket is NXCD sub-buckets, one per XCD (see WsDev::bcnt)
 constexpr int MAX_CHUNKS = 32768;   // 2^16-row chunks (no capacity hint) still reach the 2^31-row limit
 
 // index-pass modes (k_part_keys) and fold modes (k_apply_sorted)
@@ -129,6 +131,16 @@ struct WsDev {
   unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
   unsigned hc;             // entries per hot chunk
+  // ---- bucket mode (kv_fused.h ltile_body<BUCKET>, kv_papply.h): the tiles append their entries to per-partition buckets
+  uint4* bkt;              // [P][NXCD][bcap] BktRec (two uint4 each): partition p's entries, by the XCD of the tile that
+                           // appended them, in arrival order
+  unsigned* bcnt;          // [MAX_P * NXCD * BCNT_STRIDE] this batch's sub-bucket cursors (= entry counts once the tile pass is
+                           // done).  A cursor is only ever touched by tiles running on ITS XCD, with an atomic that is
+                           // performed in that XCD's L2 (workgroup scope): device-scope atomics are performed at the memory
+                           // side, and 354 k of them per launch cost the tile pass 15 us (70 us against 55 us; with 32
+                           // cursors per cache line 138 us).  Kernel boundaries make the counts visible to the partition pass.
+  unsigned* bcnt_other;    // the other parity's cursors: the tile pass clears them for the next batch
+  unsigned bcap;           // records per SUB-bucket; 0 = the index is partition-sorted per tile (toff), not bucketed
   unsigned nib;            // k_tsum: directory blocks in front of the tile blocks (a single table's launch; 16 .. 128 by batch size)
 };
 

@@ -103,8 +103,13 @@ struct LtSmem {
   unsigned short* lrun;    // [TILE + 1] deterministic mode: running count per entry
   unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); then the entries' frequency sums
   unsigned* wtot;          // [8]
+  // bucket mode (no partition sort, see ltile_body): per hash slot instead of per entry
+  unsigned* lpre;          //   [LS + 1] packed prefix of the slot's key (in lkeys' storage, behind lrow — where escan lives otherwise)
+  unsigned* lfq;           //   [LS + 1] frequency sum of the slot's key (lookups with counts; in lpos / lrun / hist's storage)
 };
 static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)(TILE + 1) * 4, "aliases fit");
+static_assert((((size_t)(LS + 1) * 2 + 15) & ~(size_t)15) + (((size_t)(TILE + 1) * 2 + 15) & ~(size_t)15) + (size_t)(MAX_P + 1) * 4 >=
+              (size_t)(LS + 1) * 4, "lfq fits lpos + lrun + hist");
 
 __host__ __device__ inline size_t ltile_smem_bytes() {
   size_t b = (size_t)(LS + 1) * 8 + 16;   // lkeys
@@ -119,13 +124,15 @@ __host__ __device__ inline size_t ltile_smem_bytes() {
 __device__ __forceinline__ LtSmem carve_ltile(char* base) {
   LtSmem s;
   auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
-  char* k0 = take((size_t)(LS + 1) * 8);
+  char* k0 = take((size_t)(LS + 1) * 8 + 16);
   s.lkeys = reinterpret_cast<long long*>(k0);
   s.lrow = reinterpret_cast<unsigned*>(k0);
   s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
+  s.lpre = s.escan;
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
-  s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
   s.mr = reinterpret_cast<unsigned*>(take((size_t)TILE * 4));
+  s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
+  s.lfq = reinterpret_cast<unsigned*>(s.lpos);
   s.lrun = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
   s.wtot = reinterpret_cast<unsigned*>(take(64));
@@ -136,8 +143,26 @@ __device__ __forceinline__ LtSmem carve_ltile(char* base) {
 // their number (bits 12..22)
 constexpr unsigned ES_POS = 0xFFFu, ES_NSH = 12;
 
+// One entry of a partition's BUCKET (bucket mode): what k_papply needs of a tile's distinct key, in one 32-byte record
+struct __attribute__((aligned(16))) BktRec {
+  long long key;
+  unsigned ea;     // occurrences in the tile (low 16) | saturating frequency count (high 16)
+  unsigned rw;     // row word (NEW_BIT: inserted by this batch)
+  unsigned hint;   // slot-row hint
+  unsigned src;    // the entry's source: its input position, or EP_TAG | its row of epart
+  unsigned pad[2];
+};
+static_assert(sizeof(BktRec) == 32, "BktRec layout");
+
 // VQ = float4 per row (power of two <= 64); GATHER: copy the rows of the tile's positions to `out`.
-template <typename IdT, int VQ, bool GATHER>
+// BUCKET: no counting sort by partition.  The tile appends each distinct key's record to its partition's bucket in
+// global memory (one returning atomic per entry on the bucket's cursor, in flight together with the index probe), so
+// the partition pass reads its entries as ONE contiguous stream — no toff directory, no per-tile segments, no binary
+// search — and the tile pass loses its partition histogram, the scan over it and the toff row.  The tile-local
+// numbering that mrow / epart need (the entries with more than one occurrence) comes from one block scan over the
+// winners in thread order.  Not for the deterministic mode (the order of a bucket is arrival order), nor the
+// (id, count) pair input of the sharded serve.
+template <typename IdT, int VQ, bool GATHER, bool BUCKET = false>
 __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, const IdT* __restrict__ ids,
                                            const int* __restrict__ counts, long long n, int det,
                                            float* __restrict__ out) {
@@ -182,7 +207,15 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     }
   }
   for (int s = tid; s <= LS; s += TBT) { sm.lkeys[s] = EMPTY_KEY; sm.lcnt[s] = 0; }
-  for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
+  if constexpr (BUCKET) {
+    if (has_counts) for (int s = tid; s <= LS; s += TBT) sm.lfq[s] = 0;
+    // the bucket cursors of the NEXT batch (the other parity: nobody touches them during this launch)
+    { const unsigned pz = tile * TBT + tid; if (pz < (unsigned)(MAX_P * NXCD)) w.bcnt_other[(size_t)pz * BCNT_STRIDE] = 0; }
+    if (w.ntiles * TBT < (unsigned)(MAX_P * NXCD) && tile == 0)
+      for (unsigned pz = w.ntiles * TBT + tid; pz < (unsigned)(MAX_P * NXCD); pz += TBT) w.bcnt_other[(size_t)pz * BCNT_STRIDE] = 0;
+  } else {
+    for (unsigned p = tid; p <= P; p += TBT) sm.hist[p] = 0;
+  }
   if (tid == 0) lsent = 0;
   if (tile == 0 && tid == 0 && t.err_host)   // the distinct keys the previous index pass counted: a hint for the host (partitions)
     __hip_atomic_store(t.err_host + 1, w.ctr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -228,6 +261,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
         }
       }
       myrank[k] = atomicAdd(&sm.lcnt[h], 1u);
+      if constexpr (BUCKET) { if (has_counts) atomicAdd(&sm.lfq[h], creg[k]); }
       tslot[k] = h;
     }
   }
@@ -244,6 +278,72 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   lds_barrier();   // lcnt is final; lkeys is dead: its storage is lrow / escan from here on
   KV_STAMP(1);
 
+  if constexpr (BUCKET) {
+    // ---- phase 2 (bucket mode): every winner reserves its place in its partition's bucket (the atomic travels beside
+    //      the probe); one block scan numbers the entries that have more than one occurrence ---------------------------
+    unsigned wcnt[IPT], wp[IPT], gpos[IPT], pre[IPT];
+    unsigned packed = 0;
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(63508) & (unsigned)(NXCD - 1);   // XCC_ID: the XCD this block runs on
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      wcnt[k] = 0; wp[k] = 0; gpos[k] = 0; pre[k] = 0;
+      if ((win >> k) & 1u) {
+        wcnt[k] = sm.lcnt[tslot[k]];
+        wp[k] = part_of(kreg[k], w.pshift);
+        wp[k] = wp[k] * (unsigned)NXCD + xcc;   // the sub-bucket
+        gpos[k] = __hip_atomic_fetch_add(&w.bcnt[(size_t)wp[k] * BCNT_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wcnt[k] > 1u) packed += wcnt[k] | (1u << ES_NSH);
+      }
+    }
+    {
+      unsigned tot;
+      unsigned run = block_excl_scan<TBT / 64, true>(packed, sm.wtot, &tot);
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        pre[k] = run;
+        if (((win >> k) & 1u) && wcnt[k] > 1u) run += wcnt[k] | (1u << ES_NSH);
+      }
+      if (tid == 0) w.mcount[tile] = (tot & ES_POS) | ((tot >> ES_NSH) << 16);
+    }
+    KV_STAMP(2);
+    // ---- the probes come back: row word + slot-row hint of every distinct key; absent keys are inserted; the entry's
+    //      record goes to its bucket in one piece ---------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      if (!((win >> k) & 1u)) continue;
+      unsigned hint = 0;
+      unsigned r = table_find_from(t, kreg[k], pp[k], en[k], &hint);
+      if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, kreg[k]); hint = 0; }
+      else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
+      sm.lrow[tslot[k]] = r;
+      sm.lpre[tslot[k]] = pre[k];
+      unsigned f = wcnt[k];
+      if (has_counts) { f = sm.lfq[tslot[k]]; f = f > 65535u ? 65535u : f; }
+      const unsigned src = wcnt[k] > 1u ? (EP_TAG | (tile * (unsigned)(TILE / 2) + (pre[k] >> ES_NSH)))
+                                        : (unsigned)base + (unsigned)(k * TBT + tid);
+      if (__builtin_expect(gpos[k] < w.bcap, 1)) {
+        uint4* rec = w.bkt + 2 * ((size_t)wp[k] * w.bcap + gpos[k]);   // BktRec
+        rec[0] = make_uint4((unsigned)kreg[k], (unsigned)((unsigned long long)kreg[k] >> 32), wcnt[k] | (f << 16), r);
+        rec[1] = make_uint4(hint, src, 0u, 0u);
+      } else {
+        raise_error(t, 2u);   // a bucket is full (see bucket_capacity in kvhip.hip): the batch is void, the next call reports it
+      }
+    }
+    lds_barrier();
+    KV_STAMP(3);
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      if (tslot[k] == 0xFFFFFFFFu || sm.lcnt[tslot[k]] <= 1u) continue;
+      const unsigned pr = sm.lpre[tslot[k]];
+      sm.mr[(pr & ES_POS) + myrank[k]] = (unsigned)(k * TBT + tid) | ((pr >> ES_NSH) << 11) | (myrank[k] == 0u ? 0x80000000u : 0u);
+    }
+    lds_barrier();
+    {
+      unsigned* dst = w.mrow + (size_t)tile * TILE;
+      for (int j = tid; j < TILE; j += TBT) dst[j] = sm.mr[j];
+    }
+    KV_STAMP(4);
+  } else {
   // ---- phase 2: the distinct keys counting-sorted by owning partition ----------------------------------------------
   unsigned wcnt[IPT], wp[IPT], wr[IPT];
 #pragma unroll
@@ -405,6 +505,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   KV_STAMP(4);
 
+  }
   // ---- phase 4: the output rows.  Wave wv, round k holds positions k * TBT + wv * 64 + lane in its own registers ---
   if constexpr (GATHER) {
     constexpr int RW = 64 / VQ;            // rows per copy instruction
@@ -487,10 +588,10 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   KV_STAMP(5);
 }
 
-template <typename IdT, int VQ, bool GATHER>
+template <typename IdT, int VQ, bool GATHER, bool BUCKET = false>
 __global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* __restrict__ ids,
                                               const int* __restrict__ counts, long long n, int det, float* __restrict__ out) {
-  ltile_body<IdT, VQ, GATHER>(t, w, ids, counts, n, det, out);
+  ltile_body<IdT, VQ, GATHER, BUCKET>(t, w, ids, counts, n, det, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1603,10 +1704,10 @@ __global__ void __launch_bounds__(TB) k_lrows(TableDev t, const IdT* __restrict_
 // meets the ids first): the block that de-duplicated a tile goes on to sum the rows of its repeated ids (tsum_body, fed
 // from the mrow image still in LDS).  The dedup chain of one block — LDS phases, one probe round trip — overlaps with
 // the row reads of the others; k_ltile<GATHER = false> + k_tsum one after the other were 23.5 + 24 us at configs[1].
-template <typename IdT, int V, int LPR, int K>
+template <typename IdT, int V, int LPR, int K, bool BUCKET = false>
 __global__ void __launch_bounds__(TBT) k_ltsum(TableDev t, WsDev w, const IdT* __restrict__ ids, const int* __restrict__ counts,
                                               long long n, int det, const float* __restrict__ grad) {
-  ltile_body<IdT, 1, false>(t, w, ids, counts, n, det, nullptr);
+  ltile_body<IdT, 1, false, BUCKET>(t, w, ids, counts, n, det, nullptr);
   __syncthreads();   // the tile's mrow image and mcount are written (and every phase of the tile pass is behind us)
   if (*reinterpret_cast<volatile unsigned*>(&t.counters[1])) return;   // the tile pass gave up on this batch
   extern __shared__ __attribute__((aligned(16))) char lt_smem_raw[];

@@ -24,6 +24,7 @@
 #pragma once
 
 enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2 };
+constexpr int PA_NOAPPLY = 0x100;   // flag: no update — the partition pass of a lookup that no apply followed (what k_part2<LOOKUP> does)
 #ifndef KV_PA_WAVES
 #define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
 #endif
@@ -37,8 +38,9 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 #ifdef KV_PA_X_MODE
   constexpr int mode = KV_PA_X_MODE;
 #else
-  const int mode = mode_;
+  const int mode = mode_ & 0xFF;
 #endif
+  const bool no_apply = (mode_ & PA_NOAPPLY) != 0;   // the lookup's bookkeeping alone (no gradient is given)
   constexpr int HSK = 1024;
   constexpr int UCAPK = HSK - TBK;
   constexpr int EB = 8;
@@ -68,8 +70,30 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   const int D = a.tv.dim;
   const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);   // the tile pass gave up: bookkeeping only
   KV_STAMPP(0);
-  unsigned pbase;
-  const unsigned E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
+  // bucket mode: the tiles appended the partition's entries to ONE contiguous bucket (kv_fused.h BktRec) — no directory
+  const bool bucket = w.bcap != 0u;
+  __shared__ unsigned bpre[NXCD + 1];   // entries in the sub-buckets before sub-bucket j
+  unsigned pbase = 0;
+  unsigned E;
+  if (bucket) {
+    if (tid == 0) {
+      unsigned run = 0;
+#pragma unroll
+      for (int j = 0; j < NXCD; ++j) { bpre[j] = run; run += min(w.bcnt[((size_t)p * NXCD + j) * BCNT_STRIDE], w.bcap); }
+      bpre[NXCD] = run;
+    }
+    __syncthreads();
+    E = bpre[NXCD];
+  } else {
+    E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
+  }
+  // record x of the partition (bucket mode): sub-bucket j = the last one with bpre[j] <= x
+  auto brec_of = [&](unsigned x) -> const uint4* {
+    unsigned j = 0;
+#pragma unroll
+    for (int q = 1; q < NXCD; ++q) j += bpre[q] <= x ? 1u : 0u;
+    return w.bkt + 2 * (((size_t)p * NXCD + j) * w.bcap + (x - bpre[j]));
+  };
   KV_STAMPP(5);
   if (E == 0) return;
   if (tid == 0) { sp = 0; lkeys = 0; }
@@ -78,11 +102,9 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (tid == 0) raise_error(a.tv, 2u);
     return;
   }
-#ifdef KV_PA_X_LDSONLY
-  constexpr bool in_lds = true;
-#else
-  const bool in_lds = E <= (unsigned)PA_LSRC;
-#endif
+  // the round's sources live in LDS; a partition-sorted index files a larger partition in its stretch of w.order, a
+  // bucketed one splits the round until it fits (below)
+  const bool in_lds = bucket || E <= (unsigned)PA_LSRC;
   unsigned* const gsrc = w.order + pbase;   // (the partitions' stretches of w.order are disjoint)
   auto src_at = [&](unsigned i) -> unsigned {
     // a stretch filed in global memory was written by other waves of this block: read past the CU's vector cache
@@ -106,17 +128,32 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       unsigned ge[EB];
       long long key[EB];
       unsigned ea[EB], rw[EB], hi[EB], sr[EB];
+      if (bucket) {
 #pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        const unsigned x = x0 + k * TBK + tid;
-        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
-      }
+        for (int k = 0; k < EB; ++k) {
+          const unsigned x = x0 + k * TBK + tid;
+          ge[k] = x < E ? x : 0xFFFFFFFFu;
+          key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
+          if (x < E) {
+            const uint4* rp = brec_of(x);
+            const uint4 ra_ = rp[0], rb_ = rp[1];
+            key[k] = (long long)(((unsigned long long)ra_.y << 32) | ra_.x);
+            ea[k] = ra_.z; rw[k] = ra_.w; hi[k] = rb_.x; sr[k] = rb_.y;
+          }
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
-        if (ge[k] != 0xFFFFFFFFu) {
-          key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]];
-          if (cached) sr[k] = w.ent_rec[ge[k]];
+        for (int k = 0; k < EB; ++k) {
+          const unsigned x = x0 + k * TBK + tid;
+          ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
+          if (ge[k] != 0xFFFFFFFFu) {
+            key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]];
+            if (cached) sr[k] = w.ent_rec[ge[k]];
+          }
         }
       }
 #pragma unroll
@@ -138,7 +175,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       }
     }
     __syncthreads();
-    if (lnu >= (unsigned)UCAPK) return true;   // more distinct keys than the hash holds
+    if (lnu >= (unsigned)UCAPK) return true;   // more distinct keys than the hash holds: the caller splits the round
     KV_STAMPP(1);
     const unsigned nu = lnu;
     if (tid == 0) lkeys += nu;
@@ -166,6 +203,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       unsigned chrun = block_excl_scan<NW>(ch, wtot, &chtot);
       unsigned hrn = block_excl_scan<NW>(hh, wtot, &htot);
       const unsigned t1 = chtot & 1023u, t2 = (chtot >> 10) & 1023u;
+      if (bucket && tot > (unsigned)PA_LSRC) return true;   // (block-uniform) the round's sources do not fit LDS: split it
       nhot = htot; ncold = nu - htot;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
@@ -220,12 +258,22 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           if (cin[k]) file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
       } else {
         for (unsigned x = tid; x < E; x += TBK) {
-          const size_t ge = seg_entry(tpre, tstart, NT, x);
-          const long long key = w.ent_key[ge];
+          long long key;
+          unsigned src;
+          if (bucket) {
+            const uint4* rp = brec_of(x);
+            const uint4 ra_ = rp[0];
+            key = (long long)(((unsigned long long)ra_.y << 32) | ra_.x);
+            src = rp[1].y;
+          } else {
+            const size_t ge = seg_entry(tpre, tstart, NT, x);
+            key = w.ent_key[ge];
+            src = w.ent_rec[ge];
+          }
           if (!in_round(key, R, round)) continue;
           bool first;
           const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
-          file(atomicAdd(&hocc[h], 1u), w.ent_rec[ge]);
+          file(atomicAdd(&hocc[h], 1u), src);
         }
       }
     }
@@ -353,7 +401,9 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           }
         }
       };
-      if (is_hot) {
+      if (no_apply) {
+        prefetch();
+      } else if (is_hot) {
         // ---- hot key: its sources, G * RB per step, summed by the whole wave ------------------------------------------
         const unsigned lo = st, hi = st + cnt;
         constexpr int SR = G * RB;
@@ -498,7 +548,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       }
 
       // ---- the update (k_apply2's tail: one copy for both kinds of item) ------------------------------------------------
-      const bool fin_live = live && errflag == 0u;
+      const bool fin_live = live && errflag == 0u && !no_apply;
       const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), row | (vnew ? NEW_BIT : 0u), hint);
       bool general = fin_live;
       if (fast) {

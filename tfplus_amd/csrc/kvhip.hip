@@ -336,6 +336,9 @@ struct Workspace {
   unsigned* ctr = nullptr;
   unsigned* mcount = nullptr;  // entry-list pipeline: [cap_n / TILE]
   long long* ids_copy = nullptr;   // [cap_n] the ids of a lookup whose tile pass is deferred (k_lrows copies them)
+  uint4* bkt = nullptr;            // bucket mode: [P][bcap] BktRec (2 uint4 each)
+  size_t bkt_records = 0;
+  unsigned* bcnt = nullptr;        // [2][MAX_P] bucket cursors, one set per batch parity
   float* epart = nullptr;      // [cap_n / 2][dim] tile sums
   long long epart_elems = 0;
   long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
@@ -401,6 +404,8 @@ struct kv_table {
   // runs it in front of its own kernels, any other op on the table runs it first thing (settle).  Same stream order
   // as before, the rows just do not wait for it.
   bool part_pending = false;
+  unsigned index_bcap = 0;         // != 0: the index the workspace holds is BUCKETED (kv_fused.h): records per bucket ...
+  unsigned bkt_parity = 0;         // ... and which set of cursors it counted in (the tile pass of the next batch takes the other)
   bool tile_pending = false;       // ... and so is its tile pass (k_lrows wrote the rows): the ids wait in ws.ids_copy
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
   hipStream_t side = nullptr;
@@ -668,6 +673,9 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   return KV_OK;
 }
 
+bool papply_enabled();
+bool fused_ok(int D);
+
 WsDev ws_view(kv_table* t, long long n) {
   Workspace& w = t->ws;
   WsDev d;
@@ -696,7 +704,56 @@ WsDev ws_view(kv_table* t, long long n) {
   d.hc = (unsigned)HC;
   // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
   d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
+  d.bkt = w.bkt;
+  d.bcap = t->index_bcap;
+  d.bcnt = w.bcnt ? w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE : nullptr;
+  d.bcnt_other = w.bcnt ? w.bcnt + (size_t)(t->bkt_parity ^ 1u) * MAX_P * NXCD * BCNT_STRIDE : nullptr;
   return d;
+}
+
+// Bucket mode of the entry-list index (kv_fused.h ltile_body<BUCKET>): the tiles append their entries to per-partition
+// buckets, so that the partition pass reads one contiguous stream instead of a segment per tile.  KV_BUCKET=1 turns it
+// on (A/B only).  Measured at configs[1]: k_papply 64.9 -> 60.8 us (no directory, no binary search, one 32-byte record
+// per entry instead of five arrays), but every entry costs the tile pass a RETURNING global atomic on its bucket's
+// cursor, and those come back after ~10 us under this load whatever their scope (k_ltile 56.4 -> 65.3 us with one cursor
+// per XCD and cache line, 70.4 us with device-scope cursors, 138 us with 32 cursors per line; the stamps put all of it
+// in the phase that waits for the cursor): a net loss of 5 us per step, so the partition-sorted tiles stay the default.
+// Not for the deterministic mode (a bucket holds its entries in arrival order), nor for batches of more tiles than a
+// partition block's source list holds (a key may have one entry per tile).
+bool bucket_enabled(const kv_table* t, long long n) {
+  static const bool on = [] { const char* e = getenv("KV_BUCKET"); return e && atoi(e) != 0; }();
+  return on && papply_enabled() && fused_ok(t->dim) && !t->deterministic && !t->overlap && (n + TILE - 1) / TILE <= PA_LSRC;
+}
+// records per sub-bucket: twice an even share of the entries (at most one per id), plus room for eight keys that occur
+// in every tile and land in the same partition (each brings ntiles / 8 entries per XCD), plus slack.  A bucket that still overflows voids the batch (the error the
+// partition pass raises when a partition holds more than 65535 entries): a hashed partition does not get there.
+unsigned bucket_capacity(long long n, unsigned P) {   // per SUB-bucket (one per XCD: the tiles go round the XCDs)
+  const long long nt = (n + TILE - 1) / TILE;
+  return (unsigned)std::min<long long>(65535, 2 * ((n + (long long)P * NXCD - 1) / ((long long)P * NXCD)) + nt + 256);
+}
+// sets wd's bucket fields for a NEW index of n ids in wd.P partitions (next parity), growing the buffers when needed
+int begin_bucket_index(kv_table* t, WsDev& wd, long long n, hipStream_t s) {
+  Workspace& w = t->ws;
+  int rc;
+  if (!w.bcnt) {
+    HIP_TRY(hipMalloc(&w.bcnt, 2 * (size_t)MAX_P * NXCD * BCNT_STRIDE * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(w.bcnt, 0, 2 * (size_t)MAX_P * NXCD * BCNT_STRIDE * sizeof(unsigned), s));
+  }
+  const unsigned cap = bucket_capacity(n, wd.P);
+  const size_t need = (size_t)wd.P * NXCD * cap;
+  if (w.bkt_records < need) {
+    HIP_TRY(hipStreamSynchronize(s));
+    w.bkt_records = 0;
+    if ((rc = regrow(&w.bkt, 2 * need))) return rc;
+    w.bkt_records = need;
+  }
+  t->bkt_parity ^= 1u;
+  t->index_bcap = cap;
+  wd.bkt = w.bkt;
+  wd.bcap = cap;
+  wd.bcnt = w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE;
+  wd.bcnt_other = w.bcnt + (size_t)(t->bkt_parity ^ 1u) * MAX_P * NXCD * BCNT_STRIDE;
+  return KV_OK;
 }
 
 // brackets one kernel launch with a pair of events when profiling is on
@@ -830,6 +887,12 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   do {                                                                                                      \
     if (md && multi_rows) k_ltile_multi<IDT, VQ, true><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md); \
     else if (md) k_ltile_multi<IDT, 1, false><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md);     \
+    else if (wd.bcap != 0u) {                                                                               \
+      if constexpr (!std::is_same<IDT, IdCount>::value) {                                                   \
+        if (out) k_ltile<IDT, VQ, true, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out); \
+        else k_ltile<IDT, 1, false, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr); \
+      }                                                                                                     \
+    }                                                                                                       \
     else if (out) k_ltile<IDT, VQ, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out); \
     else k_ltile<IDT, 1, false><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr);     \
   } while (0)
@@ -1027,6 +1090,7 @@ void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* id
                 int ids_kind, float* out, hipStream_t s, bool file_order = true) {
   t->fused_index = false;
   t->index_records = true;
+  t->index_bcap = 0;
   {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
@@ -1054,8 +1118,14 @@ int flush_part(kv_table* t, hipStream_t s) {
     launch_ltile(t, pa.tv, wd, t->ws.ids_copy, nullptr, pa.n, nullptr, s, -1);
   }
   ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-  launch_part2<MODE_LOOKUP>(wd, pa, s);
-  t->index_records = true;
+  if (wd.bcap != 0u) {   // a bucketed index: k_papply is its partition pass — here the lookup's bookkeeping alone
+    pa.day_lk = pa.day;
+    const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_LOOKUP | PA_NOAPPLY, (void*)s);
+    if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
+  } else {
+    launch_part2<MODE_LOOKUP>(wd, pa, s);
+    t->index_records = true;
+  }
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1101,7 +1171,17 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
   wd.hc = (unsigned)HC2;
   t->fused_index = true;
   t->index_records = true;
+  t->index_bcap = 0;
+  wd.bcap = 0;
   choose_partitions(t, wd, n);
+  // bucket mode: the tiles append their entries to per-partition buckets and k_papply is the only partition pass (with
+  // PA_NOAPPLY when no optimizer apply takes the batch over)
+  const bool bucket = bucket_enabled(t, n) && ids_kind != 2 && wd.seg_cap == 0 && !side_part;
+  if (bucket) {
+    const int rcb = begin_bucket_index(t, wd, n, s);
+    if (rcb) return rcb;
+    t->index_records = false;
+  }
   if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
     // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
     // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
@@ -1178,6 +1258,13 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     return KV_OK;
   }
   ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
+  if (bucket) {
+    PartArgs pb = pa;
+    pb.day_lk = pa.day;
+    const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pb, (MODE == MODE_LOOKUP ? PA_LOOKUP : PA_APPLYIDX) | PA_NOAPPLY, (void*)s);
+    if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
+    return KV_OK;
+  }
   launch_part2<MODE>(wd, pa, s);
   return KV_OK;
 }
@@ -1372,7 +1459,7 @@ int kv_destroy(kv_handle_t t) {
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
-  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy);
+  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy); hipFree(w.bkt); hipFree(w.bcnt);
   if (t->side) {
     hipStreamSynchronize(t->side);
     hipStreamDestroy(t->side);
@@ -1877,7 +1964,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
   if (fused_ok(t0->dim)) {
-    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; }
+    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
     launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     if (tokens)   // every table's workspace now holds the index of exactly its batch (kv_multi_apply_*_tok takes it over)
@@ -1889,7 +1976,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
         tokens[i] = tables[i]->batch_serial;
       }
   } else {
-    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = false; tables[i]->index_records = true; }
+    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = false; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
     launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
     launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
@@ -1981,7 +2068,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   const bool fz = fused_ok(D);
   bool skip_fin = false;
   if (fz) {
-    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = true; }
+    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = true; vars[i]->index_bcap = 0; }
     wmax.hc = (unsigned)HC2;
     skip_fin = wmax.ntiles <= wmax.hc;
     if (!reuse) {
@@ -1992,7 +2079,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     }
     if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, nmax, (void*)s, md, num_tables))) return fail(rc, "tile sums: no kernel for dim %d", D);
   } else {
-    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = false; vars[i]->index_records = true; }
+    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = false; vars[i]->index_records = true; vars[i]->index_bcap = 0; }
     launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
     launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
     launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
@@ -2139,7 +2226,10 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
       v->fused_index = true;
       v->index_records = false;
       v->side_has_items = false;
+      v->index_bcap = 0;
+      wd.bcap = 0;
       choose_partitions(v, wd, n);
+      if (bucket_enabled(v, n) && (rc = begin_bucket_index(v, wd, n, s))) return rc;
       tile_ids = ids;
       pa_mode = PA_APPLYIDX;
     } else if (fused_ok(v->dim)) {
