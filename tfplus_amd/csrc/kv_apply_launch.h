@@ -100,7 +100,7 @@ inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad,
   const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? wd.nib : wd.nib + wd.ntiles;
 #define KV_TSUM(V, LPR, K)                                                                              \
   do {                                                                                                  \
-    if (md) k_tsum_multi<V, LPR, K><<<dim3((unsigned)ITEM_BLOCKS + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md); \
+    if (md) k_tsum_multi<V, LPR, K><<<dim3((what == 1 ? 0u : (unsigned)ITEM_BLOCKS) + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md, what == 1 ? 1 : 0); \
     else k_tsum<V, LPR, K><<<grid, TBC, (size_t)TILE * 4, s>>>(td, wd, grad, what);                                    \
     return KV_OK;                                                                                       \
   } while (0)

@@ -1729,14 +1729,16 @@ __global__ void __launch_bounds__(TBK, 4) k_part2_multi(const MultiDesc* __restr
   if (blockIdx.x >= m.w.P || m.n == 0) return;
   part2_body<MODE>(m.w, m.a);
 }
+// tiles_only: no directory blocks in front (the batch goes on to k_papply, which needs no work items)
 template <int V, int LPR, int K>
-__global__ void __launch_bounds__(TBC) k_tsum_multi(const MultiDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(TBC) k_tsum_multi(const MultiDesc* __restrict__ descs, int tiles_only) {
   const MultiDesc& m = descs[blockIdx.y];
   if (m.n == 0) return;
   if (*reinterpret_cast<volatile unsigned*>(&m.a.tv.counters[1])) return;
-  if (blockIdx.x < ITEM_BLOCKS) { items2_body<TBC / 64>(m.w, (unsigned)ITEM_BLOCKS); return; }
-  if (blockIdx.x - ITEM_BLOCKS >= m.w.ntiles) return;
-  tsum_body<V, LPR, K>(m.w, m.a.grad, m.a.tv.dim, blockIdx.x - ITEM_BLOCKS);
+  const unsigned nib = tiles_only ? 0u : (unsigned)ITEM_BLOCKS;
+  if (blockIdx.x < nib) { items2_body<TBC / 64>(m.w, (unsigned)ITEM_BLOCKS); return; }
+  if (blockIdx.x - nib >= m.w.ntiles) return;
+  tsum_body<V, LPR, K>(m.w, m.a.grad, m.a.tv.dim, blockIdx.x - nib);
 }
 template <int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TBA, (K == 1 ? 4 : 1)) k_apply2_multi(const MultiDesc* __restrict__ descs) {

@@ -620,16 +620,26 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 template <int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(TBK, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) { papply_body<OPT, V, LPR, K>(w, a, mode); }
 
+// many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array; grid.x = the largest table's partitions)
+template <int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(TBK, KV_PA_WAVES) k_papply_multi(const MultiDesc* __restrict__ descs, int mode) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  papply_body<OPT, V, LPR, K>(m.w, m.a, mode);
+}
+
 // dispatch on the row geometry (the dims fused_ok() admits: float4 rows, a power-of-two lane count); one block per
 // partition.  Returns KV_OK, or KV_UNIMPLEMENTED for a dim the entry-list pipeline does not serve.
+// md != nullptr: `ntab` tables in one launch (wd = the largest ntiles / P of the batch of tables)
 template <int OPT>
-int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s) {
+int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = pa.tv.dim;
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const size_t sh = (size_t)wd.ntiles * 4 + 32;
 #define KV_PA(V, LPR, K)                                                     \
   do {                                                                       \
-    k_papply<OPT, V, LPR, K><<<(int)wd.P, TBK, sh, s>>>(wd, pa, mode);       \
+    if (md) k_papply_multi<OPT, V, LPR, K><<<dim3(wd.P, (unsigned)ntab), TBK, sh, s>>>(md, mode);   \
+    else k_papply<OPT, V, LPR, K><<<(int)wd.P, TBK, sh, s>>>(wd, pa, mode);       \
     return KV_OK;                                                            \
   } while (0)
   const int q = D / 4;

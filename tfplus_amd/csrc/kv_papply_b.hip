@@ -17,11 +17,12 @@ namespace {
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_b(int opt, const void* wd_, const void* pa_, int mode,
-                                                                      void* stream) {
+                                                                      void* stream, const void* md_, int ntab) {
   const WsDev& wd = *static_cast<const WsDev*>(wd_);
   const PartArgs& pa = *static_cast<const PartArgs*>(pa_);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (opt == OPT_ADAGRAD) return launch_papply_t<OPT_ADAGRAD>(wd, pa, mode, s);
-  if (opt == OPT_FTRL) return launch_papply_t<OPT_FTRL>(wd, pa, mode, s);
+  const MultiDesc* md = static_cast<const MultiDesc*>(md_);
+  if (opt == OPT_ADAGRAD) return launch_papply_t<OPT_ADAGRAD>(wd, pa, mode, s, md, ntab);
+  if (opt == OPT_FTRL) return launch_papply_t<OPT_FTRL>(wd, pa, mode, s, md, ntab);
   return KV_INTERNAL;
 }

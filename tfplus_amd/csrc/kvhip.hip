@@ -59,8 +59,8 @@ extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad
 // k_ltsum dispatch (kv_fused.h: tile pass + tile sums), instantiated next to k_tsum; ids_kind 0 int64, 1 int32
 extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids, int ids_kind, long long n, int det,
                                 const float* grad, void* stream);
-extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream);
-extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream);
+extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
+extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
 
 namespace {
 
@@ -1966,7 +1966,11 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
   if (fused_ok(t0->dim)) {
     for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
-    launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
+    // tokens asked for: an optimizer apply of these batches follows — every table's partition pass stays pending
+    // (kv_multi_apply_*_tok completes it inside k_papply_multi; any other op on a table settles that table first)
+    static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();
+    const bool defer = tokens != nullptr && papply_enabled() && !no_defer;
+    if (!defer) launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     if (tokens)   // every table's workspace now holds the index of exactly its batch (kv_multi_apply_*_tok takes it over)
       for (int i = 0; i < num_tables; ++i) {
         if (ns[i] <= 0) continue;
@@ -1974,6 +1978,13 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
         tables[i]->batch_n = ns[i];
         tables[i]->index_P = hd[i].w.P;
         tokens[i] = tables[i]->batch_serial;
+        if (defer) {
+          std::memcpy(tables[i]->pend_wd, &hd[i].w, sizeof(WsDev));
+          std::memcpy(tables[i]->pend_pa, &hd[i].a, sizeof(PartArgs));
+          tables[i]->part_pending = true;
+          tables[i]->tile_pending = false;
+          tables[i]->index_records = false;
+        }
       }
   } else {
     for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = false; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
@@ -2021,18 +2032,32 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
-  if ((rc = lock.enter(s))) return rc;
+  // the batches' own partition passes are still pending (kv_multi_gather_or_insert_tok deferred them) and every token
+  // matches: k_papply_multi completes them together with the update; else every pending pass is settled on entry
+  const bool pa_route = papply_enabled() && fused_ok(D);
+  bool pa_reuse = tokens != nullptr && pa_route;
+  for (int i = 0; i < num_tables && pa_reuse; ++i)
+    if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
+                       vars[i]->part_pending && !vars[i]->tile_pending && !vars[i]->index_records && vars[i]->index_bcap == 0 &&
+                       !vars[i]->side_pending))
+      pa_reuse = false;
+  for (kv_table* tb : lock.ts) {
+    bool keep = false;
+    if (pa_reuse)
+      for (int i = 0; i < num_tables; ++i) keep = keep || (vars[i] == tb && ns[i] > 0);
+    if ((rc = report_deferred_error(tb, s)) || (rc = hand_over(tb, s, !keep))) return rc;
+  }
   long long nmax = 0;
   // the batch tokens of a kv_multi_gather_or_insert_tok over the same ids: the index pass is skipped when EVERY table
   // still holds the index of its batch (one stale token and all tables are indexed again: one launch either way)
-  bool reuse = tokens != nullptr && fused_ok(D);
+  bool reuse = tokens != nullptr && fused_ok(D) && !pa_reuse;
   for (int i = 0; i < num_tables && reuse; ++i)
     if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
                        vars[i]->index_records && !vars[i]->part_pending && !vars[i]->side_pending))
       reuse = false;
   for (int i = 0; i < num_tables; ++i) {
-    if (!reuse) vars[i]->batch_serial = 0;
-    if (!reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
+    if (!reuse && !pa_reuse) vars[i]->batch_serial = 0;
+    if (!reuse && !pa_reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
     if ((rc = ensure_capacity(slots0[i], ns[i], s))) return rc;
     if (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))) return rc;
     if ((rc = ensure_workspace(vars[i], std::max<long long>(ns[i], 1), true, s))) return rc;
@@ -2058,7 +2083,15 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
-    if (reuse && ns[i] > 0 && vars[i]->index_P) { d.w.P = vars[i]->index_P; d.w.pshift = 64 - ilog2(d.w.P); }   // the lookup's partitioning
+    if ((reuse || pa_reuse) && ns[i] > 0 && vars[i]->index_P) { d.w.P = vars[i]->index_P; d.w.pshift = 64 - ilog2(d.w.P); }   // the lookup's partitioning
+    d.w.bcap = 0;
+    d.a.day_lk = d.a.day;
+    if (pa_reuse && ns[i] > 0) {   // the pending lookup's own day stamp and counting rule
+      PartArgs pend;
+      std::memcpy(&pend, vars[i]->pend_pa, sizeof pend);
+      d.a.day_lk = pend.day; d.a.count_once = pend.count_once;
+      vars[i]->part_pending = false;
+    }
     wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
     wmax.P = std::max(wmax.P, d.w.P);
   }
@@ -2068,16 +2101,29 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   const bool fz = fused_ok(D);
   bool skip_fin = false;
   if (fz) {
-    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = true; vars[i]->index_bcap = 0; }
     wmax.hc = (unsigned)HC2;
     skip_fin = wmax.ntiles <= wmax.hc;
-    if (!reuse) {
+    // partition pass + update in one launch (k_papply_multi): the pending lookups' (PA_LOOKUP), or behind a tile pass of
+    // its own when the optimizer meets the ids first (PA_APPLYIDX); an index whose key records exist (a lookup that did
+    // not defer) goes through k_apply2_multi
+    int pa_mode = pa_reuse ? PA_LOOKUP : -1;
+    if (!reuse && !pa_reuse) {
+      for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = !pa_route; vars[i]->index_bcap = 0; }
       launch_ltile(vars[0], hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, false);
-      launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+      if (pa_route) pa_mode = PA_APPLYIDX;
+      else launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
       for (int i = 0; i < num_tables; ++i)
         if (ns[i] > 0) { vars[i]->batch_serial = ++g_serial; vars[i]->batch_n = ns[i]; vars[i]->index_P = hd[i].w.P; }
     }
-    if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, nmax, (void*)s, md, num_tables))) return fail(rc, "tile sums: no kernel for dim %d", D);
+    if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, pa_mode >= 0 ? -nmax : nmax, (void*)s, md, num_tables)))
+      return fail(rc, "tile sums: no kernel for dim %d", D);
+    if (pa_mode >= 0) {
+      rc = (opt == OPT_ADAM_V4 || opt == OPT_ADAM_V3) ? kvp_launch_papply_a(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables)
+                                                      : kvp_launch_papply_b(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables);
+      if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", D);
+      HIP_TRY(hipGetLastError());
+      return KV_OK;
+    }
   } else {
     for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = false; vars[i]->index_records = true; vars[i]->index_bcap = 0; }
     launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
