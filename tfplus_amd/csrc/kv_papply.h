@@ -31,9 +31,16 @@ constexpr int PA_NOAPPLY = 0x100;   // flag: no update — the partition pass of
 #ifndef KV_PA_HOTRB
 #define KV_PA_HOTRB 8      // a hot key's sources in flight per lane group and step
 #endif
-constexpr int PA_LSRC = 1536;   // sources of a partition held in LDS; a larger partition files them in w.order
+// Two block shapes (A/B at configs[1], 109 k keys: 256 threads x 1024 partitions 64.7 us, 512 x 512 60 us, 1024 x 256
+// 75 us; at 773 k keys 512-thread blocks lose: four generations of blocks instead of two):
+//   TBP = 512: 2048 hash slots, 2048 sources in LDS — chosen when the batch has at most 512 partitions (one resident
+//              generation of two blocks per CU)
+//   TBP = 256: 1024 hash slots, 1536 sources — more partitions than that, the deterministic mode, the batched ops
+constexpr int PA_LSRC_MIN = 1536;   // the source list every block shape holds in LDS: a bucketed index of more tiles than this
+                                    // is not built (a key may have one entry per tile, and a round cannot split a key)
+template <int TBP> struct PaShape { static constexpr int HSK = TBP >= 512 ? 2048 : 1024, LSRC = TBP >= 512 ? 2048 : 1536; };
 
-template <int OPT, int V, int LPR, int K>
+template <int OPT, int V, int LPR, int K, int TBP>
 __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, const int mode_) {
 #ifdef KV_PA_X_MODE
   constexpr int mode = KV_PA_X_MODE;
@@ -41,12 +48,13 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   const int mode = mode_ & 0xFF;
 #endif
   const bool no_apply = (mode_ & PA_NOAPPLY) != 0;   // the lookup's bookkeeping alone (no gradient is given)
-  constexpr int HSK = 1024;
-  constexpr int UCAPK = HSK - TBK;
+  constexpr int HSK = PaShape<TBP>::HSK;
+  constexpr int PA_LSRC = PaShape<TBP>::LSRC;
+  constexpr int UCAPK = (HSK - TBP) < 1023 ? (HSK - TBP) : 1023;   // (the class counters of the key scan are 10-bit fields)
   constexpr int EB = 8;
   constexpr int G = 64 / LPR;
   constexpr int RB = (KV_PA_HOTRB / K) > 0 ? (KV_PA_HOTRB / K) : 1;
-  constexpr int NW = TBK / 64;
+  constexpr int NW = TBP / 64;
   __shared__ long long hkey[HSK + 1];
   __shared__ unsigned hval[HSK + 1];    // summed frequency count of the key's entries
   __shared__ unsigned hrow[HSK + 1];    // max over the key's entries of the row word (an entry that knows the row wins)
@@ -85,7 +93,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     __syncthreads();
     E = bpre[NXCD];
   } else {
-    E = seg_directory_t<TBK, NW>(w, p, tpre, tstart, wtot, &pbase);
+    E = seg_directory_t<TBP, NW>(w, p, tpre, tstart, wtot, &pbase);
   }
   // record x of the partition (bucket mode): sub-bucket j = the last one with bpre[j] <= x
   auto brec_of = [&](unsigned x) -> const uint4* {
@@ -116,22 +124,22 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   // code (what the partition phases hold in registers is dead when the apply begins), the split rounds loop below.
   auto do_round = [&](const unsigned R, const unsigned round) -> bool {
     __syncthreads();
-    for (int s = tid; s <= HSK; s += TBK) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; }
+    for (int s = tid; s <= HSK; s += TBP) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; }
     if (tid == 0) { lnu = 0; lsent = 0; lnext = 0; }
     __syncthreads();
     // ---- pass 1: distinct keys, their counts, rows and hints (the entries' sources ride along) -------------------
     unsigned csrc[EB];
     unsigned short cslot[EB];
     bool cin[EB];
-    const bool cached = (R == 1 && E <= (unsigned)(EB * TBK));
-    for (unsigned x0 = 0; x0 < E; x0 += EB * TBK) {
+    const bool cached = (R == 1 && E <= (unsigned)(EB * TBP));
+    for (unsigned x0 = 0; x0 < E; x0 += EB * TBP) {
       unsigned ge[EB];
       long long key[EB];
       unsigned ea[EB], rw[EB], hi[EB], sr[EB];
       if (bucket) {
 #pragma unroll
         for (int k = 0; k < EB; ++k) {
-          const unsigned x = x0 + k * TBK + tid;
+          const unsigned x = x0 + k * TBP + tid;
           ge[k] = x < E ? x : 0xFFFFFFFFu;
           key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
           if (x < E) {
@@ -144,7 +152,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       } else {
 #pragma unroll
         for (int k = 0; k < EB; ++k) {
-          const unsigned x = x0 + k * TBK + tid;
+          const unsigned x = x0 + k * TBP + tid;
           ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
         }
 #pragma unroll
@@ -181,7 +189,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (tid == 0) lkeys += nu;
 
     // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
-    constexpr int PERU = (UCAPK + TBK - 1) / TBK;
+    constexpr int PERU = (UCAPK + TBP - 1) / TBP;
     unsigned nhot, ncold;
     {
       unsigned kcnt[PERU];
@@ -227,9 +235,9 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     {
       auto file = [&](unsigned pos, unsigned src) { if (in_lds) lsrc[pos] = src; else gsrc[pos] = src; };
       if (a.det) {
-        // deterministic mode: a key's entries in tile order = ascending x (TBK entries per round, wave by wave)
+        // deterministic mode: a key's entries in tile order = ascending x (TBP entries per round, wave by wave)
         const int wave = tid >> 6, wl = tid & 63;
-        for (unsigned x0 = 0; x0 < E; x0 += TBK) {
+        for (unsigned x0 = 0; x0 < E; x0 += TBP) {
           const unsigned x = x0 + tid;
           bool valid = x < E;
           size_t ge = 0;
@@ -257,7 +265,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
         for (int k = 0; k < EB; ++k)
           if (cin[k]) file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
       } else {
-        for (unsigned x = tid; x < E; x += TBK) {
+        for (unsigned x = tid; x < E; x += TBP) {
           long long key;
           unsigned src;
           if (bucket) {
@@ -617,15 +625,15 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   if (tid == 0 && mode != PA_NONE) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
 }
 
-template <int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBK, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) { papply_body<OPT, V, LPR, K>(w, a, mode); }
+template <int OPT, int V, int LPR, int K, int TBP>
+__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) { papply_body<OPT, V, LPR, K, TBP>(w, a, mode); }
 
 // many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array; grid.x = the largest table's partitions)
 template <int OPT, int V, int LPR, int K>
-__global__ void __launch_bounds__(TBK, KV_PA_WAVES) k_papply_multi(const MultiDesc* __restrict__ descs, int mode) {
+__global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_multi(const MultiDesc* __restrict__ descs, int mode) {
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
-  papply_body<OPT, V, LPR, K>(m.w, m.a, mode);
+  papply_body<OPT, V, LPR, K, 256>(m.w, m.a, mode);
 }
 
 // dispatch on the row geometry (the dims fused_ok() admits: float4 rows, a power-of-two lane count); one block per
@@ -638,8 +646,9 @@ int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s
   const size_t sh = (size_t)wd.ntiles * 4 + 32;
 #define KV_PA(V, LPR, K)                                                     \
   do {                                                                       \
-    if (md) k_papply_multi<OPT, V, LPR, K><<<dim3(wd.P, (unsigned)ntab), TBK, sh, s>>>(md, mode);   \
-    else k_papply<OPT, V, LPR, K><<<(int)wd.P, TBK, sh, s>>>(wd, pa, mode);       \
+    if (md) k_papply_multi<OPT, V, LPR, K><<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);   \
+    else if (wd.P <= 512u && !pa.det) k_papply<OPT, V, LPR, K, 512><<<(int)wd.P, 512, sh, s>>>(wd, pa, mode);   \
+    else k_papply<OPT, V, LPR, K, 256><<<(int)wd.P, 256, sh, s>>>(wd, pa, mode);       \
     return KV_OK;                                                            \
   } while (0)
   const int q = D / 4;

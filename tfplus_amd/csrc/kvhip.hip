@@ -722,7 +722,7 @@ WsDev ws_view(kv_table* t, long long n) {
 // partition block's source list holds (a key may have one entry per tile).
 bool bucket_enabled(const kv_table* t, long long n) {
   static const bool on = [] { const char* e = getenv("KV_BUCKET"); return e && atoi(e) != 0; }();
-  return on && papply_enabled() && fused_ok(t->dim) && !t->deterministic && !t->overlap && (n + TILE - 1) / TILE <= PA_LSRC;
+  return on && papply_enabled() && fused_ok(t->dim) && !t->deterministic && !t->overlap && (n + TILE - 1) / TILE <= PA_LSRC_MIN;
 }
 // records per sub-bucket: twice an even share of the entries (at most one per id), plus room for eight keys that occur
 // in every tile and land in the same partition (each brings ntiles / 8 entries per XCD), plus slack.  A bucket that still overflows voids the batch (the error the
@@ -1144,12 +1144,13 @@ void choose_partitions(kv_table* t, WsDev& wd, long long n) {
       // about 384 distinct keys per partition block (the LDS hash of k_part2 holds 768 before a partition splits),
       // at most 2048 entries: 109 k keys of 1 M ids (Zipf 1.2) -> 512 partitions, 773 k (Zipf 0.8) -> 2048.
       // Measured at 1 M ids: 512 against 1024 partitions is -2.5 us per step at Zipf 1.2 and +40 us at Zipf 0.8.
-      // With k_papply (kv_papply.h) the partition block also applies its keys' updates, four blocks of four waves per
-      // CU: about 128 keys per block keep all 1024 slots of the chip busy (109 k keys -> 1024 partitions: 64.7 us
-      // against 79.9 us with 512, profiles/r04_*).
+      // With k_papply (kv_papply.h) the partition block also applies its keys' updates: two blocks of eight waves per
+      // CU, about 256 keys per block (109 k keys -> 512 partitions, one resident generation: 60 us; four blocks of four
+      // waves with 128 keys each 64.7 us, one block of sixteen waves with 512 keys 75 us; profiles/r04_tools_output.txt).
       // (a hint is only a hint: never more distinct keys than ids, never more partitions than the workspace was sized for)
       const unsigned long long u = std::min<unsigned long long>(u_prev, (unsigned long long)n);
-      const unsigned long long per = papply_enabled() ? 128ull : 384ull;
+      static const unsigned long long pa_per = [] { const char* e = getenv("KV_PA_PER"); return e ? (unsigned long long)atoll(e) : 256ull; }();   // A/B knob
+      const unsigned long long per = papply_enabled() ? pa_per : 384ull;
       const unsigned long long want = std::max<unsigned long long>((u + per - 1ull) / per, (unsigned long long)((n + 2047) / 2048));
       const unsigned pmax = std::min<unsigned>((unsigned)MAX_P, std::max(64u, t->ws.capP));
       unsigned P = 64;
