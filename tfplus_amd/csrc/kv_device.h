@@ -131,6 +131,8 @@ struct WsDev {
   unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
   unsigned hc;             // entries per hot chunk
+  unsigned short* pos_ent; // [n] k_ltile: every input position's entry number in its tile (sharded route: the finish reads
+                           // position -> entry -> record); nullptr: not filed
   // ---- bucket mode (kv_fused.h ltile_body<BUCKET>, kv_papply.h): the tiles append their entries to per-partition buckets
   uint4* bkt;              // [P][NXCD][bcap] BktRec (two uint4 each): partition p's entries, by the XCD of the tile that
                            // appended them, in arrival order

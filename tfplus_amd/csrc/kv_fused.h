@@ -162,7 +162,9 @@ static_assert(sizeof(BktRec) == 32, "BktRec layout");
 // numbering that mrow / epart need (the entries with more than one occurrence) comes from one block scan over the
 // winners in thread order.  Not for the deterministic mode (the order of a bucket is arrival order), nor the
 // (id, count) pair input of the sharded serve.
-template <typename IdT, int VQ, bool GATHER, bool BUCKET = false>
+// NOTABLE: no table behind the batch (the sharded route's index of the local ids): no probes, no inserts — the entries carry
+// keys, counts and sources only.
+template <typename IdT, int VQ, bool GATHER, bool BUCKET = false, bool NOTABLE = false>
 __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, const IdT* __restrict__ ids,
                                            const int* __restrict__ counts, long long n, int det,
                                            float* __restrict__ out) {
@@ -271,8 +273,21 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   Entry en[IPT];
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
-    pp[k] = ((win >> k) & 1u) ? home_of(t, kreg[k], mix64((unsigned long long)kreg[k])) : 0ull;
-    en[k] = load_entry(&t.entries[pp[k]]);
+    pp[k] = 0ull;
+    en[k] = Entry{0, 0u, 0u};
+    if constexpr (!NOTABLE) {
+      pp[k] = ((win >> k) & 1u) ? home_of(t, kreg[k], mix64((unsigned long long)kreg[k])) : 0ull;
+      en[k] = load_entry(&t.entries[pp[k]]);
+    }
+  }
+  if constexpr (NOTABLE) {   // sparse unique numbers (sharded route): a count of 0 = "names no key"; the partition pass sets the real ones
+    if (w.zero_counts) {
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        const long long i = base + (long long)k * TBT + tid;
+        if (i < n) w.zero_counts[i] = 0;
+      }
+    }
   }
   KV_STAMP(9);
   lds_barrier();   // lcnt is final; lkeys is dead: its storage is lrow / escan from here on
@@ -428,9 +443,12 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   for (int k = 0; k < IPT; ++k) {
     if (wpos[k] == 0xFFFFFFFFu) continue;
     unsigned hint = 0;
-    unsigned r = table_find_from(t, kreg[k], pp[k], en[k], &hint);
-    if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, kreg[k]); hint = 0; }
-    else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
+    unsigned r = 0;
+    if constexpr (!NOTABLE) {
+      r = table_find_from(t, kreg[k], pp[k], en[k], &hint);
+      if (__builtin_expect(r == 0u, 0)) { r = tile_insert(t, kreg[k]); hint = 0; }
+      else if (__builtin_expect(hint == HINT_NEW, 0)) { r |= NEW_BIT; hint = 0; }
+    }
     const size_t e = (size_t)tile * TILE + wpos[k];
     sm.lrow[tslot[k]] = r;
     w.ent_b[e] = r;
@@ -438,6 +456,13 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   lds_barrier();
   KV_STAMP(3);
+  if (w.pos_ent) {   // every position's entry in its tile (the sharded finish reads position -> entry -> record)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const long long i = base + (long long)k * TBT + tid;
+      if (i < n) w.pos_ent[i] = tslot[k] != 0xFFFFFFFFu ? sm.lpos[tslot[k]] : (unsigned short)0xFFFFu;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     if (wpos[k] == 0xFFFFFFFFu) continue;
@@ -588,10 +613,53 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   KV_STAMP(5);
 }
 
-template <typename IdT, int VQ, bool GATHER, bool BUCKET = false>
+template <typename IdT, int VQ, bool GATHER, bool BUCKET = false, bool NOTABLE = false>
 __global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* __restrict__ ids,
                                               const int* __restrict__ counts, long long n, int det, float* __restrict__ out) {
-  ltile_body<IdT, VQ, GATHER, BUCKET>(t, w, ids, counts, n, det, out);
+  ltile_body<IdT, VQ, GATHER, BUCKET, NOTABLE>(t, w, ids, counts, n, det, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shard_finish: the sharded lookup's output rows from the records that came back
+// ------------------------------------------------------------------------------------------
+// out[i] = rows[slot_of[uniq_of_entry[tile * TILE + pos_ent[i]]]]: position -> its entry in the tile (k_ltile<NOTABLE>
+// filed it) -> the entry's distinct-id number (k_papply PA_UNIQUE wrote it to ent_b) -> the record the id was sent in
+// -> the row the owner returned.  A wave takes 64 positions, lane l resolves position l, the rows go VQ lanes per row
+// with streaming stores (the copy of goz_wave).
+template <int VQ, int CW = 4>
+__global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
+                                                     const int* __restrict__ slot_of, const float* __restrict__ rows,
+                                                     float* __restrict__ out, long long n) {
+  constexpr int RW = 64 / VQ;
+  const int lane = threadIdx.x & 63;
+  const int v = lane % VQ, sub = lane / VQ;
+  const long long nwaves = (long long)gridDim.x * (TB / 64);
+  for (long long r0 = ((long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64; r0 < n; r0 += nwaves * 64) {
+    const long long i = r0 + lane;
+    unsigned rec = 0;   // record 0: a header's row (zeros) — positions past the end, ids that found no room in their segment
+    if (i < n) {
+      const unsigned e = pos_ent[i];
+      if (e != 0xFFFFu) rec = (unsigned)slot_of[ent_u[(size_t)(i / TILE) * TILE + e]];
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < VQ; j0 += CW) {
+      float4 val[CW];
+      unsigned rj[CW];
+#pragma unroll
+      for (int j = 0; j < CW && j0 + j < VQ; ++j) rj[j] = __shfl(rec, (j0 + j) * RW + sub);
+#pragma unroll
+      for (int j = 0; j < CW && j0 + j < VQ; ++j) val[j] = reinterpret_cast<const float4*>(rows + (size_t)rj[j] * (VQ * 4))[v];
+#pragma unroll
+      for (int j = 0; j < CW && j0 + j < VQ; ++j) {
+        const long long ii = r0 + (j0 + j) * RW + sub;
+        if (ii < n) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+          __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------

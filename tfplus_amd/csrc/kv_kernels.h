@@ -328,6 +328,13 @@ struct PartArgs {
   long long n;                // ids in the batch
   const float* epart;         // entry-list pipeline: list words tagged EP_TAG name rows of this array (tile sums), else of grad
   unsigned day_lk;            // k_papply (kv_papply.h), PA_LOOKUP: the day stamp of the lookup whose bookkeeping it completes
+  // k_papply PA_UNIQUE with route_world > 0 (sharded lookup route): every distinct id goes straight to its owner's segment
+  int route_world, route_rule;     // owner_rank(id, world, rule)
+  unsigned route_C;                // records per segment (header not counted)
+  long long* route_seg;            // [world][C + 1][2] (id, count) records
+  int* route_slot_of;              // [number] the record the id went to (0: no room)
+  unsigned* route_overflow;        // pinned flag: a segment was too small
+  unsigned* route_gcount;          // [world] records per owner so far (k_seg_headers_take reads and clears them)
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)

@@ -21,9 +21,14 @@
 // mode: PA_LOOKUP   the batch's training lookup left its partition pass pending: FindOrInsert bookkeeping, then apply
 //       PA_APPLYIDX the optimizer meets the ids first (FindOrInsertUnsafe: a new key gets frequency word 1, unfiltered)
 //       PA_NONE     the entries of a batch whose bookkeeping is done (a second optimizer on the same token)
+//       PA_UNIQUE   no table (the sharded route's index of a rank's local ids): the distinct ids get numbers — partition
+//                   base + local number, sparse — and go to out_keys / out_counts (occurrences); every entry learns its
+//                   id's number (ent_b).  No apply phase.
+//       PA_DEDUP    the gradient rows of the batch PA_UNIQUE numbered are summed per distinct id and written to
+//                   out_sum[out_map[number]] — the records the ids were sent in — instead of updating rows
 #pragma once
 
-enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2 };
+enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2, PA_UNIQUE = 3, PA_DEDUP = 4 };
 constexpr int PA_NOAPPLY = 0x100;   // flag: no update — the partition pass of a lookup that no apply followed (what k_part2<LOOKUP> does)
 #ifndef KV_PA_WAVES
 #define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
@@ -65,6 +70,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   __shared__ unsigned short kord[UCAPK + 8];   // key slots: hot keys, then 1 / 2 / 3.. sources
   __shared__ unsigned lsrc[PA_LSRC];
   __shared__ unsigned lnu, lsent, lnext, lkeys;
+  __shared__ unsigned rh[MAXW], rbase[MAXW];   // PA_UNIQUE with a route: the round's ids per owner, their first records
   __shared__ unsigned wtot[8];
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
@@ -176,6 +182,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
         }
         if (mode == PA_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16);
+        else if (mode == PA_UNIQUE) atomicAdd(&hval[h], ea[k] & 0xFFFFu);   // occurrences of the id in the batch
         atomicAdd(&hocc[h], 1u);
         atomicMax(&hrow[h], rw[k]);
         if (hi[k]) atomicMax(&hhint[h], hi[k]);
@@ -186,6 +193,8 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (lnu >= (unsigned)UCAPK) return true;   // more distinct keys than the hash holds: the caller splits the round
     KV_STAMPP(1);
     const unsigned nu = lnu;
+    const unsigned lkeys_before = lkeys;   // distinct keys of the partition's earlier rounds (read before the barrier below lets thread 0 add)
+    __syncthreads();
     if (tid == 0) lkeys += nu;
 
     // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
@@ -226,10 +235,55 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           kord[rank] = (unsigned short)s;
           hocc[s] = run; run += kcnt[q];
           hcn[s] = (unsigned short)kcnt[q];
+          if (mode == PA_UNIQUE) {   // the id's number: the partition's entries before it bound the numbers before it
+            const unsigned num = pbase + lkeys_before + u;
+            hrow[s] = num;
+            a.out_keys[num] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
+            a.out_counts[num] = (int)hval[s];
+          }
         }
       }
     }
     __syncthreads();
+    if (mode == PA_UNIQUE && a.route_world > 0) {
+      // ---- the sharded route: every distinct id to its owner's segment of the send buffer.  The block counts its ids per
+      //      owner in LDS and reserves their records with ONE atomic per owner (what k_owner_route_fixed does per 1024 ids)
+      if (tid < MAXW) rh[tid] = 0;
+      __syncthreads();
+      unsigned rd[PERU], rr[PERU];
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        rd[q] = 0xFFFFFFFFu; rr[q] = 0;
+        if (u < nu) {
+          const unsigned s = ulist[u];
+          const long long key = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
+          rd[q] = owner_rank(key, a.route_world, a.route_rule);
+          rr[q] = atomicAdd(&rh[rd[q]], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid < a.route_world) rbase[tid] = rh[tid] ? atomicAdd(&a.route_gcount[tid], rh[tid]) : 0u;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u < nu) {
+          const unsigned s = ulist[u];
+          const unsigned num = hrow[s];
+          const unsigned at = rbase[rd[q]] + rr[q];
+          if (at < a.route_C) {
+            const size_t slot = (size_t)rd[q] * (a.route_C + 1) + 1 + at;
+            a.route_seg[2 * slot] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
+            a.route_seg[2 * slot + 1] = (long long)(int)hval[s];
+            a.route_slot_of[num] = (int)slot;
+          } else {
+            a.route_slot_of[num] = 0;
+            atomicExch(a.route_overflow, 1u);
+          }
+        }
+      }
+    }
 
     // ---- pass 2: the source list — entry x of key h goes to its key's stretch ---------------------------------------
     {
@@ -258,16 +312,20 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             if (wave == wv && valid) { pos = hocc[h] + within; atomicAdd(&hocc[h], 1u); }
             __syncthreads();
           }
-          if (valid) file(pos, w.ent_rec[ge]);
+          if (valid) { file(pos, w.ent_rec[ge]); if (mode == PA_UNIQUE) w.ent_b[ge] = hrow[h]; }
         }
       } else if (cached) {
 #pragma unroll
         for (int k = 0; k < EB; ++k)
-          if (cin[k]) file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
+          if (cin[k]) {
+            file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
+            if (mode == PA_UNIQUE) w.ent_b[seg_entry(tpre, tstart, NT, (unsigned)(k * TBP + tid))] = hrow[cslot[k]];   // the entry learns its id's number
+          }
       } else {
         for (unsigned x = tid; x < E; x += TBP) {
           long long key;
           unsigned src;
+          size_t ge_u = 0;
           if (bucket) {
             const uint4* rp = brec_of(x);
             const uint4 ra_ = rp[0];
@@ -277,11 +335,13 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             const size_t ge = seg_entry(tpre, tstart, NT, x);
             key = w.ent_key[ge];
             src = w.ent_rec[ge];
+            ge_u = ge;
           }
           if (!in_round(key, R, round)) continue;
           bool first;
           const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
           file(atomicAdd(&hocc[h], 1u), src);
+          if (mode == PA_UNIQUE && !bucket) w.ent_b[ge_u] = hrow[h];
         }
       }
     }
@@ -325,6 +385,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 #ifdef KV_PA_X_NOAPPLY
     return false;
 #endif
+    if (mode == PA_UNIQUE) return false;   // (block-uniform) numbering only
 #ifdef KV_STAMPS
     unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0;
 #endif
@@ -409,6 +470,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           }
         }
       };
+      const bool dedup = mode == PA_DEDUP;
       if (no_apply) {
         prefetch();
       } else if (is_hot) {
@@ -426,7 +488,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
         unsigned pa_[RB], pb_[RB];
         float va[RB][K][V];
         ldpos(0, pa_);
-        prefetch();
+        if (!dedup) prefetch();
         for (unsigned stp = 0; stp < nst; ++stp) {
 #pragma unroll
           for (int j = 0; j < RB; ++j) load_row(pa_[j], va[j]);
@@ -456,7 +518,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
         const unsigned p1 = src_at((cnt >= 2u ? st + 1u : st) < E ? (cnt >= 2u ? st + 1u : st) : 0u);
         load_row(p0, gv);
         if (two) load_row(p1, g2);   // uniform over the wave
-        prefetch();
+        if (!dedup) prefetch();
         if (two) {
 #pragma unroll
           for (int k = 0; k < K; ++k)
@@ -487,6 +549,15 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 
       // ---- the lookup's bookkeeping for the key (k_part2's owner work), on what the round trip brought ----------------
       // kv_variable.h:320-363 (find_func / insert_func) for PA_LOOKUP, :382-416 (FindOrInsertUnsafe) for PA_APPLYIDX
+      if (dedup) {   // the id's sum goes to the record the id was sent in (sharded apply: out_map = the id's exchange slot)
+        if (live) {
+          float* dst = a.out_sum + (size_t)(a.out_map ? a.out_map[row] : (int)row) * D;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (evalid[k]) stv<V>(dst + eoff[k], gv[k]);
+        }
+        continue;
+      }
       bool vnew = false;   // the apply below treats the key as inserted by itself: never filtered (kv_variable.h:400-407)
       if (mode != PA_NONE) {
         const bool nk = st_live && isnew;
@@ -622,7 +693,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       __syncthreads();
     }
   }
-  if (tid == 0 && mode != PA_NONE) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
+  if (tid == 0 && mode != PA_NONE && mode != PA_DEDUP) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
 }
 
 template <int OPT, int V, int LPR, int K, int TBP>

@@ -336,6 +336,8 @@ struct Workspace {
   unsigned* ctr = nullptr;
   unsigned* mcount = nullptr;  // entry-list pipeline: [cap_n / TILE]
   long long* ids_copy = nullptr;   // [cap_n] the ids of a lookup whose tile pass is deferred (k_lrows copies them)
+  unsigned short* pos_ent = nullptr;   // [pos_cap] sharded route: every position's entry number in its tile
+  long long pos_cap = 0;
   uint4* bkt = nullptr;            // bucket mode: [P][bcap] BktRec (2 uint4 each)
   size_t bkt_records = 0;
   unsigned* bcnt = nullptr;        // [2][MAX_P] bucket cursors, one set per batch parity
@@ -704,6 +706,7 @@ WsDev ws_view(kv_table* t, long long n) {
   d.hc = (unsigned)HC;
   // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
   d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
+  d.pos_ent = nullptr;
   d.bkt = w.bkt;
   d.bcap = t->index_bcap;
   d.bcnt = w.bcnt ? w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE : nullptr;
@@ -910,6 +913,11 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   else KV_LT(long long);
 #undef KV_LT
 #undef KV_LT2
+}
+// the table-less tile pass of the sharded route (int64 ids): entries, mrow, every position's entry number
+void launch_ltile_notable(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, long long n, hipStream_t s) {
+  k_ltile<long long, 1, false, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, nullptr, n,
+                                                                                          t->deterministic ? 1 : 0, nullptr);
 }
 int ensure_side(kv_table* t) {
   if (!t->side) {
@@ -1460,7 +1468,7 @@ int kv_destroy(kv_handle_t t) {
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
-  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy); hipFree(w.bkt); hipFree(w.bcnt);
+  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy); hipFree(w.bkt); hipFree(w.bcnt); hipFree(w.pos_ent);
   if (t->side) {
     hipStreamSynchronize(t->side);
     hipStreamDestroy(t->side);
@@ -3211,6 +3219,7 @@ struct kv_shard {
   unsigned long long grows = 0;      // times the capacity was raised
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
+  bool route_fused = false;          // ... and whether it is an entry-list index (k_ltile<NOTABLE> + k_papply PA_UNIQUE), not a sorted position list
   const kv_comm* verified = nullptr; // the communicator whose ranks were seen to agree on world / capacity / dim
   uint64_t route_token = 0;
   kv_batch_token_t serve_token = 0;
@@ -3446,15 +3455,13 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   }
   if ((rc = ensure_workspace(rt, n, true, s))) return rc;
   WsDev wd = ws_view(rt, n);
-  {
-    // a skewed batch (the previous one of this length held at most n / 8 distinct ids; pinned word, no
-    // synchronisation): half the partitions, as in the unsharded index pass (fused_index_pass)
-    const unsigned u_prev = reinterpret_cast<volatile unsigned*>(sh->overflow)[1];
-    const bool few = !rt->deterministic && rt->batch_n_prev == n && u_prev > 0u && (long long)u_prev * 8 <= n && n >= (1ll << 18);
-    rt->batch_n_prev = n;
-    if (few) { wd.P = std::max(64u, wd.P / 2u); wd.pshift = 64 - ilog2(wd.P); }
-    rt->index_P = wd.P;
-  }
+  // The route's index on the entry-list kernels (KV_SHARD_OLD_ROUTE=1: the sorted-position kernels):
+  // a table-less tile pass (k_ltile<NOTABLE>: entries, mrow, every position's entry number) and k_papply in PA_UNIQUE
+  // mode (the distinct ids numbered, uniq / ucnt written, every entry learns its id's number).  The finish then reads
+  // position -> entry -> number -> record, the gradient pre-sum is k_tsum + k_papply PA_DEDUP.
+  static const bool old_route = [] { const char* e = getenv("KV_SHARD_OLD_ROUTE"); return e && atoi(e) != 0; }();
+  const bool fused_route = !old_route && papply_enabled() && fused_ok(rt->dim);
+  sh->route_fused = fused_route;
   PartArgs pa{};
   pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = sh->uniq;
@@ -3462,19 +3469,56 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   pa.sparse_unique = 1;   // unique numbers with gaps: no counter to serialise on
   pa.det = sh->table->deterministic ? 1 : 0;
   pa.n = n;
-  // tile + partition passes only: kv_shard_lookup_finish's gather files the positions (order, work items) on its way
-  WsDev wz = wd;
-  wz.zero_counts = sh->ucnt;   // sparse unique numbers: the tile pass clears the counts, the partition pass sets the real ones
-  launch_tile<false>(rt, wz, ids, nullptr, n, s, 0);
-  launch_part_keys<MODE_UNIQUE>(wd, pa, s);
+  if (fused_route) {
+    Workspace& ws = rt->ws;
+    if (ws.pos_cap < n) {
+      HIP_TRY(hipStreamSynchronize(s));
+      ws.pos_cap = 0;
+      if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
+      ws.pos_cap = std::max<long long>(n, ws.cap_n);
+    }
+    wd.hc = (unsigned)HC2;
+    rt->fused_index = true;
+    rt->index_records = false;
+    rt->index_bcap = 0;
+    wd.bcap = 0;
+    choose_partitions(rt, wd, n);   // (the distinct-id hint of the previous route of this length: k_papply publishes it)
+    WsDev wz = wd;
+    wz.zero_counts = sh->ucnt;
+    wz.pos_ent = ws.pos_ent;
+    launch_ltile_notable(rt, pa.tv, wz, ids, n, s);
+    pa.day_lk = pa.day;
+    if (!pa.det) {   // the numbered ids go straight to their owners' segments (the deterministic mode keeps the ordered scatter below)
+      pa.route_world = sh->world; pa.route_rule = sh->rule; pa.route_C = sh->C;
+      pa.route_seg = sh->send_pairs; pa.route_slot_of = sh->slot_of; pa.route_overflow = sh->overflow; pa.route_gcount = sh->gcount;
+    }
+    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_UNIQUE | PA_NOAPPLY, (void*)s))) return fail(rc, "route: no kernel for dim %d", rt->dim);
+  } else {
+    {
+      // a skewed batch (the previous one of this length held at most n / 8 distinct ids; pinned word, no
+      // synchronisation): half the partitions, as in the unsharded index pass (fused_index_pass)
+      const unsigned u_prev = reinterpret_cast<volatile unsigned*>(sh->overflow)[1];
+      const bool few = !rt->deterministic && rt->batch_n_prev == n && u_prev > 0u && (long long)u_prev * 8 <= n && n >= (1ll << 18);
+      rt->batch_n_prev = n;
+      if (few) { wd.P = std::max(64u, wd.P / 2u); wd.pshift = 64 - ilog2(wd.P); }
+      rt->index_P = wd.P;
+    }
+    rt->fused_index = false;
+    // tile + partition passes only: kv_shard_lookup_finish's gather files the positions (order, work items) on its way
+    WsDev wz = wd;
+    wz.zero_counts = sh->ucnt;   // sparse unique numbers: the tile pass clears the counts, the partition pass sets the real ones
+    launch_tile<false>(rt, wz, ids, nullptr, n, s, 0);
+    launch_part_keys<MODE_UNIQUE>(wd, pa, s);
+  }
   rt->batch_serial = ++g_serial;
   rt->batch_n = n;
   sh->route_token = rt->batch_serial;
   sh->ordered = false;
   const unsigned ntr = (unsigned)((n + RT - 1) / RT);
   if (!pa.det) {
-    k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
-                                           sh->overflow, sh->gcount);
+    if (!fused_route)
+      k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
+                                             sh->overflow, sh->gcount);
     k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need, sh->overflow + 1);
     HIP_TRY(hipGetLastError());
     return KV_OK;
@@ -3515,6 +3559,19 @@ int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
   { int rc; if ((rc = hand_over(rt, (hipStream_t)stream))) return rc; }
   // the training lookup's gather (k_gather<ORDER>) over the rows that came back: position -> entry -> dense unique
   // index -> the record its id was sent in; the same pass files the positions for the gradient sum to come
+  if (sh->route_fused) {
+    const int q = rt->dim / 4;
+    const int grid = nblocks(sh->n_last, TB, 8192);
+    hipStream_t st = (hipStream_t)stream;
+#define KV_SF(VQ) k_shard_finish<VQ><<<grid, TB, 0, st>>>(rt->ws.pos_ent, rt->ws.ent_b, sh->slot_of, sh->recv_rows, out, sh->n_last)
+    switch (q) {
+      case 1: KV_SF(1); break;   case 2: KV_SF(2); break;   case 4: KV_SF(4); break;   case 8: KV_SF(8); break;
+      case 16: KV_SF(16); break; case 32: KV_SF(32); break; default: KV_SF(64); break;
+    }
+#undef KV_SF
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   WsDev wd = ws_view(rt, sh->n_last);
   if (rt->index_P) { wd.P = rt->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the route's partitioning
   wd.row_map = sh->slot_of;
@@ -3543,6 +3600,24 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
   if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
   WsDev wd = ws_view(rt, sh->n_last);
   if (rt->index_P) { wd.P = rt->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the route's partitioning
+  if (sh->route_fused) {
+    // the tile sums of the ids repeated inside their tile, then the per-id sums straight into the records the ids were
+    // sent in (k_papply PA_DEDUP over the route's entries)
+    PartArgs pa{};
+    pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+    pa.grad = grad;
+    pa.out_sum = sh->send_rows;
+    pa.out_map = sh->slot_of;
+    pa.det = rt->deterministic ? 1 : 0;
+    pa.n = sh->n_last;
+    wd.hc = (unsigned)HC2;
+    pa.epart = wd.epart;
+    pa.day_lk = pa.day;
+    if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, -(long long)sh->n_last, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", rt->dim);
+    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "gradient pre-sum: no kernel for dim %d", rt->dim);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   if (!sh->ordered) {   // a gradient for a batch whose rows were never fetched (kv_shard_lookup_finish skipped)
     launch_order(dev_view(rt), wd, sh->n_last, s);
     sh->ordered = true;
