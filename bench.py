@@ -249,7 +249,7 @@ def main():
   ap.add_argument("--graph", action="store_true",
                   help="the timed steps replay HIP graphs captured in overlap mode (one graph per pooled batch)")
   ap.add_argument("--lossless", action="store_true",
-                  help="sharded path: kv_shard_set_lossless (capacity agreed before every exchange; a host round trip per lookup)")
+                  help="sharded path: keep the library's default lossless mode (capacity agreed before every exchange; a host round trip per lookup) instead of opting into the synchronisation-free mode")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -371,8 +371,10 @@ def main():
     comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
     cap = peer_capacity()
     shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
-    if args.lossless:   # ranks agree on the capacity before every exchange: one all-reduce + one host round trip per lookup
-      shard.set_lossless(True)
+    # the library's default is lossless (ranks agree on the capacity before every exchange: one all-reduce + one host
+    # round trip per lookup); the bench sizes peer_capacity from its own batches (peer_capacity() above: cannot overflow)
+    # and OPTS INTO the synchronisation-free mode unless --lossless is given
+    shard.set_lossless(bool(args.lossless))
     hp_t = ctypes.c_float * 9
     # this step has no dense tower to overlap with: queue it on the communicator's own stream, so the ops fork and
     # join nothing (with a tower on another stream each op pays one event hop in and one out, hidden behind it)

@@ -442,13 +442,16 @@ int kv_shard_lookup(kv_shard_t shard, kv_comm_t comm, const void* ids, int64_t n
 int kv_shard_apply(kv_shard_t shard, kv_comm_t comm, int optimizer, kv_handle_t slot0, kv_handle_t slot1,
                    const float* grad, const float* hp, int join, kv_stream_t stream);
 int kv_shard_join(kv_shard_t shard, kv_stream_t stream);
-/* Lossless mode (off by default).  The default mode never synchronises: a batch that overflows peer_capacity loses
- * its surplus ids and says so one call late.  With lossless mode on — on every rank alike — kv_shard_lookup /
- * kv_multi_shard_lookup first agree on the largest segment any rank's route produced (one 4-byte ncclAllReduce per
- * table and ONE stream synchronisation per call); when it exceeds the capacity every rank raises its capacity to the
- * same new value and routes again, so nothing is ever dropped and the ranks stay in step.  The reference's
- * partitioned lookup has no capacity at all (embedding_ops.py:115-204); this is the mode that matches it exactly,
- * at the cost of the host round trip per lookup the default avoids. */
+/* Lossless mode — ON by default since round 4: a sharded lookup can lose nothing, like the reference's capacity-free
+ * partitioned lookup (embedding_ops.py:115-204).  kv_shard_lookup / kv_multi_shard_lookup first agree on the largest
+ * segment any rank's route produced (one 4-byte ncclAllReduce per table and ONE stream synchronisation per call); when
+ * it exceeds the capacity every rank raises its capacity to the same new value and routes again, so nothing is ever
+ * dropped and the ranks stay in step.  kv_shard_set_lossless(shard, 0) — on every rank alike — opts into the
+ * synchronisation-free mode for deployments that size peer_capacity themselves: no host round trip (about 15 us per
+ * step), but a batch that overflows peer_capacity loses its surplus ids (zero rows, dropped gradients) and says so
+ * one call late (KV_RESOURCE_EXHAUSTED).  The phase calls (kv_shard_lookup_route / _serve / _finish ...) are building
+ * blocks for a caller with its own exchange and never synchronise: such a caller checks kv_shard_agree_local or sizes
+ * the capacity. */
 int kv_shard_set_lossless(kv_shard_t shard, int on);
 /* The same agreement between the shards of ONE process (kv_shard_exchange_local's companion): after every shard's
  * kv_shard_lookup_route; *rerouted != 0: the capacity was raised on all of them, run the routes again. */

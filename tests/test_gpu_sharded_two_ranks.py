@@ -309,7 +309,8 @@ def test_native_shard_lossless_whole_op_through_rccl():
   var2 = ops.kv_variable([D]); slot2 = ops.kv_variable([3 * D])
   for h, t in ((var2, table), (slot2, np.zeros((4, 3 * D), np.float32))):
     ops.kv_set_clock_days(h, DAY); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, t)
-  shards[0].set_lossless(True)
+  # (no set_lossless call: lossless is the library's DEFAULT — VERDICT r3 item 6 — a batch that overflows the capacity
+  #  grows it on every rank and is routed again: no zero rows, no dropped gradients)
   os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
   comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
   hp = (0.1, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
@@ -326,6 +327,31 @@ def test_native_shard_lossless_whole_op_through_rccl():
   o1, o2 = torch.argsort(k1), torch.argsort(k2)
   assert torch.equal(k1[o1], k2[o2])
   torch.testing.assert_close(v1[o1], v2[o2], rtol=1e-6, atol=1e-7)              # unique ids: the op boundary's tolerance
+  del comm
+
+
+@pytest.mark.gpu
+def test_native_shard_lossy_mode_is_the_opt_in():
+  """kv_shard_set_lossless(shard, 0): the synchronisation-free mode — a batch that sends one owner more than
+  peer_capacity distinct ids reads zeros for the surplus and the NEXT sharded call reports it; the default mode (the
+  test above) grows the capacity instead."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  D = 16
+  table = np.ones((4, D), np.float32)
+  ops, vars_, slots, shards = _native_setup(1, D, "hash", table, cap=16, max_ids=4096)
+  shards[0].set_lossless(False)
+  os.environ["KV_COMM_SELF_VIA_RCCL"] = "1"
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id())
+  ids = torch.arange(0, 200, dtype=torch.int64).cuda()
+  out = shards[0].lookup(comm, ids).cpu().numpy()
+  assert np.count_nonzero(out.any(axis=1)) == 16 and shards[0].peer_capacity == 16
+  torch.cuda.synchronize()
+  with pytest.raises(Exception, match="peer_capacity"):
+    shards[0].lookup(comm, ids[:8])
+  out = shards[0].lookup(comm, ids[:8]).cpu().numpy()                       # reported once; this batch fits
+  assert np.count_nonzero(out.any(axis=1)) == 8
   del comm
 
 

@@ -3215,7 +3215,8 @@ struct kv_shard {
   unsigned long long overflows = 0;  // batches reported so far
   unsigned* need = nullptr;          // device [2]: the largest segment the last routed batch wanted; the same over all ranks
   unsigned* need_host = nullptr;     // pinned copy of need[1]
-  bool lossless = false;             // kv_shard_set_lossless: ranks agree on the capacity before every exchange
+  bool lossless = true;              // ranks agree on the capacity before every exchange (the default: nothing can be lost);
+                                     // kv_shard_set_lossless(shard, 0) opts into the synchronisation-free mode
   unsigned long long grows = 0;      // times the capacity was raised
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
