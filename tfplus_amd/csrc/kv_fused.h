@@ -537,6 +537,11 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     constexpr int CW = VQ < 8 ? VQ : 8;    // copy instructions in flight
     const int lane = tid & 63;
     const int v = lane % VQ, sub = lane / VQ;
+    // a row is D4 = dim / 4 float4; VQ is the next power of two (dims 12, 20, 100 ...: the lanes v >= D4 of a row's
+    // group load float4 0 of the row instead — no branch around the load — and do not store)
+    const int D4 = t.dim >> 2;
+    const bool vlive = v < D4;
+    const int vv = vlive ? v : 0;
     // SINGLE: the slab is one chunk — rows are addressed without the chunk-table branch, which would put a wait in
     // front of every load; with two blocks per CU the CW loads of a step must really be in flight together
     auto copy_rows = [&](auto single_tag) {
@@ -552,8 +557,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const unsigned rj = __shfl(rr[k], (j0 + j) * RW + sub) & ROW_MASK;
-          if constexpr (SINGLE) val[j] = rows0[(size_t)rj * VQ + v];
-          else val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj))[v];
+          if constexpr (SINGLE) val[j] = rows0[(size_t)rj * D4 + vv];
+          else val[j] = reinterpret_cast<const float4*>(row_ptr(t, rj))[vv];
         }
       };
       auto flush = [&](int pc, float4 (&val)[CW]) {
@@ -568,8 +573,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
             const long long kj = __shfl(kreg[k], (j0 + j) * RW + sub);
             if (rj & NEW_BIT) {
               const unsigned long long h = pick64((unsigned long long)kj ^ (t.seed * 0x9E3779B97F4A7C15ULL));
-              const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[v];
-              const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[v];
+              const float4 a = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)h % t.init_rows) * t.dim)[vv];
+              const float4 b = reinterpret_cast<const float4*>(t.init_table + (size_t)((unsigned)(h >> 32) % t.init_rows) * t.dim)[vv];
               val[j] = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
             }
           }
@@ -577,8 +582,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
           const long long ii = r0 + (j0 + j) * RW + sub;
-          if (ii < n) {
-            float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+          if (ii < n && vlive) {
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * t.dim) + v;
             __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
             __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
           }
@@ -629,10 +634,13 @@ __global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* _
 template <int VQ, int CW = 4>
 __global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
                                                      const int* __restrict__ slot_of, const float* __restrict__ rows,
-                                                     float* __restrict__ out, long long n) {
+                                                     float* __restrict__ out, long long n, int dim) {
   constexpr int RW = 64 / VQ;
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
+  const int D4 = dim >> 2;   // float4 per row (<= VQ: lanes past it are masked)
+  const bool vlive = v < D4;
+  const int vv = vlive ? v : 0;
   const long long nwaves = (long long)gridDim.x * (TB / 64);
   for (long long r0 = ((long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64; r0 < n; r0 += nwaves * 64) {
     const long long i = r0 + lane;
@@ -648,12 +656,12 @@ __global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __res
 #pragma unroll
       for (int j = 0; j < CW && j0 + j < VQ; ++j) rj[j] = __shfl(rec, (j0 + j) * RW + sub);
 #pragma unroll
-      for (int j = 0; j < CW && j0 + j < VQ; ++j) val[j] = reinterpret_cast<const float4*>(rows + (size_t)rj[j] * (VQ * 4))[v];
+      for (int j = 0; j < CW && j0 + j < VQ; ++j) val[j] = reinterpret_cast<const float4*>(rows + (size_t)rj[j] * dim)[vv];
 #pragma unroll
       for (int j = 0; j < CW && j0 + j < VQ; ++j) {
         const long long ii = r0 + (j0 + j) * RW + sub;
-        if (ii < n) {
-          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * (VQ * 4)) + v;
+        if (ii < n && vlive) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * dim) + v;
           __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
           __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
         }

@@ -870,13 +870,17 @@ bool papply_enabled() {
 // ids per index pass: positions and epart rows are 30-bit fields of the entry list's words, a partition block takes
 // up to 65535 entries; 2^23 ids (4096 tiles) stay well inside both
 constexpr long long FUSED_MAX_N = 1ll << 23;
-// dims it serves: float4 rows with a power-of-two lane count (4, 8, 16, ..., 256)
+// dims it serves: every multiple of 4 up to 256 (rows of dim / 4 float4; a row's lane group is the next power of two,
+// the lanes past the row's end masked: dims 12, 20, 100 ... run the same kernels as 16, 32, 128)
 bool fused_ok(int D) {
   static const bool off = [] { const char* e = getenv("KV_NO_FUSED"); return e && atoi(e) != 0; }();   // A/B against the sorted-position pipeline
   if (off || (D & 3) != 0) return false;
   const int q = D / 4;
-  return q >= 1 && q <= 64 && (q & (q - 1)) == 0;
+  return q >= 1 && q <= 64;
 }
+// lanes per row of the row-copy kernels: dim / 4 rounded up to a power of two
+int row_lanes(int D) { return (int)pow2ceil((unsigned long long)std::max(1, D / 4)); }
+bool pow2_rows(int D) { return (D & 3) == 0 && row_lanes(D) == D / 4; }
 // tile pass: dedup, index probes / inserts, entries, tile-local order and (out != nullptr) the output rows
 // md != nullptr: `ntab` tables in one launch (grid.y), arguments from the descriptor array; multi_rows: with rows
 void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, const int* counts, long long n, float* out,
@@ -885,7 +889,7 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   const int grid = (int)wd.ntiles;
   const size_t sh = ltile_smem_bytes();
   const int det = t->deterministic ? 1 : 0;
-  const int q = td.dim / 4;
+  const int q = row_lanes(td.dim);
 #define KV_LT2(IDT, VQ)                                                                                     \
   do {                                                                                                      \
     if (md && multi_rows) k_ltile_multi<IDT, VQ, true><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md); \
@@ -1191,7 +1195,7 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     if (rcb) return rcb;
     t->index_records = false;
   }
-  if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0) {
+  if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0 && pow2_rows(t->dim)) {
     // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
     // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
     HIP_TRY(hipEventRecord(t->ev_fork, s));
@@ -1677,7 +1681,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     // only when the same few batches repeat and stay in the infinity cache) + k_ltsum 43 us against k_ltile 55 us +
     // k_tsum 24 us: the de-duplicated probes and rows of k_ltile win.  Off unless asked for.
     static const bool defer_tile_on = [] { const char* e = getenv("KV_DEFER_TILE"); return e && atoi(e) != 0; }();
-    const bool defer_tile = defer_part && papply_enabled() && defer_tile_on && !t->overlap && !cp && !pairs && seg_cap == 0;
+    const bool defer_tile = defer_part && papply_enabled() && defer_tile_on && !t->overlap && !cp && !pairs && seg_cap == 0 && pow2_rows(t->dim);
     if (fused_ok(t->dim)) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, side_part, defer_part, false, defer_tile))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
@@ -3561,10 +3565,10 @@ int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
   // the training lookup's gather (k_gather<ORDER>) over the rows that came back: position -> entry -> dense unique
   // index -> the record its id was sent in; the same pass files the positions for the gradient sum to come
   if (sh->route_fused) {
-    const int q = rt->dim / 4;
+    const int q = row_lanes(rt->dim);
     const int grid = nblocks(sh->n_last, TB, 8192);
     hipStream_t st = (hipStream_t)stream;
-#define KV_SF(VQ) k_shard_finish<VQ><<<grid, TB, 0, st>>>(rt->ws.pos_ent, rt->ws.ent_b, sh->slot_of, sh->recv_rows, out, sh->n_last)
+#define KV_SF(VQ) k_shard_finish<VQ><<<grid, TB, 0, st>>>(rt->ws.pos_ent, rt->ws.ent_b, sh->slot_of, sh->recv_rows, out, sh->n_last, rt->dim)
     switch (q) {
       case 1: KV_SF(1); break;   case 2: KV_SF(2); break;   case 4: KV_SF(4); break;   case 8: KV_SF(8); break;
       case 16: KV_SF(16); break; case 32: KV_SF(32); break; default: KV_SF(64); break;
