@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20250211 + 2
-SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "0"))   # 0: the dominant kernel is bracketed by events on every 8th step of the timed region (a pair of markers costs ~4 us of stream time), every 2nd when the run has 24 steps or fewer (so that at least 8 launches are timed)
+SAMPLE_EVERY = int(os.environ.get("KV_BENCH_SAMPLE_EVERY", "0"))   # 0: the dominant kernel is bracketed by events on every 8th step of the timed region (a pair of markers costs ~4 us of stream time), every 5th / 2nd when the run has 64 / 24 steps or fewer (so that at least 8 launches are timed)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -489,7 +489,7 @@ def main():
     torch.cuda.synchronize()
   ops.kv_profile_enable(var, 0 if (args.no_kernel_events or graphs) else args.steps + 8)
   ops.kv_profile_select(var, [dom])
-  sample_every = SAMPLE_EVERY if SAMPLE_EVERY > 0 else (2 if args.steps <= 24 else 8)
+  sample_every = SAMPLE_EVERY if SAMPLE_EVERY > 0 else (2 if args.steps <= 24 else 5 if args.steps <= 64 else 8)   # >= 8 launches timed
   ops.kv_profile_sample(var, sample_every)     # a pair of event markers costs ~4 us of stream time per launch
   barrier()
   t0 = time.perf_counter()
