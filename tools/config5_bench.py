@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--max-keys", type=float, default=4e6, help="cap of the log-uniform cardinalities (4e7 in the config)")
 ap.add_argument("--per-table", action="store_true", help="baseline: one op per table instead of the batched ops")
+ap.add_argument("--streams", type=int, default=1, help="the groups of same-shaped tables are independent: spread them over this many HIP streams")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(20250215)
@@ -41,8 +42,18 @@ for t in range(args.tables):
   grads = [torch.randn(args.batch, D, device=dev, generator=gen) * 1e-2 for _ in range(2)]
   groups.setdefault((opt, D), []).append((var, slots, ids, grads))
 
+streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
+
 def step(k):
-  for (opt, D), ms in groups.items():
+  for gi, ((opt, D), ms) in enumerate(groups.items()):
+    if streams:
+      with torch.cuda.stream(streams[gi % len(streams)]):
+        group_step(k, opt, ms)
+    else:
+      group_step(k, opt, ms)
+
+def group_step(k, opt, ms):
+  if True:
     vs = [m[0] for m in ms]; ids = [m[2][k % 4] for m in ms]; gr = [m[3][k % 2] for m in ms]
     if args.per_table:
       for m, i, g in zip(ms, ids, gr):
@@ -51,7 +62,7 @@ def step(k):
           ops.kv_variable_group_sparse_apply_adam_v4(m[0], m[1][0], g, i, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
         else:
           ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(m[0], m[1][0], m[1][1], g, i, 0.1, 0, 0, 0, 0, -0.5)
-      continue
+      return
     ops.kv_multi_gather_or_insert(vs, ids)
     if opt == "adam":
       ops.kv_multi_group_sparse_apply_adam(vs, [m[1][0] for m in ms], gr, ids, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0)
@@ -62,6 +73,6 @@ for k in range(6): step(k)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for k in range(args.steps): step(k)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
-print("%s: %d tables (%d groups), %d ids each, key space %.1f M: %.3f ms/step, %.1f M ids/s (lookup + apply)" % (
-    "per-table ops" if args.per_table else "batched ops", args.tables, len(groups), args.batch, total_keys / 1e6, dt * 1e3,
+print("%s%s: %d tables (%d groups), %d ids each, key space %.1f M: %.3f ms/step, %.1f M ids/s (lookup + apply)" % (
+    "per-table ops" if args.per_table else "batched ops", ", %d streams" % args.streams if streams else "", args.tables, len(groups), args.batch, total_keys / 1e6, dt * 1e3,
     args.tables * args.batch / dt / 1e6))
