@@ -220,6 +220,18 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
   return res
 
 
+def exchange_block(world, cap, D, distinct_per_batch, lossless, staged):
+  """The `exchange` object of a sharded line: what one rank puts on the wire per step.  Every peer gets one segment of
+  peer_capacity + 1 records per exchange — (id, count) pairs out, rows back, summed gradient rows out — whatever the
+  segment holds (fixed sizes: no size negotiation); a rank's own segment never leaves its buffers."""
+  seg = cap + 1
+  return {"exchanges_per_step": 3, "peer_capacity_records": cap, "lossless": bool(lossless),
+          "wire_bytes_per_rank_per_step": (world - 1) * seg * (16 + 2 * 4 * D),
+          "payload_bytes_per_rank_per_step_estimate": int((world - 1) / world * distinct_per_batch * (16 + 2 * 4 * D)),
+          "transport": "debug: host-staged through gloo (kv_comm_create_staged)" if staged else
+                       "grouped ncclSend / ncclRecv (RCCL) on the communicator's stream; a rank's own segment stays in place"}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +262,9 @@ def main():
                   help="the timed steps replay HIP graphs captured in overlap mode (one graph per pooled batch)")
   ap.add_argument("--lossless", action="store_true",
                   help="sharded path: keep the library's default lossless mode (capacity agreed before every exchange; a host round trip per lookup) instead of opting into the synchronisation-free mode")
+  ap.add_argument("--debug-capacity-skew", type=int, default=0,
+                  help="test hook: rank r creates its shard with peer_capacity + r * this (ranks that disagree must fail "
+                       "with FAILED_PRECONDITION at the first exchange, not hang)")
   ap.add_argument("--force-sharded", action="store_true",
                   help="run the all_to_all exchange path even with one rank (exercises the N > 1 code on one GPU)")
   args = ap.parse_args()
@@ -355,7 +370,7 @@ def main():
 
   state = {"b1p": np.float32(0.9), "b2p": np.float32(0.999)}
 
-  native_shard = shard_path and not one_gpu_debug
+  native_shard = shard_path   # (KV_BENCH_ONE_GPU=1: the same ops over a host-staged communicator)
 
   def peer_capacity():
     """The records one rank may send one owner per batch — a deployment constant: both ends of every send / recv
@@ -367,9 +382,15 @@ def main():
     return int(int(m.item()) / world * 1.25) + 1024
   if native_shard:
     # the production path: kvhip.h kv_shard_* over a kv_comm (RCCL grouped send / recv on its own stream; a world of
-    # one still goes through RCCL here so that --force-sharded prices the whole mechanism)
-    comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
-    cap = peer_capacity()
+    # one still goes through RCCL here so that --force-sharded prices the whole mechanism).
+    # Debugging mode (KV_BENCH_ONE_GPU=1): the SAME ops, every rank on cuda:0, over a communicator whose segments are
+    # staged through gloo on the host (kv_comm_create_staged; RCCL refuses two ranks on one device) — the agreement,
+    # verification and failure protocol of the N > 1 path run for real, only the wire differs.
+    if one_gpu_debug:
+      comm = ops.KvCommStaged(local)
+    else:
+      comm = ops.kv_comm_from_torch_distributed(local) if world > 1 else ops.KvComm(1, 0, ops.kv_comm_unique_id(), local)
+    cap = peer_capacity() + args.debug_capacity_skew * rank
     shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
     # the library's default is lossless (ranks agree on the capacity before every exchange: one all-reduce + one host
     # round trip per lookup); the bench sizes peer_capacity from its own batches (peer_capacity() above: cannot overflow)
@@ -382,20 +403,6 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.set_stream(comm_stream)
     stream = ctypes.c_void_p(comm_stream.cuda_stream)
-  elif shard_path:
-    # debugging mode (KV_BENCH_ONE_GPU=1): the same native phases, every rank on cuda:0, the fixed-size segments
-    # moved between the processes through gloo on the host (RCCL refuses two ranks on one device)
-    cap = peer_capacity()
-    shard = ops.KvShard(var, world, rank, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
-    hp_t = ctypes.c_float * 9
-    bufs = shard.buffers()
-
-    def xchg(what):
-      send, recv = (bufs["send_pairs"], bufs["recv_pairs"]) if what == 0 else (bufs["send_rows"], bufs["recv_rows"])
-      torch.cuda.synchronize()
-      o = torch.empty(send.numel(), dtype=torch.uint8)
-      dist.all_to_all_single(o, send.cpu())
-      recv.copy_(o)
 
   def teardown():
     """The library's communicator goes first (every rank past its last exchange), then torch's group."""
@@ -431,18 +438,11 @@ def main():
       _lib.check(L.kv_apply_group_adam_tok(var.ptr, slot.ptr, grad.data_ptr(), ids.data_ptr(), N, 1e-3,
                                            float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0,
                                            0.0, 4, tok.value if not args.no_token else 0, st))
-    elif native_shard:
+    else:
       # ids -> owners (grouped send / recv over xGMI) -> rows back; summed gradients -> owners -> fused apply
       _lib.check(L.kv_shard_lookup(shard.ptr, comm.ptr, ids.data_ptr(), N, out.data_ptr(), 1, stream))
       hp = hp_t(1e-3, float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
       _lib.check(L.kv_shard_apply(shard.ptr, comm.ptr, 0, slot.ptr, None, grad.data_ptr(), hp, 1, stream))
-    else:
-      _lib.check(L.kv_shard_lookup_route(shard.ptr, ids.data_ptr(), N, stream)); xchg(0)
-      _lib.check(L.kv_shard_lookup_serve(shard.ptr, stream)); xchg(1)
-      _lib.check(L.kv_shard_lookup_finish(shard.ptr, out.data_ptr(), stream))
-      _lib.check(L.kv_shard_apply_route(shard.ptr, grad.data_ptr(), stream)); xchg(1)
-      hp = hp_t(1e-3, float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
-      _lib.check(L.kv_shard_apply_serve(shard.ptr, 0, slot.ptr, None, hp, stream))
     state["b1p"] = np.float32(state["b1p"] * np.float32(0.9))      # TF-core Adam _finish
     state["b2p"] = np.float32(state["b2p"] * np.float32(0.999))
 
@@ -666,12 +666,7 @@ def main():
     res.pop("ops", None)
     # xGMI traffic is reported apart from HBM: three fixed-size exchanges per step, every rank sends
     # every peer one segment of peer_capacity + 1 records — (id, count) pairs, rows back, summed gradient rows
-    seg = cap + 1
-    res["exchange"] = {"exchanges_per_step": 3, "peer_capacity_records": cap, "lossless": bool(args.lossless),
-                       "wire_bytes_per_rank_per_step": (world - 1) * seg * (16 + 2 * 4 * D),
-                       "payload_bytes_per_rank_per_step_estimate": int((world - 1) / world * Ub * (16 + 2 * 4 * D)),
-                       "transport": "grouped ncclSend / ncclRecv (RCCL) on the communicator's stream; a rank's own "
-                                    "segment is a device copy" if native_shard else "debug: host-staged through gloo"}
+    res["exchange"] = exchange_block(world, cap, D, Ub, bool(args.lossless), one_gpu_debug)
   # the calibrated ceiling of this access pattern (tools/calib_r03.hip, profiles/r03_calibration.txt): 1 M random
   # 128-B rows of a table far larger than the caches are read at 4.9-5.6 TB/s on this chip, whatever their order
   RANDOM_ROW_CEILING_GBS = 5000.0

@@ -393,6 +393,18 @@ int kv_bucket_by_owner(kv_handle_t h, const void* ids, int64_t n, const int64_t*
 typedef struct kv_comm* kv_comm_t;
 int kv_comm_unique_id(void* id128);
 int kv_comm_create(int world, int rank, const void* id128, int device, kv_comm_t* out);
+/* A communicator whose exchanges the CALLER makes on the host (a rehearsal of the N > 1 control flow where RCCL cannot
+ * run: several ranks sharing one GPU, a CPU-side transport in a test).  Same ops, same agreement and failure protocol
+ * as over RCCL; the library synchronises its stream, then calls
+ *   exchange(user, send_dev, recv_dev, bytes_per_peer): segment p of send_dev to rank p, segment q of recv_dev from
+ *     rank q (device pointers, [world][bytes_per_peer]); returns 0 when the data has arrived;
+ *   max_u32(user, value): *value = the maximum of *value over all ranks (the lossless agreement); may be NULL when no
+ *     shard used with the communicator is lossless.
+ * Every rank must call the same ops in the same order, as with RCCL.  Never a measurement path. */
+typedef int (*kv_comm_exchange_fn)(void* user, const void* send_dev, void* recv_dev, int64_t bytes_per_peer);
+typedef int (*kv_comm_max_fn)(void* user, uint32_t* value);
+int kv_comm_create_staged(int world, int rank, kv_comm_exchange_fn exchange, kv_comm_max_fn max_u32, void* user,
+                          int device, kv_comm_t* out);
 int kv_comm_destroy(kv_comm_t comm);
 /* the communicator's stream: a caller that passes it as `stream` to kv_shard_lookup / kv_shard_apply (its other work
  * queued there too) pays no event hop into and out of the exchange */

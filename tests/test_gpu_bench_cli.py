@@ -68,3 +68,36 @@ def test_bench_launches_its_own_ranks():
   d = _line(r.stdout)
   assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 400000 and d["value"] > 0
   assert d["exchange"]["wire_bytes_per_rank_per_step"] > 0
+
+
+def _two_ranks(extra, timeout=600):
+  env = dict(os.environ, KV_BENCH_ONE_GPU="1")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  return subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--keys", "1000000",
+                         "--batch", "200000"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_lossless_agreement():
+  """The library's default mode on the N > 1 path: before every exchange the ranks agree on the capacity (here through
+  the staged communicator's max callback, over RCCL an all-reduce) — the same whole ops the real run calls."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  r = _two_ranks(["--lossless"])
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+  d = _line(r.stdout)
+  assert d["n_gpus"] == 2 and d["exchange"]["lossless"] is True and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_that_disagree_on_capacity_fail_fast():
+  """Ranks created with different peer_capacity must not hang in an exchange of mismatched sizes nor read each other's
+  padding: the first sharded op verifies {world, rank, capacity, dim, owner rule} across the ranks and every rank
+  fails with FAILED_PRECONDITION (kvhip.hip shard_verify)."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  r = _two_ranks(["--debug-capacity-skew", "7"], timeout=300)
+  assert r.returncode != 0
+  assert "peer_capacity" in r.stderr and "FailedPrecondition" in r.stderr, r.stderr[-2000:]
+  assert not [l for l in r.stdout.splitlines() if l.startswith("{")]   # no line from a run that did not happen

@@ -72,6 +72,7 @@ SIGNATURES = {
     "kv_bucket_by_owner": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kv_comm_unique_id": (_i32, [_vp]),
     "kv_comm_create": (_i32, [_i32, _i32, _vp, _i32, _c.POINTER(_vp)]),
+    "kv_comm_create_staged": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _c.POINTER(_vp)]),
     "kv_comm_destroy": (_i32, [_vp]),
     "kv_comm_stream": (_i32, [_vp, _c.POINTER(_vp)]),
     "kv_comm_all_to_all": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -131,6 +131,11 @@ struct WsDev {
   unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
   unsigned hc;             // entries per hot chunk
+  // ---- sharded path: a rank's OWN segment of an exchange is not copied from the send to the receive buffer: the
+  //      kernels that read a receive buffer read positions [self_lo, self_lo + self_len) from the send buffer instead
+  unsigned self_lo, self_len;   // (length 0: no such range; one unsigned compare: pos - self_lo < self_len)
+  const void* ids_self;         // k_ltile<IdCount>: the (id, count) records of that range (send_pairs)
+  const float* grad_self;       // k_tsum / k_papply: its gradient rows (send_rows)
   unsigned short* pos_ent; // [n] k_ltile: every input position's entry number in its tile (sharded route: the finish reads
                            // position -> entry -> record); nullptr: not filed
   // ---- bucket mode (kv_fused.h ltile_body<BUCKET>, kv_papply.h): the tiles append their entries to per-partition buckets

@@ -190,14 +190,17 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   for (int k = 0; k < IPT; ++k) {
     const long long i = base + (long long)k * TBT + tid;
     if (i < n) there |= 1u << k;
-    kreg[k] = load_id(ids, (size_t)(i < n ? i : n - 1));
+    const long long ic = i < n ? i : n - 1;
+    if constexpr (PAIRS) kreg[k] = load_id(((unsigned)ic - w.self_lo < w.self_len) ? static_cast<const IdT*>(w.ids_self) : ids, (size_t)ic);
+    else kreg[k] = load_id(ids, (size_t)ic);
     creg[k] = 1;
   }
   if constexpr (PAIRS) {
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
       const long long i = base + (long long)k * TBT + tid;
-      const long long ci = ids[i < n ? i : n - 1].count;
+      const long long ic = i < n ? i : n - 1;
+      const long long ci = (((unsigned)ic - w.self_lo < w.self_len) ? static_cast<const IdT*>(w.ids_self) : ids)[ic].count;
       creg[k] = (unsigned)(unsigned short)(ci < 65535 ? ci : 65535);
     }
   } else if (counts != nullptr) {
@@ -231,7 +234,8 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
       bool ok = creg[k] != 0u;
       if (ok && w.seg_cap) {   // fixed-capacity exchange segments: record 0 is the header, records past its count are stale
         const long long r = i % w.seg_cap;
-        ok = r >= 1 && r <= ids[i - r].id;
+        const long long ih = i - r;   // the segment's header
+        ok = r >= 1 && r <= (((unsigned)ih - w.self_lo < w.self_len) ? static_cast<const IdT*>(w.ids_self) : ids)[ih].id;
       }
       if (!ok) there &= ~(1u << k);
     }
@@ -634,7 +638,8 @@ __global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* _
 template <int VQ, int CW = 4>
 __global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
                                                      const int* __restrict__ slot_of, const float* __restrict__ rows,
-                                                     float* __restrict__ out, long long n, int dim) {
+                                                     float* __restrict__ out, long long n, int dim,
+                                                     const float* __restrict__ rows_self, unsigned self_lo, unsigned self_len) {
   constexpr int RW = 64 / VQ;
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
@@ -656,7 +661,8 @@ __global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __res
 #pragma unroll
       for (int j = 0; j < CW && j0 + j < VQ; ++j) rj[j] = __shfl(rec, (j0 + j) * RW + sub);
 #pragma unroll
-      for (int j = 0; j < CW && j0 + j < VQ; ++j) val[j] = reinterpret_cast<const float4*>(rows + (size_t)rj[j] * dim)[vv];
+      for (int j = 0; j < CW && j0 + j < VQ; ++j)   // (records [self_lo, self_lo + self_len): this rank's own segment, read where the serve wrote it)
+        val[j] = reinterpret_cast<const float4*>((((unsigned)rj[j] - self_lo < self_len) ? rows_self : rows) + (size_t)rj[j] * dim)[vv];
 #pragma unroll
       for (int j = 0; j < CW && j0 + j < VQ; ++j) {
         const long long ii = r0 + (j0 + j) * RW + sub;
@@ -1135,6 +1141,8 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
   const unsigned* const mrow_g = w.mrow + (size_t)tile * TILE;   // (two pointers: a select between LDS and global memory
                                                                  //  would make every read a flat load)
   const float* g0 = grad + (size_t)tile * TILE * D;
+  const float* g0s = w.grad_self + (size_t)tile * TILE * D;   // (only dereferenced for positions inside the self range)
+  const unsigned tbase = tile * (unsigned)TILE;
   float* ep = w.epart + (size_t)tile * (TILE / 2) * D;
   const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR, wv = threadIdx.x >> 6;
   int eoff[K];   // a lane past the row's end reads element 0 instead of branching around the load
@@ -1170,7 +1178,7 @@ __device__ __forceinline__ void tsum_body(const WsDev& w, const float* __restric
     float val[RB][K][V];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const float* src = g0 + (size_t)(mw[i] & 0x7FFu) * D;
+      const float* src = ((tbase + (mw[i] & 0x7FFu) - w.self_lo < w.self_len) ? g0s : g0) + (size_t)(mw[i] & 0x7FFu) * D;
 #pragma unroll
       for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], val[i][k]);
     }

@@ -334,7 +334,10 @@ struct PartArgs {
   long long* route_seg;            // [world][C + 1][2] (id, count) records
   int* route_slot_of;              // [number] the record the id went to (0: no room)
   unsigned* route_overflow;        // pinned flag: a segment was too small
-  unsigned* route_gcount;          // [world] records per owner so far (k_seg_headers_take reads and clears them)
+  unsigned* route_gcount;          // [MAXW + 1] records per owner so far; [MAXW]: blocks of the launch that are done
+  unsigned* route_need;            // != nullptr: the LAST block of the launch writes the segments' headers, the largest segment
+                                   // wanted (here) and clears the counters — what k_seg_headers_take does in its own launch
+  unsigned* route_uhint;           // pinned host word (may be null): the batch's distinct ids
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)

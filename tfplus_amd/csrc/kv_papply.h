@@ -357,12 +357,13 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     const int wl = (int)(tid2 & 63u), lane = wl % LPR, g = wl / LPR;
     const float* const gbase = a.grad;
     const float* const ebase = a.epart;
+    const float* const gself = w.grad_self;   // gradient rows of the positions in the self range (sharded owner apply)
     int eoff[K];
     bool evalid[K];
   #pragma unroll
     for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; evalid[k] = e0 < D; eoff[k] = evalid[k] ? e0 : 0; }
     auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
-      const float* base = (pos & EP_TAG) ? ebase : gbase;
+      const float* base = (pos & EP_TAG) ? ebase : (pos - w.self_lo < w.self_len) ? gself : gbase;
       const float* src = base + (size_t)(pos & ~EP_TAG) * D;
   #pragma unroll
       for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
@@ -696,8 +697,45 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   if (tid == 0 && mode != PA_NONE && mode != PA_DEDUP) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
 }
 
+// The sharded route (PA_UNIQUE with route_need set): the block that finishes LAST writes every segment's header {records,
+// 0}, the largest segment any owner was asked for and the batch's distinct ids, and clears the counters for the next
+// launch — k_seg_headers_take without its launch.  Every block comes through here, whatever its partition held.
+__device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int mode_) {
+  if ((mode_ & 0xFF) != PA_UNIQUE || a.route_world <= 0 || a.route_need == nullptr) return;   // (uniform over the launch)
+  // No fence: the block's adds to the owners' counters are RETURNING device-scope atomics (their values place the
+  // block's records), so they have been performed when the barrier below is passed, before the block reports; the
+  // last block reads the counters with device-scope atomic loads.  (A __threadfence() per thread here is a write-back
+  // and an invalidate of the XCD's L2 per wave on this chip: it cost the route 100 us.)
+  __shared__ unsigned rt_last, rt_tot, rt_max;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rt_last = __hip_atomic_fetch_add(&a.route_gcount[MAXW], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    rt_tot = 0u; rt_max = 0u;
+  }
+  __syncthreads();
+  if (!rt_last) return;
+  const int d = (int)threadIdx.x;
+  if (d < a.route_world) {
+    const unsigned c = __hip_atomic_load(&a.route_gcount[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.route_gcount[d], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.route_seg[2 * (size_t)d * (a.route_C + 1)] = c < a.route_C ? c : a.route_C;
+    a.route_seg[2 * (size_t)d * (a.route_C + 1) + 1] = 0;
+    atomicMax(&rt_max, c);
+    atomicAdd(&rt_tot, c);
+  }
+  __syncthreads();
+  if (d == 0) {
+    __hip_atomic_store(&a.route_gcount[MAXW], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *a.route_need = rt_max;
+    if (a.route_uhint) __hip_atomic_store(a.route_uhint, rt_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <int OPT, int V, int LPR, int K, int TBP>
-__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) { papply_body<OPT, V, LPR, K, TBP>(w, a, mode); }
+__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) {
+  papply_body<OPT, V, LPR, K, TBP>(w, a, mode);
+  papply_route_tail(a, mode);
+}
 
 // many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array; grid.x = the largest table's partitions)
 template <int OPT, int V, int LPR, int K>

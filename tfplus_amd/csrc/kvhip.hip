@@ -678,6 +678,18 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
 bool papply_enabled();
 bool fused_ok(int D);
 
+// The sharded owner ops (kv_shard_lookup_serve / kv_shard_apply_serve) read a rank's OWN exchange segment where it was
+// written: records [lo, lo + len) of the buffers the calling thread's next op on `table` reads come from `ids` / `grad`
+// (the send buffers) instead.  Per thread, so another thread's op on the same table sees nothing of it.
+struct SelfSegment { const kv_table* table = nullptr; unsigned lo = 0, len = 0; const void* ids = nullptr; const float* grad = nullptr; };
+static thread_local SelfSegment tl_self;
+struct SelfScope {
+  SelfScope(const kv_table* t, bool on, unsigned lo, unsigned len, const void* ids, const float* grad) {
+    if (on) { tl_self.table = t; tl_self.lo = lo; tl_self.len = len; tl_self.ids = ids; tl_self.grad = grad; }
+  }
+  ~SelfScope() { tl_self = SelfSegment{}; }
+};
+
 WsDev ws_view(kv_table* t, long long n) {
   Workspace& w = t->ws;
   WsDev d;
@@ -707,6 +719,8 @@ WsDev ws_view(kv_table* t, long long n) {
   // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
   d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
   d.pos_ent = nullptr;
+  if (tl_self.table == t) { d.self_lo = tl_self.lo; d.self_len = tl_self.len; d.ids_self = tl_self.ids; d.grad_self = tl_self.grad; }
+  else { d.self_lo = d.self_len = 0; d.ids_self = nullptr; d.grad_self = nullptr; }
   d.bkt = w.bkt;
   d.bcap = t->index_bcap;
   d.bcnt = w.bcnt ? w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE : nullptr;
@@ -1130,7 +1144,9 @@ int flush_part(kv_table* t, hipStream_t s) {
     launch_ltile(t, pa.tv, wd, t->ws.ids_copy, nullptr, pa.n, nullptr, s, -1);
   }
   ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-  if (wd.bcap != 0u) {   // a bucketed index: k_papply is its partition pass — here the lookup's bookkeeping alone
+  // (a sharded owner lookup whose own segment stays in the send buffers: the apply that may still follow must be
+  //  k_papply's — PA_NONE over the entries — because only the entry-list kernels read that segment in place)
+  if (wd.bcap != 0u || wd.self_len != 0u) {   // a bucketed index: k_papply is its partition pass — here the lookup's bookkeeping alone
     pa.day_lk = pa.day;
     const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_LOOKUP | PA_NOAPPLY, (void*)s);
     if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
@@ -3197,7 +3213,13 @@ struct kv_comm {
   int world = 1, rank = 0, device = 0;
   hipStream_t stream = nullptr;      // the collectives' own stream
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // host-staged transport (kv_comm_create_staged): the caller's callbacks move the segments
+  kv_comm_exchange_fn xfn = nullptr;
+  kv_comm_max_fn mfn = nullptr;
+  void* user = nullptr;
 };
+// the segments really travel (RCCL or the caller's transport); else: a world of one whose exchange is a device copy
+static inline bool wired(const kv_comm* c) { return c->comm != nullptr || c->xfn != nullptr; }
 
 struct kv_shard {
   kv_table* table = nullptr;         // this rank's share of the rows
@@ -3224,6 +3246,7 @@ struct kv_shard {
   unsigned long long grows = 0;      // times the capacity was raised
   long long n_last = 0;              // ids of the batch whose index `route` holds
   bool ordered = false;              // ... and whether its positions are filed (order, work items) yet
+  bool self_in_place = false;        // this rank's own segments are read from the send buffers (no device copy in the exchange)
   bool route_fused = false;          // ... and whether it is an entry-list index (k_ltile<NOTABLE> + k_papply PA_UNIQUE), not a sorted position list
   const kv_comm* verified = nullptr; // the communicator whose ranks were seen to agree on world / capacity / dim
   uint64_t route_token = 0;
@@ -3288,6 +3311,24 @@ int kv_comm_create(int world, int rank, const void* id128, int device, kv_comm_t
   return KV_OK;
 }
 
+int kv_comm_create_staged(int world, int rank, kv_comm_exchange_fn exchange, kv_comm_max_fn max_u32, void* user, int device,
+                          kv_comm_t* out) {
+  if (!out || !exchange || world < 1 || world > MAXW || rank < 0 || rank >= world)
+    return fail(KV_INVALID_ARGUMENT, "kv_comm_create_staged: world %d rank %d", world, rank);
+  DeviceGuard dg(device);
+  kv_comm* c = new kv_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  c->xfn = exchange; c->mfn = max_u32; c->user = user;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) {
+    kv_comm_destroy(c);
+    return fail(KV_INTERNAL, "kv_comm_create_staged: stream / events");
+  }
+  *out = c;
+  return KV_OK;
+}
+
 int kv_comm_stream(kv_comm_t c, kv_stream_t* stream) {
   if (!c || !stream) return fail(KV_INVALID_ARGUMENT, "kv_comm_stream: null argument");
   *stream = (kv_stream_t)c->stream;
@@ -3310,10 +3351,21 @@ int kv_comm_destroy(kv_comm_t c) {
 // link), on the communicator's own stream, behind everything `stream` was given and in front of what it gets next.
 // nseg buffers (the tables of a multi-table step) go out in ONE group: RCCL runs a group's sends and receives as one
 // launch, so 40 tables cost one exchange, not 40.
-static int comm_exchange(kv_comm* c, int nseg, const void* const* sends, void* const* recvs, const int64_t* bytes_per_peer, hipStream_t s) {
+// skip_self[k] (may be null): segment k of this rank is read from its send buffer by the kernels themselves
+static int comm_exchange(kv_comm* c, int nseg, const void* const* sends, void* const* recvs, const int64_t* bytes_per_peer, hipStream_t s,
+                         const char* skip_self = nullptr) {
+  if (c->xfn) {   // the caller's transport: everything queued so far has run, then the segments move on the host's clock
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < nseg; ++k) {
+      const int r = c->xfn(c->user, sends[k], recvs[k], bytes_per_peer[k]);
+      if (r) return fail(KV_INTERNAL, "the staged exchange failed (callback returned %d)", r);
+    }
+    return KV_OK;
+  }
   if (!c->comm) {   // world of one without RCCL
     for (int k = 0; k < nseg; ++k)
-      HIP_TRY(hipMemcpyAsync(recvs[k], sends[k], (size_t)bytes_per_peer[k], hipMemcpyDeviceToDevice, s));
+      if (!(skip_self && skip_self[k]))
+        HIP_TRY(hipMemcpyAsync(recvs[k], sends[k], (size_t)bytes_per_peer[k], hipMemcpyDeviceToDevice, s));
     return KV_OK;
   }
   const bool hop = s != c->stream;   // the sharded ops run on the communicator's stream themselves: no hop
@@ -3327,7 +3379,8 @@ static int comm_exchange(kv_comm* c, int nseg, const void* const* sends, void* c
   static const bool self_rccl = [] { const char* e = getenv("KV_COMM_SELF_VIA_RCCL"); return e && e[0] == '1'; }();
   if (!self_rccl)
     for (int k = 0; k < nseg; ++k)
-      HIP_TRY(hipMemcpyAsync((char*)recvs[k] + (size_t)c->rank * bytes_per_peer[k], (const char*)sends[k] + (size_t)c->rank * bytes_per_peer[k],
+      if (!(skip_self && skip_self[k]))
+        HIP_TRY(hipMemcpyAsync((char*)recvs[k] + (size_t)c->rank * bytes_per_peer[k], (const char*)sends[k] + (size_t)c->rank * bytes_per_peer[k],
                              (size_t)bytes_per_peer[k], hipMemcpyDeviceToDevice, c->stream));
   const bool grouped = c->world > 1 || self_rccl;
   if (grouped) NCCL_TRY(rccl()->GroupStart());
@@ -3441,6 +3494,20 @@ static int shard_late_report(kv_shard* sh, unsigned seen) {
                                      "create the shards with a larger peer_capacity on every rank", sh->C);
 }
 
+static bool shard_old_route() {
+  static const bool old_route = [] { const char* e = getenv("KV_SHARD_OLD_ROUTE"); return e && atoi(e) != 0; }();
+  return old_route;
+}
+// The whole-op entry points (kv_shard_lookup / kv_shard_apply / kv_multi_shard_*) do the exchanges themselves, so they
+// may leave this rank's own segments where they are: every kernel that reads a receive buffer downstream (the owner
+// lookup's tile pass, the finish, the owner apply's tile sums and k_papply) takes records [rank * (C + 1), +C + 1)
+// from the send buffer.  Only the entry-list kernels know how; KV_SHARD_SELF_COPY=1 keeps the three copies (A/B).
+static bool shard_can_stay(const kv_shard* sh) {
+  static const bool copy = [] { const char* e = getenv("KV_SHARD_SELF_COPY"); return e && atoi(e) != 0; }();
+  return !copy && !shard_old_route() && papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap &&
+         (long long)sh->world * (sh->C + 1) <= FUSED_MAX_N;
+}
+
 // ids -> local unique ids with counts -> the owners' segments of the send buffer.  4 launches, no host sync.
 static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
   if (!sh || (n > 0 && !ids) || n < 0 || n > sh->max_ids) return fail(KV_INVALID_ARGUMENT, "kv_shard_lookup_route: n %lld (max %lld)", (long long)n, sh ? sh->max_ids : 0ll);
@@ -3464,8 +3531,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   // a table-less tile pass (k_ltile<NOTABLE>: entries, mrow, every position's entry number) and k_papply in PA_UNIQUE
   // mode (the distinct ids numbered, uniq / ucnt written, every entry learns its id's number).  The finish then reads
   // position -> entry -> number -> record, the gradient pre-sum is k_tsum + k_papply PA_DEDUP.
-  static const bool old_route = [] { const char* e = getenv("KV_SHARD_OLD_ROUTE"); return e && atoi(e) != 0; }();
-  const bool fused_route = !old_route && papply_enabled() && fused_ok(rt->dim);
+  const bool fused_route = !shard_old_route() && papply_enabled() && fused_ok(rt->dim);
   sh->route_fused = fused_route;
   PartArgs pa{};
   pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
@@ -3496,6 +3562,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
     if (!pa.det) {   // the numbered ids go straight to their owners' segments (the deterministic mode keeps the ordered scatter below)
       pa.route_world = sh->world; pa.route_rule = sh->rule; pa.route_C = sh->C;
       pa.route_seg = sh->send_pairs; pa.route_slot_of = sh->slot_of; pa.route_overflow = sh->overflow; pa.route_gcount = sh->gcount;
+      pa.route_need = sh->need; pa.route_uhint = sh->overflow + 1;   // (the launch's last block writes the headers: no k_seg_headers_take)
     }
     if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_UNIQUE | PA_NOAPPLY, (void*)s))) return fail(rc, "route: no kernel for dim %d", rt->dim);
   } else {
@@ -3524,7 +3591,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
     if (!fused_route)
       k_owner_route_fixed<<<ntr, TB, 0, s>>>(sh->uniq, sh->ucnt, (long long)n, sh->world, sh->rule, sh->C, sh->send_pairs, sh->slot_of,
                                              sh->overflow, sh->gcount);
-    k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need, sh->overflow + 1);
+    if (!fused_route) k_seg_headers_take<<<1, MAXW, 0, s>>>(sh->gcount, sh->world, sh->C, sh->send_pairs, sh->need, sh->overflow + 1);
     HIP_TRY(hipGetLastError());
     return KV_OK;
   }
@@ -3540,6 +3607,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
 int kv_shard_lookup_route(kv_shard_t sh, const void* ids, int64_t n, kv_stream_t stream) {
   int rc;
   const unsigned seen = sh ? shard_take_flag(sh) : 0u;
+  if (sh) sh->self_in_place = false;   // the caller makes the exchanges: all segments, its own included, arrive in the receive buffers
   if ((rc = lookup_route_impl(sh, ids, n, stream))) return rc;
   return shard_late_report(sh, seen);
 }
@@ -3550,6 +3618,7 @@ int kv_shard_lookup_serve(kv_shard_t sh, kv_stream_t stream) {
   if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
   const int64_t nrec = (int64_t)sh->world * (sh->C + 1);
   sh->serve_token = 0;
+  SelfScope self(sh->table, sh->self_in_place, (unsigned)sh->rank * (sh->C + 1), sh->C + 1, sh->send_pairs, nullptr);
   return gather_or_insert_impl(sh->table, sh->recv_pairs, nullptr, nrec, sh->send_rows, stream, 1, &sh->serve_token, sh->C + 1);
 }
 
@@ -3568,7 +3637,9 @@ int kv_shard_lookup_finish(kv_shard_t sh, float* out, kv_stream_t stream) {
     const int q = row_lanes(rt->dim);
     const int grid = nblocks(sh->n_last, TB, 8192);
     hipStream_t st = (hipStream_t)stream;
-#define KV_SF(VQ) k_shard_finish<VQ><<<grid, TB, 0, st>>>(rt->ws.pos_ent, rt->ws.ent_b, sh->slot_of, sh->recv_rows, out, sh->n_last, rt->dim)
+    const unsigned slo = (unsigned)sh->rank * (sh->C + 1), slen = sh->self_in_place ? sh->C + 1 : 0u;
+#define KV_SF(VQ) k_shard_finish<VQ><<<grid, TB, 0, st>>>(rt->ws.pos_ent, rt->ws.ent_b, sh->slot_of, sh->recv_rows, out, sh->n_last, rt->dim, \
+                                                          sh->send_rows, slo, slen)
     switch (q) {
       case 1: KV_SF(1); break;   case 2: KV_SF(2); break;   case 4: KV_SF(4); break;   case 8: KV_SF(8); break;
       case 16: KV_SF(16); break; case 32: KV_SF(32); break; default: KV_SF(64); break;
@@ -3648,6 +3719,7 @@ int kv_shard_apply_serve(kv_shard_t sh, int optimizer, kv_handle_t slot0, kv_han
     return fail(KV_FAILED_PRECONDITION, "kv_shard_apply_serve: another op used the table since this batch's lookup "
                                         "(the sharded apply takes over the lookup's index)");
   const int64_t nrec = (int64_t)sh->world * (sh->C + 1);
+  SelfScope self(sh->table, sh->self_in_place, (unsigned)sh->rank * (sh->C + 1), sh->C + 1, sh->send_pairs, sh->send_rows);
   switch (optimizer) {
     case 0: case 1:
       return kv_apply_group_adam_tok(sh->table, slot0, sh->recv_rows, sh->recv_pairs, nrec, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5],
@@ -3669,6 +3741,9 @@ int kv_shard_join(kv_shard_t sh, kv_stream_t stream) {
   DeviceGuard dg(sh->table->device);
   HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sh->ev_done, 0));
   return KV_OK;
+}
+static int shard_exchange_one(kv_comm* comm, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t w, char stay) {
+  return comm_exchange(comm, 1, &send, &recv, &bytes_per_peer, w, &stay);
 }
 static int shard_fork(kv_shard* sh, hipStream_t s, hipStream_t work) {
   if (s == work) return KV_OK;   // the caller works on the communicator's stream itself: one queue, no hops
@@ -3698,13 +3773,13 @@ static int shard_verify(kv_shard* sh, kv_comm* comm) {
   int rc = KV_OK;
   do {
     if (hipMemcpy(ds, mine.data(), mine.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(KV_INTERNAL, "kv_shard: copy"); break; }
-    if ((rc = kv_comm_all_to_all(comm, ds, dr, comm->comm ? 32 : 32 * W, comm->stream))) break;
+    if ((rc = kv_comm_all_to_all(comm, ds, dr, wired(comm) ? 32 : 32 * W, comm->stream))) break;
     if (hipStreamSynchronize(comm->stream) != hipSuccess || hipMemcpy(theirs.data(), dr, theirs.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
       rc = fail(KV_INTERNAL, "kv_shard: the first exchange failed");
       break;
     }
     for (int p = 0; p < W && !rc; ++p) {
-      if ((theirs[4 * p] >> 32) != W || (int)(theirs[4 * p] & 0xFFFFFFFF) != (comm->comm ? p : sh->rank))
+      if ((theirs[4 * p] >> 32) != W || (int)(theirs[4 * p] & 0xFFFFFFFF) != (wired(comm) ? p : sh->rank))
         rc = fail(KV_FAILED_PRECONDITION, "kv_shard: rank %d of the communicator is not shard %d of a world of %d", p, p, W);
       else if (theirs[4 * p + 1] != (long long)sh->C || theirs[4 * p + 2] != sh->table->dim || theirs[4 * p + 3] != sh->rule)
         rc = fail(KV_FAILED_PRECONDITION, "kv_shard: rank %d was created with peer_capacity %lld, dim %lld, owner rule %lld; this "
@@ -3741,6 +3816,16 @@ static int shard_agree_many(const kv_shard_t* shards, int ntab, kv_comm* comm, h
     if (shards[k]->lossless)
       HIP_TRY(hipMemcpyAsync(shards[k]->need_host, shards[k]->need + (comm->comm ? 1 : 0), sizeof(unsigned), hipMemcpyDeviceToHost, w));
   HIP_TRY(hipStreamSynchronize(w));
+  if (comm->xfn && comm->world > 1) {   // the caller's transport: the maximum over the ranks, table by table
+    if (!comm->mfn) return fail(KV_UNIMPLEMENTED, "lossless sharding over a staged communicator needs its max_u32 callback");
+    for (int k = 0; k < ntab; ++k)
+      if (shards[k]->lossless) {
+        uint32_t v = *shards[k]->need_host;
+        const int r = comm->mfn(comm->user, &v);
+        if (r) return fail(KV_INTERNAL, "the staged agreement failed (callback returned %d)", r);
+        *shards[k]->need_host = v;
+      }
+  }
   for (int k = 0; k < ntab; ++k) {
     kv_shard* sh = shards[k];
     if (!sh->lossless) continue;
@@ -3805,6 +3890,8 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   int first = KV_OK;
   std::string first_msg;
   auto note = [&](int r) { if (r && !first) { first = r; first_msg = kv_last_error(); } return r; };
+  sh->self_in_place = shard_can_stay(sh);
+  char stay = sh->self_in_place ? 1 : 0;
   if (note(lookup_route_impl(sh, ids, n, w))) {
     sh->n_last = 0; sh->route_token = 0;
     HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
@@ -3815,6 +3902,7 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
     if ((rc = shard_agree_many(&sh, 1, comm, w, &grown))) return rc;
     if (grown) {
       pb = (int64_t)(sh->C + 1) * 16; rb = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float);
+      stay = (sh->self_in_place = shard_can_stay(sh)) ? 1 : 0;   // (the record count changed)
       if (!first && note(lookup_route_impl(sh, ids, n, w))) { sh->n_last = 0; sh->route_token = 0; }
       if (first) {   // this rank's batch was refused: its segments are void in the new buffers too
         HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
@@ -3822,10 +3910,10 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
       }
     }
   }
-  if ((rc = kv_comm_all_to_all(comm, sh->send_pairs, sh->recv_pairs, comm->comm ? pb : pb * sh->world, w))) return rc;
+  if ((rc = shard_exchange_one(comm, sh->send_pairs, sh->recv_pairs, wired(comm) ? pb : pb * sh->world, w, stay))) return rc;
   if (note(kv_shard_lookup_serve(sh, w)))
     HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
-  if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
+  if ((rc = shard_exchange_one(comm, sh->send_rows, sh->recv_rows, wired(comm) ? rb : rb * sh->world, w, stay))) return rc;
   if (!first) note(kv_shard_lookup_finish(sh, out, w));
   if ((rc = shard_done(sh, s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchanges were queued all the same)", first_msg.c_str());
@@ -3848,7 +3936,7 @@ int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slo
     first_msg = kv_last_error();
     HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
   }
-  if ((rc = kv_comm_all_to_all(comm, sh->send_rows, sh->recv_rows, comm->comm ? rb : rb * sh->world, w))) return rc;
+  if ((rc = shard_exchange_one(comm, sh->send_rows, sh->recv_rows, wired(comm) ? rb : rb * sh->world, w, sh->self_in_place ? 1 : 0))) return rc;
   rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w);
   if (rc && !first) { first = rc; first_msg = kv_last_error(); }
   if ((rc = shard_done(sh, s, w, join))) return rc;
@@ -3887,10 +3975,11 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   std::vector<const void*> sp(ntab), sr(ntab);
   std::vector<void*> rp(ntab), rr(ntab);
   std::vector<int64_t> pb(ntab), rb(ntab);
-  std::vector<char> routed(ntab, 1);
+  std::vector<char> routed(ntab, 1), stay(ntab, 0);
+  for (int k = 0; k < ntab; ++k) stay[k] = (shards[k]->self_in_place = shard_can_stay(shards[k])) ? 1 : 0;
   auto buffers = [&](int k) {
     kv_shard* sh = shards[k];
-    const int64_t mul = comm->comm ? 1 : sh->world;
+    const int64_t mul = wired(comm) ? 1 : sh->world;
     pb[k] = (int64_t)(sh->C + 1) * 16 * mul;
     rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * mul;
     sp[k] = sh->send_pairs; rp[k] = sh->recv_pairs; sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
@@ -3914,15 +4003,16 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
     if ((rc = shard_agree_many(shards, ntab, comm, w, grown.data()))) return rc;
     for (int k = 0; k < ntab; ++k)
       if (grown[k]) {
+        stay[k] = (shards[k]->self_in_place = shard_can_stay(shards[k])) ? 1 : 0;
         buffers(k);
         if ((rc = route(k))) return rc;
       }
   }
-  if ((rc = comm_exchange(comm, ntab, sp.data(), rp.data(), pb.data(), w))) return rc;
+  if ((rc = comm_exchange(comm, ntab, sp.data(), rp.data(), pb.data(), w, stay.data()))) return rc;
   for (int k = 0; k < ntab; ++k)
     if (note(kv_shard_lookup_serve(shards[k], w)))
-      HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (comm->comm ? shards[k]->world : 1), w));
-  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w))) return rc;
+      HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (wired(comm) ? shards[k]->world : 1), w));
+  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
   for (int k = 0; k < ntab; ++k)
     if (routed[k]) note(kv_shard_lookup_finish(shards[k], outs[k], w));
   if ((rc = shard_done(shards[0], s, w, join))) return rc;
@@ -3947,14 +4037,16 @@ int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int
   std::vector<const void*> sr(ntab);
   std::vector<void*> rr(ntab);
   std::vector<int64_t> rb(ntab);
+  std::vector<char> stay(ntab, 0);
   for (int k = 0; k < ntab; ++k) {
     kv_shard* sh = shards[k];
-    rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * (comm->comm ? 1 : sh->world);
+    stay[k] = sh->self_in_place ? 1 : 0;
+    rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * (wired(comm) ? 1 : sh->world);
     sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
     if (note(kv_shard_apply_route(sh, grads[k], w)))
-      HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb[k] * (comm->comm ? sh->world : 1), w));
+      HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb[k] * (wired(comm) ? sh->world : 1), w));
   }
-  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w))) return rc;
+  if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
   for (int k = 0; k < ntab; ++k)
     note(kv_shard_apply_serve(shards[k], optimizer, slot0[k], slot1 ? slot1[k] : nullptr, hp, w));
   if ((rc = shard_done(shards[0], s, w, join))) return rc;

@@ -762,6 +762,60 @@ class KvComm(object):
       pass
 
 
+class KvCommStaged(KvComm):
+  """A communicator whose segments travel through a torch.distributed group on the HOST (kvhip.h
+  kv_comm_create_staged): the library synchronises its stream and calls back; the segments go device -> host ->
+  all_to_all_single (gloo) -> device.  For rehearsing the N > 1 ops where RCCL cannot run (ranks sharing one GPU);
+  never a measurement path."""
+
+  _XFN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+  _MFN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32))
+
+  def __init__(self, device=0, group=None):
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", device)
+    self.exchanges = 0
+
+    class _Raw(object):
+      def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def exchange(_user, send, recv, per_peer):
+      try:
+        n = int(per_peer) * world
+        if n == 0:
+          return 0
+        src = torch.as_tensor(_Raw(send, n), device=dev).cpu()
+        dst = torch.empty(n, dtype=torch.uint8)
+        dist.all_to_all_single(dst, src, group=group)
+        torch.as_tensor(_Raw(recv, n), device=dev).copy_(dst)
+        torch.cuda.synchronize(dev)
+        self.exchanges += 1
+        return 0
+      except Exception:   # an exception cannot cross the C frames: the op reports KV_INTERNAL
+        import traceback
+        traceback.print_exc()
+        return 1
+
+    def max_u32(_user, value):
+      try:
+        t = torch.tensor([int(value[0])], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        value[0] = int(t.item())
+        return 0
+      except Exception:
+        import traceback
+        traceback.print_exc()
+        return 1
+
+    self._cb = (self._XFN(exchange), self._MFN(max_u32))   # kept alive as long as the communicator
+    self.ptr = ctypes.c_void_p()
+    _lib.check(_lib.lib().kv_comm_create_staged(int(world), int(rank), ctypes.cast(self._cb[0], ctypes.c_void_p),
+                                                ctypes.cast(self._cb[1], ctypes.c_void_p), None, int(device), ctypes.byref(self.ptr)))
+    self.world, self.rank = world, rank
+
+
 def kv_comm_unique_id():
   buf = ctypes.create_string_buffer(128)
   _lib.check(_lib.lib().kv_comm_unique_id(buf))
