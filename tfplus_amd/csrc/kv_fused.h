@@ -588,8 +588,14 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
           const long long ii = r0 + (j0 + j) * RW + sub;
           if (ii < n && vlive) {
             float4* dst = reinterpret_cast<float4*>(out + (size_t)ii * t.dim) + v;
-            __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
-            __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+            if constexpr (PAIRS) {
+              // the sharded owner lookup: its rows are read again at once — by the finish of this rank's own segment, which
+              // stays in this buffer, and by the exchange — so they are kept in the caches (k_shard_finish 40.9 -> 25 us)
+              *dst = val[j];
+            } else {
+              __builtin_nontemporal_store(val[j].x, &dst->x); __builtin_nontemporal_store(val[j].y, &dst->y);
+              __builtin_nontemporal_store(val[j].z, &dst->z); __builtin_nontemporal_store(val[j].w, &dst->w);
+            }
           }
         }
       };
