@@ -642,10 +642,10 @@ __global__ void __launch_bounds__(TBT) k_ltile(TableDev t, WsDev w, const IdT* _
 // -> the row the owner returned.  A wave takes 64 positions, lane l resolves position l, the rows go VQ lanes per row
 // with streaming stores (the copy of goz_wave).
 template <int VQ, int CW = 4>
-__global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
-                                                     const int* __restrict__ slot_of, const float* __restrict__ rows,
-                                                     float* __restrict__ out, long long n, int dim,
-                                                     const float* __restrict__ rows_self, unsigned self_lo, unsigned self_len) {
+__device__ __forceinline__ void shard_finish_body(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
+                                                  const int* __restrict__ slot_of, const float* __restrict__ rows,
+                                                  float* __restrict__ out, long long n, int dim,
+                                                  const float* __restrict__ rows_self, unsigned self_lo, unsigned self_len) {
   constexpr int RW = 64 / VQ;
   const int lane = threadIdx.x & 63;
   const int v = lane % VQ, sub = lane / VQ;
@@ -680,6 +680,30 @@ __global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __res
       }
     }
   }
+}
+template <int VQ, int CW = 4>
+__global__ void __launch_bounds__(TB) k_shard_finish(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_u,
+                                                     const int* __restrict__ slot_of, const float* __restrict__ rows,
+                                                     float* __restrict__ out, long long n, int dim,
+                                                     const float* __restrict__ rows_self, unsigned self_lo, unsigned self_len) {
+  shard_finish_body<VQ, CW>(pos_ent, ent_u, slot_of, rows, out, n, dim, rows_self, self_lo, self_len);
+}
+// several tables of one row geometry in one launch (blockIdx.y = table)
+struct FinishDesc {
+  const unsigned short* pos_ent;
+  const unsigned* ent_u;
+  const int* slot_of;
+  const float* rows;
+  float* out;
+  long long n;
+  const float* rows_self;
+  unsigned self_lo, self_len;
+  int dim, pad;
+};
+template <int VQ, int CW = 4>
+__global__ void __launch_bounds__(TB) k_shard_finish_multi(const FinishDesc* __restrict__ descs) {
+  const FinishDesc d = descs[blockIdx.y];
+  shard_finish_body<VQ, CW>(d.pos_ent, d.ent_u, d.slot_of, d.rows, d.out, d.n, d.dim, d.rows_self, d.self_lo, d.self_len);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1812,6 +1836,12 @@ __global__ void __launch_bounds__(TBT) k_ltile_multi(const MultiDesc* __restrict
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.ntiles) return;
   ltile_body<IdT, VQ, GATHER>(m.a.tv, m.w, reinterpret_cast<const IdT*>(m.ids), m.counts, m.n, m.a.det, m.out);
+}
+// the table-less tile pass of the sharded route (int64 ids), several tables in one launch
+__global__ void __launch_bounds__(TBT) k_ltile_multi_notable(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.ntiles) return;
+  ltile_body<long long, 1, false, false, true>(m.a.tv, m.w, reinterpret_cast<const long long*>(m.ids), nullptr, m.n, m.a.det, nullptr);
 }
 template <int MODE>
 __global__ void __launch_bounds__(TBK, 4) k_part2_multi(const MultiDesc* __restrict__ descs) {

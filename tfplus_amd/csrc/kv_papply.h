@@ -700,7 +700,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 // The sharded route (PA_UNIQUE with route_need set): the block that finishes LAST writes every segment's header {records,
 // 0}, the largest segment any owner was asked for and the batch's distinct ids, and clears the counters for the next
 // launch — k_seg_headers_take without its launch.  Every block comes through here, whatever its partition held.
-__device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int mode_) {
+__device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int mode_, const unsigned nblocks) {
   if ((mode_ & 0xFF) != PA_UNIQUE || a.route_world <= 0 || a.route_need == nullptr) return;   // (uniform over the launch)
   // No fence: the block's adds to the owners' counters are RETURNING device-scope atomics (their values place the
   // block's records), so they have been performed when the barrier below is passed, before the block reports; the
@@ -709,7 +709,7 @@ __device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int m
   __shared__ unsigned rt_last, rt_tot, rt_max;
   __syncthreads();
   if (threadIdx.x == 0) {
-    rt_last = __hip_atomic_fetch_add(&a.route_gcount[MAXW], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    rt_last = __hip_atomic_fetch_add(&a.route_gcount[MAXW], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u ? 1u : 0u;
     rt_tot = 0u; rt_max = 0u;
   }
   __syncthreads();
@@ -734,7 +734,7 @@ __device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int m
 template <int OPT, int V, int LPR, int K, int TBP>
 __global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) {
   papply_body<OPT, V, LPR, K, TBP>(w, a, mode);
-  papply_route_tail(a, mode);
+  papply_route_tail(a, mode, gridDim.x);
 }
 
 // many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array; grid.x = the largest table's partitions)
@@ -743,6 +743,7 @@ __global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_multi(const MultiDe
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
   papply_body<OPT, V, LPR, K, 256>(m.w, m.a, mode);
+  papply_route_tail(m.a, mode, m.w.P);   // (the table's own blocks: the sharded route of several tables in one launch)
 }
 
 // dispatch on the row geometry (the dims fused_ok() admits: float4 rows, a power-of-two lane count); one block per

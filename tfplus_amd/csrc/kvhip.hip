@@ -3957,6 +3957,189 @@ static int multi_shard_check(const kv_shard_t* shards, int ntab, kv_comm_t comm,
   }
   return KV_OK;
 }
+
+// ---- several sharded tables, one launch per phase -----------------------------------------------------
+// The route-side phases of kv_multi_shard_* run on the shards' private route tables; a table takes part in the batched
+// launches when its route is the entry-list one (not the deterministic mode, a dim the kernels serve, a batch that is
+// not empty); the others go through the per-table functions as before.
+static bool shard_batchable(const kv_shard* sh, int64_t n) {
+  return !shard_old_route() && papply_enabled() && fused_ok(sh->table->dim) && !sh->table->deterministic && n > 0 && n <= sh->max_ids;
+}
+
+// route of the tables todo[0..m): the table-less tile pass of all of them (grid.y = table), then k_papply_multi in
+// PA_UNIQUE mode — numbering, the owners' segments, and each table's headers by its own last block.  2 launches.
+static int multi_route_impl(const kv_shard_t* shards, const int* todo, int m, const void* const* ids, const int64_t* n, hipStream_t s) {
+  int rc;
+  const int device = shards[todo[0]]->table->device;
+  std::vector<kv_table*> rts;
+  for (int j = 0; j < m; ++j) rts.push_back(shards[todo[j]]->route);
+  MultiLock lock(rts);
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    if ((rc = hand_over(rt, s))) return rc;
+    rt->deterministic = false;
+    sh->n_last = n[todo[j]];
+    sh->route_token = 0;
+    sh->route_fused = true;
+    if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
+    Workspace& ws = rt->ws;
+    if (ws.pos_cap < sh->n_last) {
+      HIP_TRY(hipStreamSynchronize(s));
+      ws.pos_cap = 0;
+      if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(sh->n_last, ws.cap_n)))) return rc;
+      ws.pos_cap = std::max<long long>(sh->n_last, ws.cap_n);
+    }
+  }
+  BatchStage& st = g_stage[device][1];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)m * sizeof(MultiDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  MultiDesc* hd = reinterpret_cast<MultiDesc*>(sl->host);
+  WsDev wmax{};
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    MultiDesc& d = hd[j];
+    std::memset(&d, 0, sizeof d);
+    d.w = ws_view(rt, sh->n_last);
+    d.w.hc = (unsigned)HC2;
+    rt->fused_index = true; rt->index_records = false; rt->index_bcap = 0;
+    d.w.bcap = 0;
+    choose_partitions(rt, d.w, sh->n_last);
+    d.w.zero_counts = sh->ucnt;
+    d.w.pos_ent = rt->ws.pos_ent;
+    PartArgs& pa = d.a;
+    pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+    pa.out_keys = sh->uniq; pa.out_counts = sh->ucnt;
+    pa.sparse_unique = 1;
+    pa.det = 0;
+    pa.n = sh->n_last;
+    pa.day_lk = pa.day;
+    pa.route_world = sh->world; pa.route_rule = sh->rule; pa.route_C = sh->C;
+    pa.route_seg = sh->send_pairs; pa.route_slot_of = sh->slot_of; pa.route_overflow = sh->overflow; pa.route_gcount = sh->gcount;
+    pa.route_need = sh->need; pa.route_uhint = sh->overflow + 1;
+    d.ids = ids[todo[j]];
+    d.n = sh->n_last;
+    wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
+    wmax.P = std::max(wmax.P, d.w.P);
+  }
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)m * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
+  const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
+  k_ltile_multi_notable<<<dim3(wmax.ntiles, (unsigned)m), TBT, ltile_smem_bytes(), s>>>(md);
+  // (PA_UNIQUE | PA_NOAPPLY never reaches the code that depends on the row geometry: one variant serves every dim)
+  PartArgs p0 = hd[0].a;
+  p0.tv.dim = 4;
+  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wmax, &p0, PA_UNIQUE | PA_NOAPPLY, (void*)s, md, m))) return fail(rc, "route: no kernel");
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    rt->batch_serial = ++g_serial;
+    rt->batch_n = sh->n_last;
+    sh->route_token = rt->batch_serial;
+    sh->ordered = false;
+  }
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+// finish of the tables todo[0..m) — all of one row geometry (row_lanes(dim)): 1 launch
+static int multi_finish_impl(const kv_shard_t* shards, const int* todo, int m, float* const* outs, hipStream_t s) {
+  int rc;
+  const int device = shards[todo[0]]->table->device;
+  std::vector<kv_table*> rts;
+  for (int j = 0; j < m; ++j) rts.push_back(shards[todo[j]]->route);
+  MultiLock lock(rts);
+  BatchStage& st = g_stage[device][1];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)m * sizeof(FinishDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  FinishDesc* hd = reinterpret_cast<FinishDesc*>(sl->host);
+  long long nmax = 0;
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    if (rt->batch_serial != sh->route_token || sh->route_token == 0) return fail(KV_FAILED_PRECONDITION, "kv_multi_shard_lookup: finish without route");
+    if (!outs[todo[j]]) return fail(KV_INVALID_ARGUMENT, "kv_multi_shard_lookup: output pointer is null");
+    if ((rc = hand_over(rt, s))) return rc;
+    FinishDesc& d = hd[j];
+    d.pos_ent = rt->ws.pos_ent; d.ent_u = rt->ws.ent_b; d.slot_of = sh->slot_of; d.rows = sh->recv_rows; d.out = outs[todo[j]];
+    d.n = sh->n_last; d.rows_self = sh->send_rows;
+    d.self_lo = (unsigned)sh->rank * (sh->C + 1); d.self_len = sh->self_in_place ? sh->C + 1 : 0u;
+    d.dim = rt->dim; d.pad = 0;
+    nmax = std::max<long long>(nmax, sh->n_last);
+  }
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)m * sizeof(FinishDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
+  const FinishDesc* md = reinterpret_cast<const FinishDesc*>(sl->dev);
+  const dim3 grid((unsigned)nblocks(nmax, TB, 8192), (unsigned)m);
+#define KV_SFM(VQ) k_shard_finish_multi<VQ><<<grid, TB, 0, s>>>(md)
+  switch (row_lanes(shards[todo[0]]->table->dim)) {
+    case 1: KV_SFM(1); break;   case 2: KV_SFM(2); break;   case 4: KV_SFM(4); break;   case 8: KV_SFM(8); break;
+    case 16: KV_SFM(16); break; case 32: KV_SFM(32); break; default: KV_SFM(64); break;
+  }
+#undef KV_SFM
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
+// gradient pre-sum of the tables todo[0..m) — all of one dim: the tile sums, then k_papply_multi PA_DEDUP.  2 launches.
+static int multi_presum_impl(const kv_shard_t* shards, const int* todo, int m, const float* const* grads, hipStream_t s) {
+  int rc;
+  const int device = shards[todo[0]]->table->device;
+  std::vector<kv_table*> rts;
+  for (int j = 0; j < m; ++j) rts.push_back(shards[todo[j]]->route);
+  MultiLock lock(rts);
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    if (rt->batch_serial != sh->route_token || sh->route_token == 0)
+      return fail(KV_FAILED_PRECONDITION, "kv_multi_shard_apply: the batch's lookup must come first");
+    if (!grads[todo[j]]) return fail(KV_INVALID_ARGUMENT, "kv_multi_shard_apply: grad pointer is null");
+    if ((rc = hand_over(rt, s))) return rc;
+    if ((rc = ensure_workspace(rt, sh->n_last, true, s))) return rc;
+  }
+  BatchStage& st = g_stage[device][1];
+  StageSlot* sl = nullptr;
+  if ((rc = stage_acquire(st, (size_t)m * sizeof(MultiDesc), &sl))) return rc;
+  StageRelease rel{st, sl, s};
+  MultiDesc* hd = reinterpret_cast<MultiDesc*>(sl->host);
+  WsDev wmax{};
+  long long nmax = 0;
+  for (int j = 0; j < m; ++j) {
+    kv_shard* sh = shards[todo[j]];
+    kv_table* rt = sh->route;
+    MultiDesc& d = hd[j];
+    std::memset(&d, 0, sizeof d);
+    d.w = ws_view(rt, sh->n_last);
+    if (rt->index_P) { d.w.P = rt->index_P; d.w.pshift = 64 - ilog2(d.w.P); }
+    d.w.hc = (unsigned)HC2;
+    d.w.bcap = 0;
+    PartArgs& pa = d.a;
+    pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
+    pa.grad = grads[todo[j]];
+    pa.out_sum = sh->send_rows;
+    pa.out_map = sh->slot_of;
+    pa.det = 0;
+    pa.n = sh->n_last;
+    pa.epart = d.w.epart;
+    pa.day_lk = pa.day;
+    d.n = sh->n_last;
+    wmax.ntiles = std::max(wmax.ntiles, d.w.ntiles);
+    wmax.P = std::max(wmax.P, d.w.P);
+    nmax = std::max<long long>(nmax, sh->n_last);
+  }
+  wmax.hc = (unsigned)HC2;
+  HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)m * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
+  rel.launched = true;
+  const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
+  if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, -nmax, (void*)s, md, m))) return fail(rc, "tile sums: no kernel for dim %d", hd[0].a.tv.dim);
+  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wmax, &hd[0].a, PA_DEDUP, (void*)s, md, m))) return fail(rc, "gradient pre-sum: no kernel for dim %d", hd[0].a.tv.dim);
+  HIP_TRY(hipGetLastError());
+  return KV_OK;
+}
+
 int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, const void* const* ids, const int64_t* n,
                           float* const* outs, int join, kv_stream_t stream) {
   int rc;
@@ -3994,9 +4177,24 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
     }
     return KV_OK;
   };
-  for (int k = 0; k < ntab; ++k) {
-    buffers(k);
-    if ((rc = route(k))) return rc;
+  {
+    // the tables whose route is the entry-list one go together: 2 launches for all of them (KV_MULTI_SHARD_PER_TABLE=1: A/B)
+    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    std::vector<int> todo;
+    std::vector<char> batched(ntab, 0);
+    if (!per_table)
+      for (int k = 0; k < ntab; ++k)
+        if (shard_batchable(shards[k], n[k])) todo.push_back(k);
+    if (todo.size() >= 2) {
+      for (int k : todo) batched[k] = 1;
+      if (note(multi_route_impl(shards, todo.data(), (int)todo.size(), ids, n, w)))
+        for (int k : todo) routed[k] = 0;   // (void headers below: the peers are not left waiting)
+    }
+    for (int k = 0; k < ntab; ++k) {
+      buffers(k);
+      if (batched[k] && routed[k]) continue;
+      if ((rc = route(k))) return rc;
+    }
   }
   {   // lossless tables: one agreement for all of them (see shard_agree_many), then the grown ones are routed again
     std::vector<char> grown(ntab, 0);
@@ -4013,8 +4211,22 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
     if (note(kv_shard_lookup_serve(shards[k], w)))
       HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (wired(comm) ? shards[k]->world : 1), w));
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
-  for (int k = 0; k < ntab; ++k)
-    if (routed[k]) note(kv_shard_lookup_finish(shards[k], outs[k], w));
+  {
+    // finish: the tables of one row geometry whose route is an entry-list index in one launch
+    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    std::vector<char> done(ntab, 0);
+    if (!per_table)
+      for (int q : {1, 2, 4, 8, 16, 32, 64}) {
+        std::vector<int> grp;
+        for (int k = 0; k < ntab; ++k)
+          if (routed[k] && shards[k]->n_last > 0 && shards[k]->route_fused && row_lanes(shards[k]->table->dim) == q) grp.push_back(k);
+        if (grp.size() < 2) continue;
+        if (!note(multi_finish_impl(shards, grp.data(), (int)grp.size(), outs, w)))
+          for (int k : grp) done[k] = 1;
+      }
+    for (int k = 0; k < ntab; ++k)
+      if (routed[k] && !done[k]) note(kv_shard_lookup_finish(shards[k], outs[k], w));
+  }
   if ((rc = shard_done(shards[0], s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchanges were queued all the same)", first_msg.c_str());
   for (int k = 0; k < ntab; ++k)
@@ -4038,12 +4250,34 @@ int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int
   std::vector<void*> rr(ntab);
   std::vector<int64_t> rb(ntab);
   std::vector<char> stay(ntab, 0);
+  std::vector<char> summed(ntab, 0);
+  {
+    // gradient pre-sum: the tables of one dim whose route is an entry-list index in two launches
+    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    std::vector<int> dims;
+    if (!per_table)
+      for (int k = 0; k < ntab; ++k)
+        if (shards[k]->n_last > 0 && shards[k]->route_fused && !shards[k]->table->deterministic) dims.push_back(shards[k]->table->dim);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    for (int D : dims) {
+      std::vector<int> grp;
+      for (int k = 0; k < ntab; ++k)
+        if (shards[k]->n_last > 0 && shards[k]->route_fused && !shards[k]->table->deterministic && shards[k]->table->dim == D) grp.push_back(k);
+      if (grp.size() < 2) continue;
+      if (!note(multi_presum_impl(shards, grp.data(), (int)grp.size(), grads, w)))
+        for (int k : grp) summed[k] = 1;
+      else
+        for (int k : grp) summed[k] = 2;   // failed: zero gradient rows below
+    }
+  }
   for (int k = 0; k < ntab; ++k) {
     kv_shard* sh = shards[k];
     stay[k] = sh->self_in_place ? 1 : 0;
     rb[k] = (int64_t)(sh->C + 1) * sh->table->dim * (int64_t)sizeof(float) * (wired(comm) ? 1 : sh->world);
     sr[k] = sh->send_rows; rr[k] = sh->recv_rows;
-    if (note(kv_shard_apply_route(sh, grads[k], w)))
+    if (summed[k] == 1) continue;
+    if (summed[k] == 2 || note(kv_shard_apply_route(sh, grads[k], w)))
       HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb[k] * (wired(comm) ? sh->world : 1), w));
   }
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;

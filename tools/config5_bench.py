@@ -15,6 +15,9 @@ ap.add_argument("--batch", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--max-keys", type=float, default=4e6, help="cap of the log-uniform cardinalities (4e7 in the config)")
 ap.add_argument("--per-table", action="store_true", help="baseline: one op per table instead of the batched ops")
+ap.add_argument("--sharded", action="store_true",
+                help="the sharded ops at world 1 (kv_multi_shard_lookup / _apply over a one-rank communicator: every phase but the wire), "
+                     "one call per optimizer over all its tables")
 ap.add_argument("--streams", type=int, default=1, help="the groups of same-shaped tables are independent: spread them over this many HIP streams")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -42,9 +45,33 @@ for t in range(args.tables):
   grads = [torch.randn(args.batch, D, device=dev, generator=gen) * 1e-2 for _ in range(2)]
   groups.setdefault((opt, D), []).append((var, slots, ids, grads))
 
+comm = None
+if args.sharded:
+  comm = ops.KvComm(1, 0, None, 0)
+  for key, ms in groups.items():
+    groups[key] = [m + (ops.KvShard(m[0], 1, 0, ops.KV_OWNER_HASH, max_ids=args.batch, peer_capacity=args.batch),) for m in ms]
+    for m in groups[key]:
+      m[4].set_lossless(False)   # (capacity = the batch: cannot overflow)
+  by_opt = {"adam": [m for (o, _), ms in groups.items() if o == "adam" for m in ms],
+            "ftrl": [m for (o, _), ms in groups.items() if o == "ftrl" for m in ms]}
+
+def sharded_step(k):
+  for opt, ms in by_opt.items():
+    if not ms:
+      continue
+    sh = [m[4] for m in ms]
+    ops.kv_multi_shard_lookup(sh, comm, [m[2][k % 4] for m in ms])
+    gr = [m[3][k % 2] for m in ms]
+    if opt == "adam":
+      ops.kv_multi_shard_apply(sh, comm, ops.OPT_GROUP_ADAM_V4, [m[1] for m in ms], gr, (1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8, 0, 0, 0))
+    else:
+      ops.kv_multi_shard_apply(sh, comm, ops.OPT_SPARSE_GROUP_FTRL, [m[1] for m in ms], gr, (0.1, 0, 0, 0, 0, -0.5))
+
 streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
 
 def step(k):
+  if args.sharded:
+    return sharded_step(k)
   for gi, ((opt, D), ms) in enumerate(groups.items()):
     if streams:
       with torch.cuda.stream(streams[gi % len(streams)]):
@@ -74,5 +101,5 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for k in range(args.steps): step(k)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
 print("%s%s: %d tables (%d groups), %d ids each, key space %.1f M: %.3f ms/step, %.1f M ids/s (lookup + apply)" % (
-    "per-table ops" if args.per_table else "batched ops", ", %d streams" % args.streams if streams else "", args.tables, len(groups), args.batch, total_keys / 1e6, dt * 1e3,
+    "sharded ops, world 1" if args.sharded else "per-table ops" if args.per_table else "batched ops", ", %d streams" % args.streams if streams else "", args.tables, len(groups), args.batch, total_keys / 1e6, dt * 1e3,
     args.tables * args.batch / dt / 1e6))
