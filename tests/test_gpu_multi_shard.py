@@ -68,6 +68,67 @@ def test_multi_shard_ops_equal_the_per_table_sharded_ops():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["adam", "ftrl"])
+def test_multi_shard_batched_phases_equal_the_per_table_ops(opt):
+  """The default (not deterministic) mode: kv_multi_shard_lookup / _apply run every phase of same-shaped tables in one
+  launch (route, owner lookup, finish, gradient pre-sum, owner apply: kvhip.hip multi_*_impl).  Against the per-table
+  sharded ops on twin tables: the rows a lookup returns are bit-equal, the tables hold the same keys and — the fp32
+  sums of repeated ids being taken in another order — the same values within the summation tolerance.  One table is
+  read between its lookup and its apply (its pending pass is settled: it leaves the batched apply for the per-table
+  one), one sits out a step, dims repeat and do not."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
+  rng = np.random.default_rng(18)
+  dims = [16, 32, 32, 8, 32, 16]
+  T = len(dims)
+  sets = []
+  for which in range(2):   # 0: driven by the multi ops, 1: by the per-table ops
+    vs, ss, shs = [], [], []
+    for k, D in enumerate(dims):
+      init = np.random.default_rng(200 + k).standard_normal((32, D)).astype(np.float32)
+      v = _table(ops, D, init, False)
+      if opt == "adam":
+        sl = [_table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), False)]
+      else:
+        sl = [_table(ops, D, np.full((4, D), 0.1, np.float32), False), _table(ops, D, np.zeros((4, D), np.float32), False)]
+      vs.append(v); ss.append(sl); shs.append(ops.KvShard(v, 1, 0, ops.KV_OWNER_HASH, max_ids=1 << 15))
+    sets.append((vs, ss, shs))
+  comm = ops.KvComm(1, 0, None)
+  code = ops.OPT_GROUP_ADAM_V4 if opt == "adam" else ops.OPT_SPARSE_GROUP_FTRL
+  hp = HP if opt == "adam" else (0.1, 0, 0, 0, 0, -0.5)
+  for step in range(4):
+    ids = [torch.from_numpy(rng.integers(0, 6000, 9000 + 1111 * k)).cuda() for k in range(T)]
+    if step == 2:
+      ids[2] = ids[2][:0]
+    sign = [rng.choice([-1.0, 1.0], (1, D)) for D in dims]   # one sign per element: sums of repeated ids do not cancel
+    grads = [torch.from_numpy((rng.uniform(0.5, 1.5, (i.numel(), D)) * 1e-2 * sg).astype(np.float32)).cuda()
+             for i, D, sg in zip(ids, dims, sign)]
+    outs = ops.kv_multi_shard_lookup(sets[0][2], comm, ids)
+    want = [sets[1][2][k].lookup(comm, ids[k]) for k in range(T)]
+    for k in range(T):
+      if step == 0:
+        assert torch.equal(outs[k], want[k]), (step, k)
+      else:
+        torch.testing.assert_close(outs[k], want[k], rtol=2e-5, atol=1e-6)
+    if step == 1:   # another op on a table between its lookup and its apply
+      ops.kv_variable_gather_or_zeros_v2(sets[0][0][4], ids[4][:100])
+    ops.kv_multi_shard_apply(sets[0][2], comm, code, sets[0][1], grads, hp)
+    for k in range(T):
+      sets[1][2][k].apply(comm, code, sets[1][1][k], grads[k], hp)
+  torch.cuda.synchronize()
+  for k in range(T):
+    pairs = [(sets[0][0][k], sets[1][0][k])] + list(zip(sets[0][1][k], sets[1][1][k]))
+    for a, b in pairs:
+      ka, va = ops.read_kv_variable_op_v2(a); kb, vb = ops.read_kv_variable_op_v2(b)
+      oa, ob = torch.argsort(ka), torch.argsort(kb)
+      assert torch.equal(ka[oa], kb[ob]), k
+      torch.testing.assert_close(va[oa], vb[ob], rtol=2e-5, atol=1e-6)
+  del comm
+
+
+@pytest.mark.gpu
 def test_multi_shard_lossless_tables_grow_together():
   """Lossless tables in a multi-table step: ONE agreement (an all-reduce per table in one group, one synchronisation)
   raises the capacity of exactly the tables that need it; rows and state equal the unsharded ops."""

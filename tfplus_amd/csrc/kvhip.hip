@@ -682,12 +682,18 @@ bool fused_ok(int D);
 // written: records [lo, lo + len) of the buffers the calling thread's next op on `table` reads come from `ids` / `grad`
 // (the send buffers) instead.  Per thread, so another thread's op on the same table sees nothing of it.
 struct SelfSegment { const kv_table* table = nullptr; unsigned lo = 0, len = 0; const void* ids = nullptr; const float* grad = nullptr; };
-static thread_local SelfSegment tl_self;
+static thread_local bool tl_require_reuse = false;   // the batched sharded apply: the tables must still hold their lookups' indexes
+static thread_local std::vector<SelfSegment> tl_selfs;   // (empty outside the sharded owner ops; several tables in the batched ones)
 struct SelfScope {
-  SelfScope(const kv_table* t, bool on, unsigned lo, unsigned len, const void* ids, const float* grad) {
-    if (on) { tl_self.table = t; tl_self.lo = lo; tl_self.len = len; tl_self.ids = ids; tl_self.grad = grad; }
+  size_t mark;
+  SelfScope() : mark(tl_selfs.size()) {}
+  SelfScope(const kv_table* t, bool on, unsigned lo, unsigned len, const void* ids, const float* grad) : mark(tl_selfs.size()) {
+    add(t, on, lo, len, ids, grad);
   }
-  ~SelfScope() { tl_self = SelfSegment{}; }
+  void add(const kv_table* t, bool on, unsigned lo, unsigned len, const void* ids, const float* grad) {
+    if (on) tl_selfs.push_back(SelfSegment{t, lo, len, ids, grad});
+  }
+  ~SelfScope() { tl_selfs.resize(mark); }
 };
 
 WsDev ws_view(kv_table* t, long long n) {
@@ -719,8 +725,9 @@ WsDev ws_view(kv_table* t, long long n) {
   // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
   d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
   d.pos_ent = nullptr;
-  if (tl_self.table == t) { d.self_lo = tl_self.lo; d.self_len = tl_self.len; d.ids_self = tl_self.ids; d.grad_self = tl_self.grad; }
-  else { d.self_lo = d.self_len = 0; d.ids_self = nullptr; d.grad_self = nullptr; }
+  d.self_lo = d.self_len = 0; d.ids_self = nullptr; d.grad_self = nullptr;
+  for (const SelfSegment& x : tl_selfs)
+    if (x.table == t) { d.self_lo = x.lo; d.self_len = x.len; d.ids_self = x.ids; d.grad_self = x.grad; }
   d.bkt = w.bkt;
   d.bcap = t->index_bcap;
   d.bcnt = w.bcnt ? w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE : nullptr;
@@ -1944,9 +1951,18 @@ int kv_multi_gather_or_insert(int num_tables, const kv_handle_t* tables, const v
   return kv_multi_gather_or_insert_tok(num_tables, tables, ids, counts, ns, outs, nullptr, stream);
 }
 
+// ids_kind 2 + seg_caps: the (id, count) records of the sharded owner lookups, in fixed-capacity segments (kv_multi_shard_lookup)
+static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                             const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                             kv_batch_token_t* tokens, kv_stream_t stream, int ids_kind, const unsigned* seg_caps);
 int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, const void* const* ids,
                                   const int32_t* const* counts, const int64_t* ns, float* const* outs,
                                   kv_batch_token_t* tokens, kv_stream_t stream) {
+  return multi_lookup_impl(num_tables, tables, ids, counts, ns, outs, tokens, stream, -1, nullptr);
+}
+static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const void* const* ids,
+                             const int32_t* const* counts, const int64_t* ns, float* const* outs,
+                             kv_batch_token_t* tokens, kv_stream_t stream, int ids_kind, const unsigned* seg_caps) {
   int rc;
   if (tokens && num_tables > 0) std::memset(tokens, 0, (size_t)num_tables * sizeof(kv_batch_token_t));
   if ((rc = multi_common(num_tables, tables, ids, ns))) return rc;
@@ -1975,6 +1991,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
     MultiDesc& d = hd[i];
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
+    if (seg_caps) d.w.seg_cap = seg_caps[i];
     if (fused_ok(tables[i]->dim)) { d.w.hc = (unsigned)HC2; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
@@ -1994,7 +2011,7 @@ int kv_multi_gather_or_insert_tok(int num_tables, const kv_handle_t* tables, con
   kv_table* t0 = tables[0];
   if (fused_ok(t0->dim)) {
     for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
-    launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, true);
+    launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, ids_kind, md, num_tables, true);
     // tokens asked for: an optimizer apply of these batches follows — every table's partition pass stays pending
     // (kv_multi_apply_*_tok completes it inside k_papply_multi; any other op on a table settles that table first)
     static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();
@@ -2084,6 +2101,8 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
                        vars[i]->index_records && !vars[i]->part_pending && !vars[i]->side_pending))
       reuse = false;
+  if (tl_require_reuse && !pa_reuse && !reuse)
+    return fail(KV_FAILED_PRECONDITION, "batched sharded apply: another op used a table since this batch's lookup");
   for (int i = 0; i < num_tables; ++i) {
     if (!reuse && !pa_reuse) vars[i]->batch_serial = 0;
     if (!reuse && !pa_reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
@@ -4207,9 +4226,52 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
       }
   }
   if ((rc = comm_exchange(comm, ntab, sp.data(), rp.data(), pb.data(), w, stay.data()))) return rc;
-  for (int k = 0; k < ntab; ++k)
-    if (note(kv_shard_lookup_serve(shards[k], w)))
-      HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (wired(comm) ? shards[k]->world : 1), w));
+  {
+    // the owners' lookups: the tables of one dim in one batched lookup over their receive buffers (tile pass of all of
+    // them in one launch; the partition passes stay pending for the batched apply)
+    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    std::vector<char> served(ntab, 0);
+    std::vector<int> dims;
+    auto can = [&](int k) {
+      const kv_shard* sh = shards[k];
+      return papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap && sh->table->key_dtype == KV_DT_INT64 &&
+             (long long)sh->world * (sh->C + 1) <= (1ll << 21);
+    };
+    if (!per_table)
+      for (int k = 0; k < ntab; ++k)
+        if (can(k)) dims.push_back(shards[k]->table->dim);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    for (int D : dims) {
+      std::vector<int> grp;
+      for (int k = 0; k < ntab; ++k)
+        if (can(k) && shards[k]->table->dim == D) grp.push_back(k);
+      if (grp.size() < 2) continue;
+      const int m = (int)grp.size();
+      std::vector<kv_handle_t> tb(m);
+      std::vector<const void*> ip(m);
+      std::vector<int64_t> nn(m);
+      std::vector<float*> op(m);
+      std::vector<kv_batch_token_t> tok(m, 0);
+      std::vector<unsigned> caps(m);
+      SelfScope self;
+      for (int j = 0; j < m; ++j) {
+        kv_shard* sh = shards[grp[j]];
+        tb[j] = sh->table; ip[j] = sh->recv_pairs; nn[j] = (int64_t)sh->world * (sh->C + 1); op[j] = sh->send_rows; caps[j] = sh->C + 1;
+        sh->serve_token = 0;
+        self.add(sh->table, sh->self_in_place, (unsigned)sh->rank * (sh->C + 1), sh->C + 1, sh->send_pairs, nullptr);
+      }
+      if (note(multi_lookup_impl(m, tb.data(), ip.data(), nullptr, nn.data(), op.data(), tok.data(), w, 2, caps.data()))) {
+        for (int k : grp) HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (wired(comm) ? shards[k]->world : 1), w));
+      } else {
+        for (int j = 0; j < m; ++j) shards[grp[j]]->serve_token = tok[j];
+      }
+      for (int k : grp) served[k] = 1;
+    }
+    for (int k = 0; k < ntab; ++k)
+      if (!served[k] && note(kv_shard_lookup_serve(shards[k], w)))
+        HIP_TRY(hipMemsetAsync(shards[k]->send_rows, 0, (size_t)rb[k] * (wired(comm) ? shards[k]->world : 1), w));
+  }
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
   {
     // finish: the tables of one row geometry whose route is an entry-list index in one launch
@@ -4281,8 +4343,66 @@ int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int
       HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb[k] * (wired(comm) ? sh->world : 1), w));
   }
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
-  for (int k = 0; k < ntab; ++k)
-    note(kv_shard_apply_serve(shards[k], optimizer, slot0[k], slot1 ? slot1[k] : nullptr, hp, w));
+  {
+    // the owners' applies: the tables of one dim whose serve lookups left their batch index in one batched apply
+    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    std::vector<char> applied(ntab, 0);
+    std::vector<int> dims;
+    auto can = [&](int k) {
+      const kv_shard* sh = shards[k];
+      return papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap && sh->table->key_dtype == KV_DT_INT64 &&
+             (long long)sh->world * (sh->C + 1) <= (1ll << 21) && sh->serve_token != 0 && sh->serve_token == sh->table->batch_serial &&
+             // (the lookup's partition pass still pending: what k_papply_multi takes over; a table another op has settled
+             //  meanwhile goes through the per-table apply, which knows that state)
+             sh->table->fused_index && sh->table->part_pending && !sh->table->tile_pending && !sh->table->index_records &&
+             sh->table->index_bcap == 0 && !sh->table->side_pending &&
+             slot0[k] != nullptr && (optimizer != 3 || (slot1 && slot1[k]));
+    };
+    if (!per_table && optimizer >= 0 && optimizer <= 3)
+      for (int k = 0; k < ntab; ++k)
+        if (can(k)) dims.push_back(shards[k]->table->dim);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    for (int D : dims) {
+      std::vector<int> grp;
+      for (int k = 0; k < ntab; ++k)
+        if (can(k) && shards[k]->table->dim == D) grp.push_back(k);
+      if (grp.size() < 2) continue;
+      const int m = (int)grp.size();
+      std::vector<kv_handle_t> vs(m), s0(m), s1(m);
+      std::vector<const float*> gp(m);
+      std::vector<const void*> ip(m);
+      std::vector<int64_t> nn(m);
+      std::vector<kv_batch_token_t> tok(m);
+      SelfScope self;
+      for (int j = 0; j < m; ++j) {
+        kv_shard* sh = shards[grp[j]];
+        vs[j] = sh->table; s0[j] = slot0[grp[j]]; s1[j] = slot1 ? slot1[grp[j]] : nullptr;
+        gp[j] = sh->recv_rows; ip[j] = sh->recv_pairs; nn[j] = (int64_t)sh->world * (sh->C + 1); tok[j] = sh->serve_token;
+        self.add(sh->table, sh->self_in_place, (unsigned)sh->rank * (sh->C + 1), sh->C + 1, sh->send_pairs, sh->send_rows);
+      }
+      tl_require_reuse = true;   // (the ids are (id, count) records: an apply that rebuilt its index from them would read them as plain ids)
+      int r;
+      switch (optimizer) {
+        case 0: case 1:
+          r = kv_multi_apply_group_adam_tok(m, vs.data(), s0.data(), gp.data(), ip.data(), nn.data(), hp[0], hp[1], hp[2], hp[3], hp[4], hp[5],
+                                            hp[6], hp[7], hp[8], optimizer == 0 ? 4 : 3, tok.data(), w);
+          break;
+        case 2:
+          r = kv_multi_apply_adagrad_tok(m, vs.data(), s0.data(), hp[0], gp.data(), ip.data(), nn.data(), hp[1] != 0.f, tok.data(), w);
+          break;
+        default:
+          r = kv_multi_apply_sparse_group_ftrl_tok(m, vs.data(), s0.data(), s1.data(), gp.data(), ip.data(), nn.data(), hp[0], hp[1], hp[2],
+                                                   hp[3], hp[4], hp[5], tok.data(), w);
+          break;
+      }
+      tl_require_reuse = false;
+      note(r);
+      for (int k : grp) applied[k] = 1;
+    }
+    for (int k = 0; k < ntab; ++k)
+      if (!applied[k]) note(kv_shard_apply_serve(shards[k], optimizer, slot0[k], slot1 ? slot1[k] : nullptr, hp, w));
+  }
   if ((rc = shard_done(shards[0], s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchange was queued all the same)", first_msg.c_str());
   return KV_OK;
