@@ -387,8 +387,11 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   }
   lds_barrier();
   const unsigned nent = sm.hist[P] & 0xFFFFu;   // entries of the tile
-  // partition-major: toff[p][tile] (k_part2's block p reads rows p and p + 1 as two contiguous runs)
-  for (unsigned p = tid; p <= P; p += TBT) w.toff[(size_t)p * w.ntiles + tile] = sm.hist[p];
+  // tile-major: toff[tile][0..P] — one contiguous run per tile.  (Partition-major rows, which the partition blocks read as two
+  // contiguous runs, cost the tile pass P + 1 scattered 4-byte stores per tile — a million at low skew; the column the
+  // partition block reads instead stays in its XCD's L2, the blocks of an XCD being neighbours: k_ltile -1.5 us at
+  // configs[1], the lookup -7 .. -9 us at Zipf 0.3 / 0.8.)
+  for (unsigned p = tid; p <= P; p += TBT) w.toff[(size_t)tile * (P + 1) + p] = sm.hist[p];
   unsigned wpos[IPT];
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
@@ -709,20 +712,19 @@ __global__ void __launch_bounds__(TB) k_shard_finish_multi(const FinishDesc* __r
 // ------------------------------------------------------------------------------------------
 // k_part2: the partition pass over entries that already carry their rows
 // ------------------------------------------------------------------------------------------
-// seg_directory of kv_kernels.h over the partition-major toff: thread k takes tiles k, k + T, ... (coalesced rows),
-// the exclusive prefix over tiles is taken round by round.  *pbase = ENTRIES of the partitions before p.
+// seg_directory of kv_kernels.h over the tile-major toff (toff[tile][0..P]): thread k takes tiles k, k + T, ... — column p and
+// p + 1 of each — the exclusive prefix over tiles is taken round by round.  *pbase = ENTRIES of the partitions before p.
 template <int T, int NW>
 __device__ __forceinline__ unsigned seg_directory_t(const WsDev& w, unsigned p, unsigned short* tpre,
                                                     unsigned short* tstart, unsigned* wtot, unsigned* pbase) {
   const unsigned NT = w.ntiles;
-  const unsigned* r0 = w.toff + (size_t)p * NT;
-  const unsigned* r1 = r0 + NT;
   unsigned run0 = 0, pb = 0;
   for (unsigned tb = 0; tb < NT; tb += T) {   // block-uniform
     const unsigned t = tb + threadIdx.x;
     unsigned len = 0, s0 = 0;
     if (t < NT) {
-      const unsigned a = r0[t], b = r1[t];
+      const unsigned* c0 = w.toff + (size_t)t * (w.P + 1) + p;
+      const unsigned a = c0[0], b = c0[1];
       s0 = a & 0xFFFFu;
       len = (b & 0xFFFFu) - s0;
       tstart[t] = (unsigned short)s0;
