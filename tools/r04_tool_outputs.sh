@@ -35,6 +35,9 @@ run python tools/small_batch.py 2048 1 multi
 run python tools/small_batch.py 2048 1 multi notoken
 run python tools/config5_bench.py
 run python tools/config5_bench.py --per-table
+run python tools/config5_bench.py --sharded
+run env KV_MULTI_SHARD_PER_TABLE=1 python tools/config5_bench.py --sharded
+runb env KV_SHARD_SELF_COPY=1 python bench.py --force-sharded $B
 run python tools/sparse_lookup.py
 grep -v "amdgpu.ids" $out > $out.tmp && mv $out.tmp $out
 tail -3 $out
