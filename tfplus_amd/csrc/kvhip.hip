@@ -665,12 +665,15 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
     if ((rc = regrow(&w.hpart, (size_t)pe))) return rc;
     w.hpart_elems = pe;
   }
-  const long long ee = (w.cap_n / 2) * (long long)t->dim;
+  // the tile sums: [tiles of THIS batch][TILE / 2][dim] — sized by the batch, not by the workspace's doubled capacity
+  // (half a row per id: 512 MB for a 1 M-id batch at dim 256), grown by half when a longer batch comes
+  const long long ee = ((n + TILE - 1) / TILE) * (long long)(TILE / 2) * (long long)t->dim;
   if (need_part && w.epart_elems < ee) {
     HIP_TRY(hipStreamSynchronize(s));
+    const long long want = std::max(ee, std::min((w.cap_n / 2) * (long long)t->dim, w.epart_elems + w.epart_elems / 2));
     w.epart_elems = 0;
-    if ((rc = regrow(&w.epart, (size_t)ee))) return rc;
-    w.epart_elems = ee;
+    if ((rc = regrow(&w.epart, (size_t)want))) return rc;
+    w.epart_elems = want;
   }
   return KV_OK;
 }
