@@ -250,3 +250,109 @@ def test_world_of_eight_forty_tables_in_one_process_match_unsharded_oracles():
         x0, m0, v0, z0 = pre[r]
         adam_reorder_check(x0, m0, v0, z0, allb[sel], allg[sel], x1, hp, what="table %d rank %d step %d" % (k, r, step))
       assert total == len(refs[k].as_dict())
+
+
+@pytest.mark.gpu
+def test_multi_shard_ops_with_ranks_as_threads_match_unsharded_oracles():
+  """kv_multi_shard_lookup / kv_multi_shard_apply — batched phases — at world 3 with the ranks as threads of this
+  process over staged communicators (the rank's own segments are NOT delivered by the transport: they are read in
+  place): five tables (dims repeat, so the per-dim groups hold several tables), every rank's ids against one unsharded
+  oracle table per table."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  import threading
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops, sharded
+  world, dims = 3, [16, 32, 16, 8, 32]
+  T = len(dims)
+  rng = np.random.default_rng(91)
+  inits = [np.random.default_rng(300 + k).standard_normal((32, D)).astype(np.float32) for k, D in enumerate(dims)]
+  vs = [[_table(ops, D, inits[k], False) for k, D in enumerate(dims)] for _ in range(world)]
+  ss = [[_table(ops, 3 * D, np.zeros((4, 3 * D), np.float32), False) for D in dims] for _ in range(world)]
+  shs = [[ops.KvShard(vs[r][k], world, r, ops.KV_OWNER_HASH, max_ids=1 << 14) for k in range(T)] for r in range(world)]
+  refs = [ko.OracleKv(D, 0, inits[k], day=DAY, picker=1, seed=3) for k, D in enumerate(dims)]
+  rsl = [ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY) for D in dims]
+  dev = torch.device("cuda", 0)
+  bar = threading.Barrier(world, timeout=120)
+  sent, vals = [None] * world, [0] * world
+
+  def make_comm(r):
+    def exchange(send, recv, per_peer):
+      n = per_peer * world
+      sent[r] = ops.KvCommStaged.raw(send, n, dev)
+      torch.cuda.synchronize()
+      bar.wait()
+      dst = ops.KvCommStaged.raw(recv, n, dev)
+      for p in range(world):
+        if p == r and per_peer != 32:
+          dst[p * per_peer:(p + 1) * per_peer].fill_(0x5A)
+        else:
+          dst[p * per_peer:(p + 1) * per_peer].copy_(sent[p][r * per_peer:(r + 1) * per_peer])
+      torch.cuda.synchronize()
+      bar.wait()
+
+    def max_u32(v):
+      vals[r] = v
+      bar.wait()
+      m = max(vals)
+      bar.wait()
+      return m
+    return ops.KvCommStaged(0, world=world, rank=r, exchange=exchange, max_u32=max_u32)
+
+  comms = [make_comm(r) for r in range(world)]
+  for step in range(3):
+    ids = [[rng.integers(-200, 2000, 1500 + 300 * k + 77 * r) for k in range(T)] for r in range(world)]
+    if step == 1:
+      ids[1][2] = ids[1][2][:0]
+    sign = [rng.choice([-1.0, 1.0], (1, D)) for D in dims]
+    grads = [[(rng.uniform(0.5, 1.5, (ids[r][k].size, D)) * 1e-2 * sign[k]).astype(np.float32) for k, D in enumerate(dims)]
+             for r in range(world)]
+    outs, errs = [None] * world, []
+
+    def rank_step(r):
+      try:
+        torch.cuda.set_device(0)
+        o = ops.kv_multi_shard_lookup(shs[r], comms[r], [torch.from_numpy(x).cuda() for x in ids[r]])
+        torch.cuda.synchronize()
+        outs[r] = [x.cpu().numpy() for x in o]
+        ops.kv_multi_shard_apply(shs[r], comms[r], ops.OPT_GROUP_ADAM_V4, [[s] for s in ss[r]],
+                                 [torch.from_numpy(g).cuda() for g in grads[r]], HP)
+        torch.cuda.synchronize()
+      except Exception as e:
+        errs.append((r, repr(e)))
+        bar.abort()
+    ts = [threading.Thread(target=rank_step, args=(r,)) for r in range(world)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join()
+    assert not errs, errs
+    bar.reset()
+    for k, D in enumerate(dims):
+      allids = np.concatenate([ids[r][k] for r in range(world)])
+      want_all = refs[k].gather_or_insert(allids)
+      off = 0
+      for r in range(world):
+        want = want_all[off:off + ids[r][k].size]
+        off += ids[r][k].size
+        if step == 0:
+          np.testing.assert_array_equal(outs[r][k], want)
+        else:
+          np.testing.assert_allclose(outs[r][k], want, rtol=2e-5, atol=2e-6)
+      u, s, _ = ko.dedup_segment_sum(allids, np.concatenate([grads[r][k] for r in range(world)]))
+      ko.apply_group_adam(refs[k], rsl[k], s, u, *HP)
+  for k in range(T):
+    allk = np.array(sorted(refs[k].as_dict()), np.int64)
+    own = sharded.owner_of(torch.from_numpy(allk), world, "hash").numpy()
+    total = 0
+    for r in range(world):
+      keys, vals_r = ops.read_kv_variable_op_v2(vs[r][k])
+      keys = keys.cpu().numpy()
+      assert set(keys.tolist()) == set(allk[own == r].tolist()), (k, r)
+      got = dict(zip(keys.tolist(), vals_r.cpu().numpy()))
+      for key in keys.tolist():
+        np.testing.assert_allclose(got[key], refs[k].as_dict()[key], rtol=2e-5, atol=2e-6)
+      total += ops.kv_variable_frequency(vs[r][k])
+    assert total == refs[k].sum_freq(), k
+  del comms

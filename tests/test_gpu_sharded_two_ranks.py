@@ -544,3 +544,112 @@ def test_native_shard_every_optimizer_matches_the_unsharded_oracle(opt):
       mine = allk[own == r]
       np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(vars_[r], mine).cpu().numpy(), ref.gather_or_zeros(mine),
                                  rtol=3e-5, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,D,lossless,cap", [(2, 16, False, 0), (4, 32, True, 48), (3, 8, True, 0)])
+def test_whole_ops_with_ranks_as_threads_match_one_unsharded_table(world, D, lossless, cap):
+  """kv_shard_lookup / kv_shard_apply — the ops a real run calls — with `world` ranks as THREADS of this process, each
+  with its own tables, shard and a staged communicator (kv_comm_create_staged) whose callbacks move the segments
+  between the ranks' buffers on the device.  Unlike the phase tests this runs the whole-op code of every rank > 0: the
+  first-exchange verification, the lossless agreement (the capacity grows on every rank at once), the rank's own segment
+  read in place (the transport does NOT deliver it: it poisons that part of the receive buffer), the forked stream.
+  Checked against ONE oracle table fed every rank's ids."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  import threading
+  sys.path.insert(0, ROOT)
+  from oracle import kv_oracle as ko
+  from tfplus_amd.kv_variable.python.ops import sharded
+  rng = np.random.default_rng(31 + world)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  ops, vars_, slots, shards = _native_setup(world, D, "hash", table, cap=cap, max_ids=1 << 14)
+  for sh in shards:
+    sh.set_lossless(lossless)
+  ref = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=3)
+  rslot = ko.OracleKv(3 * D, 0, np.zeros((4, 3 * D), np.float32), day=DAY)
+  dev = torch.device("cuda", 0)
+  bar = threading.Barrier(world, timeout=120)
+  sent = [None] * world
+  vals = [0] * world
+
+  def make_comm(r):
+    def exchange(send, recv, per_peer):
+      n = per_peer * world
+      sent[r] = ops.KvCommStaged.raw(send, n, dev)
+      torch.cuda.synchronize()
+      bar.wait()
+      dst = ops.KvCommStaged.raw(recv, n, dev)
+      for p in range(world):
+        if p == r and per_peer != 32:                            # (32 bytes: the first exchange's verification record)
+          dst[p * per_peer:(p + 1) * per_peer].fill_(0xA5)      # never delivered: the ops read their own segment in place
+        else:
+          dst[p * per_peer:(p + 1) * per_peer].copy_(sent[p][r * per_peer:(r + 1) * per_peer])
+      torch.cuda.synchronize()
+      bar.wait()
+
+    def max_u32(v):
+      vals[r] = v
+      bar.wait()
+      m = max(vals)
+      bar.wait()
+      return m
+    return ops.KvCommStaged(0, world=world, rank=r, exchange=exchange, max_u32=max_u32)
+
+  comms = [make_comm(r) for r in range(world)]
+  b1p, b2p = np.float32(0.9), np.float32(0.999)
+  hp = (0.1, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+  for step in range(3):
+    batches = [rng.integers(-300, 300, 2500 + 411 * r) for r in range(world)]
+    if step == 2:
+      batches[0] = batches[0][:0]                                           # a rank with an empty batch
+    sign = rng.choice([-1.0, 1.0], (1, D))
+    grads = [(rng.uniform(0.5, 1.5, (b.size, D)) * 1e-2 * sign).astype(np.float32) for b in batches]
+    outs, errs = [None] * world, []
+
+    def rank_step(r):
+      try:
+        torch.cuda.set_device(0)
+        o = shards[r].lookup(comms[r], torch.from_numpy(batches[r]).cuda())
+        torch.cuda.synchronize()
+        outs[r] = o.cpu().numpy()
+        shards[r].apply(comms[r], ops.OPT_GROUP_ADAM_V4, [slots[r]], torch.from_numpy(grads[r]).cuda(), hp)
+        torch.cuda.synchronize()
+      except Exception as e:   # (a rank that fails breaks the barrier: the others fail too instead of waiting)
+        errs.append((r, repr(e)))
+        bar.abort()
+    ts = [threading.Thread(target=rank_step, args=(r,)) for r in range(world)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join()
+    assert not errs, errs
+    bar.reset()
+    want_all = ref.gather_or_insert(np.concatenate(batches))
+    off = 0
+    for r in range(world):
+      want = want_all[off:off + batches[r].size]
+      off += batches[r].size
+      if step == 0:
+        np.testing.assert_array_equal(outs[r], want)
+      else:
+        np.testing.assert_allclose(outs[r], want, rtol=2e-5, atol=2e-6)
+    u, s, _ = ko.dedup_segment_sum(np.concatenate(batches), np.concatenate(grads))
+    ko.apply_group_adam(ref, rslot, s, u, 0.1, float(b1p), float(b2p), 0.9, 0.999, 1e-8)
+    allk = np.array(sorted(ref.as_dict()), np.int64)
+    own = sharded.owner_of(torch.from_numpy(allk), world, "hash").numpy()
+    total = 0
+    for r in range(world):
+      keys, vals_r = ops.read_kv_variable_op_v2(vars_[r])
+      keys = keys.cpu().numpy()
+      assert set(keys.tolist()) == set(allk[own == r].tolist())
+      got = dict(zip(keys.tolist(), vals_r.cpu().numpy()))
+      for k in keys.tolist():
+        np.testing.assert_allclose(got[k], ref.as_dict()[k], rtol=2e-5, atol=2e-6)
+      total += ops.kv_variable_frequency(vars_[r])
+    assert total == ref.sum_freq()
+  if lossless and cap:
+    assert all(sh.peer_capacity > cap for sh in shards)                     # grown, on every rank alike
+    assert len({sh.peer_capacity for sh in shards}) == 1
+  assert all(c.exchanges >= 9 for c in comms)
+  del comms

@@ -763,34 +763,47 @@ class KvComm(object):
 
 
 class KvCommStaged(KvComm):
-  """A communicator whose segments travel through a torch.distributed group on the HOST (kvhip.h
-  kv_comm_create_staged): the library synchronises its stream and calls back; the segments go device -> host ->
-  all_to_all_single (gloo) -> device.  For rehearsing the N > 1 ops where RCCL cannot run (ranks sharing one GPU);
-  never a measurement path."""
+  """A communicator whose segments the CALLER moves (kvhip.h kv_comm_create_staged): the library synchronises its
+  stream and calls back.  Default transport: a torch.distributed group on the HOST — device -> host ->
+  all_to_all_single (gloo) -> device — for rehearsing the N > 1 ops where RCCL cannot run (ranks sharing one GPU).
+  `exchange(send_ptr, recv_ptr, bytes_per_peer)` / `max_u32(value) -> value` replace it (with `world` and `rank`), e.g.
+  ranks that are threads of one process.  Never a measurement path."""
 
   _XFN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
   _MFN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32))
 
-  def __init__(self, device=0, group=None):
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = torch.device("cuda", device)
-    self.exchanges = 0
-
+  @staticmethod
+  def raw(ptr, nbytes, dev):
+    """`nbytes` of device memory at `ptr` as a flat uint8 tensor (zero copy)."""
     class _Raw(object):
-      def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+      def __init__(self, p, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (p, False), "version": 2}
+    return torch.as_tensor(_Raw(ptr, nbytes), device=dev)
 
-    def exchange(_user, send, recv, per_peer):
-      try:
+  def __init__(self, device=0, group=None, world=None, rank=None, exchange=None, max_u32=None):
+    dev = torch.device("cuda", device)
+    if exchange is None:
+      import torch.distributed as dist
+      world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+      def exchange(send, recv, per_peer):
         n = int(per_peer) * world
-        if n == 0:
-          return 0
-        src = torch.as_tensor(_Raw(send, n), device=dev).cpu()
+        src = self.raw(send, n, dev).cpu()
         dst = torch.empty(n, dtype=torch.uint8)
         dist.all_to_all_single(dst, src, group=group)
-        torch.as_tensor(_Raw(recv, n), device=dev).copy_(dst)
+        self.raw(recv, n, dev).copy_(dst)
         torch.cuda.synchronize(dev)
+
+      def max_u32(value):
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(t.item())
+    self.exchanges = 0
+
+    def _x(_user, send, recv, per_peer):
+      try:
+        if int(per_peer) > 0:
+          exchange(send, recv, int(per_peer))
         self.exchanges += 1
         return 0
       except Exception:   # an exception cannot cross the C frames: the op reports KV_INTERNAL
@@ -798,21 +811,20 @@ class KvCommStaged(KvComm):
         traceback.print_exc()
         return 1
 
-    def max_u32(_user, value):
+    def _m(_user, value):
       try:
-        t = torch.tensor([int(value[0])], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        value[0] = int(t.item())
+        value[0] = int(max_u32(int(value[0])))
         return 0
       except Exception:
         import traceback
         traceback.print_exc()
         return 1
 
-    self._cb = (self._XFN(exchange), self._MFN(max_u32))   # kept alive as long as the communicator
+    self._cb = (self._XFN(_x), self._MFN(_m) if max_u32 is not None else None)   # kept alive as long as the communicator
     self.ptr = ctypes.c_void_p()
     _lib.check(_lib.lib().kv_comm_create_staged(int(world), int(rank), ctypes.cast(self._cb[0], ctypes.c_void_p),
-                                                ctypes.cast(self._cb[1], ctypes.c_void_p), None, int(device), ctypes.byref(self.ptr)))
+                                                ctypes.cast(self._cb[1], ctypes.c_void_p) if self._cb[1] else None,
+                                                None, int(device), ctypes.byref(self.ptr)))
     self.world, self.rank = world, rank
 
 
