@@ -653,3 +653,20 @@ def test_whole_ops_with_ranks_as_threads_match_one_unsharded_table(world, D, los
     assert len({sh.peer_capacity for sh in shards}) == 1
   assert all(c.exchanges >= 9 for c in comms)
   del comms
+
+
+@pytest.mark.gpu
+def test_shard_manifest_refuses_a_checkpoint_of_another_partitioning():
+  """A sharded table's checkpoint is its ranks' exports plus the record of the partitioning they were written under:
+  another world size, rank or owner rule (or the older arithmetic of the hash rule) is refused, not imported."""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  sys.path.insert(0, ROOT)
+  table = np.ones((4, 8), np.float32)
+  ops, vars_, slots, shards = _native_setup(2, 8, "hash", table)
+  m = shards[1].manifest()
+  assert m == {"world": 2, "rank": 1, "owner_rule": "hash", "owner_rule_version": 2}
+  shards[1].check_manifest(dict(m))
+  for key, val in (("world", 4), ("rank", 0), ("owner_rule", "mod"), ("owner_rule_version", 1)):
+    with pytest.raises(ValueError, match=key):
+      shards[1].check_manifest(dict(m, **{key: val}))

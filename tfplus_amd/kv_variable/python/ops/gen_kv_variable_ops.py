@@ -851,7 +851,28 @@ class KvShard(object):
     self.ptr = ctypes.c_void_p()
     _lib.check(_lib.lib().kv_shard_create(table_handle.ptr, int(world), int(rank), int(owner_rule), int(max_ids),
                                           int(peer_capacity), ctypes.byref(self.ptr)))
-    self.world, self.rank = world, rank
+    self.world, self.rank, self.owner_rule = world, rank, int(owner_rule)
+
+  # A sharded table is saved as its ranks' own exports (kv_variable_export / full_or_delta_import on each rank's local
+  # table) plus this record of WHO OWNS WHAT: rows restored under another world size or owner rule would sit on ranks
+  # that never look them up (and be silently re-initialised there).  OWNER_RULE_VERSION names the arithmetic of the
+  # "hash" rule — 2: (mix64(id) >> 32) % world, since round 3; 1 was mix64(id) % world.
+  OWNER_RULE_VERSION = 2
+
+  def manifest(self):
+    """What a checkpoint of this shard must be restored under (store it next to the rank's export)."""
+    return {"world": int(self.world), "rank": int(self.rank),
+            "owner_rule": "mod" if self.owner_rule == KV_OWNER_MOD else "hash",
+            "owner_rule_version": 1 if self.owner_rule == KV_OWNER_MOD else self.OWNER_RULE_VERSION}
+
+  def check_manifest(self, m):
+    """Raises ValueError when a checkpoint written under manifest `m` does not belong on this shard."""
+    mine = self.manifest()
+    bad = [k for k in mine if m.get(k) != mine[k]]
+    if bad:
+      raise ValueError("sharded checkpoint mismatch on %s: written under %r, this shard is %r — re-partition the rows "
+                       "(read every rank's export, route the keys with sharded.owner_of) instead of importing them as they are"
+                       % (", ".join(bad), {k: m.get(k) for k in mine}, mine))
 
   def __del__(self):
     try:
