@@ -434,7 +434,9 @@ int kv_comm_all_to_all(kv_comm_t comm, const void* send, void* recv, int64_t byt
  * kv_shard_lookup / kv_shard_apply chain the phases with the RCCL exchanges on the communicator's stream, forked from
  * `stream` by an event: the caller's stream stays free for the dense tower until kv_shard_join (or join != 0).
  * With `stream` == kv_comm_stream(comm) nothing is forked or joined (one queue, no event hops).  This rank's own
- * segment of every exchange is a device copy; the others are one grouped ncclSend / ncclRecv pair per peer. */
+ * segment of every exchange stays where it is — the phases the whole ops run read it in the send buffers (a caller
+ * that chains the phase calls itself moves all segments, its own included, into the receive buffers: a device copy) —
+ * the others are one grouped ncclSend / ncclRecv pair per peer. */
 typedef struct kv_shard* kv_shard_t;
 int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule, int64_t max_ids,
                     int64_t peer_capacity, kv_shard_t* out);

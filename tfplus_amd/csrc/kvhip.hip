@@ -3395,7 +3395,8 @@ static int comm_exchange(kv_comm* c, int nseg, const void* const* sends, void* c
     HIP_TRY(hipEventRecord(c->ev_in, s));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
   }
-  // this rank's own segment never meets RCCL: a device copy at HBM speed, queued in front of the group
+  // this rank's own segment never meets RCCL: it stays in place (skip_self: the sharded whole ops read it in the send
+  // buffer) or is a device copy at HBM speed, queued in front of the group
   // (KV_COMM_SELF_VIA_RCCL=1, a test switch: the self segment goes through ncclSend / ncclRecv like a peer's, which
   // lets a single GPU exercise the grouped send / recv code)
   static const bool self_rccl = [] { const char* e = getenv("KV_COMM_SELF_VIA_RCCL"); return e && e[0] == '1'; }();
