@@ -744,7 +744,11 @@ __device__ __forceinline__ unsigned seg_directory_t(const WsDev& w, unsigned p, 
 }
 // MODE_LOOKUP: FindOrInsert bookkeeping (frequency += occurrences, day, under-threshold flag, delta marks);
 // MODE_APPLYIDX: FindOrInsertUnsafe (a key the optimizer meets first: frequency word 1, not filtered).
-template <int MODE>
+// REC = false: the bookkeeping alone — no key records, entry list or work items.  For a lookup that no optimizer apply
+// takes over through k_apply2 (a lookup without a token; a token lookup whose pass is settled by another op): what the
+// records would serve is k_apply2, and an apply that still comes with the token runs k_papply over the tiles' entries
+// (PA_NONE).  Saves the three scans, the record and item stores and the whole second pass over the entries.
+template <int MODE, bool REC = true>
 __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
   constexpr int HSK = 1024;
   constexpr int UCAPK = HSK - TBK;
@@ -772,13 +776,13 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
   const unsigned E = seg_directory_t<TBK, TBK / 64>(w, p, tpre, tstart, wtot, &pbase);
   __shared__ unsigned lcold, lhot, lchunk, litm, lnbig;   // litm: cold batches so far (they fill the stretch from its end)
   __shared__ unsigned lbig[16][3];
-  if (E == 0) { if (tid == 0) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); return; }
+  if (E == 0) { if (REC && tid == 0) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); return; }
   __shared__ unsigned stkR[24], stkr[24];
   __shared__ int sp;
   if (tid == 0) { stkR[0] = 1; stkr[0] = 0; sp = 1; lpcur = pbase; lcold = 0; lhot = 0; lchunk = 0; litm = 0; }
   __syncthreads();
   if (E > 65535u) {
-    if (tid == 0) { raise_error(a.tv, 2u); w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
+    if (tid == 0) { raise_error(a.tv, 2u); if (REC) w.pmeta[p] = make_uint4(0u, 0u, pbase, 0u); }
     return;
   }
   const unsigned hcr = w.hc;
@@ -849,7 +853,9 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     constexpr int PERU = (UCAPK + TBK - 1) / TBK;
     unsigned kst[PERU], kcnt[PERU], krank[PERU], kchunk[PERU];
     const unsigned gb = 64u / (unsigned)apply_lanes(a.tv.dim);   // keys per cold batch
-    {
+    if constexpr (!REC) {
+      if (tid == 0) lcold += nu;   // (only the batch's distinct keys are counted: ctr[5])
+    } else {
       unsigned sum = 0, ch = 0, hh = 0;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
@@ -958,7 +964,7 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
           }
           hrow[s] = r[k] | NEW_BIT;
         }
-        put_rec(k, key, r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? NEW_BIT : 0u), isnew[k] ? 0u : hhint[s]);
+        if constexpr (REC) put_rec(k, key, r[k] | ((MODE == MODE_APPLYIDX && isnew[k]) ? NEW_BIT : 0u), isnew[k] ? 0u : hhint[s]);
         if (r[k] == 0u) continue;   // row slab overflow: the error flag is up
         RowMeta* mp = meta_ptr(a.tv, r[k]);
         if (isnew[k]) { mp->key = key; mp->delta_train = 0; mp->delta_pred = 0; }
@@ -979,18 +985,18 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
       }
     }
     __syncthreads();
-    {
+    if constexpr (REC) {
       const unsigned nbig = min(lnbig, 16u);
       for (unsigned b = 0; b < nbig; ++b)
         for (unsigned i = tid; i < lbig[b][2]; i += TBK)
           w.litem[pbase + lbig[b][1] + i] = make_uint4(lbig[b][0] | HEAD_BIT, i, lbig[b][1] + i, 0u);
-    }
 #pragma unroll
-    for (int q = 0; q < PERU; ++q) {
-      const unsigned u = tid * PERU + q;
-      if (u < nu) hval[ulist[u]] = krank[q] | (kcnt[q] > (unsigned)LCOLD ? 0x80000000u : 0u);
+      for (int q = 0; q < PERU; ++q) {
+        const unsigned u = tid * PERU + q;
+        if (u < nu) hval[ulist[u]] = krank[q] | (kcnt[q] > (unsigned)LCOLD ? 0x80000000u : 0u);
+      }
+      __syncthreads();
     }
-    __syncthreads();
     KV_STAMPP(2);
 
     // ---- rows that need lanes: contents of new rows, under-threshold flag of rows that changed ------------------
@@ -1028,7 +1034,7 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     KV_STAMPP(3);
 
     // ---- pass 2: the entry list — entry x of key h goes to order[start(h) + its number among h's entries] -------
-    {
+    if constexpr (REC) {
       auto place = [&](unsigned ge, unsigned h) {
         const unsigned idx = atomicAdd(&hrun[h], 1u);
         const unsigned src = w.ent_rec[ge];
@@ -1089,12 +1095,12 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
     KV_STAMPP(4);
   }
   if (tid == 0) {
-    w.pmeta[p] = make_uint4(lchunk + litm, lchunk, pbase, E);
+    if (REC) w.pmeta[p] = make_uint4(lchunk + litm, lchunk, pbase, E);
     atomicAdd(&w.ctr[5], lcold + lhot);   // distinct keys of the batch (no value returned: nothing waits for it)
   }
 }
-template <int MODE>
-__global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_body<MODE>(w, a); }
+template <int MODE, bool REC = true>
+__global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_body<MODE, REC>(w, a); }
 
 // ------------------------------------------------------------------------------------------
 // items2_body: the dense work-item directory, every hot chunk of the batch in front of every cold batch

@@ -990,10 +990,18 @@ void launch_lrows(kv_table* t, const TableDev& td, const void* ids, void* ids_co
 #undef KV_LR
 #undef KV_LR2
 }
+// records = false (one table): the bookkeeping alone — no key records, entry list or work items (k_part2<MODE, false>)
 template <int MODE>
-void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
+void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0, bool records = true) {
   if (md) k_part2_multi<MODE><<<dim3(wd.P, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
+  else if (!records) k_part2<MODE, false><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
   else k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
+}
+// A lookup's partition pass that no k_apply2 will follow writes no records: an apply that still comes with the batch's
+// token runs k_papply over the tiles' entries (PA_NONE).  KV_PART2_RECORDS=1: always (A/B).
+bool part2_lean() {
+  static const bool keep = [] { const char* e = getenv("KV_PART2_RECORDS"); return e && atoi(e) != 0; }();
+  return !keep && papply_enabled();
 }
 
 // segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
@@ -1161,8 +1169,9 @@ int flush_part(kv_table* t, hipStream_t s) {
     const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_LOOKUP | PA_NOAPPLY, (void*)s);
     if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
   } else {
-    launch_part2<MODE_LOOKUP>(wd, pa, s);
-    t->index_records = true;
+    const bool lean = part2_lean() && fused_ok(pa.tv.dim) && !t->overlap;
+    launch_part2<MODE_LOOKUP>(wd, pa, s, nullptr, 0, !lean);
+    t->index_records = !lean;
   }
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -1304,7 +1313,9 @@ int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids
     if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
     return KV_OK;
   }
-  launch_part2<MODE>(wd, pa, s);
+  const bool lean = MODE == MODE_LOOKUP && part2_lean() && !t->overlap;   // (a lookup without a deferred pass hands out no usable index for k_apply2)
+  launch_part2<MODE>(wd, pa, s, nullptr, 0, !lean);
+  if (lean) t->index_records = false;
   return KV_OK;
 }
 // ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
