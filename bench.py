@@ -213,8 +213,13 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
     pr = ops.kv_profile_read(var)
     ops.kv_profile_enable(var, 0)
     rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0] + pr["lookup_rows"][0]) / max(pr["lookup_tile"][1] + pr["lookup_rows"][1], 1)
-    sweep.append({"zipf": sk, "unique_per_batch": float(np.mean([b[2] for b in bs])), "ms_per_step": ms_step,
-                  "lookup_ms": ms_look, "lookup_rows_ready_ms": rows_ms, "apply_ms": ms_step - ms_look})
+    U_sk = float(np.mean([b[2] for b in bs]))
+    look_bytes = N * 8 + U_sk * (16 + 4 * D) + N * 4 * D        # ids + probe record and row per distinct id + output rows
+    sweep.append({"zipf": sk, "unique_per_batch": U_sk, "ms_per_step": ms_step,
+                  "lookup_ms": ms_look, "lookup_rows_ready_ms": rows_ms, "apply_ms": ms_step - ms_look,
+                  "lookup_algorithmic_bytes": look_bytes,
+                  "lookup_frac": look_bytes / (ms_look * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "lookup_rows_ready_frac": look_bytes / (rows_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     del bs
   res["skew_sweep"] = sweep
   return res

@@ -37,6 +37,7 @@ def test_bench_single_gpu_line():
   # what the drop-in runs, next to the headline: op boundary, no token, staged through pinned host memory; other skews
   assert d["op_boundary"]["ms"] > 0 and d["no_token"]["ms_per_step"] > 0 and d["staged"]["ms_per_step"] > 0
   assert [x["zipf"] for x in d["skew_sweep"]] == [0.3, 0.8, 1.2] and "repeated_id_tolerance" in d
+  assert all(0 < x["lookup_frac"] < 1 and x["lookup_rows_ready_frac"] >= x["lookup_frac"] * 0.9 for x in d["skew_sweep"])
 
 
 @pytest.mark.gpu
