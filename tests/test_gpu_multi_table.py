@@ -40,7 +40,8 @@ def _dump(ops, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,sizes", [(32, [2048] * 6), (64, [2048, 1, 0, 5000, 300]), (8, [70000, 100])])
+@pytest.mark.parametrize("D,sizes", [(32, [2048] * 6), (64, [2048, 1, 0, 5000, 300]), (8, [70000, 100]),
+                                     (8, [2_500_000, 3000])])   # (more than 2^21 ids in one table of a batched call)
 def test_multi_ops_equal_single_ops(ops, D, sizes):
   T = len(sizes)
   A = _tables(ops, T, D, seed=1)        # driven by the batched ops

@@ -1949,7 +1949,9 @@ static int multi_common(int num_tables, const kv_handle_t* tables, const void* c
   for (int i = 0; i < num_tables; ++i) {
     if (tables[i]->dim != tables[0]->dim || tables[i]->key_dtype != tables[0]->key_dtype)
       return fail(KV_INVALID_ARGUMENT, "batched op: tables must share dim and key dtype (group them by shape)");
-    if (ns[i] < 0 || ns[i] > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "indices: bad length %lld", (long long)ns[i]);
+    // (the entry-list kernels index up to FUSED_MAX_N ids per table and call, like the single-table ops; other dims 2^21)
+    if (ns[i] < 0 || ns[i] > (fused_ok(tables[0]->dim) ? FUSED_MAX_N : (1ll << 21)))
+      return fail(KV_INVALID_ARGUMENT, "indices: bad length %lld", (long long)ns[i]);
     if (ns[i] > 0 && !ids[i]) return fail(KV_INVALID_ARGUMENT, "indices pointer is null");
     if (!tables[i]->initialized)
       return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
