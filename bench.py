@@ -261,10 +261,8 @@ def main():
                   help="diagnostic: the apply rebuilds the batch index instead of taking over the lookup's")
   ap.add_argument("--deterministic", action="store_true",
                   help="diagnostic: the tables' deterministic reduction mode (kv_set_deterministic)")
-  ap.add_argument("--overlap", action="store_true",
-                  help="diagnostic: overlap mode (kv_set_overlap) without graph capture: the forks and joins are event hops")
   ap.add_argument("--graph", action="store_true",
-                  help="the timed steps replay HIP graphs captured in overlap mode (one graph per pooled batch)")
+                  help="diagnostic: the timed steps replay HIP graphs (one captured step per pooled batch)")
   ap.add_argument("--lossless", action="store_true",
                   help="sharded path: keep the library's default lossless mode (capacity agreed before every exchange; a host round trip per lookup) instead of opting into the synchronisation-free mode")
   ap.add_argument("--debug-capacity-skew", type=int, default=0,
@@ -430,9 +428,6 @@ def main():
     if native_shard:
       live["comm"] = comm
 
-  if args.overlap and not shard_path:
-    ops.kv_set_overlap(var, True)
-
   def step(k):
     ids, grad = pool[k % len(pool)][:2]
     if not shard_path:
@@ -476,9 +471,8 @@ def main():
   dom = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1))
   graphs = None
   if args.graph and not shard_path:
-    # one graph per pooled batch, captured in overlap mode: the lookup's rows beside its tile pass, the partition pass
-    # beside the apply's tile sums — graph edges instead of event hops, no launch gaps.  (The Adam powers b1p / b2p
-    # are arguments by value: a replay uses the ones of its capture.)
+    # one graph per pooled batch: no launch gaps.  (The Adam powers b1p / b2p are arguments by value: a replay uses
+    # the ones of its capture.)
     ops.kv_profile_enable(var, 0)
     torch.cuda.synchronize()
     for h in (var, slot):

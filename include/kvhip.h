@@ -177,17 +177,15 @@ int kv_attach_slot(kv_handle_t var, kv_handle_t slot, kv_stream_t stream);
  * key's tiles in tile order — so the same batch gives bit-identical optimizer state on every run. */
 int kv_set_deterministic(kv_handle_t h, int on);
 
-/* Overlap mode (off by default), for steps that are captured in a HIP graph.  The training lookup then forks a side
- * stream of the table: the output rows are copied there (k_copy) beside the tile pass, and the partition pass follows
- * them there, so that it runs beside whatever the caller does between the lookup and the optimizer apply (the dense
- * tower; in a bare benchmark: the apply's tile sums).  The lookup returns with `out` complete on the caller's
- * stream; the next op on the table (any op, on any stream) first joins the side stream.  Under stream capture the
- * forks and joins are graph edges; outside a capture each is an event hop of several microseconds.  Measured at
- * configs[1]: the step is SLOWER with it both eagerly and as a replayed graph (0.183 ms against
- * 0.155 ms) — parallel graph branches are scheduled like streams on this stack — so it stays off by default and is
- * kept for callers whose dense tower is long enough to hide the join.  A capture that holds a lookup must also hold
- * the table's next op (the optimizer apply), or the side stream is left unjoined.  Results are the same as without it. */
-int kv_set_overlap(kv_handle_t h, int on);
+/* Row math of the optimizer ops applied to var table `h` (training_ops.cc:7166-7195 and the other per-id bodies).
+ * on = 0 (the default): IEEE-754 sqrt and division sequences, bit-for-bit what the reference's Eigen arithmetic gives
+ * from the same summed gradient.  on = 1: every sqrt and division of the update is ONE hardware instruction
+ * (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, 1 ulp each).  Measured at configs[1]: -1.3 us of the 64 us apply kernel (the
+ * kernel is bound by its memory round trips, not by its arithmetic), and an element whose update cancels (|x| three
+ * orders below its row's scale) can leave the parity tests' rtol 1e-6 / atol 1e-9 (one element in 39 000 did): hence
+ * opt-in.  A table in deterministic mode always uses the IEEE sequences. */
+int kv_set_fast_math(kv_handle_t h, int on);
+
 /* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that
  * follows can then take `max_new_ids` more ids without consulting the device — what a stream capture needs, where a
  * synchronisation is not allowed.  KV_RESOURCE_EXHAUSTED when the table would have to grow for that many ids (it

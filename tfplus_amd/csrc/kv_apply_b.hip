@@ -32,8 +32,8 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_apply_b(int mode
 
 // k_tsum of the entry-list pipeline (kv_fused.h); td_ = TableDev of the var table
 extern "C" __attribute__((visibility("hidden"))) int kvp_launch_tsum(const void* td_, const void* wd_, const float* grad,
-                                                                 long long n, void* stream, const void* md, int ntab) {
-  return launch_tsum_t(*static_cast<const TableDev*>(td_), *static_cast<const WsDev*>(wd_), grad, n,
+                                                                 void* stream, const void* md, int ntab) {
+  return launch_tsum_t(*static_cast<const TableDev*>(td_), *static_cast<const WsDev*>(wd_), grad,
                        static_cast<hipStream_t>(stream), static_cast<const MultiDesc*>(md), ntab);
 }
 

@@ -5,8 +5,7 @@
 //
 // D % 4 == 0 -> float4 lanes, else scalar lanes.  md != nullptr: one launch over `ntab` tables (grid.y),
 // nchunks = blocks per table; only MODE_APPLY on float4 rows is instantiated for it.
-// span == 0: k_apply, span == 1: k_apply_fin, span == 2: k_apply2 (entry-list pipeline).  Returns KV_OK, or KV_UNIMPLEMENTED for an
-// unsupported dim.
+// span == 0: k_apply, span == 1: k_apply_fin.  Returns KV_OK, or KV_UNIMPLEMENTED for an unsupported dim.
 #pragma once
 
 template <int MODE, int OPT>
@@ -28,27 +27,7 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
       }();                                                                                         \
       if ((int)nchunks > resident) grid_ = resident; else grid_ = (int)nchunks;                     \
     }                                                                                              \
-    if constexpr (MODE == MODE_APPLY) {                                                            \
-      if (span == 2) {                                                                             \
-        static const int resident2 = [] {                                                          \
-          int nb = 0, cus = 0, dev = 0;                                                            \
-          hipGetDevice(&dev);                                                                      \
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                 \
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply2<OPT, V, LPR, K>, TBA, 0) != hipSuccess || nb < 1) nb = 1; \
-          if (nb > 2) nb = 2;                                                                      \
-          return nb * (cus > 0 ? cus : 256);                                                       \
-        }();                                                                                       \
-        grid_ = (int)(nchunks / 4 + 1) > resident2 ? resident2 : (int)(nchunks / 4 + 1);   /* 16 waves per block */ \
-        /* many tables in one launch: ALL their blocks are one resident generation (26 tables x 74 blocks were four, \
-           and a generation of blocks that find no item left still costs its start-up) */       \
-        if (md && ntab > 0 && grid_ * ntab > resident2) grid_ = resident2 / ntab > 1 ? resident2 / ntab : 1;  \
-      }                                                                                            \
-    }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \
-      if (md && span == 2) {                                                                       \
-        k_apply2_multi<OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBA, 0, s>>>(md);  \
-        return KV_OK;                                                                              \
-      }                                                                                            \
       if (md) {                                                                                    \
         if (span) k_apply_fin_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBF, sh, s>>>(md);   \
         else k_apply_multi<MODE, OPT, V, LPR, K><<<dim3((unsigned)grid_, (unsigned)ntab), TBS, sh, s>>>(md);      \
@@ -56,9 +35,6 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
       }                                                                                            \
     }                                                                                              \
     if (md) return KV_UNIMPLEMENTED;                                                               \
-    if constexpr (MODE == MODE_APPLY) {   /* span 2: the entry-list apply (kv_fused.h), same grid rule as k_apply */ \
-      if (span == 2) { k_apply2<OPT, V, LPR, K><<<grid_, TBA, 0, s>>>(wd, pa); return KV_OK; }        \
-    }                                                                                              \
     if (span) k_apply_fin<MODE, OPT, V, LPR, K><<<grid_, TBF, sh, s>>>(wd, pa);                     \
     else k_apply<MODE, OPT, V, LPR, K><<<grid_, TBS, sh, s>>>(wd, pa);                        \
     return KV_OK;                                                                                  \
@@ -89,19 +65,15 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
   return KV_UNIMPLEMENTED;
 }
 
-// k_tsum (kv_fused.h): the tile sums in front of the entry-list apply; same row geometry as k_apply.
-// grid = ITEM_BLOCKS + ntiles blocks of TBC threads.  Instantiated once (kv_apply_b.hip).
-// n < 0: the sums alone; grad == nullptr: the directory alone (overlap mode, kvhip.hip fused_apply).
-// md != nullptr: `ntab` tables in one launch (wd = the largest ntiles of the batch).
-inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, long long n, hipStream_t s,
+// k_tsum (kv_fused.h): the tile sums in front of k_papply; same row geometry as k_apply.  grid = ntiles blocks of TBC
+// threads.  Instantiated once (kv_apply_b.hip).  md != nullptr: `ntab` tables in one launch (wd = the largest ntiles).
+inline int launch_tsum_t(const TableDev& td, const WsDev& wd, const float* grad, hipStream_t s,
                          const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = td.dim;
-  const int what = n < 0 ? 1 : (grad == nullptr ? 2 : 0);
-  const unsigned grid = what == 1 ? wd.ntiles : what == 2 ? wd.nib : wd.nib + wd.ntiles;
 #define KV_TSUM(V, LPR, K)                                                                              \
   do {                                                                                                  \
-    if (md) k_tsum_multi<V, LPR, K><<<dim3((what == 1 ? 0u : (unsigned)ITEM_BLOCKS) + wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md, what == 1 ? 1 : 0); \
-    else k_tsum<V, LPR, K><<<grid, TBC, (size_t)TILE * 4, s>>>(td, wd, grad, what);                                    \
+    if (md) k_tsum_multi<V, LPR, K><<<dim3(wd.ntiles, (unsigned)ntab), TBC, 0, s>>>(md);                 \
+    else k_tsum<V, LPR, K><<<wd.ntiles, TBC, (size_t)TILE * 4, s>>>(td, wd, grad);                       \
     return KV_OK;                                                                                       \
   } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
@@ -125,8 +97,7 @@ inline int launch_ltsum_t(const TableDev& td, const WsDev& wd, const IdT* ids, l
   const size_t sh = ltile_smem_bytes();
 #define KV_LTSUM(V, LPR, K)                                                                              \
   do {                                                                                                   \
-    if (wd.bcap != 0u) k_ltsum<IdT, V, LPR, K, true><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);   \
-    else k_ltsum<IdT, V, LPR, K><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);     \
+    k_ltsum<IdT, V, LPR, K><<<(int)wd.ntiles, TBT, sh, s>>>(td, wd, ids, nullptr, n, det, grad);           \
     return KV_OK;                                                                                        \
   } while (0)
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;

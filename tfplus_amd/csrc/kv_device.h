@@ -36,8 +36,6 @@ constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every 
                                  // blocks' LDS lists small enough for 4 blocks per CU
 constexpr int LS = 2 * TILE;     // LDS hash slots per tile (load <= 0.5)
 constexpr int MAX_P = 2048;      // partitions (power of two); 1024 up to 1 M ids, 2048 for 2 M
-constexpr int BCNT_STRIDE = 16;     // words between two bucket cursors (bucket mode, WsDev::bcnt)
-constexpr int NXCD = 8;             // a partition's bucket is NXCD sub-buckets, one per XCD (see WsDev::bcnt)
 constexpr int MAX_CHUNKS = 32768;   // 2^16-row chunks (no capacity hint) still reach the 2^31-row limit
 
 // index-pass modes (k_part_keys) and fold modes (k_apply_sorted)
@@ -130,7 +128,6 @@ struct WsDev {
                            // | bit 31: first row of its entry  (in slot_rank's storage)
   unsigned* mcount;        // [ntiles] rows in mrow (low 16) | entries they belong to (high 16)
   float* epart;            // [ntiles][TILE / 2][dim] their gradient sums (k_tsum)
-  unsigned hc;             // entries per hot chunk
   // ---- sharded path: a rank's OWN segment of an exchange is not copied from the send to the receive buffer: the
   //      kernels that read a receive buffer read positions [self_lo, self_lo + self_len) from the send buffer instead
   unsigned self_lo, self_len;   // (length 0: no such range; one unsigned compare: pos - self_lo < self_len)
@@ -138,17 +135,6 @@ struct WsDev {
   const float* grad_self;       // k_tsum / k_papply: its gradient rows (send_rows)
   unsigned short* pos_ent; // [n] k_ltile: every input position's entry number in its tile (sharded route: the finish reads
                            // position -> entry -> record); nullptr: not filed
-  // ---- bucket mode (kv_fused.h ltile_body<BUCKET>, kv_papply.h): the tiles append their entries to per-partition buckets
-  uint4* bkt;              // [P][NXCD][bcap] BktRec (two uint4 each): partition p's entries, by the XCD of the tile that
-                           // appended them, in arrival order
-  unsigned* bcnt;          // [MAX_P * NXCD * BCNT_STRIDE] this batch's sub-bucket cursors (= entry counts once the tile pass is
-                           // done).  A cursor is only ever touched by tiles running on ITS XCD, with an atomic that is
-                           // performed in that XCD's L2 (workgroup scope): device-scope atomics are performed at the memory
-                           // side, and 354 k of them per launch cost the tile pass 15 us (70 us against 55 us; with 32
-                           // cursors per cache line 138 us).  Kernel boundaries make the counts visible to the partition pass.
-  unsigned* bcnt_other;    // the other parity's cursors: the tile pass clears them for the next batch
-  unsigned bcap;           // records per SUB-bucket; 0 = the index is partition-sorted per tile (toff), not bucketed
-  unsigned nib;            // k_tsum: directory blocks in front of the tile blocks (a single table's launch; 16 .. 128 by batch size)
 };
 
 // In-kernel phase stamps for the diagnostic build (never in the product .so): thread 0 of each
@@ -416,7 +402,19 @@ struct OptArgs {
   float lr, b1p, b2p, b1, b2, eps, l1, l2, l21, l2s, lr_power;
   float alpha, l21_norm;  // host-precomputed in fp32 exactly as the reference does
   int update_slots;
+  int fast;               // row math on the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (kv_set_fast_math; 0: IEEE sequences)
 };
+
+// sqrt and division of the row math.  fast: one v_sqrt_f32 / v_rcp_f32 (1 ulp each: the update stays within north_star's
+// 1e-6 relative of the reference's correctly rounded Eigen arithmetic); else the IEEE sequences (bit-for-bit the
+// oracle's results: the deterministic mode and every table that asks for it keep them).  `fast` is uniform over the launch.
+#ifdef KV_FASTM_CONST
+#define KV_FASTM(a) (KV_FASTM_CONST != 0)
+#else
+#define KV_FASTM(a) ((a).fast != 0)
+#endif
+__device__ __forceinline__ float kv_sqrt(float x, bool fast) { return fast ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ __forceinline__ float kv_div(float x, float y, bool fast) { return fast ? x * __builtin_amdgcn_rcpf(y) : x / y; }
 
 // optimizer-side slot-table access: FindOrInsertUnsafe(filter_out == nullptr), kv_variable.h:382-416.
 // Called by the group leader only.  New rows get freq word 1 (day 0); hits AddFrequency(1, today).
@@ -520,6 +518,7 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
     float m[K][V], nv[K][V], sq[K][V], z[K][V], uu[K][V];
     float part = 0.f;
     const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
+    const bool fm = KV_FASTM(a);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
@@ -531,13 +530,13 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
         const float gg = gv[k][c];
         const float mn = a.b1 * mo + omb1 * gg;
         const float vn = a.b2 * vo + omb2 * (gg * gg);
-        const float s = sqrtf(vn);
+        const float s = kv_sqrt(vn, fm);
         float d;
         if (OPT == OPT_ADAM_V4) {
-          d = (a.b1 > a.b1p) ? (s - sqrtf(vo)) * xo : (s + a.eps) * xo;
+          d = (a.b1 > a.b1p) ? (s - kv_sqrt(vo, fm)) * xo : (s + a.eps) * xo;
         } else {
-          d = (a.b1 > a.b1p) ? (s - sqrtf(vo)) / a.lr * xo
-                             : (s - sqrtf(vo) + a.eps) / a.lr * xo;
+          d = (a.b1 > a.b1p) ? kv_div(s - kv_sqrt(vo, fm), a.lr, fm) * xo
+                             : kv_div(s - kv_sqrt(vo, fm) + a.eps, a.lr, fm) * xo;
         }
         const float zn = zo + (a.alpha * mn - d);
         const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
@@ -546,9 +545,9 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
         if (valid) part += uv * uv;
       }
     }
-    const float norm = sqrtf(group_sum<LPR>(part));
+    const float norm = kv_sqrt(group_sum<LPR>(part), fm);
     const bool upd = norm > a.l21_norm;
-    const float scale = 1.f - a.l21_norm / norm;
+    const float scale = 1.f - kv_div(a.l21_norm, norm, fm);
     const float two_l2 = 2.f * a.l2;
     bool big = false, sbig = false;
 #pragma unroll
@@ -561,8 +560,8 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
           xn[c] = 0.f;  // blacklist: the row reads as zeros (table_manager.h:335-357)
           if (upd) {
             const float y = (OPT == OPT_ADAM_V4) ? (sq[k][c] + a.eps) + two_l2
-                                                 : (sq[k][c] + a.eps) / a.lr + two_l2;
-            xn[c] = uu[k][c] * scale / y;
+                                                 : kv_div(sq[k][c] + a.eps, a.lr, fm) + two_l2;
+            xn[c] = kv_div(uu[k][c] * scale, y, fm);
           }
           big |= fabsf(xn[c]) >= CUTOFF;
           sbig |= fabsf(m[k][c]) >= CUTOFF || fabsf(nv[k][c]) >= CUTOFF || fabsf(z[k][c]) >= CUTOFF;
@@ -582,6 +581,7 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
   } else if (OPT == OPT_ADAGRAD) {
     // training_ops.cc:1470-1482.  No CoverUpdate: flags of existing rows are left alone.
     bool sbig = false;
+    const bool fm = KV_FASTM(a);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
@@ -593,8 +593,9 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
           const float gg = gv[k][c];
           sbig |= fabsf(acc[c]) >= CUTOFF;
           if (a.update_slots) acc[c] = acc[c] + gg * gg;
-          xo[c] = (D > 1) ? xo[c] - (a.lr * gg) * (1.f / sqrtf(acc[c]))
-                          : xo[c] - (a.lr * gg) / sqrtf(acc[c]);
+          if (fm) xo[c] = xo[c] - (a.lr * gg) * __builtin_amdgcn_rsqf(acc[c]);
+          else xo[c] = (D > 1) ? xo[c] - (a.lr * gg) * (1.f / sqrtf(acc[c]))
+                               : xo[c] - (a.lr * gg) / sqrtf(acc[c]);
         }
         stv<V>(xrow + e0, xo);
         stv<V>(s0row + e0, acc);
@@ -613,6 +614,7 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
     float part = 0.f;
     const bool half = a.lr_power == -0.5f;
     const float two_l2s = 2.f * a.l2s;
+    const bool fm = KV_FASTM(a);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int e0 = (lane + k * LPR) * V;
@@ -624,18 +626,18 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
         const float xo = x[k][c], ao = ac[k][c];
         const float gs = gv[k][c] + two_l2s * xo;
         const float na = ao + gs * gs;
-        const float pn = half ? sqrtf(na) : powf(na, -a.lr_power);
-        const float po = half ? sqrtf(ao) : powf(ao, -a.lr_power);
-        const float zn = zo + (gs - (pn - po) / a.lr * xo);
+        const float pn = half ? kv_sqrt(na, fm) : powf(na, -a.lr_power);
+        const float po = half ? kv_sqrt(ao, fm) : powf(ao, -a.lr_power);
+        const float zn = zo + (gs - kv_div(pn - po, a.lr, fm) * xo);
         const float adj = fmaxf(fminf(zn, a.l1), -a.l1);
         const float uv = adj - zn;
         z[k][c] = zn; uu[k][c] = uv;
         if (valid) part += uv * uv;
       }
     }
-    const float norm = sqrtf(group_sum<LPR>(part));
+    const float norm = kv_sqrt(group_sum<LPR>(part), fm);
     const bool upd = norm > a.l21_norm;
-    const float scale = 1.f - (a.l21_norm / norm);
+    const float scale = 1.f - kv_div(a.l21_norm, norm, fm);
     const float two_l2 = 2.f * a.l2;
     bool big = false, abig = false, zbig = false;
 #pragma unroll
@@ -648,9 +650,9 @@ __device__ __forceinline__ void opt_core(float* xrow, float* s0row, float* s1row
           const float xo = x[k][c];
           const float gs = gv[k][c] + two_l2s * xo;
           const float na = ac[k][c] + gs * gs;
-          const float pn = half ? sqrtf(na) : powf(na, -a.lr_power);
+          const float pn = half ? kv_sqrt(na, fm) : powf(na, -a.lr_power);
           xn[c] = 0.f;
-          if (upd) xn[c] = uu[k][c] * scale / (pn / a.lr + two_l2);
+          if (upd) xn[c] = kv_div(uu[k][c] * scale, kv_div(pn, a.lr, fm) + two_l2, fm);
           // accum += grad_to_use.square() re-evaluates the lazy expression with the updated
           // var (:747); on the blacklist branch the reference reads a freed row — we keep
           // the pre-blacklist value like oracle/kv_oracle.cc

@@ -41,8 +41,6 @@ constexpr int PA_NOAPPLY = 0x100;   // flag: no update — the partition pass of
 //   TBP = 512: 2048 hash slots, 2048 sources in LDS — chosen when the batch has at most 512 partitions (one resident
 //              generation of two blocks per CU)
 //   TBP = 256: 1024 hash slots, 1536 sources — more partitions than that, the deterministic mode, the batched ops
-constexpr int PA_LSRC_MIN = 1536;   // the source list every block shape holds in LDS: a bucketed index of more tiles than this
-                                    // is not built (a key may have one entry per tile, and a round cannot split a key)
 template <int TBP> struct PaShape { static constexpr int HSK = TBP >= 512 ? 2048 : 1024, LSRC = TBP >= 512 ? 2048 : 1536; };
 
 template <int OPT, int V, int LPR, int K, int TBP>
@@ -84,30 +82,8 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   const int D = a.tv.dim;
   const unsigned errflag = *reinterpret_cast<volatile unsigned*>(&a.tv.counters[1]);   // the tile pass gave up: bookkeeping only
   KV_STAMPP(0);
-  // bucket mode: the tiles appended the partition's entries to ONE contiguous bucket (kv_fused.h BktRec) — no directory
-  const bool bucket = w.bcap != 0u;
-  __shared__ unsigned bpre[NXCD + 1];   // entries in the sub-buckets before sub-bucket j
   unsigned pbase = 0;
-  unsigned E;
-  if (bucket) {
-    if (tid == 0) {
-      unsigned run = 0;
-#pragma unroll
-      for (int j = 0; j < NXCD; ++j) { bpre[j] = run; run += min(w.bcnt[((size_t)p * NXCD + j) * BCNT_STRIDE], w.bcap); }
-      bpre[NXCD] = run;
-    }
-    __syncthreads();
-    E = bpre[NXCD];
-  } else {
-    E = seg_directory_t<TBP, NW>(w, p, tpre, tstart, wtot, &pbase);
-  }
-  // record x of the partition (bucket mode): sub-bucket j = the last one with bpre[j] <= x
-  auto brec_of = [&](unsigned x) -> const uint4* {
-    unsigned j = 0;
-#pragma unroll
-    for (int q = 1; q < NXCD; ++q) j += bpre[q] <= x ? 1u : 0u;
-    return w.bkt + 2 * (((size_t)p * NXCD + j) * w.bcap + (x - bpre[j]));
-  };
+  const unsigned E = seg_directory_t<TBP, NW>(w, p, tpre, tstart, wtot, &pbase);
   KV_STAMPP(5);
   if (E == 0) return;
   if (tid == 0) { sp = 0; lkeys = 0; }
@@ -116,9 +92,8 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (tid == 0) raise_error(a.tv, 2u);
     return;
   }
-  // the round's sources live in LDS; a partition-sorted index files a larger partition in its stretch of w.order, a
-  // bucketed one splits the round until it fits (below)
-  const bool in_lds = bucket || E <= (unsigned)PA_LSRC;
+  // the round's sources live in LDS; a larger partition files them in its stretch of w.order
+  const bool in_lds = E <= (unsigned)PA_LSRC;
   unsigned* const gsrc = w.order + pbase;   // (the partitions' stretches of w.order are disjoint)
   auto src_at = [&](unsigned i) -> unsigned {
     // a stretch filed in global memory was written by other waves of this block: read past the CU's vector cache
@@ -142,32 +117,17 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       unsigned ge[EB];
       long long key[EB];
       unsigned ea[EB], rw[EB], hi[EB], sr[EB];
-      if (bucket) {
 #pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const unsigned x = x0 + k * TBP + tid;
-          ge[k] = x < E ? x : 0xFFFFFFFFu;
-          key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
-          if (x < E) {
-            const uint4* rp = brec_of(x);
-            const uint4 ra_ = rp[0], rb_ = rp[1];
-            key[k] = (long long)(((unsigned long long)ra_.y << 32) | ra_.x);
-            ea[k] = ra_.z; rw[k] = ra_.w; hi[k] = rb_.x; sr[k] = rb_.y;
-          }
-        }
-      } else {
+      for (int k = 0; k < EB; ++k) {
+        const unsigned x = x0 + k * TBP + tid;
+        ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
+      }
 #pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const unsigned x = x0 + k * TBP + tid;
-          ge[k] = x < E ? (unsigned)seg_entry(tpre, tstart, NT, x) : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
-          if (ge[k] != 0xFFFFFFFFu) {
-            key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]];
-            if (cached) sr[k] = w.ent_rec[ge[k]];
-          }
+      for (int k = 0; k < EB; ++k) {
+        key[k] = 0; ea[k] = 0; rw[k] = 0; hi[k] = 0; sr[k] = 0;
+        if (ge[k] != 0xFFFFFFFFu) {
+          key[k] = w.ent_key[ge[k]]; ea[k] = w.ent_a[ge[k]]; rw[k] = w.ent_b[ge[k]]; hi[k] = w.ent_base[ge[k]];
+          if (cached) sr[k] = w.ent_rec[ge[k]];
         }
       }
 #pragma unroll
@@ -220,7 +180,6 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       unsigned chrun = block_excl_scan<NW>(ch, wtot, &chtot);
       unsigned hrn = block_excl_scan<NW>(hh, wtot, &htot);
       const unsigned t1 = chtot & 1023u, t2 = (chtot >> 10) & 1023u;
-      if (bucket && tot > (unsigned)PA_LSRC) return true;   // (block-uniform) the round's sources do not fit LDS: split it
       nhot = htot; ncold = nu - htot;
 #pragma unroll
       for (int q = 0; q < PERU; ++q) {
@@ -323,25 +282,14 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           }
       } else {
         for (unsigned x = tid; x < E; x += TBP) {
-          long long key;
-          unsigned src;
-          size_t ge_u = 0;
-          if (bucket) {
-            const uint4* rp = brec_of(x);
-            const uint4 ra_ = rp[0];
-            key = (long long)(((unsigned long long)ra_.y << 32) | ra_.x);
-            src = rp[1].y;
-          } else {
-            const size_t ge = seg_entry(tpre, tstart, NT, x);
-            key = w.ent_key[ge];
-            src = w.ent_rec[ge];
-            ge_u = ge;
-          }
+          const size_t ge = seg_entry(tpre, tstart, NT, x);
+          const long long key = w.ent_key[ge];
+          const unsigned src = w.ent_rec[ge];
           if (!in_round(key, R, round)) continue;
           bool first;
           const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
           file(atomicAdd(&hocc[h], 1u), src);
-          if (mode == PA_UNIQUE && !bucket) w.ent_b[ge_u] = hrow[h];
+          if (mode == PA_UNIQUE) w.ent_b[ge] = hrow[h];
         }
       }
     }

@@ -53,8 +53,7 @@ extern "C" int kvp_launch_apply_a(int mode, int opt, const void* wd, const void*
 extern "C" int kvp_launch_apply_b(int mode, int opt, const void* wd, const void* pa, void* stream, const void* md, int ntab,
                                   unsigned nchunks, int span);
 
-extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, long long n, void* stream, const void* md,
-                               int ntab);
+extern "C" int kvp_launch_tsum(const void* td, const void* wd, const float* grad, void* stream, const void* md, int ntab);
 // k_papply dispatch (kv_papply.h), two more translation units: a = GroupAdam V4 / V3, b = Adagrad / SparseGroupFtrl
 // k_ltsum dispatch (kv_fused.h: tile pass + tile sums), instantiated next to k_tsum; ids_kind 0 int64, 1 int32
 extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids, int ids_kind, long long n, int det,
@@ -335,12 +334,8 @@ struct Workspace {
   long long hpart_elems = 0;
   unsigned* ctr = nullptr;
   unsigned* mcount = nullptr;  // entry-list pipeline: [cap_n / TILE]
-  long long* ids_copy = nullptr;   // [cap_n] the ids of a lookup whose tile pass is deferred (k_lrows copies them)
   unsigned short* pos_ent = nullptr;   // [pos_cap] sharded route: every position's entry number in its tile
   long long pos_cap = 0;
-  uint4* bkt = nullptr;            // bucket mode: [P][bcap] BktRec (2 uint4 each)
-  size_t bkt_records = 0;
-  unsigned* bcnt = nullptr;        // [2][MAX_P] bucket cursors, one set per batch parity
   float* epart = nullptr;      // [cap_n / 2][dim] tile sums
   long long epart_elems = 0;
   long long* scat_keys = nullptr;  // kv_scatter_update on repeated ids: de-duplicated ids and combined updates
@@ -391,28 +386,19 @@ struct kv_table {
   // same token takes the index over instead of rebuilding it
   uint64_t batch_serial = 0;
   long long batch_n = 0;
-  bool fused_index = false;        // the index is an entry list (kv_fused.h), not a sorted position list
-  bool index_records = true;       // ... whose partition pass has run: key records, entry list and work items exist (k_apply2's
-                                   // input).  false: the tiles' entries alone (a deferred partition pass, or an index that
-                                   // k_papply consumed straight from the entries) — an apply of that batch goes through k_papply
+  bool fused_index = false;        // the index is the tiles' entries (kv_fused.h: an apply of that batch goes through k_papply),
+                                   // not a sorted position list (kv_kernels.h)
   long long batch_n_prev = 0;      // ids of the previous entry-list index pass (the distinct-count hint belongs to that size)
   unsigned index_P = 0;            // partitions of the entry-list index the workspace holds
-  // overlap mode (kv_set_overlap): a side stream of the table's own; side_pending: it still runs the lookup's
-  // partition pass — the table's next op joins it (ev_part) first
-  bool overlap = false, side_pending = false;
-  bool side_has_items = false;     // the side stream also built the work-item directory (the apply launches the sums alone)
   // A training lookup that hands out a batch token returns when its rows are written; its partition pass (frequency
   // words, rows of new keys, the batch's key records and entry list) is PENDING: the optimizer apply of that batch
   // runs it in front of its own kernels, any other op on the table runs it first thing (settle).  Same stream order
   // as before, the rows just do not wait for it.
   bool part_pending = false;
-  unsigned index_bcap = 0;         // != 0: the index the workspace holds is BUCKETED (kv_fused.h): records per bucket ...
-  unsigned bkt_parity = 0;         // ... and which set of cursors it counted in (the tile pass of the next batch takes the other)
-  bool tile_pending = false;       // ... and so is its tile pass (k_lrows wrote the rows): the ids wait in ws.ids_copy
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_tile = nullptr, ev_copy = nullptr, ev_part = nullptr;
   bool deterministic = false;      // kv_set_deterministic
+  bool fast_math = false;          // kv_set_fast_math: the optimizers' sqrt / division on v_sqrt_f32 / v_rcp_f32 (1 ulp) —
+                                   // never in deterministic mode, which keeps the IEEE sequences
   uint64_t uid = 0;                // unique over the process: names the attached slot table safely
   uint64_t slot_uid = 0;           // uid of the slot table the index entries' hints refer to (0 = none)
   uint64_t slot_gen = 0;           // that table's `gen` when the hints were valid
@@ -645,7 +631,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
         (rc = regrow(&w.order, (size_t)cap + 1)) || (rc = regrow(&w.coldlist, 2 * (size_t)cap)) ||
         (rc = regrow(&w.hotlist, 2 * (size_t)cap)) || (rc = regrow(&w.litem, (size_t)cap)) ||
         (rc = regrow(&w.items, (size_t)cap)) || (rc = regrow(&w.pmeta, (size_t)capP + 1)) ||
-        (rc = regrow(&w.mcount, nt + 1)) || (rc = regrow(&w.ids_copy, (size_t)cap)))
+        (rc = regrow(&w.mcount, nt + 1)))
       return rc;
     if (!w.ctr) {   // zeroed: the first tile pass publishes ctr[5] (the previous pass's distinct keys) as a hint
       HIP_TRY(hipMalloc(&w.ctr, 8 * sizeof(unsigned)));
@@ -678,7 +664,6 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   return KV_OK;
 }
 
-bool papply_enabled();
 bool fused_ok(int D);
 
 // The sharded owner ops (kv_shard_lookup_serve / kv_shard_apply_serve) read a rank's OWN exchange segment where it was
@@ -724,63 +709,11 @@ WsDev ws_view(kv_table* t, long long n) {
   d.mrow = w.slot_rank;
   d.mcount = w.mcount;
   d.epart = w.epart;
-  d.hc = (unsigned)HC;
-  // many distinct keys -> up to 1 M / 8 work items: 16 directory blocks would take 30 us to file them (Zipf 0.3)
-  d.nib = std::min(128u, std::max((unsigned)ITEM_BLOCKS, d.ntiles / 4u));
   d.pos_ent = nullptr;
   d.self_lo = d.self_len = 0; d.ids_self = nullptr; d.grad_self = nullptr;
   for (const SelfSegment& x : tl_selfs)
     if (x.table == t) { d.self_lo = x.lo; d.self_len = x.len; d.ids_self = x.ids; d.grad_self = x.grad; }
-  d.bkt = w.bkt;
-  d.bcap = t->index_bcap;
-  d.bcnt = w.bcnt ? w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE : nullptr;
-  d.bcnt_other = w.bcnt ? w.bcnt + (size_t)(t->bkt_parity ^ 1u) * MAX_P * NXCD * BCNT_STRIDE : nullptr;
   return d;
-}
-
-// Bucket mode of the entry-list index (kv_fused.h ltile_body<BUCKET>): the tiles append their entries to per-partition
-// buckets, so that the partition pass reads one contiguous stream instead of a segment per tile.  KV_BUCKET=1 turns it
-// on (A/B only).  Measured at configs[1]: k_papply 64.9 -> 60.8 us (no directory, no binary search, one 32-byte record
-// per entry instead of five arrays), but every entry costs the tile pass a RETURNING global atomic on its bucket's
-// cursor, and those come back after ~10 us under this load whatever their scope (k_ltile 56.4 -> 65.3 us with one cursor
-// per XCD and cache line, 70.4 us with device-scope cursors, 138 us with 32 cursors per line; the stamps put all of it
-// in the phase that waits for the cursor): a net loss of 5 us per step, so the partition-sorted tiles stay the default.
-// Not for the deterministic mode (a bucket holds its entries in arrival order), nor for batches of more tiles than a
-// partition block's source list holds (a key may have one entry per tile).
-bool bucket_enabled(const kv_table* t, long long n) {
-  static const bool on = [] { const char* e = getenv("KV_BUCKET"); return e && atoi(e) != 0; }();
-  return on && papply_enabled() && fused_ok(t->dim) && !t->deterministic && !t->overlap && (n + TILE - 1) / TILE <= PA_LSRC_MIN;
-}
-// records per sub-bucket: twice an even share of the entries (at most one per id), plus room for eight keys that occur
-// in every tile and land in the same partition (each brings ntiles / 8 entries per XCD), plus slack.  A bucket that still overflows voids the batch (the error the
-// partition pass raises when a partition holds more than 65535 entries): a hashed partition does not get there.
-unsigned bucket_capacity(long long n, unsigned P) {   // per SUB-bucket (one per XCD: the tiles go round the XCDs)
-  const long long nt = (n + TILE - 1) / TILE;
-  return (unsigned)std::min<long long>(65535, 2 * ((n + (long long)P * NXCD - 1) / ((long long)P * NXCD)) + nt + 256);
-}
-// sets wd's bucket fields for a NEW index of n ids in wd.P partitions (next parity), growing the buffers when needed
-int begin_bucket_index(kv_table* t, WsDev& wd, long long n, hipStream_t s) {
-  Workspace& w = t->ws;
-  int rc;
-  if (!w.bcnt) {
-    HIP_TRY(hipMalloc(&w.bcnt, 2 * (size_t)MAX_P * NXCD * BCNT_STRIDE * sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(w.bcnt, 0, 2 * (size_t)MAX_P * NXCD * BCNT_STRIDE * sizeof(unsigned), s));
-  }
-  const unsigned cap = bucket_capacity(n, wd.P);
-  const size_t need = (size_t)wd.P * NXCD * cap;
-  if (w.bkt_records < need) {
-    HIP_TRY(hipStreamSynchronize(s));
-    w.bkt_records = 0;
-    if ((rc = regrow(&w.bkt, 2 * need))) return rc;
-    w.bkt_records = need;
-  }
-  t->bkt_parity ^= 1u;
-  t->index_bcap = cap;
-  wd.bkt = w.bkt;
-  wd.bcap = cap;
-  wd.bcnt = w.bcnt + (size_t)t->bkt_parity * MAX_P * NXCD * BCNT_STRIDE;
-  wd.bcnt_other = w.bcnt + (size_t)(t->bkt_parity ^ 1u) * MAX_P * NXCD * BCNT_STRIDE;
-  return KV_OK;
 }
 
 // brackets one kernel launch with a pair of events when profiling is on
@@ -803,6 +736,9 @@ struct ProfScope {
     }
   }
 };
+
+// the optimizers' row math on the hardware's 1-ulp sqrt / reciprocal (kv_device.h kv_sqrt / kv_div)?
+bool fast_math_on(const kv_table* t) { return t->fast_math && !t->deterministic; }
 
 unsigned today(const kv_table* t) {
   if (t->fixed_day >= 0) return (unsigned)t->fixed_day & 0xFFFFu;
@@ -886,11 +822,6 @@ void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t 
 }
 
 // ---- the entry-list pipeline (kv_fused.h) ----
-// KV_NO_PAPPLY=1: A/B against k_part2 + k_apply2
-bool papply_enabled() {
-  static const bool off = [] { const char* e = getenv("KV_NO_PAPPLY"); return e && atoi(e) != 0; }();
-  return !off;
-}
 // ids per index pass: positions and epart rows are 30-bit fields of the entry list's words, a partition block takes
 // up to 65535 entries; 2^23 ids (4096 tiles) stay well inside both
 constexpr long long FUSED_MAX_N = 1ll << 23;
@@ -918,12 +849,6 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   do {                                                                                                      \
     if (md && multi_rows) k_ltile_multi<IDT, VQ, true><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md); \
     else if (md) k_ltile_multi<IDT, 1, false><<<dim3((unsigned)grid, (unsigned)ntab), TBT, sh, s>>>(md);     \
-    else if (wd.bcap != 0u) {                                                                               \
-      if constexpr (!std::is_same<IDT, IdCount>::value) {                                                   \
-        if (out) k_ltile<IDT, VQ, true, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out); \
-        else k_ltile<IDT, 1, false, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr); \
-      }                                                                                                     \
-    }                                                                                                       \
     else if (out) k_ltile<IDT, VQ, true><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, out); \
     else k_ltile<IDT, 1, false><<<grid, TBT, sh, s>>>(td, wd, (const IDT*)ids, counts, n, det, nullptr);     \
   } while (0)
@@ -944,82 +869,31 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
 }
 // the table-less tile pass of the sharded route (int64 ids): entries, mrow, every position's entry number
 void launch_ltile_notable(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, long long n, hipStream_t s) {
-  k_ltile<long long, 1, false, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, nullptr, n,
+  k_ltile<long long, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, nullptr, n,
                                                                                           t->deterministic ? 1 : 0, nullptr);
 }
-int ensure_side(kv_table* t) {
-  if (!t->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&t->ev_fork, &t->ev_tile, &t->ev_copy, &t->ev_part}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  }
-  return KV_OK;
-}
-// the training lookup's rows alone (overlap mode): one 64-id step per wave
-void launch_copy(kv_table* t, const TableDev& td, const void* ids, long long n, float* out, hipStream_t s) {
-  const int q = td.dim / 4;
-  const int grid = nblocks(n, TB, 8192);
-#define KV_CP2(IDT, VQ) k_copy<IDT, VQ><<<grid, TB, 0, s>>>(td, (const IDT*)ids, out, n)
-#define KV_CP(IDT)                                                              \
-  do {                                                                          \
-    switch (q) {                                                                \
-      case 1: KV_CP2(IDT, 1); break;   case 2: KV_CP2(IDT, 2); break;           \
-      case 4: KV_CP2(IDT, 4); break;   case 8: KV_CP2(IDT, 8); break;           \
-      case 16: KV_CP2(IDT, 16); break; case 32: KV_CP2(IDT, 32); break;         \
-      default: KV_CP2(IDT, 64); break;                                          \
-    }                                                                           \
-  } while (0)
-  if (t->key_dtype == KV_DT_INT32) KV_CP(int); else KV_CP(long long);
-#undef KV_CP
-#undef KV_CP2
-}
-// the training lookup's rows by per-position probe (+ a copy of the ids for the deferred tile pass)
-void launch_lrows(kv_table* t, const TableDev& td, const void* ids, void* ids_copy, long long n, float* out, hipStream_t s) {
-  const int q = td.dim / 4;
-  const int grid = nblocks(n, TB, 8192);
-#define KV_LR2(IDT, VQ) k_lrows<IDT, VQ><<<grid, TB, 0, s>>>(td, (const IDT*)ids, (IDT*)ids_copy, out, n)
-#define KV_LR(IDT)                                                              \
-  do {                                                                          \
-    switch (q) {                                                                \
-      case 1: KV_LR2(IDT, 1); break;   case 2: KV_LR2(IDT, 2); break;           \
-      case 4: KV_LR2(IDT, 4); break;   case 8: KV_LR2(IDT, 8); break;           \
-      case 16: KV_LR2(IDT, 16); break; case 32: KV_LR2(IDT, 32); break;         \
-      default: KV_LR2(IDT, 64); break;                                          \
-    }                                                                           \
-  } while (0)
-  if (t->key_dtype == KV_DT_INT32) KV_LR(int); else KV_LR(long long);
-#undef KV_LR
-#undef KV_LR2
-}
-// records = false (one table): the bookkeeping alone — no key records, entry list or work items (k_part2<MODE, false>)
-template <int MODE>
-void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0, bool records = true) {
-  if (md) k_part2_multi<MODE><<<dim3(wd.P, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
-  else if (!records) k_part2<MODE, false><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
-  else k_part2<MODE><<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
-}
-// A lookup's partition pass that no k_apply2 will follow writes no records: an apply that still comes with the batch's
-// token runs k_papply over the tiles' entries (PA_NONE).  KV_PART2_RECORDS=1: always (A/B).
-bool part2_lean() {
-  static const bool keep = [] { const char* e = getenv("KV_PART2_RECORDS"); return e && atoi(e) != 0; }();
-  return !keep && papply_enabled();
+// the bookkeeping of a training lookup that no apply takes over (k_part2); md: `ntab` tables in one launch
+void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
+  if (md) k_part2_multi<<<dim3(wd.P, (unsigned)ntab), TBK, (size_t)wd.ntiles * 4 + 32, s>>>(md);
+  else k_part2<<<(int)wd.P, TBK, (size_t)wd.ntiles * 4 + 32, s>>>(wd, pa);
 }
 
 // segmented fold over the sorted positions + fused update (k_apply_sorted), then the keys that cross chunk
 // boundaries (k_apply_span).  pa.n = ids of the batch (multi: nmax = the largest table's batch)
 template <int MODE, int OPT>
 int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long long nmax, hipStream_t s,
-                 const MultiDesc* md = nullptr, int ntab = 0, bool skip_fin = false, bool entry_list = false) {
+                 const MultiDesc* md = nullptr, int ntab = 0, bool skip_fin = false) {
   const int D = pa.tv.dim;
   // waves stride over the items (hot chunks, then cold batches of 64 / LPR keys); 8 blocks of 4 waves per CU
   // is everything the chip holds at once, fewer for small batches
-  static const int gmax = [] { const char* e = getenv("KV_APPLY_BLOCKS"); return e ? atoi(e) : 2048; }();
+  constexpr int gmax = 2048;
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(gmax, (nmax / 2 + chunk_cap(nmax)) / 4 + 1));
   const unsigned gfin = (unsigned)std::max<long long>(1, std::min<long long>(256, nmax / 4096 + 1));   // each block reads its share of the items at once
   auto fn = (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3)) ? kvp_launch_apply_a : kvp_launch_apply_b;
   int rc;
   {
     ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
-    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, entry_list ? 2 : 0);
+    rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, 0);
   }
   if (rc == KV_OK && !skip_fin) {
     ProfScope ps(prof_t, KV_PROF_APPLY_SPAN, s);
@@ -1058,12 +932,9 @@ int report_deferred_error(kv_table* t, hipStream_t s) {
 int flush_part(kv_table* t, hipStream_t s);
 // mutates == false: a read-only op (the inference gathers): ordered like any other op of the table — behind the table's
 // last op whatever its stream, and the next op behind it — but it does not move op_serial (a two-phase export may go on)
-int hand_over(kv_table* t, hipStream_t s, bool join_side = true, bool mutates = true) {
-  if (t->side_pending && join_side) {   // the lookup's partition pass on the table's side stream (overlap mode)
-    HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
-    t->side_pending = false;
-  }
-  if (t->part_pending && join_side) {   // (an apply that takes the batch over runs it itself, behind the stream hand-over below)
+// settle == false: the caller is the optimizer apply that takes the table's pending partition pass over
+int hand_over(kv_table* t, hipStream_t s, bool settle = true, bool mutates = true) {
+  if (t->part_pending && settle) {   // (an apply that takes the batch over runs it itself, behind the stream hand-over below)
     int rc;
     if (t->has_last && t->last_stream != s) {
       HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
@@ -1082,13 +953,9 @@ int hand_over(kv_table* t, hipStream_t s, bool join_side = true, bool mutates = 
   return KV_OK;
 }
 
-// ops that read a table without the full hand_over (no workspace, no row-set change): they still join the table's
-// side stream (overlap mode: the last lookup's partition pass may be initialising rows there)
+// ops that read a table without the full hand_over (no workspace, no row-set change): the last lookup's pending
+// partition pass (it may still have rows to initialise) is settled first
 int join_side(kv_table* t, hipStream_t s) {
-  if (t->side_pending) {
-    HIP_TRY(hipStreamWaitEvent(s, t->ev_part, 0));
-    t->side_pending = false;
-  }
   if (t->part_pending) {
     if (t->has_last && t->last_stream != s) {
       HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
@@ -1110,7 +977,7 @@ struct MultiLock {
     for (auto* t : ts) t->mu.lock();
   }
   ~MultiLock() { for (auto it = ts.rbegin(); it != ts.rend(); ++it) (*it)->mu.unlock(); }
-  // later: this table's side stream (overlap mode) is joined by the caller, behind the work that does not need it
+  // later: this table's pending partition pass is taken over by the caller (the optimizer apply of that batch)
   int enter(hipStream_t s, kv_table* later = nullptr) {
     int rc;
     for (auto* t : ts)
@@ -1133,8 +1000,6 @@ template <int MODE>
 void index_pass(kv_table* t, const WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
                 int ids_kind, float* out, hipStream_t s, bool file_order = true) {
   t->fused_index = false;
-  t->index_records = true;
-  t->index_bcap = 0;
   {
     ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
     launch_tile<false>(t, wd, ids, counts, n, s, ids_kind);
@@ -1156,23 +1021,10 @@ int flush_part(kv_table* t, hipStream_t s) {
   WsDev wd; PartArgs pa;
   std::memcpy(&wd, t->pend_wd, sizeof wd);
   std::memcpy(&pa, t->pend_pa, sizeof pa);
-  if (t->tile_pending) {   // the lookup wrote its rows by per-position probe: the tile pass over its copy of the ids
-    t->tile_pending = false;
-    ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-    launch_ltile(t, pa.tv, wd, t->ws.ids_copy, nullptr, pa.n, nullptr, s, -1);
-  }
   ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
-  // (a sharded owner lookup whose own segment stays in the send buffers: the apply that may still follow must be
-  //  k_papply's — PA_NONE over the entries — because only the entry-list kernels read that segment in place)
-  if (wd.bcap != 0u || wd.self_len != 0u) {   // a bucketed index: k_papply is its partition pass — here the lookup's bookkeeping alone
-    pa.day_lk = pa.day;
-    const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_LOOKUP | PA_NOAPPLY, (void*)s);
-    if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
-  } else {
-    const bool lean = part2_lean() && fused_ok(pa.tv.dim) && !t->overlap;
-    launch_part2<MODE_LOOKUP>(wd, pa, s, nullptr, 0, !lean);
-    t->index_records = !lean;
-  }
+  // (k_part2 reads the tiles' entries alone — also behind a sharded owner lookup whose own segment stayed in the send
+  //  buffers; an apply that still comes with the batch's token runs k_papply PA_NONE over the same entries)
+  launch_part2(wd, pa, s);
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -1196,8 +1048,7 @@ void choose_partitions(kv_table* t, WsDev& wd, long long n) {
       // waves with 128 keys each 64.7 us, one block of sixteen waves with 512 keys 75 us; profiles/r04_tools_output.txt).
       // (a hint is only a hint: never more distinct keys than ids, never more partitions than the workspace was sized for)
       const unsigned long long u = std::min<unsigned long long>(u_prev, (unsigned long long)n);
-      static const unsigned long long pa_per = [] { const char* e = getenv("KV_PA_PER"); return e ? (unsigned long long)atoll(e) : 256ull; }();   // A/B knob
-      const unsigned long long per = papply_enabled() ? pa_per : 384ull;
+      const unsigned long long per = 256ull;
       const unsigned long long want = std::max<unsigned long long>((u + per - 1ull) / per, (unsigned long long)((n + 2047) / 2048));
       const unsigned pmax = std::min<unsigned>((unsigned)MAX_P, std::max(64u, t->ws.capP));
       unsigned P = 64;
@@ -1211,159 +1062,48 @@ void choose_partitions(kv_table* t, WsDev& wd, long long n) {
   }
 }
 
-// The entry-list index of a batch (kv_fused.h): tile pass (with the output rows when out != nullptr), partition pass
-template <int MODE>
-int fused_index_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
-                     int ids_kind, float* out, hipStream_t s, bool side_part = false, bool defer_part = false,
-                     bool tile_only = false, bool defer_tile = false) {
-  wd.hc = (unsigned)HC2;
+// The training lookup on the entry-list kernels (kv_fused.h): the tile pass with the output rows; then the lookup's
+// bookkeeping (k_part2) — or, defer_part: it stays PENDING for the optimizer apply of this batch (k_papply completes it
+// in the same pass as the update) or for whatever op the table sees next (flush_part)
+int fused_lookup_pass(kv_table* t, WsDev& wd, const PartArgs& pa, const void* ids, const int* counts, long long n,
+                      int ids_kind, float* out, hipStream_t s, bool defer_part) {
   t->fused_index = true;
-  t->index_records = true;
-  t->index_bcap = 0;
-  wd.bcap = 0;
   choose_partitions(t, wd, n);
-  // bucket mode: the tiles append their entries to per-partition buckets and k_papply is the only partition pass (with
-  // PA_NOAPPLY when no optimizer apply takes the batch over)
-  const bool bucket = bucket_enabled(t, n) && ids_kind != 2 && wd.seg_cap == 0 && !side_part;
-  if (bucket) {
-    const int rcb = begin_bucket_index(t, wd, n, s);
-    if (rcb) return rcb;
-    t->index_records = false;
-  }
-  if (MODE == MODE_LOOKUP && out && t->overlap && !counts && ids_kind < 0 && pow2_rows(t->dim)) {
-    // overlap mode: rows on the side stream beside the tile pass; the partition pass follows the rows there and
-    // is joined by the table's next op (hand_over).  Under stream capture these are graph edges.
-    HIP_TRY(hipEventRecord(t->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-    {
-      ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-      launch_ltile(t, pa.tv, wd, ids, counts, n, nullptr, s, ids_kind);
-    }
-    HIP_TRY(hipEventRecord(t->ev_tile, s));
-    launch_copy(t, pa.tv, ids, n, out, t->side);
-    HIP_TRY(hipEventRecord(t->ev_copy, t->side));
-    HIP_TRY(hipStreamWaitEvent(t->side, t->ev_tile, 0));
-    launch_part2<MODE_LOOKUP>(wd, pa, t->side);
-    HIP_TRY(hipEventRecord(t->ev_part, t->side));
-    t->side_pending = true;
-    t->side_has_items = false;
-    HIP_TRY(hipStreamWaitEvent(s, t->ev_copy, 0));
-    return KV_OK;
-  }
-  if (MODE == MODE_LOOKUP && out && defer_tile && defer_part && !counts && ids_kind < 0) {
-    // The rows by per-position probe (k_lrows: the inference gather with the init rule's value for absent keys) and
-    // nothing else: the tile pass — inserts, entries — and the partition pass wait for the table's next op.  The
-    // optimizer apply of this batch runs the tile pass together with its tile sums (k_ltsum) and the partition pass
-    // together with the update (k_papply); any other op settles both first (flush_part).
-    static const bool x_goz = [] { const char* e = getenv("KV_X_LROWS_GOZ"); return e && atoi(e) != 0; }();   // diagnostic: the inference gather in k_lrows' place (every key present)
-    if (x_goz && t->key_dtype != KV_DT_INT32 && pa.tv.dim == 32) {
-      HIP_TRY(hipMemcpyAsync(t->ws.ids_copy, ids, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-      ProfScope ps(t, KV_PROF_LOOKUP_ROWS, s);
-      k_gather_or_zeros_w<long long, 8><<<nblocks(n, TB, 8192), TB, 0, s>>>(pa.tv, (const long long*)ids, out, n);
-    } else {
-      ProfScope ps(t, KV_PROF_LOOKUP_ROWS, s);
-      launch_lrows(t, pa.tv, ids, t->ws.ids_copy, n, out, s);
-    }
-    t->side_has_items = false;
-    std::memcpy(t->pend_wd, &wd, sizeof wd);
-    std::memcpy(t->pend_pa, &pa, sizeof pa);
-    t->part_pending = true;
-    t->tile_pending = true;
-    t->index_records = false;
-    return KV_OK;
-  }
   {
-    ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_TILE : KV_PROF_INDEX, s);
+    ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
     launch_ltile(t, pa.tv, wd, ids, counts, n, out, s, ids_kind);
   }
-  if (MODE == MODE_LOOKUP && side_part && !(t->prof && ((t->prof_mask >> KV_PROF_LOOKUP_PART) & 1u))) {
-    // The lookup's result is complete: the partition pass (frequency words, rows of new keys, the batch's key records
-    // and entry list) and the work-item directory go to the table's side stream, where they run beside whatever
-    // the caller does next — the dense tower; in a bare lookup + apply loop, the apply's tile sums.  One event
-    // hop on the side stream, none on the caller's; the table's next op joins (hand_over), the optimizer apply of
-    // this batch behind its tile sums (fused_apply).
-    int rc;
-    if ((rc = ensure_side(t))) return rc;
-    HIP_TRY(hipEventRecord(t->ev_tile, s));
-    HIP_TRY(hipStreamWaitEvent(t->side, t->ev_tile, 0));
-    launch_part2<MODE_LOOKUP>(wd, pa, t->side);
-    if ((rc = kvp_launch_tsum(&pa.tv, &wd, nullptr, n, (void*)t->side, nullptr, 0))) return fail(rc, "item directory");
-    HIP_TRY(hipEventRecord(t->ev_part, t->side));
-    t->side_pending = true;
-    t->side_has_items = true;
-    return KV_OK;
-  }
-  t->side_has_items = false;
-  if (tile_only) {   // the caller goes on with k_papply, which works on the tiles' entries
-    t->index_records = false;
-    return KV_OK;
-  }
-  if (MODE == MODE_LOOKUP && defer_part) {   // the rows are out: the partition pass waits for the table's next op
+  if (defer_part) {   // the rows are out: the partition pass waits for the table's next op
     std::memcpy(t->pend_wd, &wd, sizeof wd);
     std::memcpy(t->pend_pa, &pa, sizeof pa);
     t->part_pending = true;
-    t->index_records = false;
     return KV_OK;
   }
-  ProfScope ps(t, MODE == MODE_LOOKUP ? KV_PROF_LOOKUP_PART : KV_PROF_INDEX, s);
-  if (bucket) {
-    PartArgs pb = pa;
-    pb.day_lk = pa.day;
-    const int rcp = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pb, (MODE == MODE_LOOKUP ? PA_LOOKUP : PA_APPLYIDX) | PA_NOAPPLY, (void*)s);
-    if (rcp) return fail(rcp, "partition pass: no kernel for dim %d", pa.tv.dim);
-    return KV_OK;
-  }
-  const bool lean = MODE == MODE_LOOKUP && part2_lean() && !t->overlap;   // (a lookup without a deferred pass hands out no usable index for k_apply2)
-  launch_part2<MODE>(wd, pa, s, nullptr, 0, !lean);
-  if (lean) t->index_records = false;
+  ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
+  launch_part2(wd, pa, s);
   return KV_OK;
 }
-// ... and the apply over it: tile sums of the repeated ids, then k_apply on the entry list (k_apply_fin only when
-// a key can have more entries than a chunk holds, i.e. more tiles than HC2)
-// pa_mode >= 0: the tile sums, then partition pass + apply in one launch (k_papply, kv_papply.h) over the tiles' entries
+// ... and the optimizer apply over the tiles' entries: the tile sums of the repeated ids (k_tsum; tile_ids != nullptr: the
+// batch's tile pass has not run yet and runs in the same launch, k_ltsum), then partition pass + update in one launch
+// (k_papply, kv_papply.h: pa_mode = PA_LOOKUP / PA_APPLYIDX / PA_NONE)
 template <int OPT>
-int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, bool join_side = false, int pa_mode = -1,
-                const void* tile_ids = nullptr) {
-  wd.hc = (unsigned)HC2;
+int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s, int pa_mode, const void* tile_ids = nullptr) {
   pa.epart = wd.epart;
-  if (pa_mode >= 0) {
-    if (tile_ids) {   // the batch's tile pass has not run yet: it runs here, with the tile sums (k_ltsum)
-      ProfScope ps(v, KV_PROF_APPLY_TILE, s);
-      const int rc = kvp_launch_ltsum(&pa.tv, &wd, tile_ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, v->deterministic ? 1 : 0,
-                                      pa.grad, (void*)s);
-      if (rc) return fail(rc, "tile pass + tile sums: no kernel for dim %d", pa.tv.dim);
-    } else {
-      ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
-      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s, nullptr, 0);
-      if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
-    }
-    ProfScope ps(v, KV_PROF_APPLY_SORTED, s);
-    const int rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_papply_a(OPT, &wd, &pa, pa_mode, (void*)s)
-                                                              : kvp_launch_papply_b(OPT, &wd, &pa, pa_mode, (void*)s);
-    if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", pa.tv.dim);
-    return KV_OK;
-  }
-  if (join_side) {
-    // overlap mode: the tile sums need the tile pass only; the item directory needs the partition pass, so here it
-    // is its own little launch behind the join
-    {
-      ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
-      const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, -n, (void*)s, nullptr, 0);
-      if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
-    }
-    HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
-    v->side_pending = false;
-    if (!v->side_has_items) {
-      const int rc = kvp_launch_tsum(&pa.tv, &wd, nullptr, n, (void*)s, nullptr, 0);
-      if (rc) return fail(rc, "item directory");
-    }
+  if (tile_ids) {
+    ProfScope ps(v, KV_PROF_APPLY_TILE, s);
+    const int rc = kvp_launch_ltsum(&pa.tv, &wd, tile_ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, v->deterministic ? 1 : 0,
+                                    pa.grad, (void*)s);
+    if (rc) return fail(rc, "tile pass + tile sums: no kernel for dim %d", pa.tv.dim);
   } else {
     ProfScope ps(v, KV_PROF_APPLY_TSUM, s);
-    const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, n, (void*)s, nullptr, 0);
+    const int rc = kvp_launch_tsum(&pa.tv, &wd, pa.grad, (void*)s, nullptr, 0);
     if (rc) return fail(rc, "tile sums: no kernel for dim %d", pa.tv.dim);
   }
-  static const bool old_apply = [] { const char* e = getenv("KV_OLD_APPLY"); return e && atoi(e) != 0; }();   // A/B: k_apply over the entry list
-  return launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s, nullptr, 0, wd.ntiles <= wd.hc, !old_apply);
+  ProfScope ps(v, KV_PROF_APPLY_SORTED, s);
+  const int rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_papply_a(OPT, &wd, &pa, pa_mode, (void*)s)
+                                                            : kvp_launch_papply_b(OPT, &wd, &pa, pa_mode, (void*)s);
+  if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", pa.tv.dim);
+  return KV_OK;
 }
 
 std::atomic<uint64_t> g_serial{0};   // batch tokens
@@ -1509,12 +1249,7 @@ int kv_destroy(kv_handle_t t) {
   Workspace& w = t->ws;
   hipFree(w.ent_key); hipFree(w.ent_a); hipFree(w.ent_b); hipFree(w.ent_base); hipFree(w.ent_rec); hipFree(w.toff); hipFree(w.slot_rank);
   hipFree(w.order); hipFree(w.coldlist); hipFree(w.hotlist); hipFree(w.litem); hipFree(w.items); hipFree(w.pmeta); hipFree(w.hpart);
-  hipFree(w.mcount); hipFree(w.epart); hipFree(w.ids_copy); hipFree(w.bkt); hipFree(w.bcnt); hipFree(w.pos_ent);
-  if (t->side) {
-    hipStreamSynchronize(t->side);
-    hipStreamDestroy(t->side);
-    for (hipEvent_t e : {t->ev_fork, t->ev_tile, t->ev_copy, t->ev_part}) if (e) hipEventDestroy(e);
-  }
+  hipFree(w.mcount); hipFree(w.epart); hipFree(w.pos_ent);
   hipFree(w.ctr); hipFree(w.dbg); hipFree(w.scat_keys); hipFree(w.scat_sum); hipFree(w.seg_off);
   if (t->err_host) hipHostFree(t->err_host);
   if (t->last_done) hipEventDestroy(t->last_done);
@@ -1526,7 +1261,7 @@ int kv_destroy(kv_handle_t t) {
 // changes what the passes would compute (seed, deterministic order), first lets them run — on the stream of the
 // table's last op — and waits for them.
 static int settle_pending(kv_table* t) {
-  if (!t->part_pending && !t->side_pending) return KV_OK;
+  if (!t->part_pending) return KV_OK;
   hipStream_t s = t->has_last ? t->last_stream : nullptr;
   int rc;
   if ((rc = join_side(t, s))) return rc;
@@ -1706,20 +1441,8 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     pa.day = today(t);
     pa.det = t->deterministic ? 1 : 0;
     pa.n = m;
-    // KV_SIDE_PART=1 (diagnostic): the partition pass of a lookup that hands out a token runs on the table's side
-    // stream, beside the apply's tile sums.  Measured on this stack: 0.32 ms per step against 0.155 ms — one event
-    // dependency between two streams costs more than the whole pass; off unless asked for.
-    static const bool side_on = [] { const char* e = getenv("KV_SIDE_PART"); return e && atoi(e) != 0; }();
-    const bool side_part = side_on && token != nullptr && n <= CHK;
-    static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();   // A/B
-    const bool defer_part = token != nullptr && n <= CHK && !side_part && !no_defer;   // a token is asked for: an apply of this batch follows
-    // KV_DEFER_TILE=1 (A/B): the rows by per-position probe (k_lrows), the tile pass with the apply's tile sums (k_ltsum).
-    // Measured at configs[1] inside the training loop: k_lrows 49 us (the inference gather in its place: 45 us; 28 us
-    // only when the same few batches repeat and stay in the infinity cache) + k_ltsum 43 us against k_ltile 55 us +
-    // k_tsum 24 us: the de-duplicated probes and rows of k_ltile win.  Off unless asked for.
-    static const bool defer_tile_on = [] { const char* e = getenv("KV_DEFER_TILE"); return e && atoi(e) != 0; }();
-    const bool defer_tile = defer_part && papply_enabled() && defer_tile_on && !t->overlap && !cp && !pairs && seg_cap == 0 && pow2_rows(t->dim);
-    if (fused_ok(t->dim)) { if ((rc = fused_index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, side_part, defer_part, false, defer_tile))) return rc; }
+    const bool defer_part = token != nullptr && n <= CHK;   // a token is asked for: an apply of this batch follows
+    if (fused_ok(t->dim)) { if ((rc = fused_lookup_pass(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, defer_part))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -2008,7 +1731,7 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
     if (seg_caps) d.w.seg_cap = seg_caps[i];
-    if (fused_ok(tables[i]->dim)) { d.w.hc = (unsigned)HC2; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
+    if (fused_ok(tables[i]->dim)) { d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
     d.a.det = tables[i]->deterministic ? 1 : 0;
@@ -2026,13 +1749,12 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
   if (fused_ok(t0->dim)) {
-    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = true; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
+    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = true;
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, ids_kind, md, num_tables, true);
     // tokens asked for: an optimizer apply of these batches follows — every table's partition pass stays pending
     // (kv_multi_apply_*_tok completes it inside k_papply_multi; any other op on a table settles that table first)
-    static const bool no_defer = [] { const char* e = getenv("KV_NO_DEFER_PART"); return e && atoi(e) != 0; }();
-    const bool defer = tokens != nullptr && papply_enabled() && !no_defer;
-    if (!defer) launch_part2<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
+    const bool defer = tokens != nullptr;
+    if (!defer) launch_part2(wmax, hd[0].a, s, md, num_tables);
     if (tokens)   // every table's workspace now holds the index of exactly its batch (kv_multi_apply_*_tok takes it over)
       for (int i = 0; i < num_tables; ++i) {
         if (ns[i] <= 0) continue;
@@ -2044,12 +1766,10 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
           std::memcpy(tables[i]->pend_wd, &hd[i].w, sizeof(WsDev));
           std::memcpy(tables[i]->pend_pa, &hd[i].a, sizeof(PartArgs));
           tables[i]->part_pending = true;
-          tables[i]->tile_pending = false;
-          tables[i]->index_records = false;
         }
       }
   } else {
-    for (int i = 0; i < num_tables; ++i) { tables[i]->fused_index = false; tables[i]->index_records = true; tables[i]->index_bcap = 0; }
+    for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = false;
     launch_tile<false>(t0, wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
     launch_part_keys<MODE_LOOKUP>(wmax, hd[0].a, s, md, num_tables);
     launch_gather(hd[0].a.tv, wmax, nullptr, nmax, s, md, num_tables);
@@ -2094,34 +1814,33 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
-  // the batches' own partition passes are still pending (kv_multi_gather_or_insert_tok deferred them) and every token
-  // matches: k_papply_multi completes them together with the update; else every pending pass is settled on entry
-  const bool pa_route = papply_enabled() && fused_ok(D);
-  bool pa_reuse = tokens != nullptr && pa_route;
-  for (int i = 0; i < num_tables && pa_reuse; ++i)
-    if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
-                       vars[i]->part_pending && !vars[i]->tile_pending && !vars[i]->index_records && vars[i]->index_bcap == 0 &&
-                       !vars[i]->side_pending))
-      pa_reuse = false;
+  // The entry-list kernels (fused_ok): every table still holds the tiles' entries of its batch (kv_multi_gather_or_insert_tok)
+  // and every token matches -> k_papply_multi over them: PA_LOOKUP when the lookups' partition passes are still pending (it
+  // completes them together with the update), PA_NONE when they have been settled since.  One stale token and all tables
+  // are indexed again (PA_APPLYIDX: one launch either way); pending passes that are not taken over are settled on entry.
+  const bool fz = fused_ok(D);
+  bool reuse = tokens != nullptr && fz;       // every table holds its batch's entries
+  bool pa_reuse = reuse;                      // ... and its partition pass is still pending
+  for (int i = 0; i < num_tables && reuse; ++i)
+    if (ns[i] > 0) {
+      const bool held = tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index;
+      if (!held) reuse = false;
+      if (!held || !vars[i]->part_pending) pa_reuse = false;
+    }
+  if (!reuse) pa_reuse = false;
   for (kv_table* tb : lock.ts) {
     bool keep = false;
     if (pa_reuse)
       for (int i = 0; i < num_tables; ++i) keep = keep || (vars[i] == tb && ns[i] > 0);
     if ((rc = report_deferred_error(tb, s)) || (rc = hand_over(tb, s, !keep))) return rc;
   }
+  // (a table whose pass was pending while another's was not: hand_over has just settled it — the batch's entries stay valid)
   long long nmax = 0;
-  // the batch tokens of a kv_multi_gather_or_insert_tok over the same ids: the index pass is skipped when EVERY table
-  // still holds the index of its batch (one stale token and all tables are indexed again: one launch either way)
-  bool reuse = tokens != nullptr && fused_ok(D) && !pa_reuse;
-  for (int i = 0; i < num_tables && reuse; ++i)
-    if (ns[i] > 0 && !(tokens[i] != 0 && tokens[i] == vars[i]->batch_serial && ns[i] == vars[i]->batch_n && vars[i]->fused_index &&
-                       vars[i]->index_records && !vars[i]->part_pending && !vars[i]->side_pending))
-      reuse = false;
-  if (tl_require_reuse && !pa_reuse && !reuse)
+  if (tl_require_reuse && !reuse)
     return fail(KV_FAILED_PRECONDITION, "batched sharded apply: another op used a table since this batch's lookup");
   for (int i = 0; i < num_tables; ++i) {
-    if (!reuse && !pa_reuse) vars[i]->batch_serial = 0;
-    if (!reuse && !pa_reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
+    if (!reuse) vars[i]->batch_serial = 0;
+    if (!reuse && (rc = ensure_capacity(vars[i], ns[i], s))) return rc;
     if ((rc = ensure_capacity(slots0[i], ns[i], s))) return rc;
     if (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))) return rc;
     if ((rc = ensure_workspace(vars[i], std::max<long long>(ns[i], 1), true, s))) return rc;
@@ -2139,16 +1858,16 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(vars[i], std::max<long long>(ns[i], 1));
     d.a.tv = dev_view(vars[i]); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
-    if (fused_ok(D)) { d.w.hc = (unsigned)HC2; d.a.epart = d.w.epart; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
+    if (fz) { d.a.epart = d.w.epart; d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(vars[i]);
+    d.a.opt.fast = fast_math_on(vars[i]) ? 1 : 0;
     d.a.det = vars[i]->deterministic ? 1 : 0;
     d.a.n = ns[i];
     d.a.use_hints = claim_slot(vars[i], slots0[i], s) ? 1 : 0;
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
-    if ((reuse || pa_reuse) && ns[i] > 0 && vars[i]->index_P) { d.w.P = vars[i]->index_P; d.w.pshift = 64 - ilog2(d.w.P); }   // the lookup's partitioning
-    d.w.bcap = 0;
+    if (reuse && ns[i] > 0 && vars[i]->index_P) { d.w.P = vars[i]->index_P; d.w.pshift = 64 - ilog2(d.w.P); }   // the lookup's partitioning
     d.a.day_lk = d.a.day;
     if (pa_reuse && ns[i] > 0) {   // the pending lookup's own day stamp and counting rule
       PartArgs pend;
@@ -2162,43 +1881,34 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
-  const bool fz = fused_ok(D);
-  bool skip_fin = false;
   if (fz) {
-    wmax.hc = (unsigned)HC2;
-    skip_fin = wmax.ntiles <= wmax.hc;
-    // partition pass + update in one launch (k_papply_multi): the pending lookups' (PA_LOOKUP), or behind a tile pass of
-    // its own when the optimizer meets the ids first (PA_APPLYIDX); an index whose key records exist (a lookup that did
-    // not defer) goes through k_apply2_multi
-    int pa_mode = pa_reuse ? PA_LOOKUP : -1;
-    if (!reuse && !pa_reuse) {
-      for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = true; vars[i]->index_records = !pa_route; vars[i]->index_bcap = 0; }
+    // partition pass + update in one launch (k_papply_multi) behind the tile sums; an optimizer that meets the ids first
+    // runs the tile pass of all tables in front (PA_APPLYIDX)
+    int pa_mode = pa_reuse ? PA_LOOKUP : PA_NONE;
+    if (!reuse) {
+      for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = true;
       launch_ltile(vars[0], hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, -1, md, num_tables, false);
-      if (pa_route) pa_mode = PA_APPLYIDX;
-      else launch_part2<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+      pa_mode = PA_APPLYIDX;
       for (int i = 0; i < num_tables; ++i)
         if (ns[i] > 0) { vars[i]->batch_serial = ++g_serial; vars[i]->batch_n = ns[i]; vars[i]->index_P = hd[i].w.P; }
     }
-    if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, pa_mode >= 0 ? -nmax : nmax, (void*)s, md, num_tables)))
+    if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, (void*)s, md, num_tables)))
       return fail(rc, "tile sums: no kernel for dim %d", D);
-    if (pa_mode >= 0) {
-      rc = (opt == OPT_ADAM_V4 || opt == OPT_ADAM_V3) ? kvp_launch_papply_a(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables)
-                                                      : kvp_launch_papply_b(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables);
-      if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", D);
-      HIP_TRY(hipGetLastError());
-      return KV_OK;
-    }
-  } else {
-    for (int i = 0; i < num_tables; ++i) { vars[i]->fused_index = false; vars[i]->index_records = true; vars[i]->index_bcap = 0; }
-    launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
-    launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
-    launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
+    rc = (opt == OPT_ADAM_V4 || opt == OPT_ADAM_V3) ? kvp_launch_papply_a(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables)
+                                                    : kvp_launch_papply_b(opt, &wmax, &hd[0].a, pa_mode, (void*)s, md, num_tables);
+    if (rc) return fail(rc, "partition + apply pass: no kernel for dim %d", D);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
   }
+  for (int i = 0; i < num_tables; ++i) vars[i]->fused_index = false;
+  launch_tile<false>(vars[0], wmax, nullptr, nullptr, nmax, s, -1, md, num_tables, wmax.ntiles);
+  launch_part_keys<MODE_APPLYIDX>(wmax, hd[0].a, s, md, num_tables);
+  launch_order(hd[0].a.tv, wmax, nmax, s, md, num_tables);
   switch (opt) {
-    case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
-    case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
-    case OPT_ADAGRAD: rc = launch_apply<MODE_APPLY, OPT_ADAGRAD>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
-    default: rc = launch_apply<MODE_APPLY, OPT_FTRL>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables, skip_fin, fz); break;
+    case OPT_ADAM_V4: rc = launch_apply<MODE_APPLY, OPT_ADAM_V4>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    case OPT_ADAM_V3: rc = launch_apply<MODE_APPLY, OPT_ADAM_V3>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    case OPT_ADAGRAD: rc = launch_apply<MODE_APPLY, OPT_ADAGRAD>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
+    default: rc = launch_apply<MODE_APPLY, OPT_FTRL>(vars[0], wmax, hd[0].a, nmax, s, md, num_tables); break;
   }
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -2295,26 +2005,23 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
   const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
-  // The batch's own partition pass is still pending and the entry-list kernels serve this dim: k_papply completes the
-  // lookup's bookkeeping and applies the update in one launch (PA_LOOKUP).  Anything else pending is flushed first.
-  const bool pa_route = papply_enabled() && fused_ok(v->dim);
+  // The entry-list kernels serve this dim (pa_route): the tile sums, then k_papply — the partition pass and the update in
+  // one launch — in the mode the batch's state asks for:
+  //   PA_LOOKUP    the token names the lookup whose partition pass is still pending: k_papply completes its bookkeeping too
+  //   PA_NONE      the token names a batch whose bookkeeping is done (a second optimizer on the token; a pass another op settled)
+  //   PA_APPLYIDX  no (valid) token: the optimizer meets the ids first — the tile pass runs with the tile sums (k_ltsum)
+  const bool pa_route = fused_ok(v->dim);
   int pa_mode = -1;
   PartArgs pend{};
   const void* tile_ids = nullptr;   // != nullptr: the batch's tile pass runs in front of the apply (k_ltsum)
   if (v->part_pending) {
-    if (reuse && pa_route && v->fused_index && !v->side_pending) {
+    if (reuse && pa_route && v->fused_index) {
       std::memcpy(&pend, v->pend_pa, sizeof pend);
       v->part_pending = false;
       pa_mode = PA_LOOKUP;
-      if (v->tile_pending) { v->tile_pending = false; tile_ids = v->ws.ids_copy; }
     } else if ((rc = flush_part(v, s))) {
       return rc;
     }
-  }
-  const bool keep_side = reuse && v->side_pending && v->fused_index;   // overlap mode: joined behind the tile sums
-  if (v->side_pending && !keep_side) {
-    HIP_TRY(hipStreamWaitEvent(s, v->ev_part, 0));
-    v->side_pending = false;
   }
   if (!reuse && (rc = ensure_capacity(v, n, s))) return rc;
   if ((rc = ensure_capacity(s0, n, s))) return rc;
@@ -2324,6 +2031,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   PartArgs pa{};
   pa.tv = dev_view(v); pa.ts0 = dev_view(s0); pa.ts1 = s1 ? dev_view(s1) : pa.ts0;
   pa.opt = a; pa.grad = grad; pa.day = today(v);
+  pa.opt.fast = fast_math_on(v) ? 1 : 0;
   pa.det = v->deterministic ? 1 : 0;
   pa.n = n;
   pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
@@ -2332,30 +2040,20 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   if (!reuse) {
     v->batch_serial = 0;
     if (pa_route) {   // tile pass + tile sums in one launch, then partition pass + update in one launch
-      wd.hc = (unsigned)HC2;
       v->fused_index = true;
-      v->index_records = false;
-      v->side_has_items = false;
-      v->index_bcap = 0;
-      wd.bcap = 0;
       choose_partitions(v, wd, n);
-      if (bucket_enabled(v, n) && (rc = begin_bucket_index(v, wd, n, s))) return rc;
       tile_ids = ids;
       pa_mode = PA_APPLYIDX;
-    } else if (fused_ok(v->dim)) {
-      if ((rc = fused_index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s))) return rc;
     } else {
       index_pass<MODE_APPLYIDX>(v, wd, pa, ids, nullptr, n, -1, nullptr, s);
     }
     v->batch_serial = ++g_serial;   // the index stays valid for this batch (e.g. a second optimizer on the same ids)
     v->batch_n = n;
-  } else if (pa_mode < 0 && v->fused_index && !v->index_records && !keep_side) {
-    // a batch whose entries k_papply consumed before (a second optimizer on the same token): its bookkeeping is done
-    if (!pa_route) return fail(KV_FAILED_PRECONDITION, "the batch index holds no key records (KV_NO_PAPPLY set between two applies)");
-    pa_mode = PA_NONE;
+  } else if (pa_mode < 0 && v->fused_index) {
+    pa_mode = PA_NONE;   // the tiles' entries of a batch whose bookkeeping is done
   }
   if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
-  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, keep_side, pa_mode, tile_ids);
+  if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, pa_mode, tile_ids);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -2505,13 +2203,11 @@ int kv_set_deterministic(kv_handle_t t, int on) {
   return KV_OK;
 }
 
-int kv_set_overlap(kv_handle_t t, int on) {
+int kv_set_fast_math(kv_handle_t t, int on) {
   int rc;
   if ((rc = check_table(t))) return rc;
-  DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
-  if (on && (rc = ensure_side(t))) return rc;
-  t->overlap = on != 0;
+  t->fast_math = on != 0;
   return KV_OK;
 }
 
@@ -3530,18 +3226,12 @@ static int shard_late_report(kv_shard* sh, unsigned seen) {
                                      "create the shards with a larger peer_capacity on every rank", sh->C);
 }
 
-static bool shard_old_route() {
-  static const bool old_route = [] { const char* e = getenv("KV_SHARD_OLD_ROUTE"); return e && atoi(e) != 0; }();
-  return old_route;
-}
 // The whole-op entry points (kv_shard_lookup / kv_shard_apply / kv_multi_shard_*) do the exchanges themselves, so they
-// may leave this rank's own segments where they are: every kernel that reads a receive buffer downstream (the owner
-// lookup's tile pass, the finish, the owner apply's tile sums and k_papply) takes records [rank * (C + 1), +C + 1)
-// from the send buffer.  Only the entry-list kernels know how; KV_SHARD_SELF_COPY=1 keeps the three copies (A/B).
+// leave this rank's own segments where they are: every kernel that reads a receive buffer downstream (the owner lookup's
+// tile pass, the finish, the owner apply's tile sums and k_papply) takes records [rank * (C + 1), +C + 1) from the send
+// buffer.  Only the entry-list kernels know how (other dims: the segment is copied like any peer's).
 static bool shard_can_stay(const kv_shard* sh) {
-  static const bool copy = [] { const char* e = getenv("KV_SHARD_SELF_COPY"); return e && atoi(e) != 0; }();
-  return !copy && !shard_old_route() && papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap &&
-         (long long)sh->world * (sh->C + 1) <= FUSED_MAX_N;
+  return fused_ok(sh->table->dim) && (long long)sh->world * (sh->C + 1) <= FUSED_MAX_N;
 }
 
 // ids -> local unique ids with counts -> the owners' segments of the send buffer.  4 launches, no host sync.
@@ -3563,11 +3253,11 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
   }
   if ((rc = ensure_workspace(rt, n, true, s))) return rc;
   WsDev wd = ws_view(rt, n);
-  // The route's index on the entry-list kernels (KV_SHARD_OLD_ROUTE=1: the sorted-position kernels):
+  // The route's index on the entry-list kernels (dims they do not serve: the sorted-position kernels):
   // a table-less tile pass (k_ltile<NOTABLE>: entries, mrow, every position's entry number) and k_papply in PA_UNIQUE
   // mode (the distinct ids numbered, uniq / ucnt written, every entry learns its id's number).  The finish then reads
   // position -> entry -> number -> record, the gradient pre-sum is k_tsum + k_papply PA_DEDUP.
-  const bool fused_route = !shard_old_route() && papply_enabled() && fused_ok(rt->dim);
+  const bool fused_route = fused_ok(rt->dim);
   sh->route_fused = fused_route;
   PartArgs pa{};
   pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
@@ -3584,11 +3274,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
       if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
       ws.pos_cap = std::max<long long>(n, ws.cap_n);
     }
-    wd.hc = (unsigned)HC2;
     rt->fused_index = true;
-    rt->index_records = false;
-    rt->index_bcap = 0;
-    wd.bcap = 0;
     choose_partitions(rt, wd, n);   // (the distinct-id hint of the previous route of this length: k_papply publishes it)
     WsDev wz = wd;
     wz.zero_counts = sh->ucnt;
@@ -3722,10 +3408,9 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
     pa.out_map = sh->slot_of;
     pa.det = rt->deterministic ? 1 : 0;
     pa.n = sh->n_last;
-    wd.hc = (unsigned)HC2;
     pa.epart = wd.epart;
     pa.day_lk = pa.day;
-    if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, -(long long)sh->n_last, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", rt->dim);
+    if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", rt->dim);
     if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "gradient pre-sum: no kernel for dim %d", rt->dim);
     HIP_TRY(hipGetLastError());
     return KV_OK;
@@ -3999,7 +3684,7 @@ static int multi_shard_check(const kv_shard_t* shards, int ntab, kv_comm_t comm,
 // launches when its route is the entry-list one (not the deterministic mode, a dim the kernels serve, a batch that is
 // not empty); the others go through the per-table functions as before.
 static bool shard_batchable(const kv_shard* sh, int64_t n) {
-  return !shard_old_route() && papply_enabled() && fused_ok(sh->table->dim) && !sh->table->deterministic && n > 0 && n <= sh->max_ids;
+  return fused_ok(sh->table->dim) && !sh->table->deterministic && n > 0 && n <= sh->max_ids;
 }
 
 // route of the tables todo[0..m): the table-less tile pass of all of them (grid.y = table), then k_papply_multi in
@@ -4039,9 +3724,7 @@ static int multi_route_impl(const kv_shard_t* shards, const int* todo, int m, co
     MultiDesc& d = hd[j];
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(rt, sh->n_last);
-    d.w.hc = (unsigned)HC2;
-    rt->fused_index = true; rt->index_records = false; rt->index_bcap = 0;
-    d.w.bcap = 0;
+    rt->fused_index = true;
     choose_partitions(rt, d.w, sh->n_last);
     d.w.zero_counts = sh->ucnt;
     d.w.pos_ent = rt->ws.pos_ent;
@@ -4150,8 +3833,6 @@ static int multi_presum_impl(const kv_shard_t* shards, const int* todo, int m, c
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(rt, sh->n_last);
     if (rt->index_P) { d.w.P = rt->index_P; d.w.pshift = 64 - ilog2(d.w.P); }
-    d.w.hc = (unsigned)HC2;
-    d.w.bcap = 0;
     PartArgs& pa = d.a;
     pa.tv = dev_view(rt); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
     pa.grad = grads[todo[j]];
@@ -4166,11 +3847,10 @@ static int multi_presum_impl(const kv_shard_t* shards, const int* todo, int m, c
     wmax.P = std::max(wmax.P, d.w.P);
     nmax = std::max<long long>(nmax, sh->n_last);
   }
-  wmax.hc = (unsigned)HC2;
   HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)m * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
-  if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, -nmax, (void*)s, md, m))) return fail(rc, "tile sums: no kernel for dim %d", hd[0].a.tv.dim);
+  if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, (void*)s, md, m))) return fail(rc, "tile sums: no kernel for dim %d", hd[0].a.tv.dim);
   if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wmax, &hd[0].a, PA_DEDUP, (void*)s, md, m))) return fail(rc, "gradient pre-sum: no kernel for dim %d", hd[0].a.tv.dim);
   HIP_TRY(hipGetLastError());
   return KV_OK;
@@ -4214,12 +3894,10 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
     return KV_OK;
   };
   {
-    // the tables whose route is the entry-list one go together: 2 launches for all of them (KV_MULTI_SHARD_PER_TABLE=1: A/B)
-    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
+    // the tables whose route is the entry-list one go together: 2 launches for all of them
     std::vector<int> todo;
     std::vector<char> batched(ntab, 0);
-    if (!per_table)
-      for (int k = 0; k < ntab; ++k)
+    for (int k = 0; k < ntab; ++k)
         if (shard_batchable(shards[k], n[k])) todo.push_back(k);
     if (todo.size() >= 2) {
       for (int k : todo) batched[k] = 1;
@@ -4246,16 +3924,13 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   {
     // the owners' lookups: the tables of one dim in one batched lookup over their receive buffers (tile pass of all of
     // them in one launch; the partition passes stay pending for the batched apply)
-    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
     std::vector<char> served(ntab, 0);
     std::vector<int> dims;
     auto can = [&](int k) {
       const kv_shard* sh = shards[k];
-      return papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap && sh->table->key_dtype == KV_DT_INT64 &&
-             (long long)sh->world * (sh->C + 1) <= (1ll << 21);
+      return fused_ok(sh->table->dim) && sh->table->key_dtype == KV_DT_INT64 && (long long)sh->world * (sh->C + 1) <= (1ll << 21);
     };
-    if (!per_table)
-      for (int k = 0; k < ntab; ++k)
+    for (int k = 0; k < ntab; ++k)
         if (can(k)) dims.push_back(shards[k]->table->dim);
     std::sort(dims.begin(), dims.end());
     dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
@@ -4292,10 +3967,8 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
   {
     // finish: the tables of one row geometry whose route is an entry-list index in one launch
-    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
     std::vector<char> done(ntab, 0);
-    if (!per_table)
-      for (int q : {1, 2, 4, 8, 16, 32, 64}) {
+    for (int q : {1, 2, 4, 8, 16, 32, 64}) {
         std::vector<int> grp;
         for (int k = 0; k < ntab; ++k)
           if (routed[k] && shards[k]->n_last > 0 && shards[k]->route_fused && row_lanes(shards[k]->table->dim) == q) grp.push_back(k);
@@ -4332,11 +4005,9 @@ int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int
   std::vector<char> summed(ntab, 0);
   {
     // gradient pre-sum: the tables of one dim whose route is an entry-list index in two launches
-    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
     std::vector<int> dims;
-    if (!per_table)
-      for (int k = 0; k < ntab; ++k)
-        if (shards[k]->n_last > 0 && shards[k]->route_fused && !shards[k]->table->deterministic) dims.push_back(shards[k]->table->dim);
+    for (int k = 0; k < ntab; ++k)
+      if (shards[k]->n_last > 0 && shards[k]->route_fused && !shards[k]->table->deterministic) dims.push_back(shards[k]->table->dim);
     std::sort(dims.begin(), dims.end());
     dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
     for (int D : dims) {
@@ -4362,20 +4033,15 @@ int kv_multi_shard_apply(const kv_shard_t* shards, int ntab, kv_comm_t comm, int
   if ((rc = comm_exchange(comm, ntab, sr.data(), rr.data(), rb.data(), w, stay.data()))) return rc;
   {
     // the owners' applies: the tables of one dim whose serve lookups left their batch index in one batched apply
-    static const bool per_table = [] { const char* e = getenv("KV_MULTI_SHARD_PER_TABLE"); return e && atoi(e) != 0; }();
     std::vector<char> applied(ntab, 0);
     std::vector<int> dims;
     auto can = [&](int k) {
       const kv_shard* sh = shards[k];
-      return papply_enabled() && fused_ok(sh->table->dim) && !sh->table->overlap && sh->table->key_dtype == KV_DT_INT64 &&
+      return fused_ok(sh->table->dim) && sh->table->key_dtype == KV_DT_INT64 &&
              (long long)sh->world * (sh->C + 1) <= (1ll << 21) && sh->serve_token != 0 && sh->serve_token == sh->table->batch_serial &&
-             // (the lookup's partition pass still pending: what k_papply_multi takes over; a table another op has settled
-             //  meanwhile goes through the per-table apply, which knows that state)
-             sh->table->fused_index && sh->table->part_pending && !sh->table->tile_pending && !sh->table->index_records &&
-             sh->table->index_bcap == 0 && !sh->table->side_pending &&
-             slot0[k] != nullptr && (optimizer != 3 || (slot1 && slot1[k]));
+             sh->table->fused_index && slot0[k] != nullptr && (optimizer != 3 || (slot1 && slot1[k]));
     };
-    if (!per_table && optimizer >= 0 && optimizer <= 3)
+    if (optimizer >= 0 && optimizer <= 3)
       for (int k = 0; k < ntab; ++k)
         if (can(k)) dims.push_back(shards[k]->table->dim);
     std::sort(dims.begin(), dims.end());

@@ -445,9 +445,9 @@ def kv_set_deterministic(table_handle, on=True):
   _lib.check(_lib.lib().kv_set_deterministic(table_handle.ptr, int(bool(on))))
 
 
-def kv_set_overlap(table_handle, on=True):
-  """Overlap mode for steps captured in a HIP graph (kvhip.h kv_set_overlap)."""
-  _lib.check(_lib.lib().kv_set_overlap(table_handle.ptr, int(bool(on))))
+def kv_set_fast_math(table_handle, on=True):
+  """1-ulp hardware sqrt / reciprocal in the optimizers' row math (default) or the IEEE sequences (kvhip.h kv_set_fast_math)."""
+  _lib.check(_lib.lib().kv_set_fast_math(table_handle.ptr, int(bool(on))))
 
 
 def kv_prepare_capture(table_handle, max_new_ids):

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../tfplus_amd/csrc"
 out=/tmp/kres_$$; mkdir -p $out
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -w --offload-device-only -c -o $out/u.co "$1"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -w $KRES_FLAGS --offload-device-only -c -o $out/u.co "$1"
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --input=$out/u.co --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$out/u.elf --unbundle
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $out/u.elf | grep -E "^\s+\.name:|\.vgpr_count|\.sgpr_count|vgpr_spill_count|group_segment_fixed|private_segment_fixed" | paste - - - - - - \
   | python3 -c '
