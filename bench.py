@@ -150,19 +150,29 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
     return (time.perf_counter() - t0) / steps * 1e3
 
   res = {}
-  # ---- the op boundary (training_ops.cc:7011-7021: what the optimizer op receives from TF-core): unique ids and
-  #      their summed gradient rows, no token.  SURVEY 8(d): U * (8 + 4D + 16 + 2 * 4 * 4D) bytes
+  # ---- the op boundary (training_ops.cc:7011-7021: what the optimizer op receives from TF-core in an unchanged graph):
+  #      unique ids and their summed gradient rows, no token.  SURVEY 8(d): U * (8 + 4D + 16 + 2 * 4 * 4D) bytes.
+  #      kv_apply_group_adam_unique (kvhip.h): one launch, the caller's promise of unique ids guarded on the device
   uni = []
   for ids, grad in [p[:2] for p in pool[:4]]:
     u, inv = torch.unique(ids, return_inverse=True)
     sm = torch.zeros((u.numel(), D), dtype=torch.float32, device=dev).index_add_(0, inv, grad)
     uni.append((u.contiguous(), sm))
-  ms = timed(lambda k: adam(uni[k % len(uni)][0], uni[k % len(uni)][1], uni[k % len(uni)][0].numel(), 0))
+
+  def adam_unique(ids_t, grad_t, n):
+    _lib.check(L.kv_apply_group_adam_unique(var.ptr, slot.ptr, grad_t.data_ptr(), ids_t.data_ptr(), n, 1e-3,
+                                            float(state["b1p"]), float(state["b2p"]), 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0, 4, st()))
+  ms = timed(lambda k: adam_unique(uni[k % len(uni)][0], uni[k % len(uni)][1], uni[k % len(uni)][0].numel()))
+  ms_batch = timed(lambda k: adam(uni[k % len(uni)][0], uni[k % len(uni)][1], uni[k % len(uni)][0].numel(), 0))
   Uu = float(np.mean([u.numel() for u, _ in uni]))
   byt = Uu * (8 + 4 * D + 16 + 2 * 4 * 4 * D)
-  res["op_boundary"] = {"what": "kv_apply_group_adam on unique ids + pre-summed gradient rows (index pass + tile sums + apply)",
+  res["op_boundary"] = {"what": "kv_apply_group_adam_unique on unique ids + pre-summed gradient rows: ONE launch (k_uapply: probe, "
+                                "state read-modify-write, duplicate guard)",
                         "unique_ids": Uu, "ms": ms, "algorithmic_bytes": byt, "GBps": byt / (ms * 1e-3) / 1e9,
-                        "unique_applies_per_s": Uu / (ms * 1e-3)}
+                        "frac_of_peak": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "unique_applies_per_s": Uu / (ms * 1e-3),
+                        "batch_pipeline_ms": ms_batch,
+                        "batch_pipeline_what": "the same input through kv_apply_group_adam (no promise: tile pass + tile sums + k_papply)"}
   del uni
   # ---- lookup + apply of the same batch WITHOUT the token (the apply builds its own index)
   def no_token(k):
@@ -212,7 +222,7 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
     torch.cuda.synchronize()
     pr = ops.kv_profile_read(var)
     ops.kv_profile_enable(var, 0)
-    rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0] + pr["lookup_rows"][0]) / max(pr["lookup_tile"][1] + pr["lookup_rows"][1], 1)
+    rows_ms = (pr["lookup_tile"][0] + pr["lookup_order"][0]) / max(pr["lookup_tile"][1], 1)
     U_sk = float(np.mean([b[2] for b in bs]))
     look_bytes = N * 8 + U_sk * (16 + 4 * D) + N * 4 * D        # ids + probe record and row per distinct id + output rows
     sweep.append({"zipf": sk, "unique_per_batch": U_sk, "ms_per_step": ms_step,
@@ -552,11 +562,10 @@ def main():
   # reads + writes the optimizer state of every unique key in k_apply_sorted.
   Ub = U_mean
   fused = prof["apply_tsum"][1] > 0 or prof["apply_tile"][1] > 0     # the entry-list pipeline ran (kv_fused.h)
-  deferred_tile = prof["lookup_rows"][1] > 0                          # ... with the lookup's rows by per-position probe (k_lrows)
   if fused:
     alg = {
         "lookup_tile": N * 8 + Ub * (16 + 4 * D) + N * 4 * D,   # k_ltile: ids, one probe + one row per key, output rows
-        "lookup_rows": N * 8 + Ub * (16 + 4 * D) + N * 4 * D,   # k_lrows: the whole lookup of SURVEY 8d (ids, probe + row per key, output rows)
+        "apply_unique": 0,
         "lookup_part": 0,                                     # k_part2: row records only (not in SURVEY 8d's figure)
         "lookup_order": 0,
         "apply_index": N * 8 + Ub * 16,
@@ -568,7 +577,7 @@ def main():
   else:
     alg = {
         "lookup_tile": N * 8,
-        "lookup_rows": 0,
+        "apply_unique": 0,
         "lookup_part": Ub * 16,
         "lookup_order": Ub * 4 * D + N * 4 * D + N * 4,
         "apply_index": N * 8 + Ub * 16,
@@ -582,7 +591,7 @@ def main():
   achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
   # entry-list pipeline: a lookup that hands out a batch token returns when its rows are written (k_ltile); its
   # partition pass (k_part2: frequency words, key records) is deferred to the head of the apply of that batch
-  lookup_ms = kern["lookup_tile"] + kern["lookup_order"] + kern["lookup_rows"] + (0.0 if fused and not args.no_token else kern["lookup_part"])
+  lookup_ms = kern["lookup_tile"] + kern["lookup_order"] + (0.0 if fused and not args.no_token else kern["lookup_part"])
   apply_ms = kern["apply_index"] + kern["apply_sorted"] + kern["apply_span"] + kern["apply_tsum"] + kern["apply_tile"] + \
       (kern["lookup_part"] if fused and not args.no_token else 0.0)
   lookup_bytes = N * (8 + 4 * D) + Ub * (16 + 4 * D)

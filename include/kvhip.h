@@ -151,6 +151,30 @@ int kv_apply_sparse_group_ftrl(kv_handle_t var, kv_handle_t accum, kv_handle_t l
                                float l2, float l21, float l2_shrinkage, float lr_power,
                                kv_stream_t stream);
 
+/* The same three ops at the reference's REAL op boundary.  In an unchanged TF1 graph the reference's processor patch
+ * (python/ops/variable_scope.py:1096-1106) sends a KvVariable's IndexedSlices gradient through TF-core's
+ * _deduplicate_indexed_slices, so KvVariableGroupSparseApplyAdamV4 / KvVariableSparseApplyAdagrad /
+ * KvVariableSparseGroupSparseApplyFtrlV2 receive indices that are already UNIQUE and gradient rows that are already
+ * summed (kernels/training_ops.cc:7011-7021).  The caller PROMISES that `ids` holds no id twice; the op is then one
+ * launch — one lane group per id: index probe (a key the table does not hold is inserted: FindOrInsertUnsafe,
+ * kv_variable.h:382-416), then gradient row, var row, slot row and both records in one round trip, the fused row
+ * update — instead of the batch pipeline's tile dedup + tile sums + partition pass, whose answers the promise makes
+ * known.  Same arguments, checks and results as the plain ops (rows, slots, frequency words, flags: the same bits for
+ * the same summed gradient).  A BROKEN promise is detected on the device, not raced silently: every row record carries
+ * the serial of the last unique-apply launch that touched it, flipped by one returning atomic per id; an id listed
+ * twice raises the table's error word and the NEXT call on the table returns KV_INVALID_ARGUMENT (that batch was not
+ * applied as the reference applies repeated ids — sequentially).  Embedding dims the kernel does not serve (not a
+ * multiple of 4, or above 256) take the batch pipeline, which needs no promise.  No batch token is involved; a pending
+ * lookup pass of the table is settled first. */
+int kv_apply_group_adam_unique(kv_handle_t var, kv_handle_t m_v_linear, const float* grad, const void* ids, int64_t n,
+                               float lr, float beta1_power, float beta2_power, float beta1, float beta2, float epsilon,
+                               float l1, float l2, float l21, int version, kv_stream_t stream);
+int kv_apply_adagrad_unique(kv_handle_t var, kv_handle_t accum, float lr, const float* grad, const void* ids,
+                            int64_t n, int update_slots, kv_stream_t stream);
+int kv_apply_sparse_group_ftrl_unique(kv_handle_t var, kv_handle_t accum, kv_handle_t linear, const float* grad,
+                                      const void* ids, int64_t n, float lr, float l1, float l2, float l21,
+                                      float l2_shrinkage, float lr_power, kv_stream_t stream);
+
 /* The three optimizer ops with the batch token of the lookup that preceded them (0 = none). */
 int kv_apply_group_adam_tok(kv_handle_t var, kv_handle_t m_v_linear, const float* grad, const void* ids,
                             int64_t n, float lr, float beta1_power, float beta2_power, float beta1,
@@ -507,7 +531,7 @@ int kv_take_rows(int device, const void* src, const int32_t* index, const int32_
 #define KV_PROF_APPLY_SORTED 4  /* k_apply: segmented gradient sum + fused row update */
 #define KV_PROF_APPLY_SPAN 5    /* k_apply_fin: keys that span several chunks */
 #define KV_PROF_APPLY_TSUM 6    /* k_tsum: tile-local gradient sums of repeated ids (entry-list pipeline) */
-#define KV_PROF_LOOKUP_ROWS 7   /* k_lrows: the training lookup's rows by per-position probe (its tile pass is deferred) */
+#define KV_PROF_APPLY_UNIQUE 7  /* k_uapply: the optimizer apply on unique ids + pre-summed rows (kv_apply_*_unique), one launch */
 #define KV_PROF_APPLY_TILE 8    /* k_ltsum: the batch's tile pass + the tile sums in front of the optimizer apply */
 #define KV_PROF_KINDS 9
 int kv_profile_enable(kv_handle_t h, int max_launches);

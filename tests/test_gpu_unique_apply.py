@@ -1,0 +1,209 @@
+"""kv_apply_*_unique (include/kvhip.h; csrc/kv_uapply.h): the optimizer ops at the reference's real op boundary — unique ids
++ pre-summed gradient rows, what KvVariableGroupSparseApplyAdamV4 & co. receive behind TF-core's de-duplication
+(python/ops/variable_scope.py:1096-1106, kernels/training_ops.cc:7011-7021) — against the CPU oracle and, bit for bit,
+against the plain ops on a twin table; and the promise's guard: an id listed twice is reported, never raced silently.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kv_oracle as ko  # noqa: E402  (checker only)
+from test_gpu_parity import _pair, _const, _np, _beta_pows, _assert_same_table, RTOL, DAY  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+def _run(ops, name, hs, grad, ids, unique, **kw):
+  if name in ("adam4", "adam3"):
+    fn = ops.kv_variable_group_sparse_apply_adam_v4 if name == "adam4" else ops.kv_variable_group_sparse_apply_adam_v3
+    fn(hs[0], hs[1], grad, ids, kw["lr"], kw["b1p"], kw["b2p"], 0.9, 0.999, 1e-8, kw.get("l1", 0.0), kw.get("l2", 0.0),
+       kw.get("l21", 0.0), unique_indices=unique)
+  elif name == "adagrad":
+    ops.kv_variable_sparse_apply_adagrad(hs[0], hs[1], kw["lr"], grad, ids, update_slots=kw.get("us", True), unique_indices=unique)
+  else:
+    ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(hs[0], hs[1], hs[2], grad, ids, kw["lr"], kw.get("l1", 0.0), kw.get("l2", 0.0),
+                                                      kw.get("l21", 0.0), kw.get("l2s", 0.0), kw.get("lrp", -0.5), unique_indices=unique)
+
+
+def _oracle(name, os_, grad, ids, **kw):
+  if name in ("adam4", "adam3"):
+    ko.apply_group_adam(os_[0], os_[1], grad, ids, kw["lr"], kw["b1p"], kw["b2p"], 0.9, 0.999, 1e-8, kw.get("l1", 0.0),
+                        kw.get("l2", 0.0), kw.get("l21", 0.0), version=4 if name == "adam4" else 3)
+  elif name == "adagrad":
+    ko.apply_adagrad(os_[0], os_[1], kw["lr"], grad, ids, kw.get("us", True))
+  else:
+    ko.apply_sparse_group_ftrl(os_[0], os_[1], os_[2], grad, ids, kw["lr"], kw.get("l1", 0.0), kw.get("l2", 0.0), kw.get("l21", 0.0),
+                               kw.get("l2s", 0.0), kw.get("lrp", -0.5))
+
+
+def _tables(ops, name, D, thr=0, seed=1, cap=0):
+  """(unique-path tables, plain-path twin tables, oracle tables)"""
+  out = []
+  for _ in range(2):
+    rng = np.random.default_rng(100 + D)
+    hv, ov = _pair(ops, D, thr=thr, seed=seed, rng=rng, cap=cap)
+    if name in ("adam4", "adam3"):
+      hs, os_ = _const(ops, 3 * D, 0.0)
+      out.append(((hv, hs), (ov, os_)))
+    elif name == "adagrad":
+      hs, os_ = _const(ops, D, 0.1)
+      out.append(((hv, hs), (ov, os_)))
+    else:
+      ha, oa = _const(ops, D, 0.1)
+      hl, ol = _const(ops, D, 0.0)
+      out.append(((hv, ha, hl), (ov, oa, ol)))
+  return out[0][0], out[1][0], out[0][1]
+
+
+def _same_bits(ops, ha, hb, keys):
+  """two GPU tables hold the same rows, frequency words and flags for `keys`"""
+  keys = np.unique(np.asarray(keys, np.int64))
+  np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_zeros_v2(ha, keys)), _np(ops.kv_variable_gather_or_zeros_v2(hb, keys)))
+  assert ops.kv_get_meta(ha, keys) == ops.kv_get_meta(hb, keys)
+  assert ops.kv_variable_size_v2(ha) == ops.kv_variable_size_v2(hb)
+  assert ops.kv_variable_frequency(ha) == ops.kv_variable_frequency(hb)
+
+
+@pytest.mark.parametrize("D", [4, 8, 32, 64, 100, 128])
+@pytest.mark.parametrize("name", ["adam4", "adam3", "adagrad", "ftrl"])
+def test_unique_apply_equals_plain_apply_and_oracle(ops, name, D):
+  """three steps of unique ids: known keys, keys the optimizer meets first (inserted by the op), a training lookup in
+  between; the unique path against the oracle (1e-6) and bit for bit against the plain op on a twin table"""
+  rng = np.random.default_rng(300 + D)
+  hu, hp, os_ = _tables(ops, name, D)
+  seen = []
+  for t in range(3):
+    ids = rng.choice(6000, 1700, replace=False).astype(np.int64) - 500      # negative keys too
+    seen.append(ids)
+    if t == 1:                                          # a training lookup in between, like a step
+      want = os_[0].gather_or_insert(ids)
+      for h in (hu[0], hp[0]):
+        np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_insert_v2(h, ids)), want)
+    grad = rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.05, b1p=b1p, b2p=b2p)
+    _run(ops, name, hu, grad, ids, True, **kw)
+    _run(ops, name, hp, grad, ids, False, **kw)
+    _oracle(name, os_, grad, ids, **kw)
+    allk = np.concatenate(seen)
+    for a, b in zip(hu, hp):
+      _same_bits(ops, a, b, allk)
+    for h, o in zip(hu, os_):
+      _assert_same_table(ops, h, o, allk, rtol=RTOL, atol=1e-7)
+
+
+def test_unique_apply_regularizers_blacklist_threshold(ops):
+  """l1 / l2 / l21 > 0 (rows blacklist and come back), enter_threshold (rows below it are skipped): same bits as the plain op"""
+  D = 32
+  rng = np.random.default_rng(41)
+  hu, hp, os_ = _tables(ops, "adam4", D, thr=2)
+  ids = np.arange(2500, dtype=np.int64)
+  warm = np.concatenate([ids, ids[::2]])                 # even keys reach the threshold, odd ones do not
+  for h in (hu[0], hp[0]):
+    ops.kv_variable_gather_or_insert_v2(h, warm)
+  os_[0].gather_or_insert(warm)
+  for t in range(3):
+    grad = (rng.normal(0, 1, (ids.size, D)) * rng.uniform(1e-4, 3e-2, (ids.size, 1))).astype(np.float32)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.05, b1p=b1p, b2p=b2p, l1=1e-3, l2=1e-2, l21=2e-2)
+    _run(ops, "adam4", hu, grad, ids, True, **kw)
+    _run(ops, "adam4", hp, grad, ids, False, **kw)
+    for a, b in zip(hu, hp):
+      _same_bits(ops, a, b, ids)
+  metas = ops.kv_get_meta(hu[0], ids)
+  assert 0 < sum(1 for m in metas if m["blacklist"]) < ids.size
+
+
+def test_unique_apply_multi_chunk_table_and_delta_tracking(ops):
+  """tables without a capacity hint (rows behind the chunk table) and delta tracking: the kernel's general path"""
+  D = 16
+  rng = np.random.default_rng(43)
+  hu, hp, os_ = _tables(ops, "adam4", D)
+  for h in (hu[0], hp[0]):
+    ops.kv_set_delta_tracking(h, True, False)
+  for t in range(3):
+    ids = (rng.choice(400000, 90000, replace=False).astype(np.int64) * 7919) % (1 << 40)     # > 2^16 rows: several chunks
+    ids = np.unique(ids)
+    grad = rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.01, b1p=b1p, b2p=b2p)
+    _run(ops, "adam4", hu, grad, ids, True, **kw)
+    _run(ops, "adam4", hp, grad, ids, False, **kw)
+    _oracle("adam4", os_, grad, ids, **kw)
+    for a, b in zip(hu, hp):
+      _same_bits(ops, a, b, ids)
+  _assert_same_table(ops, hu[0], os_[0], ids, rtol=RTOL, atol=1e-7)
+
+
+def test_unique_apply_dim_outside_the_kernel_takes_the_batch_pipeline(ops):
+  hu, hp, os_ = _tables(ops, "adagrad", 6)
+  ids = np.arange(100, dtype=np.int64) * 3
+  grad = np.random.default_rng(5).normal(0, 1e-2, (ids.size, 6)).astype(np.float32)
+  _run(ops, "adagrad", hu, grad, ids, True, lr=0.1)
+  _run(ops, "adagrad", hp, grad, ids, False, lr=0.1)
+  for a, b in zip(hu, hp):
+    _same_bits(ops, a, b, ids)
+
+
+@pytest.mark.parametrize("where", ["adjacent", "far apart", "new key", "many"])
+def test_a_broken_promise_is_reported_not_raced(ops, where):
+  """an id listed twice under unique_indices=True: the NEXT call on the table fails with InvalidArgument; the table
+  works again afterwards"""
+  from tfplus_amd import _lib
+  D = 32
+  rng = np.random.default_rng(47)
+  hu, _, os_ = _tables(ops, "adam4", D, cap=1 << 18)
+  base = np.arange(100000, dtype=np.int64) * 13 + 1
+  ops.kv_variable_gather_or_insert_v2(hu[0], base)
+  ids = base[:60000].copy()
+  if where == "adjacent":
+    ids[1001] = ids[1000]
+  elif where == "far apart":
+    ids[59990] = ids[3]
+  elif where == "new key":
+    ids[10] = -77; ids[50000] = -77           # a key the table does not hold yet, twice
+  else:
+    ids[30000:30064] = ids[0:64]
+  grad = rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32)
+  b1p, b2p = _beta_pows(0)
+  _run(ops, "adam4", hu, grad, ids, True, lr=0.01, b1p=b1p, b2p=b2p)        # queued: the device finds the duplicate
+  torch.cuda.synchronize()
+  with pytest.raises(_lib.InvalidArgumentError, match="NOT unique"):
+    ops.kv_variable_size_v2(hu[0])
+  # the flag is cleared by the report: the table serves again, and a clean unique batch goes through
+  good = base[60000:90000]
+  g2 = rng.normal(0, 1e-2, (good.size, D)).astype(np.float32)
+  _run(ops, "adam4", hu, g2, good, True, lr=0.01, b1p=b1p, b2p=b2p)
+  torch.cuda.synchronize()
+  assert ops.kv_variable_size_v2(hu[0]) >= base.size
+  # ... and the same ids again in the NEXT launch are no duplicates (the stamp names the launch, not the id)
+  _run(ops, "adam4", hu, g2, good, True, lr=0.01, b1p=b1p, b2p=b2p)
+  torch.cuda.synchronize()
+  ops.kv_variable_size_v2(hu[0])
+
+
+def test_stamp_serial_wraps_without_false_alarms(ops):
+  """the 16-bit launch serial wraps after 65535 launches: stamps are cleared, no false duplicate, results still right"""
+  D = 8
+  hu, hp, os_ = _tables(ops, "adagrad", D)
+  ids = np.arange(64, dtype=np.int64)
+  grad = np.full((ids.size, D), 1e-3, np.float32)
+  steps = 65536 + 40
+  for _ in range(steps):
+    _run(ops, "adagrad", hu, grad, ids, True, lr=1e-4)
+  torch.cuda.synchronize()
+  ops.kv_variable_size_v2(hu[0])                       # would raise if a stale stamp had been taken for a duplicate
+  # closed form: acc = 0.1 + steps * g^2 accumulated step by step in fp32; compare with the plain op driven the same way
+  for _ in range(steps):
+    _run(ops, "adagrad", hp, grad, ids, False, lr=1e-4)
+  for a, b in zip(hu, hp):
+    _same_bits(ops, a, b, ids)

@@ -51,6 +51,9 @@ SIGNATURES = {
     "kv_apply_group_adam": (_i32, [_vp, _vp, _vp, _vp, _i64] + [_f] * 9 + [_i32, _vp]),
     "kv_apply_adagrad": (_i32, [_vp, _vp, _f, _vp, _vp, _i64, _i32, _vp]),
     "kv_apply_sparse_group_ftrl": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp]),
+    "kv_apply_group_adam_unique": (_i32, [_vp, _vp, _vp, _vp, _i64] + [_f] * 9 + [_i32, _vp]),
+    "kv_apply_adagrad_unique": (_i32, [_vp, _vp, _f, _vp, _vp, _i64, _i32, _vp]),
+    "kv_apply_sparse_group_ftrl_unique": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp]),
     "kv_apply_group_adam_tok": (_i32, [_vp, _vp, _vp, _vp, _i64] + [_f] * 9 + [_i32, _c.c_uint64, _vp]),
     "kv_apply_adagrad_tok": (_i32, [_vp, _vp, _f, _vp, _vp, _i64, _i32, _c.c_uint64, _vp]),
     "kv_apply_sparse_group_ftrl_tok": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_c.c_uint64, _vp]),

@@ -56,10 +56,12 @@ struct RowMeta {
   long long key;
   unsigned freq;          // (day << 16) | saturating u16 count
   unsigned char flags;    // FLAG_*
-  unsigned char delta_train;  // key is in train_deltalist_ (kv_variable.h:870; set only while the table tracks deltas)
-  unsigned char delta_pred;   // key is in prediction_deltalist_ (:871)
-  unsigned char pad;
+  unsigned char delta;    // DELTA_TRAIN: key is in train_deltalist_ (kv_variable.h:870; set only while the table tracks
+                          // deltas); DELTA_PRED: in prediction_deltalist_ (:871)
+  unsigned short stamp;   // serial of the last kv_apply_*_unique launch that updated the row (kv_uapply.h: how an id that
+                          // breaks the caller's promise of unique ids is caught); 0 = none
 };
+constexpr unsigned DELTA_TRAIN = 1u, DELTA_PRED = 2u;
 static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
 
 struct Chunk {
@@ -194,7 +196,7 @@ __device__ __forceinline__ long long* key_ptr(const TableDev& t, unsigned r) { r
 // train_deltalist_.insert(key) (kv_variable.h:316,451,685; MarkAsDeltaListElements :791-799): one byte in the
 // row's own RowMeta record, a plain store by the key's single owner thread
 __device__ __forceinline__ void mark_delta(const TableDev& t, unsigned r) {
-  if (t.track_delta) meta_ptr(t, r)->delta_train = 1;
+  if (t.track_delta) meta_ptr(t, r)->delta |= (unsigned char)DELTA_TRAIN;
 }
 // frequency word and flags of a row with ONE 8-byte load: .x = freq word, .y & 0xFF = flags
 __device__ __forceinline__ uint2 load_freq_flags(const TableDev& t, unsigned r) {
@@ -329,7 +331,7 @@ claimed:
   }
   slot->row = r;
   *key_ptr(t, r) = key;
-  { RowMeta* nm = meta_ptr(t, r); nm->delta_train = 0; nm->delta_pred = 0; }  // fresh (or recycled) row: in no delta list yet
+  { RowMeta* nm = meta_ptr(t, r); nm->delta = 0; nm->stamp = 0; }  // fresh (or recycled) row: in no delta list yet
   *inserted = true;
   return r;
 }

@@ -794,7 +794,7 @@ __device__ __forceinline__ void part2_body(const WsDev& w, const PartArgs& a) {
         }
         if (r[k] == 0u) continue;   // row slab overflow: the error flag is up
         RowMeta* mp = meta_ptr(a.tv, r[k]);
-        if (isnew[k]) { mp->key = key; mp->delta_train = 0; mp->delta_pred = 0; }
+        if (isnew[k]) { mp->key = key; mp->delta = 0; mp->stamp = 0; }
         mark_delta(a.tv, r[k]);
         // find_func / insert_func (kv_variable.h:320-363)
         const unsigned cnt = a.count_once ? 1u : hval[s];

@@ -338,6 +338,7 @@ struct PartArgs {
   unsigned* route_need;            // != nullptr: the LAST block of the launch writes the segments' headers, the largest segment
                                    // wanted (here) and clears the counters — what k_seg_headers_take does in its own launch
   unsigned* route_uhint;           // pinned host word (may be null): the batch's distinct ids
+  unsigned uniq_serial;            // k_uapply (kv_uapply.h): this launch's stamp (1 .. 65535)
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)

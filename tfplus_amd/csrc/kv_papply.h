@@ -553,12 +553,12 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
               RowMeta* mp = meta_ptr(a.tv, row);
               if (nk) {
                 RowMeta nm; nm.key = key; nm.freq = nf; nm.flags = (unsigned char)nfl;
-                nm.delta_train = a.tv.track_delta ? 1 : 0; nm.delta_pred = 0; nm.pad = 0;
+                nm.delta = a.tv.track_delta ? (unsigned char)DELTA_TRAIN : 0; nm.stamp = 0;
                 *mp = nm;
               } else {
                 mp->freq = nf;
                 if (nfl != oflags) mp->flags = (unsigned char)nfl;
-                if (a.tv.track_delta) mp->delta_train = 1;
+                if (a.tv.track_delta) mp->delta |= (unsigned char)DELTA_TRAIN;
               }
             }
             vm.x = nf; vm.y = (vm.y & ~0xFFu) | nfl;
@@ -567,7 +567,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           const unsigned nfl = any ? 0u : (unsigned)FLAG_UNDER;
           if (lane == 0) {
             RowMeta nm; nm.key = key; nm.freq = 1u; nm.flags = (unsigned char)nfl;
-            nm.delta_train = 0; nm.delta_pred = 0; nm.pad = 0;
+            nm.delta = 0; nm.stamp = 0;
             *meta_ptr(a.tv, row) = nm;
           }
           vm.x = 1u; vm.y = nfl;

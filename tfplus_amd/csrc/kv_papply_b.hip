@@ -14,6 +14,7 @@ namespace {
 #include "kv_kernels.h"
 #include "kv_fused.h"
 #include "kv_papply.h"
+#include "kv_uapply.h"
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_b(int opt, const void* wd_, const void* pa_, int mode,
@@ -24,5 +25,15 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_b(int opt
   const MultiDesc* md = static_cast<const MultiDesc*>(md_);
   if (opt == OPT_ADAGRAD) return launch_papply_t<OPT_ADAGRAD>(wd, pa, mode, s, md, ntab);
   if (opt == OPT_FTRL) return launch_papply_t<OPT_FTRL>(wd, pa, mode, s, md, ntab);
+  return KV_INTERNAL;
+}
+
+// k_uapply (kv_uapply.h): the apply on unique ids + pre-summed rows, one launch
+extern "C" __attribute__((visibility("hidden"))) int kvp_launch_uapply_b(int opt, const void* pa_, const void* ids, int ids32,
+                                                                      long long n, void* stream) {
+  const PartArgs& pa = *static_cast<const PartArgs*>(pa_);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (opt == OPT_ADAGRAD) return launch_uapply_t<OPT_ADAGRAD>(pa, ids, ids32, n, s);
+  if (opt == OPT_FTRL) return launch_uapply_t<OPT_FTRL>(pa, ids, ids32, n, s);
   return KV_INTERNAL;
 }

@@ -60,6 +60,9 @@ extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids,
                                 const float* grad, void* stream);
 extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
 extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
+// k_uapply dispatch (kv_uapply.h: the apply on unique ids), instantiated next to k_papply
+extern "C" int kvp_launch_uapply_a(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream);
+extern "C" int kvp_launch_uapply_b(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream);
 
 namespace {
 
@@ -115,6 +118,10 @@ __global__ void k_rehash(TableDev t, TableDev told, unsigned nrows) {
       p = (p + 1) & t.mask;
     }
   }
+}
+// kv_uapply.h: the 16-bit launch serial wrapped — every row's stamp back to "none"
+__global__ void k_clear_stamps(TableDev t, unsigned nrows) {
+  for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) meta_ptr(t, r)->stamp = 0;
 }
 // forget every slot-row hint (the attached slot table changed or was cleared)
 __global__ void k_clear_hints(Entry* e, unsigned long long count) {
@@ -252,7 +259,7 @@ __global__ void k_export_delta(TableDev t, unsigned nrows, int first_n, int fill
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     const RowMeta m = *meta_ptr(t, r);
     if (m.flags & FLAG_FREE) continue;
-    if (!(m.delta_train || (first_n <= 3 && m.delta_pred))) continue;
+    if (!((m.delta & DELTA_TRAIN) || (first_n <= 3 && (m.delta & DELTA_PRED)))) continue;
     if (first_n > 4) {  // ExportFrequencyDelta kv_variable.h:937-957: the whole 32-bit word
       unsigned long long p = atomicAdd(&cnt[2], 1ull);
       if (fill && fkeys) { fkeys[p] = m.key; fvals[p] = m.freq; }
@@ -278,7 +285,7 @@ __global__ void k_delta_resolve(TableDev t, const long long* keys, long long n, 
        i += (long long)gridDim.x * blockDim.x) {
     const unsigned r = table_find(t, keys[i]);
     present[i] = r ? 1 : 0;
-    if (r) { if (which == 0) meta_ptr(t, r)->delta_train = 1; else meta_ptr(t, r)->delta_pred = 1; }
+    if (r) meta_ptr(t, r)->delta |= (unsigned char)(which == 0 ? DELTA_TRAIN : DELTA_PRED);
   }
 }
 // end of an export (dynamic_save.hpp:179-192, 432-443).  mode 0 (training export): the train list moves
@@ -286,8 +293,9 @@ __global__ void k_delta_resolve(TableDev t, const long long* keys, long long n, 
 __global__ void k_delta_clear(TableDev t, unsigned nrows, int mode, int keep_pred) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     RowMeta* m = meta_ptr(t, r);
-    if (mode == 1) { if (m->delta_pred) m->delta_pred = 0; continue; }
-    if (m->delta_train) { if (keep_pred) m->delta_pred = 1; m->delta_train = 0; }
+    const unsigned d = m->delta;
+    if (mode == 1) { if (d & DELTA_PRED) m->delta = (unsigned char)(d & ~DELTA_PRED); continue; }
+    if (d & DELTA_TRAIN) m->delta = (unsigned char)((d & ~DELTA_TRAIN) | (keep_pred ? DELTA_PRED : 0u));
   }
 }
 
@@ -396,6 +404,7 @@ struct kv_table {
   // as before, the rows just do not wait for it.
   bool part_pending = false;
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
+  unsigned uniq_serial = 0;        // stamp of the table's last kv_apply_*_unique launch (kv_uapply.h; wraps at 65535: stamps cleared)
   bool deterministic = false;      // kv_set_deterministic
   bool fast_math = false;          // kv_set_fast_math: the optimizers' sqrt / division on v_sqrt_f32 / v_rcp_f32 (1 ulp) —
                                    // never in deterministic mode, which keeps the IEEE sequences
@@ -514,6 +523,10 @@ int flagged_error(kv_table* t, unsigned code, hipStream_t s) {
   hipStreamSynchronize(s);
   if (t->err_host) *reinterpret_cast<volatile unsigned*>(t->err_host) = 0u;
   t->batch_serial = 0;
+  if (code == 4)
+    return fail(KV_INVALID_ARGUMENT, "kv_apply_*_unique: the ids of an earlier call were NOT unique (an id was listed twice): that "
+                                     "batch was not applied as the reference applies repeated ids; pass such batches to "
+                                     "kv_apply_* (which sums repeated ids) instead");
   return fail(KV_INTERNAL, code == 2 ? "a hash partition received more than 65535 entries in one batch "
                                        "(key set crafted against the partition hash); that batch was not applied"
                                      : "row slab overflow detected on device");
@@ -670,6 +683,7 @@ bool fused_ok(int D);
 // written: records [lo, lo + len) of the buffers the calling thread's next op on `table` reads come from `ids` / `grad`
 // (the send buffers) instead.  Per thread, so another thread's op on the same table sees nothing of it.
 struct SelfSegment { const kv_table* table = nullptr; unsigned lo = 0, len = 0; const void* ids = nullptr; const float* grad = nullptr; };
+static thread_local bool tl_unique = false;          // kv_apply_*_unique: the caller promises unique ids (apply_common takes the one-launch path)
 static thread_local bool tl_require_reuse = false;   // the batched sharded apply: the tables must still hold their lookups' indexes
 static thread_local std::vector<SelfSegment> tl_selfs;   // (empty outside the sharded owner ops; several tables in the batched ones)
 struct SelfScope {
@@ -2004,6 +2018,29 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   if (!dim_supported(v->dim))
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
+  if (tl_unique && fused_ok(v->dim)) {
+    // The caller promises unique ids (kv_apply_*_unique; kv_uapply.h): one launch, one lane group per id.  A pending
+    // partition pass was settled by the caller's hand_over (no token is given).  Dims the kernel does not serve take the
+    // batch pipeline below, which needs no promise.
+    if ((rc = ensure_capacity(v, n, s)) || (rc = ensure_capacity(s0, n, s)) || (s1 && (rc = ensure_capacity(s1, n, s)))) return rc;
+    if (v->uniq_serial >= 65535u) {   // the 16-bit stamp wraps: every row back to "none" (once per 65535 launches)
+      k_clear_stamps<<<nblocks((long long)v->rows_ub, TB, 4096), TB, 0, s>>>(dev_view(v), (unsigned)v->rows_ub);
+      v->uniq_serial = 0;
+    }
+    PartArgs pa{};
+    pa.tv = dev_view(v); pa.ts0 = dev_view(s0); pa.ts1 = s1 ? dev_view(s1) : pa.ts0;
+    pa.opt = a; pa.grad = grad; pa.day = today(v);
+    pa.opt.fast = fast_math_on(v) ? 1 : 0;
+    pa.n = n;
+    pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
+    pa.uniq_serial = ++v->uniq_serial;
+    ProfScope ps(v, KV_PROF_APPLY_UNIQUE, s);
+    rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_uapply_a(OPT, &pa, ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, (void*)s)
+                                                    : kvp_launch_uapply_b(OPT, &pa, ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, (void*)s);
+    if (rc) return fail(rc, "unique apply: no kernel for dim %d", v->dim);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   const bool reuse = token != 0 && token == v->batch_serial && n == v->batch_n;
   // The entry-list kernels serve this dim (pa_route): the tile sums, then k_papply — the partition pass and the update in
   // one launch — in the mode the batch's state asks for:
@@ -2155,6 +2192,27 @@ int kv_apply_sparse_group_ftrl_tok(kv_handle_t v, kv_handle_t acc, kv_handle_t l
 int kv_apply_sparse_group_ftrl(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, const float* grad,
                                const void* ids, int64_t n, float lr, float l1, float l2, float l21,
                                float l2s, float lr_power, kv_stream_t stream) {
+  return kv_apply_sparse_group_ftrl_tok(v, acc, lin, grad, ids, n, lr, l1, l2, l21, l2s, lr_power, 0, stream);
+}
+
+// The same ops with the caller's promise that `ids` holds no id twice — what the reference's ops receive in an unchanged
+// TF graph (TF-core de-duplicates the IndexedSlices in front of them, variable_scope.py:1096-1106): kv_uapply.h
+struct UniqueScope { UniqueScope() { tl_unique = true; } ~UniqueScope() { tl_unique = false; } };
+int kv_apply_group_adam_unique(kv_handle_t v, kv_handle_t mvl, const float* grad, const void* ids, int64_t n,
+                               float lr, float b1p, float b2p, float b1, float b2, float eps, float l1,
+                               float l2, float l21, int version, kv_stream_t stream) {
+  UniqueScope u;
+  return kv_apply_group_adam_tok(v, mvl, grad, ids, n, lr, b1p, b2p, b1, b2, eps, l1, l2, l21, version, 0, stream);
+}
+int kv_apply_adagrad_unique(kv_handle_t v, kv_handle_t acc, float lr, const float* grad, const void* ids,
+                            int64_t n, int update_slots, kv_stream_t stream) {
+  UniqueScope u;
+  return kv_apply_adagrad_tok(v, acc, lr, grad, ids, n, update_slots, 0, stream);
+}
+int kv_apply_sparse_group_ftrl_unique(kv_handle_t v, kv_handle_t acc, kv_handle_t lin, const float* grad,
+                                      const void* ids, int64_t n, float lr, float l1, float l2, float l21,
+                                      float l2s, float lr_power, kv_stream_t stream) {
+  UniqueScope u;
   return kv_apply_sparse_group_ftrl_tok(v, acc, lin, grad, ids, n, lr, l1, l2, l21, l2s, lr_power, 0, stream);
 }
 

@@ -217,8 +217,14 @@ def _grad_ids(var, grad, indices):
 
 
 def _group_adam(version, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2,
-                epsilon, l1, l2, l21, use_locking):
+                epsilon, l1, l2, l21, use_locking, unique_indices=False):
   g, ids = _grad_ids(var, grad, indices)
+  if unique_indices:   # the caller's promise (what TF-core's de-duplication guarantees in the reference's graph): kvhip.h
+    _lib.check(_lib.lib().kv_apply_group_adam_unique(
+        var.ptr, m_v_linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(beta1_power),
+        _scalar(beta2_power), _scalar(beat1), _scalar(beta2), _scalar(epsilon), _scalar(l1), _scalar(l2),
+        _scalar(l21), version, _stream(var)))
+    return
   _lib.check(_lib.lib().kv_apply_group_adam_tok(
       var.ptr, m_v_linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(beta1_power),
       _scalar(beta2_power), _scalar(beat1), _scalar(beta2), _scalar(epsilon), _scalar(l1), _scalar(l2),
@@ -227,33 +233,43 @@ def _group_adam(version, var, m_v_linear, grad, indices, lr, beta1_power, beta2_
 
 def kv_variable_group_sparse_apply_adam_v4(var, m_v_linear, grad, indices, lr, beta1_power,
                                            beta2_power, beat1, beta2, epsilon, l1, l2, l21,
-                                           use_locking=False, name=None):
-  """REGISTER_OP("KvVariableGroupSparseApplyAdamV4") ops/training_ops.cc:1266-1285."""
+                                           use_locking=False, name=None, unique_indices=False):
+  """REGISTER_OP("KvVariableGroupSparseApplyAdamV4") ops/training_ops.cc:1266-1285.
+  unique_indices: the caller's promise that `indices` holds no id twice (kv_apply_group_adam_unique)."""
   _group_adam(4, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2, epsilon,
-              l1, l2, l21, use_locking)
+              l1, l2, l21, use_locking, unique_indices)
 
 
 def kv_variable_group_sparse_apply_adam_v3(var, m_v_linear, grad, indices, lr, beta1_power,
                                            beta2_power, beat1, beta2, epsilon, l1, l2, l21,
-                                           use_locking=False, name=None):
+                                           use_locking=False, name=None, unique_indices=False):
   """REGISTER_OP("KvVariableGroupSparseApplyAdamV3") ops/training_ops.cc:1086-1105."""
   _group_adam(3, var, m_v_linear, grad, indices, lr, beta1_power, beta2_power, beat1, beta2, epsilon,
-              l1, l2, l21, use_locking)
+              l1, l2, l21, use_locking, unique_indices)
 
 
 def kv_variable_sparse_apply_adagrad(var, accum, lr, grad, indices, use_locking=False,
-                                     update_slots=True, name=None):
+                                     update_slots=True, name=None, unique_indices=False):
   """REGISTER_OP("KvVariableSparseApplyAdagrad") ops/training_ops.cc:214-226."""
   g, ids = _grad_ids(var, grad, indices)
+  if unique_indices:
+    _lib.check(_lib.lib().kv_apply_adagrad_unique(var.ptr, accum.ptr, _scalar(lr), _p(g), _p(ids), ids.numel(),
+                                                  int(bool(update_slots)), _stream(var)))
+    return
   _lib.check(_lib.lib().kv_apply_adagrad_tok(var.ptr, accum.ptr, _scalar(lr), _p(g), _p(ids), ids.numel(),
                                              int(bool(update_slots)), _token_for(var, ids), _stream(var)))
 
 
 def kv_variable_sparse_group_sparse_apply_ftrl_v2(var, accum, linear, grad, indices, lr, l1, l2, l21,
                                                   l2_shrinkage, lr_power, use_locking=False,
-                                                  name=None):
+                                                  name=None, unique_indices=False):
   """REGISTER_OP("KvVariableSparseGroupSparseApplyFtrlV2") ops/training_ops.cc:135-150."""
   g, ids = _grad_ids(var, grad, indices)
+  if unique_indices:
+    _lib.check(_lib.lib().kv_apply_sparse_group_ftrl_unique(
+        var.ptr, accum.ptr, linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(l1),
+        _scalar(l2), _scalar(l21), _scalar(l2_shrinkage), _scalar(lr_power), _stream(var)))
+    return
   _lib.check(_lib.lib().kv_apply_sparse_group_ftrl_tok(
       var.ptr, accum.ptr, linear.ptr, _p(g), _p(ids), ids.numel(), _scalar(lr), _scalar(l1),
       _scalar(l2), _scalar(l21), _scalar(l2_shrinkage), _scalar(lr_power), _token_for(var, ids), _stream(var)))
@@ -433,7 +449,7 @@ def kv_reserve(table_handle, capacity):
 
 
 PROF_KINDS = ("lookup_tile", "lookup_part", "lookup_order", "apply_index", "apply_sorted", "apply_span", "apply_tsum",
-              "lookup_rows", "apply_tile")   # include/kvhip.h KV_PROF_*
+              "apply_unique", "apply_tile")   # include/kvhip.h KV_PROF_*
 
 
 def kv_attach_slot(var, slot):
