@@ -73,8 +73,9 @@ class Zipf(object):
 def cpu_baseline(args, D):
   """The oracle (a port of the reference's CPU algorithm: 1031-segment unordered_map, per-row heap buffers, rw spin
   locks, Shard-style contiguous blocks) on this host's cores, BASELINE.md section 3's protocol on a bounded sample:
-  a table with --cpu-keys keys (configs[1]'s 50 M by default, built with every host thread inside --cpu-build-budget
-  seconds: a host too slow for that times the baseline on the keys it got in, and says how many), warm-up steps, then
+  a table with --cpu-keys keys (configs[1]'s 50 M by default; the UNTIMED build fills it one hash segment per thread,
+  --cpu-build-budget seconds at most: a host too slow for that times the baseline on the keys it got in, and says how
+  many), warm-up steps, then
   --cpu-steps timed steps of the same 1 M-id Zipf batch shape; median and p95.  The lookup and the optimizer apply
   are sharded over the cores like the reference's ops; TF-core's Unique / UnsortedSegmentSum run on ONE thread, as
   they do in TF-core."""
@@ -87,11 +88,15 @@ def cpu_baseline(args, D):
   slot = ko.OracleKv(3 * D, 0, np.zeros((16, 3 * D), np.float32), day=20000, picker=1, seed=1, threads=cores)
   z = Zipf(K, args.zipf, torch.device("cpu"))
   g = torch.Generator().manual_seed(SEED)
+  # UNTIMED set-up: the 50 M-key table is filled by oracle.bulk_build (one thread per hash segment, no lock traffic) — the
+  # state the ordinary lookup would leave, reached ~20 x faster (217 s of a 264 s run went into this build in round 4).
+  # The timed steps below run the ordinary restated functions (gather_or_insert, dedup, apply) on it.
   t0 = time.perf_counter()
   built = 0
-  for i in range(0, K, 1 << 20):
-    var.gather_or_insert(splitmix64(torch.arange(i + 1, min(i + (1 << 20), K) + 1, dtype=torch.int64)).numpy())
-    built = min(i + (1 << 20), K)
+  CHB = 1 << 23
+  for i in range(0, K, CHB):
+    var.bulk_build(splitmix64(torch.arange(i + 1, min(i + CHB, K) + 1, dtype=torch.int64)).numpy())
+    built = min(i + CHB, K)
     if time.perf_counter() - t0 > args.cpu_build_budget and built < K:
       break
   build_s = time.perf_counter() - t0
@@ -526,6 +531,16 @@ def main():
     torch.cuda.synchronize()
     prof = ops.kv_profile_read(var)
   ops.kv_profile_enable(var, 0)
+  # sharded path: where the step's time goes, phase by phase (events on the communicator's stream at the phase
+  # boundaries of the whole ops, kvhip.h kv_shard_profile) — `steps` further untimed steps, every one sampled
+  shard_prof = None
+  if shard_path:
+    shard.profile(1)
+    for k in range(args.steps):
+      step(args.warmup + 2 * args.steps + k)
+    torch.cuda.synchronize()
+    shard_prof = shard.profile_read()
+    shard.profile(0)
   # the COMPLETE lookup — output rows and the op's own bookkeeping (frequency words, day stamps, rows of new keys): a
   # token lookup defers that half to the head of the apply, where k_papply does it in the same pass as the update; a
   # lookup that is followed by another lookup runs it itself.  Timed here as a lookup-only loop (every lookup settles
@@ -675,6 +690,20 @@ def main():
     # xGMI traffic is reported apart from HBM: three fixed-size exchanges per step, every rank sends
     # every peer one segment of peer_capacity + 1 records — (id, count) pairs, rows back, summed gradient rows
     res["exchange"] = exchange_block(world, cap, D, Ub, bool(args.lossless), one_gpu_debug)
+    # phase by phase (partition -> gather -> stitch, embedding_ops.py:115-204, and the gradient's way back): mean ms over
+    # `steps` sampled steps taken after the timed region; the markers themselves cost stream time, so the sum runs a
+    # few per cent over ms_per_step
+    ph = shard_prof["phases_ms"]
+    res["phases_ms"] = ph
+    res["phases_sum_ms"] = sum(v for v in ph.values() if v)
+    res["phases_samples"] = shard_prof["samples"]
+    res["rccl_ranks_seen"] = shard_prof["rccl_ranks_seen"]
+    seg = cap + 1
+    wire = {"exchange_ids": (world - 1) * seg * 16, "exchange_rows": (world - 1) * seg * 4 * D, "exchange_grads": (world - 1) * seg * 4 * D}
+    res["exchange"]["wire_GBps"] = {k: (b / (ph[k] * 1e-3) / 1e9 if ph.get(k) else None) for k, b in wire.items()}
+    res["exchange"]["wire_bytes_per_exchange"] = wire
+    res["exchange"]["capacity_grows"] = shard_prof["grows"]
+    res["exchange"]["overflowed_batches"] = shard_prof["overflows"]
   # the calibrated ceiling of this access pattern (tools/calib_r03.hip, profiles/r03_calibration.txt): 1 M random
   # 128-B rows of a table far larger than the caches are read at 4.9-5.6 TB/s on this chip, whatever their order
   RANDOM_ROW_CEILING_GBS = 5000.0

@@ -489,6 +489,25 @@ int kv_shard_join(kv_shard_t shard, kv_stream_t stream);
  * blocks for a caller with its own exchange and never synchronise: such a caller checks kv_shard_agree_local or sizes
  * the capacity. */
 int kv_shard_set_lossless(kv_shard_t shard, int on);
+
+/* Where a sharded step's time goes (for the first multi-GPU run, where nothing can be iterated on): every `every`-th
+ * kv_shard_lookup / kv_shard_apply records events on the communicator's stream at its phase boundaries (the calls that
+ * do not are unchanged; every = 0 switches it off and clears the sums).  kv_shard_profile_read gives, per phase, the
+ * milliseconds summed over the samples and their number — phases in step order (embedding_ops.py:115-204: partition ->
+ * gather -> stitch, and the gradient's way back):
+ *   0 route          ids -> local distinct ids -> the owners' segments (+ the lossless agreement when it is on)
+ *   1 exchange_ids   grouped ncclSend / ncclRecv of the (id, count) segments
+ *   2 serve          the owner's training lookup over the segments it received
+ *   3 exchange_rows  the rows back
+ *   4 finish         out[i] = the row that came back for ids[i]
+ *   5 presum         gradient rows summed per distinct id into the records the ids were sent in
+ *   6 exchange_grads the summed rows to the owners
+ *   7 apply          the owner's fused optimizer apply
+ * info (may be NULL) [4]: {ranks whose handshake record arrived in the first exchange, peer capacity now, times the
+ * capacity was raised (lossless mode), batches that overflowed a segment (lossy mode)}. */
+#define KV_SHARD_PHASES 8
+int kv_shard_profile(kv_shard_t shard, int every);
+int kv_shard_profile_read(kv_shard_t shard, double* ms_sum, int64_t* samples, int n_phases, int64_t* info);
 /* The same agreement between the shards of ONE process (kv_shard_exchange_local's companion): after every shard's
  * kv_shard_lookup_route; *rerouted != 0: the capacity was raised on all of them, run the routes again. */
 int kv_shard_agree_local(const kv_shard_t* shards, int world, int* rerouted, kv_stream_t stream);

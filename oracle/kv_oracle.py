@@ -44,6 +44,7 @@ def lib():
   L.kvo_gather_or_insert.argtypes = [ctypes.c_void_p, _i64p, _i32p, ctypes.c_int64, _f32p,
                                      ctypes.c_int]
   L.kvo_gather_or_zeros.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, _f32p, ctypes.c_int]
+  L.kvo_bulk_build.argtypes = [ctypes.c_void_p, _i64p, ctypes.c_int64, ctypes.c_int]
   L.kvo_apply_group_adam.restype = ctypes.c_int
   L.kvo_apply_group_adam.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _f32p, _i64p,
                                      ctypes.c_int64] + [ctypes.c_float] * 9 + [ctypes.c_int,
@@ -135,6 +136,12 @@ class OracleKv:
     lib().kvo_gather_or_insert(self._h, _p(ids, _i64p), _p(c, _i32p), ids.size, _p(out, _f32p),
                                self.threads)
     return out.reshape(shape + (self.dim,))
+
+  def bulk_build(self, ids):
+    """The table state gather_or_insert(ids) leaves, built without the per-id lock traffic (one thread per hash
+    segment): the UNTIMED set-up of bench.py's cpu_baseline.  With picker=0 the rows depend on std::rand() order."""
+    ids = _ids(ids)
+    lib().kvo_bulk_build(self._h, _p(ids, _i64p), ids.size, self.threads)
 
   def gather_or_zeros(self, ids):
     shape = np.asarray(ids).shape

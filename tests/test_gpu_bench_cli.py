@@ -52,6 +52,35 @@ def test_bench_two_ranks_control_flow():
   assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
   d = _line(r.stdout)
   assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 400000 and d["value"] > 0
+  _check_phases(d, 2)
+
+
+PHASES = ("route", "exchange_ids", "serve", "exchange_rows", "finish", "presum", "exchange_grads", "apply")
+
+
+def _check_phases(d, world):
+  """the sharded line says where its step goes: every phase timed, the handshake's rank count, the wire rate per exchange"""
+  assert set(d["phases_ms"]) == set(PHASES) and all(d["phases_ms"][p] is not None and d["phases_ms"][p] >= 0 for p in PHASES)
+  assert d["phases_samples"] >= 1 and d["rccl_ranks_seen"] == world
+  assert abs(d["phases_sum_ms"] - sum(d["phases_ms"].values())) < 1e-9
+  w = d["exchange"]["wire_GBps"]
+  assert set(w) == {"exchange_ids", "exchange_rows", "exchange_grads"}
+  if world > 1:
+    assert all(v is not None and v > 0 for v in w.values())
+
+
+@pytest.mark.gpu
+def test_forced_sharded_world_of_one_accounts_for_its_step():
+  """`--force-sharded` at one rank runs the N > 1 ops through RCCL itself; the phases of the whole ops add up to the step
+  (the event markers cost stream time: the sum may run over ms_per_step, not under it)"""
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  r = subprocess.run([sys.executable, "bench.py", "--force-sharded", "--steps", "8", "--warmup", "2", "--keys", "2000000",
+                      "--batch", "400000", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+  d = _line(r.stdout)
+  _check_phases(d, 1)
+  assert 0.9 * d["ms_per_step"] <= d["phases_sum_ms"] <= 1.35 * d["ms_per_step"], (d["ms_per_step"], d["phases_ms"])
 
 
 @pytest.mark.gpu

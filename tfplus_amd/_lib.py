@@ -90,6 +90,8 @@ SIGNATURES = {
     "kv_shard_lookup": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp]),
     "kv_shard_apply": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _c.POINTER(_f), _i32, _vp]),
     "kv_shard_set_lossless": (_i32, [_vp, _i32]),
+    "kv_shard_profile": (_i32, [_vp, _i32]),
+    "kv_shard_profile_read": (_i32, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i32, _c.POINTER(_i64)]),
     "kv_shard_agree_local": (_i32, [_c.POINTER(_vp), _i32, _c.POINTER(_i32), _vp]),
     "kv_multi_shard_lookup": (_i32, [_c.POINTER(_vp), _i32, _vp, _c.POINTER(_vp), _c.POINTER(_c.c_int64), _c.POINTER(_vp), _i32, _vp]),
     "kv_multi_shard_apply": (_i32, [_c.POINTER(_vp), _i32, _vp, _i32, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp),

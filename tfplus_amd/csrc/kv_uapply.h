@@ -101,14 +101,29 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
   const float* const gbase = a.grad;
   const long long nbatch = (n + G - 1) / G;
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nbatch; b += nwaves) {   // wave-uniform
+  // Two batches ahead: the id of batch b + 2 strides and the index entry of batch b + 1 stride are requested while batch b
+  // is worked on, so a batch pays one exposed round trip (its rows), not three (id -> entry -> rows).
+  auto id_at = [&](long long bb) -> long long {
+    long long j = bb * G + g;
+    if (j >= n) j = n - 1;   // (past the end: a valid address, the value is not used)
+    return ids32 ? (long long)static_cast<const int*>(ids)[j] : static_cast<const long long*>(ids)[j];
+  };
+  const long long b0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  long long key_n = id_at(b0);
+  long long key_nn = id_at(b0 + nwaves);
+  unsigned long long p_n = home_of(a.tv, key_n, mix64((unsigned long long)key_n));
+  Entry e_n = load_entry(&a.tv.entries[p_n]);
+  for (long long b = b0; b < nbatch; b += nwaves) {   // wave-uniform
     const long long i = b * G + g;
     const bool live0 = i < n;
     const long long ic = live0 ? i : n - 1;
-    const long long key = ids32 ? (long long)static_cast<const int*>(ids)[ic] : static_cast<const long long*>(ids)[ic];
-    // ---- the id's index entry: row + slot-row hint (every lane of the group asks for the same 16 bytes) -----------------
-    const unsigned long long p = home_of(a.tv, key, mix64((unsigned long long)key));
-    const Entry e0 = load_entry(&a.tv.entries[p]);
+    const long long key = key_n;
+    const unsigned long long p = p_n;
+    const Entry e0 = e_n;
+    key_n = key_nn;
+    p_n = home_of(a.tv, key_n, mix64((unsigned long long)key_n));
+    e_n = load_entry(&a.tv.entries[p_n]);
+    key_nn = id_at(b + 2 * nwaves);
     unsigned hint = 0;
     unsigned row = table_find_from(a.tv, key, p, e0, &hint);
     bool isnew = false, dup = false;

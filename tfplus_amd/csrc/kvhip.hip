@@ -3041,9 +3041,42 @@ struct kv_shard {
   uint64_t route_token = 0;
   kv_batch_token_t serve_token = 0;
   hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+  int ranks_seen = 0;                // ranks whose handshake record arrived in the first exchange (shard_verify)
+  // per-phase timing of the whole ops (kv_shard_profile): events on the communicator's stream at the phase boundaries of
+  // every prof_every-th step; one sample in flight, collected by the next sampled call or by the read
+  int prof_every = 0;
+  unsigned prof_seq_l = 0, prof_seq_a = 0;
+  hipEvent_t pev[10] = {};           // lookup: [0..5] = 5 phases; apply: [6..9] = 3 phases
+  bool pend_l = false, pend_a = false;
+  double psum[KV_SHARD_PHASES] = {};
+  long long pcnt[KV_SHARD_PHASES] = {};
 };
 
 namespace {
+// phase timing of the whole sharded ops (kv_shard_profile): see kv_shard
+void shard_prof_collect(kv_shard* sh, bool lookup) {
+  bool& pend = lookup ? sh->pend_l : sh->pend_a;
+  if (!pend) return;
+  const int e0 = lookup ? 0 : 6, np = lookup ? 5 : 3, p0 = lookup ? 0 : 5;
+  if (hipEventSynchronize(sh->pev[e0 + np]) == hipSuccess)
+    for (int i = 0; i < np; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sh->pev[e0 + i], sh->pev[e0 + i + 1]) == hipSuccess) { sh->psum[p0 + i] += ms; sh->pcnt[p0 + i] += 1; }
+    }
+  pend = false;
+}
+// does this call carry markers?  (collects the previous sample first: its events are about to be reused)
+bool shard_prof_begin(kv_shard* sh, bool lookup) {
+  if (sh->prof_every <= 0) return false;
+  unsigned& seq = lookup ? sh->prof_seq_l : sh->prof_seq_a;
+  if ((seq++ % (unsigned)sh->prof_every) != 0u) return false;
+  shard_prof_collect(sh, lookup);
+  for (hipEvent_t& e : sh->pev)
+    if (!e && hipEventCreate(&e) != hipSuccess) return false;
+  return true;
+}
+inline void shard_prof_mark(kv_shard* sh, bool on, int ev, hipStream_t w) { if (on) hipEventRecord(sh->pev[ev], w); }
+
 void shard_free_buffers(kv_shard* sh) {
   hipFree(sh->send_pairs); hipFree(sh->recv_pairs); hipFree(sh->send_rows); hipFree(sh->recv_rows);
   sh->send_pairs = sh->recv_pairs = nullptr; sh->send_rows = sh->recv_rows = nullptr;
@@ -3250,6 +3283,7 @@ int kv_shard_destroy(kv_shard_t sh) {
   if (sh->need_host) hipHostFree(sh->need_host);
   if (sh->ev_fork) hipEventDestroy(sh->ev_fork);
   if (sh->ev_done) hipEventDestroy(sh->ev_done);
+  for (hipEvent_t e : sh->pev) if (e) hipEventDestroy(e);
   if (sh->route) kv_destroy(sh->route);
   delete sh;
   return KV_OK;
@@ -3567,7 +3601,7 @@ static int shard_verify(kv_shard* sh, kv_comm* comm) {
     }
   } while (0);
   hipFree(ds); hipFree(dr);
-  if (!rc) sh->verified = comm;
+  if (!rc) { sh->verified = comm; sh->ranks_seen = W; }
   return rc;
 }
 
@@ -3617,6 +3651,24 @@ static int shard_agree_many(const kv_shard_t* shards, int ntab, kv_comm* comm, h
     ++sh->grows;
     grown[k] = 1;
   }
+  return KV_OK;
+}
+
+int kv_shard_profile(kv_shard_t sh, int every) {
+  if (!sh) return fail(KV_INVALID_ARGUMENT, "null shard");
+  DeviceGuard dg(sh->table->device);
+  shard_prof_collect(sh, true); shard_prof_collect(sh, false);
+  sh->prof_every = every > 0 ? every : 0;
+  sh->prof_seq_l = sh->prof_seq_a = 0;
+  for (int i = 0; i < KV_SHARD_PHASES; ++i) { sh->psum[i] = 0.0; sh->pcnt[i] = 0; }
+  return KV_OK;
+}
+int kv_shard_profile_read(kv_shard_t sh, double* ms_sum, int64_t* samples, int n_phases, int64_t* info) {
+  if (!sh || !ms_sum || !samples || n_phases < KV_SHARD_PHASES) return fail(KV_INVALID_ARGUMENT, "kv_shard_profile_read: bad arguments");
+  DeviceGuard dg(sh->table->device);
+  shard_prof_collect(sh, true); shard_prof_collect(sh, false);
+  for (int i = 0; i < KV_SHARD_PHASES; ++i) { ms_sum[i] = sh->psum[i]; samples[i] = sh->pcnt[i]; }
+  if (info) { info[0] = sh->ranks_seen; info[1] = (int64_t)sh->C; info[2] = (int64_t)sh->grows; info[3] = (int64_t)sh->overflows; }
   return KV_OK;
 }
 
@@ -3671,6 +3723,8 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   auto note = [&](int r) { if (r && !first) { first = r; first_msg = kv_last_error(); } return r; };
   sh->self_in_place = shard_can_stay(sh);
   char stay = sh->self_in_place ? 1 : 0;
+  const bool pm = shard_prof_begin(sh, true);
+  shard_prof_mark(sh, pm, 0, w);
   if (note(lookup_route_impl(sh, ids, n, w))) {
     sh->n_last = 0; sh->route_token = 0;
     HIP_TRY(hipMemsetAsync(sh->counts, 0, (size_t)sh->world * 8, w));
@@ -3689,11 +3743,17 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
       }
     }
   }
+  shard_prof_mark(sh, pm, 1, w);
   if ((rc = shard_exchange_one(comm, sh->send_pairs, sh->recv_pairs, wired(comm) ? pb : pb * sh->world, w, stay))) return rc;
+  shard_prof_mark(sh, pm, 2, w);
   if (note(kv_shard_lookup_serve(sh, w)))
     HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
+  shard_prof_mark(sh, pm, 3, w);
   if ((rc = shard_exchange_one(comm, sh->send_rows, sh->recv_rows, wired(comm) ? rb : rb * sh->world, w, stay))) return rc;
+  shard_prof_mark(sh, pm, 4, w);
   if (!first) note(kv_shard_lookup_finish(sh, out, w));
+  shard_prof_mark(sh, pm, 5, w);
+  if (pm) sh->pend_l = true;
   if ((rc = shard_done(sh, s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchanges were queued all the same)", first_msg.c_str());
   return shard_late_report(sh, seen);
@@ -3711,12 +3771,18 @@ int kv_shard_apply(kv_shard_t sh, kv_comm_t comm, int optimizer, kv_handle_t slo
   // as in kv_shard_lookup: a rank whose route phase failed still takes part in the exchange (zero gradient rows)
   int first = KV_OK;
   std::string first_msg;
+  const bool pm = shard_prof_begin(sh, false);
+  shard_prof_mark(sh, pm, 6, w);
   if ((first = kv_shard_apply_route(sh, grad, w))) {
     first_msg = kv_last_error();
     HIP_TRY(hipMemsetAsync(sh->send_rows, 0, (size_t)rb * sh->world, w));
   }
+  shard_prof_mark(sh, pm, 7, w);
   if ((rc = shard_exchange_one(comm, sh->send_rows, sh->recv_rows, wired(comm) ? rb : rb * sh->world, w, sh->self_in_place ? 1 : 0))) return rc;
+  shard_prof_mark(sh, pm, 8, w);
   rc = kv_shard_apply_serve(sh, optimizer, slot0, slot1, hp, w);
+  shard_prof_mark(sh, pm, 9, w);
+  if (pm) sh->pend_a = true;
   if (rc && !first) { first = rc; first_msg = kv_last_error(); }
   if ((rc = shard_done(sh, s, w, join))) return rc;
   if (first) return fail(first, "%s (this rank's exchange was queued all the same)", first_msg.c_str());

@@ -898,6 +898,22 @@ class KvShard(object):
     except Exception:  # interpreter shutdown
       pass
 
+  PHASES = ("route", "exchange_ids", "serve", "exchange_rows", "finish", "presum", "exchange_grads", "apply")   # kvhip.h kv_shard_profile
+
+  def profile(self, every=1):
+    """Per-phase event timing of every `every`-th whole lookup / apply on the communicator's stream (0: off)."""
+    _lib.check(_lib.lib().kv_shard_profile(self.ptr, int(every)))
+
+  def profile_read(self):
+    """{"phases_ms": {phase: mean ms per sampled step}, "samples": n, "rccl_ranks_seen", "peer_capacity", "grows", "overflows"}"""
+    ms = (ctypes.c_double * len(self.PHASES))()
+    cnt = (ctypes.c_int64 * len(self.PHASES))()
+    info = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.lib().kv_shard_profile_read(self.ptr, ms, cnt, len(self.PHASES), info))
+    return {"phases_ms": {p: (ms[i] / cnt[i] if cnt[i] else None) for i, p in enumerate(self.PHASES)},
+            "samples": int(min(cnt)) if len(cnt) else 0, "rccl_ranks_seen": int(info[0]), "peer_capacity": int(info[1]),
+            "grows": int(info[2]), "overflows": int(info[3])}
+
   def buffers(self):
     """The exchange buffers as flat uint8 tensors over the library's memory (zero copy): send_pairs, recv_pairs
     [world x pair_bytes], send_rows, recv_rows [world x row_bytes] — for a caller that moves the segments itself."""
