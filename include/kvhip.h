@@ -367,6 +367,19 @@ int kv_multi_apply_sparse_group_ftrl_tok(int num_tables, const kv_handle_t* vars
                                          const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
                                          float l21, float l2_shrinkage, float lr_power,
                                          const kv_batch_token_t* tokens, kv_stream_t stream);
+/* ... and with the caller's promise that no table's ids hold an id twice (kv_apply_*_unique above: what the ops of an
+ * unchanged TF graph receive): ONE launch for all tables (grid.y = table), the promise guarded per table as there. */
+int kv_multi_apply_group_adam_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* m_v_linears,
+                                     const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                                     float beta1_power, float beta2_power, float beta1, float beta2, float epsilon,
+                                     float l1, float l2, float l21, int version, kv_stream_t stream);
+int kv_multi_apply_adagrad_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                                  const float* const* grads, const void* const* ids, const int64_t* ns,
+                                  int update_slots, kv_stream_t stream);
+int kv_multi_apply_sparse_group_ftrl_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                            const kv_handle_t* linears, const float* const* grads,
+                                            const void* const* ids, const int64_t* ns, float lr, float l1, float l2,
+                                            float l21, float l2_shrinkage, float lr_power, kv_stream_t stream);
 
 
 /* embedding_lookup_sparse on a KvVariable (python/ops/embedding_ops.py:279-441), fused: the

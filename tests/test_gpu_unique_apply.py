@@ -207,3 +207,49 @@ def test_stamp_serial_wraps_without_false_alarms(ops):
     _run(ops, "adagrad", hp, grad, ids, False, lr=1e-4)
   for a, b in zip(hu, hp):
     _same_bits(ops, a, b, ids)
+
+
+@pytest.mark.parametrize("name", ["adam4", "adagrad", "ftrl"])
+def test_batched_unique_apply_equals_the_per_table_ops(ops, name):
+  """kv_multi_apply_*_unique: several tables in ONE launch (the DCN shape: one op per embedding table in the reference),
+  bit for bit the per-table unique ops; an id listed twice in ONE table is reported on that table"""
+  from tfplus_amd import _lib
+  D, T = 16, 5
+  rng = np.random.default_rng(61)
+  multi, single = [], []
+  for j in range(T):
+    hu, hp, _ = _tables(ops, name, D, seed=3 + j)
+    multi.append(hu); single.append(hp)
+  for t in range(3):
+    ids = [rng.choice(4000, int(rng.integers(1, 1500)), replace=False).astype(np.int64) for _ in range(T)]
+    ids[2] = ids[2][:0] if t == 1 else ids[2]                     # a table that sits a step out
+    grads = [rng.normal(0, 1e-2, (i.size, D)).astype(np.float32) for i in ids]
+    b1p, b2p = _beta_pows(t)
+    if name == "adam4":
+      ops.kv_multi_group_sparse_apply_adam([h[0] for h in multi], [h[1] for h in multi], grads, ids, 0.05, b1p, b2p, 0.9, 0.999,
+                                           1e-8, 0.0, 0.0, 0.0, unique_indices=True)
+    elif name == "adagrad":
+      ops.kv_multi_sparse_apply_adagrad([h[0] for h in multi], [h[1] for h in multi], 0.05, grads, ids, unique_indices=True)
+    else:
+      ops.kv_multi_sparse_group_sparse_apply_ftrl([h[0] for h in multi], [h[1] for h in multi], [h[2] for h in multi], grads, ids,
+                                                  0.05, 0.0, 1e-3, 0.0, 0.0, -0.5, unique_indices=True)
+    for j in range(T):
+      if ids[j].size:
+        _run(ops, name, single[j], grads[j], ids[j], True, lr=0.05, b1p=b1p, b2p=b2p, l2=1e-3 if name == "ftrl" else 0.0)
+    for j in range(T):
+      for a, b in zip(multi[j], single[j]):
+        _same_bits(ops, a, b, ids[j] if ids[j].size else np.arange(4))
+  # a duplicate in table 3 only
+  ids = [np.arange(200, dtype=np.int64) for _ in range(T)]
+  ids[3] = ids[3].copy(); ids[3][150] = ids[3][7]
+  grads = [np.full((200, D), 1e-3, np.float32) for _ in range(T)]
+  if name == "adam4":
+    ops.kv_multi_group_sparse_apply_adam([h[0] for h in multi], [h[1] for h in multi], grads, ids, 0.05, 0.9, 0.999, 0.9, 0.999, 1e-8,
+                                         0.0, 0.0, 0.0, unique_indices=True)
+    torch.cuda.synchronize()
+    for j in range(T):
+      if j == 3:
+        with pytest.raises(_lib.InvalidArgumentError, match="NOT unique"):
+          ops.kv_variable_size_v2(multi[j][0])
+      else:
+        ops.kv_variable_size_v2(multi[j][0])

@@ -38,7 +38,12 @@ class mutex_lock {
  private:
   mutex* m_;
 };
-class NodeDef;
+// (tensorflow/core/framework/node_def.pb.h) what the shim reads of a node: its input edge names
+class NodeDef {
+ public:
+  int input_size() const;
+  const std::string& input(int i) const;
+};
 
 class Status {
  public:
@@ -134,6 +139,7 @@ class Tensor {
 
 class OpKernelConstruction {
  public:
+  const NodeDef& def() const;
   template <typename T> Status GetAttr(const char* name, T* v) const;
   void CtxFailure(const char* file, int line, const Status& s);
   void CtxFailureWithWarning(const char* file, int line, const Status& s);

@@ -108,6 +108,9 @@ SIGNATURES = {
     "kv_multi_apply_adagrad": (_i32, [_i32, _vp, _vp, _c.c_float, _vp, _vp, _vp, _i32, _vp]),
     "kv_multi_apply_sparse_group_ftrl": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 6 + [_vp]),
     "kv_multi_gather_or_insert_tok": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kv_multi_apply_group_adam_unique": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 9 + [_i32, _vp]),
+    "kv_multi_apply_adagrad_unique": (_i32, [_i32, _vp, _vp, _c.c_float, _vp, _vp, _vp, _i32, _vp]),
+    "kv_multi_apply_sparse_group_ftrl_unique": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 6 + [_vp]),
     "kv_multi_apply_group_adam_tok": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 9 + [_i32, _vp, _vp]),
     "kv_multi_apply_adagrad_tok": (_i32, [_i32, _vp, _vp, _c.c_float, _vp, _vp, _vp, _i32, _vp, _vp]),
     "kv_multi_apply_sparse_group_ftrl_tok": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp] + [_c.c_float] * 6 + [_vp, _vp]),

@@ -651,9 +651,13 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 __device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int mode_, const unsigned nblocks) {
   if ((mode_ & 0xFF) != PA_UNIQUE || a.route_world <= 0 || a.route_need == nullptr) return;   // (uniform over the launch)
   // No fence: the block's adds to the owners' counters are RETURNING device-scope atomics (their values place the
-  // block's records), so they have been performed when the barrier below is passed, before the block reports; the
-  // last block reads the counters with device-scope atomic loads.  (A __threadfence() per thread here is a write-back
-  // and an invalidate of the XCD's L2 per wave on this chip: it cost the route 100 us.)
+  // block's records), so they have been performed — at the memory side, where every XCD sees them — when the barrier
+  // below is passed, before the block takes its ticket; the last block reads the counters with device-scope atomic
+  // loads, which bypass its L2 as well.  This rests on how gfx950 performs device-scope atomics, not on the HIP memory
+  // model; the model's form — the ticket ACQ_REL, the last block's loads ACQUIRE, one thread per block — was
+  // built and measured in round 5: a release is a write-back of the XCD's L2, and 512 of them behind a kernel that left
+  // megabytes dirty take the route from 42 to 56 us (sharded world-1 step 0.219 -> 0.233 ms).  (A __threadfence() per
+  // thread cost it 100 us.)  Relaxed stays; tests/test_gpu_sharded_two_ranks.py checks the headers on every run.
   __shared__ unsigned rt_last, rt_tot, rt_max;
   __syncthreads();
   if (threadIdx.x == 0) {

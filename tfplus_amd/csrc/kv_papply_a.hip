@@ -30,10 +30,11 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_a(int opt
 
 // k_uapply (kv_uapply.h): the apply on unique ids + pre-summed rows, one launch
 extern "C" __attribute__((visibility("hidden"))) int kvp_launch_uapply_a(int opt, const void* pa_, const void* ids, int ids32,
-                                                                      long long n, void* stream) {
+                                                                      long long n, void* stream, const void* md_, int ntab) {
   const PartArgs& pa = *static_cast<const PartArgs*>(pa_);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (opt == OPT_ADAM_V4) return launch_uapply_t<OPT_ADAM_V4>(pa, ids, ids32, n, s);
-  if (opt == OPT_ADAM_V3) return launch_uapply_t<OPT_ADAM_V3>(pa, ids, ids32, n, s);
+  const MultiDesc* md = static_cast<const MultiDesc*>(md_);
+  if (opt == OPT_ADAM_V4) return launch_uapply_t<OPT_ADAM_V4>(pa, ids, ids32, n, s, md, ntab);
+  if (opt == OPT_ADAM_V3) return launch_uapply_t<OPT_ADAM_V3>(pa, ids, ids32, n, s, md, ntab);
   return KV_INTERNAL;
 }

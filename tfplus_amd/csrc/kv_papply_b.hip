@@ -30,10 +30,11 @@ extern "C" __attribute__((visibility("hidden"))) int kvp_launch_papply_b(int opt
 
 // k_uapply (kv_uapply.h): the apply on unique ids + pre-summed rows, one launch
 extern "C" __attribute__((visibility("hidden"))) int kvp_launch_uapply_b(int opt, const void* pa_, const void* ids, int ids32,
-                                                                      long long n, void* stream) {
+                                                                      long long n, void* stream, const void* md_, int ntab) {
   const PartArgs& pa = *static_cast<const PartArgs*>(pa_);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (opt == OPT_ADAGRAD) return launch_uapply_t<OPT_ADAGRAD>(pa, ids, ids32, n, s);
-  if (opt == OPT_FTRL) return launch_uapply_t<OPT_FTRL>(pa, ids, ids32, n, s);
+  const MultiDesc* md = static_cast<const MultiDesc*>(md_);
+  if (opt == OPT_ADAGRAD) return launch_uapply_t<OPT_ADAGRAD>(pa, ids, ids32, n, s, md, ntab);
+  if (opt == OPT_FTRL) return launch_uapply_t<OPT_FTRL>(pa, ids, ids32, n, s, md, ntab);
   return KV_INTERNAL;
 }

@@ -268,10 +268,20 @@ __global__ void __launch_bounds__(256, (K == 1 ? 4 : 2)) k_uapply(PartArgs a, co
   uapply_body<OPT, V, LPR, K>(a, ids, ids32, n);
 }
 
+// many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array)
+template <int OPT, int V, int LPR, int K>
+__global__ void __launch_bounds__(256, (K == 1 ? 4 : 2)) k_uapply_multi(const MultiDesc* __restrict__ descs, int ids32) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (m.n == 0) return;
+  uapply_body<OPT, V, LPR, K>(m.a, m.ids, ids32, m.n);
+}
+
 // dispatch on the row geometry (as k_papply: float4 rows, a power-of-two lane count).  KV_UNIMPLEMENTED for other dims:
-// the caller falls back to the batch pipeline, which serves them.
+// the caller falls back to the batch pipeline, which serves them.  md != nullptr: `ntab` tables in one launch (n = the
+// largest table's ids, pa = any table's arguments: only the dim is read)
 template <int OPT>
-int launch_uapply_t(const PartArgs& pa, const void* ids, int ids32, long long n, hipStream_t s) {
+int launch_uapply_t(const PartArgs& pa, const void* ids, int ids32, long long n, hipStream_t s, const MultiDesc* md = nullptr,
+                    int ntab = 0) {
   const int D = pa.tv.dim;
   if ((D & 3) != 0) return KV_UNIMPLEMENTED;
 #define KV_UA(V, LPR, K)                                                                                        \
@@ -287,8 +297,13 @@ int launch_uapply_t(const PartArgs& pa, const void* ids, int ids32, long long n,
     }();                                                                                                        \
     const long long nbatch = (n + G - 1) / G;                                                                   \
     const long long want = (nbatch + 3) / 4;                                                                    \
-    const int grid = (int)(want < 1 ? 1 : want > resident ? resident : want);                                   \
-    k_uapply<OPT, V, LPR, K><<<grid, 256, 0, s>>>(pa, ids, ids32, n);                                            \
+    int grid = (int)(want < 1 ? 1 : want > resident ? resident : want);                                         \
+    if (md) {   /* all tables' blocks are one resident generation */                                            \
+      if (ntab > 0 && (long long)grid * ntab > resident) grid = resident / ntab > 1 ? resident / ntab : 1;       \
+      k_uapply_multi<OPT, V, LPR, K><<<dim3((unsigned)grid, (unsigned)ntab), 256, 0, s>>>(md, ids32);            \
+    } else {                                                                                                    \
+      k_uapply<OPT, V, LPR, K><<<grid, 256, 0, s>>>(pa, ids, ids32, n);                                          \
+    }                                                                                                           \
     return KV_OK;                                                                                               \
   } while (0)
   const int q = D / 4;

@@ -61,8 +61,10 @@ extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids,
 extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
 extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
 // k_uapply dispatch (kv_uapply.h: the apply on unique ids), instantiated next to k_papply
-extern "C" int kvp_launch_uapply_a(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream);
-extern "C" int kvp_launch_uapply_b(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream);
+extern "C" int kvp_launch_uapply_a(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream, const void* md = nullptr,
+                                   int ntab = 0);
+extern "C" int kvp_launch_uapply_b(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream, const void* md = nullptr,
+                                   int ntab = 0);
 
 namespace {
 
@@ -1828,6 +1830,51 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
+  if (tl_unique && fused_ok(D)) {
+    // The caller promises that no table's ids hold an id twice (kv_multi_apply_*_unique; kv_uapply.h): ONE launch for all
+    // tables, one lane group per id (grid.y = table).  Pending lookup passes are settled first.
+    long long nmax = 0;
+    for (kv_table* tb : lock.ts)
+      if ((rc = report_deferred_error(tb, s)) || (rc = hand_over(tb, s))) return rc;
+    for (int i = 0; i < num_tables; ++i) {
+      if ((rc = ensure_capacity(vars[i], ns[i], s)) || (rc = ensure_capacity(slots0[i], ns[i], s)) ||
+          (slots1 && (rc = ensure_capacity(slots1[i], ns[i], s))))
+        return rc;
+      nmax = std::max<long long>(nmax, ns[i]);
+    }
+    if (nmax == 0) return KV_OK;
+    BatchStage& st = g_stage[device][1];
+    StageSlot* sl = nullptr;
+    if ((rc = stage_acquire(st, (size_t)num_tables * sizeof(MultiDesc), &sl))) return rc;
+    StageRelease rel{st, sl, s};
+    MultiDesc* hd = reinterpret_cast<MultiDesc*>(sl->host);
+    for (int i = 0; i < num_tables; ++i) {
+      kv_table* v = vars[i];
+      if (v->uniq_serial >= 65535u) {   // the 16-bit stamp wraps: every row back to "none"
+        k_clear_stamps<<<nblocks((long long)v->rows_ub, TB, 4096), TB, 0, s>>>(dev_view(v), (unsigned)v->rows_ub);
+        v->uniq_serial = 0;
+      }
+      MultiDesc& d = hd[i];
+      std::memset(&d, 0, sizeof d);
+      d.a.tv = dev_view(v); d.a.ts0 = dev_view(slots0[i]); d.a.ts1 = slots1 ? dev_view(slots1[i]) : d.a.ts0;
+      d.a.opt = a; d.a.grad = grads[i]; d.a.day = today(v);
+      d.a.opt.fast = fast_math_on(v) ? 1 : 0;
+      d.a.n = ns[i];
+      d.a.use_hints = claim_slot(v, slots0[i], s) ? 1 : 0;
+      d.a.uniq_serial = ns[i] > 0 ? ++v->uniq_serial : 0u;
+      d.ids = ids[i];
+      d.n = ns[i];
+    }
+    HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, (size_t)num_tables * sizeof(MultiDesc), hipMemcpyHostToDevice, s));
+    rel.launched = true;
+    const int ids32 = vars[0]->key_dtype == KV_DT_INT32 ? 1 : 0;
+    ProfScope ps(vars[0], KV_PROF_APPLY_UNIQUE, s);
+    rc = (opt == OPT_ADAM_V4 || opt == OPT_ADAM_V3) ? kvp_launch_uapply_a(opt, &hd[0].a, nullptr, ids32, nmax, (void*)s, sl->dev, num_tables)
+                                                    : kvp_launch_uapply_b(opt, &hd[0].a, nullptr, ids32, nmax, (void*)s, sl->dev, num_tables);
+    if (rc) return fail(rc, "batched unique apply: no kernel for dim %d", D);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   // The entry-list kernels (fused_ok): every table still holds the tiles' entries of its batch (kv_multi_gather_or_insert_tok)
   // and every token matches -> k_papply_multi over them: PA_LOOKUP when the lookups' partition passes are still pending (it
   // completes them together with the update), PA_NONE when they have been settled since.  One stale token and all tables
@@ -2203,6 +2250,28 @@ int kv_apply_group_adam_unique(kv_handle_t v, kv_handle_t mvl, const float* grad
                                float l2, float l21, int version, kv_stream_t stream) {
   UniqueScope u;
   return kv_apply_group_adam_tok(v, mvl, grad, ids, n, lr, b1p, b2p, b1, b2, eps, l1, l2, l21, version, 0, stream);
+}
+int kv_multi_apply_group_adam_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* slots,
+                                     const float* const* grads, const void* const* ids, const int64_t* ns, float lr,
+                                     float b1p, float b2p, float b1, float b2, float eps, float l1, float l2, float l21,
+                                     int version, kv_stream_t stream) {
+  UniqueScope u;
+  return kv_multi_apply_group_adam_tok(num_tables, vars, slots, grads, ids, ns, lr, b1p, b2p, b1, b2, eps, l1, l2, l21, version,
+                                       nullptr, stream);
+}
+int kv_multi_apply_adagrad_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums, float lr,
+                                  const float* const* grads, const void* const* ids, const int64_t* ns, int update_slots,
+                                  kv_stream_t stream) {
+  UniqueScope u;
+  return kv_multi_apply_adagrad_tok(num_tables, vars, accums, lr, grads, ids, ns, update_slots, nullptr, stream);
+}
+int kv_multi_apply_sparse_group_ftrl_unique(int num_tables, const kv_handle_t* vars, const kv_handle_t* accums,
+                                            const kv_handle_t* linears, const float* const* grads, const void* const* ids,
+                                            const int64_t* ns, float lr, float l1, float l2, float l21, float l2s,
+                                            float lr_power, kv_stream_t stream) {
+  UniqueScope u;
+  return kv_multi_apply_sparse_group_ftrl_tok(num_tables, vars, accums, linears, grads, ids, ns, lr, l1, l2, l21, l2s, lr_power,
+                                              nullptr, stream);
 }
 int kv_apply_adagrad_unique(kv_handle_t v, kv_handle_t acc, float lr, const float* grad, const void* ids,
                             int64_t n, int update_slots, kv_stream_t stream) {
@@ -3731,6 +3800,12 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
     k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
   }
   if (sh->lossless) {   // every rank takes part in the agreement, whatever its own route did
+    // (the agreement reads a device word on the host: one stream synchronisation — not allowed inside a stream capture)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(w, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(KV_FAILED_PRECONDITION, "kv_shard_lookup under stream capture: the lossless mode (the default) synchronises once per "
+                                          "lookup; capture sharded steps with kv_shard_set_lossless(shard, 0) and a peer_capacity "
+                                          "sized for the workload");
     char grown = 0;
     if ((rc = shard_agree_many(&sh, 1, comm, w, &grown))) return rc;
     if (grown) {
@@ -4036,6 +4111,12 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   }
   {   // lossless tables: one agreement for all of them (see shard_agree_many), then the grown ones are routed again
     std::vector<char> grown(ntab, 0);
+    bool any_lossless = false;
+    for (int k = 0; k < ntab; ++k) any_lossless = any_lossless || shards[k]->lossless;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (any_lossless && hipStreamIsCapturing(w, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(KV_FAILED_PRECONDITION, "kv_multi_shard_lookup under stream capture: the lossless mode (the default) synchronises once "
+                                          "per lookup; capture sharded steps with kv_shard_set_lossless(shard, 0)");
     if ((rc = shard_agree_many(shards, ntab, comm, w, grown.data()))) return rc;
     for (int k = 0; k < ntab; ++k)
       if (grown[k]) {

@@ -602,8 +602,9 @@ def _multi_tokens(var_handles, indices):
 
 
 def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, indices, lr, beta1_power, beta2_power,
-                                     beat1, beta2, epsilon, l1, l2, l21, version=4):
-  """KvVariableGroupSparseApplyAdamV4 (V3) on many (var, m_v_linear) pairs with two kernel launches."""
+                                     beat1, beta2, epsilon, l1, l2, l21, version=4, unique_indices=False):
+  """KvVariableGroupSparseApplyAdamV4 (V3) on many (var, m_v_linear) pairs with two kernel launches (one with
+  unique_indices: the caller's promise that no table's indices hold an id twice, kvhip.h kv_multi_apply_*_unique)."""
   n = len(var_handles)
   if n < 1 or not (n == len(m_v_linear_handles) == len(grads) == len(indices)):
     raise _lib.InvalidArgumentError("vars, slots, grads and indices must be equally long, N >= 1")
@@ -616,6 +617,10 @@ def kv_multi_group_sparse_apply_adam(var_handles, m_v_linear_handles, grads, ind
   sp = (ctypes.c_void_p * n)(*[h.ptr for h in m_v_linear_handles])
   ns = (ctypes.c_int64 * n)(*[i.numel() for i in ids])
   sc = [ctypes.c_float(_scalar(x)) for x in (lr, beta1_power, beta2_power, beat1, beta2, epsilon, l1, l2, l21)]
+  if unique_indices:
+    _lib.check(_lib.lib().kv_multi_apply_group_adam_unique(n, vp, sp, _ptr_array(gr), _ptr_array(ids), ns, *sc, int(version),
+                                                           _stream(var_handles[0])))
+    return
   _lib.check(_lib.lib().kv_multi_apply_group_adam_tok(n, vp, sp, _ptr_array(gr), _ptr_array(ids), ns, *sc, int(version),
                                                       toks, _stream(var_handles[0])))
 
@@ -630,19 +635,23 @@ def _multi_prep(var_handles, grads, indices):
   return ids, gr, (ctypes.c_int64 * n)(*[i.numel() for i in ids]), toks
 
 
-def kv_multi_sparse_apply_adagrad(var_handles, accum_handles, lr, grads, indices, update_slots=True):
+def kv_multi_sparse_apply_adagrad(var_handles, accum_handles, lr, grads, indices, update_slots=True, unique_indices=False):
   """KvVariableSparseApplyAdagrad on many (var, accum) pairs with two kernel launches."""
   n = len(var_handles)
   if n < 1 or not (n == len(accum_handles) == len(grads) == len(indices)):
     raise _lib.InvalidArgumentError("vars, accums, grads and indices must be equally long, N >= 1")
   ids, gr, ns, toks = _multi_prep(var_handles, grads, indices)
   vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
+  if unique_indices:
+    _lib.check(_lib.lib().kv_multi_apply_adagrad_unique(n, vp, ap, ctypes.c_float(_scalar(lr)), _ptr_array(gr), _ptr_array(ids), ns,
+                                                        int(bool(update_slots)), _stream(var_handles[0])))
+    return
   _lib.check(_lib.lib().kv_multi_apply_adagrad_tok(n, vp, ap, ctypes.c_float(_scalar(lr)), _ptr_array(gr), _ptr_array(ids), ns,
                                                    int(bool(update_slots)), toks, _stream(var_handles[0])))
 
 
 def kv_multi_sparse_group_sparse_apply_ftrl(var_handles, accum_handles, linear_handles, grads, indices, lr, l1, l2, l21,
-                                            l2_shrinkage, lr_power):
+                                            l2_shrinkage, lr_power, unique_indices=False):
   """KvVariableSparseGroupSparseApplyFtrlV2 on many (var, accum, linear) triples with two launches."""
   n = len(var_handles)
   if n < 1 or not (n == len(accum_handles) == len(linear_handles) == len(grads) == len(indices)):
@@ -651,6 +660,10 @@ def kv_multi_sparse_group_sparse_apply_ftrl(var_handles, accum_handles, linear_h
   vp = (ctypes.c_void_p * n)(*[h.ptr for h in var_handles]); ap = (ctypes.c_void_p * n)(*[h.ptr for h in accum_handles])
   lp = (ctypes.c_void_p * n)(*[h.ptr for h in linear_handles])
   sc = [ctypes.c_float(_scalar(x)) for x in (lr, l1, l2, l21, l2_shrinkage, lr_power)]
+  if unique_indices:
+    _lib.check(_lib.lib().kv_multi_apply_sparse_group_ftrl_unique(n, vp, ap, lp, _ptr_array(gr), _ptr_array(ids), ns, *sc,
+                                                                  _stream(var_handles[0])))
+    return
   _lib.check(_lib.lib().kv_multi_apply_sparse_group_ftrl_tok(n, vp, ap, lp, _ptr_array(gr), _ptr_array(ids), ns, *sc,
                                                              toks, _stream(var_handles[0])))
 

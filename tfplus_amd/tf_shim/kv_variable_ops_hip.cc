@@ -18,10 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kvhip.h"
 #include "tensorflow/core/framework/common_shape_fns.h"
+#include "tensorflow/core/framework/node_def.pb.h"
 #include "tensorflow/core/framework/op.h"
 #include "tensorflow/core/framework/op_kernel.h"
 #include "tensorflow/core/framework/resource_mgr.h"
@@ -130,6 +132,9 @@ class KvHipResource : public ResourceBase {
   const void* token_ids = nullptr;
   int64_t token_n = 0;
   uint64_t token_sum = 0;
+  Tensor token_keep;   // DEVICE_GPU: a reference to the lookup's ids tensor, held until the token is used or dropped — while
+                       // it is held the allocator cannot hand the buffer to another tensor, so "same address and length"
+                       // means "same tensor" (BFC readily reuses a freed buffer of the same size)
   // the init table as the graph gave it (KvVariableExport returns it: dynamic_save.hpp:110-118)
   std::vector<float> init_host;
   int64_t init_rows = 0;
@@ -739,6 +744,25 @@ REGISTER_OP("KvVariableGroupSparseApplyAdamV4")
     .Attr("use_locking: bool = false")
     .SetShapeFn(shape_inference::NoOutputs);
 
+// Are the `indices` of this optimizer node unique?  In an UNCHANGED reference graph they are: the processor patch
+// (python/ops/variable_scope.py:1096-1106) sends the gradient through TF-core's _deduplicate_indexed_slices, whose
+// array_ops.unique produces the node ".../Unique" that feeds input `input` here.  Then the op is ONE launch
+// (kv_apply_*_unique, include/kvhip.h).  The test is the producer's name — a heuristic; the promise it makes is guarded on
+// the device (an id listed twice raises the table's error word: the next op on the table fails with InvalidArgument
+// instead of a silent race).  TFPLUS_KV_UNIQUE_INDICES=0 never takes that path, =1 always does.
+static bool IndicesComeFromUnique(const NodeDef& def, int input) {
+  const char* e = std::getenv("TFPLUS_KV_UNIQUE_INDICES");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  if (input >= def.input_size()) return false;
+  std::string in = def.input(input);   // "scope/Unique", "scope/Unique:0"
+  const size_t colon = in.rfind(':');
+  if (colon != std::string::npos) in.resize(colon);
+  const size_t slash = in.rfind('/');
+  const std::string leaf = slash == std::string::npos ? in : in.substr(slash + 1);
+  return leaf.rfind("Unique", 0) == 0;   // Unique, Unique_1, UniqueV2 ...
+}
+
 // gradient + indices of an optimizer op on the var's ring; the var's stream carries the whole op
 struct GradIds {
   StagingRing::Slot *sg = nullptr, *si = nullptr;
@@ -775,7 +799,7 @@ static Status ReleaseGradIds(KvHipResource* var, GradIds* g) {
 template <int VERSION>
 class KvGroupAdamHipOp : public OpKernel {
  public:
-  using OpKernel::OpKernel;
+  explicit KvGroupAdamHipOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 3)) {}
   void Compute(OpKernelContext* ctx) override {
     KV_RESOURCE(ctx, 0, var);
     KV_RESOURCE(ctx, 1, slot);
@@ -787,11 +811,19 @@ class KvGroupAdamHipOp : public OpKernel {
     GradIds g;
     OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(2), ctx->input(3), &g));
     if (g.n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), reinterpret_cast<const float*>(g.sg->dev), g.si->dev,
-                                                       g.n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), VERSION,
-                                                       g.token, var->stream())));
+    if (g.token == 0 && unique_)
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_unique(var->h(), slot->h(), reinterpret_cast<const float*>(g.sg->dev), g.si->dev,
+                                                            g.n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), VERSION,
+                                                            var->stream())));
+    else
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), reinterpret_cast<const float*>(g.sg->dev), g.si->dev,
+                                                         g.n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), VERSION,
+                                                         g.token, var->stream())));
     OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
   }
+
+ private:
+  const bool unique_;
 };
 #define KV_REGISTER_APPLY(NAME, CLASS)                                                                                    \
   REGISTER_KERNEL_BUILDER(Name(NAME).Device(DEVICE_CPU).TypeConstraint<float>("T").TypeConstraint<int32>("Tindices"), CLASS);   \
@@ -815,7 +847,7 @@ REGISTER_OP("KvVariableSparseApplyAdagrad")
 
 class KvAdagradHipOp : public OpKernel {
  public:
-  explicit KvAdagradHipOp(OpKernelConstruction* c) : OpKernel(c) {
+  explicit KvAdagradHipOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 4)) {
     OP_REQUIRES_OK(c, c->GetAttr("update_slots", &update_slots_));
   }
   void Compute(OpKernelContext* ctx) override {
@@ -827,13 +859,19 @@ class KvAdagradHipOp : public OpKernel {
     GradIds g;
     OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(3), ctx->input(4), &g));
     if (g.n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
-                                                    reinterpret_cast<const float*>(g.sg->dev), g.si->dev, g.n,
-                                                    update_slots_ ? 1 : 0, g.token, var->stream())));
+    if (g.token == 0 && unique_)
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_unique(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                         reinterpret_cast<const float*>(g.sg->dev), g.si->dev, g.n,
+                                                         update_slots_ ? 1 : 0, var->stream())));
+    else
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                      reinterpret_cast<const float*>(g.sg->dev), g.si->dev, g.n,
+                                                      update_slots_ ? 1 : 0, g.token, var->stream())));
     OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
   }
 
  private:
+  const bool unique_;
   bool update_slots_ = true;
 };
 KV_REGISTER_APPLY("KvVariableSparseApplyAdagrad", KvAdagradHipOp);
@@ -858,7 +896,7 @@ REGISTER_OP("KvVariableSparseGroupSparseApplyFtrlV2")
 
 class KvGroupFtrlHipOp : public OpKernel {
  public:
-  using OpKernel::OpKernel;
+  explicit KvGroupFtrlHipOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 4)) {}
   void Compute(OpKernelContext* ctx) override {
     KV_RESOURCE(ctx, 0, var);
     KV_RESOURCE(ctx, 1, acc);
@@ -871,11 +909,20 @@ class KvGroupFtrlHipOp : public OpKernel {
     GradIds g;
     OP_REQUIRES_OK(ctx, StageGradIds(ctx, var, ctx->input(3), ctx->input(4), &g));
     if (g.n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), reinterpret_cast<const float*>(g.sg->dev),
-                                                              g.si->dev, g.n, f(5), f(6), f(7), f(8), f(9), f(10), g.token,
-                                                              var->stream())));
+    if (g.token == 0 && unique_) {
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_unique(var->h(), acc->h(), lin->h(), reinterpret_cast<const float*>(g.sg->dev),
+                                                                g.si->dev, g.n, f(5), f(6), f(7), f(8), f(9), f(10),
+                                                                var->stream())));
+    } else {
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), reinterpret_cast<const float*>(g.sg->dev),
+                                                                g.si->dev, g.n, f(5), f(6), f(7), f(8), f(9), f(10), g.token,
+                                                                var->stream())));
+    }
     OP_REQUIRES_OK(ctx, ReleaseGradIds(var, &g));
   }
+
+ private:
+  const bool unique_;
 };
 KV_REGISTER_APPLY("KvVariableSparseGroupSparseApplyFtrlV2", KvGroupFtrlHipOp);
 
@@ -987,7 +1034,7 @@ class KvDeleteHipOp : public OpKernel {
     const int64_t n = ids.NumElements();
     if (n == 0) return;
     std::lock_guard<std::mutex> l(*r->mu());
-    r->token = 0;   // rows go away: no index of an earlier batch may be taken over
+    r->token = 0; r->token_keep = Tensor();   // rows go away: no index of an earlier batch may be taken over
     StagingRing::Slot* si = nullptr;
     OP_REQUIRES_OK(ctx, r->ring()->Acquire(ids.TotalBytes(), &si));
     OP_REQUIRES_OK(ctx, StagingRing::Upload(si, ids.data(), ids.TotalBytes(), r->stream()));
@@ -1401,6 +1448,7 @@ class KvGatherGpuOp : public OpKernel {
     OP_REQUIRES_OK(ctx, FromKv(kv_gather_or_insert_tok(r->h(), ids.data(), counts ? static_cast<const int32_t*>(counts->data()) : nullptr,
                                                        n, static_cast<float*>(out->data()), &tok, st)));
     r->token = tok; r->token_ids = ids.data(); r->token_n = n; r->token_sum = 0;
+    r->token_keep = ids;   // (shares the buffer: it cannot be freed and handed to another tensor while the token lives)
   }
 };
 #define KV_REGISTER_GATHER_GPU(NAME, MODE)                                                                                \
@@ -1425,13 +1473,14 @@ static Status DeviceGradIds(KvHipResource* var, const Tensor& grad, const Tensor
   *n = ids.dim_size(0);
   *token = (var->token != 0 && var->token_n == *n && var->token_ids == ids.data()) ? var->token : 0;
   var->token = 0;   // one apply per lookup: a second optimizer op on the same ids rebuilds the index
+  var->token_keep = Tensor();
   return OkStatus();
 }
 
 template <int VERSION>
 class KvGroupAdamGpuOp : public OpKernel {
  public:
-  using OpKernel::OpKernel;
+  explicit KvGroupAdamGpuOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 3)) {}
   void Compute(OpKernelContext* ctx) override {
     KV_RESOURCE(ctx, 0, var);
     KV_RESOURCE(ctx, 1, slot);
@@ -1444,10 +1493,18 @@ class KvGroupAdamGpuOp : public OpKernel {
     kv_batch_token_t token = 0;
     OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(2), ctx->input(3), &n, &token));
     if (n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), static_cast<const float*>(ctx->input(2).data()),
-                                                       ctx->input(3).data(), n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11),
-                                                       f(12), VERSION, token, TfStream(ctx))));
+    if (token == 0 && unique_)
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_unique(var->h(), slot->h(), static_cast<const float*>(ctx->input(2).data()),
+                                                            ctx->input(3).data(), n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11),
+                                                            f(12), VERSION, TfStream(ctx))));
+    else
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_group_adam_tok(var->h(), slot->h(), static_cast<const float*>(ctx->input(2).data()),
+                                                         ctx->input(3).data(), n, f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11),
+                                                         f(12), VERSION, token, TfStream(ctx))));
   }
+
+ private:
+  const bool unique_;
 };
 #define KV_GPU_ADAM_HOST .HostMemory("var").HostMemory("m_v_linear").HostMemory("lr").HostMemory("beta1_power")           \
       .HostMemory("beta2_power").HostMemory("beat1").HostMemory("beta2").HostMemory("epsilon").HostMemory("l1")          \
@@ -1461,7 +1518,9 @@ KV_REGISTER_APPLY_GPU("KvVariableGroupSparseApplyAdamV4", KV_GPU_ADAM_HOST, KvGr
 
 class KvAdagradGpuOp : public OpKernel {
  public:
-  explicit KvAdagradGpuOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("update_slots", &update_slots_)); }
+  explicit KvAdagradGpuOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 4)) {
+    OP_REQUIRES_OK(c, c->GetAttr("update_slots", &update_slots_));
+  }
   void Compute(OpKernelContext* ctx) override {
     KV_RESOURCE(ctx, 0, var);
     KV_RESOURCE(ctx, 1, acc);
@@ -1472,12 +1531,18 @@ class KvAdagradGpuOp : public OpKernel {
     kv_batch_token_t token = 0;
     OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(3), ctx->input(4), &n, &token));
     if (n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
-                                                    static_cast<const float*>(ctx->input(3).data()), ctx->input(4).data(), n,
-                                                    update_slots_ ? 1 : 0, token, TfStream(ctx))));
+    if (token == 0 && unique_)
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_unique(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                         static_cast<const float*>(ctx->input(3).data()), ctx->input(4).data(), n,
+                                                         update_slots_ ? 1 : 0, TfStream(ctx))));
+    else
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_adagrad_tok(var->h(), acc->h(), ctx->input(2).scalar<float>()(),
+                                                      static_cast<const float*>(ctx->input(3).data()), ctx->input(4).data(), n,
+                                                      update_slots_ ? 1 : 0, token, TfStream(ctx))));
   }
 
  private:
+  const bool unique_;
   bool update_slots_ = true;
 };
 #define KV_GPU_ADAGRAD_HOST .HostMemory("var").HostMemory("accum").HostMemory("lr")
@@ -1485,7 +1550,7 @@ KV_REGISTER_APPLY_GPU("KvVariableSparseApplyAdagrad", KV_GPU_ADAGRAD_HOST, KvAda
 
 class KvGroupFtrlGpuOp : public OpKernel {
  public:
-  using OpKernel::OpKernel;
+  explicit KvGroupFtrlGpuOp(OpKernelConstruction* c) : OpKernel(c), unique_(IndicesComeFromUnique(c->def(), 4)) {}
   void Compute(OpKernelContext* ctx) override {
     KV_RESOURCE(ctx, 0, var);
     KV_RESOURCE(ctx, 1, acc);
@@ -1499,10 +1564,19 @@ class KvGroupFtrlGpuOp : public OpKernel {
     kv_batch_token_t token = 0;
     OP_REQUIRES_OK(ctx, DeviceGradIds(var, ctx->input(3), ctx->input(4), &n, &token));
     if (n == 0) return;
-    OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), static_cast<const float*>(ctx->input(3).data()),
-                                                              ctx->input(4).data(), n, f(5), f(6), f(7), f(8), f(9), f(10), token,
-                                                              TfStream(ctx))));
+    if (token == 0 && unique_) {
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_unique(var->h(), acc->h(), lin->h(), static_cast<const float*>(ctx->input(3).data()),
+                                                                ctx->input(4).data(), n, f(5), f(6), f(7), f(8), f(9), f(10),
+                                                                TfStream(ctx))));
+    } else {
+      OP_REQUIRES_OK(ctx, FromKv(kv_apply_sparse_group_ftrl_tok(var->h(), acc->h(), lin->h(), static_cast<const float*>(ctx->input(3).data()),
+                                                                ctx->input(4).data(), n, f(5), f(6), f(7), f(8), f(9), f(10), token,
+                                                                TfStream(ctx))));
+    }
   }
+
+ private:
+  const bool unique_;
 };
 #define KV_GPU_FTRL_HOST .HostMemory("var").HostMemory("accum").HostMemory("linear").HostMemory("lr").HostMemory("l1")    \
       .HostMemory("l2").HostMemory("l21").HostMemory("l2_shrinkage").HostMemory("lr_power")
