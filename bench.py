@@ -618,11 +618,11 @@ def main():
   traffic, traffic_src, traffic_raw = None, None, None
   tj = None
   try:
-    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_traffic.json")))
+    tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_traffic.json")))
     if tj.get("workload") == [K, N, D, args.zipf] and dom in tj["kernels"]:
       traffic = tj["kernels"][dom]["hbm_bytes"]
       traffic_raw = tj["kernels"][dom]["fetch_size_kib_raw"] * 1024 + tj["kernels"][dom]["write_bytes"]
-      traffic_src = ("profiles/r04_traffic.json, a COMMITTED profile of this command taken on the builder's box (PMC counters "
+      traffic_src = ("profiles/r05_traffic.json, a COMMITTED profile of this command taken on the builder's box (PMC counters "
                      "cannot be read from inside this process; not measured in this run): " + tj["source"])
     else:
       tj = None
@@ -719,6 +719,8 @@ def main():
                                   "tests/_reorder.py (typically a few 1e-6 relative), bit-reproducible in deterministic mode")
   if not shard_path and not args.no_extras:
     res.update(extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state))
+    if tj and "apply_unique" in tj["kernels"]:      # HBM bytes of one k_uapply launch (committed profile, as roofline.traffic)
+      res["op_boundary"]["traffic"] = tj["kernels"]["apply_unique"]["hbm_bytes"]
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:

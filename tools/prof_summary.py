@@ -1,10 +1,10 @@
 """Condenses a scripts_prof.sh output directory into the per-kernel table kept under profiles/."""
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
-KEYS = {"k_ltile<": "lookup_tile  k_ltile", "k_part2<0>": "lookup_part  k_part2<LOOKUP>", "k_part2<6>": "apply_index  k_part2<APPLYIDX>",
-        "k_tsum<": "apply_tsum   k_tsum", "k_apply2<0": "apply_sorted k_apply2<ADAM_V4>", "k_copy<": "lookup_copy  k_copy",
-        "k_papply<0": "apply_sorted k_papply<ADAM_V4>", "k_lrows<": "lookup_rows  k_lrows", "k_ltsum<": "apply_tile   k_ltsum",
-        "k_tile<": "old_tile     k_tile (sorted-position pipeline: dims outside the entry-list pipeline, here the slot table's build)", "k_part_keys<0>": "old_part     k_part_keys<LOOKUP>",
+KEYS = {"k_ltile<": "lookup_tile  k_ltile", "k_part2": "lookup_part  k_part2 (a lookup's bookkeeping when no apply takes it over)",
+        "k_tsum<": "apply_tsum   k_tsum", "k_papply<0": "apply_sorted k_papply<ADAM_V4>", "k_ltsum<": "apply_tile   k_ltsum",
+        "k_uapply<0": "apply_unique k_uapply<ADAM_V4> (unique ids + pre-summed rows: the reference's op boundary)",
+        "k_tile<": "old_tile     k_tile (sorted-position pipeline: dims outside the entry-list pipeline)", "k_part_keys<0>": "old_part     k_part_keys<LOOKUP>",
         "k_gather<8, true>": "lookup_order k_gather<8,ORDER>", "k_part_keys<6>": "old_index    k_part_keys<APPLYIDX>",
         "k_order": "apply_index  k_order",
         "k_apply<1, 0": "apply_sorted k_apply<APPLY,ADAM_V4>", "k_apply_fin<1, 0": "apply_span   k_apply_fin<APPLY,ADAM_V4>",
