@@ -586,7 +586,7 @@ def main():
         "apply_index": N * 8 + Ub * 16,
         "apply_tsum": (N - S1_mean) * 4 * D,                   # k_tsum: gradient rows of ids repeated inside their tile
         "apply_tile": N * 8 + (N - S1_mean) * 4 * D,           # k_ltsum: the ids again (tile pass) + those gradient rows
-        "apply_sorted": S1_mean * 4 * D + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,   # k_papply / k_apply2: the other gradient rows + state r/w
+        "apply_sorted": S1_mean * 4 * D + Ub * (16 + 4 * 4 * D) + Ub * 4 * 4 * D,   # k_papply: the other gradient rows + state r/w
         "apply_span": 0,
     }
   else:

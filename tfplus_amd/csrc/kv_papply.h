@@ -1,9 +1,9 @@
 // kv_papply.h — the partition pass and the optimizer apply of a batch in ONE launch (included after kv_fused.h).
 //
-// k_part2 + k_apply2 (kv_fused.h) hand the batch from one to the other through global memory: key records, the entry
-// list, work items, a dense item directory — and through two dependent chains (directory -> entries -> RowMeta;
-// item -> record -> rows) during which HBM idles, 28 + 46 us at configs[1] for 112 MB of state traffic.  Here the
-// block that owns a hash partition keeps what it learned in LDS and goes on to update its keys itself:
+// The round-3 kernels (a partition pass, then an apply over key records) handed the batch from one to the other through
+// global memory — key records, the entry list, work items, a dense item directory — and through two dependent chains
+// during which HBM idled (28 + 46 us at configs[1] for 112 MB of state traffic).  Here the block that owns a hash
+// partition keeps what it learned in LDS and goes on to update its keys itself:
 //
 //   directory of the partition's segment in every tile -> its entries {key, counts, row word, hint, source}, all loads
 //   in flight -> LDS hash of the distinct keys (summed frequency count, row, hint, entries) -> block scans: every
@@ -11,7 +11,7 @@
 //   sources filed -> the waves take items from an LDS ticket: a hot key (more than LCOLD sources) per wave, or a batch
 //   of 64 / LPR cold keys, one per lane group: sources (gradient rows, or tile sums of k_tsum), the var row and its
 //   record, the hinted slot row and its record in ONE round trip -> the lookup's bookkeeping for the key (frequency
-//   word, day, under-threshold flag, a new key's record and row: what k_part2<LOOKUP> does) and the fused row update
+//   word, day, under-threshold flag, a new key's record and row: what k_part2 does alone) and the fused row update
 //   (opt_core), both by the key's single owner.
 //
 // No key record, entry list, work item or directory is written; the var record is read once for both purposes; a key
@@ -29,7 +29,7 @@
 #pragma once
 
 enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2, PA_UNIQUE = 3, PA_DEDUP = 4 };
-constexpr int PA_NOAPPLY = 0x100;   // flag: no update — the partition pass of a lookup that no apply followed (what k_part2<LOOKUP> does)
+constexpr int PA_NOAPPLY = 0x100;   // flag: no update phase (the sharded route's PA_UNIQUE pass; a lookup's pass alone is k_part2's)
 #ifndef KV_PA_WAVES
 #define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
 #endif
@@ -575,7 +575,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
         }
       }
 
-      // ---- the update (k_apply2's tail: one copy for both kinds of item) ------------------------------------------------
+      // ---- the update (one copy for both kinds of item) ------------------------------------------------------------------
       const bool fin_live = live && errflag == 0u && !no_apply;
       const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), row | (vnew ? NEW_BIT : 0u), hint);
       bool general = fin_live;

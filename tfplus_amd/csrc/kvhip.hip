@@ -7,21 +7,23 @@
 //                           home of the one key that equals the EMPTY sentinel.
 //   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32 and RowMeta[r] 16 B {int64 key,
 //            u32 freq = (day << 16) | saturating u16 frequency, u8 flags (bit0 blacklist, bit1
-//            under_threshold, bit2 under_threshold stale, bit3 released by Delete)}.  Row ids are
+//            under_threshold, bit2 under_threshold stale, bit3 released by Delete), u8 delta-list bits,
+//            u16 stamp (serial of the last unique-ids apply that updated the row)}.  Row ids are
 //            dense (bump allocated; rows released by Delete are recycled from a device free
 //            list), row 0 is a permanent all-zero row (misses / nothing).
-//   workspace per-batch index (ent_key / ent_a / ent_b / ent_base, toff, slot_rank, order, key lists, chunk
-//            partials): plain stores only, rewritten by every op — nothing to clean.
+//   workspace per-batch index (ent_key / ent_a / ent_b / ent_base / ent_rec, toff, mrow, epart, order; the
+//            sorted-position kernels' lists in the same buffers): plain stores only, rewritten by every
+//            op — nothing to clean.
 //
-// Kernel pipeline (kv_kernels.h explains why; DESIGN.md has the byte accounting):
-//   lookup : k_tile              LDS dedup per 2048-id tile, entries sorted by hash partition
-//            k_part_keys<LOOKUP> one block owns a partition's keys: find / insert, frequency, flags, the keys'
-//                                places in the sorted position list, their records and work items
-//            k_gather<ORDER>     output rows; files every position in the sorted list; item directory
-//   apply  : [k_tile, k_part_keys<APPLYIDX>, k_order unless the batch token names the lookup's index]
-//            k_apply<OPT>        hot chunks (128 rows of one key) and cold batches (one key per lane group):
-//                                segmented sum over the sorted positions + fused row update
-//            k_apply_fin<OPT>    keys that span several chunks
+// Kernel pipelines (DESIGN.md section 3 has the byte accounting):
+//   entry-list kernels (kv_fused.h, kv_papply.h, kv_uapply.h; dims that are multiples of 4 up to 256):
+//     lookup : k_ltile            tile pass (LDS dedup, winner probes / inserts, entries by hash partition) + output rows
+//              k_part2            the lookup's bookkeeping alone (deferred when a batch token is handed out)
+//     apply  : k_tsum + k_papply  tile sums, then partition pass + bookkeeping + fused update in one launch
+//              k_ltsum + k_papply the same for ids the table has not indexed (no token)
+//              k_uapply           ids promised unique + pre-summed rows: one launch
+//   sorted-position kernels (kv_kernels.h; every other dim, kv_unique / dedup / scatter / marks / sparse lookup):
+//     k_tile, k_part_keys<MODE>, k_gather<ORDER> / k_order, k_apply<OPT>, k_apply_fin<OPT>
 //   sharded: kv_comm_* (RCCL by dlopen, grouped send / recv), kv_shard_* (route / serve / finish phases)
 //   many tables in one launch: the *_multi entry points (grid.y = table)
 //
