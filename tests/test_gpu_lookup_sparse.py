@@ -58,7 +58,7 @@ def _ragged(rng, nseg, maxlen, keyspace):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D", [32, 8, 5, 256])
+@pytest.mark.parametrize("D", [32, 8, 5, 256, 12, 100])
 @pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_lookup_sparse_matches_oracle(ops, D, combiner, weighted):
@@ -77,6 +77,35 @@ def test_lookup_sparse_matches_oracle(ops, D, combiner, weighted):
   k, v = ops.read_kv_variable_op_v2(h)
   assert dict(zip(k.cpu().numpy().tolist(), map(bytes, v.cpu().numpy()))) == \
       {kk: bytes(vv) for kk, vv in o.as_dict().items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,n", [(32, 3_000_000), (20, 700_001)])
+def test_lookup_sparse_large_batch_cold_then_warm(ops, D, n):
+  """One call over more ids than the sorted-position kernels take (2^21), every key new in the first call — a key
+  repeated in several tiles is inserted by one of them and the others find its row through the index — then the same
+  batch again, found.  Against the rows read back + a float64 segment sum; frequency = one per distinct key and call."""
+  dev = torch.device("cuda", 0)
+  gen = torch.Generator(device=dev).manual_seed(D)
+  h = ops.kv_variable([D], capacity_hint=2 * n)
+  ops.kv_set_seed(h, 11)
+  ops.init_kv_variable_v2(h, torch.randn(257, D, device=dev, generator=gen))
+  ids = torch.randint(-(1 << 40), 1 << 40, (n,), device=dev, generator=gen)
+  ids[1::3] = ids[0::3][: ids[1::3].numel()].flip(0)          # a third of the positions repeat a key from far away
+  seg = (torch.arange(n, device=dev) // 3).to(torch.int64)
+  nseg = (n + 2) // 3
+  w = torch.rand(n, device=dev, generator=gen) + 0.5
+  distinct = int(torch.unique(ids).numel())
+  for call in range(2):
+    got = ops.kv_variable_lookup_sparse(h, ids, seg, w, nseg, "sum", count_occurrences=False)
+    assert ops.kv_variable_size_v2(h) == distinct and ops.kv_variable_frequency(h) == distinct * (call + 1)
+    rows = torch.cat([ops.kv_variable_gather_or_zeros_v2(h, ids[i:i + (1 << 20)]) for i in range(0, n, 1 << 20)])
+    want = torch.zeros((nseg, D), device=dev, dtype=torch.float64).index_add_(0, seg, rows.double() * w.double()[:, None])
+    torch.testing.assert_close(got.double(), want, rtol=2e-6, atol=1e-6)
+  from tfplus_amd import _lib
+  with pytest.raises(_lib.InvalidArgumentError):             # the limit of one call is stated, not silently chunked
+    big = torch.zeros((1 << 23) + 1, dtype=torch.int64, device=dev)
+    ops.kv_variable_lookup_sparse(h, big, big, None, 1, "sum")
 
 
 @pytest.mark.gpu

@@ -638,6 +638,64 @@ __global__ void __launch_bounds__(TB) k_shard_finish_multi(const FinishDesc* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// k_seg_combine_e: embedding_lookup_sparse's combiner over the tiles' entries
+// ------------------------------------------------------------------------------------------
+// out[s] = combine_j( w_j * rows[row(id_j)] ) over segment s's positions in position order (tf.segment_sum's order;
+// embedding_ops.py:395-441); position j -> its entry in its tile (pos_ent, filed by k_ltile) -> the entry's row word.  A
+// key this batch inserted in ANOTHER tile may not know its row yet (NEW_BIT, row part 0): it is probed — the partition
+// pass in front of this kernel has published every new row.  VQ lanes (power of two >= dim / 4) per segment, SU
+// positions of a segment in flight; the sums are taken in position order whatever SU is.
+template <int VQ>
+__global__ void __launch_bounds__(TB) k_seg_combine_e(TableDev t, const unsigned short* __restrict__ pos_ent,
+                                                      const unsigned* __restrict__ ent_b, const long long* __restrict__ ent_key,
+                                                      const unsigned* __restrict__ off, const float* __restrict__ wts,
+                                                      long long nseg, int combiner, float* __restrict__ out) {
+  const int D4 = t.dim >> 2;
+  const int v = threadIdx.x % VQ;
+  const bool vlive = v < D4;
+  const int vv = vlive ? v : 0;
+  const long long g0 = ((long long)blockIdx.x * TB + threadIdx.x) / VQ;
+  const long long gstride = (long long)gridDim.x * TB / VQ;
+  constexpr int SU = 4;
+  for (long long sgi = g0; sgi < nseg; sgi += gstride) {
+    const unsigned lo = off[sgi], hi = off[sgi + 1];
+    float wsum = 0.f, w2 = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned j = lo; j < hi; j += SU) {
+      unsigned e[SU], r[SU];
+      float wj[SU];
+      float4 x[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const bool ok = j + u < hi;
+        const unsigned pe = ok ? (unsigned)pos_ent[j + u] : 0xFFFFu;
+        e[u] = pe != 0xFFFFu ? ((j + u) / (unsigned)TILE) * (unsigned)TILE + pe : 0xFFFFFFFFu;
+        wj[u] = ok ? (wts ? wts[j + u] : 1.f) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) r[u] = e[u] != 0xFFFFFFFFu ? ent_b[e[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (__builtin_expect((r[u] & NEW_BIT) != 0u && (r[u] & ROW_MASK) == 0u, 0)) r[u] = table_find(t, ent_key[e[u]]);
+        r[u] &= ROW_MASK;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) x[u] = reinterpret_cast<const float4*>(row_ptr(t, r[u]))[vv];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (!(j + u < hi)) continue;
+        acc.x += x[u].x * wj[u]; acc.y += x[u].y * wj[u]; acc.z += x[u].z * wj[u]; acc.w += x[u].w * wj[u];
+        wsum += wj[u]; w2 += wj[u] * wj[u];
+      }
+    }
+    float den = 1.f;
+    if (combiner == 1) den = wsum; else if (combiner == 2) den = sqrtf(w2);
+    if (combiner != 0 && (wts || hi > lo)) { acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den; }
+    if (vlive) reinterpret_cast<float4*>(out + (size_t)sgi * t.dim)[v] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_part2: the partition pass over entries that already carry their rows
 // ------------------------------------------------------------------------------------------
 // seg_directory of kv_kernels.h over the tile-major toff (toff[tile][0..P]): thread k takes tiles k, k + T, ... — column p and

@@ -21,9 +21,10 @@
 // mode: PA_LOOKUP   the batch's training lookup left its partition pass pending: FindOrInsert bookkeeping, then apply
 //       PA_APPLYIDX the optimizer meets the ids first (FindOrInsertUnsafe: a new key gets frequency word 1, unfiltered)
 //       PA_NONE     the entries of a batch whose bookkeeping is done (a second optimizer on the same token)
-//       PA_UNIQUE   no table (the sharded route's index of a rank's local ids): the distinct ids get numbers — partition
-//                   base + local number, sparse — and go to out_keys / out_counts (occurrences); every entry learns its
-//                   id's number (ent_b).  No apply phase.
+//       PA_UNIQUE   no table (the sharded route's index of a rank's local ids; kv_unique / kv_dedup_segment_sum): the distinct
+//                   ids get numbers — sparse_unique: partition base + local number, with gaps; else dense, from one counter
+//                   (ctr[0], an atomic per block) — and go to out_keys / out_counts (occurrences; dense: the summed counts,
+//                   saturating); every entry learns its id's number (ent_b).  No apply phase.
 //       PA_DEDUP    the gradient rows of the batch PA_UNIQUE numbered are summed per distinct id and written to
 //                   out_sum[out_map[number]] — the records the ids were sent in — instead of updating rows
 #pragma once
@@ -43,13 +44,12 @@ constexpr int PA_NOAPPLY = 0x100;   // flag: no update phase (the sharded route'
 //   TBP = 256: 1024 hash slots, 1536 sources — more partitions than that, the deterministic mode, the batched ops
 template <int TBP> struct PaShape { static constexpr int HSK = TBP >= 512 ? 2048 : 1024, LSRC = TBP >= 512 ? 2048 : 1536; };
 
-template <int OPT, int V, int LPR, int K, int TBP>
+// FM: the mode when the kernel is compiled for one (PA_UNIQUE has its own, k_papply_uniq: numbering only, no row geometry,
+// none of the apply's registers; the kernels of the other modes carry none of its code), -1: the mode is an argument
+template <int OPT, int V, int LPR, int K, int TBP, int FM = -1>
 __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, const int mode_) {
-#ifdef KV_PA_X_MODE
-  constexpr int mode = KV_PA_X_MODE;
-#else
-  const int mode = mode_ & 0xFF;
-#endif
+  constexpr bool UQ = FM == PA_UNIQUE;
+  const int mode = FM >= 0 ? FM : (mode_ & 0xFF);
   const bool no_apply = (mode_ & PA_NOAPPLY) != 0;   // the lookup's bookkeeping alone (no gradient is given)
   constexpr int HSK = PaShape<TBP>::HSK;
   constexpr int PA_LSRC = PaShape<TBP>::LSRC;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   __shared__ unsigned short ulist[UCAPK + 8];
   __shared__ unsigned short kord[UCAPK + 8];   // key slots: hot keys, then 1 / 2 / 3.. sources
   __shared__ unsigned lsrc[PA_LSRC];
-  __shared__ unsigned lnu, lsent, lnext, lkeys;
+  __shared__ unsigned lnu, lsent, lnext, lkeys, lbase;
   __shared__ unsigned rh[MAXW], rbase[MAXW];   // PA_UNIQUE with a route: the round's ids per owner, their first records
   __shared__ unsigned wtot[8];
   __shared__ unsigned stkR[24], stkr[24];
@@ -142,7 +142,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
         }
         if (mode == PA_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16);
-        else if (mode == PA_UNIQUE) atomicAdd(&hval[h], ea[k] & 0xFFFFu);   // occurrences of the id in the batch
+        else if (UQ) atomicAdd(&hval[h], a.sparse_unique ? (ea[k] & 0xFFFFu) : (ea[k] >> 16));   // occurrences of the id in the batch (dense: its summed counts)
         atomicAdd(&hocc[h], 1u);
         atomicMax(&hrow[h], rw[k]);
         if (hi[k]) atomicMax(&hhint[h], hi[k]);
@@ -155,7 +155,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     const unsigned nu = lnu;
     const unsigned lkeys_before = lkeys;   // distinct keys of the partition's earlier rounds (read before the barrier below lets thread 0 add)
     __syncthreads();
-    if (tid == 0) lkeys += nu;
+    if (tid == 0) {
+      lkeys += nu;
+      // dense numbers (kv_unique / kv_dedup_segment_sum): the round's keys take the next nu of one counter
+      if (UQ && !a.sparse_unique) lbase = atomicAdd(&w.ctr[0], nu);
+    }
 
     // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
     constexpr int PERU = (UCAPK + TBP - 1) / TBP;
@@ -194,17 +198,18 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           kord[rank] = (unsigned short)s;
           hocc[s] = run; run += kcnt[q];
           hcn[s] = (unsigned short)kcnt[q];
-          if (mode == PA_UNIQUE) {   // the id's number: the partition's entries before it bound the numbers before it
-            const unsigned num = pbase + lkeys_before + u;
+          if (UQ) {   // the id's number: the partition's entries before it bound the numbers before it
+            const unsigned num = a.sparse_unique ? pbase + lkeys_before + u : lbase + u;   // (lbase: written before the scans' barriers)
             hrow[s] = num;
             a.out_keys[num] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
-            a.out_counts[num] = (int)hval[s];
+            if (a.sparse_unique) a.out_counts[num] = (int)hval[s];
+            else if (a.out_counts) a.out_counts[num] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
           }
         }
       }
     }
     __syncthreads();
-    if (mode == PA_UNIQUE && a.route_world > 0) {
+    if (UQ && a.route_world > 0) {
       // ---- the sharded route: every distinct id to its owner's segment of the send buffer.  The block counts its ids per
       //      owner in LDS and reserves their records with ONE atomic per owner (what k_owner_route_fixed does per 1024 ids)
       if (tid < MAXW) rh[tid] = 0;
@@ -271,14 +276,14 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             if (wave == wv && valid) { pos = hocc[h] + within; atomicAdd(&hocc[h], 1u); }
             __syncthreads();
           }
-          if (valid) { file(pos, w.ent_rec[ge]); if (mode == PA_UNIQUE) w.ent_b[ge] = hrow[h]; }
+          if (valid) { file(pos, w.ent_rec[ge]); if (UQ) w.ent_b[ge] = hrow[h]; }
         }
       } else if (cached) {
 #pragma unroll
         for (int k = 0; k < EB; ++k)
           if (cin[k]) {
             file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
-            if (mode == PA_UNIQUE) w.ent_b[seg_entry(tpre, tstart, NT, (unsigned)(k * TBP + tid))] = hrow[cslot[k]];   // the entry learns its id's number
+            if (UQ) w.ent_b[seg_entry(tpre, tstart, NT, (unsigned)(k * TBP + tid))] = hrow[cslot[k]];   // the entry learns its id's number
           }
       } else {
         for (unsigned x = tid; x < E; x += TBP) {
@@ -289,7 +294,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           bool first;
           const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
           file(atomicAdd(&hocc[h], 1u), src);
-          if (mode == PA_UNIQUE) w.ent_b[ge] = hrow[h];
+          if (UQ) w.ent_b[ge] = hrow[h];
         }
       }
     }
@@ -334,7 +339,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 #ifdef KV_PA_X_NOAPPLY
     return false;
 #endif
-    if (mode == PA_UNIQUE) return false;   // (block-uniform) numbering only
+    if (UQ) return false;   // (block-uniform) numbering only
 #ifdef KV_STAMPS
     unsigned long long st_t0 = wall_clock64(), st_hot = 0, st_cold = 0, st_nh = 0, st_nc = 0;
 #endif
@@ -686,16 +691,26 @@ __device__ __forceinline__ void papply_route_tail(const PartArgs& a, const int m
 template <int OPT, int V, int LPR, int K, int TBP>
 __global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply(WsDev w, PartArgs a, int mode) {
   papply_body<OPT, V, LPR, K, TBP>(w, a, mode);
-  papply_route_tail(a, mode, gridDim.x);
 }
 
 // many tables in one launch (blockIdx.y = table; arguments from the MultiDesc array; grid.x = the largest table's partitions)
+// PA_UNIQUE alone (the sharded route's index, kv_unique, kv_dedup_segment_sum's numbering)
+template <int TBP>
+__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_uniq(WsDev w, PartArgs a, int mode) {
+  papply_body<OPT_ADAM_V4, 4, 1, 1, TBP, PA_UNIQUE>(w, a, mode);
+  papply_route_tail(a, mode, gridDim.x);
+}
+__global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_uniq_multi(const MultiDesc* __restrict__ descs, int mode) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  papply_body<OPT_ADAM_V4, 4, 1, 1, 256, PA_UNIQUE>(m.w, m.a, mode);
+  papply_route_tail(m.a, mode, m.w.P);   // (the table's own blocks: the sharded route of several tables in one launch)
+}
 template <int OPT, int V, int LPR, int K>
 __global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_multi(const MultiDesc* __restrict__ descs, int mode) {
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
   papply_body<OPT, V, LPR, K, 256>(m.w, m.a, mode);
-  papply_route_tail(m.a, mode, m.w.P);   // (the table's own blocks: the sharded route of several tables in one launch)
 }
 
 // dispatch on the row geometry (the dims fused_ok() admits: float4 rows, a power-of-two lane count); one block per
@@ -704,8 +719,17 @@ __global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_multi(const MultiDe
 template <int OPT>
 int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = pa.tv.dim;
-  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
   const size_t sh = (size_t)wd.ntiles * 4 + 32;
+  if ((mode & 0xFF) == PA_UNIQUE) {   // numbering only: one kernel whatever the dim (instantiated with the GroupAdam unit)
+    if constexpr (OPT == OPT_ADAM_V4) {
+      if (md) k_papply_uniq_multi<<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);
+      else if (wd.P <= 512u && !pa.det) k_papply_uniq<512><<<(int)wd.P, 512, sh, s>>>(wd, pa, mode);
+      else k_papply_uniq<256><<<(int)wd.P, 256, sh, s>>>(wd, pa, mode);
+      return KV_OK;
+    }
+    return KV_UNIMPLEMENTED;
+  }
+  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
 #define KV_PA(V, LPR, K)                                                     \
   do {                                                                       \
     if (md) k_papply_multi<OPT, V, LPR, K><<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);   \

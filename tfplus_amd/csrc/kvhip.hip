@@ -682,6 +682,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
 }
 
 bool fused_ok(int D);
+bool fused_off();
 
 // The sharded owner ops (kv_shard_lookup_serve / kv_shard_apply_serve) read a rank's OWN exchange segment where it was
 // written: records [lo, lo + len) of the buffers the calling thread's next op on `table` reads come from `ids` / `grad`
@@ -845,9 +846,12 @@ void launch_order(const TableDev& td, const WsDev& wd, long long n, hipStream_t 
 constexpr long long FUSED_MAX_N = 1ll << 23;
 // dims it serves: every multiple of 4 up to 256 (rows of dim / 4 float4; a row's lane group is the next power of two,
 // the lanes past the row's end masked: dims 12, 20, 100 ... run the same kernels as 16, 32, 128)
-bool fused_ok(int D) {
+bool fused_off() {
   static const bool off = [] { const char* e = getenv("KV_NO_FUSED"); return e && atoi(e) != 0; }();   // A/B against the sorted-position pipeline
-  if (off || (D & 3) != 0) return false;
+  return off;
+}
+bool fused_ok(int D) {
+  if (fused_off() || (D & 3) != 0) return false;
   const int q = D / 4;
   return q >= 1 && q <= 64;
 }
@@ -886,9 +890,11 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
 #undef KV_LT2
 }
 // the table-less tile pass of the sharded route (int64 ids): entries, mrow, every position's entry number
-void launch_ltile_notable(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, long long n, hipStream_t s) {
-  k_ltile<long long, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, nullptr, n,
-                                                                                          t->deterministic ? 1 : 0, nullptr);
+void launch_ltile_notable(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, long long n, hipStream_t s,
+                          const int* counts = nullptr, bool int32_ids = false) {
+  const int det = t->deterministic ? 1 : 0;
+  if (int32_ids) k_ltile<int, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const int*)ids, counts, n, det, nullptr);
+  else k_ltile<long long, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, counts, n, det, nullptr);
 }
 // the bookkeeping of a training lookup that no apply takes over (k_part2); md: `ntab` tables in one launch
 void launch_part2(const WsDev& wd, const PartArgs& pa, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
@@ -1481,7 +1487,9 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
     return fail(KV_INVALID_ARGUMENT, "combiner must be one of 'mean', 'sqrtn' or 'sum'");  // embedding_ops.py:345
   if (segment_dtype != KV_DT_INT32 && segment_dtype != KV_DT_INT64)
     return fail(KV_INVALID_ARGUMENT, "segment ids must be int32 or int64");
-  if (n < 0 || n > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "sp_ids: %lld values (at most 2^21 per call)", (long long)n);
+  const bool fused = fused_ok(t->dim);   // (dim is fixed at creation: readable without the lock)
+  if (n < 0 || n > (fused ? FUSED_MAX_N : (1ll << 21)))
+    return fail(KV_INVALID_ARGUMENT, "sp_ids: %lld values (at most 2^%d per call)", (long long)n, fused ? 23 : 21);
   if (num_segments < 0 || num_segments > (1ll << 31) - 2) return fail(KV_INVALID_ARGUMENT, "bad num_segments");
   if (num_segments == 0) return KV_OK;
   if (!out || (n > 0 && (!ids || !segment_ids))) return fail(KV_INVALID_ARGUMENT, "ids / segment ids / output pointer is null");
@@ -1506,8 +1514,14 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
     if ((rc = regrow(&ws.seg_off, (size_t)(want + 1)))) return rc;
     ws.seg_cap = want;
   }
+  if (fused && ws.pos_cap < n) {   // every position's entry in its tile (k_ltile files it for the combiner)
+    HIP_TRY(hipStreamSynchronize(s));
+    ws.pos_cap = 0;
+    if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
+    ws.pos_cap = std::max<long long>(n, ws.cap_n);
+  }
   const TableDev td = dev_view(t);
-  const WsDev wd = ws_view(t, n);
+  WsDev wd = ws_view(t, n);
   PartArgs pa{};
   pa.tv = td; pa.ts0 = td; pa.ts1 = td;
   pa.day = today(t);
@@ -1515,11 +1529,16 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   pa.det = t->deterministic ? 1 : 0;
   pa.n = n;
   t->batch_serial = 0;
-  {
-    ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
-    launch_tile<false>(t, wd, ids, nullptr, n, s);
-  }
-  {
+  if (fused) {
+    // the entry-list kernels: tile pass without rows (entries, every position's entry), the lookup's bookkeeping (which
+    // also publishes the rows of new keys), then the combiner reads position -> entry -> row
+    wd.pos_ent = ws.pos_ent;
+    if ((rc = fused_lookup_pass(t, wd, pa, ids, nullptr, n, -1, nullptr, s, false))) return rc;
+  } else {
+    {
+      ProfScope ps(t, KV_PROF_LOOKUP_TILE, s);
+      launch_tile<false>(t, wd, ids, nullptr, n, s);
+    }
     ProfScope ps(t, KV_PROF_LOOKUP_PART, s);
     launch_part_keys<MODE_LOOKUP>(wd, pa, s);
   }
@@ -1528,6 +1547,18 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
     k_seg_offsets<int><<<nblocks(n + 1, TB, 2048), TB, 0, s>>>((const int*)segment_ids, n, num_segments, ws.seg_off);
   else
     k_seg_offsets<long long><<<nblocks(n + 1, TB, 2048), TB, 0, s>>>((const long long*)segment_ids, n, num_segments, ws.seg_off);
+  if (fused) {
+    const int ql = row_lanes(D);
+    const int grid = nblocks(num_segments * ql, TB, 8192);
+#define KV_SCE(VQ) k_seg_combine_e<VQ><<<grid, TB, 0, s>>>(td, ws.pos_ent, wd.ent_b, wd.ent_key, ws.seg_off, weights, num_segments, combiner, out)
+    switch (ql) {
+      case 1: KV_SCE(1); break;   case 2: KV_SCE(2); break;   case 4: KV_SCE(4); break;   case 8: KV_SCE(8); break;
+      case 16: KV_SCE(16); break; case 32: KV_SCE(32); break; default: KV_SCE(64); break;
+    }
+#undef KV_SCE
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   const int q = (D % 4 == 0) ? D / 4 : 0;
   const bool vec = q > 0 && (q & (q - 1)) == 0 && q <= 64;
   const int grid = nblocks(num_segments * (vec ? q : 1), TB, 8192);
@@ -2365,13 +2396,41 @@ int kv_prepare_capture(kv_handle_t t, int64_t max_new_ids, kv_stream_t stream) {
   return KV_OK;
 }
 
+// inverse[i] = the dense number of position i's id: position -> its entry in its tile -> the number k_papply PA_UNIQUE gave it
+__global__ void __launch_bounds__(TB) k_inverse_e(const unsigned short* __restrict__ pos_ent, const unsigned* __restrict__ ent_b,
+                                                  long long n, int* __restrict__ inverse) {
+  for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB)
+    inverse[i] = (int)ent_b[(size_t)(i / TILE) * TILE + pos_ent[i]];
+}
+
+// tf.unique_with_counts on the entry-list kernels (any dim: no row is touched): a table-less tile pass (entries, every
+// position's entry) and k_papply PA_UNIQUE with dense numbers — uniq / uniq_counts written, every entry learns its id's
+// number, the count in wd.ctr[0].  The table's mutex is held by the caller.
+static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* ids, const int* counts, long long n, hipStream_t s) {
+  Workspace& ws = t->ws;
+  int rc;
+  if (ws.pos_cap < n) {
+    HIP_TRY(hipStreamSynchronize(s));
+    ws.pos_cap = 0;
+    if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
+    ws.pos_cap = std::max<long long>(n, ws.cap_n);
+  }
+  t->fused_index = true;
+  choose_partitions(t, wd, n);
+  wd.pos_ent = ws.pos_ent;
+  launch_ltile_notable(t, pa.tv, wd, ids, n, s, counts, t->key_dtype == KV_DT_INT32);
+  // (k_papply_uniq: numbering only, nothing of the row geometry is touched — one kernel whatever the table's dim)
+  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_UNIQUE | PA_NOAPPLY, (void*)s))) return fail(rc, "unique: no kernel");
+  return KV_OK;
+}
+
 // tf.unique + unsorted_segment_sum on the batch pipeline; the table's mutex is held by the caller.
 // fold_op: how the rows of one id combine (KV_SCATTER_ADD = sum, MUL = product, MIN, MAX)
 static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t n, int64_t* uniq,
                         float* summed, int32_t* inverse, int64_t* num_unique, int fold_op, hipStream_t s) {
   int rc;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
-  const WsDev wd = ws_view(t, n);
+  WsDev wd = ws_view(t, n);
   t->batch_serial = 0;
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
@@ -2381,9 +2440,21 @@ static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t
   pa.fold_op = fold_op;
   pa.det = t->deterministic ? 1 : 0;
   pa.n = n;
-  index_pass<MODE_UNIQUE>(t, wd, pa, ids, nullptr, n, -1, nullptr, s);
-  if ((rc = launch_apply<MODE_DEDUP, OPT_ADAGRAD>(t, wd, pa, n, s))) return rc;
-  if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
+  if (fold_op == KV_SCATTER_ADD && fused_ok(t->dim)) {
+    // the entry-list kernels: distinct ids numbered (fused_unique_pass), tile sums of the rows of ids repeated inside their
+    // tile (k_tsum), the per-id sums over the tiles' entries straight to summed[number] (k_papply PA_DEDUP)
+    if ((rc = fused_unique_pass(t, wd, pa, ids, nullptr, n, s))) return rc;
+    pa.out_keys = nullptr; pa.out_map = nullptr;
+    pa.epart = wd.epart;
+    pa.day_lk = pa.day;
+    if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", t->dim);
+    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "per-id sums: no kernel for dim %d", t->dim);
+    if (inverse) k_inverse_e<<<nblocks(n, TB, 2048), TB, 0, s>>>(t->ws.pos_ent, wd.ent_b, n, inverse);
+  } else {
+    index_pass<MODE_UNIQUE>(t, wd, pa, ids, nullptr, n, -1, nullptr, s);
+    if ((rc = launch_apply<MODE_DEDUP, OPT_ADAGRAD>(t, wd, pa, n, s))) return rc;
+    if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
+  }
   unsigned U = 0;
   HIP_TRY(hipMemcpyAsync(&U, wd.ctr, sizeof U, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -2399,7 +2470,8 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   *num_unique = 0;
   if (n == 0) return KV_OK;
   if (n < 0 || !ids || !grad || !uniq || !summed) return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
+  if (n > (fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21)))
+    return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^%d)", (long long)n, fused_ok(t->dim) ? 23 : 21);
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
@@ -2451,23 +2523,28 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
     return KV_OK;
   }
   if (n < 0 || !ids || !uniq) return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^21)", (long long)n);
+  if (n > (fused_off() ? (1ll << 21) : FUSED_MAX_N)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^%d)", (long long)n, fused_off() ? 21 : 23);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
-  const WsDev wd = ws_view(t, n);
+  WsDev wd = ws_view(t, n);
   t->batch_serial = 0;
-  launch_tile<false>(t, wd, ids, counts, n, s);   // ent_a = occurrences | saturating count per tile (and zeroes wd.ctr)
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = (long long*)uniq;
   pa.out_counts = uniq_counts;
   pa.det = t->deterministic ? 1 : 0;
   pa.n = n;
-  launch_part_keys<MODE_UNIQUE>(wd, pa, s);
-  if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
+  if (!fused_off()) {   // the entry-list kernels, whatever the table's dim (no row is touched)
+    if ((rc = fused_unique_pass(t, wd, pa, ids, counts, n, s))) return rc;
+    if (inverse) k_inverse_e<<<nblocks(n, TB, 2048), TB, 0, s>>>(t->ws.pos_ent, wd.ent_b, n, inverse);
+  } else {
+    launch_tile<false>(t, wd, ids, counts, n, s);   // ent_a = occurrences | saturating count per tile (and zeroes wd.ctr)
+    launch_part_keys<MODE_UNIQUE>(wd, pa, s);
+    if (inverse) k_dedup_inverse<<<nblocks(n, TB, 2048), TB, 0, s>>>(wd, n, inverse);
+  }
   if (num_unique_dev) k_store_count<<<1, 1, 0, s>>>(wd.ctr, (long long*)num_unique_dev);
   HIP_TRY(hipGetLastError());
   if (num_unique) {   // synchronous form
