@@ -157,7 +157,7 @@ def build(force=False):
   stale = (not os.path.exists(SO_PATH)
            or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs))
   if force or stale:
-    subprocess.check_call(["make", "-C", CSRC, "-s", "-j5"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j6"] + (["-B"] if force else []))
   return SO_PATH
 
 

@@ -30,7 +30,6 @@
 #pragma once
 
 enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2, PA_UNIQUE = 3, PA_DEDUP = 4 };
-constexpr int PA_NOAPPLY = 0x100;   // flag: no update phase (the sharded route's PA_UNIQUE pass; a lookup's pass alone is k_part2's)
 #ifndef KV_PA_WAVES
 #define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
 #endif
@@ -44,13 +43,13 @@ constexpr int PA_NOAPPLY = 0x100;   // flag: no update phase (the sharded route'
 //   TBP = 256: 1024 hash slots, 1536 sources — more partitions than that, the deterministic mode, the batched ops
 template <int TBP> struct PaShape { static constexpr int HSK = TBP >= 512 ? 2048 : 1024, LSRC = TBP >= 512 ? 2048 : 1536; };
 
-// FM: the mode when the kernel is compiled for one (PA_UNIQUE has its own, k_papply_uniq: numbering only, no row geometry,
-// none of the apply's registers; the kernels of the other modes carry none of its code), -1: the mode is an argument
+// FM: the mode when the kernel is compiled for one — PA_UNIQUE (k_papply_uniq: numbering only, no row geometry, none of
+// the apply's registers) and PA_DEDUP (k_papply_dedup: sources summed and stored, no state, no optimizer) have their own
+// kernels and the kernels of the table modes carry none of their code; -1: PA_LOOKUP / PA_APPLYIDX / PA_NONE, an argument
 template <int OPT, int V, int LPR, int K, int TBP, int FM = -1>
 __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, const int mode_) {
-  constexpr bool UQ = FM == PA_UNIQUE;
+  constexpr bool UQ = FM == PA_UNIQUE, DD = FM == PA_DEDUP;
   const int mode = FM >= 0 ? FM : (mode_ & 0xFF);
-  const bool no_apply = (mode_ & PA_NOAPPLY) != 0;   // the lookup's bookkeeping alone (no gradient is given)
   constexpr int HSK = PaShape<TBP>::HSK;
   constexpr int PA_LSRC = PaShape<TBP>::LSRC;
   constexpr int UCAPK = (HSK - TBP) < 1023 ? (HSK - TBP) : 1023;   // (the class counters of the key scan are 10-bit fields)
@@ -424,10 +423,8 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           }
         }
       };
-      const bool dedup = mode == PA_DEDUP;
-      if (no_apply) {
-        prefetch();
-      } else if (is_hot) {
+      constexpr bool dedup = DD;
+      if (is_hot) {
         // ---- hot key: its sources, G * RB per step, summed by the whole wave ------------------------------------------
         const unsigned lo = st, hi = st + cnt;
         constexpr int SR = G * RB;
@@ -581,7 +578,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       }
 
       // ---- the update (one copy for both kinds of item) ------------------------------------------------------------------
-      const bool fin_live = live && errflag == 0u && !no_apply;
+      const bool fin_live = live && errflag == 0u;
       const uint4 ra = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), row | (vnew ? NEW_BIT : 0u), hint);
       bool general = fin_live;
       if (fast) {
@@ -647,7 +644,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       __syncthreads();
     }
   }
-  if (tid == 0 && mode != PA_NONE && mode != PA_DEDUP) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
+  if (tid == 0 && mode != PA_NONE && !DD) atomicAdd(&w.ctr[5], lkeys);   // distinct keys of the batch: the host's hint for the next batch's partitions
 }
 
 // The sharded route (PA_UNIQUE with route_need set): the block that finishes LAST writes every segment's header {records,
@@ -700,6 +697,17 @@ __global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_uniq(WsDev w, PartA
   papply_body<OPT_ADAM_V4, 4, 1, 1, TBP, PA_UNIQUE>(w, a, mode);
   papply_route_tail(a, mode, gridDim.x);
 }
+// PA_DEDUP alone (the sharded apply's gradient pre-sum, kv_dedup_segment_sum's sums)
+template <int V, int LPR, int K, int TBP>
+__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_dedup(WsDev w, PartArgs a) {
+  papply_body<OPT_ADAGRAD, V, LPR, K, TBP, PA_DEDUP>(w, a, PA_DEDUP);
+}
+template <int V, int LPR, int K>
+__global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_dedup_multi(const MultiDesc* __restrict__ descs) {
+  const MultiDesc& m = descs[blockIdx.y];
+  if (blockIdx.x >= m.w.P || m.n == 0) return;
+  papply_body<OPT_ADAGRAD, V, LPR, K, 256, PA_DEDUP>(m.w, m.a, PA_DEDUP);
+}
 __global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_uniq_multi(const MultiDesc* __restrict__ descs, int mode) {
   const MultiDesc& m = descs[blockIdx.y];
   if (blockIdx.x >= m.w.P || m.n == 0) return;
@@ -720,16 +728,7 @@ template <int OPT>
 int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
   const int D = pa.tv.dim;
   const size_t sh = (size_t)wd.ntiles * 4 + 32;
-  if ((mode & 0xFF) == PA_UNIQUE) {   // numbering only: one kernel whatever the dim (instantiated with the GroupAdam unit)
-    if constexpr (OPT == OPT_ADAM_V4) {
-      if (md) k_papply_uniq_multi<<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);
-      else if (wd.P <= 512u && !pa.det) k_papply_uniq<512><<<(int)wd.P, 512, sh, s>>>(wd, pa, mode);
-      else k_papply_uniq<256><<<(int)wd.P, 256, sh, s>>>(wd, pa, mode);
-      return KV_OK;
-    }
-    return KV_UNIMPLEMENTED;
-  }
-  if ((D & 3) != 0) return KV_UNIMPLEMENTED;
+  if ((D & 3) != 0 || (mode & 0xFF) > PA_NONE) return KV_UNIMPLEMENTED;   // (PA_UNIQUE / PA_DEDUP: launch_papply_ud_t)
 #define KV_PA(V, LPR, K)                                                     \
   do {                                                                       \
     if (md) k_papply_multi<OPT, V, LPR, K><<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);   \
@@ -752,5 +751,37 @@ int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s
   if (q <= 32) KV_PA(4, 16, 2);
   if (q <= 64) KV_PA(4, 64, 1);
 #undef KV_PA
+  return KV_UNIMPLEMENTED;
+}
+
+// PA_UNIQUE (numbering only: one kernel whatever the dim) and PA_DEDUP (the per-id sums, by row geometry): their own
+// kernels, instantiated in their own translation unit (kv_papply_c.hip).  A template so that only that unit holds them.
+template <int UNIT>
+int launch_papply_ud_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s, const MultiDesc* md = nullptr, int ntab = 0) {
+  const size_t sh = (size_t)wd.ntiles * 4 + 32;
+  if (mode == PA_UNIQUE) {
+    if (md) k_papply_uniq_multi<<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md, mode);
+    else if (wd.P <= 512u && !pa.det) k_papply_uniq<512><<<(int)wd.P, 512, sh, s>>>(wd, pa, mode);
+    else k_papply_uniq<256><<<(int)wd.P, 256, sh, s>>>(wd, pa, mode);
+    return KV_OK;
+  }
+  const int D = pa.tv.dim;
+  if (mode != PA_DEDUP || (D & 3) != 0) return KV_UNIMPLEMENTED;
+#define KV_PD(V, LPR, K)                                                     \
+  do {                                                                       \
+    if (md) k_papply_dedup_multi<V, LPR, K><<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md);   \
+    else if (wd.P <= 512u && !pa.det) k_papply_dedup<V, LPR, K, 512><<<(int)wd.P, 512, sh, s>>>(wd, pa);   \
+    else k_papply_dedup<V, LPR, K, 256><<<(int)wd.P, 256, sh, s>>>(wd, pa);   \
+    return KV_OK;                                                            \
+  } while (0)
+  const int q = D / 4;
+  if (q <= 1) KV_PD(4, 1, 1);
+  if (q <= 2) KV_PD(4, 2, 1);
+  if (q <= 4) KV_PD(4, 4, 1);
+  if (q <= 8) KV_PD(4, 8, 1);
+  if (q <= 16) KV_PD(4, 8, 2);
+  if (q <= 32) KV_PD(4, 16, 2);
+  if (q <= 64) KV_PD(4, 64, 1);
+#undef KV_PD
   return KV_UNIMPLEMENTED;
 }

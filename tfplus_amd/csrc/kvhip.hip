@@ -62,6 +62,7 @@ extern "C" int kvp_launch_ltsum(const void* td, const void* wd, const void* ids,
                                 const float* grad, void* stream);
 extern "C" int kvp_launch_papply_a(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
 extern "C" int kvp_launch_papply_b(int opt, const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);
+extern "C" int kvp_launch_papply_ud(const void* wd, const void* pa, int mode, void* stream, const void* md = nullptr, int ntab = 0);   // PA_UNIQUE / PA_DEDUP
 // k_uapply dispatch (kv_uapply.h: the apply on unique ids), instantiated next to k_papply
 extern "C" int kvp_launch_uapply_a(int opt, const void* pa, const void* ids, int ids32, long long n, void* stream, const void* md = nullptr,
                                    int ntab = 0);
@@ -2420,7 +2421,7 @@ static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* i
   wd.pos_ent = ws.pos_ent;
   launch_ltile_notable(t, pa.tv, wd, ids, n, s, counts, t->key_dtype == KV_DT_INT32);
   // (k_papply_uniq: numbering only, nothing of the row geometry is touched — one kernel whatever the table's dim)
-  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_UNIQUE | PA_NOAPPLY, (void*)s))) return fail(rc, "unique: no kernel");
+  if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_UNIQUE, (void*)s))) return fail(rc, "unique: no kernel");
   return KV_OK;
 }
 
@@ -2448,7 +2449,7 @@ static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t
     pa.epart = wd.epart;
     pa.day_lk = pa.day;
     if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", t->dim);
-    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "per-id sums: no kernel for dim %d", t->dim);
+    if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "per-id sums: no kernel for dim %d", t->dim);
     if (inverse) k_inverse_e<<<nblocks(n, TB, 2048), TB, 0, s>>>(t->ws.pos_ent, wd.ent_b, n, inverse);
   } else {
     index_pass<MODE_UNIQUE>(t, wd, pa, ids, nullptr, n, -1, nullptr, s);
@@ -3526,7 +3527,7 @@ static int lookup_route_impl(kv_shard_t sh, const void* ids, int64_t n, kv_strea
       pa.route_seg = sh->send_pairs; pa.route_slot_of = sh->slot_of; pa.route_overflow = sh->overflow; pa.route_gcount = sh->gcount;
       pa.route_need = sh->need; pa.route_uhint = sh->overflow + 1;   // (the launch's last block writes the headers: no k_seg_headers_take)
     }
-    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_UNIQUE | PA_NOAPPLY, (void*)s))) return fail(rc, "route: no kernel for dim %d", rt->dim);
+    if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_UNIQUE, (void*)s))) return fail(rc, "route: no kernel for dim %d", rt->dim);
   } else {
     {
       // a skewed batch (the previous one of this length held at most n / 8 distinct ids; pinned word, no
@@ -3651,7 +3652,7 @@ int kv_shard_apply_route(kv_shard_t sh, const float* grad, kv_stream_t stream) {
     pa.epart = wd.epart;
     pa.day_lk = pa.day;
     if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", rt->dim);
-    if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "gradient pre-sum: no kernel for dim %d", rt->dim);
+    if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "gradient pre-sum: no kernel for dim %d", rt->dim);
     HIP_TRY(hipGetLastError());
     return KV_OK;
   }
@@ -4025,10 +4026,10 @@ static int multi_route_impl(const kv_shard_t* shards, const int* todo, int m, co
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   k_ltile_multi_notable<<<dim3(wmax.ntiles, (unsigned)m), TBT, ltile_smem_bytes(), s>>>(md);
-  // (PA_UNIQUE | PA_NOAPPLY never reaches the code that depends on the row geometry: one variant serves every dim)
+  // (PA_UNIQUE never reaches the code that depends on the row geometry: one variant serves every dim)
   PartArgs p0 = hd[0].a;
   p0.tv.dim = 4;
-  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wmax, &p0, PA_UNIQUE | PA_NOAPPLY, (void*)s, md, m))) return fail(rc, "route: no kernel");
+  if ((rc = kvp_launch_papply_ud(&wmax, &p0, PA_UNIQUE, (void*)s, md, m))) return fail(rc, "route: no kernel");
   for (int j = 0; j < m; ++j) {
     kv_shard* sh = shards[todo[j]];
     kv_table* rt = sh->route;
@@ -4129,7 +4130,7 @@ static int multi_presum_impl(const kv_shard_t* shards, const int* todo, int m, c
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   if ((rc = kvp_launch_tsum(&hd[0].a.tv, &wmax, nullptr, (void*)s, md, m))) return fail(rc, "tile sums: no kernel for dim %d", hd[0].a.tv.dim);
-  if ((rc = kvp_launch_papply_a(OPT_ADAM_V4, &wmax, &hd[0].a, PA_DEDUP, (void*)s, md, m))) return fail(rc, "gradient pre-sum: no kernel for dim %d", hd[0].a.tv.dim);
+  if ((rc = kvp_launch_papply_ud(&wmax, &hd[0].a, PA_DEDUP, (void*)s, md, m))) return fail(rc, "gradient pre-sum: no kernel for dim %d", hd[0].a.tv.dim);
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }

@@ -10,14 +10,14 @@ obj=$root/build/ab/obj_$name
 mkdir -p $obj
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -w $*"
 pids=()
-for u in ${UNITS:-kvhip kv_apply_a kv_apply_b kv_papply_a kv_papply_b}; do
+for u in ${UNITS:-kvhip kv_apply_a kv_apply_b kv_papply_a kv_papply_b kv_papply_c}; do
   /opt/rocm/bin/hipcc $FLAGS -c -o $obj/$u.o $src/$u.hip &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
 # units not rebuilt come from the product build
 objs=""
-for u in kvhip kv_apply_a kv_apply_b kv_papply_a kv_papply_b; do
+for u in kvhip kv_apply_a kv_apply_b kv_papply_a kv_papply_b kv_papply_c; do
   if [ -f $obj/$u.o ]; then objs="$objs $obj/$u.o"; else objs="$objs $src/_obj/$u.o"; fi
 done
 /opt/rocm/bin/hipcc $FLAGS -shared -o $root/build/ab/$name.so $objs
