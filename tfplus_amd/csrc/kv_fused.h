@@ -916,6 +916,11 @@ __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_b
 // The order of the additions depends on nothing but the list.  The positions of the next step are requested with
 // the rows of this one.
 constexpr int TBC = 512;
+// k_ltsum runs tsum_body in the tile pass's own block: its waves' shares and the wave-by-wave meeting in LDS assume TBC
+// threads.  (A tile kernel rebuilt with fewer threads — round 3's TILE = 1024 experiment, 256 threads — left the waves
+// tsum_body waits on unstarted: their lmeta words were never written and the sums went to epart rows nobody owns, past
+// the buffer's end for the last tile.  That was the fault DESIGN.md's round-3 notes recorded without a cause.)
+static_assert(TBC == TBT, "k_ltsum: the tile pass and the tile sums share one block");
 // FROM_LDS: the tile's mrow image is read from LDS at mrow_l — the tile pass's own image (k_ltsum: LtSmem::mr), or the
 // copy k_tsum stages while the count is still on its way (one round trip in front of the rows instead of two); mc_l = mcount[tile]
 template <int V, int LPR, int K, bool FROM_LDS = false>

@@ -314,12 +314,6 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     bool evalid[K];
   #pragma unroll
     for (int k = 0; k < K; ++k) { const int e0 = (lane + k * LPR) * V; evalid[k] = e0 < D; eoff[k] = evalid[k] ? e0 : 0; }
-    auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
-      const float* base = (pos & EP_TAG) ? ebase : (pos - w.self_lo < w.self_len) ? gself : gbase;
-      const float* src = base + (size_t)(pos & ~EP_TAG) * D;
-  #pragma unroll
-      for (int k = 0; k < K; ++k) ldv_stream<V>(src + eoff[k], dst[k]);
-    };
     const bool fast = (OPT != OPT_FTRL) && a.tv.single != 0u && a.ts0.single != 0u && a.use_hints != 0 &&
                       (a.tv.track_delta | a.ts0.track_delta) == 0u;
     float* const vrows = a.tv.c0.rows;
@@ -350,6 +344,21 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       if (wl == 0) it = atomicAdd(&lnext, 1u);
       it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);   // wave-uniform (a scalar): the branches on it are scalar branches
       if (it >= nitems) break;
+      // The lane's element offsets through an opaque move, per item.  An address "base + row * D + offset" whose per-lane part
+      // is loop-invariant is hoisted in front of the loop as one 64-bit pointer per base — and spilled: the reload from
+      // scratch sat in front of the state loads behind an s_waitcnt vmcnt(0) that also waited for the records, a second
+      // round trip per item (the ISA of round 5's kernel; profiles/r05_papply_spill.txt).
+      int eo[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { eo[k] = eoff[k]; asm volatile("" : "+v"(eo[k])); }
+      int lane_i = lane;   // (opt_core / finish_key / prefetch_state derive their own offsets from the lane: the same move)
+      asm volatile("" : "+v"(lane_i));
+      auto load_row = [&](unsigned pos, float (&dst)[K][V]) {
+        const float* base = (pos & EP_TAG) ? ebase : (pos - w.self_lo < w.self_len) ? gself : gbase;
+        const float* src = base + (size_t)(pos & ~EP_TAG) * D;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ldv_stream<V>(src + eo[k], dst[k]);
+      };
 #ifdef KV_PA_X_NOHOT
       const bool is_hot = false;
 #else
@@ -406,15 +415,15 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           const float* sr = srows + (size_t)hh * SD;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            ldv<V>(xr + eoff[k], pre.x[k]);
+            ldv<V>(xr + eo[k], pre.x[k]);
 #pragma unroll
-            for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eoff[k], pre.s[b3][k]);
+            for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eo[k], pre.s[b3][k]);
           }
           hint_loaded = hh != 0u; have_x = true; have_s = hh != 0u;
         } else {
           if (st_live && !isnew) vm = load_freq_flags(a.tv, row);
           uint4 rq = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), st_live ? row : 0u, st_live ? hint : 0u);
-          prefetch_state<OPT, V, LPR, K>(a, rq, st_live, lane, D, m0, hint_loaded, pre, have_x, have_s);
+          prefetch_state<OPT, V, LPR, K>(a, rq, st_live, lane_i, D, m0, hint_loaded, pre, have_x, have_s);
           if (!have_x) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -505,7 +514,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           float* dst = a.out_sum + (size_t)(a.out_map ? a.out_map[row] : (int)row) * D;
 #pragma unroll
           for (int k = 0; k < K; ++k)
-            if (evalid[k]) stv<V>(dst + eoff[k], gv[k]);
+            if (evalid[k]) stv<V>(dst + eo[k], gv[k]);
         }
         continue;
       }
@@ -521,11 +530,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               float va_[V], vb_[V];
-              ldv<V>(ia + eoff[k], va_);
-              ldv<V>(ib + eoff[k], vb_);
+              ldv<V>(ia + eo[k], va_);
+              ldv<V>(ib + eo[k], vb_);
 #pragma unroll
               for (int cc = 0; cc < V; ++cc) pre.x[k][cc] = (va_[cc] + vb_[cc]) * 0.5f;
-              if (evalid[k]) stv<V>(xrow + eoff[k], pre.x[k]);
+              if (evalid[k]) stv<V>(xrow + eo[k], pre.x[k]);
             }
             have_x = true;
           }
@@ -597,12 +606,12 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
         }
         const unsigned rr = act ? row : 0u, h2 = act ? hh : 0u;
         opt_core<OPT, V, LPR, K>(vrows + (size_t)rr * D, srows + (size_t)h2 * SD, nullptr, &vmeta[rr].flags, &smeta[h2].flags,
-                                 nullptr, act, false, D, gv, a.opt, lane, pre.x, pre.s);
+                                 nullptr, act, false, D, gv, a.opt, lane_i, pre.x, pre.s);
         general = fin_live && !ok;
       }
 #ifndef KV_PA_X_NOGENERAL
       if (!fast || __ballot(general) != 0ull)
-        finish_key<MODE_APPLY, OPT, V, LPR, K>(a, ra, general, hint_loaded && general, m0, gv, lane, &pre, have_x && general,
+        finish_key<MODE_APPLY, OPT, V, LPR, K>(a, ra, general, hint_loaded && general, m0, gv, lane_i, &pre, have_x && general,
                                                have_s && general);
 #endif
 #ifdef KV_STAMPS
