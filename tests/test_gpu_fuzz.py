@@ -62,8 +62,8 @@ def test_random_program_matches_oracle(ops, seed):
   day = DAY0
   b1p, b2p = np.float32(0.9), np.float32(0.999)
   for step in range(40):
-    op = rng.choice(["lookup", "lookup_counts", "apply", "apply", "scatter", "insert", "delete", "expire", "roundtrip"],
-                    p=[.2, .1, .2, .15, .1, .05, .1, .05, .05])
+    op = rng.choice(["lookup", "lookup_counts", "apply", "apply", "scatter", "insert", "delete", "expire", "roundtrip", "sparse"],
+                    p=[.15, .1, .2, .15, .1, .05, .1, .05, .05, .05])
     n = int(rng.choice([1, 7, 300, 3000]))
     ids = rng.integers(-keyspace, keyspace, n)
     if op == "roundtrip" and kd == torch.int32:
@@ -79,16 +79,34 @@ def test_random_program_matches_oracle(ops, seed):
     elif op == "apply":
       g = (rng.uniform(0.5, 1.5, (n, D)) * 1e-2 * rng.choice([-1.0, 1.0], (1, D))).astype(np.float32)
       u, s, _ = ko.dedup_segment_sum(ids, g)
+      # TF-core's dedup on the GPU (kv_dedup_segment_sum / kv_unique): the same keys, sums up to the order of the additions
+      gu, gs, ginv = ops.kv_dedup_segment_sum(var.h, ids, g)
+      gu, gs, ginv = gu.cpu().numpy(), gs.cpu().numpy(), ginv.cpu().numpy()
+      assert np.array_equal(gu[ginv], ids) and np.array_equal(np.sort(gu), np.sort(u)), tag
+      np.testing.assert_allclose(gs[np.argsort(gu)], s[np.argsort(u)], rtol=1e-5, atol=1e-8, err_msg=tag)
+      qu, qc, qinv = ops.kv_unique(var.h, ids)
+      assert np.array_equal(qu.cpu().numpy()[qinv.cpu().numpy()], ids) and int(qc.sum()) == n, tag
+      uq = dict(unique_indices=bool(rng.integers(0, 2)))   # the op as an unchanged graph calls it: ids promised unique (one launch)
       if opt == "adam":
-        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0)
+        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0, **uq)
         ko.apply_group_adam(var.o, sl[0].o, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8)
         b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
       elif opt == "adagrad":
-        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, s, u, use_locking=True)
+        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, s, u, use_locking=True, **uq)
         ko.apply_adagrad(var.o, sl[0].o, 0.05, s, u)
       else:
-        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
+        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5, **uq)
         ko.apply_sparse_group_ftrl(var.o, sl[0].o, sl[1].o, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
+    elif op == "sparse":   # embedding_lookup_sparse in one call: unique -> GatherOrInsert -> segment sum in position order
+      nseg = max(1, n // 3)
+      seg = np.sort(rng.integers(0, nseg, n))
+      got = ops.kv_variable_lookup_sparse(var.h, ids, seg, None, nseg, "sum", count_occurrences=False).cpu().numpy()
+      uniq, idx = np.unique(ids, return_inverse=True)
+      emb = var.o.gather_or_insert(uniq)[idx]
+      want = np.zeros((nseg, D), np.float32)
+      for j in range(n):
+        want[seg[j]] = want[seg[j]] + emb[j]
+      np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7, err_msg=tag)
     elif op == "scatter":
       uids = np.unique(ids)
       upd = rng.uniform(0.5, 2.0, (uids.size, D)).astype(np.float32)
