@@ -510,8 +510,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       // ---- the lookup's bookkeeping for the key (k_part2's owner work), on what the round trip brought ----------------
       // kv_variable.h:320-363 (find_func / insert_func) for PA_LOOKUP, :382-416 (FindOrInsertUnsafe) for PA_APPLYIDX
       if (dedup) {   // the id's sum goes to the record the id was sent in (sharded apply: out_map = the id's exchange slot)
-        if (live) {
-          float* dst = a.out_sum + (size_t)(a.out_map ? a.out_map[row] : (int)row) * D;
+        // (direct_rows > 0 — tf.unsorted_segment_sum: the keys ARE the output rows; a key outside [0, direct_rows) is dropped)
+        const bool direct = a.direct_rows > 0;
+        if (live && (!direct || (unsigned long long)key < (unsigned long long)a.direct_rows)) {
+          const size_t orow = direct ? (size_t)key : (size_t)(a.out_map ? a.out_map[row] : (int)row);
+          float* dst = a.out_sum + orow * D;
 #pragma unroll
           for (int k = 0; k < K; ++k)
             if (evalid[k]) stv<V>(dst + eo[k], gv[k]);

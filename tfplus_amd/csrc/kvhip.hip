@@ -2487,7 +2487,8 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   if (n < 0 || num_segments < 0 || num_segments > 0x7FFFFFFFll || (n > 0 && (!segment_ids || !data)) ||
       (num_segments > 0 && !out))
     return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (1ll << 21)) return fail(KV_UNIMPLEMENTED, "%lld rows in one call (limit 2^21)", (long long)n);
+  if (n > (fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21)))
+    return fail(KV_UNIMPLEMENTED, "%lld rows in one call (limit 2^%d)", (long long)n, fused_ok(t->dim) ? 23 : 21);
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   if (num_segments == 0) return KV_OK;
   DeviceGuard dg(t->device);
@@ -2497,7 +2498,7 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * t->dim * sizeof(float), s));  // segments nobody names
   if (n == 0) return KV_OK;
   if ((rc = ensure_workspace(t, n, true, s))) return rc;
-  const WsDev wd = ws_view(t, n);
+  WsDev wd = ws_view(t, n);
   t->batch_serial = 0;
   PartArgs pa{};
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
@@ -2507,6 +2508,19 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   pa.fold_op = KV_SCATTER_ADD;
   pa.det = t->deterministic ? 1 : 0;
   pa.n = n;
+  if (fused_ok(t->dim)) {
+    // the entry-list kernels: the segment ids de-duplicated per tile (no numbering: an id IS its output row), the tile
+    // sums, the per-id sums over the tiles' entries straight to out[id]
+    t->fused_index = true;
+    choose_partitions(t, wd, n);
+    launch_ltile_notable(t, pa.tv, wd, segment_ids, n, s, nullptr, true);
+    pa.epart = wd.epart;
+    pa.day_lk = pa.day;
+    if ((rc = kvp_launch_tsum(&pa.tv, &wd, data, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", t->dim);
+    if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_DEDUP, (void*)s))) return fail(rc, "segment sums: no kernel for dim %d", t->dim);
+    HIP_TRY(hipGetLastError());
+    return KV_OK;
+  }
   index_pass<MODE_UNIQUE>(t, wd, pa, segment_ids, nullptr, n, 1, nullptr, s);
   if ((rc = launch_apply<MODE_DEDUP, OPT_ADAGRAD>(t, wd, pa, n, s))) return rc;
   HIP_TRY(hipGetLastError());
