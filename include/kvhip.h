@@ -164,8 +164,9 @@ int kv_apply_sparse_group_ftrl(kv_handle_t var, kv_handle_t accum, kv_handle_t l
  * the serial of the last unique-apply launch that touched it, flipped by one returning atomic per id; an id listed
  * twice raises the table's error word and the NEXT call on the table returns KV_INVALID_ARGUMENT (that batch was not
  * applied as the reference applies repeated ids — sequentially).  Embedding dims the kernel does not serve (not a
- * multiple of 4, or above 256) take the batch pipeline, which needs no promise.  No batch token is involved; a pending
- * lookup pass of the table is settled first. */
+ * multiple of 4, or above 256) take the batch pipeline, which needs no promise — and so does a call made under
+ * stream capture (the launch serial lives on the host: a replayed launch would meet its own stamps).  No batch token
+ * is involved; a pending lookup pass of the table is settled first. */
 int kv_apply_group_adam_unique(kv_handle_t var, kv_handle_t m_v_linear, const float* grad, const void* ids, int64_t n,
                                float lr, float beta1_power, float beta2_power, float beta1, float beta2, float epsilon,
                                float l1, float l2, float l21, int version, kv_stream_t stream);
@@ -213,7 +214,9 @@ int kv_set_fast_math(kv_handle_t h, int on);
 /* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that
  * follows can then take `max_new_ids` more ids without consulting the device — what a stream capture needs, where a
  * synchronisation is not allowed.  KV_RESOURCE_EXHAUSTED when the table would have to grow for that many ids (it
- * grows here, outside the capture, if it can). */
+ * grows here, outside the capture, if it can).  The table's batch workspace is sized by the calls themselves: issue the
+ * op once with the batch length outside the capture; a captured call that would have to grow it returns
+ * KV_FAILED_PRECONDITION before it queues anything (the capture stays valid). */
 int kv_prepare_capture(kv_handle_t h, int64_t max_new_ids, kv_stream_t stream);
 
 /* The TF-core step on its own (for callers that want the [U, dim] IndexedSlices):

@@ -629,12 +629,25 @@ int regrow(T** p, size_t count) {
   return KV_OK;
 }
 
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+}
+// the workspace grows behind a stream synchronisation: under a stream capture that is refused BEFORE anything is queued
+// (a failed synchronisation would invalidate the caller's capture)
+static int ws_sync(hipStream_t s) {
+  if (stream_is_capturing(s))
+    return fail(KV_FAILED_PRECONDITION, "the table's batch workspace has to grow for this call, which needs a stream synchronisation: "
+                                        "run the op once with this batch length outside the stream capture first");
+  HIP_TRY(hipStreamSynchronize(s));
+  return KV_OK;
+}
 int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   Workspace& w = t->ws;
   const unsigned P = pick_partitions(n, true);
   int rc;
   if (n > w.cap_n || P > w.capP) {
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;
     long long cap = std::max<long long>(n, TILE);
     if (w.cap_n) cap = std::max<long long>(cap, std::min<long long>(w.cap_n * 2, 1ll << 30));
     cap = (cap + TILE - 1) / TILE * TILE;
@@ -664,7 +677,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   }
   const long long pe = (long long)chunk_cap(w.cap_n) * (long long)t->dim;
   if (need_part && w.hpart_elems < pe) {
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;
     w.hpart_elems = 0;
     if ((rc = regrow(&w.hpart, (size_t)pe))) return rc;
     w.hpart_elems = pe;
@@ -673,7 +686,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
   // (half a row per id: 512 MB for a 1 M-id batch at dim 256), grown by half when a longer batch comes
   const long long ee = ((n + TILE - 1) / TILE) * (long long)(TILE / 2) * (long long)t->dim;
   if (need_part && w.epart_elems < ee) {
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;
     const long long want = std::max(ee, std::min((w.cap_n / 2) * (long long)t->dim, w.epart_elems + w.epart_elems / 2));
     w.epart_elems = 0;
     if ((rc = regrow(&w.epart, (size_t)want))) return rc;
@@ -690,6 +703,9 @@ bool fused_off();
 // (the send buffers) instead.  Per thread, so another thread's op on the same table sees nothing of it.
 struct SelfSegment { const kv_table* table = nullptr; unsigned lo = 0, len = 0; const void* ids = nullptr; const float* grad = nullptr; };
 static thread_local bool tl_unique = false;          // kv_apply_*_unique: the caller promises unique ids (apply_common takes the one-launch path)
+// The duplicate guard of the one-launch path stamps rows with a launch serial that lives on the HOST: a captured launch
+// would be replayed with the serial it was captured with and find its own stamps.  Under stream capture the unique forms
+// therefore run the batch pipeline (which needs no promise; same results, bit for bit): stream_is_capturing().
 static thread_local bool tl_require_reuse = false;   // the batched sharded apply: the tables must still hold their lookups' indexes
 static thread_local std::vector<SelfSegment> tl_selfs;   // (empty outside the sharded owner ops; several tables in the batched ones)
 struct SelfScope {
@@ -1864,7 +1880,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
-  if (tl_unique && fused_ok(D)) {
+  if (tl_unique && fused_ok(D) && !stream_is_capturing(s)) {
     // The caller promises that no table's ids hold an id twice (kv_multi_apply_*_unique; kv_uapply.h): ONE launch for all
     // tables, one lane group per id (grid.y = table).  Pending lookup passes are settled first.
     long long nmax = 0;
@@ -2099,7 +2115,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   if (!dim_supported(v->dim))
     return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported by the fused kernels", v->dim);
   int rc;
-  if (tl_unique && fused_ok(v->dim)) {
+  if (tl_unique && fused_ok(v->dim) && !stream_is_capturing(s)) {
     // The caller promises unique ids (kv_apply_*_unique; kv_uapply.h): one launch, one lane group per id.  A pending
     // partition pass was settled by the caller's hand_over (no token is given).  Dims the kernel does not serve take the
     // batch pipeline below, which needs no promise.
