@@ -139,6 +139,7 @@ static_assert(TILE <= (1 << 11), "mrow: the tile-local position is an 11-bit fie
 static_assert(TILE / 2 <= (1 << 10), "mrow: the entry's epart row is a 10-bit field (an entry in mrow has >= 2 rows)");
 static_assert(TILE <= (int)ES_POS && TILE / 2 < (1 << (23 - ES_NSH)), "escan: rows and entry numbers of a tile fit their fields");
 static_assert(TILE <= 65535, "toff / hist / mcount pack per-tile counts into 16-bit halves");
+constexpr int LT_TOUCH_MAXENT = TILE / 2;   // early row touches: only in tiles with at most this many distinct keys
 
 // VQ = float4 per row (power of two <= 64); GATHER: copy the rows of the tile's positions to `out`.
 // NOTABLE: no table behind the batch (the sharded route's index of the local ids): no probes, no inserts — the entries carry
@@ -208,6 +209,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   // row word (NEW_BIT: the table does not hold the key yet, or a tile of this launch is inserting it — row part 0 when the
   // row is not known) and slot-row hint of the positions in `mask`
   unsigned rr[IPT], hn[IPT];
+  float pf = 0.f;   // (sum of the early row touches: keeps the loads alive, see below)
 #pragma unroll
   for (int k = 0; k < IPT; ++k) { rr[k] = 0u; hn[k] = 0u; }
   auto resolve_probes = [&](unsigned mask) {
@@ -474,6 +476,14 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
     sm.lrow[tslot[k]] = r;
     w.ent_b[e] = r;
     w.ent_base[e] = hn[k];
+    // The winner touches its key's row NOW.  A key the batch has not met for a few steps is two dependent HBM round trips
+    // away (index entry, then row), and the row copy below keeps only two pieces per wave in flight: with the rows' first
+    // lines already on their way into L2 while the block files its entries and its mrow image, the copy finds them there
+    // (k_ltile 54.3 -> 48.0 us at configs[1]).  Only for a tile with at most LT_TOUCH_MAXENT distinct keys: the touched
+    // lines of a CU's blocks must still be in the XCD's 4 MB L2 when the copy comes (at Zipf 0.8 / 0.3, 1700 / 2030
+    // distinct keys per tile, the touches were fetched twice: +16 / +21 us; profiles/r05_row_touch.txt).
+    if (GATHER && nent <= (unsigned)LT_TOUCH_MAXENT && (r & ROW_MASK) != 0u && !(r & NEW_BIT))
+      pf += *reinterpret_cast<const volatile float*>(row_ptr(t, r & ROW_MASK));
   }
   lds_barrier();
   KV_STAMP(3);
@@ -554,6 +564,7 @@ __device__ __forceinline__ void ltile_body(const TableDev& t, const WsDev& w, co
   if constexpr (GATHER) {
 #pragma unroll
     for (int k = 0; k < IPT; ++k) rr[k] = tslot[k] != 0xFFFFFFFFu ? sm.lrow[tslot[k]] : 0u;   // skipped records read the zero row
+    if (__builtin_expect(pf == 1.2345678e-38f, 0)) sm.wtot[0] = 1u;   // (the touches' only use; never true, and harmless if it were)
     output_rows();
   }
   KV_STAMP(5);
