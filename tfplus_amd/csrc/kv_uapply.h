@@ -75,9 +75,6 @@ __device__ __forceinline__ unsigned uniq_insert(const TableDev& t, long long key
   return r;
 }
 
-#ifndef KV_UA_TOUCH
-#define KV_UA_TOUCH 0
-#endif
 template <int OPT, int V, int LPR, int K>
 __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __restrict__ ids, int ids32, long long n) {
   constexpr int G = 64 / LPR;
@@ -116,13 +113,7 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
   long long key_nn = id_at(b0 + nwaves);
   unsigned long long p_n = home_of(a.tv, key_n, mix64((unsigned long long)key_n));
   Entry e_n = load_entry(&a.tv.entries[p_n]);
-#if KV_UA_TOUCH
-  float tch = 0.f, tacc = 0.f;
-#endif
   for (long long b = b0; b < nbatch; b += nwaves) {   // wave-uniform
-#if KV_UA_TOUCH
-    tacc += tch;   // (last step's touches: their only use)
-#endif
     const long long i = b * G + g;
     const bool live0 = i < n;
     const long long ic = live0 ? i : n - 1;
@@ -190,23 +181,6 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
       }
     }
 
-#if KV_UA_TOUCH
-    // (experiment) the NEXT batch's index entry is back (it was requested in front of this batch's state): its key's lines —
-    // var row, both records, the slot rows, the gradient row — are touched now, one line per lane of the group
-    if (fast && b + nwaves < nbatch) {
-      const long long jn = (b + nwaves) * G + g;
-      const bool hit = jn < n && e_n.key == key_n && e_n.row != ROW_TOMB && e_n.row != 0u && e_n.hint != HINT_NEW;
-      const unsigned rn = hit ? e_n.row : 0u, hn_ = (hit && e_n.hint < smax) ? e_n.hint : 0u;
-      float t = 0.f;
-      for (int j = lane; j < 4 + NS0 * ((D + 31) / 32); j += LPR) {
-        const float* q = j == 0 ? vrows + (size_t)rn * D : j == 1 ? reinterpret_cast<const float*>(vmeta + rn)
-                       : j == 2 ? reinterpret_cast<const float*>(smeta + hn_)
-                       : j == 3 ? gbase + (size_t)(jn < n ? jn : n - 1) * D : srows + (size_t)hn_ * SD + (size_t)(j - 4) * 32;
-        t += *reinterpret_cast<const volatile float*>(q);
-      }
-      tch = t;
-    }
-#endif
     // ---- the promise: nobody else of this launch holds the row (see the head of this file) ----------------------------------
     const unsigned st0 = vm.y >> 16;
     bool mine = st_live && !isnew;
@@ -287,9 +261,6 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
       if (dup && lane == 0) raise_error(a.tv, 4u);
     }
   }
-#if KV_UA_TOUCH
-  if (__builtin_expect(tacc + tch == 1.2345678e-38f, 0)) raise_error(a.tv, 0u);   // (keeps the touches alive; never true)
-#endif
 }
 
 template <int OPT, int V, int LPR, int K>
