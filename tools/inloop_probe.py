@@ -2,6 +2,9 @@
 ids, dim 32) timed by events behind different predecessors.  python tools/inloop_probe.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tfplus_amd import _lib
+if len(sys.argv) > 1:
+  _lib.SO_PATH = os.path.abspath(sys.argv[1])   # (another build of the library)
 import bench
 from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
 dev = torch.device("cuda", 0)
