@@ -58,9 +58,9 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   constexpr int RB = (KV_PA_HOTRB / K) > 0 ? (KV_PA_HOTRB / K) : 1;
   constexpr int NW = TBP / 64;
   __shared__ long long hkey[HSK + 1];
-  __shared__ unsigned hval[HSK + 1];    // summed frequency count of the key's entries
+  __shared__ unsigned hval[DD ? 1 : HSK + 1];    // summed frequency count of the key's entries (the per-id sums need none)
   __shared__ unsigned hrow[HSK + 1];    // max over the key's entries of the row word (an entry that knows the row wins)
-  __shared__ unsigned hhint[HSK + 1];   // slot-row hint
+  __shared__ unsigned hhint[(UQ || DD) ? 1 : HSK + 1];   // slot-row hint (table modes only)
   __shared__ unsigned hocc[HSK + 1];    // entries of the key; then the cursor into the source list (ends at the stretch's end)
   __shared__ unsigned short hcn[HSK + 1];   // entries of the key (final)
   __shared__ unsigned short ulist[UCAPK + 8];
@@ -104,7 +104,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
   // code (what the partition phases hold in registers is dead when the apply begins), the split rounds loop below.
   auto do_round = [&](const unsigned R, const unsigned round) -> bool {
     __syncthreads();
-    for (int s = tid; s <= HSK; s += TBP) { hkey[s] = EMPTY_KEY; hval[s] = 0; hrow[s] = 0; hhint[s] = 0; hocc[s] = 0; }
+    for (int s = tid; s <= HSK; s += TBP) {
+      hkey[s] = EMPTY_KEY; hrow[s] = 0; hocc[s] = 0;
+      if constexpr (!DD) hval[s] = 0;
+      if constexpr (!UQ && !DD) hhint[s] = 0;
+    }
     if (tid == 0) { lnu = 0; lsent = 0; lnext = 0; }
     __syncthreads();
     // ---- pass 1: distinct keys, their counts, rows and hints (the entries' sources ride along) -------------------
@@ -140,11 +144,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           const unsigned u = atomicAdd(&lnu, 1u);
           if (u < (unsigned)UCAPK) ulist[u] = (unsigned short)h;
         }
-        if (mode == PA_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16);
-        else if (UQ) atomicAdd(&hval[h], a.sparse_unique ? (ea[k] & 0xFFFFu) : (ea[k] >> 16));   // occurrences of the id in the batch (dense: its summed counts)
+        if constexpr (UQ) atomicAdd(&hval[h], a.sparse_unique ? (ea[k] & 0xFFFFu) : (ea[k] >> 16));   // occurrences of the id in the batch (dense: its summed counts)
+        else if constexpr (!DD) { if (mode == PA_LOOKUP) atomicAdd(&hval[h], ea[k] >> 16); }
         atomicAdd(&hocc[h], 1u);
         atomicMax(&hrow[h], rw[k]);
-        if (hi[k]) atomicMax(&hhint[h], hi[k]);
+        if constexpr (!UQ && !DD) { if (hi[k]) atomicMax(&hhint[h], hi[k]); }
         if (x0 == 0) { cslot[k] = (unsigned short)h; cin[k] = true; }
       }
     }
@@ -374,8 +378,8 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
       const unsigned rww = hrow[s];
       unsigned row = rww & ROW_MASK;
       const bool isnew = have && mode != PA_NONE && (rww & NEW_BIT) != 0u;
-      const unsigned hint = isnew ? 0u : hhint[s];
-      const unsigned fsum = hval[s];
+      unsigned hint = 0u, fsum = 0u;
+      if constexpr (!UQ && !DD) { hint = isnew ? 0u : hhint[s]; fsum = hval[s]; }
       const bool live = is_hot ? g == 0 : have;
       if (__builtin_expect(__ballot(isnew) != 0ull, 0)) {
         // the tile that won the key published {row, HINT_NEW}; the hint goes back to "none"
@@ -710,8 +714,11 @@ __global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_uniq(WsDev w, PartA
   papply_route_tail(a, mode, gridDim.x);
 }
 // PA_DEDUP alone (the sharded apply's gradient pre-sum, kv_dedup_segment_sum's sums)
+#ifndef KV_PD_WAVES
+#define KV_PD_WAVES 6   // (no optimizer state in registers, 41 KB of LDS per 512-thread block: three blocks per CU)
+#endif
 template <int V, int LPR, int K, int TBP>
-__global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_dedup(WsDev w, PartArgs a) {
+__global__ void __launch_bounds__(TBP, TBP >= 512 ? KV_PD_WAVES : KV_PA_WAVES) k_papply_dedup(WsDev w, PartArgs a) {
   papply_body<OPT_ADAGRAD, V, LPR, K, TBP, PA_DEDUP>(w, a, PA_DEDUP);
 }
 template <int V, int LPR, int K>
