@@ -29,7 +29,10 @@ constexpr int HC2 = 512;    // entries per hot chunk of the entry-list apply: a 
                             // 1 M ids no key spans chunks and k_apply_fin is not launched
 
 constexpr int TB = 256;          // threads per block of the gather / maintenance kernels
-constexpr int TBT = 512;  // threads per block of the tile kernel
+#ifndef KV_TBT
+#define KV_TBT 512   // (A/B: 256 = 1024-id tiles, four tile blocks per CU)
+#endif
+constexpr int TBT = KV_TBT;  // threads per block of the tile kernel
 constexpr int IPT = 4;           // ids per thread in the tile kernel
 constexpr int TILE = TBT * IPT;  // ids per tile (2048): a key present in every tile contributes
                                  // N / 2048 entries to its partition, which keeps the partition

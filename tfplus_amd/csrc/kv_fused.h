@@ -103,13 +103,14 @@ struct LtSmem {
   unsigned* hist;          // [MAX_P + 1] per partition: entries (low 16) | positions (high 16); then the entries' frequency sums
   unsigned* wtot;          // [8]
 };
-static_assert((size_t)(LS + 1) * 8 >= (size_t)(LS + 1) * 4 + 16 + (size_t)(TILE + 1) * 4, "aliases fit");
+// lkeys' storage (+ 64 bytes) holds, once the hash insert is done: lrow [LS + 1], escan [TILE + 1] and the mrow image mr [TILE]
+constexpr size_t LT_KEYS_BYTES = (size_t)(LS + 1) * 8 + 64;
+static_assert(LT_KEYS_BYTES >= (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15) + (((size_t)(TILE + 1) * 4 + 15) & ~(size_t)15) + (size_t)TILE * 4, "aliases fit");
 
 __host__ __device__ inline size_t ltile_smem_bytes() {
-  size_t b = (size_t)(LS + 1) * 8 + 16;   // lkeys
+  size_t b = LT_KEYS_BYTES + 16;          // lkeys (then lrow, escan, mr)
   b += (size_t)(LS + 1) * 4 + 16;         // lcnt
   b += (size_t)(LS + 1) * 2 + 16;         // lpos
-  b += (size_t)TILE * 4 + 16;             // mr
   b += (size_t)(TILE + 1) * 2 + 16;       // lrun
   b += (size_t)(MAX_P + 1) * 4 + 16;      // hist
   b += 64;                                // wtot
@@ -118,12 +119,12 @@ __host__ __device__ inline size_t ltile_smem_bytes() {
 __device__ __forceinline__ LtSmem carve_ltile(char* base) {
   LtSmem s;
   auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~(size_t)15; return p; };
-  char* k0 = take((size_t)(LS + 1) * 8 + 16);
+  char* k0 = take(LT_KEYS_BYTES);
   s.lkeys = reinterpret_cast<long long*>(k0);
   s.lrow = reinterpret_cast<unsigned*>(k0);
   s.escan = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15));
+  s.mr = reinterpret_cast<unsigned*>(k0 + (((size_t)(LS + 1) * 4 + 15) & ~(size_t)15) + (((size_t)(TILE + 1) * 4 + 15) & ~(size_t)15));
   s.lcnt = reinterpret_cast<unsigned*>(take((size_t)(LS + 1) * 4));
-  s.mr = reinterpret_cast<unsigned*>(take((size_t)TILE * 4));
   s.lpos = reinterpret_cast<unsigned short*>(take((size_t)(LS + 1) * 2));
   s.lrun = reinterpret_cast<unsigned short*>(take((size_t)(TILE + 1) * 2));
   s.hist = reinterpret_cast<unsigned*>(take((size_t)(MAX_P + 1) * 4));
@@ -926,11 +927,11 @@ __global__ void __launch_bounds__(TBK, 4) k_part2(WsDev w, PartArgs a) { part2_b
 //                   by wave in order
 // The order of the additions depends on nothing but the list.  The positions of the next step are requested with
 // the rows of this one.
-constexpr int TBC = 512;
+constexpr int TBC = TBT;
 // k_ltsum runs tsum_body in the tile pass's own block: its waves' shares and the wave-by-wave meeting in LDS assume TBC
-// threads.  (A tile kernel rebuilt with fewer threads — round 3's TILE = 1024 experiment, 256 threads — left the waves
-// tsum_body waits on unstarted: their lmeta words were never written and the sums went to epart rows nobody owns, past
-// the buffer's end for the last tile.  That was the fault DESIGN.md's round-3 notes recorded without a cause.)
+// threads, so TBC IS TBT.  (Round 3's TILE = 1024 experiment rebuilt the tile kernel with 256 threads and left TBC at 512:
+// the waves tsum_body waited on never ran, their lmeta words were never written and the sums went to epart rows nobody
+// owns — past the buffer's end for the last tile.  With TBC = TBT the 1024-id tile runs: -DKV_TBT=256)
 static_assert(TBC == TBT, "k_ltsum: the tile pass and the tile sums share one block");
 // FROM_LDS: the tile's mrow image is read from LDS at mrow_l — the tile pass's own image (k_ltsum: LtSmem::mr), or the
 // copy k_tsum stages while the count is still on its way (one round trip in front of the rows instead of two); mc_l = mcount[tile]
