@@ -759,13 +759,7 @@ int launch_papply_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_t s
   if (q <= 1) KV_PA(4, 1, 1);
   if (q <= 2) KV_PA(4, 2, 1);
   if (q <= 4) KV_PA(4, 4, 1);
-#ifdef KV_PA_D32_L4K2
-  if (q <= 8) KV_PA(4, 4, 2);
-#elif defined(KV_PA_D32_L2K4)
-  if (q <= 8) KV_PA(4, 2, 4);
-#else
-  if (q <= 8) KV_PA(4, 8, 1);
-#endif
+  if (q <= 8) KV_PA(4, 8, 1);   // (dim 32 with 4 lanes x 2 vectors or 2 x 4 per key — 16 / 32 keys per wave and step: 102 / 177 us against 62.7)
   if (q <= 16) KV_PA(4, 8, 2);
   if (q <= 32) KV_PA(4, 16, 2);
   if (q <= 64) KV_PA(4, 64, 1);
