@@ -38,6 +38,16 @@ def test_bench_single_gpu_line():
   assert d["op_boundary"]["ms"] > 0 and d["no_token"]["ms_per_step"] > 0 and d["staged"]["ms_per_step"] > 0
   assert [x["zipf"] for x in d["skew_sweep"]] == [0.3, 0.8, 1.2] and "repeated_id_tolerance" in d
   assert all(0 < x["lookup_frac"] < 1 and x["lookup_rows_ready_frac"] >= x["lookup_frac"] * 0.9 for x in d["skew_sweep"])
+  # round 6: the unchanged graph's step and the sharded mechanism at world 1 are on the driver's line
+  ug = d["unchanged_graph"]
+  assert ug["ms_per_step"] > 0 and set(ug["parts_ms"]) == {"lookup_complete", "dedup_segment_sum", "apply_unique"}
+  sw = d["sharded_world1"]
+  assert "error" not in sw, sw
+  assert sw["ms_per_step"] > 0 and set(sw["phases_ms"]) == set(PHASES) and sw["overflowed_batches"] == 0
+  assert sw["phases_sum_ms"] >= 0.8 * sw["ms_per_step"]          # the phases account for the step (markers cost time: >= )
+  ph = cb["phases_s"]
+  assert set(ph) == {"lookup", "dedup_1_thread", "apply"} and all(v > 0 for v in ph.values())
+  assert str(cb["cores"]) in cb["threads_sweep_ids_per_s"] and cb["cores"] <= cb["host_cores"]
 
 
 @pytest.mark.gpu

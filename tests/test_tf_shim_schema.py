@@ -236,3 +236,29 @@ def test_shim_type_checks_against_a_mock_of_the_tf_api():
                       os.path.join(root, "tfplus_amd", "tf_shim", "kv_variable_ops_hip.cc")],
                      capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_unique_producer_rule(tmp_path):
+  """the shim takes the racy-unless-unique one-launch apply when `indices` is output 0 of a tf.unique
+  node.  The rule (tfplus_amd/tf_shim/unique_input.h, plain strings) is compiled and run here: the exact leaf Unique /
+  UniqueV2 with TensorFlow's _<n> suffix, slot 0 only — ':1' is the inverse index vector, UniqueWithCounts and a
+  placeholder called UniqueIds are not it, a control edge carries no tensor."""
+  import shutil
+  import subprocess
+  if shutil.which("g++") is None:
+    pytest.skip("needs g++")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cases = [("Unique", 1), ("Unique:0", 1), ("Unique_1:0", 1), ("tower/gradients/Unique_12", 1), ("a/b/UniqueV2:0", 1),
+           ("UniqueV2_3", 1), ("Unique:1", 0), ("scope/Unique:1", 0), ("UniqueWithCounts", 0), ("UniqueWithCounts:0", 0),
+           ("UniqueWithCounts:2", 0), ("UniqueIds", 0), ("UniqueIds:0", 0), ("Unique_", 0), ("Unique_x1", 0),
+           ("Unique_1a", 0), ("^Unique", 0), ("scope/^Unique", 0), ("NotUnique", 0), ("unique", 0), ("", 0),
+           ("Unique/read:0", 0), ("Unique:00", 0), ("UniqueV2:1", 0), ("UniqueV3", 0)]
+  src = tmp_path / "u.cc"
+  src.write_text('#include "unique_input.h"\n#include <cstdio>\nint main(int c, char** v) { for (int i = 1; i < c; ++i) '
+                 'std::printf("%d\\n", kv_shim::InputIsUniqueValues(v[i]) ? 1 : 0); return 0; }\n')
+  exe = tmp_path / "u"
+  subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "tfplus_amd", "tf_shim"), "-o", str(exe), str(src)])
+  # (an empty argv string is passed through as is)
+  out = subprocess.run([str(exe)] + [c for c, _ in cases], capture_output=True, text=True, check=True).stdout.split()
+  got = [int(x) for x in out]
+  assert got == [w for _, w in cases], [(c, g, w) for (c, w), g in zip(cases, got) if g != w]

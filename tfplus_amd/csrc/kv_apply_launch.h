@@ -17,14 +17,8 @@ int launch_apply_t(const WsDev& wd, const PartArgs& pa, hipStream_t s, const Mul
   do {                                                                                             \
     const size_t sh = span == 1 ? (size_t)(TBF / 64) * D * 4 + 16 : 0;                              \
     if (span != 1) {  /* one resident generation of blocks: a second one would start when the first ends */  \
-      static const int resident = [] {                                                             \
-        int nb = 0, cus = 0, dev = 0;                                                              \
-        hipGetDevice(&dev);                                                                        \
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                   \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_apply<MODE, OPT, V, LPR, K>, TBS, 0) != hipSuccess || nb < 1) nb = 4; \
-        if (nb > 6) nb = 6;   /* > 96 SGPRs: the hardware admits 6 blocks of 256 threads per CU */   \
-        return nb * (cus > 0 ? cus : 256);                                                         \
-      }();                                                                                         \
+      struct ApTag {};                                                                             \
+      const int resident = resident_blocks<ApTag>(k_apply<MODE, OPT, V, LPR, K>, TBS, 6, 4);   /* per device */ \
       if ((int)nchunks > resident) grid_ = resident; else grid_ = (int)nchunks;                     \
     }                                                                                              \
     if constexpr (MODE == MODE_APPLY && V == 4) {                                                  \

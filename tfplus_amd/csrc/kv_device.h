@@ -164,6 +164,27 @@ struct WsDev {
 #define KV_STAMPT(slot) do { } while (0)
 #endif
 
+// Blocks of `threads` threads of kernel `k` that are resident at once on the CURRENT device (CUs x occupancy, at most
+// `cap_per_cu` per CU: above 96 SGPRs the hardware admits 6 blocks of 256 threads, one fewer than the API says), cached
+// PER DEVICE: a process that drives GPUs with different CU counts or partition modes gets each device's own number
+// (a function-local static kept the first caller's device).  `Tag` makes the cache one per call site.
+template <typename Tag, typename Kernel>
+static inline int resident_blocks(Kernel k, int threads, int cap_per_cu, int fallback_per_cu) {
+  constexpr int MAXDEV = 64;
+  static int cache[MAXDEV];   // 0 = not asked yet (benign race: every thread computes the same number)
+  int dev = 0;
+  hipGetDevice(&dev);
+  const bool slot = dev >= 0 && dev < MAXDEV;
+  if (slot) { const int c = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED); if (c > 0) return c; }
+  int nb = 0, cus = 0;
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, threads, 0) != hipSuccess || nb < 1) nb = fallback_per_cu;
+  if (nb > cap_per_cu) nb = cap_per_cu;
+  const int r = nb * (cus > 0 ? cus : 256);
+  if (slot) __atomic_store_n(&cache[dev], r, __ATOMIC_RELAXED);
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------

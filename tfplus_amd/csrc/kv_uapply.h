@@ -287,14 +287,8 @@ int launch_uapply_t(const PartArgs& pa, const void* ids, int ids32, long long n,
 #define KV_UA(V, LPR, K)                                                                                        \
   do {                                                                                                          \
     constexpr int G = 64 / LPR;                                                                                 \
-    static const int resident = [] {                                                                            \
-      int nb = 0, cus = 0, dev = 0;                                                                             \
-      hipGetDevice(&dev);                                                                                       \
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                                  \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_uapply<OPT, V, LPR, K>, 256, 0) != hipSuccess || nb < 1) nb = 2; \
-      if (nb > 6) nb = 6;   /* > 96 SGPRs: the hardware admits 6 blocks of 256 threads per CU */                 \
-      return nb * (cus > 0 ? cus : 256);                                                                        \
-    }();                                                                                                        \
+    struct UaTag {};                                                                                            \
+    const int resident = resident_blocks<UaTag>(k_uapply<OPT, V, LPR, K>, 256, 6, 2);   /* per device */          \
     const long long nbatch = (n + G - 1) / G;                                                                   \
     const long long want = (nbatch + 3) / 4;                                                                    \
     int grid = (int)(want < 1 ? 1 : want > resident ? resident : want);                                         \

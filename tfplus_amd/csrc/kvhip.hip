@@ -1525,14 +1525,14 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
   Workspace& ws = t->ws;
   if (ws.seg_cap < num_segments) {
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;
     const long long want = std::max<long long>(num_segments, ws.seg_cap * 2);
     ws.seg_cap = 0;
     if ((rc = regrow(&ws.seg_off, (size_t)(want + 1)))) return rc;
     ws.seg_cap = want;
   }
   if (fused && ws.pos_cap < n) {   // every position's entry in its tile (k_ltile files it for the combiner)
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;
     ws.pos_cap = 0;
     if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
     ws.pos_cap = std::max<long long>(n, ws.cap_n);
@@ -2427,7 +2427,7 @@ static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* i
   Workspace& ws = t->ws;
   int rc;
   if (ws.pos_cap < n) {
-    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = ws_sync(s))) return rc;   // (refused under a stream capture before anything is queued, like ensure_workspace)
     ws.pos_cap = 0;
     if ((rc = regrow(&ws.pos_ent, (size_t)std::max<long long>(n, ws.cap_n)))) return rc;
     ws.pos_cap = std::max<long long>(n, ws.cap_n);
@@ -3889,6 +3889,13 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
   DeviceGuard dg(sh->table->device);
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  // The lossless mode's agreement reads a device word on the host: one stream synchronisation, not allowed inside a stream
+  // capture.  Refused HERE, before the communicator's stream is forked into the capture and before anything is queued (a
+  // refusal behind the fork would leave the side stream unjoined and invalidate the caller's capture).
+  if (sh->lossless && (stream_is_capturing(s) || stream_is_capturing(comm->stream)))
+    return fail(KV_FAILED_PRECONDITION, "kv_shard_lookup under stream capture: the lossless mode (the default) synchronises once per "
+                                        "lookup; capture sharded steps with kv_shard_set_lossless(shard, 0) and a peer_capacity "
+                                        "sized for the workload");
   if ((rc = shard_verify(sh, comm))) return rc;
   const unsigned seen = shard_take_flag(sh);
   hipStream_t w = comm->stream;   // phases and exchanges in one queue: no event hop between a kernel and its exchange
@@ -3910,12 +3917,6 @@ int kv_shard_lookup(kv_shard_t sh, kv_comm_t comm, const void* ids, int64_t n, f
     k_seg_headers<<<1, MAXW, 0, w>>>(sh->counts, sh->world, sh->C, sh->send_pairs, sh->need);
   }
   if (sh->lossless) {   // every rank takes part in the agreement, whatever its own route did
-    // (the agreement reads a device word on the host: one stream synchronisation — not allowed inside a stream capture)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(w, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-      return fail(KV_FAILED_PRECONDITION, "kv_shard_lookup under stream capture: the lossless mode (the default) synchronises once per "
-                                          "lookup; capture sharded steps with kv_shard_set_lossless(shard, 0) and a peer_capacity "
-                                          "sized for the workload");
     char grown = 0;
     if ((rc = shard_agree_many(&sh, 1, comm, w, &grown))) return rc;
     if (grown) {
@@ -4172,6 +4173,13 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
   if (!ids || !n || !outs) return fail(KV_INVALID_ARGUMENT, "kv_multi_shard_lookup: null argument list");
   DeviceGuard dg(shards[0]->table->device);
   hipStream_t s = (hipStream_t)stream, w = comm->stream;
+  {   // as in kv_shard_lookup: the lossless agreement's synchronisation is refused before the fork, not behind it
+    bool lossless = false;
+    for (int k = 0; k < ntab; ++k) lossless = lossless || shards[k]->lossless;
+    if (lossless && (stream_is_capturing(s) || stream_is_capturing(w)))
+      return fail(KV_FAILED_PRECONDITION, "kv_multi_shard_lookup under stream capture: the lossless mode (the default) synchronises once "
+                                          "per lookup; capture sharded steps with kv_shard_set_lossless(shard, 0)");
+  }
   for (int k = 0; k < ntab; ++k)
     if ((rc = shard_verify(shards[k], comm))) return rc;
   std::vector<unsigned> seen(ntab);
@@ -4223,10 +4231,6 @@ int kv_multi_shard_lookup(const kv_shard_t* shards, int ntab, kv_comm_t comm, co
     std::vector<char> grown(ntab, 0);
     bool any_lossless = false;
     for (int k = 0; k < ntab; ++k) any_lossless = any_lossless || shards[k]->lossless;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (any_lossless && hipStreamIsCapturing(w, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-      return fail(KV_FAILED_PRECONDITION, "kv_multi_shard_lookup under stream capture: the lossless mode (the default) synchronises once "
-                                          "per lookup; capture sharded steps with kv_shard_set_lossless(shard, 0)");
     if ((rc = shard_agree_many(shards, ntab, comm, w, grown.data()))) return rc;
     for (int k = 0; k < ntab; ++k)
       if (grown[k]) {

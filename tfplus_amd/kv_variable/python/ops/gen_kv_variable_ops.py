@@ -462,7 +462,9 @@ def kv_set_deterministic(table_handle, on=True):
 
 
 def kv_set_fast_math(table_handle, on=True):
-  """1-ulp hardware sqrt / reciprocal in the optimizers' row math (default) or the IEEE sequences (kvhip.h kv_set_fast_math)."""
+  """Opt-in: the optimizers' row math on the 1-ulp hardware sqrt / reciprocal instructions.  The LIBRARY default (never
+  calling this, or on=False) is the IEEE sequences — bit-parity with the oracle from the same summed gradient; with
+  on=True an element whose update cancels can leave rtol 1e-6 (kvhip.h kv_set_fast_math).  Ignored in deterministic mode."""
   _lib.check(_lib.lib().kv_set_fast_math(table_handle.ptr, int(bool(on))))
 
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "kvhip.h"
+#include "unique_input.h"
 #include "tensorflow/core/framework/common_shape_fns.h"
 #include "tensorflow/core/framework/node_def.pb.h"
 #include "tensorflow/core/framework/op.h"
@@ -746,21 +747,17 @@ REGISTER_OP("KvVariableGroupSparseApplyAdamV4")
 
 // Are the `indices` of this optimizer node unique?  In an UNCHANGED reference graph they are: the processor patch
 // (python/ops/variable_scope.py:1096-1106) sends the gradient through TF-core's _deduplicate_indexed_slices, whose
-// array_ops.unique produces the node ".../Unique" that feeds input `input` here.  Then the op is ONE launch
-// (kv_apply_*_unique, include/kvhip.h).  The test is the producer's name — a heuristic; the promise it makes is guarded on
-// the device (an id listed twice raises the table's error word: the next op on the table fails with InvalidArgument
-// instead of a silent race).  TFPLUS_KV_UNIQUE_INDICES=0 never takes that path, =1 always does.
+// array_ops.unique produces the node ".../Unique" whose output 0 feeds input `input` here.  Then the op is ONE launch
+// (kv_apply_*_unique, include/kvhip.h).  The test is the producer's name and output slot (unique_input.h: the exact leaf
+// Unique / UniqueV2 with TensorFlow's _<n> suffix, slot 0 only — ":1" is the inverse index vector) — a heuristic; the
+// promise it makes is also guarded on the device (an id listed twice raises the table's error word: the next op on the
+// table fails with InvalidArgument).  TFPLUS_KV_UNIQUE_INDICES=0 never takes that path, =1 always does.
 static bool IndicesComeFromUnique(const NodeDef& def, int input) {
   const char* e = std::getenv("TFPLUS_KV_UNIQUE_INDICES");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
   if (input >= def.input_size()) return false;
-  std::string in = def.input(input);   // "scope/Unique", "scope/Unique:0"
-  const size_t colon = in.rfind(':');
-  if (colon != std::string::npos) in.resize(colon);
-  const size_t slash = in.rfind('/');
-  const std::string leaf = slash == std::string::npos ? in : in.substr(slash + 1);
-  return leaf.rfind("Unique", 0) == 0;   // Unique, Unique_1, UniqueV2 ...
+  return kv_shim::InputIsUniqueValues(def.input(input));
 }
 
 // gradient + indices of an optimizer op on the var's ring; the var's stream carries the whole op
