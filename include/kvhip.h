@@ -208,7 +208,10 @@ int kv_set_deterministic(kv_handle_t h, int on);
  * (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, 1 ulp each).  Measured at configs[1]: -1.3 us of the 64 us apply kernel (the
  * kernel is bound by its memory round trips, not by its arithmetic), and an element whose update cancels (|x| three
  * orders below its row's scale) can leave the parity tests' rtol 1e-6 / atol 1e-9 (one element in 39 000 did): hence
- * opt-in.  A table in deterministic mode always uses the IEEE sequences. */
+ * opt-in.  SparseGroupFtrl is the optimizer it suits least: its linear term (sqrt(n) - sqrt(a)) / lr * x cancels by
+ * construction, so each root's ulp reaches the state multiplied by |x| / lr (tests/test_gpu_fast_math.py states the
+ * bound: 4e-6 absolute at lr = 0.05 against 1e-7 for the other three).  A table in deterministic mode always uses the
+ * IEEE sequences. */
 int kv_set_fast_math(kv_handle_t h, int on);
 
 /* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that

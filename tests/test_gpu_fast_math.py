@@ -10,6 +10,8 @@ What is pinned here:
     parity tests use (1e-7, rows of scale O(1)): an element whose update CANCELS (|x| orders below its row's scale) is
     bounded relative to the terms that cancelled, not to itself — round 6's first run of this test met one such element
     in 209 408 (|x| = 1.2e-5 in a row of scale 1, off by 2.0e-8 = 1.6e-3 of itself), the case kvhip.h documents;
+    SparseGroupFtrl gets its own absolute term (4e-6 at the tests' lr = 0.05): its (sqrt(n) - sqrt(a)) / lr * x cancels
+    by construction and multiplies the roots' ulps by |x| / lr — derived at FTRL_FAST_ATOL below;
   * on = 1 really changes the arithmetic (some element differs from the IEEE twin), so the test would notice a switch
     that does nothing;
   * a table in deterministic mode ignores it: same bits as the IEEE twin.
@@ -25,6 +27,15 @@ from test_gpu_parity import _np, _beta_pows, _assert_same_table  # noqa: E402
 from test_gpu_unique_apply import _run, _oracle, _tables, _same_bits  # noqa: E402
 
 FAST_RTOL, FAST_ATOL = 2e-6, 1e-7
+# SparseGroupFtrl's linear term subtracts two square roots and divides by lr — z += g' - (sqrt(n) - sqrt(a)) / lr * x
+# (training_ops.cc:726-733) — so a 1-ulp error of each root (2^-24 * sqrt(a) ~ 2e-8 at a ~ 0.1) reaches z multiplied by
+# |x| / lr: with the tests' lr = 0.05 and |x| <= 4 that is 2 * 2e-8 * 4 / 0.05 = 3.2e-6 absolute, and x follows z.  The
+# first run measured 2.3e-7 at most (1.3 % of the elements beyond 1e-7); the bound, not the luck, is what is stated.
+FTRL_FAST_ATOL = 4e-6
+
+
+def _atol(name):
+  return FTRL_FAST_ATOL if name == "ftrl" else FAST_ATOL
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +70,7 @@ def test_fast_math_within_stated_tolerance_of_oracle(ops, name, D):
   ops.kv_set_fast_math(hf[0], True)
   keys = _steps(ops, name, D, [hf, hi], oracle=os_)
   for h, o in zip(hf, os_):
-    _assert_same_table(ops, h, o, keys, rtol=FAST_RTOL, atol=FAST_ATOL)
+    _assert_same_table(ops, h, o, keys, rtol=FAST_RTOL, atol=_atol(name))
   # the switch does something: at least one state element differs from the IEEE twin
   differs = False
   uk = np.unique(keys)
@@ -76,7 +87,7 @@ def test_fast_math_unique_path_within_tolerance(ops, name):
   ops.kv_set_fast_math(hf[0], True)
   keys = _steps(ops, name, D, [hf, hi], oracle=os_, unique=True)
   for h, o in zip(hf, os_):
-    _assert_same_table(ops, h, o, keys, rtol=FAST_RTOL, atol=FAST_ATOL)
+    _assert_same_table(ops, h, o, keys, rtol=FAST_RTOL, atol=_atol(name))
 
 
 @pytest.mark.parametrize("name", ["adam4", "adam3", "adagrad", "ftrl"])

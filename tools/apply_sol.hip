@@ -7,10 +7,8 @@
 //     * every gradient row read ONCE (N x 4D bytes), straight into its key's sum;
 //     * every key's state read and written once: var row (D), slot row m | v | z (3D), both 16-byte records.
 //
-//   cold key (<= HOTMIN positions): one 8-lane group per key, 8 keys per wave; its gradient rows 4 at a time.
-//   hot key: chunks of CH positions, one wave per chunk (8 groups x CH / 8 rows, xor-shuffle reduce), the chunk's sum added
-//   to the key's accumulator with float atomics (memory-side on gfx950), a returning counter add tells the LAST chunk,
-//   whose wave reads the accumulator past its L2 (agent-scope atomic loads), clears it and does the key's update.
+//   cold key (<= HOTMIN positions): one 8-lane group per key, 8 keys per wave; its gradient rows RB at a time.
+//   hot key: a tree of fan-in 64 over leaves of 256 positions (below): no atomics on data, one counter add per node.
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o build/apply_sol.so tools/apply_sol.hip
 #include <hip/hip_runtime.h>
@@ -74,70 +72,116 @@ __device__ __forceinline__ void update_key(float* __restrict__ vrows, float* __r
   }
 }
 
-// items: [0, nhot) hot chunks {start, cnt, row, hot index | chunks of the key << 16}; then the cold keys, 8 per wave item:
-// cold[k] = {start, cnt, row, -}
+// Hot keys are reduced by a TREE (memory-side float atomics into one row serialise at ~95 ns per 128-B add: the head key's
+// 2.9 k chunk sums took 274 us that way — measured with this tool's first version).  A leaf = one wave summing up to LEAF
+// positions of one key (64 rows per round trip, the next step's positions requested with this step's rows); the leaves of a
+// key form groups of at most 64 siblings; a leaf writes its sum to its slot of `hpart` past the L2 (sc1), counts itself on the
+// group's counter, and the wave whose count came LAST sums the group's slots (one round trip) and goes on as a node of the
+// next level — until the root, which does the key's state update.
+//   leaf[it]  = {start, cnt, group, slot}
+//   group[g]  = {first slot, siblings, parent group or NONE, its slot in the parent | row of the key (root)}
+// then the cold keys, 8 per wave item: cold[k] = {start, cnt, row, first position}.
+constexpr unsigned NONE = 0xFFFFFFFFu;
+constexpr int LEAF = 256;
+
 template <int RB>
 __global__ void __launch_bounds__(256) k_apply_sol(const float* __restrict__ grad, const unsigned* __restrict__ kpos,
-                                                   const uint4* __restrict__ hot, unsigned nhot, const uint4* __restrict__ cold,
-                                                   unsigned ncold, float* __restrict__ vrows, float* __restrict__ srows,
-                                                   uint4* __restrict__ vmeta, uint4* __restrict__ smeta, float* __restrict__ hotacc,
-                                                   unsigned* __restrict__ hotcnt, Hp h, unsigned day, int state) {
+                                                   const uint4* __restrict__ leaf, unsigned nhot, const uint4* __restrict__ group,
+                                                   const uint4* __restrict__ cold, unsigned ncold, float* __restrict__ vrows,
+                                                   float* __restrict__ srows, uint4* __restrict__ vmeta, uint4* __restrict__ smeta,
+                                                   float* __restrict__ hpart, unsigned* __restrict__ gcnt, Hp h, unsigned day, int state) {
   const int wl = threadIdx.x & 63, lane = wl % LPR, g = wl / LPR;
   const unsigned nwaves = gridDim.x * (blockDim.x / 64);
   const unsigned nitems = nhot + (ncold + G - 1) / G;
   const float4* gr = reinterpret_cast<const float4*>(grad);
-  for (unsigned it = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); it < nitems; it += nwaves) {
+  const bool nograd = (state & 2) != 0;   // the state read-modify-write alone (no gradient row is read)
+  state &= 1;
+  auto record = [&](unsigned it) -> uint4 {
+    if (it >= nitems) return make_uint4(0u, 0u, 0u, 0u);
+    if (it < nhot) return leaf[it];
+    const unsigned k = (it - nhot) * G + g;
+    uint4 c = cold[k < ncold ? k : ncold - 1u];
+    if (k >= ncold) c.y = 0u;
+    return c;
+  };
+  unsigned it = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  uint4 cn = record(it);
+  for (; it < nitems; it += nwaves) {
+    const uint4 c = cn;
+    cn = record(it + nwaves);
     if (it < nhot) {
-      const uint4 c = hot[it];
       const unsigned start = c.x, cnt = c.y;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (unsigned j0 = 0; j0 < cnt; j0 += G * RB) {
-        unsigned p[RB];
-        float4 v[RB];
+      unsigned kp = kpos[start + ((unsigned)wl < cnt ? (unsigned)wl : 0u)];
+      for (unsigned j0 = 0; j0 < cnt; j0 += 64) {   // wave-uniform
+        float4 v[8];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) { const unsigned jj = j0 + j * G + g; p[j] = kpos[start + (jj < cnt ? jj : 0u)]; }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) v[j] = ld_stream(gr + (size_t)p[j] * LPR + lane);
-#pragma unroll
-        for (int j = 0; j < RB; ++j) if (j0 + j * G + g < cnt) add4(acc, v[j]);
-      }
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-      }
-      const unsigned hi = c.w & 0xFFFFu, nch = c.w >> 16;
-      float* a = hotacc + (size_t)hi * D + lane * 4;
-      bool last = nch == 1u;
-      if (nch > 1u) {
-        if (g == 0) { atomicAdd(a, acc.x); atomicAdd(a + 1, acc.y); atomicAdd(a + 2, acc.z); atomicAdd(a + 3, acc.w); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds are performed (memory side) before the chunk is counted
-        unsigned old = 0;
-        if (wl == 0) old = __hip_atomic_fetch_add(&hotcnt[hi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        last = old == nch - 1u;
-        if (last) {
-          if (g == 0) {
-            acc.x = __hip_atomic_exchange(a, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc.y = __hip_atomic_exchange(a + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc.z = __hip_atomic_exchange(a + 2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc.w = __hip_atomic_exchange(a + 3, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (wl == 0) __hip_atomic_store(&hotcnt[hi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 8; ++j) {
+          const unsigned p = __shfl(kp, g * 8 + j);
+          v[j] = nograd ? make_float4(1e-3f, 1e-3f, 1e-3f, 1e-3f) : ld_stream(gr + (size_t)p * LPR + lane);
         }
+        const unsigned nx = j0 + 64 + (unsigned)wl;
+        kp = kpos[start + (nx < cnt ? nx : 0u)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j0 + (unsigned)(g * 8 + j) < cnt) add4(acc, v[j]);
       }
-      if (last && state) {
-        const KeyState ks = load_state(vrows, srows, vmeta, smeta, c.z, g == 0, lane);
-        update_key(vrows, srows, vmeta, smeta, c.z, g == 0, lane, acc, h, day, ks);
+      unsigned gi = c.z, slot = c.w;
+      for (;;) {   // up the tree while this wave is the last of its group
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+        }
+        const uint4 gd = group[gi];
+        if (gd.y == 1u && gd.z == NONE) {   // the root: the key's sum is complete
+          if (state) {
+            const KeyState ks = load_state(vrows, srows, vmeta, smeta, gd.w, g == 0, lane);
+            update_key(vrows, srows, vmeta, smeta, gd.w, g == 0, lane, acc, h, day, ks);
+          }
+          break;
+        }
+        float* a = hpart + (size_t)slot * D + lane * 4;
+        if (g == 0) {
+          __hip_atomic_store(a, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a + 3, acc.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot is written (past the L2) before the leaf counts itself
+        unsigned old = 0;
+        if (wl == 0) old = __hip_atomic_fetch_add(&gcnt[gi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        if (old != gd.y - 1u) break;
+        if (wl == 0) __hip_atomic_store(&gcnt[gi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the group's slots: 8 lane groups x 8 rows, read past the L2
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned sidx = (unsigned)(g * 8 + j);
+          const float* q = hpart + (size_t)(gd.x + (sidx < gd.y ? sidx : 0u)) * D + lane * 4;
+          float4 v;
+          v.x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sidx < gd.y) add4(acc, v);
+        }
+        if (gd.z == NONE) {   // this group was the key's top level: its sum is the key's (reduced below), gd.w = the row
+#pragma unroll
+          for (int o = LPR; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+          }
+          if (state) {
+            const KeyState ks = load_state(vrows, srows, vmeta, smeta, gd.w, g == 0, lane);
+            update_key(vrows, srows, vmeta, smeta, gd.w, g == 0, lane, acc, h, day, ks);
+          }
+          break;
+        }
+        gi = gd.z; slot = gd.w;
       }
     } else {
-      const unsigned k = (it - nhot) * G + g;
-      const bool have = k < ncold;
-      const uint4 c = cold[have ? k : ncold - 1u];
-      const unsigned start = c.x, cnt = have ? c.y : 0u;
+      const unsigned start = c.x, cnt = c.y;
+      const bool have = cnt != 0u;
       KeyState ks{};
-      if (state) ks = load_state(vrows, srows, vmeta, smeta, c.z, have, lane);   // with the first gradient rows: one round trip
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (unsigned j0 = 0; __ballot(j0 < cnt) != 0ull; j0 += RB) {
+      if (state) ks = load_state(vrows, srows, vmeta, smeta, c.z, have, lane);   // with the first gradient row: one round trip
+      float4 acc = nograd ? make_float4(1e-3f, 1e-3f, 1e-3f, 1e-3f) : ld_stream(gr + (size_t)c.w * LPR + lane);
+      if (!have) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (unsigned j0 = 1; !nograd && __ballot(j0 < cnt) != 0ull; j0 += RB) {
         unsigned p[RB];
         float4 v[RB];
 #pragma unroll
@@ -148,23 +192,23 @@ __global__ void __launch_bounds__(256) k_apply_sol(const float* __restrict__ gra
         for (int j = 0; j < RB; ++j) if (j0 + j < cnt) add4(acc, v[j]);
       }
       if (state) update_key(vrows, srows, vmeta, smeta, c.z, have, lane, acc, h, day, ks);
-      else if (have && acc.x == 1.2345e-30f) hotacc[0] = acc.x;   // (keeps the sums alive)
+      else if (have && acc.x == 1.2345e-30f) hpart[0] = acc.x;   // (keeps the sums alive)
     }
   }
 }
 }  // namespace
 
-// state = 0: the gradient stream alone (sums dropped); 1: the whole apply.  rb: gradient rows in flight per lane group (2 / 4 / 8)
-extern "C" int sol_apply(const float* grad, const unsigned* kpos, const void* hot, unsigned nhot, const void* cold, unsigned ncold,
-                         float* vrows, float* srows, void* vmeta, void* smeta, float* hotacc, unsigned* hotcnt, float lr, float b1p,
-                         float b2p, unsigned day, int grid, int rb, int state, void* stream) {
+// state = 0: the gradient stream alone (sums dropped); 1: the whole apply; 3: the state read-modify-write alone.  rb: gradient rows in flight per lane group (2 / 4 / 8)
+extern "C" int sol_apply(const float* grad, const unsigned* kpos, const void* leaf, unsigned nhot, const void* group, const void* cold,
+                         unsigned ncold, float* vrows, float* srows, void* vmeta, void* smeta, float* hpart, unsigned* gcnt, float lr,
+                         float b1p, float b2p, unsigned day, int grid, int rb, int state, void* stream) {
   Hp h;
   h.lr = lr; h.b1 = 0.9f; h.b2 = 0.999f; h.eps = 1e-8f;
   h.alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
   hipStream_t s = (hipStream_t)stream;
 #define GO(RB)                                                                                                                  \
-  k_apply_sol<RB><<<grid, 256, 0, s>>>(grad, kpos, (const uint4*)hot, nhot, (const uint4*)cold, ncold, vrows, srows,            \
-                                       (uint4*)vmeta, (uint4*)smeta, hotacc, hotcnt, h, day, state)
+  k_apply_sol<RB><<<grid, 256, 0, s>>>(grad, kpos, (const uint4*)leaf, nhot, (const uint4*)group, (const uint4*)cold, ncold,    \
+                                       vrows, srows, (uint4*)vmeta, (uint4*)smeta, hpart, gcnt, h, day, state)
   if (rb <= 2) GO(2); else if (rb <= 4) GO(4); else GO(8);
 #undef GO
   return (int)hipGetLastError();

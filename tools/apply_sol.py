@@ -18,7 +18,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-
 S = ctypes.CDLL(so)
 dev = torch.device("cuda", 0)
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
-N, D, HOTMIN, CH = 1_000_000, 32, 16, 256
+N, D, HOTMIN, LEAF = 1_000_000, 32, 16, 256
 gen = torch.Generator(device=dev).manual_seed(bench.SEED)
 L = _lib.lib()
 
@@ -58,31 +58,50 @@ for _ in range(8):
   # cold keys, most positions first (the lane groups of a wave get keys of equal length)
   ck = torch.nonzero(~hotm).flatten()
   ck = ck[torch.argsort(cnt[ck], descending=True, stable=True)]
-  cold = torch.stack([start[ck], cnt[ck], u[ck], torch.zeros_like(ck)], 1).to(torch.int32).contiguous()
-  # hot keys in chunks of CH positions
+  cold = torch.stack([start[ck], cnt[ck], u[ck], kpos[start[ck]].to(torch.int64)], 1).to(torch.int32).contiguous()
+  # hot keys: leaves of LEAF positions, groups of at most 64 siblings, at most two levels (tools/apply_sol.hip)
   hk = torch.nonzero(hotm).flatten()
-  nch = (cnt[hk] + CH - 1) // CH
-  rep = torch.repeat_interleave(torch.arange(hk.numel(), device=dev), nch)
-  first = torch.cumsum(nch, 0) - nch
-  cix = torch.arange(rep.numel(), device=dev) - first[rep]
-  cstart = start[hk][rep] + cix * CH
-  ccnt = torch.minimum(cnt[hk][rep] - cix * CH, torch.tensor(CH, device=dev))
-  hot = torch.stack([cstart, ccnt, u[hk][rep], rep | (nch[rep] << 16)], 1).to(torch.int32).contiguous()
-  pool.append(dict(ids=ids, grad=grad, kpos=kpos.contiguous(), cold=cold, hot=hot, U=int(u.numel()), nhotkeys=int(hk.numel()),
-                   hotpos=int(cnt[hk].sum()), u=u, inv=inv))
-hotacc = torch.zeros((max(p["nhotkeys"] for p in pool) + 1, D), device=dev)
-hotcnt = torch.zeros(hotacc.shape[0], dtype=torch.int32, device=dev)
+  h_start, h_cnt, h_row = start[hk].tolist(), cnt[hk].tolist(), u[hk].tolist()
+  NONE = 0xFFFFFFFF
+  leaves, groups, nslots = [], [], 0
+  for s0, c0, r0 in zip(h_start, h_cnt, h_row):
+    nl = (c0 + LEAF - 1) // LEAF
+    if nl == 1:
+      groups.append((0, 1, NONE, r0)); leaves.append((s0, c0, len(groups) - 1, 0)); continue
+    if nl <= 64:
+      groups.append((nslots, nl, NONE, r0)); gi = len(groups) - 1
+      for j in range(nl):
+        leaves.append((s0 + j * LEAF, min(LEAF, c0 - j * LEAF), gi, nslots + j))
+      nslots += nl
+      continue
+    n1 = (nl + 63) // 64
+    groups.append((nslots, n1, NONE, r0)); top = len(groups) - 1
+    top_first = nslots; nslots += n1
+    for q in range(n1):
+      ns = min(64, nl - q * 64)
+      groups.append((nslots, ns, top, top_first + q)); gq = len(groups) - 1
+      for j in range(ns):
+        jj = q * 64 + j
+        leaves.append((s0 + jj * LEAF, min(LEAF, c0 - jj * LEAF), gq, nslots + j))
+      nslots += ns
+  # the longest leaves first (a wave's items are dealt round-robin)
+  leaves.sort(key=lambda t: -t[1])
+  i32 = lambda rows: torch.tensor(rows, dtype=torch.int64, device=dev).to(torch.int32).contiguous()
+  pool.append(dict(ids=ids, grad=grad, kpos=kpos.contiguous(), cold=cold, leaf=i32(leaves), group=i32(groups), nslots=nslots,
+                   U=int(u.numel()), nhotkeys=int(hk.numel()), hotpos=int(cnt[hk].sum()), u=u, inv=inv))
+hpart = torch.zeros((max(p["nslots"] for p in pool) + 64, D), device=dev)
+gcnt = torch.zeros(max(p["group"].shape[0] for p in pool) + 1, dtype=torch.int32, device=dev)
 out = torch.empty((N, D), device=dev)
 U = sum(p["U"] for p in pool) / len(pool)
-print("K = %d, N = %d, D = %d: %.0f distinct keys per batch, %d hot keys (> %d positions) holding %d positions in %d chunks of %d"
-      % (K, N, D, U, pool[0]["nhotkeys"], HOTMIN, pool[0]["hotpos"], pool[0]["hot"].shape[0], CH))
+print("K = %d, N = %d, D = %d: %.0f distinct keys per batch, %d hot keys (> %d positions) holding %d positions in %d leaves of <= %d, %d tree groups"
+      % (K, N, D, U, pool[0]["nhotkeys"], HOTMIN, pool[0]["hotpos"], pool[0]["leaf"].shape[0], LEAF, pool[0]["group"].shape[0]))
 
 
 def sol(p, grid, rb, state, b1p=0.5, b2p=0.9):
-  rc = S.sol_apply(ctypes.c_void_p(p["grad"].data_ptr()), ctypes.c_void_p(p["kpos"].data_ptr()), ctypes.c_void_p(p["hot"].data_ptr()),
-                   p["hot"].shape[0], ctypes.c_void_p(p["cold"].data_ptr()), p["cold"].shape[0], ctypes.c_void_p(vrows.data_ptr()),
-                   ctypes.c_void_p(srows.data_ptr()), ctypes.c_void_p(vmeta.data_ptr()), ctypes.c_void_p(smeta.data_ptr()),
-                   ctypes.c_void_p(hotacc.data_ptr()), ctypes.c_void_p(hotcnt.data_ptr()), ctypes.c_float(1e-3), ctypes.c_float(b1p),
+  rc = S.sol_apply(ctypes.c_void_p(p["grad"].data_ptr()), ctypes.c_void_p(p["kpos"].data_ptr()), ctypes.c_void_p(p["leaf"].data_ptr()),
+                   p["leaf"].shape[0], ctypes.c_void_p(p["group"].data_ptr()), ctypes.c_void_p(p["cold"].data_ptr()), p["cold"].shape[0],
+                   ctypes.c_void_p(vrows.data_ptr()), ctypes.c_void_p(srows.data_ptr()), ctypes.c_void_p(vmeta.data_ptr()),
+                   ctypes.c_void_p(smeta.data_ptr()), ctypes.c_void_p(hpart.data_ptr()), ctypes.c_void_p(gcnt.data_ptr()), ctypes.c_float(1e-3), ctypes.c_float(b1p),
                    ctypes.c_float(b2p), 20000, grid, rb, state, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
   assert rc == 0, rc
 
@@ -96,7 +115,7 @@ got = srows[p["u"], :D]
 err = ((got - want).abs().max() / want.abs().max()).item()
 print("check: slot m after one step against 0.1 * index_add of the gradient: max error %.2e of the largest element" % err)
 assert err < 1e-4, err
-assert int(hotcnt.sum()) == 0 and float(hotacc.abs().sum()) == 0.0
+assert int(gcnt.sum()) == 0
 srows.zero_(); vrows.fill_(0.01)
 
 
@@ -146,4 +165,8 @@ for grid in (2048,):
     us = loop("sol", grid=grid, rb=rb, state=0)
     print("  the gradient stream alone (sums dropped), grid %4d, %d in flight %6.1f us   (%.0f MB at %.2f TB/s)"
           % (grid, rb, us, N * 4 * D / 1e6, N * 4 * D / us / 1e6))
+for grid in (2048, 4096):
+  us = loop("sol", grid=grid, rb=4, state=3)
+  print("  the state read-modify-write alone (no gradient row read), grid %4d  %6.1f us   (%.0f MB at %.2f TB/s)"
+        % (grid, us, U * (32 + 2 * 4 * 4 * D) / 1e6, U * (32 + 2 * 4 * 4 * D) / us / 1e6))
 print("speed of light of the apply inside the loop: %.1f us" % best)
