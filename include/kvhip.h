@@ -447,6 +447,12 @@ typedef int (*kv_comm_max_fn)(void* user, uint32_t* value);
 int kv_comm_create_staged(int world, int rank, kv_comm_exchange_fn exchange, kv_comm_max_fn max_u32, void* user,
                           int device, kv_comm_t* out);
 int kv_comm_destroy(kv_comm_t comm);
+/* Ops of one table run in issue order whatever their streams: when the stream changes, the table's next op first waits
+ * for the previous one (an event recorded on the PREVIOUS stream).  A stream handed to an op must therefore still exist at
+ * the table's next op.  kv_comm_destroy retires the communicator's own stream from every table by itself; a caller that
+ * destroys a stream of its own synchronises it and says so here (the call synchronises `stream`, then no table refers to
+ * it any more). */
+int kv_forget_stream(kv_stream_t stream);
 /* the communicator's stream: a caller that passes it as `stream` to kv_shard_lookup / kv_shard_apply (its other work
  * queued there too) pays no event hop into and out of the exchange */
 int kv_comm_stream(kv_comm_t comm, kv_stream_t* stream);

@@ -299,3 +299,38 @@ def test_two_streams_on_one_table_are_serialised_by_the_library(ops):
   np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(v, q).cpu().numpy(), ov.gather_or_zeros(q), rtol=1e-6, atol=1e-9)
   np.testing.assert_allclose(ops.kv_variable_gather_or_zeros_v2(s, q).cpu().numpy(), os_.gather_or_zeros(q), rtol=1e-6, atol=1e-9)
   assert ops.kv_variable_frequency(v) == ov.sum_freq() and ops.kv_variable_frequency(s) == os_.sum_freq()
+
+
+@pytest.mark.gpu
+def test_a_table_survives_the_stream_of_its_last_op(ops):
+  """Ops of one table are ordered across streams by an event recorded on the PREVIOUS op's stream at the next op.  A stream
+  the library owns (a communicator's) may be destroyed in between: kv_comm_destroy retires it from every table first.
+  (Round 6: bench.py's sharded_world1 sub-record destroyed its communicator, the next lookup on the default stream crashed
+  in hipEventRecord on the dead stream — under rocprofv3, silently wrong without it.)  kv_forget_stream is the same service
+  for a stream the caller owns."""
+  rng = np.random.default_rng(3)
+  D = 16
+  table = rng.standard_normal((32, D)).astype(np.float32)
+  h = ops.kv_variable([D])
+  ops.kv_set_seed(h, 4); ops.kv_set_clock_days(h, DAY); ops.init_kv_variable_v2(h, table)
+  o = ko.OracleKv(D, 0, table, day=DAY, picker=1, seed=4)
+  comm = ops.KvComm(1, 0, ops.kv_comm_unique_id(), 0)
+  cs = comm.stream()
+  ids = rng.integers(-500, 500, 3000)
+  with torch.cuda.stream(cs):                      # the table's last op runs on the communicator's stream ...
+    got = ops.kv_variable_gather_or_insert_v2(h, ids)
+  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids))
+  from tfplus_amd import _lib
+  _lib.check(_lib.lib().kv_comm_destroy(comm.ptr)); comm.ptr = None     # ... which goes away
+  ids2 = rng.integers(-500, 500, 3000)
+  got = ops.kv_variable_gather_or_insert_v2(h, ids2)                    # the next op, on the default stream
+  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids2))
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    got = ops.kv_variable_gather_or_insert_v2(h, ids)
+  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids))
+  ops.kv_forget_stream(side)                                            # the caller's own stream, about to be dropped
+  del side
+  got = ops.kv_variable_gather_or_insert_v2(h, ids2)
+  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids2))
+  assert ops.kv_variable_frequency(h) == o.sum_freq()

@@ -77,6 +77,7 @@ SIGNATURES = {
     "kv_comm_create": (_i32, [_i32, _i32, _vp, _i32, _c.POINTER(_vp)]),
     "kv_comm_create_staged": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _c.POINTER(_vp)]),
     "kv_comm_destroy": (_i32, [_vp]),
+    "kv_forget_stream": (_i32, [_vp]),
     "kv_comm_stream": (_i32, [_vp, _c.POINTER(_vp)]),
     "kv_comm_all_to_all": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "kv_shard_create": (_i32, [_vp, _i32, _i32, _i32, _i64, _i64, _c.POINTER(_vp)]),

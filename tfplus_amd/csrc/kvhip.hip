@@ -46,6 +46,7 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+#include <unordered_set>
 
 #include "../../include/kvhip.h"
 
@@ -1147,6 +1148,21 @@ int fused_apply(kv_table* v, WsDev& wd, PartArgs& pa, long long n, hipStream_t s
   return KV_OK;
 }
 
+// Every live table: a stream the LIBRARY owns (a communicator's) is retired from the tables that last ran on it before it
+// is destroyed — hand_over would otherwise record an event on a dead stream at the table's next op (found in round 6:
+// bench.py's sharded_world1 sub-record destroys its communicator, the next lookup on another stream crashed in
+// hipEventRecord).  A stream the CALLER owns must outlive the table's next op, or the caller synchronises it first and
+// calls kv_forget_stream.
+std::mutex g_tables_mu;
+std::unordered_set<kv_table*> g_tables;
+void retire_stream(hipStream_t dead) {   // `dead` is drained (the caller synchronised it)
+  std::lock_guard<std::mutex> l(g_tables_mu);
+  for (kv_table* t : g_tables) {
+    std::lock_guard<std::mutex> lt(t->mu);
+    if (t->has_last && t->last_stream == dead) { t->has_last = false; t->last_stream = nullptr; }
+  }
+}
+
 std::atomic<uint64_t> g_serial{0};   // batch tokens
 std::atomic<uint64_t> g_uid{0};
 
@@ -1274,12 +1290,14 @@ int kv_create(int key_dtype, int value_dtype, int dim, int enter_threshold, int6
     if ((rc = build_index(t, pow2ceil(std::max<unsigned long long>(2 * t->rows_cap, 1024)), 1, s))) break;
   } while (0);
   if (rc) { kv_destroy(t); return rc; }
+  { std::lock_guard<std::mutex> l(g_tables_mu); g_tables.insert(t); }
   *out = t;
   return KV_OK;
 }
 
 int kv_destroy(kv_handle_t t) {
   if (!t) return KV_OK;
+  { std::lock_guard<std::mutex> l(g_tables_mu); g_tables.erase(t); }
   DeviceGuard dg(t->device);
   hipDeviceSynchronize();
   for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.meta); }
@@ -3336,10 +3354,17 @@ int kv_comm_stream(kv_comm_t c, kv_stream_t* stream) {
   return KV_OK;
 }
 
+int kv_forget_stream(kv_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(KV_INVALID_ARGUMENT, "kv_forget_stream: the stream cannot be synchronised");
+  retire_stream(s);
+  return KV_OK;
+}
+
 int kv_comm_destroy(kv_comm_t c) {
   if (!c) return KV_OK;
   DeviceGuard dg(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream) { hipStreamSynchronize(c->stream); retire_stream(c->stream); }   // no table keeps the stream as its last one
   if (c->comm && rccl()->ok) rccl()->CommDestroy(c->comm);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_out) hipEventDestroy(c->ev_out);

@@ -468,6 +468,11 @@ def kv_set_fast_math(table_handle, on=True):
   _lib.check(_lib.lib().kv_set_fast_math(table_handle.ptr, int(bool(on))))
 
 
+def kv_forget_stream(stream):
+  """A torch stream the caller is about to drop: synchronised, then no table's next op refers to it (kvhip.h kv_forget_stream)."""
+  _lib.check(_lib.lib().kv_forget_stream(ctypes.c_void_p(stream.cuda_stream)))
+
+
 def kv_prepare_capture(table_handle, max_new_ids):
   """Refreshes the host's row-count bounds so that captured calls taking up to max_new_ids ids need no sync."""
   _lib.check(_lib.lib().kv_prepare_capture(table_handle.ptr, int(max_new_ids), _stream(table_handle)))

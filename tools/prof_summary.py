@@ -64,7 +64,7 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
            "workload": workload},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
 try:
-  b = json.load(open(os.path.join(out, "bench_under_trace.json")))
+  b = json.loads([l for l in open(os.path.join(out, "bench_under_trace.json")) if l.startswith("{")][-1])   # (RCCL prints a banner to stdout)
   print(); print("bench.py line of the traced run:"); print(json.dumps({k: b[k] for k in ("ms_per_step", "kernels_ms", "roofline")}))
 except Exception as e:
   print("no bench json:", e)
