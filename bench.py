@@ -251,16 +251,7 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
   #      a rank's own segment stays in place), serve, finish, pre-sum, apply — over the library's communicator on this one
   #      GPU, so that the mechanism's own cost is on the driver's N = 1 line.  Never `value`.
   try:
-    # (RCCL prints a version banner to the process's stdout when its first communicator is made: kept off this program's
-    #  one-JSON-line stdout by pointing fd 1 at stderr for the moment)
-    sys.stdout.flush()
-    fd1 = os.dup(1)
-    os.dup2(2, 1)
-    try:
-      comm = ops.KvComm(1, 0, ops.kv_comm_unique_id(), dev.index)
-    finally:
-      os.dup2(fd1, 1)
-      os.close(fd1)
+    comm = ops.KvComm(1, 0, ops.kv_comm_unique_id(), dev.index)
     cap = int(max(p[2] for p in pool) * 1.25) + 1024
     shard = ops.KvShard(var, 1, 0, ops.KV_OWNER_HASH, max_ids=N, peer_capacity=cap)
     shard.set_lossless(False)      # capacity sized from the pool: cannot overflow (as the N > 1 line does)
@@ -379,6 +370,15 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  # This program's stdout is ONE JSON line.  RCCL prints a version banner to the process's stdout (fd 1) when its first
+  # communicator is made — torch.distributed's at N > 1, the library's own in the sharded_world1 record at N = 1 — so fd 1
+  # points at stderr from here on and the line goes out through the saved descriptor (emit below).
+  sys.stdout.flush()
+  real_stdout = os.dup(1)
+  os.dup2(2, 1)
+
+  def emit(line):
+    os.write(real_stdout, (line + "\n").encode())
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     # not under a launcher: start one rank per GPU as CHILD processes (nothing in this process has touched the GPU
     # yet; a process that has must never be replaced by another), relay rank 0's JSON line, exit with their status
@@ -392,7 +392,7 @@ def main():
     r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if lines:
-      print(lines[-1], flush=True)
+      emit(lines[-1])
     sys.exit(r.returncode if r.returncode or lines else 1)
   # KV_BENCH_ONE_GPU=1 (debugging only, never a measurement): every rank shares cuda:0 and the
   # collectives are staged through gloo on the host, so the N > 1 control flow of this file can be
@@ -654,7 +654,7 @@ def main():
   value = N * world / (dt / args.steps)
   if args.no_kernel_events or graphs:
     if rank == 0:
-      print(json.dumps({"ms_per_step": ms_per_step, "value": value, "note": "diagnostic run without kernel events"}))
+      emit(json.dumps({"ms_per_step": ms_per_step, "value": value, "note": "diagnostic run without kernel events"}))
     if shard_path:
       teardown()
     return
@@ -813,7 +813,7 @@ def main():
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
     res["cpu_baseline"] = cpu_baseline(args, D)
   if rank == 0:
-    print(json.dumps(res), flush=True)
+    emit(json.dumps(res))
   if shard_path:
     teardown()
 
