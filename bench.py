@@ -166,7 +166,7 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
                                          ctypes.byref(tok) if want_token else None, st()))
     return tok.value
 
-  def timed(fn, steps=12, warm=3):
+  def timed(fn, steps=30, warm=5):   # (12 steps of a 45 us op are 0.5 ms: one host hiccup moved the record by 12 %)
     for k in range(warm):
       fn(k)
     torch.cuda.synchronize()
@@ -298,8 +298,8 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
     def full(k):
       ids, grad, _ = bs[k % NB]
       adam(ids, grad, N, lookup(ids, True))
-    ms_step = timed(full, steps=12, warm=3)
-    ms_look = timed(lambda k: lookup(bs[k % NB][0], True), steps=12, warm=2)
+    ms_step = timed(full, steps=24, warm=4)
+    ms_look = timed(lambda k: lookup(bs[k % NB][0], True), steps=24, warm=3)
     # when the lookup's output rows are complete (a token lookup defers its partition pass): the tile kernel alone
     ops.kv_profile_enable(var, 64)
     for k in range(NB):
