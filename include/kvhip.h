@@ -214,6 +214,14 @@ int kv_set_deterministic(kv_handle_t h, int on);
  * IEEE sequences. */
 int kv_set_fast_math(kv_handle_t h, int on);
 
+/* Counters of the table's own ops, for tests and tools (no kernel reads them).  KV_STAT_MIRROR_APPLIES: optimizer applies
+ * with `h` as the var that worked on the rows' slot mirrors (the lean update: the slot row's frequency word and flags are
+ * read and written in the var row's own record line, csrc/kv_device.h SlotMirror); KV_STAT_MIRROR_EPOCHS: how often the
+ * mirrors of `h` (as the var) were flushed back and invalidated because another op entered one of the two tables. */
+#define KV_STAT_MIRROR_APPLIES 0
+#define KV_STAT_MIRROR_EPOCHS 1
+int kv_get_stat(kv_handle_t h, int which, int64_t* value);
+
 /* Brings the host's upper bounds of the table's row count up to date (one synchronisation): a lookup or apply that
  * follows can then take `max_new_ids` more ids without consulting the device — what a stream capture needs, where a
  * synchronisation is not allowed.  KV_RESOURCE_EXHAUSTED when the table would have to grow for that many ids (it

@@ -318,8 +318,8 @@ def test_a_table_survives_the_stream_of_its_last_op(ops):
   cs = comm.stream()
   ids = rng.integers(-500, 500, 3000)
   with torch.cuda.stream(cs):                      # the table's last op runs on the communicator's stream ...
-    got = ops.kv_variable_gather_or_insert_v2(h, ids)
-  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids))
+    got = ops.kv_variable_gather_or_insert_v2(h, ids).cpu().numpy()      # (read back on that stream too)
+  np.testing.assert_array_equal(got, o.gather_or_insert(ids))
   from tfplus_amd import _lib
   _lib.check(_lib.lib().kv_comm_destroy(comm.ptr)); comm.ptr = None     # ... which goes away
   ids2 = rng.integers(-500, 500, 3000)
@@ -327,8 +327,8 @@ def test_a_table_survives_the_stream_of_its_last_op(ops):
   np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids2))
   side = torch.cuda.Stream()
   with torch.cuda.stream(side):
-    got = ops.kv_variable_gather_or_insert_v2(h, ids)
-  np.testing.assert_array_equal(got.cpu().numpy(), o.gather_or_insert(ids))
+    got = ops.kv_variable_gather_or_insert_v2(h, ids).cpu().numpy()
+  np.testing.assert_array_equal(got, o.gather_or_insert(ids))
   ops.kv_forget_stream(side)                                            # the caller's own stream, about to be dropped
   del side
   got = ops.kv_variable_gather_or_insert_v2(h, ids2)

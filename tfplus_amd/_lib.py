@@ -60,6 +60,7 @@ SIGNATURES = {
     "kv_attach_slot": (_i32, [_vp, _vp, _vp]),
     "kv_set_deterministic": (_i32, [_vp, _i32]),
     "kv_set_fast_math": (_i32, [_vp, _i32]),
+    "kv_get_stat": (_i32, [_vp, _i32, _c.POINTER(_i64)]),
     "kv_prepare_capture": (_i32, [_vp, _i64, _vp]),
     "kv_dedup_segment_sum": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_i64), _vp]),
     "kv_export_count": (_i32, [_vp, _i32, _c.POINTER(_i64), _vp]),

@@ -67,6 +67,27 @@ struct RowMeta {
 constexpr unsigned DELTA_TRAIN = 1u, DELTA_PRED = 2u;
 static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
 
+// A row's record array holds META_STRIDE 16-byte units per row: [0] the RowMeta, [1] a SlotMirror — in the SAME 32-byte
+// sector, so the two are one line to read and one request to write.  Every read miss on this chip is a 128-byte line
+// (profiles/r06_fetch_calibration.txt): the optimizer apply used to read two lines per key for two 16-byte records — the
+// var's and the hinted slot row's.  The mirror is a write-back copy of what the apply needs of the SLOT row's record (its
+// frequency word and flags), kept next to the VAR row's record: while it is valid the apply neither reads nor writes the
+// slot table's own record.  `srow` names the slot row it stands for (must equal the index entry's hint), `epoch` the
+// generation of the pairing (the host bumps it — one integer — whenever anything but a mirror apply may have read or
+// written the slot table's records, after flushing the dirty mirrors back: kvhip.hip mirror_*), `state` 0 invalid / 1 clean /
+// 2 dirty.  Only var tables of an attached (var, slot) pair use their mirrors; the units exist in every table.
+constexpr int META_STRIDE = 2;
+struct SlotMirror {
+  unsigned srow;          // the slot row this stands for
+  unsigned freq;          // its frequency word (day << 16 | saturating count)
+  unsigned char flags;    // its FLAG_* byte
+  unsigned char state;    // MIRROR_*
+  unsigned short epoch;   // pairing generation (PartArgs::mirror_epoch)
+  unsigned pad;
+};
+static_assert(sizeof(SlotMirror) == 16, "SlotMirror layout");
+constexpr unsigned MIRROR_INVALID = 0u, MIRROR_CLEAN = 1u, MIRROR_DIRTY = 2u;
+
 struct Chunk {
   float* rows;
   RowMeta* meta;
@@ -211,8 +232,11 @@ __device__ __forceinline__ float* row_ptr(const TableDev& t, unsigned r) {
 // front of the load — a loop that asks this once keeps all its row loads in flight together
 __device__ __forceinline__ bool single_chunk(const TableDev& t) { return t.single != 0u; }
 __device__ __forceinline__ RowMeta* meta_ptr(const TableDev& t, unsigned r) {
-  if (t.single || (r >> t.chunk_bits) == 0) return t.c0.meta + r;
-  return t.chunks[r >> t.chunk_bits].meta + (r & ((1u << t.chunk_bits) - 1));
+  if (t.single || (r >> t.chunk_bits) == 0) return t.c0.meta + (size_t)r * META_STRIDE;
+  return t.chunks[r >> t.chunk_bits].meta + (size_t)(r & ((1u << t.chunk_bits) - 1)) * META_STRIDE;
+}
+__device__ __forceinline__ SlotMirror* mirror_ptr(const TableDev& t, unsigned r) {
+  return reinterpret_cast<SlotMirror*>(meta_ptr(t, r) + 1);
 }
 __device__ __forceinline__ unsigned* freq_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->freq; }
 __device__ __forceinline__ unsigned char* flags_ptr(const TableDev& t, unsigned r) { return &meta_ptr(t, r)->flags; }

@@ -339,6 +339,8 @@ struct PartArgs {
                                    // wanted (here) and clears the counters — what k_seg_headers_take does in its own launch
   unsigned* route_uhint;           // pinned host word (may be null): the batch's distinct ids
   unsigned uniq_serial;            // k_uapply (kv_uapply.h): this launch's stamp (1 .. 65535)
+  int use_mirror;                  // the lean update reads / writes the slot row's frequency word and flags in the var row's
+  unsigned mirror_epoch;           // SlotMirror (kv_device.h) when it is valid for this epoch; the host flushes (kvhip.hip mirror_*)
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)
@@ -1113,6 +1115,15 @@ __device__ __forceinline__ void finish_key(const PartArgs& a, const uint4 hd, bo
     // the slot rows in `pre` are those of the hinted row: good only if the hint stood up
     opt_update_row<OPT, V, LPR, K>(a.tv, a.ts0, a.ts1, key, ro.tag, ro.r0, (ro.nb & 2u) != 0, ro.r1, (ro.nb & 4u) != 0,
                                    live, gv, a.opt, lane, pre, have_x, have_s && (ro.nb & 8u) != 0);
+    // the key's slot record as this update left it goes into the var row's mirror (clean: the slot table's own record is
+    // up to date), so that the key's NEXT apply takes the lean path without reading it
+    if (OPT != OPT_FTRL && a.use_mirror && live && lane == 0 && ro.r0 != 0u && (ro.tag & ROW_MASK) != 0u && !(ro.tag & ROW_FILTERED)) {
+      const uint2 sm = load_freq_flags(a.ts0, ro.r0);
+      SlotMirror nm;
+      nm.srow = ro.r0; nm.freq = sm.x; nm.flags = (unsigned char)(sm.y & 0xFFu); nm.state = (unsigned char)MIRROR_CLEAN;
+      nm.epoch = (unsigned short)a.mirror_epoch; nm.pad = 0u;
+      *mirror_ptr(a.tv, ro.tag & ROW_MASK) = nm;
+    }
   } else if (live && hd.z != ROW_MASK) {
     const size_t orow = a.out_map ? (size_t)a.out_map[hd.z] : (size_t)hd.z;   // sharded apply: the unique id's exchange slot
 #pragma unroll

@@ -89,14 +89,14 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
   // the lean update: single-chunk tables, the var's index entries remember the slot rows, no delta lists (every pre-sized
   // training table); any other key or table goes through finish_key (kv_kernels.h)
   const bool fast = (OPT != OPT_FTRL) && a.tv.single != 0u && a.ts0.single != 0u && a.use_hints != 0 &&
-                    (a.tv.track_delta | a.ts0.track_delta) == 0u;
+                    (a.tv.track_delta | a.ts0.track_delta) == 0u && a.use_mirror != 0;   // ... and slot mirrors (kv_device.h)
   float* const vrows = a.tv.c0.rows;
   RowMeta* const vmeta = a.tv.c0.meta;
   float* const srows = a.ts0.c0.rows;
-  RowMeta* const smeta = a.ts0.c0.meta;
   const int SD = a.ts0.dim;
   const unsigned smax = a.ts0.max_rows, thr = a.tv.enter_threshold;
   const bool need_vmeta = OPT == OPT_ADAGRAD || thr != 0u;
+  const unsigned mepoch = a.mirror_epoch & 0xFFFFu;
   const unsigned serial = a.uniq_serial & 0xFFFFu;
   const float* const gbase = a.grad;
   const long long nbatch = (n + G - 1) / G;
@@ -150,16 +150,15 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
     }
     RowMeta m0{};
     uint2 vm = make_uint2(0u, 0u);
+    uint4 mir = make_uint4(0u, 0u, 0u, 0u);   // {srow, freq, flags | state << 8 | epoch << 16, -}
     bool hint_loaded = false, have_x = false, have_s = false;
     PreRows<V, K> pre;
     if (fast) {
       const unsigned rr = st_live ? row : 0u;
       const unsigned hh = (st_live && hint < smax) ? hint : 0u;
-      const uint4 mm = *reinterpret_cast<const uint4*>(smeta + hh);
-      m0.key = (long long)(((unsigned long long)mm.y << 32) | mm.x);
-      m0.freq = mm.z;
-      m0.flags = (unsigned char)(mm.w & 0xFFu);
-      vm = *reinterpret_cast<const uint2*>(&vmeta[rr].freq);
+      const RowMeta* const vrec = vmeta + (size_t)rr * META_STRIDE;
+      mir = *reinterpret_cast<const uint4*>(vrec + 1);   // the slot record's copy, in the var record's own line
+      vm = *reinterpret_cast<const uint2*>(&vrec->freq);
       const float* xr = vrows + (size_t)rr * D;
       const float* sr = srows + (size_t)hh * SD;
 #pragma unroll
@@ -168,7 +167,7 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
 #pragma unroll
         for (int b3 = 0; b3 < NS0; ++b3) ldv<V>(sr + b3 * D + eoff[k], pre.s[b3][k]);
       }
-      hint_loaded = hh != 0u; have_x = true; have_s = hh != 0u;
+      hint_loaded = false; have_x = true; have_s = hh != 0u;   // (the general path reads the slot record itself)
     } else {
       if (st_live && !isnew) vm = load_freq_flags(a.tv, row);
       const uint4 rq = make_uint4((unsigned)key, (unsigned)((unsigned long long)key >> 32), st_live ? row : 0u, st_live ? hint : 0u);
@@ -236,20 +235,24 @@ __device__ __forceinline__ void uapply_body(const PartArgs& a, const void* __res
     if (fast) {
       const unsigned hh = hint < smax ? hint : 0u;
       // the hint stands up: the slot row carries this key and is not released (what resolve_rows checks)
-      const bool ok = go && row != 0u && hh != 0u && m0.key == key && !(m0.flags & FLAG_FREE);
+      // ... or, with mirrors: the var row's mirror stands for exactly that slot row in this epoch (kv_device.h SlotMirror)
+      const bool ok = go && row != 0u && hh != 0u && ((mir.z >> 8) & 0xFFu) != MIRROR_INVALID && (mir.z >> 16) == mepoch && mir.x == hh;
+      const unsigned sfreq = mir.y;   // the slot row's frequency word
       bool act = ok;
       if (need_vmeta && ok && !vnew) {   // frequency filter / un-blacklisting (resolve_rows; kv_variable.h:910)
         if ((vm.x & 0xFFFFu) < thr) act = false;
-        else if ((vm.y & FLAG_BLACK) && lane == 0) vmeta[row].flags = FLAG_UNDER;
-      }
-      if (act && lane == 0) {   // AddFrequency(1, today) on the slot row (kv_variable.h:409-414)
-        unsigned lo16 = (m0.freq & 0xFFFFu) + 1u;
-        if (lo16 > 65535u) lo16 = 65535u;
-        smeta[hh].freq = (a.day << 16) | lo16;
+        else if ((vm.y & FLAG_BLACK) && lane == 0) vmeta[(size_t)row * META_STRIDE].flags = FLAG_UNDER;
       }
       const unsigned rr = act ? row : 0u, h2 = act ? hh : 0u;
-      opt_core<OPT, V, LPR, K>(vrows + (size_t)rr * D, srows + (size_t)h2 * SD, nullptr, &vmeta[rr].flags, &smeta[h2].flags,
-                               nullptr, act, false, D, gv, a.opt, lane, pre.x, pre.s);
+      SlotMirror* const mp = reinterpret_cast<SlotMirror*>(vmeta + (size_t)rr * META_STRIDE + 1);
+      if (act && lane == 0) {   // AddFrequency(1, today) on the slot row (kv_variable.h:409-414)
+        unsigned lo16 = (sfreq & 0xFFFFu) + 1u;
+        if (lo16 > 65535u) lo16 = 65535u;
+        mp->freq = (a.day << 16) | lo16;
+        mp->state = (unsigned char)MIRROR_DIRTY;
+      }
+      opt_core<OPT, V, LPR, K>(vrows + (size_t)rr * D, srows + (size_t)h2 * SD, nullptr, &vmeta[(size_t)rr * META_STRIDE].flags,
+                               &mp->flags, nullptr, act, false, D, gv, a.opt, lane, pre.x, pre.s);
       general = go && !ok;
     }
     if (!fast || __ballot(general) != 0ull)

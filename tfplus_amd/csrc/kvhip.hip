@@ -134,16 +134,47 @@ __global__ void k_clear_hints(Entry* e, unsigned long long count) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (unsigned long long)gridDim.x * blockDim.x) e[i].hint = 0;
 }
-// kv_attach_slot: every key of the var learns its row in the slot table (one pass over the var's rows)
-__global__ void k_link_hints(TableDev tv, TableDev ts, unsigned nrows) {
+// kv_attach_slot: every key of the var learns its row in the slot table (one pass over the var's rows) and, mirrors != 0,
+// takes a clean copy of that row's frequency word and flags into its own record line (kv_device.h SlotMirror)
+__global__ void k_link_hints(TableDev tv, TableDev ts, unsigned nrows, unsigned epoch, int mirrors) {
   for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    if (mirrors) mirror_ptr(tv, r)->state = (unsigned char)MIRROR_INVALID;
     if (*flags_ptr(tv, r) & FLAG_FREE) continue;
     const long long key = *key_ptr(tv, r);
     const unsigned sr = table_find(ts, key);
     if (!sr) continue;
     Entry* e = table_entry_of(tv, key);
-    if (e && load_entry(e).row == r) e->hint = sr;
+    if (e && load_entry(e).row == r) {
+      e->hint = sr;
+      if (mirrors) {
+        const uint2 sm = load_freq_flags(ts, sr);
+        SlotMirror nm;
+        nm.srow = sr; nm.freq = sm.x; nm.flags = (unsigned char)(sm.y & 0xFFu); nm.state = (unsigned char)MIRROR_CLEAN;
+        nm.epoch = (unsigned short)epoch; nm.pad = 0u;
+        *mirror_ptr(tv, r) = nm;
+      }
+    }
   }
+}
+// the end of a mirror epoch: what the lean applies wrote into the var rows' mirrors goes back into the slot table's own
+// records (a dirty mirror of THIS epoch names a live slot row: nothing else has touched the slot table since it was made)
+__global__ void k_flush_mirrors(TableDev tv, TableDev ts, unsigned epoch) {
+  const unsigned nrows = min(tv.counters[0], tv.max_rows);
+  for (unsigned r = 1 + blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    SlotMirror* mp = mirror_ptr(tv, r);
+    const SlotMirror m = *mp;
+    if (m.state != MIRROR_DIRTY || m.epoch != (unsigned short)epoch || m.srow == 0u || m.srow >= ts.max_rows) continue;
+    RowMeta* sm = meta_ptr(ts, m.srow);
+    sm->freq = m.freq;
+    sm->flags = m.flags;
+    mp->state = (unsigned char)MIRROR_CLEAN;
+  }
+}
+// the 16-bit epoch wrapped: every mirror back to "none"
+__global__ void k_clear_mirrors(TableDev tv) {
+  const unsigned nrows = min(tv.counters[0], tv.max_rows);
+  for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
+    mirror_ptr(tv, r)->state = (unsigned char)MIRROR_INVALID;
 }
 
 // size() / sum_freq() kv_variable.h:139-175 ; out[0] = size, out[1] = sum_freq
@@ -410,6 +441,15 @@ struct kv_table {
   // as before, the rows just do not wait for it.
   bool part_pending = false;
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
+  // Slot mirrors (kv_device.h SlotMirror; mirror_* below): a var table paired with ONE slot table keeps, next to each row's
+  // record, a write-back copy of the slot row's frequency word and flags; the lean apply works on the copy alone.
+  long long stat_mirror_applies = 0, stat_mirror_epochs = 0;   // kv_get_stat
+  kv_table* mirror_slot = nullptr;          // var side: the slot table its mirrors stand for
+  std::atomic<unsigned> mirror_epoch{1};    // var side: generation of the copies (16 bits on the device)
+  std::atomic<bool> mirror_dirty{false};    // var side: a lean apply has written mirrors since the last flush
+  kv_table* mirror_var = nullptr;           // slot side: the var that holds this table's mirrors
+  bool mirror_banned = false;               // either side: the table is used under stream capture (kv_prepare_capture): no mirrors, ever
+  bool mirror_shared = false;               // slot side: a second var attached it — no mirrors for this table any more
   unsigned uniq_serial = 0;        // stamp of the table's last kv_apply_*_unique launch (kv_uapply.h; wraps at 65535: stamps cleared)
   bool deterministic = false;      // kv_set_deterministic
   bool fast_math = false;          // kv_set_fast_math: the optimizers' sqrt / division on v_sqrt_f32 / v_rcp_f32 (1 ulp) —
@@ -492,11 +532,13 @@ int add_chunk(kv_table* t, hipStream_t s) {
   const size_t R = (size_t)1 << t->chunk_bits;
   Chunk c{};
   HIP_TRY(hipMalloc(&c.rows, R * t->dim * sizeof(float)));
-  HIP_TRY(hipMalloc(&c.meta, R * sizeof(RowMeta)));
+  HIP_TRY(hipMalloc(&c.meta, R * META_STRIDE * sizeof(RowMeta)));   // (record + slot mirror per row: kv_device.h)
+  // every mirror unit starts INVALID (state 0): k_flush_mirrors walks all rows below next_row, also those no apply has met
+  HIP_TRY(hipMemsetAsync(c.meta, 0, R * META_STRIDE * sizeof(RowMeta), s));
   if (t->chunks.empty()) {
     // row 0: the permanent zero row
     HIP_TRY(hipMemsetAsync(c.rows, 0, (size_t)t->dim * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(c.meta, 0, sizeof(RowMeta), s));
+    HIP_TRY(hipMemsetAsync(c.meta, 0, META_STRIDE * sizeof(RowMeta), s));
   }
   t->chunks.push_back(c);
   HIP_TRY(hipMemcpyAsync(t->d_chunks + (t->chunks.size() - 1), &t->chunks.back(), sizeof(Chunk),
@@ -972,6 +1014,126 @@ int report_deferred_error(kv_table* t, hipStream_t s) {
 // waits for everything the previous stream had been given.
 // launches a lookup's pending partition pass (see kv_table::part_pending) on stream s
 int flush_part(kv_table* t, hipStream_t s);
+// ---- slot mirrors: the host side -------------------------------------------------------------------------------------
+// Invariant: the slot table's own records are up to date for every key whose var-row mirror is not (valid in the current
+// epoch AND dirty).  Mirrors are written only by the lean apply of (var, slot) — k_papply / k_uapply with use_mirror — and
+// read only by it.  EVERY other op that enters either table first ends the epoch (mirror_end_epoch: flush the dirty
+// copies, one kernel over the var's rows, then epoch + 1 — which invalidates every copy at once), so it sees, and may
+// change, the authoritative records; the keys' next lean apply finds no valid mirror, takes the general path once and
+// leaves a fresh clean copy (finish_key).  The ops that keep the epoch name their tables in tl_mirror_keep while they
+// enter: the training / inference lookups on the var (they touch var records and rows only), the single-table GroupAdam
+// and Adagrad applies on (var, slot).  KV_NO_MIRROR=1: never (A/B).
+static thread_local kv_table* tl_mirror_keep[2] = {nullptr, nullptr};   // [0]: kept in its VAR role, [1]: kept in its SLOT role
+static thread_local kv_table* const* tl_mirror_keep_vars = nullptr;      // ... a batched op's tables in their VAR role
+static thread_local int tl_mirror_keep_nvars = 0;
+static thread_local kv_table* const* tl_mirror_keep_slots = nullptr;     // ... a batched apply's first slot tables, in their SLOT role
+static thread_local int tl_mirror_keep_nslots = 0;
+struct MirrorKeep {   // (scopes nest: the previous names come back)
+  kv_table* p0; kv_table* p1; kv_table* const* pv; int pn; kv_table* const* ps; int psn;
+  void save() {
+    p0 = tl_mirror_keep[0]; p1 = tl_mirror_keep[1]; pv = tl_mirror_keep_vars; pn = tl_mirror_keep_nvars;
+    ps = tl_mirror_keep_slots; psn = tl_mirror_keep_nslots;
+  }
+  explicit MirrorKeep(kv_table* as_var, kv_table* as_slot = nullptr) { save(); tl_mirror_keep[0] = as_var; tl_mirror_keep[1] = as_slot; }
+  MirrorKeep(kv_table* const* vars, int n, kv_table* const* slots = nullptr, int nslots = 0) {
+    save(); tl_mirror_keep_vars = vars; tl_mirror_keep_nvars = n; tl_mirror_keep_slots = slots; tl_mirror_keep_nslots = nslots;
+  }
+  ~MirrorKeep() {
+    tl_mirror_keep[0] = p0; tl_mirror_keep[1] = p1; tl_mirror_keep_vars = pv; tl_mirror_keep_nvars = pn;
+    tl_mirror_keep_slots = ps; tl_mirror_keep_nslots = psn;
+  }
+};
+static bool mirror_kept_as_var(const kv_table* t) {
+  if (t == tl_mirror_keep[0]) return true;
+  for (int i = 0; i < tl_mirror_keep_nvars; ++i)
+    if (tl_mirror_keep_vars[i] == t) return true;
+  return false;
+}
+static bool mirror_kept_as_slot(const kv_table* t) {
+  if (t == tl_mirror_keep[1]) return true;
+  for (int i = 0; i < tl_mirror_keep_nslots; ++i)
+    if (tl_mirror_keep_slots[i] == t) return true;
+  return false;
+}
+bool mirror_off() {
+  static const bool off = [] { const char* e = getenv("KV_NO_MIRROR"); return e && e[0] == '1'; }();
+  return off;
+}
+void mirror_end_epoch(kv_table* var, hipStream_t s) {
+  kv_table* sl = var->mirror_slot;
+  if (!sl) return;
+  ++var->stat_mirror_epochs;
+  if (var->mirror_dirty.exchange(false))
+    k_flush_mirrors<<<nblocks((long long)var->rows_ub + 1, TB, 8192), TB, 0, s>>>(dev_view(var), dev_view(sl), var->mirror_epoch.load() & 0xFFFFu);
+  if ((var->mirror_epoch.fetch_add(1) + 1u) > 0xFFFFu) {
+    k_clear_mirrors<<<nblocks((long long)var->rows_ub + 1, TB, 8192), TB, 0, s>>>(dev_view(var));
+    var->mirror_epoch.store(1);
+  }
+}
+void mirror_unpair(kv_table* var, hipStream_t s) {
+  if (!var->mirror_slot) return;
+  mirror_end_epoch(var, s);
+  var->mirror_slot->mirror_var = nullptr;
+  var->mirror_slot = nullptr;
+}
+// the entry hook of hand_over / join_side.  Under a stream capture the flush would be RECORDED, not run, and a replay would
+// carry the epoch of its capture: a table that is captured gives up its mirrors beforehand (kv_prepare_capture ->
+// mirror_ban); an op that would have to end an epoch inside a capture is refused.
+int mirror_on_entry(kv_table* t, hipStream_t s) {
+  if (!t->mirror_var && !t->mirror_slot) return KV_OK;
+  const bool end_slot = t->mirror_var && !mirror_kept_as_slot(t), end_var = t->mirror_slot && !mirror_kept_as_var(t);
+  if ((end_slot || end_var) && stream_is_capturing(s))
+    return fail(KV_FAILED_PRECONDITION, "this table is half of a (var, slot) pair whose optimizer applies keep the slot records' "
+                                        "frequency words in the var's rows between ops; call kv_prepare_capture on it (outside the "
+                                        "capture) before capturing ops on it");
+  if (end_slot) mirror_end_epoch(t->mirror_var, s);   // t is a slot table: its records are about to be read or written
+  if (end_var) mirror_end_epoch(t, s);                // t is a var: its rows may be released, moved or read back
+  return KV_OK;
+}
+// kv_prepare_capture: the table's ops are about to be captured and replayed — no host code runs at a replay, so nothing
+// could flush or re-validate a mirror: the pair is dissolved now (the dirty copies go back) and never forms again
+void mirror_ban(kv_table* t, hipStream_t s) {
+  if (t->mirror_slot) mirror_unpair(t, s);
+  if (t->mirror_var) mirror_unpair(t->mirror_var, s);
+  t->mirror_banned = true;
+}
+// (var, slot) become a mirror pair — or stay / become unpaired when the slot table already serves another var
+bool mirror_pair(kv_table* v, kv_table* sl, hipStream_t s) {
+  if (mirror_off() || sl->mirror_shared || v->mirror_banned || sl->mirror_banned) return false;
+  if (v->mirror_slot == sl && sl->mirror_var == v) return true;
+  if (sl->mirror_var && sl->mirror_var != v) {   // a second var on one slot table: no mirrors for it at all
+    mirror_unpair(sl->mirror_var, s);
+    sl->mirror_shared = true;
+    return false;
+  }
+  if (v->mirror_slot && v->mirror_slot != sl) mirror_unpair(v, s);
+  v->mirror_slot = sl;
+  sl->mirror_var = v;
+  mirror_end_epoch(v, s);   // a fresh epoch: whatever bytes the rows' mirror units hold are void
+  return true;
+}
+
+// Does this apply of (v, s0) work on the var rows' slot mirrors?  lean: the launch is k_papply / k_uapply (their lean
+// update is the only code that reads or writes a mirror).  Otherwise the apply reads and writes the slot table's own
+// records: the epoch ends first (the caller entered both tables under MirrorKeep, so nothing has ended it yet).
+static void mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s);
+template <int OPT>
+static void mirror_decide(kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) { mirror_decide_rt(OPT, v, s0, pa, lean, s); }
+static void mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) {
+  pa.use_mirror = 0; pa.mirror_epoch = 0u;
+  const bool eligible = opt != OPT_FTRL && lean && pa.use_hints != 0 && pa.tv.single != 0u && pa.ts0.single != 0u &&
+                        !v->track_delta && !s0->track_delta && !stream_is_capturing(s) && mirror_pair(v, s0, s);
+  if (eligible) {
+    pa.use_mirror = 1;
+    pa.mirror_epoch = v->mirror_epoch.load() & 0xFFFFu;
+    v->mirror_dirty.store(true);
+    ++v->stat_mirror_applies;
+  } else {
+    if (v->mirror_slot) mirror_end_epoch(v, s);
+    if (s0->mirror_var && s0->mirror_var != v) mirror_end_epoch(s0->mirror_var, s);
+  }
+}
+
 // mutates == false: a read-only op (the inference gathers): ordered like any other op of the table — behind the table's
 // last op whatever its stream, and the next op behind it — but it does not move op_serial (a two-phase export may go on)
 // settle == false: the caller is the optimizer apply that takes the table's pending partition pass over
@@ -992,7 +1154,7 @@ int hand_over(kv_table* t, hipStream_t s, bool settle = true, bool mutates = tru
   t->last_stream = s;
   t->has_last = true;
   if (mutates) ++t->op_serial;
-  return KV_OK;
+  return mirror_on_entry(t, s);
 }
 
 // ops that read a table without the full hand_over (no workspace, no row-set change): the last lookup's pending
@@ -1004,9 +1166,10 @@ int join_side(kv_table* t, hipStream_t s) {
       HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
       t->last_stream = s;
     }
-    return flush_part(t, s);
+    const int rc = flush_part(t, s);
+    if (rc) return rc;
   }
-  return KV_OK;
+  return mirror_on_entry(t, s);
 }
 
 // locks tables in address order like MaybeLockVariableInputMutexesInOrder (training_ops.cc:96-184)
@@ -1298,6 +1461,11 @@ int kv_create(int key_dtype, int value_dtype, int dim, int enter_threshold, int6
 int kv_destroy(kv_handle_t t) {
   if (!t) return KV_OK;
   { std::lock_guard<std::mutex> l(g_tables_mu); g_tables.erase(t); }
+  {   // slot mirrors: a var hands its dirty copies back before it goes; a slot table takes its var's pairing with it
+    DeviceGuard dgm(t->device);
+    if (t->mirror_slot) mirror_unpair(t, nullptr);
+    if (t->mirror_var) { t->mirror_var->mirror_dirty.store(false); t->mirror_var->mirror_slot = nullptr; t->mirror_var = nullptr; }
+  }
   DeviceGuard dg(t->device);
   hipDeviceSynchronize();
   for (auto& c : t->chunks) { hipFree(c.rows); hipFree(c.meta); }
@@ -1477,6 +1645,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t);   // a training lookup touches the var's rows and records, never a slot record or a mirror
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
@@ -1532,6 +1701,7 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
     return fail(KV_FAILED_PRECONDITION, "Failed to use uninitialized variables: KvVariable init table not set");
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t);   // the table's own rows and records only
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
   const int D = t->dim;
@@ -1621,6 +1791,7 @@ int kv_gather_or_zeros(kv_handle_t t, const void* ids, int64_t n, float* out, kv
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
+  MirrorKeep mk(t);   // (the inference gather reads rows and flags of THIS table: as a var it leaves the mirrors alone)
   if ((rc = hand_over(t, s, true, false))) return rc;   // a read: behind the table's last op on whatever stream, no serial bump
   const TableDev td = dev_view(t);
   const int q = t->dim / 4;
@@ -1717,6 +1888,7 @@ int kv_batch_gather_or_zeros(int num_tables, const kv_handle_t* tables, const vo
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  MirrorKeep mk(tables, num_tables);
   // every table is read on the op's stream: behind whatever its own last op queued on another stream (an optimizer
   // apply that has not finished), and its next op behind this read
   for (kv_table* tb : lock.ts)
@@ -1794,6 +1966,7 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(std::vector<kv_table*>(tables, tables + num_tables));
+  MirrorKeep mk(tables, num_tables);   // lookups: the tables' own rows and records only
   if ((rc = lock.enter(s))) return rc;
   long long nmax = 0;
   for (int i = 0; i < num_tables; ++i) {
@@ -1898,6 +2071,9 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
   DeviceGuard dg(device);
   hipStream_t s = (hipStream_t)stream;
   MultiLock lock(all);
+  // GroupAdam / Adagrad over pairs (var_i, slot_i): the lean update works on the var rows' slot mirrors (mirror_decide per
+  // table below); FTRL reads and writes the slot tables' own records: its entry ends the tables' epochs
+  MirrorKeep mk(vars, opt != OPT_FTRL ? num_tables : 0, slots0, opt != OPT_FTRL ? num_tables : 0);
   if (tl_unique && fused_ok(D) && !stream_is_capturing(s)) {
     // The caller promises that no table's ids hold an id twice (kv_multi_apply_*_unique; kv_uapply.h): ONE launch for all
     // tables, one lane group per id (grid.y = table).  Pending lookup passes are settled first.
@@ -1929,6 +2105,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
       d.a.opt.fast = fast_math_on(v) ? 1 : 0;
       d.a.n = ns[i];
       d.a.use_hints = claim_slot(v, slots0[i], s) ? 1 : 0;
+      mirror_decide_rt(opt, v, slots0[i], d.a, true, s);
       d.a.uniq_serial = ns[i] > 0 ? ++v->uniq_serial : 0u;
       d.ids = ids[i];
       d.n = ns[i];
@@ -1993,6 +2170,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     d.a.det = vars[i]->deterministic ? 1 : 0;
     d.a.n = ns[i];
     d.a.use_hints = claim_slot(vars[i], slots0[i], s) ? 1 : 0;
+    mirror_decide_rt(opt, vars[i], slots0[i], d.a, fz, s);   // (fz: k_papply_multi; else the sorted-position kernels, no mirrors)
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
@@ -2148,6 +2326,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     pa.opt.fast = fast_math_on(v) ? 1 : 0;
     pa.n = n;
     pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
+    mirror_decide<OPT>(v, s0, pa, true, s);
     pa.uniq_serial = ++v->uniq_serial;
     ProfScope ps(v, KV_PROF_APPLY_UNIQUE, s);
     rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_uapply_a(OPT, &pa, ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, (void*)s)
@@ -2205,6 +2384,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     pa_mode = PA_NONE;   // the tiles' entries of a batch whose bookkeeping is done
   }
   if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
+  mirror_decide<OPT>(v, s0, pa, v->fused_index, s);
   if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, pa_mode, tile_ids);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
@@ -2234,6 +2414,7 @@ int kv_apply_group_adam_tok(kv_handle_t v, kv_handle_t mvl, const float* grad, c
   if (n == 0) return KV_OK;
   DeviceGuard dg(v->device);
   MultiLock lk({v, mvl});
+  MirrorKeep mk(v, mvl);   // (apply_common decides whether this apply works on the mirrors: mirror_decide)
   hipStream_t s = (hipStream_t)stream;
   if ((rc = lk.enter(s, token != 0 && token == v->batch_serial ? v : nullptr))) return rc;
   OptArgs a{};
@@ -2266,6 +2447,7 @@ int kv_apply_adagrad_tok(kv_handle_t v, kv_handle_t acc, float lr, const float* 
   if (n == 0) return KV_OK;
   DeviceGuard dg(v->device);
   MultiLock lk({v, acc});
+  MirrorKeep mk(v, acc);   // (mirror_decide in apply_common)
   hipStream_t s = (hipStream_t)stream;
   if ((rc = lk.enter(s, token != 0 && token == v->batch_serial ? v : nullptr))) return rc;
   OptArgs a{};
@@ -2382,7 +2564,10 @@ int kv_attach_slot(kv_handle_t v, kv_handle_t sl, kv_stream_t stream) {
   v->slot_uid = sl->uid;
   v->slot_gen = sl->gen;
   v->batch_serial = 0;
-  if (nrows > 1) k_link_hints<<<nblocks(nrows, TB, 8192), TB, 0, s>>>(dev_view(v), dev_view(sl), nrows);
+  // (the entry above ended any running epoch of either table; a pair of single-chunk tables gets its mirrors filled here)
+  const bool mir = v->chunks.size() == 1 && sl->chunks.size() == 1 && !v->track_delta && !sl->track_delta && mirror_pair(v, sl, s);
+  if (nrows > 1)
+    k_link_hints<<<nblocks(nrows, TB, 8192), TB, 0, s>>>(dev_view(v), dev_view(sl), nrows, v->mirror_epoch.load() & 0xFFFFu, mir ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return KV_OK;
 }
@@ -2406,6 +2591,16 @@ int kv_set_fast_math(kv_handle_t t, int on) {
   return KV_OK;
 }
 
+int kv_get_stat(kv_handle_t t, int which, int64_t* value) {
+  int rc;
+  if ((rc = check_table(t))) return rc;
+  if (!value) return fail(KV_INVALID_ARGUMENT, "kv_get_stat: null value");
+  std::lock_guard<std::mutex> l(t->mu);
+  if (which == KV_STAT_MIRROR_APPLIES) { *value = t->stat_mirror_applies; return KV_OK; }
+  if (which == KV_STAT_MIRROR_EPOCHS) { *value = t->stat_mirror_epochs; return KV_OK; }
+  return fail(KV_INVALID_ARGUMENT, "kv_get_stat: unknown counter %d", which);
+}
+
 int kv_prepare_capture(kv_handle_t t, int64_t max_new_ids, kv_stream_t stream) {
   int rc;
   if ((rc = check_table(t))) return rc;
@@ -2414,6 +2609,7 @@ int kv_prepare_capture(kv_handle_t t, int64_t max_new_ids, kv_stream_t stream) {
   std::lock_guard<std::mutex> l(t->mu);
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
+  mirror_ban(t, s);   // (a captured apply replays without host code: no slot mirrors for this table from here on)
   unsigned c[3];
   HIP_TRY(hipMemcpyAsync(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -2510,6 +2706,7 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t, t);   // `t` lends its workspace: neither its rows nor any record is touched
   if ((rc = enter_op(t, (hipStream_t)stream))) return rc;
   return dedup_locked(t, ids, grad, n, uniq, summed, inverse, num_unique, KV_SCATTER_ADD, (hipStream_t)stream);
 }
@@ -2527,6 +2724,7 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   if (num_segments == 0) return KV_OK;
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t, t);   // `t` lends its workspace: neither its rows nor any record is touched
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
   HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_segments * t->dim * sizeof(float), s));  // segments nobody names
@@ -2575,6 +2773,7 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   if (n > (fused_off() ? (1ll << 21) : FUSED_MAX_N)) return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^%d)", (long long)n, fused_off() ? 21 : 23);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t, t);   // `t` lends its workspace: neither its rows nor any record is touched
   hipStream_t s = (hipStream_t)stream;
   if ((rc = enter_op(t, s))) return rc;
   if ((rc = ensure_workspace(t, n, false, s))) return rc;
@@ -2616,6 +2815,7 @@ int kv_bucket_by_owner(kv_handle_t t, const void* ids, int64_t n, const int64_t*
     return fail(KV_INVALID_ARGUMENT, "bad arguments");
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
+  MirrorKeep mk(t, t);   // `t` lends its workspace: neither its rows nor any record is touched
   hipStream_t s = (hipStream_t)stream;
   const unsigned ntiles = (unsigned)((n + RT - 1) / RT);
   const size_t need = (size_t)std::max(1u, ntiles) * world;

@@ -468,6 +468,16 @@ def kv_set_fast_math(table_handle, on=True):
   _lib.check(_lib.lib().kv_set_fast_math(table_handle.ptr, int(bool(on))))
 
 
+KV_STAT_MIRROR_APPLIES, KV_STAT_MIRROR_EPOCHS = 0, 1
+
+
+def kv_get_stat(table_handle, which):
+  """Counters of the table's own ops (kvhip.h kv_get_stat)."""
+  v = ctypes.c_int64(0)
+  _lib.check(_lib.lib().kv_get_stat(table_handle.ptr, int(which), ctypes.byref(v)))
+  return int(v.value)
+
+
 def kv_forget_stream(stream):
   """A torch stream the caller is about to drop: synchronised, then no table's next op refers to it (kvhip.h kv_forget_stream)."""
   _lib.check(_lib.lib().kv_forget_stream(ctypes.c_void_p(stream.cuda_stream)))
