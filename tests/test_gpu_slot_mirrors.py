@@ -222,6 +222,15 @@ def test_stream_capture_gives_the_mirrors_up(ops):
     with torch.cuda.graph(g, stream=side):
       ops.kv_variable_gather_or_zeros_v2(hs[1], q)
   torch.cuda.synchronize()
+  # ... and so is an optimizer apply of the pair (its end-of-epoch flush would be recorded instead of run)
+  dids = torch.from_numpy(ids).cuda()
+  dgrad = torch.zeros((ids.size, D), device="cuda")
+  g2 = torch.cuda.CUDAGraph()
+  side.wait_stream(torch.cuda.current_stream())
+  with pytest.raises(_lib.KvError):
+    with torch.cuda.graph(g2, stream=side):
+      ops.kv_variable_group_sparse_apply_adam_v4(hs[0], hs[1], dgrad, dids, 0.05, 0.5, 0.9, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+  torch.cuda.synchronize()
   # (b) behind kv_prepare_capture the pair is gone for good: the applies go on (general path), everything still agrees
   for h in hs:
     ops.kv_prepare_capture(h, 10_000)

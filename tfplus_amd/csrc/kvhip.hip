@@ -1021,8 +1021,8 @@ int flush_part(kv_table* t, hipStream_t s);
 // copies, one kernel over the var's rows, then epoch + 1 — which invalidates every copy at once), so it sees, and may
 // change, the authoritative records; the keys' next lean apply finds no valid mirror, takes the general path once and
 // leaves a fresh clean copy (finish_key).  The ops that keep the epoch name their tables in tl_mirror_keep while they
-// enter: the training / inference lookups on the var (they touch var records and rows only), the single-table GroupAdam
-// and Adagrad applies on (var, slot).  KV_NO_MIRROR=1: never (A/B).
+// enter: the training / inference lookups on the var (they touch var records and rows only), the GroupAdam and Adagrad
+// applies on (var, slot), single and batched, and the ops that only borrow a table's workspace.  KV_NO_MIRROR=1: never (A/B).
 static thread_local kv_table* tl_mirror_keep[2] = {nullptr, nullptr};   // [0]: kept in its VAR role, [1]: kept in its SLOT role
 static thread_local kv_table* const* tl_mirror_keep_vars = nullptr;      // ... a batched op's tables in their VAR role
 static thread_local int tl_mirror_keep_nvars = 0;
@@ -1116,11 +1116,15 @@ bool mirror_pair(kv_table* v, kv_table* sl, hipStream_t s) {
 // Does this apply of (v, s0) work on the var rows' slot mirrors?  lean: the launch is k_papply / k_uapply (their lean
 // update is the only code that reads or writes a mirror).  Otherwise the apply reads and writes the slot table's own
 // records: the epoch ends first (the caller entered both tables under MirrorKeep, so nothing has ended it yet).
-static void mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s);
+static int mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s);
 template <int OPT>
-static void mirror_decide(kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) { mirror_decide_rt(OPT, v, s0, pa, lean, s); }
-static void mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) {
+static int mirror_decide(kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) { return mirror_decide_rt(OPT, v, s0, pa, lean, s); }
+static int mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bool lean, hipStream_t s) {
   pa.use_mirror = 0; pa.mirror_epoch = 0u;
+  // (a captured apply of a pair that still has mirrors: their flush would be recorded, not run — see mirror_on_entry)
+  if ((v->mirror_slot || s0->mirror_var) && stream_is_capturing(s))
+    return fail(KV_FAILED_PRECONDITION, "optimizer apply under stream capture on a (var, slot) pair with live slot mirrors: call "
+                                        "kv_prepare_capture on both tables (outside the capture) first");
   const bool eligible = opt != OPT_FTRL && lean && pa.use_hints != 0 && pa.tv.single != 0u && pa.ts0.single != 0u &&
                         !v->track_delta && !s0->track_delta && !stream_is_capturing(s) && mirror_pair(v, s0, s);
   if (eligible) {
@@ -1132,6 +1136,7 @@ static void mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, b
     if (v->mirror_slot) mirror_end_epoch(v, s);
     if (s0->mirror_var && s0->mirror_var != v) mirror_end_epoch(s0->mirror_var, s);
   }
+  return KV_OK;
 }
 
 // mutates == false: a read-only op (the inference gathers): ordered like any other op of the table — behind the table's
@@ -2105,7 +2110,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
       d.a.opt.fast = fast_math_on(v) ? 1 : 0;
       d.a.n = ns[i];
       d.a.use_hints = claim_slot(v, slots0[i], s) ? 1 : 0;
-      mirror_decide_rt(opt, v, slots0[i], d.a, true, s);
+      if ((rc = mirror_decide_rt(opt, v, slots0[i], d.a, true, s))) return rc;
       d.a.uniq_serial = ns[i] > 0 ? ++v->uniq_serial : 0u;
       d.ids = ids[i];
       d.n = ns[i];
@@ -2170,7 +2175,7 @@ static int multi_apply_common(int num_tables, const kv_handle_t* vars, const kv_
     d.a.det = vars[i]->deterministic ? 1 : 0;
     d.a.n = ns[i];
     d.a.use_hints = claim_slot(vars[i], slots0[i], s) ? 1 : 0;
-    mirror_decide_rt(opt, vars[i], slots0[i], d.a, fz, s);   // (fz: k_papply_multi; else the sorted-position kernels, no mirrors)
+    if ((rc = mirror_decide_rt(opt, vars[i], slots0[i], d.a, fz, s))) return rc;   // (fz: k_papply_multi; else the sorted-position kernels, no mirrors)
     d.ids = ids[i];
     d.n = ns[i];
     if (ns[i] == 0) d.w.ntiles = 0;
@@ -2326,7 +2331,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     pa.opt.fast = fast_math_on(v) ? 1 : 0;
     pa.n = n;
     pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
-    mirror_decide<OPT>(v, s0, pa, true, s);
+    if ((rc = mirror_decide<OPT>(v, s0, pa, true, s))) return rc;
     pa.uniq_serial = ++v->uniq_serial;
     ProfScope ps(v, KV_PROF_APPLY_UNIQUE, s);
     rc = (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3) ? kvp_launch_uapply_a(OPT, &pa, ids, v->key_dtype == KV_DT_INT32 ? 1 : 0, n, (void*)s)
@@ -2384,7 +2389,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
     pa_mode = PA_NONE;   // the tiles' entries of a batch whose bookkeeping is done
   }
   if (v->fused_index && reuse && v->index_P) { wd.P = v->index_P; wd.pshift = 64 - ilog2(wd.P); }   // the lookup's partitioning
-  mirror_decide<OPT>(v, s0, pa, v->fused_index, s);
+  if ((rc = mirror_decide<OPT>(v, s0, pa, v->fused_index, s))) return rc;
   if (v->fused_index) rc = fused_apply<OPT>(v, wd, pa, n, s, pa_mode, tile_ids);
   else rc = launch_apply<MODE_APPLY, OPT>(v, wd, pa, n, s);
   if (rc) return rc;
