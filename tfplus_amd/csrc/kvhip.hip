@@ -5,10 +5,11 @@
 //   index    Entry[cap+1]   16 B {int64 key, u32 row, u32 slot-row hint}, open addressing, linear
 //                           probing, cap = 2^k >= 2 * rows (load <= 0.5).  Entry[cap] is the
 //                           home of the one key that equals the EMPTY sentinel.
-//   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32 and RowMeta[r] 16 B {int64 key,
-//            u32 freq = (day << 16) | saturating u16 frequency, u8 flags (bit0 blacklist, bit1
+//   chunks   row slab in chunks of 2^cb rows: rows[r][dim] fp32 and one 32-byte record unit per row: RowMeta 16 B
+//            {int64 key, u32 freq = (day << 16) | saturating u16 frequency, u8 flags (bit0 blacklist, bit1
 //            under_threshold, bit2 under_threshold stale, bit3 released by Delete), u8 delta-list bits,
-//            u16 stamp (serial of the last unique-ids apply that updated the row)}.  Row ids are
+//            u16 stamp (serial of the last unique-ids apply that updated the row)} + SlotMirror 16 B (var tables of
+//            a (var, slot) pair: a write-back copy of the slot row's frequency word and flags; mirror_* below).  Row ids are
 //            dense (bump allocated; rows released by Delete are recycled from a device free
 //            list), row 0 is a permanent all-zero row (misses / nothing).
 //   workspace per-batch index (ent_key / ent_a / ent_b / ent_base / ent_rec, toff, mrow, epart, order; the
