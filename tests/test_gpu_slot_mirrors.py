@@ -238,3 +238,56 @@ def test_stream_capture_gives_the_mirrors_up(ops):
     _step(ops, name, hs, os_, rng, t, ids, unique=(t != 3))
   _check(ops, hs, os_, ids)
   assert ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_APPLIES) == 2
+
+
+def test_a_query_on_another_stream_and_another_thread(ops):
+  """the slot table is queried from a second host thread on a second stream while the first thread steps (lookup + apply) on its
+  own stream, no synchronisation between them: the query ends the epoch behind the apply it follows (a flush that overtook
+  the apply would orphan the copies that apply wrote), the steps go on; at the end both tables are the oracle's"""
+  import threading
+  name, D = "adam4", 16
+  rng = np.random.default_rng(23)
+  hs, os_ = _mk(ops, name, D, seed=23, cap=60_000)
+  ids = np.arange(20_000, dtype=np.int64) - 1000
+  STEPS = 25
+  grads = [rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32) for _ in range(STEPS)]
+  errs, stop = [], threading.Event()
+
+  def stepper():
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        dids = torch.from_numpy(ids).cuda()
+        for t in range(STEPS):
+          b1p, b2p = _beta_pows(t)
+          ops.kv_variable_gather_or_insert_v2(hs[0], dids)
+          ops.kv_variable_group_sparse_apply_adam_v4(hs[0], hs[1], torch.from_numpy(grads[t]).cuda(), dids, 0.05, b1p, b2p, 0.9, 0.999,
+                                                     1e-8, 0.0, 0.0, 0.0, unique_indices=(t % 2 == 0))
+        torch.cuda.current_stream().synchronize()
+    except Exception as e:  # pragma: no cover
+      errs.append(repr(e))
+    finally:
+      stop.set()
+
+  def asker():
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        q = torch.from_numpy(ids[::97].copy()).cuda()
+        while not stop.is_set():
+          ops.kv_get_meta(hs[1], q)                 # a point query on the slot table: ends the running epoch
+          ops.kv_variable_size_v2(hs[0])            # ... and one on the var
+    except Exception as e:  # pragma: no cover
+      errs.append(repr(e))
+
+  th = [threading.Thread(target=stepper), threading.Thread(target=asker)]
+  for t in th:
+    t.start()
+  for t in th:
+    t.join()
+  torch.cuda.synchronize()
+  assert not errs, errs
+  for t in range(STEPS):
+    b1p, b2p = _beta_pows(t)
+    os_[0].gather_or_insert(ids)
+    ko.apply_group_adam(os_[0], os_[1], grads[t], ids, 0.05, b1p, b2p, 0.9, 0.999, 1e-8)
+  _check(ops, hs, os_, ids)
+  assert ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_EPOCHS) > 2

@@ -1175,6 +1175,14 @@ int join_side(kv_table* t, hipStream_t s) {
     const int rc = flush_part(t, s);
     if (rc) return rc;
   }
+  // An epoch of slot mirrors that ends here flushes copies the last lean apply wrote — on the stream of t's last op (an apply
+  // enters both tables; anything later on t has ended the epoch already): the flush must run behind it.  (A flush that
+  // overtook the apply would miss its copies, and the epoch number that ends with it would orphan them for good.)
+  if ((t->mirror_var || t->mirror_slot) && t->has_last && t->last_stream != s) {
+    HIP_TRY(hipEventRecord(t->last_done, t->last_stream));
+    HIP_TRY(hipStreamWaitEvent(s, t->last_done, 0));
+    t->last_stream = s;
+  }
   return mirror_on_entry(t, s);
 }
 
