@@ -197,9 +197,20 @@ int kv_apply_sparse_group_ftrl_tok(kv_handle_t var, kv_handle_t accum, kv_handle
  * already hold (after a checkpoint restore, or a table filled by kv_insert / kv_gather_or_insert). */
 int kv_attach_slot(kv_handle_t var, kv_handle_t slot, kv_stream_t stream);
 
-/* Deterministic reduction mode (off by default): the gradient rows of a repeated id are then summed in an
- * order fixed by the input positions alone — in-tile ranks by position instead of LDS-atomic arrival, a
- * key's tiles in tile order — so the same batch gives bit-identical optimizer state on every run. */
+/* Reduction order of the gradient rows of an id that is repeated in a batch (the optimizer ops, kv_dedup_segment_sum, the
+ * scatter family).  on = 0 (the default): as they arrive.  on = 1, deterministic: an order fixed by the input positions
+ * alone — in-tile ranks by position instead of LDS-atomic arrival, a key's tiles in tile order — so the same batch gives
+ * bit-identical optimizer state on every run.  on = 2, occurrence order: one by one in input order starting from +0, the sum
+ * TF-core's unsorted_segment_sum takes on the CPU in front of the reference's optimizer ops
+ * (_deduplicate_indexed_slices; python/ops/variable_scope.py:1096-1106) — bit for bit, so a batch with repeated ids leaves
+ * the state the reference's CPU path leaves to the same 1e-6 as a batch of unique ids.  A key's sum is then ONE chain of
+ * additions: the table's ops take the sorted-position pipeline (2^21 ids per call) and a key that fills much of the batch
+ * is summed by one wave (DESIGN.md section 3b has the cost).  Implies on = 1.  Single-table ops only: KV_UNIMPLEMENTED from the
+ * kv_multi_* ops and kv_shard_create for such a table (and from this call for a table a kv_shard serves) — the sharded
+ * ops add the senders' partial sums in rank order, which no CPU run defines.  KV_INVALID_ARGUMENT for other values. */
+#define KV_ORDER_ARRIVAL 0
+#define KV_ORDER_FIXED 1
+#define KV_ORDER_OCCURRENCE 2
 int kv_set_deterministic(kv_handle_t h, int on);
 
 /* Row math of the optimizer ops applied to var table `h` (training_ops.cc:7166-7195 and the other per-id bodies).

@@ -1,0 +1,233 @@
+"""kv_set_deterministic(h, 2) — occurrence order (include/kvhip.h): the gradient rows of an id repeated in the batch are
+added one by one in input order starting from +0, which is what TF-core's unsorted_segment_sum does on the CPU in front of
+the reference's optimizer ops (python/ops/variable_scope.py:1096-1106 -> _deduplicate_indexed_slices).  VERDICT r5
+"What's weak" 1: in the default mode a repeated id meets a per-element REORDER bound, not north_star's 1e-6.  Here:
+
+  * kv_dedup_segment_sum on such a table returns the oracle's sums BIT FOR BIT — cold keys, keys with thousands of rows,
+    a key that owns a third of the batch, rows of -0.0 and rows that cancel to zero, dims on and off the float4 grid;
+  * the four optimizer ops on batches with repeated ids leave the oracle's state to the SAME bar as unique ids
+    (rtol 1e-6, atol 1e-7; rows the update does not reach, frequency words, flags: exact), with and without a batch token,
+    over several steps, for every key of the batch;
+  * the mode is a single-table notion: the batched and the sharded ops refuse such a table, and say so;
+  * switching the mode off returns the table to the entry-list kernels.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kv_oracle as ko  # noqa: E402  (checker only)
+from test_gpu_parity import _np, _beta_pows, _assert_same_table, _zipf_ids  # noqa: E402
+from test_gpu_unique_apply import _run, _oracle, _tables  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip("needs a GPU")
+  from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as g
+  return g
+
+
+def _batch(rng, n, universe, D, hot_share=0.0):
+  """Zipf ids (many repeats), optionally one key that owns `hot_share` of the batch; two-signed rows of mixed scale, some
+  exactly -0.0, some that cancel"""
+  ids = _zipf_ids(rng, n, universe) - 17                     # negative keys too
+  if hot_share > 0:
+    ids[rng.random(n) < hot_share] = 424242
+  grad = (rng.normal(0, 1, (n, D)) * rng.choice([1e-4, 1e-2, 3.0], (n, 1))).astype(np.float32)
+  grad[rng.random(n) < 0.02] = -0.0                           # whole rows of negative zero
+  z = np.nonzero(rng.random(n) < 0.02)[0]
+  grad[z, : D // 2 + 1] = -0.0                                # ... and partial ones
+  # pairs that cancel exactly: a later occurrence of the same id carries the negated row
+  order = np.argsort(ids, kind="stable")
+  same = np.nonzero(ids[order][1:] == ids[order][:-1])[0]
+  pick = same[rng.random(same.size) < 0.05]
+  grad[order[pick + 1]] = -grad[order[pick]]
+  return ids, grad
+
+
+def _sums_by_id(uniq, summed):
+  o = np.argsort(uniq, kind="stable")
+  return uniq[o], summed[o]
+
+
+@pytest.mark.parametrize("D", [1, 4, 7, 8, 32, 64, 100, 256])
+def test_dedup_segment_sum_is_the_oracles_bit_for_bit(ops, D):
+  rng = np.random.default_rng(600 + D)
+  n = 60_000 if D <= 64 else 20_000
+  h = ops.kv_variable([D])
+  ops.init_kv_variable_v2(h, np.zeros((4, D), np.float32))
+  ops.kv_set_deterministic(h, ops.KV_ORDER_OCCURRENCE)
+  for hot in (0.0, 0.35):
+    ids, grad = _batch(rng, n, 5000, D, hot_share=hot)
+    u, sm, inv = ops.kv_dedup_segment_sum(h, ids, grad)
+    eu, es, _ = ko.dedup_segment_sum(ids, grad)
+    gu, gs = _sums_by_id(_np(u), _np(sm))
+    xu, xs = _sums_by_id(eu, es)
+    np.testing.assert_array_equal(gu, xu)
+    assert np.array_equal(gs.view(np.uint32), xs.view(np.uint32)), \
+        "sums differ in %d of %d elements" % (int((gs.view(np.uint32) != xs.view(np.uint32)).sum()), gs.size)
+    np.testing.assert_array_equal(_np(u)[_np(inv)], ids)      # the inverse map names each position's id
+    cnt = np.bincount(np.unique(ids, return_inverse=True)[1])
+    assert cnt.max() > (0.3 * n if hot else 1000)             # the batch really had a long chain
+  # the same table in the default mode: not the same bits (the test would notice a switch that does nothing) ...
+  ops.kv_set_deterministic(h, ops.KV_ORDER_ARRIVAL)
+  if D >= 4:
+    u2, sm2, _ = ops.kv_dedup_segment_sum(h, ids, grad)
+    g2u, g2s = _sums_by_id(_np(u2), _np(sm2))
+    np.testing.assert_array_equal(g2u, xu)
+    assert not np.array_equal(g2s.view(np.uint32), xs.view(np.uint32))
+    np.testing.assert_allclose(g2s, xs, rtol=1e-3, atol=1e-3)  # ... yet the same sums
+
+
+@pytest.mark.parametrize("D", [8, 32, 64, 7])
+@pytest.mark.parametrize("name", ["adam4", "adam3", "adagrad", "ftrl"])
+def test_repeated_ids_meet_the_unique_id_bar(ops, name, D):
+  """four steps of Zipf batches (a key with > 30 % of one batch among them), token and plain entry: every key of every batch
+  against the oracle fed TF-core's unique + unsorted_segment_sum of the same batch"""
+  rng = np.random.default_rng(700 + D)
+  hs, _, os_ = _tables(ops, name, D, cap=40_000)
+  ops.kv_set_deterministic(hs[0], ops.KV_ORDER_OCCURRENCE)
+  seen = []
+  for t in range(4):
+    ids, grad = _batch(rng, 30_000, 8000, D, hot_share=0.33 if t == 2 else 0.0)
+    grad *= np.float32(1e-2)
+    seen.append(ids)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.05, b1p=b1p, b2p=b2p)
+    if t % 2 == 0:                                            # a training step: the lookup names the batch for the apply
+      want = os_[0].gather_or_insert(ids)
+      np.testing.assert_array_equal(_np(ops.kv_variable_gather_or_insert_v2(hs[0], ids)), want)
+    _run(ops, name, hs, grad, ids, False, **kw)
+    u, sm, _ = ko.dedup_segment_sum(ids, grad)
+    _oracle(name, os_, sm, u, **kw)
+    allk = np.concatenate(seen)
+    for h, o in zip(hs, os_):
+      _assert_same_table(ops, h, o, allk, rtol=1e-6, atol=1e-7)
+
+
+REG_RTOL = 4e-6   # four regularised steps, each within 1e-6 of the oracle's from the same state
+
+
+def test_regularizers_and_threshold_under_occurrence_order(ops):
+  """l1 / l2 / l21 > 0 and an enter threshold: the branches that blacklist rows and skip low-frequency keys see the same
+  summed gradient as the oracle, so they take the same side"""
+  D = 32
+  rng = np.random.default_rng(77)
+  hs, _, os_ = _tables(ops, "adam4", D, thr=3, cap=40_000)
+  ops.kv_set_deterministic(hs[0], 2)
+  seen = []
+  for t in range(4):
+    ids, grad = _batch(rng, 20_000, 3000, D)
+    grad *= np.float32(3e-3)
+    seen.append(ids)
+    want = os_[0].gather_or_insert(ids)
+    # (rows the regularised update has written are the oracle's to the 1e-6 of the state bar, not to the bit: the shrinkage
+    #  terms are evaluated in the kernels' operation order — see tests/test_gpu_parity.py's regulariser cases)
+    np.testing.assert_allclose(_np(ops.kv_variable_gather_or_insert_v2(hs[0], ids)), want, rtol=REG_RTOL, atol=1e-7)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.05, b1p=b1p, b2p=b2p, l1=1e-3, l2=1e-2, l21=2e-2)
+    _run(ops, "adam4", hs, grad, ids, False, **kw)
+    u, sm, _ = ko.dedup_segment_sum(ids, grad)
+    _oracle("adam4", os_, sm, u, **kw)
+    for h, o in zip(hs, os_):
+      _assert_same_table(ops, h, o, np.concatenate(seen), rtol=REG_RTOL, atol=1e-7)
+
+
+def test_single_table_notion(ops):
+  from tfplus_amd import _lib
+  D = 16
+  hv = ops.kv_variable([D]); hs = ops.kv_variable([3 * D])
+  for h, w in ((hv, D), (hs, 3 * D)):
+    ops.init_kv_variable_v2(h, np.zeros((4, w), np.float32))
+  with pytest.raises(Exception, match="0, 1 or 2"):
+    ops.kv_set_deterministic(hv, 3)
+  ops.kv_set_deterministic(hv, 2)
+  ids = torch.arange(100, device="cuda")
+  with pytest.raises(Exception, match="per-table ops"):
+    ops.kv_multi_gather_or_insert([hv], [ids])
+  sh = ctypes.c_void_p()
+  rc = _lib.lib().kv_shard_create(hv.ptr, 2, 0, 0, 1 << 16, 0, ctypes.byref(sh))
+  assert rc != 0 and "single-table" in _lib.lib().kv_last_error().decode()
+  # ... and the other way round: a table a shard serves cannot enter the mode
+  ops.kv_set_deterministic(hv, 0)
+  rc = _lib.lib().kv_shard_create(hv.ptr, 2, 0, 0, 1 << 16, 0, ctypes.byref(sh))
+  assert rc == 0, _lib.lib().kv_last_error()
+  with pytest.raises(Exception, match="kv_shard"):
+    ops.kv_set_deterministic(hv, 2)
+  ops.kv_set_deterministic(hv, 1)                             # the plain deterministic mode is fine there
+  assert _lib.lib().kv_shard_destroy(sh) == 0
+  ops.kv_set_deterministic(hv, 2)                             # the shard is gone
+
+
+def test_mode_off_returns_to_the_entry_lists(ops):
+  """on, a step, off, a step with a token: both agree with the oracle (the second within the reorder tolerance the default
+  mode documents), and the second step runs the lean slot-mirror update — an entry-list kernel"""
+  D = 32
+  rng = np.random.default_rng(5)
+  hs, _, os_ = _tables(ops, "adam4", D, cap=40_000)
+  ops.kv_set_deterministic(hs[0], 2)
+  seen = []
+  for t in range(4):
+    if t == 2:
+      ops.kv_set_deterministic(hs[0], 0)
+    ids = rng.permutation(np.repeat(np.arange(6000, dtype=np.int64), 2))   # every id twice
+    grad = rng.normal(0, 1e-2, (ids.size, D)).astype(np.float32)
+    seen.append(ids)
+    ops.kv_variable_gather_or_insert_v2(hs[0], ids); os_[0].gather_or_insert(ids)
+    b1p, b2p = _beta_pows(t)
+    kw = dict(lr=0.05, b1p=b1p, b2p=b2p)
+    before = ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_APPLIES)
+    _run(ops, "adam4", hs, grad, ids, False, **kw)
+    lean = ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_APPLIES) - before
+    assert (lean > 0) == (t >= 2), (t, lean)                  # the slot-mirror update is the entry-list kernels' alone
+    u, sm, _ = ko.dedup_segment_sum(ids, grad)
+    _oracle("adam4", os_, sm, u, **kw)
+    for h, o in zip(hs, os_):
+      # two addends: a + b == b + a bit for bit, so even the default mode meets 1e-6 here
+      _assert_same_table(ops, h, o, np.concatenate(seen), rtol=1e-6, atol=1e-7)
+
+
+def test_headline_shape_batch(ops):
+  """configs[1]'s batch shape on a table small enough for the oracle to hold whole: 1 M ids, Zipf 1.2 over 2 M keys, dim 32,
+  GroupAdam — every touched key at 1e-6, and the time a step takes in this mode (printed; DESIGN section 3b quotes it)"""
+  import time
+  D, K, N = 32, 2_000_000, 1_000_000
+  rng = np.random.default_rng(9)
+  table = rng.standard_normal((64, D)).astype(np.float32)
+  hv = ops.kv_variable([D], capacity_hint=K + N); hs = ops.kv_variable([3 * D], capacity_hint=K + N)
+  ov = ko.OracleKv(D, 0, table, day=19000, picker=1, seed=3); osl = ko.OracleKv(3 * D, 0, np.zeros((16, 3 * D), np.float32), day=19000, picker=1, seed=3)
+  for h, tb in ((hv, table), (hs, np.zeros((16, 3 * D), np.float32))):
+    ops.kv_set_clock_days(h, 19000); ops.kv_set_seed(h, 3); ops.init_kv_variable_v2(h, tb)
+  ops.kv_set_deterministic(hv, 2)
+  ranks = np.arange(1, K + 1, dtype=np.float64) ** -1.2
+  cdf = np.cumsum(ranks); cdf /= cdf[-1]
+  took = []
+  seen = []
+  for t in range(3):
+    ids = (np.searchsorted(cdf, rng.random(N)).astype(np.int64) * 2654435761) % (1 << 40)
+    grad = rng.normal(0, 1e-2, (N, D)).astype(np.float32)
+    dids, dgrad = torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda()
+    seen.append(ids)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = ops.kv_variable_gather_or_insert_v2(hv, dids)
+    b1p, b2p = _beta_pows(t)
+    ops.kv_variable_group_sparse_apply_adam_v4(hv, hs, dgrad, dids, 1e-3, b1p, b2p, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+    torch.cuda.synchronize(); took.append(time.perf_counter() - t0)
+    np.testing.assert_array_equal(_np(out), ov.gather_or_insert(ids))
+    u, sm, _ = ko.dedup_segment_sum(ids, grad)
+    ko.apply_group_adam(ov, osl, sm, u, 1e-3, b1p, b2p, 0.9, 0.999, 1e-8)
+  keys = np.unique(np.concatenate(seen))
+  cnt = np.bincount(np.unique(seen[-1], return_inverse=True)[1])
+  print("\noccurrence order, 1 M ids Zipf 1.2 (largest key: %d rows), dim 32: %.2f ms per step (lookup + GroupAdam)"
+        % (cnt.max(), min(took) * 1e3))
+  got, exp = _np(ops.kv_variable_gather_or_zeros_v2(hv, keys)), ov.gather_or_zeros(keys)
+  np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-7)
+  gots, exps = _np(ops.kv_variable_gather_or_zeros_v2(hs, keys)), osl.gather_or_zeros(keys)
+  np.testing.assert_allclose(gots, exps, rtol=1e-6, atol=1e-7)
+  np.testing.assert_array_equal(_np(ops.kv_variable_get_count_v2(hs, keys[:20000])), osl.get_count(keys[:20000]))

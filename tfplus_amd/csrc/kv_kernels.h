@@ -437,8 +437,9 @@ __host__ __device__ inline int apply_lanes(int D) {
 }
 
 // chunk geometry of a hot key: HC rows per chunk — about what a batch of cold keys costs, so every work item
-// of the apply weighs the same and a round-robin hand-out is balanced
-__host__ __device__ inline unsigned chunk_rows(unsigned cnt) { (void)cnt; return (unsigned)HC; }
+// of the apply weighs the same and a round-robin hand-out is balanced.  Occurrence order (det == 2): one chunk, the
+// whole key — a sum taken one row at a time in list order is one chain.
+__host__ __device__ inline unsigned chunk_rows(unsigned cnt, int det) { return det == 2 ? cnt : (unsigned)HC; }
 
 // HSK_: LDS hash slots (the lookup that runs beside the probing gather takes 512 to leave LDS for the
 // gather blocks; more unique keys than 3/4 of the slots split into sub-hash classes either way)
@@ -571,7 +572,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         sum += kcnt[q];
         if (u < nu) {
           if (kcnt[q] <= (unsigned)LCOLD) ch += 1u;
-          else { ch += 1u << 16; nchs += (kcnt[q] + chunk_rows(kcnt[q]) - 1u) / chunk_rows(kcnt[q]); }
+          else { ch += 1u << 16; nchs += (kcnt[q] + chunk_rows(kcnt[q], a.det) - 1u) / chunk_rows(kcnt[q], a.det); }
         }
       }
       const unsigned cur = lpcur;
@@ -590,7 +591,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
           if (kcnt[q] <= (unsigned)LCOLD) { krank[q] = cbase + (chrun & 0xFFFFu); chrun += 1u; }
           else {
             krank[q] = hbase + (chrun >> 16); chrun += 1u << 16;
-            kchunk[q] = kbase + nrun; nrun += (kcnt[q] + chunk_rows(kcnt[q]) - 1u) / chunk_rows(kcnt[q]);
+            kchunk[q] = kbase + nrun; nrun += (kcnt[q] + chunk_rows(kcnt[q], a.det) - 1u) / chunk_rows(kcnt[q], a.det);
           }
         }
       }
@@ -604,7 +605,7 @@ __device__ __forceinline__ void part_keys_body(const WsDev& w, const PartArgs& a
         w.coldlist[2 * (size_t)krank[q]] = ra;
         w.coldlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], 0u, 0u);
       } else {
-        const unsigned cr = chunk_rows(kcnt[q]);
+        const unsigned cr = chunk_rows(kcnt[q], a.det);
         w.hotlist[2 * (size_t)krank[q]] = ra;
         w.hotlist[2 * (size_t)krank[q] + 1] = make_uint4(kst[q], kcnt[q], kchunk[q], cr);
         const unsigned nch = (kcnt[q] + cr - 1u) / cr;
@@ -1003,6 +1004,188 @@ __device__ __forceinline__ float fold_identity(int op) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_occ_sum: occurrence order (PartArgs::det == 2) — the hot keys' sums, one chain per key
+// ------------------------------------------------------------------------------------------
+// TF-core's unsorted_segment_sum adds a segment's rows one by one in input order, starting from +0; fp32 addition does not
+// associate, so the only way to the same bits is the same chain.  A cold key (<= LCOLD rows) is summed that way by its lane
+// group in k_apply anyway.  A hot key has ONE work item in this mode (chunk_rows) and this kernel in front of k_apply takes
+// its chain: one block per item; wave 0 carries the running sum (lane = column, NC columns per lane) over the rows of a
+// stage in LDS while the other waves fetch the next stage's rows (positions of the stage after that): the chain's wave
+// never waits for HBM, only for its own additions.  The sum goes to hpart[the item's chunk number], where k_apply's hot path
+// picks it up.  Fold ops of the scatter family ride the same chain.
+constexpr int OCC_TB = 512;            // 1 chain wave + 7 fetch waves
+constexpr int OCC_STAGE = 14336;       // floats per stage (two stages in LDS: 124 KB with the positions — one block per CU;
+                                       // a block's fetch is one HBM round trip per stage, so the stage is what it can hold)
+constexpr int OCC_ROWS = 1024;         // rows per stage at most (the stage's positions: three stages in LDS)
+inline size_t occ_smem_bytes() { return (size_t)2 * OCC_STAGE * 4 + (size_t)3 * OCC_ROWS * 4; }
+template <int NC, int FOP>
+__device__ __forceinline__ void occ_chain(const float* __restrict__ buf, unsigned rows, int D, int lane, float (&acc)[NC]) {
+  // rows of the stage in order; a lane's columns are independent chains.  The LDS reads of a batch of rows are issued
+  // together, one batch ahead of the additions; lanes past the row's end read column 0 and their sums are dropped.
+  // Measured on a key of 188 k rows of dim 32 (tools/occ_step.py): 1.3 ms for the chain, ~15 cycles a row.
+  constexpr int UJ = NC >= 8 ? 2 : 16 / NC;
+  int col[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) col[c] = (lane + c * 64 < D) ? lane + c * 64 : 0;
+  auto rd = [&](unsigned r0, float (&x)[UJ][NC]) {
+#pragma unroll
+    for (int j = 0; j < UJ; ++j)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) x[j][c] = buf[(size_t)(r0 + j) * D + col[c]];
+  };
+  auto add = [&](const float (&x)[UJ][NC]) {
+#pragma unroll
+    for (int j = 0; j < UJ; ++j)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = fold2(FOP, acc[c], x[j][c]);   // (FOP is a constant: a run-time switch per addition cost 80 cycles a row, 6.6 ms)
+  };
+  float xa[UJ][NC], xb[UJ][NC];
+  const unsigned full = rows / (2 * UJ) * (2 * UJ);
+  unsigned r = 0;
+  if (full) {
+    rd(0, xa);
+    for (; r < full; r += 2 * UJ) {   // wave-uniform
+      rd(r + UJ, xb);
+      add(xa);
+      if (r + 2 * UJ < full) rd(r + 2 * UJ, xa);
+      add(xb);
+    }
+  }
+  for (; r < rows; ++r) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float x = buf[(size_t)r * D + col[c]];
+      acc[c] = fold2(FOP, acc[c], x);
+    }
+  }
+}
+template <int NC>
+__device__ __forceinline__ void occ_sum_body(const WsDev& w, const PartArgs& a, int fop) {
+  if (*reinterpret_cast<volatile unsigned*>(&a.tv.counters[1])) return;   // the index pass gave up on this batch
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* buf = reinterpret_cast<float*>(smem_raw);                               // [2][OCC_STAGE]
+  unsigned* lpos = reinterpret_cast<unsigned*>(smem_raw + (size_t)2 * OCC_STAGE * 4);   // [3][OCC_ROWS]
+  const unsigned total = w.ctr[2];
+  const int D = a.tv.dim;
+  const unsigned S = min((unsigned)OCC_ROWS, (unsigned)OCC_STAGE / (unsigned)D);   // rows per stage (D <= 1024: at least 14)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool chain = tid < 64;
+  const int ft = tid - 64;                       // fetch thread number
+  constexpr int FT = OCC_TB - 64;
+  const float ident = fold_identity(fop);
+  const bool vec = (D & 3) == 0;
+  for (unsigned it = blockIdx.x; it < total; it += gridDim.x) {   // block-uniform
+    const uint4 item = w.items[it];
+    if (!(item.x & HEAD_BIT)) continue;
+    const uint4 rb = w.hotlist[2 * (size_t)(item.x & ~HEAD_BIT) + 1];
+    const unsigned lo = rb.x, cnt = rb.y;
+    const unsigned nst = (cnt + S - 1) / S;
+    auto rows_of = [&](unsigned st) { return min(S, cnt - st * S); };
+    constexpr int PV = (OCC_ROWS + FT - 1) / FT;
+    auto ask_pos = [&](unsigned st, unsigned (&pv)[PV]) {   // fetch waves: the stage's positions, asked for ...
+      if (st >= nst) return;
+      const unsigned n_ = rows_of(st);
+#pragma unroll
+      for (int k = 0; k < PV; ++k) pv[k] = w.order[lo + st * S + min((unsigned)(ft + k * FT), n_ - 1u)] & ~HEAD_BIT;
+    };
+    auto put_pos = [&](unsigned st, const unsigned (&pv)[PV]) {   // ... and filed (behind the rows' loads: one round trip for both)
+      if (st >= nst) return;
+      unsigned* dst = lpos + (size_t)(st % 3u) * OCC_ROWS;
+      const unsigned n_ = rows_of(st);
+#pragma unroll
+      for (int k = 0; k < PV; ++k) {
+        const unsigned r = ft + k * FT;
+        if (r < n_) dst[r] = pv[k];
+      }
+    };
+    auto fetch_rows = [&](unsigned st) {         // fetch waves: the stage's rows, every load of a thread in flight together
+      if (st >= nst) return;
+      const unsigned* ps = lpos + (size_t)(st % 3u) * OCC_ROWS;
+      float* dst = buf + (size_t)(st & 1u) * OCC_STAGE;
+      const unsigned n_ = rows_of(st);
+      if (vec) {
+        const unsigned q = (unsigned)D >> 2, nv = n_ * q;
+        constexpr int UB = 8;
+        for (unsigned e0 = 0; e0 < nv; e0 += UB * FT) {
+          float4 v[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            // (no branch around a load: a thread past the stage's end reads its last element again — a load under a
+            //  condition made the compiler wait for the one before it, eight round trips per stage instead of one: 2.2 ms
+            //  against 0.9 for the fetch of the same key)
+            const unsigned e = min(e0 + u * FT + ft, nv - 1u);
+            const unsigned r = e / q, c4 = e - r * q;
+            const unsigned pos = ps[r];
+            const float* base = (pos & EP_TAG) ? a.epart : a.grad;
+            const float* src = base + (size_t)(pos & ~EP_TAG) * D + 4u * c4;
+            float t4[4];
+            ldv_stream<4>(src, t4);
+            v[u] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const unsigned e = e0 + u * FT + ft;
+            if (e < nv) reinterpret_cast<float4*>(dst)[e] = v[u];
+          }
+        }
+      } else {
+        const unsigned ne = n_ * (unsigned)D;
+        constexpr int UB = 8;
+        for (unsigned e0 = 0; e0 < ne; e0 += UB * FT) {
+          float v[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const unsigned e = min(e0 + u * FT + ft, ne - 1u);
+            const unsigned r = e / (unsigned)D, c = e - r * (unsigned)D;
+            const unsigned pos = ps[r];
+            const float* base = (pos & EP_TAG) ? a.epart : a.grad;
+            v[u] = __builtin_nontemporal_load(base + (size_t)(pos & ~EP_TAG) * D + c);
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const unsigned e = e0 + u * FT + ft;
+            if (e < ne) dst[e] = v[u];
+          }
+        }
+      }
+    };
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = ident;
+    __syncthreads();                             // the previous item's buffers have been read
+    unsigned pv[PV];
+    if (!chain) { ask_pos(0, pv); put_pos(0, pv); ask_pos(1, pv); put_pos(1, pv); }
+    __syncthreads();
+    if (!chain) fetch_rows(0);
+    __syncthreads();
+    for (unsigned st = 0; st < nst; ++st) {      // block-uniform
+      if (chain) {
+        const float* sb = buf + (size_t)(st & 1u) * OCC_STAGE;
+        switch (fop) {
+          case KV_SCATTER_MUL: occ_chain<NC, KV_SCATTER_MUL>(sb, rows_of(st), D, lane, acc); break;
+          case KV_SCATTER_MIN: occ_chain<NC, KV_SCATTER_MIN>(sb, rows_of(st), D, lane, acc); break;
+          case KV_SCATTER_MAX: occ_chain<NC, KV_SCATTER_MAX>(sb, rows_of(st), D, lane, acc); break;
+          default: occ_chain<NC, KV_SCATTER_ADD>(sb, rows_of(st), D, lane, acc); break;
+        }
+      }
+      else { ask_pos(st + 2, pv); fetch_rows(st + 1); put_pos(st + 2, pv); }
+      __syncthreads();
+    }
+    if (chain) {
+      float* dst = w.hpart + (size_t)item.z * D;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int d = lane + c * 64;
+        if (d < D) dst[d] = acc[c];
+      }
+    }
+  }
+}
+template <int NC>
+__global__ void __launch_bounds__(OCC_TB) k_occ_sum(WsDev w, PartArgs a, int fop) { occ_sum_body<NC>(w, a, fop); }
+
+
 // The slot-table rows of one key, resolved by the group leader.  FindOrInsertUnsafe(var, filter_out !=
 // nullptr) kv_variable.h:382-408 and FindOrInsertUnsafe(slot, nullptr) :409-414; FTRL probes linear
 // before accum (training_ops.cc:701-704).  `m0` is the record of the hinted slot row (requested early).
@@ -1218,27 +1401,42 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
       // hides the hops: a second row buffer costs more than it gains); positions one step ahead
       unsigned pa_[RB], pb_[RB];
       float va[RB][K][V];
-      ldpos(0, pa_);
-      for (unsigned st = 0; st < nst; ++st) {
-        ldrows(pa_, va);
-        ldpos(st + 1, pb_);
+      const bool occ_order = a.det == 2;   // uniform over the launch
+      if (occ_order) {
+        // occurrence order: the key's rows were added one by one, in list order, by k_occ_sum (one chain per key: a block
+        // with its own load pipeline); every group reads the sum
+        const float* src = w.hpart + (size_t)item.z * D;
 #pragma unroll
-        for (int j = 0; j < RB; ++j) { acc_row(gv, va[j]); pa_[j] = pb_[j]; }
+        for (int k = 0; k < K; ++k) {
+          const int e0 = (lane + k * LPR) * V;
+          if (e0 < D) ldv<V>(src + e0, gv[k]);
+        }
+      } else {
+        ldpos(0, pa_);
+        for (unsigned st = 0; st < nst; ++st) {
+          ldrows(pa_, va);
+          ldpos(st + 1, pb_);
+#pragma unroll
+          for (int j = 0; j < RB; ++j) { acc_row(gv, va[j]); pa_[j] = pb_[j]; }
+        }
       }
       // a key with a single chunk is finished here: its state rows are requested now (the row buffers are free),
       // one round trip under the shuffle tree instead of three hops behind it
       const unsigned nch = (rb.y + rb.w - 1u) / rb.w;
       if (MODE == MODE_APPLY && nch == 1u) prefetch_state<OPT, V, LPR, K>(a, ra, g == 0, lane, D, m0, hint_loaded, pre, have_x, have_s);
       // the groups' sums meet: a fixed shuffle tree, every lane ends with the chunk's sum
+      // (occurrence order: every group holds the whole sum already)
+      if (!occ_order) {
 #pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
+        for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+          for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int cc = 0; cc < V; ++cc) {
-            const float x = __shfl_xor(gv[k][cc], o);
-            gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
-          }
+            for (int cc = 0; cc < V; ++cc) {
+              const float x = __shfl_xor(gv[k][cc], o);
+              gv[k][cc] = (MODE == MODE_APPLY) ? gv[k][cc] + x : fold2(fop, gv[k][cc], x);
+            }
+        }
       }
       if (nch > 1u) {
         if (g == 0) {
@@ -1262,7 +1460,15 @@ __device__ __forceinline__ void apply_body(const WsDev& w, const PartArgs& a) {
       uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = ra;
       if (live) { ra = w.coldlist[2 * (size_t)u]; rb = w.coldlist[2 * (size_t)u + 1]; }
       const unsigned start = rb.x, cnt = live ? rb.y : 0u;
-      if (cnt > 0u) load_row(rb.z, gv);     // ident op with one operand: the first row IS the partial result
+      if (cnt > 0u) {
+        load_row(rb.z, gv);     // ident op with one operand: the first row IS the partial result
+        if (a.det == 2) {       // ... up to the sign of a zero: TF-core's segment sum starts from +0 (0 + -0 = +0)
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int cc = 0; cc < V; ++cc) gv[k][cc] = (MODE == MODE_APPLY) ? 0.f + gv[k][cc] : fold2(fop, ident, gv[k][cc]);
+        }
+      }
       if (MODE == MODE_APPLY) prefetch_state<OPT, V, LPR, K>(a, ra, live, lane, D, m0, hint_loaded, pre, have_x, have_s);
       for (unsigned j0 = 1; j0 < cnt; j0 += RC) {
         float val[RC][K][V];

@@ -453,6 +453,9 @@ struct kv_table {
   bool mirror_shared = false;               // slot side: a second var attached it — no mirrors for this table any more
   unsigned uniq_serial = 0;        // stamp of the table's last kv_apply_*_unique launch (kv_uapply.h; wraps at 65535: stamps cleared)
   bool deterministic = false;      // kv_set_deterministic
+  bool occurrence_order = false;   // kv_set_deterministic(h, 2): a repeated id's gradient rows are added one by one in input order
+                                   // (the sorted-position pipeline with one chain per key; implies deterministic)
+  std::atomic<int> shard_refs{0};  // kv_shard handles built on this table
   bool fast_math = false;          // kv_set_fast_math: the optimizers' sqrt / division on v_sqrt_f32 / v_rcp_f32 (1 ulp) —
                                    // never in deterministic mode, which keeps the IEEE sequences
   uint64_t uid = 0;                // unique over the process: names the attached slot table safely
@@ -741,6 +744,7 @@ int ensure_workspace(kv_table* t, long long n, bool need_part, hipStream_t s) {
 
 bool fused_ok(int D);
 bool fused_off();
+bool fused_tab(const kv_table* t);
 
 // The sharded owner ops (kv_shard_lookup_serve / kv_shard_apply_serve) read a rank's OWN exchange segment where it was
 // written: records [lo, lo + len) of the buffers the calling thread's next op on `table` reads come from `ids` / `grad`
@@ -819,6 +823,8 @@ struct ProfScope {
 
 // the optimizers' row math on the hardware's 1-ulp sqrt / reciprocal (kv_device.h kv_sqrt / kv_div)?
 bool fast_math_on(const kv_table* t) { return t->fast_math && !t->deterministic; }
+// PartArgs::det: 0 arrival order, 1 an order fixed by the input positions, 2 occurrence order (one chain per key; kv_kernels.h)
+int det_mode(const kv_table* t) { return t->occurrence_order ? 2 : t->deterministic ? 1 : 0; }
 
 unsigned today(const kv_table* t) {
   if (t->fixed_day >= 0) return (unsigned)t->fixed_day & 0xFFFFu;
@@ -835,7 +841,7 @@ void launch_tile(kv_table* t, const WsDev& wd, const void* ids, const int* count
   if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
   const int grid = (int)wd.ntiles;
   const size_t sh = tile_smem_bytes(FIRST);
-  const int det = t->deterministic ? 1 : 0;
+  const int det = det_mode(t);
 #define KV_TILE(IDT)                                                                     \
   do {                                                                                   \
     if (md) k_tile_multi<FIRST, IDT><<<dim3(gx, (unsigned)ntab), TBT, sh, s>>>(md);       \
@@ -916,6 +922,9 @@ bool fused_ok(int D) {
   const int q = D / 4;
   return q >= 1 && q <= 64;
 }
+// ... and tables: one in occurrence-order mode takes the sorted-position pipeline for every op, like a dim the entry-list
+// kernels do not serve (its sums are one chain per key there; the entry lists sum tile by tile)
+bool fused_tab(const kv_table* t) { return fused_ok(t->dim) && !t->occurrence_order; }
 // lanes per row of the row-copy kernels: dim / 4 rounded up to a power of two
 int row_lanes(int D) { return (int)pow2ceil((unsigned long long)std::max(1, D / 4)); }
 bool pow2_rows(int D) { return (D & 3) == 0 && row_lanes(D) == D / 4; }
@@ -926,7 +935,7 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
   if (ids_kind < 0) ids_kind = t->key_dtype == KV_DT_INT32 ? 1 : 0;
   const int grid = (int)wd.ntiles;
   const size_t sh = ltile_smem_bytes();
-  const int det = t->deterministic ? 1 : 0;
+  const int det = det_mode(t);
   const int q = row_lanes(td.dim);
 #define KV_LT2(IDT, VQ)                                                                                     \
   do {                                                                                                      \
@@ -953,7 +962,7 @@ void launch_ltile(kv_table* t, const TableDev& td, const WsDev& wd, const void* 
 // the table-less tile pass of the sharded route (int64 ids): entries, mrow, every position's entry number
 void launch_ltile_notable(kv_table* t, const TableDev& td, const WsDev& wd, const void* ids, long long n, hipStream_t s,
                           const int* counts = nullptr, bool int32_ids = false) {
-  const int det = t->deterministic ? 1 : 0;
+  const int det = det_mode(t);
   if (int32_ids) k_ltile<int, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const int*)ids, counts, n, det, nullptr);
   else k_ltile<long long, 1, false, true><<<(int)wd.ntiles, TBT, ltile_smem_bytes(), s>>>(td, wd, (const long long*)ids, counts, n, det, nullptr);
 }
@@ -976,6 +985,24 @@ int launch_apply(kv_table* prof_t, const WsDev& wd, const PartArgs& pa, long lon
   const unsigned gfin = (unsigned)std::max<long long>(1, std::min<long long>(256, nmax / 4096 + 1));   // each block reads its share of the items at once
   auto fn = (MODE == MODE_APPLY && (OPT == OPT_ADAM_V4 || OPT == OPT_ADAM_V3)) ? kvp_launch_apply_a : kvp_launch_apply_b;
   int rc;
+  if (pa.det == 2 && !md) {
+    // occurrence order: the hot keys' chains first (k_occ_sum: one block per key, the sums to hpart), k_apply reads them
+    const int fop = MODE == MODE_APPLY ? KV_SCATTER_ADD : pa.fold_op;
+    const unsigned og = (unsigned)std::max<long long>(1, std::min<long long>(2048, nmax / 256 + 1));
+    const int nc = (D + 63) / 64;
+    // (two stages + positions: above the 64 KB a launch gets without asking — per device, so asked at every launch)
+#define KV_OCC(NC_)                                                                                                          \
+    do {                                                                                                                       \
+      HIP_TRY(hipFuncSetAttribute((const void*)k_occ_sum<NC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)occ_smem_bytes())); \
+      k_occ_sum<NC_><<<og, OCC_TB, occ_smem_bytes(), s>>>(wd, pa, fop);                                                        \
+    } while (0)
+    if (nc <= 1) KV_OCC(1);
+    else if (nc <= 2) KV_OCC(2);
+    else if (nc <= 4) KV_OCC(4);
+    else if (nc <= 8) KV_OCC(8);
+    else KV_OCC(16);
+#undef KV_OCC
+  }
   {
     ProfScope ps(prof_t, KV_PROF_APPLY_SORTED, s);
     rc = fn(MODE, OPT, &wd, &pa, (void*)s, md, ntab, grid, 0);
@@ -1665,7 +1692,7 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
   // any batch length: chunks of 2^21 ids are looked up one after another (same semantics as one
   // pass: the frequency adds saturate identically and rows are inserted by the first chunk)
   // the entry-list pipeline indexes a batch of up to FUSED_MAX_N ids in one pass; the sorted-position one 2^21
-  const long long CHK = fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21);
+  const long long CHK = fused_tab(t) ? FUSED_MAX_N : (1ll << 21);
   const size_t idsz = pairs ? 16 : (t->key_dtype == KV_DT_INT32 ? 4 : 8);
   t->batch_serial = 0;
   for (long long off = 0; off < n; off += CHK) {
@@ -1681,10 +1708,10 @@ static int gather_or_insert_impl(kv_handle_t t, const void* ids, const int32_t* 
     PartArgs pa{};
     pa.tv = td; pa.ts0 = td; pa.ts1 = td;
     pa.day = today(t);
-    pa.det = t->deterministic ? 1 : 0;
+    pa.det = det_mode(t);
     pa.n = m;
     const bool defer_part = token != nullptr && n <= CHK;   // a token is asked for: an apply of this batch follows
-    if (fused_ok(t->dim)) { if ((rc = fused_lookup_pass(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, defer_part))) return rc; }
+    if (fused_tab(t)) { if ((rc = fused_lookup_pass(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, defer_part))) return rc; }
     else index_pass<MODE_LOOKUP>(t, wd, pa, idp, cp, m, pairs ? 2 : -1, op, s, token != nullptr && n <= CHK);
   }
   HIP_TRY(hipGetLastError());
@@ -1705,7 +1732,7 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
     return fail(KV_INVALID_ARGUMENT, "combiner must be one of 'mean', 'sqrtn' or 'sum'");  // embedding_ops.py:345
   if (segment_dtype != KV_DT_INT32 && segment_dtype != KV_DT_INT64)
     return fail(KV_INVALID_ARGUMENT, "segment ids must be int32 or int64");
-  const bool fused = fused_ok(t->dim);   // (dim is fixed at creation: readable without the lock)
+  const bool fused = fused_tab(t);   // (dim is fixed at creation: readable without the lock)
   if (n < 0 || n > (fused ? FUSED_MAX_N : (1ll << 21)))
     return fail(KV_INVALID_ARGUMENT, "sp_ids: %lld values (at most 2^%d per call)", (long long)n, fused ? 23 : 21);
   if (num_segments < 0 || num_segments > (1ll << 31) - 2) return fail(KV_INVALID_ARGUMENT, "bad num_segments");
@@ -1745,7 +1772,7 @@ int kv_lookup_sparse(kv_handle_t t, const void* ids, const void* segment_ids, in
   pa.tv = td; pa.ts0 = td; pa.ts1 = td;
   pa.day = today(t);
   pa.count_once = count_occurrences ? 0 : 1;
-  pa.det = t->deterministic ? 1 : 0;
+  pa.det = det_mode(t);
   pa.n = n;
   t->batch_serial = 0;
   if (fused) {
@@ -1942,8 +1969,10 @@ static int multi_common(int num_tables, const kv_handle_t* tables, const void* c
   for (int i = 0; i < num_tables; ++i) {
     if (tables[i]->dim != tables[0]->dim || tables[i]->key_dtype != tables[0]->key_dtype)
       return fail(KV_INVALID_ARGUMENT, "batched op: tables must share dim and key dtype (group them by shape)");
+    if (tables[i]->occurrence_order)
+      return fail(KV_UNIMPLEMENTED, "batched op: a table in occurrence-order mode (kv_set_deterministic(h, 2)) takes the per-table ops");
     // (the entry-list kernels index up to FUSED_MAX_N ids per table and call, like the single-table ops; other dims 2^21)
-    if (ns[i] < 0 || ns[i] > (fused_ok(tables[0]->dim) ? FUSED_MAX_N : (1ll << 21)))
+    if (ns[i] < 0 || ns[i] > (fused_tab(tables[0]) ? FUSED_MAX_N : (1ll << 21)))
       return fail(KV_INVALID_ARGUMENT, "indices: bad length %lld", (long long)ns[i]);
     if (ns[i] > 0 && !ids[i]) return fail(KV_INVALID_ARGUMENT, "indices pointer is null");
     if (!tables[i]->initialized)
@@ -2002,7 +2031,7 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
     std::memset(&d, 0, sizeof d);
     d.w = ws_view(tables[i], std::max<long long>(ns[i], 1));
     if (seg_caps) d.w.seg_cap = seg_caps[i];
-    if (fused_ok(tables[i]->dim)) { d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
+    if (fused_tab(tables[i])) { d.w.P = fused_default_P(std::max<long long>(ns[i], 1)); d.w.pshift = 64 - ilog2(d.w.P); }
     d.a.tv = dev_view(tables[i]); d.a.ts0 = d.a.tv; d.a.ts1 = d.a.tv;
     d.a.day = today(tables[i]);
     d.a.det = tables[i]->deterministic ? 1 : 0;
@@ -2019,7 +2048,7 @@ static int multi_lookup_impl(int num_tables, const kv_handle_t* tables, const vo
   rel.launched = true;
   const MultiDesc* md = reinterpret_cast<const MultiDesc*>(sl->dev);
   kv_table* t0 = tables[0];
-  if (fused_ok(t0->dim)) {
+  if (fused_tab(t0)) {
     for (int i = 0; i < num_tables; ++i) tables[i]->fused_index = true;
     launch_ltile(t0, hd[0].a.tv, wmax, nullptr, nullptr, nmax, nullptr, s, ids_kind, md, num_tables, true);
     // tokens asked for: an optimizer apply of these batches follows — every table's partition pass stays pending
@@ -2317,7 +2346,7 @@ static bool claim_slot(kv_table* v, kv_table* sl, hipStream_t s);
 template <int OPT>
 static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* grad, const void* ids, int64_t n,
                         const OptArgs& a, kv_batch_token_t token, hipStream_t s) {
-  const long long nmax = fused_ok(v->dim) ? FUSED_MAX_N : (1ll << 21);
+  const long long nmax = fused_tab(v) ? FUSED_MAX_N : (1ll << 21);
   if (n < 0 || n > nmax)
     return fail(n < 0 ? KV_INVALID_ARGUMENT : KV_UNIMPLEMENTED,
                 "indices: %lld ids in one optimizer call (limit %lld for this embedding dim; split the batch)", (long long)n, nmax);
@@ -2355,7 +2384,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   //   PA_LOOKUP    the token names the lookup whose partition pass is still pending: k_papply completes its bookkeeping too
   //   PA_NONE      the token names a batch whose bookkeeping is done (a second optimizer on the token; a pass another op settled)
   //   PA_APPLYIDX  no (valid) token: the optimizer meets the ids first — the tile pass runs with the tile sums (k_ltsum)
-  const bool pa_route = fused_ok(v->dim);
+  const bool pa_route = fused_tab(v);
   int pa_mode = -1;
   PartArgs pend{};
   const void* tile_ids = nullptr;   // != nullptr: the batch's tile pass runs in front of the apply (k_ltsum)
@@ -2377,7 +2406,7 @@ static int apply_common(kv_table* v, kv_table* s0, kv_table* s1, const float* gr
   pa.tv = dev_view(v); pa.ts0 = dev_view(s0); pa.ts1 = s1 ? dev_view(s1) : pa.ts0;
   pa.opt = a; pa.grad = grad; pa.day = today(v);
   pa.opt.fast = fast_math_on(v) ? 1 : 0;
-  pa.det = v->deterministic ? 1 : 0;
+  pa.det = det_mode(v);
   pa.n = n;
   pa.use_hints = claim_slot(v, s0, s) ? 1 : 0;
   pa.day_lk = pa.day;
@@ -2592,8 +2621,13 @@ int kv_set_deterministic(kv_handle_t t, int on) {
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
   if ((rc = settle_pending(t))) return rc;
+  if (on < 0 || on > 2) return fail(KV_INVALID_ARGUMENT, "kv_set_deterministic: on = %d (0, 1 or 2)", on);
+  if (on == 2 && t->shard_refs.load() > 0)
+    return fail(KV_UNIMPLEMENTED, "kv_set_deterministic(h, 2): the table serves a kv_shard (occurrence order is a single-table notion)");
   t->deterministic = on != 0;
-  t->batch_serial = 0;
+  t->occurrence_order = on == 2;
+  t->batch_serial = 0;      // the index a lookup left was built by the other pipeline's rules
+  t->fused_index = false;
   return KV_OK;
 }
 
@@ -2683,9 +2717,9 @@ static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t
   pa.out_keys = (long long*)uniq;
   pa.out_sum = summed;
   pa.fold_op = fold_op;
-  pa.det = t->deterministic ? 1 : 0;
+  pa.det = det_mode(t);
   pa.n = n;
-  if (fold_op == KV_SCATTER_ADD && fused_ok(t->dim)) {
+  if (fold_op == KV_SCATTER_ADD && fused_tab(t)) {
     // the entry-list kernels: distinct ids numbered (fused_unique_pass), tile sums of the rows of ids repeated inside their
     // tile (k_tsum), the per-id sums over the tiles' entries straight to summed[number] (k_papply PA_DEDUP)
     if ((rc = fused_unique_pass(t, wd, pa, ids, nullptr, n, s))) return rc;
@@ -2715,8 +2749,8 @@ int kv_dedup_segment_sum(kv_handle_t t, const void* ids, const float* grad, int6
   *num_unique = 0;
   if (n == 0) return KV_OK;
   if (n < 0 || !ids || !grad || !uniq || !summed) return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21)))
-    return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^%d)", (long long)n, fused_ok(t->dim) ? 23 : 21);
+  if (n > (fused_tab(t) ? FUSED_MAX_N : (1ll << 21)))
+    return fail(KV_UNIMPLEMENTED, "%lld ids in one call (limit 2^%d)", (long long)n, fused_tab(t) ? 23 : 21);
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   DeviceGuard dg(t->device);
   std::lock_guard<std::mutex> l(t->mu);
@@ -2732,8 +2766,8 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   if (n < 0 || num_segments < 0 || num_segments > 0x7FFFFFFFll || (n > 0 && (!segment_ids || !data)) ||
       (num_segments > 0 && !out))
     return fail(KV_INVALID_ARGUMENT, "bad arguments");
-  if (n > (fused_ok(t->dim) ? FUSED_MAX_N : (1ll << 21)))
-    return fail(KV_UNIMPLEMENTED, "%lld rows in one call (limit 2^%d)", (long long)n, fused_ok(t->dim) ? 23 : 21);
+  if (n > (fused_tab(t) ? FUSED_MAX_N : (1ll << 21)))
+    return fail(KV_UNIMPLEMENTED, "%lld rows in one call (limit 2^%d)", (long long)n, fused_tab(t) ? 23 : 21);
   if (!dim_supported(t->dim)) return fail(KV_UNIMPLEMENTED, "embedding dim %d not supported", t->dim);
   if (num_segments == 0) return KV_OK;
   DeviceGuard dg(t->device);
@@ -2752,9 +2786,9 @@ int kv_unsorted_segment_sum(kv_handle_t t, const int32_t* segment_ids, const flo
   pa.out_sum = out;
   pa.direct_rows = num_segments;
   pa.fold_op = KV_SCATTER_ADD;
-  pa.det = t->deterministic ? 1 : 0;
+  pa.det = det_mode(t);
   pa.n = n;
-  if (fused_ok(t->dim)) {
+  if (fused_tab(t)) {
     // the entry-list kernels: the segment ids de-duplicated per tile (no numbering: an id IS its output row), the tile
     // sums, the per-id sums over the tiles' entries straight to out[id]
     t->fused_index = true;
@@ -2797,7 +2831,7 @@ int kv_unique(kv_handle_t t, const void* ids, const int32_t* counts, int64_t n, 
   pa.tv = dev_view(t); pa.ts0 = pa.tv; pa.ts1 = pa.tv;
   pa.out_keys = (long long*)uniq;
   pa.out_counts = uniq_counts;
-  pa.det = t->deterministic ? 1 : 0;
+  pa.det = det_mode(t);
   pa.n = n;
   if (!fused_off()) {   // the entry-list kernels, whatever the table's dim (no row is touched)
     if ((rc = fused_unique_pass(t, wd, pa, ids, counts, n, s))) return rc;
@@ -3661,9 +3695,12 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
   if (max_ids < 1 || max_ids > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "max_ids %lld: 1 .. 2^21 ids per sharded batch", (long long)max_ids);
   if (local_table->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "sharded tables carry int64 ids");
   if ((local_table->dim & 3) != 0) return fail(KV_UNIMPLEMENTED, "sharded tables: dim %d (multiples of 4)", local_table->dim);
+  if (local_table->occurrence_order)
+    return fail(KV_UNIMPLEMENTED, "sharded tables: occurrence-order mode is a single-table notion (senders pre-sum, owners add the senders' sums in rank order)");
   DeviceGuard dg(local_table->device);
   kv_shard* sh = new kv_shard();
   sh->table = local_table; sh->world = world; sh->rank = rank; sh->rule = owner_rule; sh->max_ids = max_ids;
+  local_table->shard_refs.fetch_add(1);
   do {
     if ((rc = kv_create(KV_DT_INT64, KV_DT_FLOAT, local_table->dim, 0, 0, local_table->device, &sh->route))) break;
     // default capacity: twice an even share of max_ids distinct ids (hashed ownership spreads them evenly), at least 1024
@@ -3693,6 +3730,7 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
 int kv_shard_destroy(kv_shard_t sh) {
   if (!sh) return KV_OK;
   DeviceGuard dg(sh->table->device);
+  sh->table->shard_refs.fetch_sub(1);
   hipDeviceSynchronize();
   shard_free_buffers(sh);
   hipFree(sh->uniq); hipFree(sh->ucnt); hipFree(sh->slot_of); hipFree(sh->counts); hipFree(sh->hist); hipFree(sh->gcount);

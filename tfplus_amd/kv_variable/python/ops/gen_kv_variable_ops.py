@@ -457,8 +457,14 @@ def kv_attach_slot(var, slot):
   _lib.check(_lib.lib().kv_attach_slot(var.ptr, slot.ptr, _stream(var)))
 
 
+KV_ORDER_ARRIVAL, KV_ORDER_FIXED, KV_ORDER_OCCURRENCE = 0, 1, 2
+
+
 def kv_set_deterministic(table_handle, on=True):
-  _lib.check(_lib.lib().kv_set_deterministic(table_handle.ptr, int(bool(on))))
+  """False / 0: the gradient rows of a repeated id are summed as they arrive; True / 1: in an order fixed by the input
+  positions (bit-reproducible); 2 (KV_ORDER_OCCURRENCE): one by one in input order, the sum TF-core's unsorted_segment_sum
+  takes on the CPU — bit for bit (include/kvhip.h kv_set_deterministic)."""
+  _lib.check(_lib.lib().kv_set_deterministic(table_handle.ptr, int(on)))
 
 
 def kv_set_fast_math(table_handle, on=True):
