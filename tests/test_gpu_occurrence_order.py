@@ -231,3 +231,29 @@ def test_headline_shape_batch(ops):
   gots, exps = _np(ops.kv_variable_gather_or_zeros_v2(hs, keys)), osl.gather_or_zeros(keys)
   np.testing.assert_allclose(gots, exps, rtol=1e-6, atol=1e-7)
   np.testing.assert_array_equal(_np(ops.kv_variable_get_count_v2(hs, keys[:20000])), osl.get_count(keys[:20000]))
+
+
+@pytest.mark.parametrize("op", [1, 2, 3, 4, 5, 6])          # ScatterAdd / Sub / Mul / Div / Min / Max
+def test_scatter_family_rides_the_same_chain(ops, op):
+  """the scatter ops fold a repeated id's updates before they touch the row (the reference walks the indices and touches
+  the row every time, kv_variable.h:616-734: ((x + u1) + u2) against x + (u1 + u2) — same bar as in the other modes,
+  tests/test_next_rows.py); in occurrence mode the fold is k_occ_sum's chain with the op's own identity and operation"""
+  from test_gpu_parity import _pair
+  D = 16
+  h, o = _pair(ops, D)
+  ops.kv_set_deterministic(h, 2)
+  rng = np.random.default_rng(40 + op)
+  ids = rng.integers(-20, 20, 3000 if op <= 2 else 1200)    # 75 / 30 occurrences per id: every key is a hot one
+  ops.kv_variable_gather_or_insert_v2(h, ids); o.gather_or_insert(ids)
+  lo, hi = (0.5, 1.5) if op <= 2 else (0.97, 1.03)
+  upd = rng.uniform(lo, hi, (ids.size, D)).astype(np.float32)
+  [None, ops.kv_variable_scatter_add_v2, ops.kv_variable_scatter_sub_v2, ops.kv_variable_scatter_mul_v2,
+   ops.kv_variable_scatter_div_v2, ops.kv_variable_scatter_min_v2, ops.kv_variable_scatter_max_v2][op](h, ids, upd)
+  o.scatter_update(ids, upd, op)
+  q = np.arange(-20, 20)
+  got, exp = _np(ops.kv_variable_gather_or_zeros_v2(h, q)), o.gather_or_zeros(q)
+  if op >= 5:
+    np.testing.assert_array_equal(got, exp)                 # min / max: exact in any order
+  else:
+    np.testing.assert_allclose(got, exp, rtol=4e-6, atol=1e-6)
+  assert ops.kv_variable_frequency(h) == o.sum_freq()
