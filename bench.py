@@ -317,6 +317,21 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
                   "lookup_rows_ready_frac": look_bytes / (rows_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     del bs
   res["skew_sweep"] = sweep
+  # ---- the headline's own batches in occurrence-order mode (kv_set_deterministic(var, 2): a repeated id's gradient rows
+  #      added one by one in input order, TF-core's unsorted_segment_sum chain — the reference's CPU bits).
+  #      After the sweep: the mode takes the sorted-position kernels, so the entry-list kernels' last launches in a trace of
+  #      this run stay the sweep's.
+  ops.kv_set_deterministic(var, 2)
+
+  def occ(k):
+    ids, grad = pool[k % len(pool)][:2]
+    adam(ids, grad, N, lookup(ids, True))
+  ms_occ = timed(occ, steps=8, warm=2)
+  ops.kv_set_deterministic(var, 0)
+  res["occurrence_order"] = {"what": "lookup + GroupAdam on the headline's batches with kv_set_deterministic(var, 2): the summed "
+                                     "gradient of a repeated id is TF-core's occurrence-ordered fp32 sum bit for bit (one chain per "
+                                     "key, k_occ_sum), so every key meets the 1e-6 of the op boundary against the CPU path",
+                             "ms_per_step": ms_occ, "ids_per_s": N / (ms_occ * 1e-3)}
   return res
 
 

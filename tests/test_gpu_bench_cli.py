@@ -45,6 +45,8 @@ def test_bench_single_gpu_line():
   assert "error" not in sw, sw
   assert sw["ms_per_step"] > 0 and set(sw["phases_ms"]) == set(PHASES) and sw["overflowed_batches"] == 0
   assert sw["phases_sum_ms"] >= 0.8 * sw["ms_per_step"]          # the phases account for the step (markers cost time: >= )
+  oo = d["occurrence_order"]
+  assert oo["ms_per_step"] > d["ms_per_step"] and oo["ids_per_s"] > 0      # the reference's bits cost a chain per key
   ph = cb["phases_s"]
   assert set(ph) == {"lookup", "dedup_1_thread", "apply"} and all(v > 0 for v in ph.values())
   assert str(cb["cores"]) in cb["threads_sweep_ids_per_s"] and cb["cores"] <= cb["host_cores"]
