@@ -49,6 +49,19 @@ class Pair(object):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_random_program_matches_oracle(ops, seed):
+  _random_program(ops, seed, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 108))
+def test_random_program_occurrence_order(ops, seed):
+  """the same programs on a var in occurrence-order mode (kv_set_deterministic(h, 2)), and the optimizer ops get the RAW ids
+  and gradient rows — repeats and all — while the oracle gets TF-core's unique + segment sum of them: same 1e-6, and
+  kv_dedup_segment_sum's sums are the oracle's bit for bit"""
+  _random_program(ops, seed, True)
+
+
+def _random_program(ops, seed, occ):
   rng = np.random.default_rng(1000 + seed)
   kd = torch.int32 if seed % 4 == 3 else torch.int64    # int32 keys: same values, the narrow id path of every kernel
   D = int(rng.choice([4, 8, 20, 32, 64]))
@@ -59,6 +72,8 @@ def test_random_program_matches_oracle(ops, seed):
   var = Pair(ops, D, thr, table, seed, kd)
   slots = {"adam": [(3 * D, 0.0)], "adagrad": [(D, 0.1)], "ftrl": [(D, 0.1), (D, 0.0)]}[opt]
   sl = [Pair(ops, d, 0, np.full((4, d), v, np.float32), seed, kd) for d, v in slots]
+  if occ:
+    ops.kv_set_deterministic(var.h, ops.KV_ORDER_OCCURRENCE)
   day = DAY0
   b1p, b2p = np.float32(0.9), np.float32(0.999)
   for step in range(40):
@@ -83,19 +98,25 @@ def test_random_program_matches_oracle(ops, seed):
       gu, gs, ginv = ops.kv_dedup_segment_sum(var.h, ids, g)
       gu, gs, ginv = gu.cpu().numpy(), gs.cpu().numpy(), ginv.cpu().numpy()
       assert np.array_equal(gu[ginv], ids) and np.array_equal(np.sort(gu), np.sort(u)), tag
-      np.testing.assert_allclose(gs[np.argsort(gu)], s[np.argsort(u)], rtol=1e-5, atol=1e-8, err_msg=tag)
+      if occ:
+        assert np.array_equal(gs[np.argsort(gu)].view(np.uint32), s[np.argsort(u)].view(np.uint32)), tag   # TF-core's chain
+      else:
+        np.testing.assert_allclose(gs[np.argsort(gu)], s[np.argsort(u)], rtol=1e-5, atol=1e-8, err_msg=tag)
       qu, qc, qinv = ops.kv_unique(var.h, ids)
       assert np.array_equal(qu.cpu().numpy()[qinv.cpu().numpy()], ids) and int(qc.sum()) == n, tag
       uq = dict(unique_indices=bool(rng.integers(0, 2)))   # the op as an unchanged graph calls it: ids promised unique (one launch)
+      gi, gg = (ids, g) if occ else (u, s)                 # occurrence order: the op sums the repeats itself, in TF-core's order
+      if occ:
+        uq = {}
       if opt == "adam":
-        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0, **uq)
+        ops.kv_variable_group_sparse_apply_adam_v4(var.h, sl[0].h, gg, gi, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8, 0, 0, 0, **uq)
         ko.apply_group_adam(var.o, sl[0].o, s, u, 1e-2, b1p, b2p, 0.9, 0.999, 1e-8)
         b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
       elif opt == "adagrad":
-        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, s, u, use_locking=True, **uq)
+        ops.kv_variable_sparse_apply_adagrad(var.h, sl[0].h, 0.05, gg, gi, use_locking=True, **uq)
         ko.apply_adagrad(var.o, sl[0].o, 0.05, s, u)
       else:
-        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5, **uq)
+        ops.kv_variable_sparse_group_sparse_apply_ftrl_v2(var.h, sl[0].h, sl[1].h, gg, gi, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5, **uq)
         ko.apply_sparse_group_ftrl(var.o, sl[0].o, sl[1].o, s, u, 0.05, 0.0, 1e-3, 0.0, 0.0, -0.5)
     elif op == "sparse":   # embedding_lookup_sparse in one call: unique -> GatherOrInsert -> segment sum in position order
       nseg = max(1, n // 3)
