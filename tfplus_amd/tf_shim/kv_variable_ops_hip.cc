@@ -291,6 +291,11 @@ class CreateKvVariableHipOp : public OpKernel {
                                 const char* p = std::getenv("SUPPORT_PREDICTION_DELTA_EXPORT");
                                 const bool dd = d && std::strcmp(d, "1") == 0, pp = p && std::strcmp(p, "1") == 0;
                                 if (dd || pp) TF_RETURN_IF_ERROR(FromKv(kv_set_delta_tracking(h, dd, pp)));
+                                // this library's own switch, for graphs that hand the optimizer ops repeated ids (the
+                                // batch-token path): TFPLUS_KV_REDUCTION_ORDER = 0 arrival, 1 fixed, 2 TF-core's
+                                // occurrence order — the reference's CPU bits (include/kvhip.h kv_set_deterministic)
+                                if (const char* ro = std::getenv("TFPLUS_KV_REDUCTION_ORDER"))
+                                  if (ro[0] >= '0' && ro[0] <= '2' && ro[1] == 0) TF_RETURN_IF_ERROR(FromKv(kv_set_deterministic(h, ro[0] - '0')));
                                 *out = new KvHipResource(h, dim, kd);
                                 return OkStatus();
                               }));
