@@ -321,17 +321,21 @@ def extras(args, ops, L, _lib, var, slot, dev, pool, out, K, N, D, gen, state):
   #      added one by one in input order, TF-core's unsorted_segment_sum chain — the reference's CPU bits).
   #      After the sweep: the mode takes the sorted-position kernels, so the entry-list kernels' last launches in a trace of
   #      this run stay the sweep's.
-  ops.kv_set_deterministic(var, 2)
+  try:
+    ops.kv_set_deterministic(var, 2)
 
-  def occ(k):
-    ids, grad = pool[k % len(pool)][:2]
-    adam(ids, grad, N, lookup(ids, True))
-  ms_occ = timed(occ, steps=8, warm=2)
-  ops.kv_set_deterministic(var, 0)
-  res["occurrence_order"] = {"what": "lookup + GroupAdam on the headline's batches with kv_set_deterministic(var, 2): the summed "
-                                     "gradient of a repeated id is TF-core's occurrence-ordered fp32 sum bit for bit (one chain per "
-                                     "key, k_occ_sum), so every key meets the 1e-6 of the op boundary against the CPU path",
-                             "ms_per_step": ms_occ, "ids_per_s": N / (ms_occ * 1e-3)}
+    def occ(k):
+      ids, grad = pool[k % len(pool)][:2]
+      adam(ids, grad, N, lookup(ids, True))
+    ms_occ = timed(occ, steps=8, warm=2)
+    res["occurrence_order"] = {"what": "lookup + GroupAdam on the headline's batches with kv_set_deterministic(var, 2): the summed "
+                                       "gradient of a repeated id is TF-core's occurrence-ordered fp32 sum bit for bit (one chain "
+                                       "per key, k_occ_sum), so every key meets the 1e-6 of the op boundary against the CPU path",
+                               "ms_per_step": ms_occ, "ids_per_s": N / (ms_occ * 1e-3)}
+  except Exception as e:   # (e.g. the table still serves the shard of a sharded_world1 leg that failed half way: refused)
+    res["occurrence_order"] = {"error": "%s: %s" % (type(e).__name__, e)}
+  finally:
+    ops.kv_set_deterministic(var, 0)
   return res
 
 
