@@ -1019,20 +1019,24 @@ constexpr int OCC_STAGE = 14336;       // floats per stage (two stages in LDS: 1
                                        // a block's fetch is one HBM round trip per stage, so the stage is what it can hold)
 constexpr int OCC_ROWS = 1024;         // rows per stage at most (the stage's positions: three stages in LDS)
 inline size_t occ_smem_bytes() { return (size_t)2 * OCC_STAGE * 4 + (size_t)3 * OCC_ROWS * 4; }
-template <int NC, int FOP>
-__device__ __forceinline__ void occ_chain(const float* __restrict__ buf, unsigned rows, int D, int lane, float (&acc)[NC]) {
+template <int NC, int FOP, int DC = 0>   // DC: the dim when it is one of the common ones (the rows' LDS offsets become immediates), else 0
+__device__ __forceinline__ void occ_chain(const float* __restrict__ buf, unsigned rows, int D_, int lane, float (&acc)[NC]) {
+  const int D = DC ? DC : D_;
   // rows of the stage in order; a lane's columns are independent chains.  The LDS reads of a batch of rows are issued
   // together, one batch ahead of the additions; lanes past the row's end read column 0 and their sums are dropped.
-  // Measured on a key of 188 k rows of dim 32 (tools/occ_step.py): 1.3 ms for the chain, ~15 cycles a row.
+  // Measured on a key of 188 k rows of dim 32 (tools/occ_step.py): 1.3 ms for the chain with computed addresses (~15
+  // cycles a row); with the rows as immediates (DC) the fetch's 0.9 ms is what remains.
   constexpr int UJ = NC >= 8 ? 2 : 16 / NC;
   int col[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) col[c] = (lane + c * 64 < D) ? lane + c * 64 : 0;
   auto rd = [&](unsigned r0, float (&x)[UJ][NC]) {
 #pragma unroll
-    for (int j = 0; j < UJ; ++j)
+    for (int c = 0; c < NC; ++c) {
+      const float* pc = buf + (size_t)r0 * D + col[c];   // (one address a batch and column: the rows are immediates when DC != 0)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) x[j][c] = buf[(size_t)(r0 + j) * D + col[c]];
+      for (int j = 0; j < UJ; ++j) x[j][c] = pc[j * D];
+    }
   };
   auto add = [&](const float (&x)[UJ][NC]) {
 #pragma unroll
@@ -1166,7 +1170,14 @@ __device__ __forceinline__ void occ_sum_body(const WsDev& w, const PartArgs& a, 
           case KV_SCATTER_MUL: occ_chain<NC, KV_SCATTER_MUL>(sb, rows_of(st), D, lane, acc); break;
           case KV_SCATTER_MIN: occ_chain<NC, KV_SCATTER_MIN>(sb, rows_of(st), D, lane, acc); break;
           case KV_SCATTER_MAX: occ_chain<NC, KV_SCATTER_MAX>(sb, rows_of(st), D, lane, acc); break;
-          default: occ_chain<NC, KV_SCATTER_ADD>(sb, rows_of(st), D, lane, acc); break;
+          default:   // the optimizers' sum: the common dims get their own copy (one LDS read and one addition a row, nothing else)
+            if (NC == 1 && D == 32) occ_chain<NC, KV_SCATTER_ADD, 32>(sb, rows_of(st), D, lane, acc);
+            else if (NC == 1 && D == 64) occ_chain<NC, KV_SCATTER_ADD, 64>(sb, rows_of(st), D, lane, acc);
+            else if (NC == 1 && D == 16) occ_chain<NC, KV_SCATTER_ADD, 16>(sb, rows_of(st), D, lane, acc);
+            else if (NC == 1 && D == 8) occ_chain<NC, KV_SCATTER_ADD, 8>(sb, rows_of(st), D, lane, acc);
+            else if (NC == 2 && D == 128) occ_chain<NC, KV_SCATTER_ADD, 128>(sb, rows_of(st), D, lane, acc);
+            else occ_chain<NC, KV_SCATTER_ADD>(sb, rows_of(st), D, lane, acc);
+            break;
         }
       }
       else { ask_pos(st + 2, pv); fetch_rows(st + 1); put_pos(st + 2, pv); }
