@@ -257,3 +257,45 @@ def test_scatter_family_rides_the_same_chain(ops, op):
   else:
     np.testing.assert_allclose(got, exp, rtol=4e-6, atol=1e-6)
   assert ops.kv_variable_frequency(h) == o.sum_freq()
+
+
+def test_occurrence_order_step_replays_in_a_graph(ops):
+  """a captured apply on a table in occurrence-order mode (k_occ_sum asks for its LDS size at every launch: not a stream
+  operation), replayed three times, against the same three steps issued eagerly on a twin: the same bits"""
+  dev = torch.device("cuda", 0)
+  gen = torch.Generator(device=dev).manual_seed(11)
+  D, n = 32, 40_000
+  ids = (torch.randint(0, 3000, (n,), device=dev, generator=gen) ** 2) % 2500 - 40      # repeats, a few keys with hundreds of rows
+  grad = torch.randn(n, D, device=dev, generator=gen) * 1e-2
+  init = torch.randn(64, D, device=dev, generator=gen)
+  hp = (1e-2, 0.9, 0.999, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0)
+
+  def pair():
+    v = ops.kv_variable([D], capacity_hint=4 * n)
+    s = ops.kv_variable([3 * D], capacity_hint=4 * n)
+    ops.kv_set_seed(v, 7)
+    ops.init_kv_variable_v2(v, init)
+    ops.init_kv_variable_v2(s, torch.zeros(4, 3 * D, device=dev))
+    ops.kv_set_deterministic(v, 2)
+    ops.kv_variable_gather_or_insert_v2(v, ids)
+    ops.kv_variable_group_sparse_apply_adam_v4(v, s, grad, ids, *hp)          # warm-up: slot rows, hints, workspace
+    return v, s
+
+  (gv, gs), (ev, es) = pair(), pair()
+  torch.cuda.synchronize()
+  for h in (gv, gs):
+    ops.kv_prepare_capture(h, 4 * n)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g, stream=side):
+    ops.kv_variable_group_sparse_apply_adam_v4(gv, gs, grad, ids, *hp)
+  for _ in range(3):
+    g.replay()
+    ops.kv_variable_group_sparse_apply_adam_v4(ev, es, grad, ids, *hp)
+  torch.cuda.synchronize()
+  u = torch.unique(ids)
+  assert torch.equal(ops.kv_variable_gather_or_zeros_v2(gv, u), ops.kv_variable_gather_or_zeros_v2(ev, u))
+  assert torch.equal(ops.kv_variable_gather_or_zeros_v2(gs, u), ops.kv_variable_gather_or_zeros_v2(es, u))
+  assert ops.kv_variable_frequency(gs) == ops.kv_variable_frequency(es)
+  assert ops.kv_variable_size_v2(gv) == u.numel()
