@@ -341,6 +341,8 @@ struct PartArgs {
   unsigned uniq_serial;            // k_uapply (kv_uapply.h): this launch's stamp (1 .. 65535)
   int use_mirror;                  // the lean update reads / writes the slot row's frequency word and flags in the var row's
   unsigned mirror_epoch;           // SlotMirror (kv_device.h) when it is valid for this epoch; the host flushes (kvhip.hip mirror_*)
+  int dd_number;                   // k_papply PA_DEDUP: the pass numbers the distinct ids itself (dense, ctr[0]; out_keys[number] = id) —
+                                   // kv_dedup_segment_sum in one partition pass instead of PA_UNIQUE's and then this one
 };
 
 // round r of R keeps the keys whose sub-hash selects it (R = 1: everything)

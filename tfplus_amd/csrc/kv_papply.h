@@ -161,7 +161,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (tid == 0) {
       lkeys += nu;
       // dense numbers (kv_unique / kv_dedup_segment_sum): the round's keys take the next nu of one counter
-      if (UQ && !a.sparse_unique) lbase = atomicAdd(&w.ctr[0], nu);
+      if ((UQ && !a.sparse_unique) || (DD && a.dd_number)) lbase = atomicAdd(&w.ctr[0], nu);   // (kv_dedup_segment_sum: the sums' pass numbers the ids itself)
     }
 
     // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
@@ -207,6 +207,11 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             a.out_keys[num] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
             if (a.sparse_unique) a.out_counts[num] = (int)hval[s];
             else if (a.out_counts) a.out_counts[num] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
+          }
+          if (DD && a.dd_number) {   // the id's dense number = the row of its sum (and what its entries remember for the inverse map)
+            const unsigned num = lbase + u;
+            hrow[s] = num;
+            a.out_keys[num] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
           }
         }
       }
@@ -254,6 +259,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 
     // ---- pass 2: the source list — entry x of key h goes to its key's stretch ---------------------------------------
     {
+      const bool numbers = UQ || (DD && a.dd_number != 0);   // the entries learn their id's number
       auto file = [&](unsigned pos, unsigned src) { if (in_lds) lsrc[pos] = src; else gsrc[pos] = src; };
       if (a.det) {
         // deterministic mode: a key's entries in tile order = ascending x (TBP entries per round, wave by wave)
@@ -279,14 +285,14 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             if (wave == wv && valid) { pos = hocc[h] + within; atomicAdd(&hocc[h], 1u); }
             __syncthreads();
           }
-          if (valid) { file(pos, w.ent_rec[ge]); if (UQ) w.ent_b[ge] = hrow[h]; }
+          if (valid) { file(pos, w.ent_rec[ge]); if (numbers) w.ent_b[ge] = hrow[h]; }
         }
       } else if (cached) {
 #pragma unroll
         for (int k = 0; k < EB; ++k)
           if (cin[k]) {
             file(atomicAdd(&hocc[cslot[k]], 1u), csrc[k]);
-            if (UQ) w.ent_b[seg_entry(tpre, tstart, NT, (unsigned)(k * TBP + tid))] = hrow[cslot[k]];   // the entry learns its id's number
+            if (numbers) w.ent_b[seg_entry(tpre, tstart, NT, (unsigned)(k * TBP + tid))] = hrow[cslot[k]];   // the entry learns its id's number
           }
       } else {
         for (unsigned x = tid; x < E; x += TBP) {
@@ -297,7 +303,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
           bool first;
           const unsigned h = lds_key_slot<HSK>(hkey, &lsent, key, false, &first);
           file(atomicAdd(&hocc[h], 1u), src);
-          if (UQ) w.ent_b[ge] = hrow[h];
+          if (numbers) w.ent_b[ge] = hrow[h];
         }
       }
     }

@@ -2685,7 +2685,8 @@ __global__ void __launch_bounds__(TB) k_inverse_e(const unsigned short* __restri
 // tf.unique_with_counts on the entry-list kernels (any dim: no row is touched): a table-less tile pass (entries, every
 // position's entry) and k_papply PA_UNIQUE with dense numbers — uniq / uniq_counts written, every entry learns its id's
 // number, the count in wd.ctr[0].  The table's mutex is held by the caller.
-static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* ids, const int* counts, long long n, hipStream_t s) {
+// the table-less tile pass of the distinct-id ops: entries, every position's entry number (pos_ent)
+static int unique_tile_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* ids, const int* counts, long long n, hipStream_t s) {
   Workspace& ws = t->ws;
   int rc;
   if (ws.pos_cap < n) {
@@ -2698,6 +2699,11 @@ static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* i
   choose_partitions(t, wd, n);
   wd.pos_ent = ws.pos_ent;
   launch_ltile_notable(t, pa.tv, wd, ids, n, s, counts, t->key_dtype == KV_DT_INT32);
+  return KV_OK;
+}
+static int fused_unique_pass(kv_table* t, WsDev& wd, PartArgs& pa, const void* ids, const int* counts, long long n, hipStream_t s) {
+  int rc;
+  if ((rc = unique_tile_pass(t, wd, pa, ids, counts, n, s))) return rc;
   // (k_papply_uniq: numbering only, nothing of the row geometry is touched — one kernel whatever the table's dim)
   if ((rc = kvp_launch_papply_ud(&wd, &pa, PA_UNIQUE, (void*)s))) return fail(rc, "unique: no kernel");
   return KV_OK;
@@ -2722,8 +2728,11 @@ static int dedup_locked(kv_table* t, const void* ids, const float* grad, int64_t
   if (fold_op == KV_SCATTER_ADD && fused_tab(t)) {
     // the entry-list kernels: distinct ids numbered (fused_unique_pass), tile sums of the rows of ids repeated inside their
     // tile (k_tsum), the per-id sums over the tiles' entries straight to summed[number] (k_papply PA_DEDUP)
-    if ((rc = fused_unique_pass(t, wd, pa, ids, nullptr, n, s))) return rc;
-    pa.out_keys = nullptr; pa.out_map = nullptr;
+    // (round 6: ONE partition pass — k_papply PA_DEDUP numbers the ids it sums, dd_number — where PA_UNIQUE's numbering pass
+    //  ran in front of it: the table-less tile pass, the tile sums, the pass)
+    if ((rc = unique_tile_pass(t, wd, pa, ids, nullptr, n, s))) return rc;
+    pa.out_map = nullptr;
+    pa.dd_number = 1;
     pa.epart = wd.epart;
     pa.day_lk = pa.day;
     if ((rc = kvp_launch_tsum(&pa.tv, &wd, grad, (void*)s, nullptr, 0))) return fail(rc, "tile sums: no kernel for dim %d", t->dim);
