@@ -444,7 +444,13 @@ struct kv_table {
   unsigned char pend_wd[sizeof(WsDev)], pend_pa[sizeof(PartArgs)];
   // Slot mirrors (kv_device.h SlotMirror; mirror_* below): a var table paired with ONE slot table keeps, next to each row's
   // record, a write-back copy of the slot row's frequency word and flags; the lean apply works on the copy alone.
-  long long stat_mirror_applies = 0, stat_mirror_epochs = 0;   // kv_get_stat
+  long long stat_mirror_applies = 0;            // kv_get_stat
+  std::atomic<long long> stat_mirror_epochs{0}; // ... (an epoch of a var's mirrors may be ended under the slot table's lock)
+  // both tables of a mirror pair hold the pair's device views as the last lean apply (or the pairing) saw them — written with
+  // BOTH locks held.  An op that ends the epoch holds ONE of the two locks: it flushes through the copy in the table it
+  // holds and never reads the other table's host state (whose owner may be growing it on another thread).  What a dirty
+  // copy names — a var row and a slot row of the chunk-0 slabs — is inside these views whatever happened to the tables since.
+  TableDev mview_var{}, mview_slot{};
   kv_table* mirror_slot = nullptr;          // var side: the slot table its mirrors stand for
   std::atomic<unsigned> mirror_epoch{1};    // var side: generation of the copies (16 bits on the device)
   std::atomic<bool> mirror_dirty{false};    // var side: a lean apply has written mirrors since the last flush
@@ -1087,22 +1093,29 @@ bool mirror_off() {
   static const bool off = [] { const char* e = getenv("KV_NO_MIRROR"); return e && e[0] == '1'; }();
   return off;
 }
-void mirror_end_epoch(kv_table* var, hipStream_t s) {
-  kv_table* sl = var->mirror_slot;
-  if (!sl) return;
-  ++var->stat_mirror_epochs;
+// held: the table of the pair whose lock the caller holds (the var itself, or its slot table): the views come from there
+void mirror_end_epoch(kv_table* var, hipStream_t s, const kv_table* held) {
+  if (!var->mirror_slot) return;
+  var->stat_mirror_epochs.fetch_add(1);
+  const TableDev& tv = held->mview_var;
+  const long long rows = (long long)tv.max_rows + 1;
   if (var->mirror_dirty.exchange(false))
-    k_flush_mirrors<<<nblocks((long long)var->rows_ub + 1, TB, 8192), TB, 0, s>>>(dev_view(var), dev_view(sl), var->mirror_epoch.load() & 0xFFFFu);
+    k_flush_mirrors<<<nblocks(rows, TB, 8192), TB, 0, s>>>(tv, held->mview_slot, var->mirror_epoch.load() & 0xFFFFu);
   if ((var->mirror_epoch.fetch_add(1) + 1u) > 0xFFFFu) {
-    k_clear_mirrors<<<nblocks((long long)var->rows_ub + 1, TB, 8192), TB, 0, s>>>(dev_view(var));
+    k_clear_mirrors<<<nblocks(rows, TB, 8192), TB, 0, s>>>(tv);
     var->mirror_epoch.store(1);
   }
 }
-void mirror_unpair(kv_table* var, hipStream_t s) {
+void mirror_unpair(kv_table* var, hipStream_t s, const kv_table* held) {
   if (!var->mirror_slot) return;
-  mirror_end_epoch(var, s);
+  mirror_end_epoch(var, s, held);
   var->mirror_slot->mirror_var = nullptr;
   var->mirror_slot = nullptr;
+}
+// (both locks held)
+static void mirror_snapshot(kv_table* v, kv_table* sl) {
+  v->mview_var = sl->mview_var = dev_view(v);
+  v->mview_slot = sl->mview_slot = dev_view(sl);
 }
 // the entry hook of hand_over / join_side.  Under a stream capture the flush would be RECORDED, not run, and a replay would
 // carry the epoch of its capture: a table that is captured gives up its mirrors beforehand (kv_prepare_capture ->
@@ -1114,15 +1127,15 @@ int mirror_on_entry(kv_table* t, hipStream_t s) {
     return fail(KV_FAILED_PRECONDITION, "this table is half of a (var, slot) pair whose optimizer applies keep the slot records' "
                                         "frequency words in the var's rows between ops; call kv_prepare_capture on it (outside the "
                                         "capture) before capturing ops on it");
-  if (end_slot) mirror_end_epoch(t->mirror_var, s);   // t is a slot table: its records are about to be read or written
-  if (end_var) mirror_end_epoch(t, s);                // t is a var: its rows may be released, moved or read back
+  if (end_slot) mirror_end_epoch(t->mirror_var, s, t);   // t is a slot table: its records are about to be read or written
+  if (end_var) mirror_end_epoch(t, s, t);                // t is a var: its rows may be released, moved or read back
   return KV_OK;
 }
 // kv_prepare_capture: the table's ops are about to be captured and replayed — no host code runs at a replay, so nothing
 // could flush or re-validate a mirror: the pair is dissolved now (the dirty copies go back) and never forms again
 void mirror_ban(kv_table* t, hipStream_t s) {
-  if (t->mirror_slot) mirror_unpair(t, s);
-  if (t->mirror_var) mirror_unpair(t->mirror_var, s);
+  if (t->mirror_slot) mirror_unpair(t, s, t);
+  if (t->mirror_var) mirror_unpair(t->mirror_var, s, t);
   t->mirror_banned = true;
 }
 // (var, slot) become a mirror pair — or stay / become unpaired when the slot table already serves another var
@@ -1130,14 +1143,15 @@ bool mirror_pair(kv_table* v, kv_table* sl, hipStream_t s) {
   if (mirror_off() || sl->mirror_shared || v->mirror_banned || sl->mirror_banned) return false;
   if (v->mirror_slot == sl && sl->mirror_var == v) return true;
   if (sl->mirror_var && sl->mirror_var != v) {   // a second var on one slot table: no mirrors for it at all
-    mirror_unpair(sl->mirror_var, s);
+    mirror_unpair(sl->mirror_var, s, sl);
     sl->mirror_shared = true;
     return false;
   }
-  if (v->mirror_slot && v->mirror_slot != sl) mirror_unpair(v, s);
+  if (v->mirror_slot && v->mirror_slot != sl) mirror_unpair(v, s, v);
   v->mirror_slot = sl;
   sl->mirror_var = v;
-  mirror_end_epoch(v, s);   // a fresh epoch: whatever bytes the rows' mirror units hold are void
+  mirror_snapshot(v, sl);
+  mirror_end_epoch(v, s, v);   // a fresh epoch: whatever bytes the rows' mirror units hold are void
   return true;
 }
 
@@ -1158,11 +1172,12 @@ static int mirror_decide_rt(int opt, kv_table* v, kv_table* s0, PartArgs& pa, bo
   if (eligible) {
     pa.use_mirror = 1;
     pa.mirror_epoch = v->mirror_epoch.load() & 0xFFFFu;
+    mirror_snapshot(v, s0);   // what this apply's dirty copies name is inside these views
     v->mirror_dirty.store(true);
     ++v->stat_mirror_applies;
   } else {
-    if (v->mirror_slot) mirror_end_epoch(v, s);
-    if (s0->mirror_var && s0->mirror_var != v) mirror_end_epoch(s0->mirror_var, s);
+    if (v->mirror_slot) mirror_end_epoch(v, s, v);
+    if (s0->mirror_var && s0->mirror_var != v) mirror_end_epoch(s0->mirror_var, s, s0);
   }
   return KV_OK;
 }
@@ -1504,7 +1519,7 @@ int kv_destroy(kv_handle_t t) {
   { std::lock_guard<std::mutex> l(g_tables_mu); g_tables.erase(t); }
   {   // slot mirrors: a var hands its dirty copies back before it goes; a slot table takes its var's pairing with it
     DeviceGuard dgm(t->device);
-    if (t->mirror_slot) mirror_unpair(t, nullptr);
+    if (t->mirror_slot) mirror_unpair(t, nullptr, t);
     if (t->mirror_var) { t->mirror_var->mirror_dirty.store(false); t->mirror_var->mirror_slot = nullptr; t->mirror_var = nullptr; }
   }
   DeviceGuard dg(t->device);
@@ -2645,7 +2660,7 @@ int kv_get_stat(kv_handle_t t, int which, int64_t* value) {
   if (!value) return fail(KV_INVALID_ARGUMENT, "kv_get_stat: null value");
   std::lock_guard<std::mutex> l(t->mu);
   if (which == KV_STAT_MIRROR_APPLIES) { *value = t->stat_mirror_applies; return KV_OK; }
-  if (which == KV_STAT_MIRROR_EPOCHS) { *value = t->stat_mirror_epochs; return KV_OK; }
+  if (which == KV_STAT_MIRROR_EPOCHS) { *value = t->stat_mirror_epochs.load(); return KV_OK; }
   return fail(KV_INVALID_ARGUMENT, "kv_get_stat: unknown counter %d", which);
 }
 
