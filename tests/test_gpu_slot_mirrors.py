@@ -291,3 +291,55 @@ def test_a_query_on_another_stream_and_another_thread(ops):
     ko.apply_group_adam(os_[0], os_[1], grads[t], ids, 0.05, b1p, b2p, 0.9, 0.999, 1e-8)
   _check(ops, hs, os_, ids)
   assert ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_EPOCHS) > 2
+
+
+def test_slot_queries_from_another_thread_while_the_var_grows(ops):
+  """the stepper's batches move on (new keys every step: the var's index is rebuilt and both tables leave their first slab, so
+  lean and general applies alternate) while a second thread keeps ending epochs from the SLOT side, under the slot table's
+  lock alone: the flush goes through the pair's views kept in the slot table, never through the var's host state"""
+  import threading
+  name, D = "adam4", 16
+  rng = np.random.default_rng(29)
+  hs, os_ = _mk(ops, name, D, seed=29, cap=9_000)          # small slabs: growth on the way
+  STEPS, N, SHIFT = 30, 6_000, 700
+  batches = [np.arange(N, dtype=np.int64) + t * SHIFT - 500 for t in range(STEPS)]
+  grads = [rng.normal(0, 1e-2, (N, D)).astype(np.float32) for _ in range(STEPS)]
+  errs, stop = [], threading.Event()
+
+  def stepper():
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        for t in range(STEPS):
+          b1p, b2p = _beta_pows(t)
+          dids = torch.from_numpy(batches[t]).cuda()
+          ops.kv_variable_gather_or_insert_v2(hs[0], dids)
+          ops.kv_variable_group_sparse_apply_adam_v4(hs[0], hs[1], torch.from_numpy(grads[t]).cuda(), dids, 0.05, b1p, b2p, 0.9, 0.999,
+                                                     1e-8, 0.0, 0.0, 0.0)
+        torch.cuda.current_stream().synchronize()
+    except Exception as e:  # pragma: no cover
+      errs.append(repr(e))
+    finally:
+      stop.set()
+
+  def asker():
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        q = torch.arange(0, 20_000, 53, device="cuda")
+        while not stop.is_set():
+          ops.kv_get_meta(hs[1], q)
+          ops.kv_variable_get_count_v2(hs[1], q)
+    except Exception as e:  # pragma: no cover
+      errs.append(repr(e))
+
+  th = [threading.Thread(target=stepper), threading.Thread(target=asker)]
+  for t in th:
+    t.start()
+  for t in th:
+    t.join()
+  torch.cuda.synchronize()
+  assert not errs, errs
+  for t in range(STEPS):
+    b1p, b2p = _beta_pows(t)
+    os_[0].gather_or_insert(batches[t])
+    ko.apply_group_adam(os_[0], os_[1], grads[t], batches[t], 0.05, b1p, b2p, 0.9, 0.999, 1e-8)
+  _check(ops, hs, os_, np.unique(np.concatenate(batches)))
