@@ -1,5 +1,5 @@
 """Occurrence-order mode (kv_set_deterministic(h, 2)) at the headline's batch shape: 1 M ids, Zipf 1.2, dim 32, GroupAdam —
-time per step next to the default mode on the same table shape.  python tools/occ_step.py [keys]  """
+time per step next to the default mode on the same table shape.  python tools/occ_step.py [keys [zipf]]  """
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,9 +8,11 @@ from tfplus_amd.kv_variable.python.ops import gen_kv_variable_ops as ops
 
 dev = torch.device("cuda", 0)
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+SKEW = float(sys.argv[2]) if len(sys.argv) > 2 else 1.2
 N, D = 1_000_000, 32
 gen = torch.Generator(device=dev).manual_seed(bench.SEED)
-z = bench.Zipf(K, 1.2, dev)
+z = bench.Zipf(K, SKEW, dev)
+print("Zipf %.1f over %d keys" % (SKEW, K))
 pool = [(bench.splitmix64(z.sample(N, gen)), torch.randn(N, D, device=dev, generator=gen) * 1e-2) for _ in range(4)]
 for mode in (0, 1, 2):
   var = ops.kv_variable([D], capacity_hint=K + 4 * N)
