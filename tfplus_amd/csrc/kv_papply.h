@@ -29,7 +29,8 @@
 //                   out_sum[out_map[number]] — the records the ids were sent in — instead of updating rows
 #pragma once
 
-enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2, PA_UNIQUE = 3, PA_DEDUP = 4 };
+enum PaMode { PA_LOOKUP = 0, PA_APPLYIDX = 1, PA_NONE = 2, PA_UNIQUE = 3, PA_DEDUP = 4,
+              PA_DEDUP_NUM = 5 };   // (a template constant only: PA_DEDUP that numbers the ids itself — kv_dedup_segment_sum)
 #ifndef KV_PA_WAVES
 #define KV_PA_WAVES 4      // waves per SIMD the register budget is set for (A/B knob: tools/mkvariant.sh)
 #endif
@@ -48,8 +49,8 @@ template <int TBP> struct PaShape { static constexpr int HSK = TBP >= 512 ? 2048
 // kernels and the kernels of the table modes carry none of their code; -1: PA_LOOKUP / PA_APPLYIDX / PA_NONE, an argument
 template <int OPT, int V, int LPR, int K, int TBP, int FM = -1>
 __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, const int mode_) {
-  constexpr bool UQ = FM == PA_UNIQUE, DD = FM == PA_DEDUP;
-  const int mode = FM >= 0 ? FM : (mode_ & 0xFF);
+  constexpr bool UQ = FM == PA_UNIQUE, DN = FM == PA_DEDUP_NUM, DD = FM == PA_DEDUP || DN;
+  const int mode = FM >= 0 ? (DN ? (int)PA_DEDUP : FM) : (mode_ & 0xFF);
   constexpr int HSK = PaShape<TBP>::HSK;
   constexpr int PA_LSRC = PaShape<TBP>::LSRC;
   constexpr int UCAPK = (HSK - TBP) < 1023 ? (HSK - TBP) : 1023;   // (the class counters of the key scan are 10-bit fields)
@@ -161,7 +162,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
     if (tid == 0) {
       lkeys += nu;
       // dense numbers (kv_unique / kv_dedup_segment_sum): the round's keys take the next nu of one counter
-      if ((UQ && !a.sparse_unique) || (DD && a.dd_number)) lbase = atomicAdd(&w.ctr[0], nu);   // (kv_dedup_segment_sum: the sums' pass numbers the ids itself)
+      if ((UQ && !a.sparse_unique) || DN) lbase = atomicAdd(&w.ctr[0], nu);   // (kv_dedup_segment_sum: the sums' pass numbers the ids itself)
     }
 
     // ---- the keys' stretches of the source list; their order: hot keys, then 1 / 2 / 3.. sources --------------------
@@ -208,7 +209,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
             if (a.sparse_unique) a.out_counts[num] = (int)hval[s];
             else if (a.out_counts) a.out_counts[num] = (int)(hval[s] > 65535u ? 65535u : hval[s]);
           }
-          if (DD && a.dd_number) {   // the id's dense number = the row of its sum (and what its entries remember for the inverse map)
+          if (DN) {   // the id's dense number = the row of its sum (and what its entries remember for the inverse map)
             const unsigned num = lbase + u;
             hrow[s] = num;
             a.out_keys[num] = (s == (unsigned)HSK) ? EMPTY_KEY : hkey[s];
@@ -259,7 +260,7 @@ __device__ __forceinline__ void papply_body(const WsDev& w, const PartArgs& a, c
 
     // ---- pass 2: the source list — entry x of key h goes to its key's stretch ---------------------------------------
     {
-      const bool numbers = UQ || (DD && a.dd_number != 0);   // the entries learn their id's number
+      constexpr bool numbers = UQ || DN;   // the entries learn their id's number
       auto file = [&](unsigned pos, unsigned src) { if (in_lds) lsrc[pos] = src; else gsrc[pos] = src; };
       if (a.det) {
         // deterministic mode: a key's entries in tile order = ascending x (TBP entries per round, wave by wave)
@@ -730,9 +731,9 @@ __global__ void __launch_bounds__(TBP, KV_PA_WAVES) k_papply_uniq(WsDev w, PartA
 #ifndef KV_PD_WAVES
 #define KV_PD_WAVES 6   // (no optimizer state in registers, 41 KB of LDS per 512-thread block: three blocks per CU)
 #endif
-template <int V, int LPR, int K, int TBP>
+template <int V, int LPR, int K, int TBP, bool NUM = false>   // NUM: the pass numbers the ids it sums (PartArgs::dd_number)
 __global__ void __launch_bounds__(TBP, TBP >= 512 ? KV_PD_WAVES : KV_PA_WAVES) k_papply_dedup(WsDev w, PartArgs a) {
-  papply_body<OPT_ADAGRAD, V, LPR, K, TBP, PA_DEDUP>(w, a, PA_DEDUP);
+  papply_body<OPT_ADAGRAD, V, LPR, K, TBP, NUM ? PA_DEDUP_NUM : PA_DEDUP>(w, a, PA_DEDUP);
 }
 template <int V, int LPR, int K>
 __global__ void __launch_bounds__(256, KV_PA_WAVES) k_papply_dedup_multi(const MultiDesc* __restrict__ descs) {
@@ -796,6 +797,10 @@ int launch_papply_ud_t(const WsDev& wd, const PartArgs& pa, int mode, hipStream_
 #define KV_PD(V, LPR, K)                                                     \
   do {                                                                       \
     if (md) k_papply_dedup_multi<V, LPR, K><<<dim3(wd.P, (unsigned)ntab), 256, sh, s>>>(md);   \
+    else if (pa.dd_number) {                                                 \
+      if (wd.P <= 512u && !pa.det) k_papply_dedup<V, LPR, K, 512, true><<<(int)wd.P, 512, sh, s>>>(wd, pa);   \
+      else k_papply_dedup<V, LPR, K, 256, true><<<(int)wd.P, 256, sh, s>>>(wd, pa);   \
+    }                                                                        \
     else if (wd.P <= 512u && !pa.det) k_papply_dedup<V, LPR, K, 512><<<(int)wd.P, 512, sh, s>>>(wd, pa);   \
     else k_papply_dedup<V, LPR, K, 256><<<(int)wd.P, 256, sh, s>>>(wd, pa);   \
     return KV_OK;                                                            \
