@@ -1027,7 +1027,8 @@ __device__ __forceinline__ void occ_chain(const float* __restrict__ buf, unsigne
   // rows of the stage in order; a lane's columns are independent chains.  The LDS reads of a batch of rows are issued
   // together, one batch ahead of the additions; lanes past the row's end read column 0 and their sums are dropped.
   // Measured on a key of 188 k rows of dim 32 (tools/occ_step.py): 1.3 ms for the chain with computed addresses (~15
-  // cycles a row); with the rows as immediates (DC) the fetch's 0.9 ms is what remains.
+  // cycles a row); with the rows as immediates (DC) ~10 cycles a row — 0.8 ms, level with the fetch's 0.9 (a fetch twice as
+  // fast, two groups on alternate stages, changed nothing: a dependent fp32 addition of a wave64 is ~8 cycles by itself).
   constexpr int UJ = NC >= 8 ? 2 : 16 / NC;
   int col[NC];
 #pragma unroll
