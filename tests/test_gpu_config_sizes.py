@@ -70,7 +70,7 @@ def _adam_bound(gsum, gabs, cnt, alpha, omb1, omb2, eps32):
   return 1e-6 + slope * dg
 
 
-def _lookup_apply_check(ops, var, slot, K, D, table, seed, sample_max, zipf=1.2):
+def _lookup_apply_check(ops, var, slot, K, D, table, seed, sample_max, zipf=1.2, occurrence=False):
   """one training step of the configs[1] / configs[3] shape + every check; returns (unique ids, sampled)."""
   import bench
   dev = torch.device("cuda", 0)
@@ -112,6 +112,10 @@ def _lookup_apply_check(ops, var, slot, K, D, table, seed, sample_max, zipf=1.2)
   ko.apply_group_adam(ov, os_, sm, u, 1e-3, 0.9, 0.999, 0.9, 0.999, 1e-8)
   got = ops.kv_variable_gather_or_zeros_v2(var, uniq)
   gots = ops.kv_variable_gather_or_zeros_v2(slot, uniq)
+  if occurrence:
+    # kv_set_deterministic(var, 2): the repeats were added in TF-core's order — EVERY sampled key at the unique-id bar
+    np.testing.assert_allclose(got[pick].cpu().numpy(), ov.gather_or_zeros(skeys), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gots[pick].cpu().numpy(), os_.gather_or_zeros(skeys), rtol=1e-6, atol=1e-9)
   # (1) ids that occur once: 1e-6 against the oracle, var and m | v | z
   once = (cnt[pick] == 1).cpu().numpy()
   assert once.sum() > 1000
@@ -145,6 +149,20 @@ def test_config1_50M_keys_1M_zipf_ids(ops):
   table = (rng.standard_normal((10000, D)) * 0.05).astype(np.float32)
   var, slot = _build(ops, K, D, table, seed=11)
   u, s = _lookup_apply_check(ops, var, slot, K, D, table, 11, sample_max=10 ** 9)   # every touched key
+  assert 90_000 < u < 130_000 and s == u
+
+
+@pytest.mark.gpu
+def test_config1_occurrence_order_every_key(ops):
+  """configs[1] at full size with the var in occurrence-order mode: every touched key — the one with 188 k rows of the batch
+  included — is the oracle's to 1e-6 (the default mode above holds the repeated keys to the reorder bound instead)"""
+  _need_hbm(60)
+  rng = np.random.Generator(np.random.PCG64(SEED + 2))
+  D, K = 32, 50_000_000
+  table = (rng.standard_normal((10000, D)) * 0.05).astype(np.float32)
+  var, slot = _build(ops, K, D, table, seed=11)
+  ops.kv_set_deterministic(var, ops.KV_ORDER_OCCURRENCE)
+  u, s = _lookup_apply_check(ops, var, slot, K, D, table, 11, sample_max=10 ** 9, occurrence=True)
   assert 90_000 < u < 130_000 and s == u
 
 
