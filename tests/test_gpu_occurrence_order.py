@@ -12,6 +12,7 @@ the reference's optimizer ops (python/ops/variable_scope.py:1096-1106 -> _dedupl
   * switching the mode off returns the table to the entry-list kernels.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -185,7 +186,8 @@ def test_mode_off_returns_to_the_entry_lists(ops):
     before = ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_APPLIES)
     _run(ops, "adam4", hs, grad, ids, False, **kw)
     lean = ops.kv_get_stat(hs[0], ops.KV_STAT_MIRROR_APPLIES) - before
-    assert (lean > 0) == (t >= 2), (t, lean)                  # the slot-mirror update is the entry-list kernels' alone
+    if not (os.environ.get("KV_NO_MIRROR") == "1" or os.environ.get("KV_NO_FUSED", "0") not in ("", "0")):   # (the A/B switches of tools/README.md)
+      assert (lean > 0) == (t >= 2), (t, lean)                # the slot-mirror update is the entry-list kernels' alone
     u, sm, _ = ko.dedup_segment_sum(ids, grad)
     _oracle("adam4", os_, sm, u, **kw)
     for h, o in zip(hs, os_):
