@@ -3730,6 +3730,8 @@ int kv_shard_create(kv_handle_t local_table, int world, int rank, int owner_rule
   if (max_ids < 1 || max_ids > (1ll << 21)) return fail(KV_INVALID_ARGUMENT, "max_ids %lld: 1 .. 2^21 ids per sharded batch", (long long)max_ids);
   if (local_table->key_dtype == KV_DT_INT32) return fail(KV_UNIMPLEMENTED, "sharded tables carry int64 ids");
   if ((local_table->dim & 3) != 0) return fail(KV_UNIMPLEMENTED, "sharded tables: dim %d (multiples of 4)", local_table->dim);
+  if (fused_off())   // (the owners' serve side exists on the entry-list kernels alone)
+    return fail(KV_UNIMPLEMENTED, "KV_NO_FUSED=1 is an A/B switch of the single-table ops: no sharded tables under it");
   if (local_table->occurrence_order)
     return fail(KV_UNIMPLEMENTED, "sharded tables: occurrence-order mode is a single-table notion (senders pre-sum, owners add the senders' sums in rank order)");
   DeviceGuard dg(local_table->device);
